@@ -1,0 +1,151 @@
+"""``nonlinear_fit`` problem setup and result reduction (ORACLE ONLY).
+
+Restates the numerical content of src/lsqfit/__init__.py:455-737 without
+gvar objects: data and prior arrive as (mean, sdev-or-cov) arrays.
+
+  * ``_unpack_data``  (:1840-1901): concat(y, prior) -> PDF(svdcut); ``udata``
+    drops data correlations (:1892-1893);
+  * ``_unpack_p0``    (:1947-1948): default start = prior mean, or
+    ``mean + 0.1*sdev`` where the mean is exactly 0;
+  * ``nf = nchiv``, ``dof = nf - P`` (:574-575);
+  * fitter call (:662-664) -> ``chi2 = sum f**2`` (:667), ``Q`` (:670);
+  * ``logGBF = (-logdet(J^T J) - pdf.logdet - chi2 - dof log 2pi)/2``
+    (:709-725), ``None`` without a prior (:711-712).
+"""
+import numpy as np
+from scipy.special import gammaincc
+
+from .chiv import Chiv
+from .lm import gsl_multifit
+from .pdf import PDF
+
+
+def gammaQ(a, x):
+    """src/lsqfit/_scipy.py:16-18."""
+    return float(gammaincc(a, x))
+
+
+def _spec(mean, err):
+    """(mean, sdev[n]) or (mean, cov[n,n]) -> mean, sdev, dense-cov-or-None."""
+    mean = np.asarray(mean, float).reshape(-1)
+    err = np.asarray(err, float)
+    if err.ndim == 2:
+        return mean, np.sqrt(np.diag(err)), err
+    return mean, err.reshape(-1) * np.ones_like(mean), None
+
+
+def build_pdf(ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12,
+              udata=False, extra_cov=None):
+    """``extra_cov``: optional list of ((i, j), value) cross-covariances between
+    entries of concat(y, prior) (data-prior correlations, test_lsqfit.py:1000-1017)."""
+    from .pdf import find_blocks
+    ymean, ysd, ycov = _spec(ymean, yerr)
+    if udata:
+        ycov = None
+    if prior_mean is None:
+        mean, sd = ymean, ysd
+        covs = [(0, ycov)]
+    else:
+        pmean, psd, pcov = _spec(prior_mean, prior_err)
+        mean = np.concatenate([ymean, pmean])
+        sd = np.concatenate([ysd, psd])
+        covs = [(0, ycov), (ymean.size, pcov)]
+    if extra_cov:
+        n = mean.size
+        full = np.diag(sd ** 2)
+        for off, c in covs:
+            if c is not None:
+                full[off:off + c.shape[0], off:off + c.shape[0]] = c
+        for (i, j), v in extra_cov:
+            full[i, j] = full[j, i] = v
+        return PDF.from_dense(mean, full, svdcut=svdcut)
+    blocks = []
+    for off, c in covs:
+        if c is None:
+            continue
+        for comp in find_blocks(c):
+            if comp.size > 1:
+                blocks.append((comp + off, c[np.ix_(comp, comp)]))
+    return PDF(mean, sd, blocks, svdcut=svdcut)
+
+
+def default_p0(prior_mean, prior_sdev):
+    pm = np.asarray(prior_mean, float).reshape(-1)
+    ps = np.asarray(prior_sdev, float).reshape(-1)
+    return np.where(pm != 0.0, pm, pm + 0.1 * ps)
+
+
+class FitResult:
+    pass
+
+
+def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
+                  svdcut=1e-12, tol=1e-8, maxit=1000, udata=False, extra_cov=None,
+                  jac=None, **fitterargs):
+    """``fcn(x, p)`` must accept float arrays and ``oracle.dual.Dual`` arrays
+    (or pass ``jac(x, p)`` returning d fcn / d p explicitly)."""
+    from .dual import Dual
+    pdf = build_pdf(ymean, yerr, prior_mean, prior_err, svdcut=svdcut,
+                    udata=udata, extra_cov=extra_cov)
+    noprior = prior_mean is None
+    if p0 is None:
+        if noprior:
+            raise ValueError('neither p0 nor prior is specified')
+        _, psd, _ = _spec(prior_mean, prior_err)
+        p0 = default_p0(prior_mean, psd)
+    p0 = np.asarray(p0, float).reshape(-1)
+
+    def flatfcn(p):
+        ans = fcn(p) if x is False else fcn(x, p)
+        if isinstance(ans, Dual):
+            return ans.reshape(-1)
+        if isinstance(ans, (list, tuple)) and any(isinstance(a, Dual) for a in ans):
+            from .dual import concatenate
+            return concatenate([a if isinstance(a, Dual) else np.asarray(a, float).reshape(-1)
+                                for a in ans])
+        return np.asarray(ans, float).reshape(-1)
+
+    chiv = Chiv(pdf, flatfcn, noprior)
+    if jac is None:
+        dchiv = chiv.jacobian
+    else:
+        def dchiv(p):
+            Jf = np.asarray(jac(p) if x is False else jac(x, p), float)
+            Jd = Jf if noprior else np.vstack([Jf, np.eye(p.size)])
+            out = np.zeros((pdf.nchiv, p.size))
+            iw, w = pdf.i_invwgts[0]
+            i2 = len(iw)
+            out[:i2] = w[:, None] * Jd[iw]
+            for iw, W in pdf.i_invwgts[1:]:
+                i1, i2 = i2, i2 + len(W)
+                out[i1:i2] = W @ Jd[iw]
+            return out
+    nf = pdf.nchiv
+    fit = FitResult()
+    fit.pdf = pdf
+    fit.p0 = p0
+    fit.dof = nf - p0.size
+    fit.svdn = pdf.nmod
+    fit.nblocks = pdf.nblocks
+    fit.svdcut = svdcut
+    lm = gsl_multifit(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
+    fit.lm = lm
+    fit.error = lm.error
+    fit.cov = lm.cov
+    fit.chi2 = float(np.sum(lm.f ** 2))
+    fit.J = lm.J
+    fit.residuals = np.array(lm.f)
+    fit.Q = gammaQ(fit.dof / 2., fit.chi2 / 2.)
+    fit.nit = lm.nit
+    fit.tol = lm.tol
+    fit.stopping_criterion = lm.stopping_criterion
+    fit.description = lm.description
+    fit.pmean = np.array(lm.x)
+    fit.psdev = np.sqrt(np.diag(lm.cov))
+    if noprior:
+        fit.logGBF = None
+    else:
+        sign, ld = np.linalg.slogdet(lm.J.T @ lm.J)
+        fit.logdet_JtJ = float(ld)
+        fit.logGBF = 0.5 * (-ld - pdf.logdet - fit.chi2 - fit.dof * np.log(2. * np.pi))
+    return fit

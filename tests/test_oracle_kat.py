@@ -1,0 +1,291 @@
+"""Pin the oracle on the literal known answers of the reference's tests/examples
+(tests/golden/kat.json, transcribed by tests/golden/make_golden.py)."""
+import re
+
+import numpy as np
+import pytest
+
+from oracle import dual, gvar_lite
+from oracle import fit as ofit
+from oracle import lm as olm
+from oracle.pdf import PDF
+from tests.helpers import load
+
+KAT = load('kat.json')
+
+
+def header(fit):
+    chi2_dof = fit.chi2 / fit.dof
+    return chi2_dof, fit.dof, fit.Q, fit.logGBF
+
+
+def parse_header(text):
+    h = re.search(r'chi2/dof \[dof\] = (\S+) \[(\d+)\]\s+Q = (\S+)\s+logGBF = (\S+)', text)
+    return h.group(1), int(h.group(2)), h.group(3), h.group(4)
+
+
+def check_header(fit, text, sig_gbf=5):
+    c, d, q, g = parse_header(text)
+    assert fit.dof == d
+    assert '%.2g' % (fit.chi2 / fit.dof) == c, (fit.chi2 / fit.dof, c)
+    assert '%.2g' % fit.Q == q or abs(fit.Q - float(q)) < 0.006
+    assert '%.*g' % (sig_gbf, fit.logGBF) == g, (fit.logGBF, g)
+
+
+def test_gvar_strings():
+    assert gvar_lite.parse('0.0005502(73)') == pytest.approx((0.0005502, 73e-7))
+    assert gvar_lite.parse('238.9(2.7)') == pytest.approx((238.9, 2.7))
+    assert gvar_lite.parse('0(47788)') == (0.0, 47788.0)
+    assert gvar_lite.parse('0.00(11)') == pytest.approx((0.0, 0.11))
+    assert gvar_lite.parse('0.0(2.5)e-05') == pytest.approx((0.0, 2.5e-5))
+    assert gvar_lite.parse('-1.43(28)e-06') == pytest.approx((-1.43e-6, 0.28e-6))
+    assert gvar_lite.parse('0 +- 1.0187876330E-01') == pytest.approx((0.0, 0.1018787633))
+    assert gvar_lite.fmt(0.9038, 0.098058) == '0.904(98)'
+    assert gvar_lite.fmt(238.942, 2.707) == '238.9(2.7)'
+    assert gvar_lite.fmt(-1.43e-6, 0.28e-6) == '-1.43(28)e-06'
+
+
+def test_fitters_conformance():
+    """tests/test_lsqfit.py:1811-1833."""
+    k = KAT['test_fitters']
+    ym, ys = gvar_lite.parse_array(k['data'])
+    pm, ps = gvar_lite.parse_array(k['prior'])
+    for solver in ['qr', 'cholesky', 'svd']:
+        fit = ofit.nonlinear_fit(False, ym, ys, lambda p: p, prior_mean=pm, prior_err=ps, solver=solver)
+        assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == k['expected_p']
+    # closed form
+    w = 1 / ys ** 2 + 1 / ps ** 2
+    np.testing.assert_allclose(fit.pmean, (ym / ys ** 2 + pm / ps ** 2) / w, rtol=1e-9)
+    np.testing.assert_allclose(fit.cov, np.diag(1 / w), rtol=1e-10, atol=1e-18)
+
+
+def test_gammaQ():
+    """tests/test_lsqfit.py:1887-1901."""
+    for a, x, gax, gxa in KAT['gammaQ']:
+        np.testing.assert_allclose(gax, ofit.gammaQ(a, x), rtol=0.01)
+        np.testing.assert_allclose(gxa, ofit.gammaQ(x, a), rtol=0.01)
+
+
+def test_gsl_multifit_direct():
+    """tests/test_lsqfit.py:1700-1715: singular-J^T J double root, stops on xtol."""
+    k = KAT['gsl_multifit']
+    xans = np.array(k['xans'])
+    f = lambda x: (x - xans) ** 2 + (x - xans) ** 4
+    df = lambda x: np.diag(2 * (x - xans) + 4 * (x - xans) ** 3)
+    for c in k['cases']:
+        for solver in ['qr', 'cholesky']:
+            ans = olm.gsl_multifit(np.array(c['x0']), 3, f, df, alg=c['alg'], tol=tuple(c['tol']),
+                                   solver=solver)
+            np.testing.assert_allclose(ans.x, xans, rtol=c['rtol'])
+            assert ans.stopping_criterion == c['stopping_criterion']
+    # gtol route (the reference's 2nd case uses lmaccel; same criterion with lm)
+    ans = olm.gsl_multifit(np.zeros(3), 3, f, df, tol=(0.0, 1e-10, 0.0))
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 2
+
+
+def test_tol_normalisation():
+    assert olm.normalize_tol(1e-5) == (1e-5, 1e-10, 1e-10)
+    assert olm.normalize_tol((1e-5,)) == (1e-5, 1e-10, 1e-10)
+    assert olm.normalize_tol((1e-5, 1e-6)) == (1e-5, 1e-6, 1e-10)
+    with pytest.raises(ValueError):
+        olm.normalize_tol((1, 2, 3, 4))
+
+
+def test_exceptions_propagate():
+    """tests/test_lsqfit.py:1684-1698: errors raised in the fit function surface unchanged."""
+    with pytest.raises(ValueError):
+        ofit.nonlinear_fit(False, [1., 2.], [1., 1.], lambda p: np.array([p[0]] * 4),
+                           prior_mean=[0.], prior_err=[2.])
+    with pytest.raises(ZeroDivisionError):
+        def f(p):
+            1 / 0.
+        ofit.nonlinear_fit(False, [1., 2.], [1., 1.], f, prior_mean=[0.], prior_err=[2.])
+
+
+def test_format_case1():
+    """tests/test_lsqfit.py:257-283."""
+    k = KAT['format1']
+    y = np.array(k['y'])
+    pr = np.array(k['prior'])
+    fit = ofit.nonlinear_fit(False, y[:, 0], y[:, 1], lambda p: dual.concatenate([p, p]),
+                             prior_mean=pr[:, 0], prior_err=pr[:, 1], svdcut=k['svdcut'], tol=tuple(k['tol']))
+    c, d, q, g = parse_header(k['header'])
+    assert fit.dof == d and '%.1g' % (fit.chi2 / fit.dof) == c
+    assert '%.2g' % fit.Q == q and '%.5g' % fit.logGBF == g
+    assert gvar_lite.fmt(fit.pmean[0], fit.psdev[0]) == k['p'].replace(' ', '')
+
+
+def test_logGBF_closed_form():
+    """tests/test_lsqfit.py:845-868 with a fixed draw for y."""
+    ygm, ygs = gvar_lite.parse_array(KAT['logGBF']['yg'])
+    y = ygm + ygs * np.array([0.3, -1.1, 0.7, 0.2])
+    pm, ps = ygm, 0.5 * ygs
+    yvar = ygs ** 2 + ps ** 2
+    logprob = np.sum(-(y - ygm) ** 2 / (2 * yvar) - 0.5 * np.log(2 * np.pi * yvar))
+    chi2 = np.sum((y - ygm) ** 2 / yvar)
+    fit = ofit.nonlinear_fit(False, y, ygs, lambda p: p, prior_mean=pm, prior_err=ps)
+    assert fit.logGBF == pytest.approx(logprob, abs=1e-7)
+    assert fit.chi2 == pytest.approx(chi2, abs=1e-7)
+
+
+def test_unpack_data_weights():
+    """tests/test_lsqfit.py:955-962,:1024-1032,:1000-1017."""
+    for key in ['unpack_case2', 'unpack_case4']:
+        k = KAT[key]
+        y = np.array(k['y'], float)
+        p = np.array(k['prior'], float)
+        pdf = ofit.build_pdf(y[:, 0], y[:, 1], p[:, 0], p[:, 1], svdcut=0)
+        assert list(pdf.i_invwgts[0][0]) == k['idx']
+        assert list(pdf.i_invwgts[0][1]) == k['wgts']
+        assert len(pdf.i_invwgts) == 1 and pdf.nmod == 0
+    # data-prior correlation: y[0] *= one, p[0] *= one with one = 1 +- 1e-3
+    cov = np.diag([4., 16., 4., 16.])
+    mean = np.array([1., 10., 1., 1.])
+    cov[0, 0] += 1e-6 * 1
+    cov[2, 2] += 1e-6 * 1
+    cov[0, 2] = cov[2, 0] = 1e-6
+    pdf = PDF.from_dense(mean, cov, svdcut=0)
+    assert list(pdf.i_invwgts[0][0]) == [1, 3]
+    assert pdf.i_invwgts[0][1].ndim == 1
+    assert list(pdf.i_invwgts[1][0]) == [0, 2]
+    assert pdf.i_invwgts[1][1].ndim == 2
+    np.testing.assert_allclose(pdf.icov(), np.linalg.inv(cov), rtol=1e-8, atol=1e-15)
+    assert pdf.logdet == pytest.approx(np.log(np.linalg.det(cov)))
+    assert pdf.nblocks == {1: 2, 2: 1}
+
+
+def test_svdcut_positive_and_negative():
+    """tests/test_lsqfit.py:1081-1117 (floor) and :829-841 (drop)."""
+    # a = 1(1), da = 0(0.01): y = [a+da, a-da]
+    cov = np.array([[1 + 1e-4, 1 - 1e-4], [1 - 1e-4, 1 + 1e-4]])
+    mean = np.array([1., 1.])
+    sc = 0.01
+    pdf0 = PDF.from_dense(mean, cov, svdcut=0.0)
+    assert pdf0.nmod == 0
+    np.testing.assert_allclose(pdf0.icov(), np.linalg.inv(cov), rtol=1e-9)
+    pdf = PDF.from_dense(mean, cov, svdcut=sc)
+    assert pdf.nmod == 1
+    creg = np.linalg.inv(pdf.icov())
+    # (y1-y0)/2 now has variance svdcut (lam_max ~ 2, corr ~ cov/1.0001)
+    var_diff = np.array([-.5, .5]) @ creg @ np.array([-.5, .5])
+    assert var_diff == pytest.approx(sc, rel=1e-3)
+    assert pdf.logdet == pytest.approx(np.log(np.linalg.det(creg)))
+    # negative cut: data = [(x+dx)/2, (x-dx)/20], x=1(1), dx=0.01(1)
+    k = KAT['svd_negative']
+    xm, xs = gvar_lite.parse(k['x'])
+    dm, ds = gvar_lite.parse(k['dx'])
+    A = np.array([[0.5, 0.5], [0.05, -0.05]])
+    ymean = A @ np.array([xm, dm])
+    ycov = A @ np.diag([xs ** 2, ds ** 2]) @ A.T
+    pm, ps = gvar_lite.parse_array(k['prior'])
+    fit = ofit.nonlinear_fit(False, ymean, ycov, lambda p: p, prior_mean=pm, prior_err=ps, svdcut=k['svdcut'])
+    assert fit.dof == k['dof'] and fit.svdn == k['svdn']
+    w = np.array([1., 10.])
+    assert gvar_lite.fmt(w @ fit.pmean, np.sqrt(w @ fit.cov @ w)).startswith('1.0(1.0') or \
+        '%.1f(%.1f)' % (w @ fit.pmean, np.sqrt(w @ fit.cov @ w)) == k['combo_fmt1']
+
+
+def _p_corr_problem():
+    k = KAT['p_corr']
+    ym, ys = gvar_lite.parse_array(k['y'])
+    x = np.array(k['x'])
+    pcov = np.eye(4)
+    pcov[1, 1] = 400. + 0.1 ** 2
+    pcov[0, 1] = pcov[1, 0] = 20.
+    fcn = lambda x, p: (p[0] * (x ** 2 + p[1] * x)) / (x ** 2 + x * p[2] + p[3])
+    return x, ym, ys, fcn, np.zeros(4), pcov, k['out']
+
+
+def test_p_corr_example():
+    """examples/p-corr.py:44-61 vs examples/p-corr.out (correlated 2x2 prior block)."""
+    x, ym, ys, fcn, pm, pcov, out = _p_corr_problem()
+    fit = ofit.nonlinear_fit(x, ym, ys, fcn, prior_mean=pm, prior_err=pcov)
+    check_header(fit, out)
+    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.149(17) 2.97(34) 1.23(61) 0.59(15)]'
+    corr01 = fit.cov[0, 1] / np.sqrt(fit.cov[0, 0] * fit.cov[1, 1])
+    assert '%.4f' % corr01 == '0.9571'
+    assert fit.nblocks == {1: 13, 2: 1} and fit.svdn == 0
+    assert fit.stopping_criterion == 1
+
+
+def _y_vs_x(nexp):
+    k = KAT['y_vs_x']
+    x = np.array(k['x'])
+    pm = np.concatenate([np.full(nexp, 0.5), np.arange(1, nexp + 1.0)])
+    ps = np.full(2 * nexp, 0.4)
+
+    def fcn(x, p):
+        return dual.stack_sum(p[i] * dual.exp(-p[nexp + i] * x) for i in range(nexp))
+    return x, np.array(k['ymean']), np.array(k['ycov']), fcn, pm, ps
+
+
+def test_y_vs_x_example():
+    """examples/y-vs-x.py vs y-vs-x.out: dense 8x8 ycov, one SVD mode modified."""
+    out = KAT['y_vs_x']['out']
+    blocks = re.split(r'\*+ nexp = (\d+)\n', out)[1:]
+    p0 = None
+    expected_p = {
+        2: '[0.4024(40) 0.4471(46) 0.90104(51) 1.8282(14)]',
+        3: '[0.4019(40) 0.406(14) 0.61(36) 0.90039(54) 1.8026(82) 2.83(19)]',
+    }
+    for nexp_s, text in zip(blocks[0::2], blocks[1::2]):
+        nexp = int(nexp_s)
+        x, ym, ycov, fcn, pm, ps = _y_vs_x(nexp)
+        q0 = None
+        if p0 is not None:      # _unpack_p0: overlap of old p0 with the new prior layout
+            q0 = ofit.default_p0(pm, ps)
+            n_old = p0.size // 2
+            q0[:n_old] = p0[:n_old]
+            q0[nexp:nexp + n_old] = p0[n_old:]
+        fit = ofit.nonlinear_fit(x, ym, ycov, fcn, prior_mean=pm, prior_err=ps, p0=q0)
+        assert fit.svdn == 1 and fit.nblocks[8] == 1
+        c, d, q, g = parse_header(text)
+        assert fit.dof == d
+        assert '%.2g' % (fit.chi2 / fit.dof) == c
+        assert '%.5g' % fit.logGBF == g, (nexp, fit.logGBF, g)
+        if nexp in expected_p:
+            assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == expected_p[nexp]
+        if fit.chi2 / fit.dof < 1.:
+            p0 = fit.pmean
+
+
+def test_empbayes_example():
+    """examples/empbayes.py / .out: logGBF maximised over the prior width."""
+    from scipy.optimize import minimize
+    k = KAT['empbayes']
+    x = np.array(k['src_inputs']['x'])
+    ym, ys = gvar_lite.parse_array(k['src_inputs']['y'])
+    fcn = lambda x, p: dual.exp(-p[0] - p[1] * x - p[2] * x ** 2 - p[3] * x ** 3)
+    last = dict(p0=None)
+
+    def neg_logGBF(z):
+        fit = ofit.nonlinear_fit(x, ym, ys, fcn, prior_mean=np.zeros(4), prior_err=np.full(4, abs(z[0])),
+                                 p0=last['p0'])
+        last['p0'] = fit.pmean
+        last['fit'] = fit
+        return -fit.logGBF
+    res = minimize(neg_logGBF, [1.0], method='Nelder-Mead', tol=1e-4)
+    fit = ofit.nonlinear_fit(x, ym, ys, fcn, prior_mean=np.zeros(4), prior_err=np.full(4, abs(res.x[0])),
+                             p0=last['p0'])
+    check_header(fit, k['out'])
+    assert '%.1f' % abs(res.x[0]) == '5.3'
+    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[2.5904(22) -6.530(22) 7.832(65) -1.688(55)]'
+
+
+def test_simple_example_header():
+    """examples/simple.py:28-41 vs simple.out: mixed 2x2 data blocks + scalar."""
+    ymean = np.array([1.376, 2.010, 1.329, 1.582, 2.0])
+    ycov = np.zeros((5, 5))
+    ycov[:2, :2] = [[0.0047, 0.01], [0.01, 0.056]]
+    ycov[2:4, 2:4] = [[0.0047, 0.0067], [0.0067, 0.0136]]
+    ycov[4, 4] = 0.25
+    x1, x2 = np.array([0.1, 1.0]), np.array([0.1, 0.5])
+
+    def fcn(p):
+        return dual.concatenate([dual.exp(p[0] + x1 * p[1]), dual.exp(p[0] + x2 * p[1]),
+                                 (p[1] / p[0]).reshape(1) if isinstance(p, dual.Dual) else np.array([p[1] / p[0]])])
+    fit = ofit.nonlinear_fit(False, ymean, ycov, fcn, prior_mean=[0.5, 0.5], prior_err=[0.5, 0.5])
+    check_header(fit, KAT['simple']['out'])
+    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.253(32) 0.449(65)]'
+    assert fit.nblocks == {1: 3, 2: 2}
