@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""fp64 LM steps/sec at (N_data, N_param) = (65536, 4096) on N MI355X GPUs.
+
+One "step" = one accepted Levenberg-Marquardt iteration of the device path
+(>= 1 damped Cholesky solve + >= 1 trial residual evaluation + exactly one
+Jacobian assembly + one J^T J / J^T f formation + one all-reduce when N > 1;
+SURVEY.md 8d), on the synthetic correlated-Gaussian workload C4: cosmix model,
+256-row covariance blocks (fake_fitargs recipe), dense correlated 4096x4096
+prior.  Inputs are resident in HBM before the timed region; the data rows are
+sharded over the ranks (total work fixed -> "strong" scaling).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8 ...
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra
+objects: "roofline" for the dominant kernel (the fp64-MFMA SYRK J^T J, timed
+with HIP events on the stream it runs on) and "cpu_baseline" (the numpy oracle
+timed on this box's host cores on a bounded sample; a baseline, not a target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_MFMA_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 128 FLOP/clk/CU x 256 CU x 2.4 GHz
+
+WORKLOADS = {
+    # name: (N_data, N_param, block, dense prior, seed)   -- BASELINE.json configs
+    'c4': (65536, 4096, 256, True, 20263),
+    'c3': (8192, 1024, 8192, True, 20262),
+    'c2': (4096, 256, 0, False, 20261),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
+    ap.add_argument('--ndata', type=int, default=0, help='override N_data (debug)')
+    ap.add_argument('--nparam', type=int, default=0, help='override N_param (debug)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=25.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(d, wh_blocks_from, budget_s):
+    """Oracle (numpy, 'port') LM steps/s on the same inputs: same normal-equation
+    algorithm (whitening GEMMs, J^T J, damped Cholesky), all host cores via the
+    BLAS numpy links.  Bounded: stops after the first LM step that crosses the
+    time budget (at least one step)."""
+    import scipy.linalg as sla
+    from oracle import lm as olm
+    x, ymean = d['x'], d['ymean']
+    pm, perr = d['prior']
+    P = pm.size
+    K = P // 2
+    sd = np.asarray(d['yerr']['sdev'] if isinstance(d['yerr'], dict) else d['yerr'], float)
+    blocks = d['yerr']['blocks'] if isinstance(d['yerr'], dict) else []
+    # whitening setup (untimed, as on the GPU side): W_b = inv(chol(C_b))
+    Ws = []
+    for r0, cov in blocks:
+        L = sla.cholesky(cov, lower=True)
+        Ws.append((r0, sla.solve_triangular(L, np.eye(cov.shape[0]), lower=True)))
+    inblk = np.zeros(ymean.size, bool)
+    for r0, W in Ws:
+        inblk[r0:r0 + W.shape[0]] = True
+    wdiag = np.where(inblk, 1.0, 1.0 / sd)
+    prec = np.linalg.inv(perr) if np.ndim(perr) == 2 else np.diag(1.0 / np.asarray(perr) ** 2)
+
+    def resid_raw(p):
+        return np.cos(np.outer(x, p[K:])) @ p[:K] - ymean
+
+    def whiten(v):
+        out = v * (wdiag[:, None] if v.ndim == 2 else wdiag)
+        for r0, W in Ws:
+            out[r0:r0 + W.shape[0]] = W @ v[r0:r0 + W.shape[0]]
+        return out
+
+    def chi2_fn(p):
+        r = whiten(resid_raw(p))
+        dp = p - pm
+        return float(r @ r + dp @ prec @ dp)
+
+    def normal_eq(p):
+        wx = np.outer(x, p[K:])
+        c, s = np.cos(wx), np.sin(wx)
+        J = whiten(np.hstack([c, -p[:K] * x[:, None] * s]))
+        r = whiten(c @ p[:K] - ymean)
+        dp = p - pm
+        return J.T @ J + prec, J.T @ r + prec @ dp, float(r @ r + dp @ prec @ dp)
+
+    steps = 0
+    t0 = time.perf_counter()
+    nits = []
+    # run whole fits with maxit = 1, 2, ... would re-do work; instead time one driver
+    # call capped at the number of steps the budget allows (measure the first step).
+    res = olm.lm_normal(d['p0'], normal_eq, chi2_fn, tol=(1e-8, 1e-10, 1e-10), maxit=1)
+    t1 = time.perf_counter() - t0
+    steps, elapsed = res.nit, t1
+    extra = int(min(8, max(0, (budget_s - t1) // max(t1, 1e-9))))
+    if extra >= 1:
+        t0 = time.perf_counter()
+        res = olm.lm_normal(d['p0'], normal_eq, chi2_fn, tol=(1e-8, 1e-10, 1e-10), maxit=1 + extra)
+        elapsed = time.perf_counter() - t0
+        steps = res.nit
+    try:
+        import threadpoolctl
+        cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return dict(value=steps / elapsed, unit='LM steps/s', cores=int(cores), kind='port',
+                sample='%d full-size LM step(s) of the same workload (N=%d, P=%d), numpy/OpenBLAS oracle, '
+                       'whitening setup excluded' % (steps, ymean.size, P)), res
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    import lsqfit_amd
+    from lsqfit_amd import _lib, synth
+    from lsqfit_amd.dist import sharded_problem
+    import ctypes as C
+
+    N, P, block, dense_prior, seed = WORKLOADS[args.workload]
+    if args.ndata:
+        N = args.ndata
+    if args.nparam:
+        P = args.nparam
+    block = min(block, N)
+    t0 = time.perf_counter()
+    d = synth.make_cosmix(N=N, P=P, seed=seed, block=block, prior_corr=dense_prior)
+    wh = lsqfit_amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    pr = sharded_problem(d['model'], d['x'], wh, rank, world)
+    pr.set_options((1e-8, 1e-10, 1e-10), 1000)
+    t_setup = time.perf_counter() - t0
+    lib, h = pr.lib, pr.h
+
+    rng = np.random.Generator(np.random.PCG64(seed + 1))
+    ps = np.concatenate([np.full(P // 2, 0.5), np.full(P // 2, 0.1)])
+
+    def fresh_start():
+        # every restart draws the same start on all ranks (same seed stream)
+        return np.ascontiguousarray(d['p0'] + 0.3 * ps * rng.standard_normal(P))
+
+    state = dict(reinits=0, converged=True, trials0=0)
+
+    def one_step():
+        if state['converged']:
+            p0 = fresh_start()
+            rc = lib.lsqamd_init(h, _lib.dptr(p0))
+            pr._raise_reduce()
+            if rc != 0:
+                raise RuntimeError('init failed: %s' % lib.lsqamd_last_error(h))
+            state['reinits'] += 1
+            state['converged'] = False
+        info = C.c_int32(0)
+        rc = lib.lsqamd_step(h, C.byref(info))
+        pr._raise_reduce()
+        if rc < 0:
+            raise RuntimeError('step failed: %s' % lib.lsqamd_last_error(h))
+        if rc != 0 or info.value != 0:
+            state['converged'] = True
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    pr.timing(True)
+    pr.timing_reset()
+    state['reinits'] = 0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tm = pr.timings()
+    pr.timing(False)
+    s = _lib.Summary()
+    lib.lsqamd_finish(h, C.byref(s))
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        n_local = pr.N
+        syrk_ms, syrk_n = tm['syrk']
+        flops = float(n_local) * P * (P + 1)          # algorithmic, upper triangle, 2 flop/MAC
+        ach = (flops / (syrk_ms / syrk_n * 1e-3) / 1e12) if syrk_n else 0.0
+        out = {
+            'metric': 'fp64 LM steps/sec at (N_data,N_param)=(%d,%d)' % (N, P),
+            'value': args.steps / elapsed, 'unit': 'LM steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': '%s: cosmix N_data=%d N_param=%d, %s data covariance, %s prior, '
+                                   'rows sharded over %d GPU(s)' % (
+                                       args.workload, N, P,
+                                       ('%d-row block-diagonal' % block) if block > 1 else 'diagonal',
+                                       'dense correlated' if dense_prior else 'diagonal', world),
+                       'solver': 'lm/more/cholesky', 'restarts_in_timed_region': state['reinits'],
+                       'setup_s': round(t_setup, 3), 'chi2_dof_last': s.chi2 / max(1, wh.nchiv - P)},
+            'phases_ms_per_call': {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()},
+            'phases_calls': {k: v[1] for k, v in tm.items()},
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_tn_f64_kernel (J^T J)', 'achieved': ach,
+                         'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': ach / PEAK_FP64_MFMA_TFLOPS, 'traffic': None,
+                         'flops_per_launch': flops,
+                         'avg_launch_ms': (syrk_ms / syrk_n) if syrk_n else None},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cb, _ = cpu_baseline(d, wh, args.cpu_seconds)
+                out['cpu_baseline'] = cb
+            except Exception as e:   # the baseline must never take the measurement down
+                out['cpu_baseline'] = {'value': None, 'unit': 'LM steps/s', 'cores': 0, 'kind': 'port',
+                                       'sample': 'failed: %r' % (e,)}
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out))
+    pr.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,228 @@
+/*
+ * lsqfit_amd.h -- C ABI of the MI355X-native Levenberg-Marquardt backend.
+ *
+ * This is the drop-in boundary for ONE path of gplepage/lsqfit: the fitter
+ * plugin that `nonlinear_fit` constructs at src/lsqfit/__init__.py:662-664
+ *
+ *     fit = FITTERS[name](p0, nf, chiv, tol=tol, maxit=maxit, **fitterargs)
+ *
+ * and whose attributes it reads back at :665-679 (error, cov, f, J, nit, tol,
+ * stopping_criterion, description, results, x).  In the reference that plugin
+ * is `gsl_multifit` (src/lsqfit/_gsl.pyx:414-723), a Cython wrapper around
+ * GSL's C API; the entry points below are what a binding for this backend
+ * binds instead (INTEGRATION.md shows the ctypes stub).  Every function cites
+ * the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types, no exceptions, no abort();
+ *   - every call returns int: 0 success; GSL numbering for the codes the
+ *     reference inspects (_gsl.pyx:686-701,:714): 11 EMAXITER, 27 ENOPROG,
+ *     29 ETOLF, 30 ETOLX, 31 ETOLG; negative = backend failure
+ *     (LSQAMD_E*); lsqamd_last_error() gives the text;
+ *   - all state is handle-scoped (the reference keeps module globals
+ *     _valder/_p_f/_pyerr, _gsl.pyx:397-399): handles are re-entrant and may be
+ *     used from different host threads, one handle = one HIP stream;
+ *   - host buffers passed to lsqamd_set_* are copied before the call returns
+ *     and never retained; output buffers are caller-allocated with an element
+ *     capacity; device memory is ONE caller-provided workspace
+ *     (lsqamd_workspace_bytes) that the handle carves and never frees;
+ *   - matrices are row-major float64, like gsl_matrix (tda = size2,
+ *     _gsl.pyx:60-64).
+ */
+#ifndef LSQFIT_AMD_H
+#define LSQFIT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSQAMD_ABI_VERSION 1
+
+/* error codes (negative = backend, positive = GSL numbering) */
+#define LSQAMD_SUCCESS 0
+#define LSQAMD_EMAXITER 11 /* GSL_EMAXITER, _gsl.pyx:714 */
+#define LSQAMD_ENOPROG 27  /* GSL_ENOPROG,  _gsl.pyx:698 */
+#define LSQAMD_ETOLF 29
+#define LSQAMD_ETOLX 30
+#define LSQAMD_ETOLG 31
+#define LSQAMD_EINVAL (-1)    /* bad argument / call order               */
+#define LSQAMD_EHIP (-2)      /* HIP runtime error                       */
+#define LSQAMD_ENOMEM (-3)    /* workspace too small                     */
+#define LSQAMD_ENOTPD (-4)    /* J^T J + mu D^2 not positive definite    */
+#define LSQAMD_ENONFINITE (-5)/* residual or Jacobian not finite         */
+#define LSQAMD_EUNSUPPORTED (-6)
+#define LSQAMD_EREDUCE (-7)   /* the all-reduce hook reported failure    */
+#define LSQAMD_ECAPACITY (-8) /* caller's output buffer too small        */
+
+/* Row models f(x_i; p) the kernels evaluate with forward-mode AD.  They take
+ * the place of the user's Python fit function + gvar.valder derivative
+ * propagation (_gsl.pyx:671,742-760; _utilities.pyx:74-93), which a device
+ * cannot call. */
+enum {
+  LSQAMD_MODEL_COSMIX = 1,   /* sum_k a_k cos(w_k x); p=[a_0..a_{K-1}, w_0..w_{K-1}] */
+  LSQAMD_MODEL_MULTIEXP = 2, /* sum_k a_k exp(-E_k x); p=[a.., E..] (examples/y-vs-x.py:58-61) */
+  LSQAMD_MODEL_TAPE = 3,     /* RPN expression tape over x[0..n_x) and p[0..P) (examples/nist.py models) */
+  LSQAMD_MODEL_IDENTITY = 4  /* f_i = p_i (tests/test_lsqfit.py:1815) */
+};
+
+enum { LSQAMD_SCALE_MORE = 0, LSQAMD_SCALE_LEVENBERG = 1, LSQAMD_SCALE_MARQUARDT = 2 }; /* _gsl.pyx:637-644 */
+enum { LSQAMD_SOLVER_CHOLESKY = 0 };                                                    /* _gsl.pyx:646-653 */
+
+/* tape opcodes (LSQAMD_MODEL_TAPE); operands in `arg` */
+enum {
+  LSQAMD_OP_CONST = 0, /* push consts[arg] */
+  LSQAMD_OP_X = 1,     /* push x[row][arg]  */
+  LSQAMD_OP_P = 2,     /* push p[arg] (derivative seed e_arg) */
+  LSQAMD_OP_ADD = 3, LSQAMD_OP_SUB = 4, LSQAMD_OP_MUL = 5, LSQAMD_OP_DIV = 6,
+  LSQAMD_OP_POW = 7,   /* a ** b */
+  LSQAMD_OP_NEG = 8, LSQAMD_OP_EXP = 9, LSQAMD_OP_LOG = 10, LSQAMD_OP_SIN = 11,
+  LSQAMD_OP_COS = 12, LSQAMD_OP_ATAN = 13, LSQAMD_OP_SQRT = 14,
+  LSQAMD_OP_POWI = 15  /* a ** (int)arg */
+};
+#define LSQAMD_TAPE_MAX_PARAM 16
+#define LSQAMD_TAPE_MAX_STACK 16
+
+typedef struct lsqamd_fit lsqamd_fit; /* opaque handle (replaces gsl_multifit_nlinear_workspace, _gsl.pyx:672) */
+
+/* Problem shape.  n_data rows are the LOCAL rows of this process when the fit
+ * is row-sharded; the prior is replicated. */
+typedef struct {
+  int32_t abi_version;   /* LSQAMD_ABI_VERSION */
+  int32_t model;         /* LSQAMD_MODEL_* */
+  int64_t n_data;        /* N (local) : len(fcn(p)) */
+  int64_t n_param;       /* P : len(x0), _gsl.pyx:618 */
+  int32_t n_x;           /* predictors per data row */
+  int32_t has_prior;     /* 0: chi2 over data only (prior=None, _utilities.pyx:72-73) */
+  int32_t prior_dense;   /* 0: diagonal prior precision; 1: dense P x P */
+  int32_t n_blocks;      /* correlated data blocks (contiguous row ranges); 0 = all rows 1x1 */
+  int64_t max_block;     /* largest block size */
+  int64_t sum_block_sq;  /* sum over blocks of B_b * B_b (whitening storage) */
+  int32_t want_jacobian_out; /* keep the whitened J retrievable (fit.J, __init__.py:668) */
+  int32_t n_batch;       /* independent fits sharing shape (1 unless batched sweep) */
+} lsqamd_config;
+
+/* Driver options: gsl_multifit.__init__ keyword arguments (_gsl.pyx:563-575). */
+typedef struct {
+  double xtol, gtol, ftol;  /* tol normalised to a 3-tuple, _gsl.pyx:594-603 */
+  int32_t maxit;            /* _gsl.pyx:568 */
+  int32_t scaler;           /* LSQAMD_SCALE_* */
+  int32_t solver;           /* LSQAMD_SOLVER_* */
+  int32_t reserved;
+  double factor_up;         /* 3.0, _gsl.pyx:573 */
+  double factor_down;       /* 2.0, _gsl.pyx:574 */
+} lsqamd_options;
+
+/* What nonlinear_fit reads from the plugin (__init__.py:665-679) plus the
+ * counters the benchmark reports. */
+typedef struct {
+  int32_t status;             /* GSL-style driver status (0, 11, ...) -> fit.error */
+  int32_t info;               /* raw convergence info (1 xtol, 2 gtol, 27 ...) */
+  int32_t stopping_criterion; /* 0..4, _gsl.pyx:690-701 */
+  int32_t nit;                /* gsl_multifit_nlinear_niter, _gsl.pyx:713 */
+  int32_t nfev;               /* residual evaluations (trial steps + 1) */
+  int32_t njev;               /* Jacobian evaluations */
+  int32_t ntrial;             /* damped solves attempted */
+  int32_t chol_fail;          /* factorizations that hit a non-positive pivot */
+  double chi2;                /* sum f**2, __init__.py:667 */
+  double mu;                  /* final LM parameter */
+  double logdet_jtj;          /* log det(J^T J) at the end (for logGBF, __init__.py:719) */
+  double t_setup_ms, t_run_ms;
+} lsqamd_summary;
+
+/* All-reduce hook: sum `count` doubles at device address `dev_buf` over all
+ * ranks, in place, and return only when the result is visible to work queued
+ * afterwards on the handle's stream.  Return 0 on success.  (No counterpart in
+ * the reference, which has no distributed path: SURVEY.md 5.) */
+typedef int (*lsqamd_reduce_fn)(void *user, void *dev_buf, int64_t count);
+
+/* ---- lifecycle ------------------------------------------------------------ */
+int lsqamd_abi_version(void);
+/* bytes of device workspace lsqamd_create needs for this shape */
+size_t lsqamd_workspace_bytes(const lsqamd_config *cfg);
+/* replaces gsl_multifit_nlinear_alloc (_gsl.pyx:672); `stream` is a hipStream_t (NULL = default) */
+int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspace_bytes,
+                  void *stream, lsqamd_fit **out);
+/* replaces gsl_multifit_nlinear_free (_gsl.pyx:720) */
+int lsqamd_destroy(lsqamd_fit *fit);
+/* replaces gsl_strerror (_gsl.pyx:687); valid until the next call on the handle */
+const char *lsqamd_last_error(const lsqamd_fit *fit);
+
+/* ---- problem data (copied host -> device) ----------------------------------- */
+/* x[n_data][n_x]: what the closure `flatfcn` hides (__init__.py:566-568,:1997-2042) */
+int lsqamd_set_x(lsqamd_fit *fit, const double *x, int64_t n_rows, int32_t n_x);
+/* tape for LSQAMD_MODEL_TAPE: code[n_code] = opcode | arg << 8 */
+int lsqamd_set_tape(lsqamd_fit *fit, const int32_t *code, int32_t n_code,
+                    const double *consts, int32_t n_consts);
+/* Whitening of the data rows = PDF.mean / PDF.i_invwgts (_utilities.pyx:58-61):
+ *   ymean[n_data];  wdiag[n_data]: 1/sdev for 1x1 rows (ignored inside blocks);
+ *   block b covers rows [block_row0[b], block_row0[b]+block_size[b]) and has
+ *   block_modes[b] <= block_size[b] kept modes; wt holds, back to back, each
+ *   block's TRANSPOSED weights Wt_b[B_b][B_b] (row j = column j of W_b,
+ *   columns >= block_modes[b] zero) so that W_b^T W_b = inv(C_b regulated).
+ *   block_tri[b] != 0 promises Wt_b is upper triangular (W_b = inv(chol)). */
+int lsqamd_set_data(lsqamd_fit *fit, const double *ymean, const double *wdiag, int32_t n_blocks,
+                    const int64_t *block_row0, const int64_t *block_size,
+                    const int64_t *block_modes, const int32_t *block_tri, const double *wt);
+/* Prior: mean[P] and precision = inv(C_prior regulated): prec[P] (diagonal) or
+ * prec[P*P] (dense, symmetric) as cfg.prior_dense says.  The prior rows of
+ * chiv (_utilities.pyx:76-77) enter J^T J / J^T f / chi2 through it. */
+int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);
+int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
+int lsqamd_set_reduce(lsqamd_fit *fit, lsqamd_reduce_fn fn, void *user);
+/* Row-sharded fits: exactly one rank (on != 0) contributes the replicated prior
+ * terms to the sums before the all-reduce.  Default on. */
+int lsqamd_set_adds_prior(lsqamd_fit *fit, int32_t on);
+
+/* ---- the hot path ------------------------------------------------------------ */
+/* replaces gsl_multifit_nlinear_init + _driver (_gsl.pyx:676-677) */
+int lsqamd_run(lsqamd_fit *fit, const double *p0, lsqamd_summary *out);
+/* the same, one piece at a time (benchmark timing, sweeps):
+ *   init  = gsl_multifit_nlinear_init      (f, J, g, D, mu at p0)
+ *   step  = gsl_multifit_nlinear_iterate + _test; *converged = info (0 = continue)
+ *   finish= covariance + logdet at the current point */
+int lsqamd_init(lsqamd_fit *fit, const double *p0);
+int lsqamd_step(lsqamd_fit *fit, int32_t *info);
+int lsqamd_finish(lsqamd_fit *fit, lsqamd_summary *out);
+
+/* ---- kernel-level entry points (parity tests, roofline measurement) ----------- */
+/* _c_f  (_gsl.pyx:727-740): whitened residual at p; returns chi2 = |f|^2 */
+int lsqamd_eval_residual(lsqamd_fit *fit, const double *p, double *chi2);
+/* _c_df (_gsl.pyx:742-760) + solver.init: J, then J^T J, J^T f, chi2 at p */
+int lsqamd_eval_normal(lsqamd_fit *fit, const double *p, double *chi2);
+/* damped solve (J^T J + mu D^2) v = J^T f with D = diag (host, P); v -> host */
+int lsqamd_solve_damped(lsqamd_fit *fit, double mu, const double *diag, double *v);
+/* raw dense ops on device pointers (row-major, see gemm_tn_f64.hip) */
+int lsqamd_op_gemm_tn(void *stream, int64_t M, int64_t N, int64_t K, double alpha, const double *X,
+                      int64_t ldx, const double *Y, int64_t ldy, double beta, double *C, int64_t ldc,
+                      int32_t upper_only, int32_t x_upper_tri);
+int lsqamd_op_potrf_upper(void *stream, double *A, int64_t n, int64_t lda, int64_t n_cols,
+                          double *work, size_t work_bytes, int32_t *dev_info);
+size_t lsqamd_op_potrf_work_bytes(int64_t n);
+
+/* ---- results (replace vector2array / matrix2array, _gsl.pyx:77-86,:104-120) ---- */
+int lsqamd_get_x(lsqamd_fit *fit, double *out, size_t cap);       /* P        : fit.x  */
+int lsqamd_get_f(lsqamd_fit *fit, double *out, size_t cap);       /* nf       : fit.f  */
+int lsqamd_get_J(lsqamd_fit *fit, double *out, size_t cap);       /* nf * P   : fit.J  */
+int lsqamd_get_jtj(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : J^T J  */
+int lsqamd_get_grad(lsqamd_fit *fit, double *out, size_t cap);    /* P        : J^T f  */
+int lsqamd_get_cov(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : fit.cov (gsl_multifit_nlinear_covar, _gsl.pyx:704-706) */
+int64_t lsqamd_nf(const lsqamd_fit *fit);                         /* nchiv (__init__.py:574) */
+
+/* ---- measurement ------------------------------------------------------------ */
+enum {
+  LSQAMD_T_RESIDUAL = 0, LSQAMD_T_JACOBIAN = 1, LSQAMD_T_WHITEN = 2, LSQAMD_T_SYRK = 3,
+  LSQAMD_T_GRAD = 4, LSQAMD_T_REDUCE = 5, LSQAMD_T_CHOLESKY = 6, LSQAMD_T_SOLVE = 7,
+  LSQAMD_T_COVAR = 8, LSQAMD_T_COUNT = 9
+};
+/* HIP-event timing of each phase on the handle's stream; off by default */
+int lsqamd_timing_enable(lsqamd_fit *fit, int32_t on);
+int lsqamd_timing_get(lsqamd_fit *fit, int32_t which, double *total_ms, int64_t *count);
+int lsqamd_timing_reset(lsqamd_fit *fit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSQFIT_AMD_H */

@@ -1,0 +1,22 @@
+"""lsqfit_amd -- MI355X-native Levenberg-Marquardt backend for lsqfit's fitter plugin.
+
+Host side (Python, like the reference) of ONE path of gplepage/lsqfit: the
+``nonlinear_fit(..., fitter=...)`` hot path (src/lsqfit/__init__.py:539-575,
+:662-725).  All numerics below the plugin boundary run in hand-written gfx950
+HIP kernels behind the C ABI declared in ``include/lsqfit_amd.h``; there is no
+CPU fallback -- importing the compute entry points without the built library
+raises.
+
+  models     row models the kernels can differentiate (replaces user fcn + gvar AD)
+  whiten     host mirror of gvar.PDF: block structure, svdcut, whitening weights
+  fitter     ``mi355x_lm``: the fitter plugin class (mirror of gsl_multifit)
+  fit        ``nonlinear_fit``: problem setup + chi2/dof/Q/logGBF reduction
+  dist       row sharding across GPUs + the all-reduce hook (torch.distributed/RCCL)
+  synth      fake_fitargs-style synthetic problems (benchmark generator)
+"""
+from .models import Model, cosmix, multiexp, identity, expr  # noqa: F401
+from .whiten import Whitening  # noqa: F401
+from .fitter import mi355x_lm, DeviceProblem, register  # noqa: F401
+from .fit import nonlinear_fit, gammaQ  # noqa: F401
+
+__version__ = '0.1.0'

@@ -1,0 +1,59 @@
+"""Build recipe for the gfx950 shared library (hipcc, in-tree).
+
+    python -m lsqfit_amd.build        # -> lsqfit_amd/liblsqfit_amd.so
+
+hipcc cross-compiles for gfx950 without a GPU; the resulting .so is git-ignored
+but travels with the tree to the GPU box.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIB = os.path.join(HERE, 'liblsqfit_amd.so')
+SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'model.hip', 'vecops.hip', 'api.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'lsqfit_amd.h')]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or not _newer(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed:\n%s\n%s' % (' '.join(cmd), r.stdout))
+        return r.stdout
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for out in ex.map(run, jobs):
+            if verbose and out.strip():
+                print(out)
+    if jobs or not os.path.exists(LIB):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose=True))

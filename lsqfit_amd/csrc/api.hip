@@ -1,0 +1,999 @@
+// C-ABI entry points + the host side of the trust-region LM driver (gfx950).
+//
+// The driver restates GSL's multifit_nlinear trust/lm/nielsen/scaling/convergence
+// logic that src/lsqfit/_gsl.pyx:676-677 runs (init + driver), on the normal
+// equations (solver='cholesky').  All O(N P), O(N P^2) and O(P^3) work is on the
+// device; the host keeps only O(P) vectors (x, g, D, dx) and the scalars
+// (mu, nu, rho), so that every rank of a row-sharded fit takes identical
+// decisions from the identical all-reduced (J^T J, J^T f, chi2).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+using namespace lsqamd;
+
+namespace {
+
+constexpr int64_t ALIGN = 256;
+inline int64_t rup(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct Carver {
+  char *base;
+  size_t off = 0, cap;
+  bool dry;
+  Carver(void *b, size_t c, bool d) : base((char *)b), cap(c), dry(d) {}
+  template <typename T>
+  T *take(int64_t count) {
+    const size_t bytes = (size_t)rup((int64_t)(count < 1 ? 1 : count) * (int64_t)sizeof(T), ALIGN);
+    T *p = dry ? nullptr : reinterpret_cast<T *>(base + off);
+    off += bytes;
+    return p;
+  }
+};
+
+struct TimerSlot {
+  double total_ms = 0.0;
+  int64_t count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace
+
+struct lsqamd_fit {
+  lsqamd_config cfg;
+  lsqamd_options opt;
+  hipStream_t st = nullptr;
+  std::string err;
+
+  int64_t N = 0, P = 0, ld = 0, ldm = 0, npk = 0;
+  int32_t splits = 1;
+  int64_t npartial = 256;
+
+  // device buffers
+  double *x = nullptr, *ymean = nullptr, *wdiag = nullptr;
+  uint8_t *in_block = nullptr;
+  int64_t *blk_row0 = nullptr, *blk_size = nullptr, *blk_woff = nullptr;
+  double *wt = nullptr;
+  double *prior_mean = nullptr, *prior_prec = nullptr;
+  double *p_dev = nullptr, *p_trial = nullptr;
+  double *r = nullptr, *r_raw = nullptr;
+  double *J = nullptr, *Jraw = nullptr;
+  double *slabs = nullptr;
+  double *redbuf = nullptr;  // [packed J^T J | J^T f | chi2]
+  double *red_scalar = nullptr;
+  double *M = nullptr, *chol_work = nullptr, *yv = nullptr, *diag_dev = nullptr, *tvec = nullptr;
+  double *partial = nullptr, *Wl = nullptr, *cov = nullptr, *scal = nullptr;
+  int32_t *info_dev = nullptr;
+  int32_t *tape = nullptr;
+  double *consts = nullptr;
+  int32_t n_tape = 0;
+
+  // host mirrors of the block structure
+  std::vector<int64_t> h_row0, h_size, h_modes, h_woff;
+  std::vector<int32_t> h_tri;
+  bool uniform_blocks = false;
+  bool have_x = false, have_data = false, have_prior = false, have_tape = false;
+
+  // reduce hook
+  lsqamd_reduce_fn reduce = nullptr;
+  void *reduce_user = nullptr;
+  bool adds_prior = true;
+
+  // LM state (host)
+  std::vector<double> hx, hg, hdiag, hdx, hv, hcoln, htmp;
+  double chi2 = 0.0, mu = 0.0, delta = 0.0;
+  long nu = 2;
+  bool initialised = false, have_cov = false;
+  int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
+  double logdet = NAN;
+
+  // timing
+  bool timing = false;
+  TimerSlot timers[LSQAMD_T_COUNT];
+};
+
+namespace {
+
+#define FAIL(fit, code, ...)                         \
+  do {                                               \
+    char _b[512];                                    \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);           \
+    (fit)->err = _b;                                 \
+    return (code);                                   \
+  } while (0)
+
+#define HIPCHK(fit, expr)                                                              \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) FAIL(fit, LSQAMD_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+struct Scope {  // HIP-event bracket for one phase
+  lsqamd_fit *f;
+  int which;
+  hipEvent_t a = nullptr, b = nullptr;
+  Scope(lsqamd_fit *fit, int w) : f(fit), which(w) {
+    if (f->timing) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, f->st);
+    }
+  }
+  ~Scope() {
+    if (f->timing) {
+      (void)hipEventRecord(b, f->st);
+      f->timers[which].pending.emplace_back(a, b);
+    }
+  }
+};
+
+void resolve_timers(lsqamd_fit *f) {
+  for (auto &t : f->timers) {
+    for (auto &pr : t.pending) {
+      (void)hipEventSynchronize(pr.second);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        t.total_ms += ms;
+        t.count += 1;
+      }
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    t.pending.clear();
+  }
+}
+
+int32_t choose_splits(int64_t N, int64_t P) {
+  const int64_t T = (P + 127) / 128;
+  const int64_t tiles = T * (T + 1) / 2;
+  int64_t s = (4096 + tiles - 1) / tiles;
+  const int64_t maxs = N / 1024 > 1 ? N / 1024 : 1;
+  if (s > maxs) s = maxs;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int32_t)s;
+}
+
+size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
+  const lsqamd_config &c = f->cfg;
+  const int64_t N = c.n_data, P = c.n_param;
+  f->N = N;
+  f->P = P;
+  f->ld = rup(P + 1, 16);
+  f->ldm = rup(P + 1, 16);
+  f->npk = packed_doubles(P);
+  f->splits = choose_splits(N, P);
+  f->npartial = 256;
+  Carver cv(ws, cap, dry);
+  f->x = cv.take<double>(N * (c.n_x > 0 ? c.n_x : 1));
+  f->ymean = cv.take<double>(N);
+  f->wdiag = cv.take<double>(N);
+  f->in_block = cv.take<uint8_t>(N);
+  f->blk_row0 = cv.take<int64_t>(c.n_blocks);
+  f->blk_size = cv.take<int64_t>(c.n_blocks);
+  f->blk_woff = cv.take<int64_t>(c.n_blocks);
+  f->wt = cv.take<double>(c.sum_block_sq);
+  f->prior_mean = cv.take<double>(P);
+  f->prior_prec = cv.take<double>(c.prior_dense ? P * P : P);
+  f->p_dev = cv.take<double>(P);
+  f->p_trial = cv.take<double>(P);
+  f->r = cv.take<double>(N);
+  f->r_raw = cv.take<double>(c.n_blocks > 0 ? N : 1);
+  f->J = cv.take<double>(N * f->ld);
+  f->Jraw = cv.take<double>(c.n_blocks > 0 ? N * f->ld : 1);
+  f->slabs = cv.take<double>((int64_t)f->splits * P * f->ldm);
+  f->redbuf = cv.take<double>(f->npk + P + 1);
+  f->red_scalar = cv.take<double>(8);
+  f->M = cv.take<double>(P * f->ldm);
+  f->chol_work = cv.take<double>((int64_t)(potrf_work_bytes(P) / sizeof(double)));
+  f->yv = cv.take<double>(2 * P);
+  f->diag_dev = cv.take<double>(P);
+  f->tvec = cv.take<double>(P + 1);
+  const int64_t part = f->npartial * (P + 1);
+  f->partial = cv.take<double>(part > 2048 ? part : 2048);
+  f->Wl = cv.take<double>(P * f->ldm);
+  f->cov = cv.take<double>(P * f->ldm);
+  f->scal = cv.take<double>(16);
+  f->info_dev = cv.take<int32_t>(16);
+  f->tape = cv.take<int32_t>(1024);
+  f->consts = cv.take<double>(256);
+  return cv.off;
+}
+
+int check_cfg(const lsqamd_config *c) {
+  if (!c || c->abi_version != LSQAMD_ABI_VERSION) return LSQAMD_EINVAL;
+  if (c->n_data < 0 || c->n_param < 1 || c->n_blocks < 0) return LSQAMD_EINVAL;
+  if (c->model < LSQAMD_MODEL_COSMIX || c->model > LSQAMD_MODEL_IDENTITY) return LSQAMD_EINVAL;
+  if (c->model == LSQAMD_MODEL_TAPE && c->n_param > LSQAMD_TAPE_MAX_PARAM) return LSQAMD_EINVAL;
+  if ((c->model == LSQAMD_MODEL_COSMIX || c->model == LSQAMD_MODEL_MULTIEXP) && (c->n_param & 1))
+    return LSQAMD_EINVAL;
+  if (c->n_batch > 1) return LSQAMD_EUNSUPPORTED;
+  return 0;
+}
+
+ModelArgs model_args(const lsqamd_fit *f, const double *p) {
+  ModelArgs m;
+  m.model = f->cfg.model;
+  m.n_data = f->N;
+  m.n_param = f->P;
+  m.n_x = f->cfg.n_x > 0 ? f->cfg.n_x : 1;
+  m.x = f->x;
+  m.ymean = f->ymean;
+  m.wdiag = f->wdiag;
+  m.in_block = f->cfg.n_blocks > 0 ? f->in_block : nullptr;
+  m.p = p;
+  m.tape = f->tape;
+  m.n_tape = f->n_tape;
+  m.consts = f->consts;
+  return m;
+}
+
+int ready(lsqamd_fit *f) {
+  if (!f->have_data) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_data has not been called");
+  if (f->cfg.has_prior && !f->have_prior) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_prior has not been called");
+  if (f->cfg.model != LSQAMD_MODEL_IDENTITY && !f->have_x) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_x has not been called");
+  if (f->cfg.model == LSQAMD_MODEL_TAPE && !f->have_tape) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_tape has not been called");
+  return 0;
+}
+
+int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
+  if (!f->reduce) return 0;
+  Scope sc(f, LSQAMD_T_REDUCE);
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  const int rc = f->reduce(f->reduce_user, buf, count);
+  if (rc != 0) FAIL(f, LSQAMD_EREDUCE, "all-reduce hook returned %d", rc);
+  return 0;
+}
+
+// whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return
+int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
+  {
+    Scope sc(f, LSQAMD_T_RESIDUAL);
+    ModelArgs m = model_args(f, p);
+    HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
+    if (f->cfg.n_blocks > 0)
+      HIPCHK(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff,
+                                        f->cfg.n_blocks, f->cfg.max_block, f->r_raw, f->r));
+    HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, f->red_scalar));
+    if (f->cfg.has_prior && f->adds_prior)
+      HIPCHK(f, launch_prior_chi2(f->st, f->P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, p,
+                                  f->tvec, f->red_scalar));
+  }
+  int rc = do_reduce(f, f->red_scalar, 1);
+  if (rc) return rc;
+  double c2 = 0.0;
+  HIPCHK(f, hipMemcpyAsync(&c2, f->red_scalar, sizeof(double), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  *chi2_out = c2;
+  f->nfev++;
+  return 0;
+}
+
+int whiten_jacobian(lsqamd_fit *f) {
+  const int nb = f->cfg.n_blocks;
+  if (nb <= 0) return 0;
+  Scope sc(f, LSQAMD_T_WHITEN);
+  const int64_t ncols = f->P + 1;
+  if (f->uniform_blocks) {
+    const int64_t B = f->h_size[0];
+    GemmTN g;
+    g.X = f->wt; g.ldx = B; g.sx = B * B;
+    g.Y = f->Jraw + f->h_row0[0] * f->ld; g.ldy = f->ld; g.sy = B * f->ld;
+    g.C = f->J + f->h_row0[0] * f->ld; g.ldc = f->ld; g.sc = B * f->ld;
+    g.M = B; g.N = ncols; g.K = B;
+    g.batch = nb;
+    g.x_upper_tri = f->h_tri[0];
+    HIPCHK(f, launch_gemm_tn(f->st, g));
+    return 0;
+  }
+  for (int b = 0; b < nb; ++b) {
+    const int64_t B = f->h_size[b];
+    GemmTN g;
+    g.X = f->wt + f->h_woff[b]; g.ldx = B;
+    g.Y = f->Jraw + f->h_row0[b] * f->ld; g.ldy = f->ld;
+    g.C = f->J + f->h_row0[b] * f->ld; g.ldc = f->ld;
+    g.M = B; g.N = ncols; g.K = B;
+    g.x_upper_tri = f->h_tri[b];
+    HIPCHK(f, launch_gemm_tn(f->st, g));
+  }
+  return 0;
+}
+
+// J, J^T J (packed), J^T f, chi2 at device parameters p; host g/chi2/colnorm refreshed
+int eval_normal_dev(lsqamd_fit *f, const double *p) {
+  const int64_t P = f->P;
+  {
+    Scope sc(f, LSQAMD_T_JACOBIAN);
+    ModelArgs m = model_args(f, p);
+    HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
+  }
+  int rc = whiten_jacobian(f);
+  if (rc) return rc;
+  {
+    Scope sc(f, LSQAMD_T_SYRK);
+    GemmTN g;
+    g.X = f->J; g.Y = f->J; g.ldx = g.ldy = f->ld;
+    g.C = f->slabs; g.ldc = f->ldm;
+    g.M = P; g.N = P; g.K = f->N;
+    g.upper_only = 1;
+    g.splits = f->splits;
+    g.split_stride = P * f->ldm;
+    if (f->N > 0) {
+      HIPCHK(f, launch_gemm_tn(f->st, g));
+    } else {
+      HIPCHK(f, hipMemsetAsync(f->slabs, 0, sizeof(double) * f->splits * P * f->ldm, f->st));
+    }
+  }
+  double *gvec = f->redbuf + f->npk;
+  {
+    Scope sc(f, LSQAMD_T_GRAD);
+    // when splits == 1 the kernel ignored split_stride and wrote slab 0 directly
+    HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf));
+    HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
+    if (f->cfg.has_prior && f->adds_prior)
+      HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
+                                 f->prior_mean, p, f->tvec, gvec, 1));
+  }
+  rc = do_reduce(f, f->redbuf, f->npk + P + 1);
+  if (rc) return rc;
+  HIPCHK(f, launch_packed_diag(f->st, f->redbuf, P, f->diag_dev));
+  f->htmp.resize(P + 1);
+  HIPCHK(f, hipMemcpyAsync(f->htmp.data(), gvec, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->hcoln.data(), f->diag_dev, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  for (int64_t j = 0; j < P; ++j) {
+    f->hg[j] = f->htmp[j];
+    f->hcoln[j] = std::sqrt(f->hcoln[j] > 0.0 ? f->hcoln[j] : 0.0);
+  }
+  f->chi2 = f->htmp[P];
+  f->njev++;
+  f->have_cov = false;
+  if (!std::isfinite(f->chi2)) FAIL(f, LSQAMD_ENONFINITE, "chi2 is not finite at this point");
+  return 0;
+}
+
+// (A + mu D^2) v = g  -> f->hv ; returns LSQAMD_ENOTPD when a pivot fails
+int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
+  const int64_t P = f->P;
+  double *gvec = f->redbuf + f->npk;
+  int32_t info = 0;
+  {
+    Scope sc(f, LSQAMD_T_CHOLESKY);
+    HIPCHK(f, hipMemcpyAsync(f->diag_dev, diag_host, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, f->diag_dev, gvec, f->M));
+    HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, P + 1, f->chol_work, f->info_dev));
+  }
+  {
+    Scope sc(f, LSQAMD_T_SOLVE);
+    HIPCHK(f, launch_copy_strided(f->st, f->M + P, f->ldm, f->yv, 1, P, 1));
+    HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
+    HIPCHK(f, hipMemcpyAsync(f->hv.data(), f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipMemcpyAsync(&info, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+  }
+  f->ntrial++;
+  if (info != 0) {
+    f->chol_fail++;
+    return LSQAMD_ENOTPD;
+  }
+  for (int64_t j = 0; j < P; ++j)
+    if (!std::isfinite(f->hv[j])) {
+      f->chol_fail++;
+      return LSQAMD_ENOTPD;
+    }
+  return 0;
+}
+
+void scale_init(lsqamd_fit *f) {
+  for (int64_t j = 0; j < f->P; ++j) {
+    if (f->opt.scaler == LSQAMD_SCALE_LEVENBERG) f->hdiag[j] = 1.0;
+    else f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
+  }
+}
+
+void scale_update(lsqamd_fit *f) {
+  for (int64_t j = 0; j < f->P; ++j) {
+    if (f->opt.scaler == LSQAMD_SCALE_MORE) f->hdiag[j] = std::fmax(f->hdiag[j], f->hcoln[j]);
+    else if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT) f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
+  }
+}
+
+// one trust_iterate: GSL_SUCCESS (0) or LSQAMD_ENOPROG; negative on backend failure
+int iterate(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  int bad_steps = 0;
+  std::vector<double> xt(P);
+  while (true) {
+    double rho = -1.0;
+    int rc = solve_damped_dev(f, f->mu, f->hdiag.data());
+    if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+    if (rc == 0) {
+      double vg = 0.0, dv2 = 0.0;
+      for (int64_t j = 0; j < P; ++j) {
+        f->hdx[j] = -f->hv[j];
+        xt[j] = f->hx[j] + f->hdx[j];
+        vg += f->hv[j] * f->hg[j];
+        const double t = f->hdiag[j] * f->hv[j];
+        dv2 += t * t;
+      }
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, xt.data(), sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      double chi2_t = 0.0;
+      rc = eval_residual_dev(f, f->p_trial, &chi2_t);
+      if (rc) return rc;
+      const double normf = std::sqrt(f->chi2), normf_t = std::sqrt(chi2_t);
+      if (normf_t < normf) {  // NaN-safe: anything else rejects
+        const double u = normf_t / normf;
+        const double actual = 1.0 - u * u;
+        // |J v|^2 = v^T A v = v^T g - mu |D v|^2  since (A + mu D^2) v = g
+        const double pred = (vg + f->mu * dv2) / f->chi2;
+        rho = pred > 0.0 ? actual / pred : -1.0;
+      }
+    }
+    if (rho > 0.75) f->delta *= f->opt.factor_up;
+    else if (rho < 0.25) f->delta /= f->opt.factor_down;
+    if (rho > 0.0) {
+      rc = eval_normal_dev(f, f->p_trial);
+      if (rc) return rc;
+      f->hx = xt;
+      std::swap(f->p_dev, f->p_trial);
+      scale_update(f);
+      const double b = 2.0 * rho - 1.0;
+      f->mu *= std::fmax(0.333333333333333, 1.0 - b * b * b);
+      f->nu = 2;
+      return 0;
+    }
+    f->mu *= (double)f->nu;
+    f->nu <<= 1;
+    if (++bad_steps > 15) return LSQAMD_ENOPROG;
+  }
+}
+
+int convergence_test(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  const double xtol = f->opt.xtol, gtol = f->opt.gtol;
+  bool ok = true;
+  for (int64_t j = 0; j < P; ++j)
+    if (!(std::fabs(f->hdx[j]) < xtol * xtol + xtol * std::fabs(f->hx[j]))) { ok = false; break; }
+  if (ok) return 1;
+  double gnorm = 0.0;
+  for (int64_t j = 0; j < P; ++j) {
+    const double t = std::fabs(std::fmax(f->hx[j], 1.0) * f->hg[j]);
+    if (t > gnorm) gnorm = t;
+  }
+  if (gnorm <= gtol * std::fmax(0.5 * f->chi2, 1.0)) return 2;
+  return 0;
+}
+
+int do_init(lsqamd_fit *f, const double *p0) {
+  int rc = ready(f);
+  if (rc) return rc;
+  const int64_t P = f->P;
+  f->hx.assign(p0, p0 + P);
+  f->hg.assign(P, 0.0);
+  f->hdiag.assign(P, 1.0);
+  f->hdx.assign(P, 0.0);
+  f->hv.assign(P, 0.0);
+  f->hcoln.assign(P, 0.0);
+  f->nit = f->nfev = f->njev = f->ntrial = f->chol_fail = 0;
+  f->logdet = NAN;
+  HIPCHK(f, hipMemcpyAsync(f->p_dev, p0, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+  rc = eval_normal_dev(f, f->p_dev);
+  if (rc) return rc;
+  f->nfev++;
+  scale_init(f);
+  double mx = -1.0;
+  for (int64_t j = 0; j < P; ++j) mx = std::fmax(mx, f->hcoln[j] / f->hdiag[j]);
+  f->mu = 1e-3 * mx * mx;
+  f->nu = 2;
+  double dxn = 0.0;
+  for (int64_t j = 0; j < P; ++j) dxn += f->hdiag[j] * f->hx[j] * f->hdiag[j] * f->hx[j];
+  f->delta = 0.3 * std::fmax(1.0, std::sqrt(dxn));
+  f->initialised = true;
+  return 0;
+}
+
+void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
+  if (!s) return;
+  std::memset(s, 0, sizeof(*s));
+  s->status = status;
+  s->info = info;
+  if (info >= 0 && info <= 3) s->stopping_criterion = info;
+  else if (info == 30) s->stopping_criterion = 1;
+  else if (info == 31) s->stopping_criterion = 2;
+  else if (info == 29) s->stopping_criterion = 3;
+  else if (info == 27) s->stopping_criterion = 4;
+  else s->stopping_criterion = 0;
+  s->nit = f->nit; s->nfev = f->nfev; s->njev = f->njev; s->ntrial = f->ntrial;
+  s->chol_fail = f->chol_fail;
+  s->chi2 = f->chi2;
+  s->mu = f->mu;
+  s->logdet_jtj = f->logdet;
+}
+
+// covariance + logdet at the current point: factor A (mu = 0), invert
+int do_covariance(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  Scope sc(f, LSQAMD_T_COVAR);
+  int32_t info = 0;
+  double ld = 0.0;
+  HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, 0.0, f->diag_dev, nullptr, f->M));
+  HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, P, f->chol_work, f->info_dev));
+  HIPCHK(f, logdiag_sum(f->st, f->M, P, f->ldm, f->scal));
+  HIPCHK(f, trtri_upper_to_lower_T(f->st, f->M, P, f->ldm, f->chol_work, f->Wl, f->ldm));
+  GemmTN g;
+  g.X = f->Wl; g.Y = f->Wl; g.ldx = g.ldy = f->ldm;
+  g.C = f->cov; g.ldc = f->ldm;
+  g.M = P; g.N = P; g.K = P;
+  g.upper_only = 1;
+  g.xy_lower_tri = 1;
+  HIPCHK(f, launch_gemm_tn(f->st, g));
+  HIPCHK(f, launch_symmetrize_from_upper(f->st, f->cov, P, f->ldm));
+  HIPCHK(f, hipMemcpyAsync(&info, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(&ld, f->scal, sizeof(double), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->have_cov = true;
+  if (info != 0) {
+    f->logdet = NAN;
+    char b[160];
+    snprintf(b, sizeof(b), "J^T J is not positive definite at the solution (pivot %d); covariance undefined", info);
+    f->err = b;
+    return LSQAMD_ENOTPD;
+  }
+  f->logdet = 2.0 * ld;
+  return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+int lsqamd_abi_version(void) { return LSQAMD_ABI_VERSION; }
+
+size_t lsqamd_workspace_bytes(const lsqamd_config *cfg) {
+  if (check_cfg(cfg) != 0) return 0;
+  lsqamd_fit tmp;
+  tmp.cfg = *cfg;
+  return carve(&tmp, nullptr, 0, true);
+}
+
+int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspace_bytes, void *stream,
+                  lsqamd_fit **out) {
+  if (!out) return LSQAMD_EINVAL;
+  *out = nullptr;
+  const int rc = check_cfg(cfg);
+  if (rc) return rc;
+  if (!dev_workspace || (reinterpret_cast<uintptr_t>(dev_workspace) & 255)) return LSQAMD_EINVAL;
+  lsqamd_fit *f = new (std::nothrow) lsqamd_fit;
+  if (!f) return LSQAMD_ENOMEM;
+  f->cfg = *cfg;
+  f->st = reinterpret_cast<hipStream_t>(stream);
+  const size_t need = carve(f, dev_workspace, workspace_bytes, true);
+  if (need > workspace_bytes) {
+    delete f;
+    return LSQAMD_ENOMEM;
+  }
+  carve(f, dev_workspace, workspace_bytes, false);
+  f->opt.xtol = 1e-8; f->opt.gtol = 1e-10; f->opt.ftol = 1e-10;   // __init__.py:102, _gsl.pyx:595-596
+  f->opt.maxit = 1000;
+  f->opt.scaler = LSQAMD_SCALE_MORE;
+  f->opt.solver = LSQAMD_SOLVER_CHOLESKY;
+  f->opt.factor_up = 3.0;
+  f->opt.factor_down = 2.0;
+  if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
+    delete f;
+    return LSQAMD_EHIP;
+  }
+  *out = f;
+  return 0;
+}
+
+int lsqamd_destroy(lsqamd_fit *fit) {
+  if (!fit) return 0;
+  (void)hipStreamSynchronize(fit->st);
+  resolve_timers(fit);
+  delete fit;
+  return 0;
+}
+
+const char *lsqamd_last_error(const lsqamd_fit *fit) { return fit ? fit->err.c_str() : "null handle"; }
+
+int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!x || n_rows != f->N || n_x != (f->cfg.n_x > 0 ? f->cfg.n_x : 1))
+    FAIL(f, LSQAMD_EINVAL, "set_x: expected %lld x %d", (long long)f->N, f->cfg.n_x);
+  HIPCHK(f, hipMemcpyAsync(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->have_x = true;
+  return 0;
+}
+
+int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const double *consts,
+                    int32_t n_consts) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!code || n_code < 1 || n_code > 1024 || n_consts < 0 || n_consts > 256)
+    FAIL(f, LSQAMD_EINVAL, "set_tape: 1..1024 instructions, <= 256 constants");
+  // validate stack discipline and operand ranges on the host
+  int sp = 0;
+  for (int t = 0; t < n_code; ++t) {
+    const int op = code[t] & 0xff, arg = code[t] >> 8;
+    if (op == LSQAMD_OP_CONST) { if (arg < 0 || arg >= n_consts) FAIL(f, LSQAMD_EINVAL, "tape: bad const index"); ++sp; }
+    else if (op == LSQAMD_OP_X) { if (arg < 0 || arg >= (f->cfg.n_x > 0 ? f->cfg.n_x : 1)) FAIL(f, LSQAMD_EINVAL, "tape: bad x index"); ++sp; }
+    else if (op == LSQAMD_OP_P) { if (arg < 0 || arg >= f->P) FAIL(f, LSQAMD_EINVAL, "tape: bad parameter index"); ++sp; }
+    else if (op >= LSQAMD_OP_ADD && op <= LSQAMD_OP_POW) { if (sp < 2) FAIL(f, LSQAMD_EINVAL, "tape: stack underflow"); --sp; }
+    else if (op >= LSQAMD_OP_NEG && op <= LSQAMD_OP_POWI) { if (sp < 1) FAIL(f, LSQAMD_EINVAL, "tape: stack underflow"); }
+    else FAIL(f, LSQAMD_EINVAL, "tape: unknown opcode %d", op);
+    if (sp > LSQAMD_TAPE_MAX_STACK) FAIL(f, LSQAMD_EINVAL, "tape: stack deeper than %d", LSQAMD_TAPE_MAX_STACK);
+  }
+  if (sp != 1) FAIL(f, LSQAMD_EINVAL, "tape: must leave exactly one value");
+  HIPCHK(f, hipMemcpyAsync(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice, f->st));
+  if (n_consts > 0)
+    HIPCHK(f, hipMemcpyAsync(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->n_tape = n_code;
+  f->have_tape = true;
+  return 0;
+}
+
+int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int32_t n_blocks,
+                    const int64_t *block_row0, const int64_t *block_size, const int64_t *block_modes,
+                    const int32_t *block_tri, const double *wt) {
+  if (!f) return LSQAMD_EINVAL;
+  if (n_blocks != f->cfg.n_blocks) FAIL(f, LSQAMD_EINVAL, "set_data: n_blocks differs from the config");
+  if (f->N > 0 && (!ymean || !wdiag)) FAIL(f, LSQAMD_EINVAL, "set_data: null ymean/wdiag");
+  const int64_t N = f->N;
+  std::vector<uint8_t> inb((size_t)(N > 0 ? N : 1), 0);
+  f->h_row0.assign(block_row0, block_row0 + n_blocks);
+  f->h_size.assign(block_size, block_size + n_blocks);
+  f->h_modes.assign(block_modes, block_modes + n_blocks);
+  f->h_tri.assign(n_blocks, 0);
+  f->h_woff.assign(n_blocks, 0);
+  int64_t off = 0, prev_end = 0, maxb = 0;
+  f->uniform_blocks = n_blocks > 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int64_t r0 = f->h_row0[b], B = f->h_size[b];
+    if (B < 1 || r0 < prev_end || r0 + B > N || f->h_modes[b] < 0 || f->h_modes[b] > B)
+      FAIL(f, LSQAMD_EINVAL, "set_data: block %d is not a valid ascending contiguous row range", b);
+    prev_end = r0 + B;
+    if (B > maxb) maxb = B;
+    f->h_tri[b] = block_tri ? block_tri[b] : 0;
+    f->h_woff[b] = off;
+    off += B * B;
+    for (int64_t i = 0; i < B; ++i) inb[(size_t)(r0 + i)] = 1;
+    if (B != f->h_size[0] || f->h_tri[b] != f->h_tri[0] || r0 != f->h_row0[0] + b * f->h_size[0])
+      f->uniform_blocks = false;
+  }
+  if (off > f->cfg.sum_block_sq || maxb > f->cfg.max_block)
+    FAIL(f, LSQAMD_EINVAL, "set_data: blocks exceed the sizes promised in the config");
+  if (N > 0) {
+    HIPCHK(f, hipMemcpyAsync(f->ymean, ymean, sizeof(double) * N, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->wdiag, wdiag, sizeof(double) * N, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->in_block, inb.data(), (size_t)N, hipMemcpyHostToDevice, f->st));
+  }
+  if (n_blocks > 0) {
+    if (!wt) FAIL(f, LSQAMD_EINVAL, "set_data: null block weights");
+    HIPCHK(f, hipMemcpyAsync(f->blk_row0, f->h_row0.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->blk_size, f->h_size.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->blk_woff, f->h_woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->wt, wt, sizeof(double) * off, hipMemcpyHostToDevice, f->st));
+  }
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->have_data = true;
+  return 0;
+}
+
+int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!f->cfg.has_prior) FAIL(f, LSQAMD_EINVAL, "set_prior: the config says has_prior = 0");
+  if (!mean || !prec) FAIL(f, LSQAMD_EINVAL, "set_prior: null argument");
+  const int64_t P = f->P;
+  HIPCHK(f, hipMemcpyAsync(f->prior_mean, mean, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->prior_prec, prec, sizeof(double) * (f->cfg.prior_dense ? P * P : P),
+                           hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->have_prior = true;
+  return 0;
+}
+
+int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
+  if (!f || !opt) return LSQAMD_EINVAL;
+  if (opt->xtol < 0 || opt->gtol < 0 || opt->maxit < 0) FAIL(f, LSQAMD_EINVAL, "set_options: negative tolerance/maxit");
+  if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
+  if (opt->solver != LSQAMD_SOLVER_CHOLESKY) FAIL(f, LSQAMD_EUNSUPPORTED, "set_options: only the cholesky solver runs on the device");
+  if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
+  f->opt = *opt;
+  return 0;
+}
+
+int lsqamd_set_reduce(lsqamd_fit *f, lsqamd_reduce_fn fn, void *user) {
+  if (!f) return LSQAMD_EINVAL;
+  f->reduce = fn;
+  f->reduce_user = user;
+  return 0;
+}
+
+// rank that contributes the (replicated) prior terms before the all-reduce; default: this one
+int lsqamd_set_adds_prior(lsqamd_fit *f, int32_t on) {
+  if (!f) return LSQAMD_EINVAL;
+  f->adds_prior = on != 0;
+  return 0;
+}
+
+int lsqamd_init(lsqamd_fit *f, const double *p0) {
+  if (!f || !p0) return LSQAMD_EINVAL;
+  return do_init(f, p0);
+}
+
+int lsqamd_step(lsqamd_fit *f, int32_t *info) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_step before lsqamd_init");
+  const int rc = iterate(f);
+  if (rc < 0) return rc;
+  f->nit++;
+  if (f->timing) resolve_timers(f);
+  if (rc == LSQAMD_ENOPROG) {
+    if (info) *info = LSQAMD_ENOPROG;
+    return LSQAMD_ENOPROG;
+  }
+  if (info) *info = convergence_test(f);
+  return 0;
+}
+
+int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_finish before lsqamd_init");
+  const int rc = do_covariance(f);
+  if (f->timing) resolve_timers(f);
+  fill_summary(f, out, 0, 0);
+  return rc == LSQAMD_ENOTPD ? 0 : rc;
+}
+
+int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
+  if (!f || !p0) return LSQAMD_EINVAL;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, f->st);
+  int rc = do_init(f, p0);
+  if (rc) return rc;
+  // gsl_multifit_nlinear_driver
+  int iter = 0, info = 0, status = -2;
+  bool early = false;
+  const int maxit = f->opt.maxit;
+  if (maxit > 0) {
+    do {
+      rc = iterate(f);
+      if (rc < 0) return rc;
+      f->nit++;
+      if (rc == LSQAMD_ENOPROG && iter == 0) {
+        info = LSQAMD_ENOPROG;
+        status = LSQAMD_EMAXITER;
+        early = true;
+        break;
+      }
+      ++iter;
+      info = convergence_test(f);
+      status = info ? 0 : -2;
+    } while (status == -2 && iter < maxit);
+    if (!early && iter >= maxit && status != 0) status = LSQAMD_EMAXITER;
+  } else {
+    status = 0;
+  }
+  rc = do_covariance(f);
+  if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+  (void)hipEventRecord(e1, f->st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (f->timing) resolve_timers(f);
+  fill_summary(f, out, status, info);
+  if (out) out->t_run_ms = ms;
+  return 0;
+}
+
+int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) {
+  if (!f || !p || !chi2) return LSQAMD_EINVAL;
+  int rc = ready(f);
+  if (rc) return rc;
+  HIPCHK(f, hipMemcpyAsync(f->p_trial, p, sizeof(double) * f->P, hipMemcpyHostToDevice, f->st));
+  rc = eval_residual_dev(f, f->p_trial, chi2);
+  if (f->timing) resolve_timers(f);
+  return rc;
+}
+
+int lsqamd_eval_normal(lsqamd_fit *f, const double *p, double *chi2) {
+  if (!f || !p) return LSQAMD_EINVAL;
+  int rc = ready(f);
+  if (rc) return rc;
+  const int64_t P = f->P;
+  f->hx.assign(p, p + P);
+  f->hg.assign(P, 0.0);
+  f->hcoln.assign(P, 0.0);
+  f->hv.assign(P, 0.0);
+  f->hdx.assign(P, 0.0);
+  if ((int64_t)f->hdiag.size() != P) f->hdiag.assign(P, 1.0);
+  HIPCHK(f, hipMemcpyAsync(f->p_dev, p, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+  rc = eval_normal_dev(f, f->p_dev);
+  if (f->timing) resolve_timers(f);
+  if (rc) return rc;
+  // the Jacobian evaluation leaves the whitened residual in column P of J; mirror it into r
+  HIPCHK(f, launch_copy_strided(f->st, f->J + P, f->ld, f->r, 1, f->N, 1));
+  f->initialised = true;
+  if (chi2) *chi2 = f->chi2;
+  return 0;
+}
+
+int lsqamd_solve_damped(lsqamd_fit *f, double mu, const double *diag, double *v) {
+  if (!f || !diag || !v) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "solve_damped needs lsqamd_eval_normal / lsqamd_init first");
+  const int rc = solve_damped_dev(f, mu, diag);
+  if (f->timing) resolve_timers(f);
+  if (rc) {
+    if (rc == LSQAMD_ENOTPD) f->err = "damped normal matrix is not positive definite";
+    return rc;
+  }
+  std::memcpy(v, f->hv.data(), sizeof(double) * f->P);
+  return 0;
+}
+
+int lsqamd_op_gemm_tn(void *stream, int64_t M, int64_t N, int64_t K, double alpha, const double *X,
+                      int64_t ldx, const double *Y, int64_t ldy, double beta, double *C, int64_t ldc,
+                      int32_t upper_only, int32_t x_upper_tri) {
+  GemmTN g;
+  g.X = X; g.Y = Y; g.C = C;
+  g.M = M; g.N = N; g.K = K;
+  g.ldx = ldx; g.ldy = ldy; g.ldc = ldc;
+  g.alpha = alpha; g.beta = beta;
+  g.upper_only = upper_only;
+  g.x_upper_tri = x_upper_tri;
+  return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), g) == hipSuccess ? 0 : LSQAMD_EHIP;
+}
+
+size_t lsqamd_op_potrf_work_bytes(int64_t n) { return potrf_work_bytes(n); }
+
+int lsqamd_op_potrf_upper(void *stream, double *A, int64_t n, int64_t lda, int64_t n_cols, double *work,
+                          size_t work_bytes, int32_t *dev_info) {
+  if (work_bytes < potrf_work_bytes(n)) return LSQAMD_ENOMEM;
+  return potrf_upper(reinterpret_cast<hipStream_t>(stream), A, n, lda, n_cols, work, dev_info) == hipSuccess
+             ? 0 : LSQAMD_EHIP;
+}
+
+int64_t lsqamd_nf(const lsqamd_fit *f) {
+  if (!f) return 0;
+  int64_t nf = f->N;
+  for (size_t b = 0; b < f->h_size.size(); ++b) nf -= f->h_size[b] - f->h_modes[b];
+  if (f->cfg.has_prior) nf += f->P;
+  return nf;
+}
+
+int lsqamd_get_x(lsqamd_fit *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (cap < (size_t)f->P) FAIL(f, LSQAMD_ECAPACITY, "get_x: need %lld", (long long)f->P);
+  if ((int64_t)f->hx.size() != f->P) FAIL(f, LSQAMD_EINVAL, "get_x: no fit has run");
+  std::memcpy(out, f->hx.data(), sizeof(double) * f->P);
+  return 0;
+}
+
+int lsqamd_get_grad(lsqamd_fit *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (cap < (size_t)f->P) FAIL(f, LSQAMD_ECAPACITY, "get_grad: need %lld", (long long)f->P);
+  if ((int64_t)f->hg.size() != f->P) FAIL(f, LSQAMD_EINVAL, "get_grad: no fit has run");
+  std::memcpy(out, f->hg.data(), sizeof(double) * f->P);
+  return 0;
+}
+
+// Data part of f / J in the reference's order (_utilities.pyx:85-93): all 1x1 rows first,
+// then each block's kept modes.  Prior rows are appended by the host layer, which owns the
+// prior's whitening (any W with W^T W = precision is equivalent: SURVEY.md App. B).
+int lsqamd_get_f(lsqamd_fit *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_f: no fit has run");
+  int64_t nfd = f->N;
+  for (size_t b = 0; b < f->h_size.size(); ++b) nfd -= f->h_size[b] - f->h_modes[b];
+  if (cap < (size_t)nfd) FAIL(f, LSQAMD_ECAPACITY, "get_f: need %lld", (long long)nfd);
+  std::vector<double> r((size_t)(f->N > 0 ? f->N : 1));
+  // the residual at the CURRENT point is column P of J
+  HIPCHK(f, launch_copy_strided(f->st, f->J + f->P, f->ld, f->r, 1, f->N, 1));
+  HIPCHK(f, hipMemcpyAsync(r.data(), f->r, sizeof(double) * f->N, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  std::vector<uint8_t> inb((size_t)(f->N > 0 ? f->N : 1), 0);
+  for (size_t b = 0; b < f->h_size.size(); ++b)
+    for (int64_t i = 0; i < f->h_size[b]; ++i) inb[(size_t)(f->h_row0[b] + i)] = 1;
+  size_t o = 0;
+  for (int64_t i = 0; i < f->N; ++i)
+    if (!inb[(size_t)i]) out[o++] = r[(size_t)i];
+  for (size_t b = 0; b < f->h_size.size(); ++b)
+    for (int64_t m = 0; m < f->h_modes[b]; ++m) out[o++] = r[(size_t)(f->h_row0[b] + m)];
+  return 0;
+}
+
+int lsqamd_get_J(lsqamd_fit *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_J: no fit has run");
+  const int64_t P = f->P;
+  int64_t nfd = f->N;
+  for (size_t b = 0; b < f->h_size.size(); ++b) nfd -= f->h_size[b] - f->h_modes[b];
+  if (cap < (size_t)(nfd * P)) FAIL(f, LSQAMD_ECAPACITY, "get_J: need %lld", (long long)(nfd * P));
+  std::vector<uint8_t> inb((size_t)(f->N > 0 ? f->N : 1), 0);
+  for (size_t b = 0; b < f->h_size.size(); ++b)
+    for (int64_t i = 0; i < f->h_size[b]; ++i) inb[(size_t)(f->h_row0[b] + i)] = 1;
+  // copy row by row ranges with 2D copies (ld -> P)
+  auto copy_rows = [&](int64_t src_row, int64_t nrows, size_t dst_row) -> hipError_t {
+    return hipMemcpy2DAsync(out + dst_row * P, sizeof(double) * P, f->J + src_row * f->ld,
+                            sizeof(double) * f->ld, sizeof(double) * P, (size_t)nrows,
+                            hipMemcpyDeviceToHost, f->st);
+  };
+  size_t o = 0;
+  int64_t i = 0;
+  while (i < f->N) {
+    if (inb[(size_t)i]) { ++i; continue; }
+    int64_t j = i;
+    while (j < f->N && !inb[(size_t)j]) ++j;
+    HIPCHK(f, copy_rows(i, j - i, o));
+    o += (size_t)(j - i);
+    i = j;
+  }
+  for (size_t b = 0; b < f->h_size.size(); ++b) {
+    if (f->h_modes[b] > 0) HIPCHK(f, copy_rows(f->h_row0[b], f->h_modes[b], o));
+    o += (size_t)f->h_modes[b];
+  }
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
+int lsqamd_get_jtj(lsqamd_fit *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_jtj: no fit has run");
+  const int64_t P = f->P;
+  if (cap < (size_t)(P * P)) FAIL(f, LSQAMD_ECAPACITY, "get_jtj: need %lld", (long long)(P * P));
+  HIPCHK(f, launch_unpack_sym(f->st, f->redbuf, P, f->Wl, f->ldm));
+  HIPCHK(f, hipMemcpy2DAsync(out, sizeof(double) * P, f->Wl, sizeof(double) * f->ldm, sizeof(double) * P,
+                             (size_t)P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
+int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_cov: no fit has run");
+  const int64_t P = f->P;
+  if (cap < (size_t)(P * P)) FAIL(f, LSQAMD_ECAPACITY, "get_cov: need %lld", (long long)(P * P));
+  if (!f->have_cov) {
+    const int rc = do_covariance(f);
+    if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+  }
+  HIPCHK(f, hipMemcpy2DAsync(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P,
+                             (size_t)P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
+int lsqamd_timing_enable(lsqamd_fit *f, int32_t on) {
+  if (!f) return LSQAMD_EINVAL;
+  f->timing = on != 0;
+  return 0;
+}
+
+int lsqamd_timing_get(lsqamd_fit *f, int32_t which, double *total_ms, int64_t *count) {
+  if (!f || which < 0 || which >= LSQAMD_T_COUNT) return LSQAMD_EINVAL;
+  resolve_timers(f);
+  if (total_ms) *total_ms = f->timers[which].total_ms;
+  if (count) *count = f->timers[which].count;
+  return 0;
+}
+
+int lsqamd_timing_reset(lsqamd_fit *f) {
+  if (!f) return LSQAMD_EINVAL;
+  resolve_timers(f);
+  for (auto &t : f->timers) { t.total_ms = 0.0; t.count = 0; }
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared declarations for the gfx950 backend (device launchers + handle).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/lsqfit_amd.h"
+
+namespace lsqamd {
+
+// ---- fp64 MFMA GEMM, "TN" form (gemm_tn_f64.hip) ---------------------------------
+// C[M x N] = alpha * sum_k X[k][m] * Y[k][n] + beta * C      (all row-major)
+// Every dense contraction on the LM path has this shape with k-major operands:
+//   J^T J (X = Y = J), whitening (X = W^T), Cholesky row-panel solve
+//   (X = inv(U_kk)), trailing update (X = Y = panel), covariance (X = Y = U^-T).
+struct GemmTN {
+  const double *X = nullptr, *Y = nullptr;
+  double *C = nullptr;
+  int64_t M = 0, N = 0, K = 0;
+  int64_t ldx = 0, ldy = 0, ldc = 0;
+  double alpha = 1.0, beta = 0.0;
+  int32_t batch = 1;
+  int64_t sx = 0, sy = 0, sc = 0;  // batch strides (elements)
+  int32_t upper_only = 0;          // skip tiles strictly below the diagonal (C square-aligned)
+  int32_t x_upper_tri = 0;         // X[k][m] == 0 for k > m  -> k loop stops at the tile's last row
+  int32_t xy_lower_tri = 0;        // X[k][m] == 0 for m > k (and same for Y) -> k loop starts at the tile
+  int32_t splits = 1;              // split-K: split s writes C + s*split_stride (beta ignored)
+  int64_t split_stride = 0;
+};
+hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
+
+// ---- Cholesky family (chol.hip) ---------------------------------------------------
+constexpr int CHOL_NB = 128;
+// workspace: inverses of the diagonal blocks, ceil(n/NB) * NB*NB doubles
+size_t potrf_work_bytes(int64_t n);
+// In-place upper Cholesky A = U^T U of the leading n x n block of A[n x n_cols]
+// (row-major, lda); columns n..n_cols-1 are carried along (they become U^-T * A[:, n:]).
+// *dev_info (device int32) is set to (first failing pivot + 1) if not positive definite.
+hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
+                       double *work, int32_t *dev_info);
+// v = U^-1 y (y = column `ycol` of A rows 0..n-1), using the diagonal-block inverses in work
+hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                           const double *work, double *y_inout);
+// Wl (n x n, ld) = U^-T (lower triangular), given factored A and the block inverses.
+hipError_t trtri_upper_to_lower_T(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                                  const double *work, double *Wl, int64_t ldw);
+// sum_j log(A[j][j]) -> *dev_out (device double)
+hipError_t logdiag_sum(hipStream_t st, const double *A, int64_t n, int64_t lda, double *dev_out);
+
+// ---- model kernels (model.hip) ----------------------------------------------------
+struct ModelArgs {
+  int32_t model = 0;
+  int64_t n_data = 0, n_param = 0;
+  int32_t n_x = 0;
+  const double *x = nullptr;          // [n_data][n_x]
+  const double *ymean = nullptr;      // [n_data]
+  const double *wdiag = nullptr;      // [n_data] 1/sdev of 1x1 rows
+  const uint8_t *in_block = nullptr;  // [n_data] 1 if the row belongs to a correlated block (or null)
+  const double *p = nullptr;          // [n_param] device
+  const int32_t *tape = nullptr;
+  int32_t n_tape = 0;
+  const double *consts = nullptr;
+};
+// r_w[i] = w_i (f(x_i;p) - y_i) for 1x1 rows; r_raw[i] = f - y for rows inside blocks
+hipError_t launch_residual_ex(hipStream_t st, const ModelArgs &m, double *r_w, double *r_raw);
+// J[i][0..P) = w_i d f_i / d p ; J[i][P] = w_i delta_i (ld >= P+1); block rows -> J_raw unweighted
+hipError_t launch_jacobian_ex(hipStream_t st, const ModelArgs &m, double *J_w, double *J_raw,
+                              int64_t ld);
+
+// ---- vector / reduction kernels (vecops.hip) --------------------------------------
+// out[j] = sum_i J[i][j] * J[i][rcol] for j in [0, ncols)   (ncols = P+1 gives grad and chi2)
+hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
+                             int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
+                             double *out);
+// out[0] = sum_i r[i]^2   (partial: >= 1024 doubles)
+hipError_t launch_sumsq(hipStream_t st, const double *r, int64_t n, double *partial, double *out);
+// whitened block residual: r_out[row0_b + m] = sum_j Wt_b[j][m] * delta[row0_b + j]
+hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64_t *row0,
+                                   const int64_t *bsize, const int64_t *woff, int32_t n_blocks,
+                                   int64_t max_block, const double *delta, double *r_out);
+// packed upper tiles <- sum over split-K slabs (matrix layout, P x ld each)
+hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
+                                int64_t split_stride, int64_t P, int64_t ld, double *apk);
+// prior precision into the packed tiles (with_matrix) and into gvec = [J^T f ; chi2]
+hipError_t launch_add_prior(hipStream_t st, double *apk, int64_t P, const double *prec, int32_t dense,
+                            const double *pmean, const double *p, double *tvec, double *gvec,
+                            int32_t with_matrix);
+hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int32_t dense,
+                             const double *pmean, const double *p, double *tvec, double *scalar);
+// M (P x ld, upper tiles) = A + mu diag(d^2); M[:, P] = g
+hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
+                               const double *diag, const double *g, double *Mout);
+hipError_t launch_packed_diag(hipStream_t st, const double *apk, int64_t P, double *out);
+hipError_t launch_unpack_sym(hipStream_t st, const double *apk, int64_t P, double *out, int64_t ld);
+hipError_t launch_symmetrize_from_upper(hipStream_t st, double *A, int64_t P, int64_t ld);
+hipError_t launch_set_identity(hipStream_t st, double *A, int64_t P, int64_t ld);
+hipError_t launch_copy_strided(hipStream_t st, const double *src, int64_t lds_, double *dst,
+                               int64_t ldd, int64_t rows, int64_t cols);
+
+inline int64_t packed_doubles(int64_t P) {
+  const int64_t T = (P + 127) / 128;
+  return T * (T + 1) / 2 * 128 * 128;
+}
+
+}  // namespace lsqamd

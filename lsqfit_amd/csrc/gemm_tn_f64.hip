@@ -1,0 +1,213 @@
+// fp64 MFMA GEMM in "TN" form for gfx950 (MI355X):
+//
+//     C[M x N] = alpha * sum_k X[k][m] * Y[k][n] + beta * C        (row-major)
+//
+// This one kernel carries every dense contraction of the LM step:
+//   J^T J            X = Y = J                       (replaces gsl_blas_dsyrk in GSL's
+//                                                     cholesky solver init, reached from
+//                                                     src/lsqfit/_gsl.pyx:677)
+//   whitening        X = W_b^T, Y = raw Jacobian     (replaces `dot`, _utilities.pyx:20-36,90-93)
+//   Cholesky panel   X = inv(U_kk), Y = row panel
+//   trailing update  X = Y = row panel, alpha = -1, beta = 1
+//   covariance       X = Y = U^-T                     (replaces gsl_multifit_nlinear_covar,
+//                                                     _gsl.pyx:704-706)
+//
+// Design (MI355X_MICROARCH / cdna_hip_programming guides):
+//   * v_mfma_f64_16x16x4_f64: A operand lane l = A[l&15][l>>4], B operand lane l =
+//     B[l>>4][l&15], C/D lane l reg r = C[(l>>4) + 4r][l&15].  With k-major
+//     operands both fragments are plain row reads of the staged tile -- no
+//     transpose anywhere, and global loads are full 1 KiB rows (coalesced).
+//   * 128x128 block tile, BK = 16, 256 threads = 4 waves in 2x2, each wave a
+//     64x64 sub-tile = 4x4 MFMA tiles (128 accumulator VGPRs): 16 MFMAs (1024
+//     matrix-pipe cycles) per 8 ds_read_b64.
+//   * LDS rows padded 128 -> 144 doubles so the four k-rows a wave reads in one
+//     ds_read_b64 fall in different bank halves (stride 288 dwords = 32 mod 64).
+//   * two LDS stages (73.7 KB) -> 2 blocks / CU; global loads for stage t+1 are
+//     issued before the MFMAs of stage t and written to LDS after them.
+//   * split-K over rows (the long dimension, N_data) into per-split slabs summed
+//     by a second pass: deterministic, and gives >> 256 workgroups.
+#include "common.h"
+
+namespace lsqamd {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDT = BM + 16;                       // padded LDS row (doubles)
+constexpr int STAGE = 2 * BK * LDT;                // X tile + Y tile per stage (doubles)
+constexpr size_t GEMM_LDS_BYTES = 2 * STAGE * sizeof(double);
+
+struct GemmDev {
+  const double *X, *Y;
+  double *C;
+  int64_t M, N, K, ldx, ldy, ldc;
+  double alpha, beta;
+  int64_t sx, sy, sc;
+  int32_t tiles_n, upper_only, x_upper_tri, xy_lower_tri, splits;
+  int32_t vec_x, vec_y;  // operand rows are 16-byte aligned -> dwordx4 loads
+  int64_t kchunk, split_stride;
+};
+
+__device__ __forceinline__ v2d load2(const double *base, int64_t row, int64_t rows_end, int64_t ld,
+                                     int64_t col, int64_t cols_end, int vec) {
+  v2d v = {0.0, 0.0};
+  if (row < rows_end && col < cols_end) {
+    const double *p = base + row * ld + col;
+    if (vec) {
+      v = *reinterpret_cast<const v2d *>(p);
+      if (col + 1 >= cols_end) v.y = 0.0;
+    } else {
+      v.x = p[0];
+      if (col + 1 < cols_end) v.y = p[1];
+    }
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x % g.tiles_n;
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  if (g.upper_only && n0 + BN <= m0) return;  // tile strictly below the diagonal
+
+  const int64_t b = blockIdx.z;
+  const double *X = g.X + b * g.sx;
+  const double *Y = g.Y + b * g.sy;
+  double *C = g.C + b * g.sc + (int64_t)blockIdx.y * g.split_stride;
+
+  int64_t kb = (int64_t)blockIdx.y * g.kchunk;
+  int64_t ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
+  if (g.x_upper_tri) {  // X[k][m] = 0 for k > m
+    const int64_t lim = m0 + BM;
+    if (ke > lim) ke = lim;
+  }
+  if (g.xy_lower_tri) {  // X[k][m] = 0 for m > k, same for Y
+    int64_t lo = m0 > n0 ? m0 : n0;
+    lo -= lo % BK;
+    if (kb < lo) kb = lo;
+  }
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  // staging map: thread -> (row group, 2 columns)
+  const int c2 = (tid & 63) * 2;
+  const int rg = tid >> 6;
+  v2d xr[4], yr[4];
+
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t row = k0 + rg + 4 * i;
+      xr[i] = load2(X, row, ke, g.ldx, m0 + c2, g.M, g.vec_x);
+      yr[i] = load2(Y, row, ke, g.ldy, n0 + c2, g.N, g.vec_y);
+    }
+  };
+  auto sstore = [&](int buf) {
+    double *Xs = smem + buf * STAGE;
+    double *Ys = Xs + BK * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = rg + 4 * i;
+      *reinterpret_cast<v2d *>(Xs + row * LDT + c2) = xr[i];
+      *reinterpret_cast<v2d *>(Ys + row * LDT + c2) = yr[i];
+    }
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  if (kb < ke) {
+    gload(kb);
+    sstore(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+    const bool more = k0 + BK < ke;
+    if (more) gload(k0 + BK);
+    const double *Xs = smem + cur * STAGE;
+    const double *Ys = Xs + BK * LDT;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDT + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: lane holds rows fq + 4r, column fr of each 16x16 sub-tile
+  const double alpha = g.alpha;
+  const double beta = g.splits > 1 ? 0.0 : g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = n0 + wn * 64 + j * 16 + fr;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 16 + fq + 4 * r;
+        if (row >= g.M) continue;
+        double *cp = C + row * g.ldc + col;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * *cp;
+        *cp = v;
+      }
+    }
+  }
+}
+
+static bool g_attr_set = false;
+
+hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (!g_attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    g_attr_set = true;
+  }
+  GemmDev g;
+  g.X = a.X; g.Y = a.Y; g.C = a.C;
+  g.M = a.M; g.N = a.N; g.K = a.K;
+  g.ldx = a.ldx; g.ldy = a.ldy; g.ldc = a.ldc;
+  g.alpha = a.alpha; g.beta = a.beta;
+  g.sx = a.sx; g.sy = a.sy; g.sc = a.sc;
+  g.vec_x = !((a.ldx & 1) || (reinterpret_cast<uintptr_t>(a.X) & 15) || (a.sx & 1));
+  g.vec_y = !((a.ldy & 1) || (reinterpret_cast<uintptr_t>(a.Y) & 15) || (a.sy & 1));
+  const int64_t tiles_m = (a.M + BM - 1) / BM;
+  const int64_t tiles_n = (a.N + BN - 1) / BN;
+  g.tiles_n = (int32_t)tiles_n;
+  g.upper_only = a.upper_only;
+  g.x_upper_tri = a.x_upper_tri;
+  g.xy_lower_tri = a.xy_lower_tri;
+  g.splits = a.splits < 1 ? 1 : a.splits;
+  int64_t kchunk = (a.K + g.splits - 1) / g.splits;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  if (kchunk < BK) kchunk = BK;
+  g.kchunk = kchunk;
+  g.split_stride = g.splits > 1 ? a.split_stride : 0;
+  dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
+  hipLaunchKernelGGL(gemm_tn_f64_kernel, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  return hipGetLastError();
+}
+
+}  // namespace lsqamd

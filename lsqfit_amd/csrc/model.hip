@@ -1,0 +1,242 @@
+// Residual and Jacobian assembly kernels (gfx950).
+//
+// Replace the two callbacks GSL re-enters Python through on every evaluation
+// (src/lsqfit/_gsl.pyx:727-740 `_c_f`, :742-760 `_c_df`) together with the body
+// of `chiv.__call__` (src/lsqfit/_utilities.pyx:65-94): delta = f(x;p) - mean,
+// times the 1x1 whitening weights.  The reference gets d f / d p by pushing
+// gvar.valder derivative vectors through the user's Python function; here each
+// row model carries its own forward-mode (dual-number) evaluation.
+//
+// Sum models (cosmix, multiexp): one wave64 per data row, lanes stride the K
+// terms, so the two Jacobian half-rows are written as contiguous 512-byte
+// segments per wave instruction; the parameter vector is staged once per
+// workgroup in LDS and reused for all of the workgroup's rows.  Rows that belong
+// to a correlated block are written unweighted into the raw buffer and whitened
+// afterwards by the TN GEMM (X = W_b^T).
+//
+// Tape model: one lane per data row runs an RPN program over (x_i, p) with dual
+// numbers of width P <= 16 -- the NIST StRD / examples-sized problems.
+#include "common.h"
+
+namespace lsqamd {
+
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+struct ModelDev {
+  int32_t model, n_x, n_tape;
+  int64_t n_data, n_param;
+  const double *x, *ymean, *wdiag, *p, *consts;
+  const uint8_t *in_block;
+  const int32_t *tape;
+  double *out_w;    // whitened destination (residual vector, or J rows)
+  double *out_raw;  // raw destination for rows inside correlated blocks
+  int64_t ld;
+  int32_t p_in_lds;
+};
+
+template <int MODEL, bool JAC>
+__global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
+  extern __shared__ __attribute__((aligned(16))) double sp[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t P = m.n_param, K = P / 2;
+  const double *pp = m.p;
+  if (m.p_in_lds) {
+    for (int64_t i = tid; i < P; i += 256) sp[i] = m.p[i];
+    __syncthreads();
+    pp = sp;
+  }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m.n_data; row += (int64_t)gridDim.x * 4) {
+    const double x = m.x[row * m.n_x];
+    const bool blk = m.in_block && m.in_block[row];
+    const double w = blk ? 1.0 : m.wdiag[row];
+    double *dst = blk ? m.out_raw : m.out_w;
+    double f = 0.0;
+    for (int64_t k = lane; k < K; k += 64) {
+      const double a = pp[k], q = pp[K + k];
+      double term, dq;
+      if (MODEL == LSQAMD_MODEL_COSMIX) {
+        double s, c;
+        sincos(q * x, &s, &c);
+        term = c;
+        dq = -a * x * s;
+      } else {
+        const double e = exp(-q * x);
+        term = e;
+        dq = -a * x * e;
+      }
+      f += a * term;
+      if (JAC) {
+        dst[row * m.ld + k] = w * term;
+        dst[row * m.ld + K + k] = w * dq;
+      }
+    }
+    f = wave_sum_all(f);
+    if (lane == 0) {
+      const double delta = f - m.ymean[row];
+      if (JAC)
+        dst[row * m.ld + P] = w * delta;
+      else
+        dst[row] = w * delta;
+    }
+  }
+}
+
+template <bool JAC>
+__global__ __launch_bounds__(256) void identity_model_kernel(ModelDev m) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= m.n_data) return;
+  const bool blk = m.in_block && m.in_block[row];
+  const double w = blk ? 1.0 : m.wdiag[row];
+  double *dst = blk ? m.out_raw : m.out_w;
+  const double delta = m.p[row] - m.ymean[row];
+  if (JAC) {
+    for (int64_t j = 0; j < m.n_param; ++j) dst[row * m.ld + j] = (j == row) ? w : 0.0;
+    dst[row * m.ld + m.n_param] = w * delta;
+  } else {
+    dst[row] = w * delta;
+  }
+}
+
+// RPN tape with forward-mode duals; one lane per row.
+template <bool JAC>
+__global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
+  constexpr int MP = LSQAMD_TAPE_MAX_PARAM, MS = LSQAMD_TAPE_MAX_STACK;
+  const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (row >= m.n_data) return;
+  const int P = (int)m.n_param;
+  double sv[MS];
+  double sd[JAC ? MS : 1][JAC ? MP : 1];
+  int sp = 0;
+  for (int t = 0; t < m.n_tape; ++t) {
+    const int32_t ins = m.tape[t];
+    const int op = ins & 0xff, arg = ins >> 8;
+    switch (op) {
+      case LSQAMD_OP_CONST:
+        sv[sp] = m.consts[arg];
+        if (JAC) for (int j = 0; j < P; ++j) sd[sp][j] = 0.0;
+        ++sp;
+        break;
+      case LSQAMD_OP_X:
+        sv[sp] = m.x[row * m.n_x + arg];
+        if (JAC) for (int j = 0; j < P; ++j) sd[sp][j] = 0.0;
+        ++sp;
+        break;
+      case LSQAMD_OP_P:
+        sv[sp] = m.p[arg];
+        if (JAC) for (int j = 0; j < P; ++j) sd[sp][j] = (j == arg) ? 1.0 : 0.0;
+        ++sp;
+        break;
+      case LSQAMD_OP_ADD:
+      case LSQAMD_OP_SUB:
+      case LSQAMD_OP_MUL:
+      case LSQAMD_OP_DIV:
+      case LSQAMD_OP_POW: {
+        const double b = sv[sp - 1], a = sv[sp - 2];
+        double v, da, db;  // d/da, d/db
+        if (op == LSQAMD_OP_ADD) { v = a + b; da = 1.0; db = 1.0; }
+        else if (op == LSQAMD_OP_SUB) { v = a - b; da = 1.0; db = -1.0; }
+        else if (op == LSQAMD_OP_MUL) { v = a * b; da = b; db = a; }
+        else if (op == LSQAMD_OP_DIV) { v = a / b; da = 1.0 / b; db = -v / b; }
+        else {
+          v = pow(a, b);
+          da = b * pow(a, b - 1.0);
+          db = (a > 0.0) ? v * log(a) : 0.0;
+        }
+        if (JAC) for (int j = 0; j < P; ++j) sd[sp - 2][j] = da * sd[sp - 2][j] + db * sd[sp - 1][j];
+        sv[sp - 2] = v;
+        --sp;
+        break;
+      }
+      default: {
+        const double a = sv[sp - 1];
+        double v, da;
+        switch (op) {
+          case LSQAMD_OP_NEG: v = -a; da = -1.0; break;
+          case LSQAMD_OP_EXP: v = exp(a); da = v; break;
+          case LSQAMD_OP_LOG: v = log(a); da = 1.0 / a; break;
+          case LSQAMD_OP_SIN: v = sin(a); da = cos(a); break;
+          case LSQAMD_OP_COS: v = cos(a); da = -sin(a); break;
+          case LSQAMD_OP_ATAN: v = atan(a); da = 1.0 / (1.0 + a * a); break;
+          case LSQAMD_OP_SQRT: v = sqrt(a); da = 0.5 / v; break;
+          case LSQAMD_OP_POWI: {
+            const int n = arg;  // sign-extended by the arithmetic shift
+            v = pow(a, (double)n);
+            da = (n == 0) ? 0.0 : n * pow(a, (double)(n - 1));
+            break;
+          }
+          default: v = a; da = 1.0; break;
+        }
+        if (JAC) for (int j = 0; j < P; ++j) sd[sp - 1][j] *= da;
+        sv[sp - 1] = v;
+        break;
+      }
+    }
+  }
+  const bool blk = m.in_block && m.in_block[row];
+  const double w = blk ? 1.0 : m.wdiag[row];
+  double *dst = blk ? m.out_raw : m.out_w;
+  const double delta = sv[0] - m.ymean[row];
+  if (JAC) {
+    for (int j = 0; j < P; ++j) dst[row * m.ld + j] = w * sd[0][j];
+    dst[row * m.ld + P] = w * delta;
+  } else {
+    dst[row] = w * delta;
+  }
+}
+
+template <bool JAC>
+static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w, double *out_raw,
+                               int64_t ld) {
+  if (a.n_data <= 0) return hipSuccess;
+  ModelDev m;
+  m.model = a.model; m.n_x = a.n_x; m.n_tape = a.n_tape;
+  m.n_data = a.n_data; m.n_param = a.n_param;
+  m.x = a.x; m.ymean = a.ymean; m.wdiag = a.wdiag; m.p = a.p; m.consts = a.consts;
+  m.in_block = a.in_block; m.tape = a.tape;
+  m.out_w = out_w; m.out_raw = out_raw; m.ld = ld;
+  m.p_in_lds = 0;
+  switch (a.model) {
+    case LSQAMD_MODEL_COSMIX:
+    case LSQAMD_MODEL_MULTIEXP: {
+      size_t lds = 0;
+      if ((size_t)a.n_param * sizeof(double) <= 48 * 1024) {
+        lds = (size_t)a.n_param * sizeof(double);
+        m.p_in_lds = 1;
+      }
+      int64_t blocks = (a.n_data + 3) / 4;
+      if (blocks > 4096) blocks = 4096;
+      if (a.model == LSQAMD_MODEL_COSMIX)
+        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_COSMIX, JAC>), dim3((unsigned)blocks),
+                           dim3(256), lds, st, m);
+      else
+        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_MULTIEXP, JAC>), dim3((unsigned)blocks),
+                           dim3(256), lds, st, m);
+      break;
+    }
+    case LSQAMD_MODEL_IDENTITY:
+      hipLaunchKernelGGL((identity_model_kernel<JAC>), dim3((unsigned)((a.n_data + 255) / 256)),
+                         dim3(256), 0, st, m);
+      break;
+    case LSQAMD_MODEL_TAPE:
+      hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64)), dim3(64),
+                         0, st, m);
+      break;
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_residual_ex(hipStream_t st, const ModelArgs &m, double *r_w, double *r_raw) {
+  return launch_model<false>(st, m, r_w, r_raw, 1);
+}
+hipError_t launch_jacobian_ex(hipStream_t st, const ModelArgs &m, double *J_w, double *J_raw,
+                              int64_t ld) {
+  return launch_model<true>(st, m, J_w, J_raw, ld);
+}
+
+}  // namespace lsqamd

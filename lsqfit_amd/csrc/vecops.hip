@@ -1,0 +1,354 @@
+// Streaming (HBM-bound) kernels of the LM step: J^T f, |f|^2, block whitening of
+// the residual vector, split-K slab reduction into the packed upper-triangular
+// tile format, prior terms, damped-matrix assembly.  All reductions are
+// two-stage and order-fixed (no floating-point atomics), so every rank of a
+// row-sharded fit computes bit-identical replicated quantities.
+//
+// Packed format "Apk": the 128x128 tiles (tm, tn), tn >= tm, of J^T J stored
+// back to back, tile index tm*T - tm(tm-1)/2 + (tn - tm), T = ceil(P/128),
+// followed (by the caller) by the vector [J^T f ; |f|^2].  It is the buffer
+// that is all-reduced between GPUs: 8*(T(T+1)/2*16384 + P + 1) bytes.
+#include "common.h"
+
+namespace lsqamd {
+
+constexpr int TB = 128;  // packed tile edge
+
+__device__ __forceinline__ double wsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__host__ __device__ inline int64_t packed_tile_index(int64_t tm, int64_t tn, int64_t T) {
+  return tm * T - tm * (tm - 1) / 2 + (tn - tm);
+}
+
+// ---- J^T f and |f|^2 in one pass over J ------------------------------------------------
+// stage 1: partial[rc][j] = sum_{i in row chunk rc} J[i][j] * J[i][rcol]
+__global__ __launch_bounds__(256) void colsum_dot_stage1(const double *J, int64_t nrows, int64_t ld,
+                                                         int64_t ncols, int64_t rcol,
+                                                         int64_t rows_per_chunk, double *partial) {
+  const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > nrows) r1 = nrows;
+  if (j >= ncols) return;
+  const bool two = j + 1 < ncols;
+  double a0 = 0.0, a1 = 0.0;
+  if ((ld & 1) == 0 && two) {
+    for (int64_t i = r0; i < r1; ++i) {
+      const double ri = J[i * ld + rcol];
+      const double2 v = *reinterpret_cast<const double2 *>(J + i * ld + j);
+      a0 += v.x * ri;
+      a1 += v.y * ri;
+    }
+  } else {
+    for (int64_t i = r0; i < r1; ++i) {
+      const double ri = J[i * ld + rcol];
+      a0 += J[i * ld + j] * ri;
+      if (two) a1 += J[i * ld + j + 1] * ri;
+    }
+  }
+  partial[(int64_t)blockIdx.y * ncols + j] = a0;
+  if (two) partial[(int64_t)blockIdx.y * ncols + j + 1] = a1;
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const double *partial, int64_t nchunks,
+                                                     int64_t ncols, double *out, int accumulate) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncols) return;
+  double a = 0.0;
+  for (int64_t c = 0; c < nchunks; ++c) a += partial[c * ncols + j];
+  out[j] = accumulate ? out[j] + a : a;
+}
+
+hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
+                             int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
+                             double *out) {
+  int64_t nchunks = npartial;
+  if (nchunks > nrows) nchunks = nrows > 0 ? nrows : 1;
+  const int64_t rpc = nrows > 0 ? (nrows + nchunks - 1) / nchunks : 1;
+  nchunks = nrows > 0 ? (nrows + rpc - 1) / rpc : 0;
+  if (nchunks > 0) {
+    dim3 grid((unsigned)((ncols + 511) / 512), (unsigned)nchunks);
+    hipLaunchKernelGGL(colsum_dot_stage1, grid, dim3(256), 0, st, J, nrows, ld, ncols, rcol, rpc,
+                       partial);
+  }
+  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, partial,
+                     nchunks, ncols, out, 0);
+  return hipGetLastError();
+}
+
+// ---- |r|^2 ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_stage1(const double *r, int64_t n, double *partial) {
+  __shared__ double part[4];
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = r[i];
+    a += v * v;
+  }
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void sum_stage2(const double *partial, int n, double *out) {
+  __shared__ double part[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) a += partial[i];
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = part[0] + part[1] + part[2] + part[3];
+}
+
+hipError_t launch_sumsq(hipStream_t st, const double *r, int64_t n, double *partial, double *out) {
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, st, r, n, partial);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(256), 0, st, partial, blocks, out);
+  return hipGetLastError();
+}
+
+// ---- whitening of the residual inside correlated blocks -----------------------------------
+__global__ __launch_bounds__(256) void block_whiten_vec_kernel(const double *wt, const int64_t *row0,
+                                                               const int64_t *bsize,
+                                                               const int64_t *woff,
+                                                               const double *delta, double *r_out) {
+  const int b = blockIdx.y;
+  const int64_t B = bsize[b], r0 = row0[b];
+  const double *W = wt + woff[b];
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= B) return;
+  double a = 0.0;
+  for (int64_t j = 0; j < B; ++j) a += W[j * B + m] * delta[r0 + j];
+  r_out[r0 + m] = a;
+}
+
+hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64_t *row0,
+                                   const int64_t *bsize, const int64_t *woff, int32_t n_blocks,
+                                   int64_t max_block, const double *delta, double *r_out) {
+  if (n_blocks <= 0) return hipSuccess;
+  dim3 grid((unsigned)((max_block + 255) / 256), (unsigned)n_blocks);
+  hipLaunchKernelGGL(block_whiten_vec_kernel, grid, dim3(256), 0, st, wt, row0, bsize, woff, delta,
+                     r_out);
+  return hipGetLastError();
+}
+
+// ---- split-K slabs -> packed upper tiles ---------------------------------------------------
+__global__ __launch_bounds__(256) void finalize_pack_kernel(const double *slabs, int32_t splits,
+                                                            int64_t split_stride, int64_t P,
+                                                            int64_t ld, int64_t T, double *apk) {
+  // blockIdx.x = packed tile index, blockIdx.y = 16-row strip inside the tile
+  int64_t t = blockIdx.x, tm = 0;
+  while (t >= T - tm) { t -= T - tm; ++tm; }
+  const int64_t tn = tm + t;
+  double *dst = apk + (int64_t)blockIdx.x * TB * TB;
+  const int c = threadIdx.x & 127;
+  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
+    const int r = blockIdx.y * 8 + rr;
+    const int64_t i = tm * TB + r, j = tn * TB + c;
+    double a = 0.0;
+    if (i < P && j < P)
+      for (int s = 0; s < splits; ++s) a += slabs[s * split_stride + i * ld + j];
+    dst[r * TB + c] = a;
+  }
+}
+
+hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
+                                int64_t split_stride, int64_t P, int64_t ld, double *apk) {
+  const int64_t T = (P + TB - 1) / TB;
+  dim3 grid((unsigned)(T * (T + 1) / 2), 16);
+  hipLaunchKernelGGL(finalize_pack_kernel, grid, dim3(256), 0, st, slabs, splits, split_stride, P, ld,
+                     T, apk);
+  return hipGetLastError();
+}
+
+// ---- prior: A += Lambda, g += Lambda (p - pbar), chi2 += (p-pbar)^T Lambda (p-pbar) ------------
+__global__ __launch_bounds__(256) void prior_matrix_kernel(double *apk, int64_t P, int64_t T,
+                                                           const double *prec, int dense) {
+  int64_t t = blockIdx.x, tm = 0;
+  while (t >= T - tm) { t -= T - tm; ++tm; }
+  const int64_t tn = tm + t;
+  if (!dense && tn != tm) return;
+  double *dst = apk + (int64_t)blockIdx.x * TB * TB;
+  const int c = threadIdx.x & 127;
+  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
+    const int r = blockIdx.y * 8 + rr;
+    const int64_t i = tm * TB + r, j = tn * TB + c;
+    if (i < P && j < P) {
+      if (dense) dst[r * TB + c] += prec[i * P + j];
+      else if (i == j) dst[r * TB + c] += prec[i];
+    }
+  }
+}
+
+// t[j] = (Lambda d)_j, d = p - pbar; one wave per row j
+__global__ __launch_bounds__(256) void prior_vec_kernel(int64_t P, const double *prec, int dense,
+                                                        const double *pmean, const double *p,
+                                                        double *tvec) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= P) return;
+  if (!dense) {
+    if (lane == 0) tvec[j] = prec[j] * (p[j] - pmean[j]);
+    return;
+  }
+  double a = 0.0;
+  for (int64_t k = lane; k < P; k += 64) a += prec[j * P + k] * (p[k] - pmean[k]);
+  a = wsum(a);
+  if (lane == 0) tvec[j] = a;
+}
+
+// g[j] += t[j]; g[P] += sum_j d_j t_j  (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void prior_apply_kernel(int64_t P, const double *pmean,
+                                                          const double *p, const double *tvec,
+                                                          double *gvec) {
+  __shared__ double part[4];
+  double a = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double t = tvec[j];
+    gvec[j] += t;
+    a += (p[j] - pmean[j]) * t;
+  }
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) gvec[P] += part[0] + part[1] + part[2] + part[3];
+}
+
+hipError_t launch_add_prior(hipStream_t st, double *apk, int64_t P, const double *prec, int32_t dense,
+                            const double *pmean, const double *p, double *tvec, double *gvec,
+                            int32_t with_matrix) {
+  const int64_t T = (P + TB - 1) / TB;
+  if (with_matrix) {
+    dim3 grid((unsigned)(T * (T + 1) / 2), 16);
+    hipLaunchKernelGGL(prior_matrix_kernel, grid, dim3(256), 0, st, apk, P, T, prec, dense);
+  }
+  hipLaunchKernelGGL(prior_vec_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, P, prec, dense,
+                     pmean, p, tvec);
+  hipLaunchKernelGGL(prior_apply_kernel, dim3(1), dim3(256), 0, st, P, pmean, p, tvec, gvec);
+  return hipGetLastError();
+}
+
+// scalar[0] += sum_j (p-pbar)_j t_j   (single workgroup, fixed order)
+__global__ __launch_bounds__(256) void prior_chi2_kernel(int64_t P, const double *pmean,
+                                                         const double *p, const double *tvec,
+                                                         double *scalar) {
+  __shared__ double part[4];
+  double a = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) a += (p[j] - pmean[j]) * tvec[j];
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) scalar[0] += part[0] + part[1] + part[2] + part[3];
+}
+
+hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int32_t dense,
+                             const double *pmean, const double *p, double *tvec, double *scalar) {
+  hipLaunchKernelGGL(prior_vec_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, P, prec, dense,
+                     pmean, p, tvec);
+  hipLaunchKernelGGL(prior_chi2_kernel, dim3(1), dim3(256), 0, st, P, pmean, p, tvec, scalar);
+  return hipGetLastError();
+}
+
+// ---- packed tiles -> dense working copies ------------------------------------------------------
+// M[i][j] = A[i][j] + mu d_i^2 [i==j] for the upper tiles; M[i][P] = g[i]
+__global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, int64_t P, int64_t T,
+                                                           int64_t ld, double mu, const double *diag,
+                                                           const double *g, double *M) {
+  int64_t t = blockIdx.x, tm = 0;
+  while (t >= T - tm) { t -= T - tm; ++tm; }
+  const int64_t tn = tm + t;
+  const double *src = apk + (int64_t)blockIdx.x * TB * TB;
+  const int c = threadIdx.x & 127;
+  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
+    const int r = blockIdx.y * 8 + rr;
+    const int64_t i = tm * TB + r, j = tn * TB + c;
+    if (i < P && j < P) {
+      double v = src[r * TB + c];
+      if (i == j) {
+        const double d = diag[i];
+        v += mu * d * d;
+      }
+      M[i * ld + j] = v;
+    }
+    if (tn == T - 1 && c == 0 && i < P && g) M[i * ld + P] = g[i];
+  }
+}
+
+hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
+                               const double *diag, const double *g, double *Mout) {
+  const int64_t T = (P + TB - 1) / TB;
+  dim3 grid((unsigned)(T * (T + 1) / 2), 16);
+  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void packed_diag_kernel(const double *apk, int64_t P, int64_t T,
+                                                          double *out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  const int64_t tm = j / TB, r = j % TB;
+  out[j] = apk[packed_tile_index(tm, tm, T) * TB * TB + r * TB + r];
+}
+
+hipError_t launch_packed_diag(hipStream_t st, const double *apk, int64_t P, double *out) {
+  const int64_t T = (P + TB - 1) / TB;
+  hipLaunchKernelGGL(packed_diag_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, apk, P,
+                     T, out);
+  return hipGetLastError();
+}
+
+// full symmetric P x P (ld) from the packed upper tiles
+__global__ __launch_bounds__(256) void unpack_sym_kernel(const double *apk, int64_t P, int64_t T,
+                                                         double *out, int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j >= P) return;
+  const int64_t a = i < j ? i : j, b = i < j ? j : i;  // a <= b : upper element (a, b)
+  const int64_t tm = a / TB, tn = b / TB;
+  out[i * ld + j] = apk[packed_tile_index(tm, tn, T) * TB * TB + (a % TB) * TB + (b % TB)];
+}
+
+hipError_t launch_unpack_sym(hipStream_t st, const double *apk, int64_t P, double *out, int64_t ld) {
+  const int64_t T = (P + TB - 1) / TB;
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)P);
+  hipLaunchKernelGGL(unpack_sym_kernel, grid, dim3(256), 0, st, apk, P, T, out, ld);
+  return hipGetLastError();
+}
+
+// A[j][i] = A[i][j] for j > i (dense, in place)
+__global__ __launch_bounds__(256) void symmetrize_kernel(double *A, int64_t P, int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j >= P || j >= i) return;
+  A[i * ld + j] = A[j * ld + i];
+}
+
+hipError_t launch_symmetrize_from_upper(hipStream_t st, double *A, int64_t P, int64_t ld) {
+  dim3 grid((unsigned)((P + 255) / 256), (unsigned)P);
+  hipLaunchKernelGGL(symmetrize_kernel, grid, dim3(256), 0, st, A, P, ld);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void copy_strided_kernel(const double *src, int64_t lds_,
+                                                           double *dst, int64_t ldd, int64_t rows,
+                                                           int64_t cols) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  for (int64_t i = blockIdx.y; i < rows; i += gridDim.y) dst[i * ldd + j] = src[i * lds_ + j];
+}
+
+hipError_t launch_copy_strided(hipStream_t st, const double *src, int64_t lds_, double *dst,
+                               int64_t ldd, int64_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  hipLaunchKernelGGL(copy_strided_kernel, grid, dim3(256), 0, st, src, lds_, dst, ldd, rows, cols);
+  return hipGetLastError();
+}
+
+}  // namespace lsqamd

@@ -1,0 +1,63 @@
+"""Row sharding across the GPUs of one node.
+
+chi2 is a sum over independent covariance blocks, so data rows shard with one
+exchange per Jacobian evaluation:  J^T J = sum_g J_g^T J_g (+ prior),
+J^T f = sum_g J_g^T f_g (+ prior), |f|^2 = sum_g |f_g|^2 (+ prior), plus one scalar
+per trial step.  One process per GPU; ``torch.distributed`` (backend "nccl" =
+RCCL over xGMI on the GPU box, "gloo" in the CPU tests) carries the sums.  The
+reference has no distributed path at all; this is new design.
+
+The exchange is the all-reduce hook of the C ABI (``lsqamd_reduce_fn``): the
+library hands the hook a device address inside the torch-owned workspace and the
+hook all-reduces a float64 view of exactly that region in place.
+"""
+import numpy as np
+
+
+def shard_rows(n_data, blocks, world):
+    """Contiguous row ranges [(a, b)] * world that never cut a covariance block.
+
+    blocks: iterable of (row0, size).  Balances rows greedily at block/row granularity."""
+    cuts = set(range(n_data + 1))
+    for r0, B in blocks:
+        for i in range(r0 + 1, r0 + B):
+            cuts.discard(i)
+    cuts = np.array(sorted(cuts))
+    bounds = [0]
+    for r in range(1, world):
+        target = n_data * r / world
+        k = int(np.argmin(np.abs(cuts - target)))
+        bounds.append(max(int(cuts[k]), bounds[-1]))
+    bounds.append(n_data)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def make_reduce_hook(view_fn, group=None, sync=None):
+    """-> hook(dev_ptr, count) summing a float64 region over ranks in place.
+
+    view_fn(dev_ptr, count) must return a torch float64 tensor aliasing that memory
+    (``DeviceProblem.view``).  ``sync()`` is called after the collective so the sums
+    are visible to work queued afterwards (CUDA: current-stream synchronize)."""
+    import torch.distributed as dist
+
+    def hook(dev_ptr, count):
+        t = view_fn(dev_ptr, count)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if sync is not None:
+            sync()
+    return hook
+
+
+def cuda_sync():
+    import torch
+    torch.cuda.current_stream().synchronize()
+
+
+def sharded_problem(model, x, whitening, rank, world, group=None):
+    """DeviceProblem for this rank's rows with the RCCL all-reduce hook installed."""
+    from .fitter import DeviceProblem
+    ranges = shard_rows(whitening.n_data, [(b['row0'], b['size']) for b in whitening.blocks], world)
+    pr = DeviceProblem(model, x, whitening, rows=ranges[rank], adds_prior=(rank == 0))
+    if world > 1:
+        pr.set_reduce(make_reduce_hook(pr.view, group=group, sync=cuda_sync))
+    return pr

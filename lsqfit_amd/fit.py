@@ -1,0 +1,120 @@
+"""``nonlinear_fit``: problem setup and result reduction around the fitter plugin.
+
+Host mirror of the numerical content of src/lsqfit/__init__.py:455-737 for the
+device path, without gvar objects: data and prior arrive as (mean, error)
+arrays, the fit function as a :class:`lsqfit_amd.Model`.
+
+  :539-561   whitening of concat(y, prior)         -> :class:`Whitening`
+  :562-565   default p0 (prior mean; mean + sdev/10 where the mean is 0, :1947-1948)
+  :574-575   nf = nchiv, dof = nf - P
+  :662-664   fit = FITTERS[fitter](p0, nf, chiv, tol=tol, maxit=maxit, **fitterargs)
+  :665-682   error, cov, chi2, Q, nit, tol, stopping_criterion, pmean, psdev
+  :709-725   logGBF = (-logdet(J^T J) - pdf.logdet - chi2 - dof log 2pi) / 2
+"""
+import time
+
+import numpy as np
+
+from .fitter import DeviceProblem, mi355x_lm
+from .whiten import Whitening
+
+FITTERS = {'mi355x_lm': mi355x_lm}
+DEFAULTS = dict(tol=1e-8, svdcut=1e-12, maxit=1000, fitter='mi355x_lm')   # __init__.py:100-107
+
+
+def gammaQ(a, x):
+    """Regularised upper incomplete gamma function (src/lsqfit/_scipy.py:16-18)."""
+    from scipy.special import gammaincc
+    return float(gammaincc(a, x))
+
+
+def default_p0(prior_mean, prior_sdev):
+    pm = np.asarray(prior_mean, float).reshape(-1)
+    ps = np.asarray(prior_sdev, float).reshape(-1)
+    return np.where(pm != 0.0, pm, pm + 0.1 * ps)
+
+
+class _Chiv:
+    """What the reference hands the plugin as ``f``: p -> whitened residual.  On this
+    path it only exists so the plugin call has the reference's shape."""
+
+    def __init__(self, problem):
+        self.problem = problem
+
+    def __call__(self, p):
+        self.problem.normal(p)
+        return self.problem.get_f_data()
+
+
+class nonlinear_fit(object):
+    """data = (x, ymean, yerr) with yerr an sdev vector, a covariance matrix, or
+    dict(sdev=..., blocks=[(row0, cov), ...]); prior = (mean, err) likewise;
+    model = :class:`lsqfit_amd.Model`."""
+
+    def __init__(self, data=None, model=None, prior=None, p0=None, svdcut=False, tol=None,
+                 maxit=None, udata=None, fitter=None, problem=None, **fitterargs):
+        if data is None and udata is None:
+            raise ValueError('neither data nor udata is specified')
+        if model is None:
+            raise ValueError('no fit function (model) specified')
+        if p0 is None and prior is None:
+            raise ValueError('neither p0 nor prior is specified')
+        if svdcut is False:
+            svdcut = DEFAULTS['svdcut']
+        tol = DEFAULTS['tol'] if tol is None else tol
+        maxit = DEFAULTS['maxit'] if maxit is None else maxit
+        self.fitter = DEFAULTS['fitter'] if fitter is None else fitter
+        if self.fitter not in FITTERS:
+            raise ValueError('unknown fitter: ' + str(self.fitter))
+        clock = time.perf_counter
+        t0 = clock()
+        uncorrelated = data is None
+        x, ymean, yerr = udata if uncorrelated else data
+        pm, perr = (None, None) if prior is None else prior
+        if problem is None:
+            wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, udata=uncorrelated)
+            problem = DeviceProblem(model, x, wh)
+        else:
+            wh = problem.wh
+        self.problem = problem
+        self.whitening = wh
+        self.svdcut = svdcut
+        self.svdn = wh.nmod
+        self.nblocks = wh.nblocks
+        self.model = model
+        if p0 is None:
+            p0 = default_p0(pm, wh.prior_sdev)
+        self.p0 = np.array(p0, float).reshape(-1)
+        nf = wh.nchiv
+        self.dof = nf - self.p0.size
+        self._chiv = _Chiv(problem)
+        t1 = clock()
+        fit = FITTERS[self.fitter](self.p0, nf, self._chiv, tol=tol, maxit=maxit, problem=problem,
+                                   **fitterargs)
+        self.fitter_results = fit
+        self.error = fit.error
+        self.cov = fit.cov
+        self.chi2 = fit.chi2                       # = sum(fit.f**2), computed on the device
+        self.Q = gammaQ(self.dof / 2., self.chi2 / 2.)
+        self.nit = fit.nit
+        self.tol = fit.tol
+        self.maxit = maxit
+        self.stopping_criterion = fit.stopping_criterion
+        self.description = fit.description
+        self.pmean = np.array(fit.x)
+        self.psdev = np.sqrt(np.diag(fit.cov))
+        if prior is None:
+            self.logGBF = None
+        else:
+            self.logGBF = 0.5 * (-fit.logdet_jtj - wh.logdet - self.chi2 - self.dof * np.log(2. * np.pi))
+        self.time = clock() - t0
+        self.time_setup = t1 - t0
+        self.time_fit = self.time - self.time_setup
+
+    @property
+    def residuals(self):
+        return self.fitter_results.f
+
+    @property
+    def J(self):
+        return self.fitter_results.J

@@ -1,0 +1,340 @@
+"""``mi355x_lm``: the fitter plugin (host mirror of ``lsqfit.gsl_multifit``).
+
+Same constructor contract as the reference's plugins
+(src/lsqfit/__init__.py:662-664):
+
+    fit = FITTERS[name](p0, nf, chiv, tol=tol, maxit=maxit, **fitterargs)
+
+and the same result attributes (``x cov f J nit tol stopping_criterion error
+description results``, read at :665-679).  The callable ``f`` the reference
+passes is ignored -- a device cannot call Python; the problem itself arrives
+through the ``problem=`` fitter argument (a :class:`DeviceProblem`), using the
+reference's own pass-through of unknown keyword arguments (:505-515).
+"""
+import ctypes as C
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .models import MODEL_IDENTITY, MODEL_TAPE, Model
+from .whiten import Whitening
+
+_SCALERS = dict(more=0, levenberg=1, marquardt=2)
+
+
+def _check(lib, h, rc, what):
+    if rc < 0:
+        msg = lib.lsqamd_last_error(h)
+        raise RuntimeError('lsqfit_amd: %s failed (%s): %s' % (
+            what, _lib.ERRORS.get(rc, rc), msg.decode() if msg else ''))
+    return rc
+
+
+def normalize_tol(tol):
+    """src/lsqfit/_gsl.pyx:594-603."""
+    shape = np.shape(tol)
+    if shape == ():
+        return (tol, 1e-10, 1e-10)
+    if shape == (1,):
+        return (tol[0], 1e-10, 1e-10)
+    if shape == (2,):
+        return (tol[0], tol[1], 1e-10)
+    if shape != (3,):
+        raise ValueError('tol must be number or a 1-, 2-, or 3-tuple')
+    return tuple(tol)
+
+
+class DeviceProblem:
+    """Model + data + whitening resident on one GPU (one C-ABI handle).
+
+    ``rows=(a, b)`` restricts the data rows to a shard (whole covariance blocks);
+    the prior stays replicated."""
+
+    def __init__(self, model, x, whitening, rows=None, device=None, reduce_hook=None,
+                 adds_prior=True):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('lsqfit_amd: no MI355X visible (torch.cuda.is_available() is False); '
+                               'the fitter has no CPU path')
+        self.lib = _lib.load()
+        self.model = model
+        self.wh = whitening
+        a, b = (0, whitening.n_data) if rows is None else rows
+        self.rows = (a, b)
+        N = b - a
+        P = model.n_param
+        if whitening.has_prior and whitening.prior_mean.size != P:
+            raise ValueError('prior has %d entries, model has %d parameters'
+                             % (whitening.prior_mean.size, P))
+        if model.kind == MODEL_IDENTITY and whitening.n_data != P:
+            raise ValueError('identity model needs len(y) == len(p)')
+        row0, size, modes, tri, wt = whitening.block_arrays((a, b))
+        cfg = _lib.Config(abi_version=_lib.ABI_VERSION, model=model.kind, n_data=N, n_param=P,
+                          n_x=model.n_x, has_prior=int(whitening.has_prior),
+                          prior_dense=int(whitening.prior_dense), n_blocks=len(size),
+                          max_block=int(size.max()) if len(size) else 0,
+                          sum_block_sq=int(np.sum(size * size)), want_jacobian_out=1, n_batch=1)
+        self.cfg = cfg
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        t0 = time.perf_counter()
+        nbytes = self.lib.lsqamd_workspace_bytes(C.byref(cfg))
+        if nbytes == 0:
+            raise ValueError('lsqfit_amd: unsupported problem shape/model')
+        self.workspace = torch.empty(nbytes + 512, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        self._ws_off = (-base) % 256
+        self.stream = torch.cuda.current_stream(self.device)
+        h = C.c_void_p()
+        rc = self.lib.lsqamd_create(C.byref(cfg), C.c_void_p(base + self._ws_off), nbytes,
+                                    C.c_void_p(self.stream.cuda_stream), C.byref(h))
+        if rc != 0:
+            raise RuntimeError('lsqfit_amd: lsqamd_create failed (%s)' % _lib.ERRORS.get(rc, rc))
+        self.h = h
+        self.N, self.P = N, P
+        lib = self.lib
+        if model.kind != MODEL_IDENTITY:
+            xa = np.ascontiguousarray(np.asarray(x, np.float64).reshape(whitening.n_data, model.n_x)[a:b])
+            _check(lib, h, lib.lsqamd_set_x(h, _lib.dptr(xa), N, model.n_x), 'set_x')
+        if model.kind == MODEL_TAPE:
+            code = np.ascontiguousarray(model.tape, np.int32)
+            consts = np.ascontiguousarray(model.consts, np.float64)
+            _check(lib, h, lib.lsqamd_set_tape(h, code.ctypes.data_as(C.POINTER(C.c_int32)), code.size,
+                                               _lib.dptr(consts), consts.size), 'set_tape')
+        ym = np.ascontiguousarray(whitening.ymean[a:b])
+        if model.kind == MODEL_IDENTITY:
+            # identity rows address p by GLOBAL row index: only unsharded use is supported
+            if (a, b) != (0, whitening.n_data):
+                raise ValueError('identity model cannot be row-sharded')
+        wd = np.ascontiguousarray(whitening.wdiag[a:b])
+        _check(lib, h, lib.lsqamd_set_data(
+            h, _lib.dptr(ym), _lib.dptr(wd), len(size),
+            row0.ctypes.data_as(C.POINTER(C.c_int64)), size.ctypes.data_as(C.POINTER(C.c_int64)),
+            modes.ctypes.data_as(C.POINTER(C.c_int64)), tri.ctypes.data_as(C.POINTER(C.c_int32)),
+            _lib.dptr(wt)), 'set_data')
+        if whitening.has_prior:
+            self.set_prior(whitening.prior_mean, whitening.prior_prec)
+        self._reduce_cb = None
+        if reduce_hook is not None:
+            self.set_reduce(reduce_hook)
+        lib.lsqamd_set_adds_prior(h, int(bool(adds_prior)))
+        self.t_setup = time.perf_counter() - t0
+
+    # -- knobs ------------------------------------------------------------------------
+    def set_prior(self, mean, prec):
+        mean = np.ascontiguousarray(mean, np.float64)
+        prec = np.ascontiguousarray(prec, np.float64)
+        _check(self.lib, self.h, self.lib.lsqamd_set_prior(self.h, _lib.dptr(mean), _lib.dptr(prec)), 'set_prior')
+
+    def set_reduce(self, hook):
+        """hook(dev_ptr:int, count:int) -> None sums count doubles over ranks in place."""
+        def cb(user, ptr, count):
+            try:
+                hook(int(ptr), int(count))
+                return 0
+            except Exception as e:      # never unwind through the C frames
+                self._reduce_error = e
+                return 1
+        self._reduce_error = None
+        self._reduce_cb = _lib.REDUCE_FN(cb)
+        _check(self.lib, self.h, self.lib.lsqamd_set_reduce(self.h, self._reduce_cb, None), 'set_reduce')
+
+    def view(self, dev_ptr, count):
+        """float64 torch view of a region of the workspace (what the reduce hook sums)."""
+        import torch
+        off = dev_ptr - self.workspace.data_ptr()
+        if off < 0 or off + 8 * count > self.workspace.numel():
+            raise ValueError('pointer outside the workspace')
+        return self.workspace[off:off + 8 * count].view(torch.float64)
+
+    def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0):
+        xtol, gtol, ftol = normalize_tol(tol)
+        if scaler not in _SCALERS:
+            raise ValueError('unkown scaler ' + str(scaler))
+        opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler],
+                           solver=0, reserved=0, factor_up=factor_up, factor_down=factor_down)
+        _check(self.lib, self.h, self.lib.lsqamd_set_options(self.h, C.byref(opt)), 'set_options')
+
+    def timing(self, on=True):
+        self.lib.lsqamd_timing_enable(self.h, int(on))
+
+    def timings(self):
+        out = {}
+        for i, name in enumerate(_lib.T_NAMES):
+            ms, cnt = C.c_double(), C.c_int64()
+            self.lib.lsqamd_timing_get(self.h, i, C.byref(ms), C.byref(cnt))
+            out[name] = (ms.value, cnt.value)
+        return out
+
+    def timing_reset(self):
+        self.lib.lsqamd_timing_reset(self.h)
+
+    # -- kernel-level calls -------------------------------------------------------------
+    def _raise_reduce(self):
+        e, self._reduce_error = getattr(self, '_reduce_error', None), None
+        if e is not None:
+            raise e
+
+    def chi2(self, p):
+        p = np.ascontiguousarray(p, np.float64)
+        out = C.c_double()
+        rc = self.lib.lsqamd_eval_residual(self.h, _lib.dptr(p), C.byref(out))
+        self._raise_reduce()
+        _check(self.lib, self.h, rc, 'eval_residual')
+        return out.value
+
+    def normal(self, p):
+        p = np.ascontiguousarray(p, np.float64)
+        out = C.c_double()
+        rc = self.lib.lsqamd_eval_normal(self.h, _lib.dptr(p), C.byref(out))
+        self._raise_reduce()
+        _check(self.lib, self.h, rc, 'eval_normal')
+        return out.value
+
+    def solve_damped(self, mu, diag):
+        diag = np.ascontiguousarray(diag, np.float64)
+        v = np.empty(self.P)
+        _check(self.lib, self.h, self.lib.lsqamd_solve_damped(self.h, float(mu), _lib.dptr(diag), _lib.dptr(v)),
+               'solve_damped')
+        return v
+
+    def _get(self, fn, n, shape=None):
+        out = np.empty(int(n))
+        _check(self.lib, self.h, fn(self.h, _lib.dptr(out), out.size), fn.__name__)
+        return out if shape is None else out.reshape(shape)
+
+    def get_x(self):
+        return self._get(self.lib.lsqamd_get_x, self.P)
+
+    def get_grad(self):
+        return self._get(self.lib.lsqamd_get_grad, self.P)
+
+    def get_jtj(self):
+        return self._get(self.lib.lsqamd_get_jtj, self.P * self.P, (self.P, self.P))
+
+    def get_cov(self):
+        return self._get(self.lib.lsqamd_get_cov, self.P * self.P, (self.P, self.P))
+
+    def nf_data(self):
+        nf = self.lib.lsqamd_nf(self.h)
+        return nf - (self.P if self.wh.has_prior else 0)
+
+    def get_f_data(self):
+        return self._get(self.lib.lsqamd_get_f, self.nf_data())
+
+    def get_J_data(self):
+        n = self.nf_data()
+        return self._get(self.lib.lsqamd_get_J, n * self.P, (n, self.P))
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.lsqamd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class mi355x_lm(object):
+    r"""MI355X fitter for nonlinear least-squares multidimensional fits.
+
+    Args mirror :class:`lsqfit.gsl_multifit` (src/lsqfit/_gsl.pyx:563-575):
+    ``x0, n, f, tol, maxit, alg, solver, scaler, factor_up, factor_down, avmax``
+    plus ``problem`` (a :class:`DeviceProblem`).  Attributes: ``x cov f J nit
+    tol stopping_criterion error description results`` (+ ``chi2``,
+    ``logdet_jtj``, ``summary``).  ``f`` and ``J`` are fetched from the device on
+    first access (J is n x P float64 -- 2.3 GB at the north-star shape).
+    """
+
+    def __init__(self, x0, n, f=None, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm', solver='cholesky',
+                 scaler='more', factor_up=3.0, factor_down=2.0, avmax=0.75, problem=None):
+        if problem is None:
+            raise ValueError("mi355x_lm needs problem=DeviceProblem(...): the fit function must be "
+                             "given as a device model, the Python callable cannot run on the GPU")
+        if alg != 'lm':
+            raise NotImplementedError("mi355x_lm implements alg='lm' (got %r)" % (alg,))
+        if solver != 'cholesky':
+            raise NotImplementedError("mi355x_lm solves the normal equations (solver='cholesky'); "
+                                      "got %r" % (solver,))
+        self.tol = normalize_tol(tol)
+        self.maxit = maxit
+        self.alg, self.solver, self.scaler = alg, solver, scaler
+        self.factor_up, self.factor_down, self.avmax = factor_up, factor_down, avmax
+        self.x0 = np.ascontiguousarray(x0, np.float64)
+        self.n = n
+        self.error = None
+        self.description = 'methods = {}/{}/{}'.format(alg, scaler, solver)
+        pr = self.problem = problem
+        if self.x0.size != pr.P:
+            raise ValueError('len(x0) = %d but the model has %d parameters' % (self.x0.size, pr.P))
+        nf_total = pr.wh.nchiv
+        if n is not None and int(n) != nf_total:
+            raise ValueError('n = %d but the whitened residual has %d entries' % (n, nf_total))
+        pr.set_options(self.tol, maxit, scaler, factor_up, factor_down)
+        lib = pr.lib
+        s = _lib.Summary()
+        rc = lib.lsqamd_run(pr.h, _lib.dptr(self.x0), C.byref(s))
+        pr._raise_reduce()
+        _check(lib, pr.h, rc, 'run')
+        self.summary = s
+        self.nit = s.nit
+        self.chi2 = s.chi2
+        self.logdet_jtj = s.logdet_jtj
+        self.stopping_criterion = s.stopping_criterion
+        # _gsl.pyx:686-687,:714-717
+        if s.status:
+            self.error = (s.status, {11: 'exceeded max number of iterations'}.get(s.status, 'error'))
+        if s.status == 11 and self.nit < maxit:
+            self.error = "gsl_multifit can't improve on starting value; may have converged already."
+        if s.info == 0 and self.error is None and maxit > 0:
+            self.error = "gsl_multifit didn't converge in {} iterations".format(maxit)
+        self.x = pr.get_x()
+        self.cov = pr.get_cov()
+        self.results = None
+        self._f = self._J = None
+
+    def _prior_rows(self):
+        return self.problem.wh.prior_rows(self.x)
+
+    @property
+    def f(self):
+        if self._f is None:
+            wh = self.problem.wh
+            fd = self.problem.get_f_data()
+            if not wh.has_prior:
+                self._f = fd
+            else:
+                nd1 = wh.n_data - sum(b['size'] for b in wh.blocks)
+                rows = wh.prior_rows(self.x)
+                if wh.prior_W[0] == 'diag':
+                    self._f = np.concatenate([fd[:nd1], rows[0], fd[nd1:]])
+                else:
+                    self._f = np.concatenate([fd[:nd1], rows[0], fd[nd1:]] + list(rows[2]))
+        return self._f
+
+    @property
+    def J(self):
+        if self._J is None:
+            wh = self.problem.wh
+            Jd = self.problem.get_J_data()
+            if not wh.has_prior:
+                self._J = Jd
+            else:
+                nd1 = wh.n_data - sum(b['size'] for b in wh.blocks)
+                rows = wh.prior_rows(self.x)
+                if wh.prior_W[0] == 'diag':
+                    self._J = np.vstack([Jd[:nd1], rows[1], Jd[nd1:]])
+                else:
+                    self._J = np.vstack([Jd[:nd1], rows[1], Jd[nd1:]] + list(rows[3]))
+        return self._J
+
+
+def register(lsqfit_module):
+    """``lsqfit.nonlinear_fit.FITTERS['mi355x_lm'] = mi355x_lm`` when lsqfit is importable
+    (src/lsqfit/__init__.py:110-126,:453)."""
+    lsqfit_module.nonlinear_fit.FITTERS['mi355x_lm'] = mi355x_lm
+    return 'mi355x_lm'

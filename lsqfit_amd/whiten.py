@@ -1,0 +1,261 @@
+"""Host-side whitening setup: the product's mirror of what ``nonlinear_fit``
+obtains from ``gvar.PDF`` (src/lsqfit/__init__.py:1892-1900, read back at
+:553-561,:574,:723 and src/lsqfit/_utilities.pyx:58-61).
+
+Runs once per fit on the host (in the reference it is host code too: gvar's
+block search + per-block eigen-decomposition).  It produces what the device
+path consumes through ``lsqamd_set_data`` / ``lsqamd_set_prior``:
+
+  * ``wdiag``   1/sdev for the 1x1 rows;
+  * per correlated data block the TRANSPOSED whitening matrix ``Wt`` with
+    ``W^T W = inv(C_block regulated)``.  When the svdcut floor touches no mode
+    (the usual case) ``W = inv(chol(C))`` -- triangular, so the device GEMM
+    skips half the work; otherwise the eigen form ``w_i = v_i^T D^-1/sqrt(lam_i)``
+    of doc/source/overview.rst:1546-1556 (floor) / :1595-1603 (drop) is used.
+    Any such W gives the same chi2, J^T J, J^T f, p, cov, logGBF; only the
+    rotation of ``fit.f`` / ``fit.J`` rows inside a block differs from gvar's;
+  * the prior precision ``inv(C_prior regulated)`` (diagonal or dense);
+  * ``logdet`` (= log det of the regulated covariance), ``nmod`` (svdn),
+    ``nblocks``, ``nchiv``.
+
+Blocks must be contiguous row ranges (true for every layout the benchmark and
+the reference's example fixtures use); data-prior cross-correlations are not
+supported on the device path and raise.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+
+def _regulate_block(cov, svdcut, force_eig=False):
+    """-> dict(Wt[B,B], modes, tri, logdet, nmod, cov_reg_diag)."""
+    cov = np.asarray(cov, float)
+    B = cov.shape[0]
+    sd = np.sqrt(np.diag(cov))
+    if not np.all(np.isfinite(sd)) or np.any(sd <= 0):
+        raise ValueError('covariance block has a non-positive variance')
+    corr = cov / np.outer(sd, sd)
+    cut = 0.0 if svdcut is None else float(svdcut)
+    touched = True
+    L = None
+    if not force_eig:
+        try:
+            L = sla.cholesky(corr, lower=True)
+        except sla.LinAlgError:
+            L = None
+        if L is not None:
+            if cut == 0.0:
+                touched = False
+            else:
+                lmax, lmin = _extreme_eigs(corr, L)
+                # generous margin: power-iteration estimates are good to a few percent
+                touched = not (lmin > 4.0 * abs(cut) * lmax)
+    if not touched:
+        Linv = sla.solve_triangular(L, np.eye(B), lower=True)
+        W = Linv / sd[None, :]                      # inv(chol(C)) = inv(L) D^-1
+        logdet = 2.0 * float(np.sum(np.log(np.diag(L)))) + 2.0 * float(np.sum(np.log(sd)))
+        return dict(Wt=np.ascontiguousarray(W.T), modes=B, tri=1, logdet=logdet, nmod=0,
+                    var_reg=sd ** 2)
+    lam, vec = np.linalg.eigh(corr)
+    keep = np.ones(B, bool)
+    lam_reg = lam.copy()
+    nmod = 0
+    if cut != 0.0:
+        lmin = abs(cut) * lam[-1]
+        low = lam < lmin
+        nmod = int(np.sum(low))
+        if cut > 0:
+            lam_reg[low] = lmin
+        else:
+            keep = ~low
+    if np.any(lam_reg[keep] <= 0):
+        raise ValueError('covariance block is not positive definite; use an svdcut')
+    lam_k, vec_k = lam_reg[keep], vec[:, keep]
+    W = (vec_k / np.sqrt(lam_k)).T / sd[None, :]
+    m = W.shape[0]
+    Wt = np.zeros((B, B))
+    Wt[:, :m] = W.T
+    logdet = float(np.sum(np.log(lam_k)) + 2.0 * np.sum(np.log(sd)))
+    var_reg = np.einsum('ik,k,ik->i', vec_k, lam_k, vec_k) * sd ** 2 if np.all(keep) else sd ** 2
+    return dict(Wt=Wt, modes=m, tri=0, logdet=logdet, nmod=nmod, var_reg=var_reg)
+
+
+def _extreme_eigs(corr, L, iters=40):
+    """(lambda_max, lambda_min) of an SPD matrix: exact for small blocks, power /
+    inverse-power iteration through its Cholesky factor for large ones."""
+    B = corr.shape[0]
+    if B <= 1536:
+        w = sla.eigvalsh(corr)
+        return float(w[-1]), float(w[0])
+    rng = np.random.default_rng(12345)
+    v = rng.standard_normal(B)
+    v /= np.linalg.norm(v)
+    lmax = 1.0
+    for _ in range(iters):
+        w = corr @ v
+        lmax = float(np.linalg.norm(w))
+        v = w / lmax
+    u = rng.standard_normal(B)
+    u /= np.linalg.norm(u)
+    inv_l = 1.0
+    for _ in range(iters):
+        w = sla.cho_solve((L, True), u)
+        inv_l = float(np.linalg.norm(w))
+        u = w / inv_l
+    return lmax, 1.0 / inv_l
+
+
+def _as_blocks(err, n):
+    """Normalise an error spec to (sdev[n], [(row0, cov_block), ...]).
+
+    err: sdev vector | dense cov (n x n, split at zero off-diagonal bands) |
+         dict(sdev=..., blocks=[(row0, cov), ...])."""
+    if isinstance(err, dict):
+        sd = np.array(err['sdev'], float).reshape(-1)
+        blocks = [(int(r0), np.asarray(c, float)) for r0, c in err.get('blocks', [])]
+        return sd, blocks
+    err = np.asarray(err, float)
+    if err.ndim <= 1:
+        return err.reshape(-1) * np.ones(n), []
+    if err.shape != (n, n):
+        raise ValueError('covariance must be %d x %d' % (n, n))
+    sd = np.sqrt(np.diag(err))
+    # connected components of the off-diagonal pattern must be contiguous ranges
+    nz = err != 0.0
+    reach = np.arange(n)
+    for i in range(n):
+        js = np.nonzero(nz[i])[0]
+        if js.size:
+            reach[i] = max(reach[i], js[-1])
+    blocks = []
+    i = 0
+    while i < n:
+        end = reach[i]
+        j = i
+        while j <= end:
+            end = max(end, reach[j])
+            j += 1
+        B = end - i + 1
+        if B > 1:
+            blk = err[i:end + 1, i:end + 1]
+            # a contiguous range that is not fully connected would be split by gvar;
+            # keeping it whole changes nothing numerically when svdcut touches no mode
+            blocks.append((i, blk))
+        i = end + 1
+    return sd, blocks
+
+
+class Whitening:
+    """Everything the device path needs to know about concat(y, prior)."""
+
+    def __init__(self, ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12, eps=None,
+                 udata=False):
+        if eps is not None:
+            raise NotImplementedError('eps regulation is not available on the device path')
+        self.svdcut = svdcut
+        self.eps = None
+        self.ymean = np.array(ymean, float).reshape(-1)
+        N = self.ymean.size
+        ysd, yblocks = _as_blocks(yerr, N)
+        if udata:
+            yblocks = []                      # __init__.py:1892-1893
+        self.logdet = 0.0
+        self.nmod = 0
+        self.nblocks = {}
+        self.wdiag = np.ones(N)
+        self.blocks = []                      # dicts: row0, size, modes, tri, Wt
+        in_block = np.zeros(N, bool)
+        for r0, cov in sorted(yblocks, key=lambda b: b[0]):
+            B = cov.shape[0]
+            reg = _regulate_block(cov, svdcut)
+            reg.update(row0=int(r0), size=int(B))
+            self.blocks.append(reg)
+            in_block[r0:r0 + B] = True
+            self.logdet += reg['logdet']
+            self.nmod += reg['nmod']
+            self.nblocks[B] = self.nblocks.get(B, 0) + 1
+        d = ~in_block
+        if np.any(ysd[d] <= 0) or not np.all(np.isfinite(ysd[d])):
+            raise ValueError('some input data have zero or non-finite standard deviations')
+        self.wdiag[d] = 1.0 / ysd[d]
+        self.logdet += 2.0 * float(np.sum(np.log(ysd[d])))
+        n1 = int(np.sum(d))
+        self.n_data = N
+        self.nchiv_data = n1 + sum(b['modes'] for b in self.blocks)
+        # ---- prior
+        self.has_prior = prior_mean is not None
+        self.prior_mean = None
+        self.prior_prec = None
+        self.prior_dense = False
+        self.prior_W = None                   # rows of the whitened prior residual (for fit.f / fit.J)
+        nprior = 0
+        if self.has_prior:
+            pm = np.array(prior_mean, float).reshape(-1)
+            P = pm.size
+            psd, pblocks = _as_blocks(prior_err, P)
+            self.prior_mean = pm
+            if not pblocks:
+                if np.any(psd <= 0):
+                    raise ValueError('some priors have zero standard deviations')
+                self.prior_prec = 1.0 / psd ** 2
+                self.prior_W = ('diag', 1.0 / psd)
+                self.logdet += 2.0 * float(np.sum(np.log(psd)))
+                n1 += P
+                nprior = P
+            else:
+                self.prior_dense = True
+                prec = np.zeros((P, P))
+                Wrows = []
+                pin = np.zeros(P, bool)
+                for r0, cov in sorted(pblocks, key=lambda b: b[0]):
+                    B = cov.shape[0]
+                    reg = _regulate_block(cov, svdcut)
+                    W = reg['Wt'].T[:reg['modes']]
+                    prec[r0:r0 + B, r0:r0 + B] = W.T @ W
+                    full = np.zeros((W.shape[0], P))
+                    full[:, r0:r0 + B] = W
+                    Wrows.append(full)
+                    pin[r0:r0 + B] = True
+                    self.logdet += reg['logdet']
+                    self.nmod += reg['nmod']
+                    self.nblocks[B] = self.nblocks.get(B, 0) + 1
+                    nprior += reg['modes']
+                dd = np.nonzero(~pin)[0]
+                prec[dd, dd] = 1.0 / psd[dd] ** 2
+                self.logdet += 2.0 * float(np.sum(np.log(psd[dd])))
+                diag_rows = np.zeros((dd.size, P))
+                diag_rows[np.arange(dd.size), dd] = 1.0 / psd[dd]
+                n1 += dd.size
+                nprior += dd.size
+                self.prior_prec = prec
+                self.prior_W = ('dense', diag_rows, Wrows)
+            self.prior_sdev = psd
+        if n1:
+            self.nblocks[1] = n1
+        self.nchiv = self.nchiv_data + nprior
+
+    # -- device-facing packing ------------------------------------------------------
+    def block_arrays(self, rows=None):
+        """(row0, size, modes, tri, wt_flat) for the blocks inside rows [a, b)
+        (row0 relative to a)."""
+        a, b = (0, self.n_data) if rows is None else rows
+        sel = [k for k in self.blocks if k['row0'] >= a and k['row0'] + k['size'] <= b]
+        for k in self.blocks:
+            inside = k['row0'] >= a and k['row0'] + k['size'] <= b
+            outside = k['row0'] + k['size'] <= a or k['row0'] >= b
+            if not (inside or outside):
+                raise ValueError('a shard boundary cuts through a covariance block')
+        row0 = np.array([k['row0'] - a for k in sel], np.int64)
+        size = np.array([k['size'] for k in sel], np.int64)
+        modes = np.array([k['modes'] for k in sel], np.int64)
+        tri = np.array([k['tri'] for k in sel], np.int32)
+        wt = (np.concatenate([k['Wt'].reshape(-1) for k in sel]) if sel else np.zeros(0))
+        return row0, size, modes, tri, np.ascontiguousarray(wt, np.float64)
+
+    def prior_rows(self, p):
+        """Whitened prior residual rows and their Jacobian, in the reference's order."""
+        d = np.asarray(p, float) - self.prior_mean
+        if self.prior_W[0] == 'diag':
+            w = self.prior_W[1]
+            return w * d, np.diag(w)
+        _, diag_rows, Wrows = self.prior_W
+        return diag_rows @ d, diag_rows, [W @ d for W in Wrows], Wrows

@@ -1,0 +1,118 @@
+"""-m gpu: the raw dense kernels through the C ABI against numpy (fp64, rtol 1e-12)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def env():
+    import torch
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    return torch, lib
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 130, 77), (5, 3, 9), (256, 384, 1000), (129, 257, 4),
+                                   (1, 1, 1), (300, 300, 3000)])
+def test_gemm_tn(env, M, N, K):
+    torch, lib = env
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    ldx, ldy, ldc = M + (M & 1) + 2, N + (N & 1) + 4, N + 3
+    X = rng.standard_normal((K, ldx))
+    Y = rng.standard_normal((K, ldy))
+    C0 = rng.standard_normal((M, ldc))
+    dX, dY, dC = dev(torch, X), dev(torch, Y), dev(torch, C0)
+    rc = lib.lsqamd_op_gemm_tn(None, M, N, K, 0.75, dX.data_ptr(), ldx, dY.data_ptr(), ldy, -0.5,
+                               dC.data_ptr(), ldc, 0, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = C0.copy()
+    want[:, :N] = 0.75 * X[:, :M].T @ Y[:, :N] - 0.5 * C0[:, :N]
+    got = dC.cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+
+
+def test_gemm_tn_unaligned_and_upper(env):
+    torch, lib = env
+    rng = np.random.default_rng(3)
+    M = N = 333
+    K = 517
+    ld = 335                      # odd leading dimension -> scalar load path
+    X = rng.standard_normal((K, ld))
+    dX = dev(torch, X)
+    dC = torch.full((M, N), np.nan, dtype=torch.float64, device='cuda')
+    rc = lib.lsqamd_op_gemm_tn(None, M, N, K, 1.0, dX.data_ptr(), ld, dX.data_ptr(), ld, 0.0,
+                               dC.data_ptr(), N, 1, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    got = dC.cpu().numpy()
+    want = X[:, :M].T @ X[:, :N]
+    iu = np.triu_indices(M)
+    np.testing.assert_allclose(got[iu], want[iu], rtol=1e-12, atol=1e-11)
+    # tiles strictly below the diagonal are never touched
+    assert np.all(np.isnan(got[128:, :128][128:, :]))
+
+
+def test_gemm_tn_triangular_x(env):
+    torch, lib = env
+    rng = np.random.default_rng(4)
+    B, N = 300, 70
+    Wt = np.triu(rng.standard_normal((B, B)))      # X[k][m] = 0 for k > m
+    Y = rng.standard_normal((B, N + 2))
+    dX, dY = dev(torch, Wt), dev(torch, Y)
+    dC = torch.zeros((B, N + 2), dtype=torch.float64, device='cuda')
+    rc = lib.lsqamd_op_gemm_tn(None, B, N, B, 1.0, dX.data_ptr(), B, dY.data_ptr(), N + 2, 0.0,
+                               dC.data_ptr(), N + 2, 0, 1)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dC.cpu().numpy()[:, :N], Wt.T @ Y[:, :N], rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize('n', [1, 7, 128, 129, 300, 520])
+def test_potrf_upper_with_rhs_column(env, n):
+    torch, lib = env
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n + 20, n))
+    A = G.T @ G + 0.1 * np.eye(n)
+    b = rng.standard_normal(n)
+    lda = n + 1 + ((n + 1) & 1)
+    Ab = np.zeros((n, lda))
+    Ab[:, :n] = np.triu(A)              # only the upper triangle is read
+    Ab[:, n] = b
+    dA = dev(torch, Ab)
+    wbytes = lib.lsqamd_op_potrf_work_bytes(n)
+    work = torch.empty(wbytes // 8 + 8, dtype=torch.float64, device='cuda')
+    info = torch.zeros(4, dtype=torch.int32, device='cuda')
+    rc = lib.lsqamd_op_potrf_upper(None, dA.data_ptr(), n, lda, n + 1, work.data_ptr(), wbytes, info.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(info[0]) == 0
+    out = dA.cpu().numpy()
+    U = np.triu(out[:, :n])
+    np.testing.assert_allclose(U.T @ U, A, rtol=1e-11, atol=1e-11 * np.abs(A).max())
+    Uref = np.linalg.cholesky(A).T
+    np.testing.assert_allclose(U, Uref, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(out[:, n], np.linalg.solve(Uref.T, b), rtol=1e-9, atol=1e-10)
+
+
+def test_potrf_flags_indefinite(env):
+    torch, lib = env
+    n = 200
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((n, n))
+    A = G + G.T                       # indefinite
+    dA = dev(torch, np.triu(A))
+    wbytes = lib.lsqamd_op_potrf_work_bytes(n)
+    work = torch.empty(wbytes // 8 + 8, dtype=torch.float64, device='cuda')
+    info = torch.zeros(4, dtype=torch.int32, device='cuda')
+    rc = lib.lsqamd_op_potrf_upper(None, dA.data_ptr(), n, n, n, work.data_ptr(), wbytes, info.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(info[0]) > 0

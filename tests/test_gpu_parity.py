@@ -1,0 +1,238 @@
+"""-m gpu: the HIP path through the C ABI against the CPU oracle.
+
+Tolerance: 1e-6 relative on parameters, chi2/dof and covariance (BASELINE.json
+north_star); the kernel-level checks are held to 1e-10 since only the summation
+order differs."""
+import numpy as np
+import pytest
+
+from oracle import gvar_lite
+from oracle import fit as ofit
+from tests import gpu_util as gu
+from tests.helpers import load, nist_problem
+
+pytestmark = pytest.mark.gpu
+
+NIST = load('nist.json')
+KAT = load('kat.json')
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+CASES = {
+    'diag': dict(N=300, P=16, seed=11, block=0, prior_corr=False),
+    'blocks': dict(N=512, P=32, seed=12, block=64, prior_corr=True),
+    'ragged': dict(N=333, P=10, seed=13, block=100, prior_corr=True),
+    'oneblock': dict(N=200, P=8, seed=14, block=200, prior_corr=False),
+    'wide': dict(N=700, P=300, seed=15, block=0, prior_corr=True),
+}
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_normal_equations_match_oracle(amd, case):
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(**CASES[case])
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    p = d['p0'] + 0.01 * np.random.default_rng(1).standard_normal(d['p0'].size)
+    chi2 = pr.normal(p)
+    c0, A0, g0, f0, J0 = gu.oracle_normal(d, p)
+    assert chi2 == pytest.approx(c0, rel=1e-10)
+    assert gu.relmax(pr.get_jtj(), A0) < 1e-10
+    assert gu.relmax(pr.get_grad(), g0) < 1e-10
+    assert pr.chi2(p) == pytest.approx(c0, rel=1e-10)
+    # whitened residual / Jacobian rows: identical for 1x1 rows, same invariants for blocks
+    fd, Jd = pr.get_f_data(), pr.get_J_data()
+    nprior = d['p0'].size
+    assert fd.size + nprior == wh.nchiv == f0.size
+    assert float(fd @ fd) + float(f0[-0:0].sum()) == pytest.approx(chi2 - prior_chi2(wh, p), rel=1e-9)
+    A_data = Jd.T @ Jd
+    assert gu.relmax(A_data + prior_prec(wh), A0) < 1e-10
+    pr.close()
+
+
+def prior_prec(wh):
+    return wh.prior_prec if wh.prior_dense else np.diag(wh.prior_prec)
+
+
+def prior_chi2(wh, p):
+    dlt = p - wh.prior_mean
+    return float(dlt @ prior_prec(wh) @ dlt)
+
+
+def test_solve_damped_matches_numpy(amd):
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=600, P=260, seed=21, block=0, prior_corr=True)
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    pr.normal(d['p0'])
+    A, g = pr.get_jtj(), pr.get_grad()
+    diag = np.sqrt(np.diag(A))
+    for mu in (0.0, 1e-3, 10.0):
+        v = pr.solve_damped(mu, diag)
+        want = np.linalg.solve(A + mu * np.diag(diag ** 2), g)
+        assert gu.relmax(v, want) < 1e-9
+    cov = pr.get_cov()
+    assert gu.relmax(cov, np.linalg.inv(A)) < 1e-8
+    pr.close()
+
+
+@pytest.mark.parametrize('case', sorted(CASES))
+def test_fit_matches_oracle(amd, case):
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(**CASES[case])
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    ref = gu.oracle_fit(d, solver='cholesky')
+    assert fit.dof == ref.dof
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert fit.chi2 / fit.dof == pytest.approx(ref.chi2 / ref.dof, rel=1e-6)
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    assert fit.Q == pytest.approx(ref.Q, rel=1e-6, abs=1e-12)
+    assert fit.stopping_criterion == ref.stopping_criterion
+    assert abs(fit.nit - ref.nit) <= 1
+    assert fit.svdn == ref.svdn and fit.nblocks == ref.nblocks
+    # reference default solver (QR on J) converges to the same answer
+    ref_qr = gu.oracle_fit(d, solver='qr')
+    assert gu.relmax(fit.pmean, ref_qr.pmean) < 1e-6
+    # plugin attributes (src/lsqfit/__init__.py:665-679)
+    fr = fit.fitter_results
+    assert fr.f.shape == (fit.dof + fit.p0.size,)
+    assert float(fr.f @ fr.f) == pytest.approx(fit.chi2, rel=1e-9)
+    assert fr.J.shape == (fr.f.size, fit.p0.size)
+    assert gu.relmax(fr.J.T @ fr.J, np.linalg.inv(fit.cov)) < 1e-6
+    assert fr.description == 'methods = lm/more/cholesky' and fr.error is None
+
+
+@pytest.mark.parametrize('name', sorted(NIST))
+def test_nist_on_device(amd, name):
+    """All 27 NIST StRD problems through the device tape model vs certified values
+    and the oracle (examples/nist.py harness: priors 0 +- 200|b|, start 2, tol 1e-10)."""
+    pr = nist_problem(name, NIST)
+    model = amd.expr(pr['expr'], ['b%d' % (i + 1) for i in range(pr['P'])], pr['columns'][1:])
+    x = np.stack([pr['x'][c] for c in pr['columns'][1:]], axis=1)
+    fit = amd.nonlinear_fit(data=(x, pr['y'], pr['ysd']), model=model,
+                            prior=(pr['prior_mean'], pr['prior_sd']), p0=pr['p0'], tol=pr['tol'])
+    ref = ofit.nonlinear_fit(pr['x'], pr['y'], pr['ysd'], pr['fcn'], prior_mean=pr['prior_mean'],
+                             prior_err=pr['prior_sd'], p0=pr['p0'], tol=pr['tol'], solver='cholesky')
+    got = gvar_lite.fmt_array(fit.pmean, fit.psdev)
+    em, es = gvar_lite.parse_array(pr['expected_p'][1:-1].split())
+    if got != pr['expected_p']:
+        assert np.all(np.abs(fit.pmean - em) <= np.maximum(es, fit.psdev) / 10.), (got, pr['expected_p'])
+    assert np.all(np.abs(fit.pmean - pr['certified']) <= 1e-2 * pr['certified_sd'] + 1e-9 * np.abs(pr['certified']))
+    np.testing.assert_allclose(fit.psdev, pr['certified_sd'], rtol=2e-3)
+    assert fit.dof == pr['out']['dof']
+    assert '%.5g' % fit.logGBF == pr['out']['logGBF'], (fit.logGBF, pr['out']['logGBF'])
+    assert abs(fit.Q - float(pr['out']['Q'])) < 0.006
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-6)
+    assert np.all(np.abs(fit.pmean - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-3 * ref.psdev)
+    assert fit.stopping_criterion == 1
+
+
+def test_fitters_conformance_on_device(amd):
+    """tests/test_lsqfit.py:1811-1833 with the identity model."""
+    k = KAT['test_fitters']
+    ym, ys = gvar_lite.parse_array(k['data'])
+    pm, ps = gvar_lite.parse_array(k['prior'])
+    for scaler in ('more', 'levenberg', 'marquardt'):
+        fit = amd.nonlinear_fit(data=(None, ym, ys), model=amd.identity(2), prior=(pm, ps), scaler=scaler)
+        assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == k['expected_p']
+    w = 1 / ys ** 2 + 1 / ps ** 2
+    np.testing.assert_allclose(fit.cov, np.diag(1 / w), rtol=1e-10, atol=1e-18)
+
+
+def test_p_corr_example_on_device(amd):
+    """examples/p-corr.out: correlated 2x2 prior block (dense prior precision path)."""
+    k = KAT['p_corr']
+    ym, ys = gvar_lite.parse_array(k['y'])
+    pcov = np.eye(4)
+    pcov[1, 1] = 400. + 0.1 ** 2
+    pcov[0, 1] = pcov[1, 0] = 20.
+    model = amd.expr(k['expr'], ['b1', 'b2', 'b3', 'b4'])
+    fit = amd.nonlinear_fit(data=(np.array(k['x']), ym, ys), model=model, prior=(np.zeros(4), pcov))
+    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.149(17) 2.97(34) 1.23(61) 0.59(15)]'
+    assert '%.2g' % (fit.chi2 / fit.dof) == '0.61' and fit.dof == 11
+    assert '%.5g' % fit.logGBF == '19.129'
+    corr01 = fit.cov[0, 1] / np.sqrt(fit.cov[0, 0] * fit.cov[1, 1])
+    assert '%.4f' % corr01 == '0.9571'
+    assert fit.nblocks == {1: 13, 2: 1}
+
+
+def test_y_vs_x_example_on_device(amd):
+    """examples/y-vs-x.out nexp=2,3: dense 8x8 data covariance with one SVD-modified
+    mode (eigen-form whitening, non-triangular W) and the multiexp kernel."""
+    k = KAT['y_vs_x']
+    exp_p = {2: '[0.4024(40) 0.4471(46) 0.90104(51) 1.8282(14)]',
+             3: '[0.4019(40) 0.406(14) 0.61(36) 0.90039(54) 1.8026(82) 2.83(19)]'}
+    exp_gbf = {2: '111.69', 3: '116.29'}
+    for nexp in (2, 3):
+        pm = np.concatenate([np.full(nexp, 0.5), np.arange(1, nexp + 1.0)])
+        ps = np.full(2 * nexp, 0.4)
+        fit = amd.nonlinear_fit(data=(np.array(k['x']), np.array(k['ymean']), np.array(k['ycov'])),
+                                model=amd.multiexp(nexp), prior=(pm, ps))
+        assert fit.svdn == 1 and fit.nblocks[8] == 1 and fit.dof == 8
+        assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == exp_p[nexp]
+        assert '%.5g' % fit.logGBF == exp_gbf[nexp]
+
+
+def test_negative_svdcut_drops_modes(amd):
+    """tests/test_lsqfit.py:829-841: dof == 1, svdn == 1."""
+    k = KAT['svd_negative']
+    xm, xs = gvar_lite.parse(k['x'])
+    dm, ds = gvar_lite.parse(k['dx'])
+    A = np.array([[0.5, 0.5], [0.05, -0.05]])
+    ymean = A @ np.array([xm, dm])
+    ycov = A @ np.diag([xs ** 2, ds ** 2]) @ A.T
+    pm, ps = gvar_lite.parse_array(k['prior'])
+    fit = amd.nonlinear_fit(data=(None, ymean, ycov), model=amd.identity(2), prior=(pm, ps), svdcut=k['svdcut'])
+    ref = ofit.nonlinear_fit(False, ymean, ycov, lambda p: p, prior_mean=pm, prior_err=ps, svdcut=k['svdcut'])
+    assert fit.dof == 1 and fit.svdn == 1
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-8 and gu.relmax(fit.cov, ref.cov) < 1e-8
+
+
+def test_direct_plugin_double_root(amd):
+    """tests/test_lsqfit.py:1700-1715: f = (x-x*)^2 + (x-x*)^4, singular J^T J at the root,
+    must stop on xtol (stopping_criterion 1) with x ~ x* to 1e-3."""
+    model = amd.expr('(b1-x)**2 + (b1-x)**4', ['b1'])
+    # three independent 1-parameter problems share the driver logic; run the P=1 case
+    xans = np.array([2.0])
+    wh = amd.Whitening(np.zeros(1), np.ones(1))
+    pr = amd.DeviceProblem(model, xans, wh)
+    ans = amd.mi355x_lm(np.ones(1), 1, None, tol=(1e-10, 0.0, 0.0), problem=pr)
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 1
+
+
+def test_no_prior_and_errors(amd):
+    """prior=None -> logGBF None (src/lsqfit/__init__.py:711-712); bad input fails loudly."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=128, P=8, seed=31, block=0)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], p0=d['p0'])
+    assert fit.logGBF is None and fit.dof == 120
+    ref = ofit.nonlinear_fit(d['x'], d['ymean'], d['yerr'], gu.cosmix_fcn, p0=d['p0'], jac=gu.cosmix_jac,
+                             solver='cholesky')
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'])
+    with pytest.raises(NotImplementedError):
+        amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], p0=d['p0'], solver='qr')
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=amd.cosmix(5), p0=d['p0'])
+
+
+def test_maxit_reports_nonconvergence(amd):
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=256, P=16, seed=32, block=0)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], maxit=2,
+                            tol=1e-14)
+    ref = gu.oracle_fit(d, solver='cholesky', maxit=2, tol=1e-14)
+    assert fit.nit == ref.nit == 2
+    assert fit.stopping_criterion == ref.stopping_criterion == 0
+    assert fit.error == ref.error
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-8

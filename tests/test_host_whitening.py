@@ -1,0 +1,163 @@
+"""Host logic of the product (lsqfit_amd.whiten / models / dist) against the oracle.
+No GPU needed."""
+import numpy as np
+import pytest
+
+from lsqfit_amd import models, synth
+from lsqfit_amd.dist import shard_rows
+from lsqfit_amd.whiten import Whitening
+from oracle import fit as ofit
+from oracle.pdf import PDF
+from tests.helpers import load
+
+KAT = load('kat.json')
+
+
+def icov_from_whitening(wh):
+    N = wh.n_data
+    ic = np.zeros((N, N))
+    d = np.ones(N, bool)
+    for b in wh.blocks:
+        r0, B = b['row0'], b['size']
+        W = b['Wt'].T[:b['modes']]
+        ic[r0:r0 + B, r0:r0 + B] = W.T @ W
+        d[r0:r0 + B] = False
+    idx = np.nonzero(d)[0]
+    ic[idx, idx] = wh.wdiag[idx] ** 2
+    return ic
+
+
+@pytest.mark.parametrize('svdcut', [1e-12, 0.0, None, 1e-2, -1e-2])
+def test_whitening_matches_oracle_pdf(svdcut):
+    rng = np.random.default_rng(5)
+    N, P = 24, 6
+    cov = np.diag(rng.uniform(0.5, 2.0, N) ** 2)
+    # two correlated blocks: rows 3..8 (nearly singular) and 12..15
+    Q, _ = np.linalg.qr(rng.standard_normal((6, 6)))
+    c1 = (Q * np.array([3.0, 1.0, 0.5, 0.2, 1e-3, 2e-6])) @ Q.T      # cond ~ 1e6
+    cov[3:9, 3:9] = c1
+    B = rng.standard_normal((4, 4))
+    cov[12:16, 12:16] = B @ B.T + 0.1 * np.eye(4)
+    ymean = rng.standard_normal(N)
+    C = rng.standard_normal((P, P))
+    pcov = C @ C.T + 0.5 * np.eye(P)
+    pmean = rng.standard_normal(P)
+    wh = Whitening(ymean, cov, pmean, pcov, svdcut=svdcut)
+    pdf = ofit.build_pdf(ymean, cov, pmean, pcov, svdcut=svdcut)
+    assert wh.nchiv == pdf.nchiv
+    assert wh.nmod == pdf.nmod
+    assert wh.nblocks == pdf.nblocks
+    assert wh.logdet == pytest.approx(pdf.logdet, rel=1e-10, abs=1e-9)
+    full = pdf.icov()
+    np.testing.assert_allclose(icov_from_whitening(wh), full[:N, :N], rtol=1e-7, atol=1e-9 * np.abs(full).max())
+    np.testing.assert_allclose(wh.prior_prec, full[N:, N:], rtol=1e-7, atol=1e-9 * np.abs(full).max())
+    if svdcut in (1e-12, 0.0, None):
+        assert all(b['tri'] == 1 for b in wh.blocks)       # Cholesky route when nothing is touched
+        for b in wh.blocks:
+            assert np.allclose(np.tril(b['Wt'], -1), 0.0)
+
+
+def test_whitening_literal_weights():
+    """tests/test_lsqfit.py:955-962,:1024-1032 through the product's host code."""
+    k = KAT['unpack_case4']
+    y = np.array(k['y'], float)
+    p = np.array(k['prior'], float)
+    wh = Whitening(y[:, 0], y[:, 1], p[:, 0], p[:, 1], svdcut=0)
+    assert list(wh.wdiag) == k['wgts'][:2]
+    assert list(np.sqrt(wh.prior_prec)) == k['wgts'][2:]
+    assert wh.nchiv == 4 and wh.nmod == 0 and wh.nblocks == {1: 4}
+    assert wh.logdet == pytest.approx(np.log(np.prod(np.concatenate([y[:, 1], p[:, 1]]) ** 2)))
+
+
+def test_y_vs_x_whitening_one_mode_modified():
+    k = KAT['y_vs_x']
+    wh = Whitening(k['ymean'], np.array(k['ycov']), [0.5, 1.0], [0.4, 0.4], svdcut=1e-12)
+    assert wh.nmod == 1 and wh.nblocks == {8: 1, 1: 2}
+    assert wh.blocks[0]['tri'] == 0
+
+
+def test_udata_drops_correlations():
+    d = synth.make_cosmix(64, 8, 3, block=16)
+    wh = Whitening(d['ymean'], d['yerr'], *d['prior'], udata=True)
+    assert wh.blocks == [] and wh.nblocks == {1: 64 + 8}
+
+
+def test_tape_compiler_matches_numpy():
+    nist = load('nist.json')
+    rng = np.random.default_rng(0)
+    for name, d in nist.items():
+        P = d['nparam']
+        xn = [c for c in d['columns'][1:]]
+        m = models.expr(d['expr'], ['b%d' % (i + 1) for i in range(P)], xn)
+        assert m.kind == models.MODEL_TAPE and m.n_param == P and m.n_x == len(xn)
+        # run the tape on the host with a tiny interpreter and compare with python eval
+        data = np.array(d['data'], float)
+        p = np.array(d['start2'], float)
+        x = data[:, 1:]
+        ns = dict(exp=np.exp, log=np.log, sin=np.sin, cos=np.cos, arctan=np.arctan, sqrt=np.sqrt, pi=np.pi)
+        ns.update({c: x[:, i] for i, c in enumerate(xn)})
+        ns.update({'b%d' % (i + 1): p[i] for i in range(P)})
+        want = eval(d['expr'], {'__builtins__': {}}, ns)
+        got = run_tape(m, x, p)
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-300)
+
+
+def run_tape(m, x, p):
+    O = models.OP
+    st = []
+    for ins in m.tape:
+        op, arg = int(ins) & 0xff, int(ins) >> 8
+        if op == O['CONST']:
+            st.append(np.full(x.shape[0], m.consts[arg]))
+        elif op == O['X']:
+            st.append(x[:, arg].copy())
+        elif op == O['P']:
+            st.append(np.full(x.shape[0], p[arg]))
+        elif op in (O['ADD'], O['SUB'], O['MUL'], O['DIV'], O['POW']):
+            b = st.pop()
+            a = st.pop()
+            st.append({O['ADD']: a + b, O['SUB']: a - b, O['MUL']: a * b, O['DIV']: a / b,
+                       O['POW']: a ** b}[op])
+        elif op == O['POWI']:
+            st.append(st.pop() ** float(arg))
+        else:
+            a = st.pop()
+            st.append({O['NEG']: lambda v: -v, O['EXP']: np.exp, O['LOG']: np.log, O['SIN']: np.sin,
+                       O['COS']: np.cos, O['ATAN']: np.arctan, O['SQRT']: np.sqrt}[op](a))
+    assert len(st) == 1
+    return st[0]
+
+
+def test_shard_rows_respects_blocks():
+    blocks = [(r, 16) for r in range(0, 128, 16)]
+    for world in (1, 2, 3, 4, 8):
+        rs = shard_rows(128, blocks, world)
+        assert rs[0][0] == 0 and rs[-1][1] == 128
+        for (a, b), (c, d) in zip(rs[:-1], rs[1:]):
+            assert b == c
+        for a, b in rs:
+            assert a % 16 == 0 and b % 16 == 0
+    assert shard_rows(10, [], 4) == [(0, 2), (2, 5), (5, 7), (7, 10)]
+    # more ranks than blocks: trailing ranks get empty ranges, nothing is cut
+    rs = shard_rows(32, [(0, 32)], 4)
+    assert sum(b - a for a, b in rs) == 32 and all((a, b) in [(0, 0), (0, 32), (32, 32)] for a, b in rs)
+
+
+def test_synth_generator_is_fake_fitargs_like():
+    """src/lsqfit/_extras.py:2560-2589 recipe; acceptance chi2/dof < 6 (tests/test_lsqfit.py:1199-1200)."""
+    d = synth.make_cosmix(96, 8, 7, block=24)
+    assert np.all(d['yerr']['sdev'] > 0)
+    for r0, cov in d['yerr']['blocks']:
+        s = np.sqrt(np.diag(cov))
+        np.testing.assert_allclose(s, d['yerr']['sdev'][r0:r0 + 24])
+        corr = cov / np.outer(s, s)
+        assert np.all(corr > 0) and np.allclose(np.diag(corr), 1.0)
+    from oracle import dual
+    K = 4
+    fcn = lambda x, p: dual.stack_sum(p[k] * dual.cos(p[K + k] * x) for k in range(K))
+    cov = np.diag(d['yerr']['sdev'] ** 2)
+    for r0, c in d['yerr']['blocks']:
+        cov[r0:r0 + 24, r0:r0 + 24] = c
+    fit = ofit.nonlinear_fit(d['x'], d['ymean'], cov, fcn, prior_mean=d['prior'][0], prior_err=d['prior'][1])
+    assert fit.chi2 / fit.dof < 6
+    assert np.all(np.abs(fit.pmean - d['p_true']) < 6 * fit.psdev)
