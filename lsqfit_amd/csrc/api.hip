@@ -77,6 +77,7 @@ struct lsqamd_fit {
   std::vector<int64_t> h_row0, h_size, h_modes, h_woff;
   std::vector<int32_t> h_tri;
   bool uniform_blocks = false;
+  int32_t uniform_tri = 0;
   bool have_x = false, have_data = false, have_prior = false, have_tape = false;
 
   // reduce hook
@@ -287,7 +288,7 @@ int whiten_jacobian(lsqamd_fit *f) {
     g.C = f->J + f->h_row0[0] * f->ld; g.ldc = f->ld; g.sc = B * f->ld;
     g.M = B; g.N = ncols; g.K = B;
     g.batch = nb;
-    g.x_upper_tri = f->h_tri[0];
+    g.x_upper_tri = f->uniform_tri;
     HIPCHK(f, launch_gemm_tn(f->st, g));
     return 0;
   }
@@ -654,6 +655,7 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
   f->h_tri.assign(n_blocks, 0);
   f->h_woff.assign(n_blocks, 0);
   int64_t off = 0, prev_end = 0, maxb = 0;
+  bool all_tri = true;
   f->uniform_blocks = n_blocks > 0;
   for (int b = 0; b < n_blocks; ++b) {
     const int64_t r0 = f->h_row0[b], B = f->h_size[b];
@@ -665,9 +667,10 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
     f->h_woff[b] = off;
     off += B * B;
     for (int64_t i = 0; i < B; ++i) inb[(size_t)(r0 + i)] = 1;
-    if (B != f->h_size[0] || f->h_tri[b] != f->h_tri[0] || r0 != f->h_row0[0] + b * f->h_size[0])
-      f->uniform_blocks = false;
+    if (B != f->h_size[0] || r0 != f->h_row0[0] + b * f->h_size[0]) f->uniform_blocks = false;
+    if (!f->h_tri[b]) all_tri = false;
   }
+  f->uniform_tri = all_tri ? 1 : 0;  // mixed blocks run batched without the triangular shortcut
   if (off > f->cfg.sum_block_sq || maxb > f->cfg.max_block)
     FAIL(f, LSQAMD_EINVAL, "set_data: blocks exceed the sizes promised in the config");
   if (N > 0) {
@@ -973,6 +976,12 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
                              (size_t)P, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;
+}
+
+// introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor
+int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
+  if (!f) return -1;
+  return (int64_t)(f->uniform_blocks ? 1 : 0) | ((int64_t)f->splits << 8) | ((int64_t)f->h_size.size() << 32);
 }
 
 int lsqamd_timing_enable(lsqamd_fit *f, int32_t on) {

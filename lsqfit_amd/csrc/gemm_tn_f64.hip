@@ -49,22 +49,21 @@ struct GemmDev {
   int64_t kchunk, split_stride;
 };
 
-__device__ __forceinline__ v2d load2(const double *base, int64_t row, int64_t rows_end, int64_t ld,
-                                     int64_t col, int64_t cols_end, int vec) {
-  v2d v = {0.0, 0.0};
-  if (row < rows_end && col < cols_end) {
-    const double *p = base + row * ld + col;
-    if (vec) {
-      v = *reinterpret_cast<const v2d *>(p);
-      if (col + 1 >= cols_end) v.y = 0.0;
-    } else {
-      v.x = p[0];
-      if (col + 1 < cols_end) v.y = p[1];
-    }
-  }
+// Branch-free staging loads.  Out-of-range rows/columns are CLAMPED to a valid
+// address and zeroed when the registers are written to LDS, i.e. after the wait
+// the compiler places in front of the ds_write -- so the global loads of stage
+// t+1 stay in flight across the MFMAs of stage t (a mask applied at load time
+// forces an s_waitcnt vmcnt(0) right behind every load).
+template <bool VEC>
+__device__ __forceinline__ v2d load2(const double *rowptr, int64_t i0, int64_t i1) {
+  if (VEC) return *reinterpret_cast<const v2d *>(rowptr + i0);  // i0 even, i0 + 1 < ld
+  v2d v;
+  v.x = rowptr[i0];
+  v.y = rowptr[i1];
   return v;
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
@@ -97,34 +96,50 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-  // staging map: thread -> (row group, 2 columns)
+  // staging map: thread -> (row group, 2 columns); column validity is loop-invariant
   const int c2 = (tid & 63) * 2;
   const int rg = tid >> 6;
+  const int64_t xc = m0 + c2, yc = n0 + c2;
+  const bool x0ok = xc < g.M, x1ok = xc + 1 < g.M;
+  const bool y0ok = yc < g.N, y1ok = yc + 1 < g.N;
+  // always-readable indices: VEC -> aligned pair inside the (even) leading dimension,
+  // scalar -> each element clamped to the last valid column
+  const int64_t xi0 = VEC ? (xc < g.ldx - 2 ? xc : g.ldx - 2) : (xc < g.M ? xc : g.M - 1);
+  const int64_t xi1 = xc + 1 < g.M ? xc + 1 : g.M - 1;
+  const int64_t yi0 = VEC ? (yc < g.ldy - 2 ? yc : g.ldy - 2) : (yc < g.N ? yc : g.N - 1);
+  const int64_t yi1 = yc + 1 < g.N ? yc + 1 : g.N - 1;
   v2d xr[4], yr[4];
 
   auto gload = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t row = k0 + rg + 4 * i;
-      xr[i] = load2(X, row, ke, g.ldx, m0 + c2, g.M, g.vec_x);
-      yr[i] = load2(Y, row, ke, g.ldy, n0 + c2, g.N, g.vec_y);
+      int64_t row = k0 + rg + 4 * i;
+      row = row < ke ? row : ke - 1;
+      xr[i] = load2<VEC>(X + row * g.ldx, xi0, xi1);
+      yr[i] = load2<VEC>(Y + row * g.ldy, yi0, yi1);
     }
   };
-  auto sstore = [&](int buf) {
+  auto sstore = [&](int buf, int64_t k0) {
     double *Xs = smem + buf * STAGE;
     double *Ys = Xs + BK * LDT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = rg + 4 * i;
-      *reinterpret_cast<v2d *>(Xs + row * LDT + c2) = xr[i];
-      *reinterpret_cast<v2d *>(Ys + row * LDT + c2) = yr[i];
+      const bool rok = k0 + row < ke;
+      v2d xv, yv;
+      xv.x = (rok && x0ok) ? xr[i].x : 0.0;
+      xv.y = (rok && x1ok) ? xr[i].y : 0.0;
+      yv.x = (rok && y0ok) ? yr[i].x : 0.0;
+      yv.y = (rok && y1ok) ? yr[i].y : 0.0;
+      *reinterpret_cast<v2d *>(Xs + row * LDT + c2) = xv;
+      *reinterpret_cast<v2d *>(Ys + row * LDT + c2) = yv;
     }
   };
 
   const int fr = lane & 15, fq = lane >> 4;
   if (kb < ke) {
     gload(kb);
-    sstore(0);
+    sstore(0, kb);
   }
   __syncthreads();
   int cur = 0;
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
-    if (more) sstore(cur ^ 1);
+    if (more) sstore(cur ^ 1, k0 + BK);
     __syncthreads();
     cur ^= 1;
   }
@@ -179,9 +194,12 @@ static bool g_attr_set = false;
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (!g_attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     g_attr_set = true;
   }
@@ -206,7 +224,10 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.kchunk = kchunk;
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
-  hipLaunchKernelGGL(gemm_tn_f64_kernel, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  if (g.vec_x && g.vec_y)
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  else
+    hipLaunchKernelGGL(gemm_tn_f64_kernel<false>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   return hipGetLastError();
 }
 

@@ -21,8 +21,8 @@ def make_cosmix(N, P, seed, block=0, prior_corr=False, fsig=1e-3, dtype=np.float
     """-> dict(model, x, ymean, yerr, prior=(mean, err), p_true, p0).
 
     block = 0: uncorrelated data (C2); block = B: block-diagonal data covariance with
-    B x B blocks of the fake_fitargs recipe (C4); block = N: one dense block built from
-    a rectangular U (N x 2N) to keep it well conditioned (C3)."""
+    B x B blocks corr = normalize(U U^T), U ~ Uniform(0.1, 0.9)^{B x 2B} (C4); block = N:
+    one dense block of the same kind (C3)."""
     rng = np.random.Generator(np.random.PCG64(seed))
     K = P // 2
     x = np.arange(N) * (2 * np.pi / N)
@@ -38,7 +38,12 @@ def make_cosmix(N, P, seed, block=0, prior_corr=False, fsig=1e-3, dtype=np.float
         noise = np.empty(N)
         for r0 in range(0, N, block):
             B = min(block, N - r0)
-            U = rng.uniform(0.1, 0.9, (B, 2 * B if B == N and N > 1024 else B))
+            # rectangular U (B x 2B): same structure as the reference's square recipe
+            # (positive correlations, unit diagonal) but cond(corr) ~ 55 B instead of the
+            # 1e9..1e12 the square one gives at B = 256 (measured), which would put ~10 %
+            # of the blocks on the svdcut = 1e-12 threshold (SURVEY.md 8d makes the same
+            # substitution for C3)
+            U = rng.uniform(0.1, 0.9, (B, 2 * B))
             corr = U @ U.T
             d = 1.0 / np.sqrt(np.diag(corr))
             corr *= np.outer(d, d)
