@@ -48,6 +48,23 @@ def make_reduce_hook(view_fn, group=None, sync=None):
     return hook
 
 
+class WorkspaceView:
+    """pointer -> float64 view into ONE torch tensor that owns the memory (the handle's
+    workspace on the GPU; a CPU tensor in the gloo tests)."""
+
+    def __init__(self, tensor):
+        import torch
+        assert tensor.dtype == torch.uint8 and tensor.is_contiguous()
+        self.t = tensor
+
+    def __call__(self, ptr, count):
+        import torch
+        off = int(ptr) - self.t.data_ptr()
+        if off < 0 or off % 8 or off + 8 * count > self.t.numel():
+            raise ValueError('pointer outside the workspace')
+        return self.t[off:off + 8 * count].view(torch.float64)
+
+
 def cuda_sync():
     import torch
     torch.cuda.current_stream().synchronize()

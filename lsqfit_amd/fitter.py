@@ -142,11 +142,8 @@ class DeviceProblem:
 
     def view(self, dev_ptr, count):
         """float64 torch view of a region of the workspace (what the reduce hook sums)."""
-        import torch
-        off = dev_ptr - self.workspace.data_ptr()
-        if off < 0 or off + 8 * count > self.workspace.numel():
-            raise ValueError('pointer outside the workspace')
-        return self.workspace[off:off + 8 * count].view(torch.float64)
+        from .dist import WorkspaceView
+        return WorkspaceView(self.workspace)(dev_ptr, count)
 
     def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0):
         xtol, gtol, ftol = normalize_tol(tol)

@@ -1,0 +1,85 @@
+"""-m "not gpu": the C-ABI library builds for gfx950, loads, and exports every symbol
+include/lsqfit_amd.h declares (no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def libpath():
+    from lsqfit_amd import build
+    return build.build()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'lsqfit_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(lsqamd_[A-Za-z_0-9]+)\s*\(', text)) - {'lsqamd_reduce_fn'})
+
+
+def test_every_declared_symbol_is_exported(libpath):
+    so = ctypes.CDLL(libpath)
+    names = header_symbols()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(so, n)]
+    assert not missing, missing
+
+
+def test_binding_covers_the_header(libpath):
+    from lsqfit_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == header_symbols()
+    lib = _lib.load()
+    assert lib.lsqamd_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors of lsqamd_config / options / summary (sizes as compiled by gcc)."""
+    import subprocess
+    import tempfile
+    from lsqfit_amd import _lib
+    src = '#include <stdio.h>\n#include "lsqfit_amd.h"\nint main(){printf("%zu %zu %zu\\n", sizeof(lsqamd_config), sizeof(lsqamd_options), sizeof(lsqamd_summary));return 0;}\n'
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, 't.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(td, 't')
+        subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert sizes == [ctypes.sizeof(_lib.Config), ctypes.sizeof(_lib.Options), ctypes.sizeof(_lib.Summary)]
+
+
+def test_workspace_sizing_and_config_validation(libpath):
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.Config(abi_version=1, model=1, n_data=65536, n_param=4096, n_x=1, has_prior=1, prior_dense=1,
+                      n_blocks=256, max_block=256, sum_block_sq=256 * 256 * 256, want_jacobian_out=1, n_batch=1)
+    nbytes = lib.lsqamd_workspace_bytes(ctypes.byref(cfg))
+    assert 4e9 < nbytes < 12e9          # two Jacobian-sized buffers dominate (2 x 2.16 GB)
+    cfg.n_param = 4095                  # sum models need an even parameter count
+    assert lib.lsqamd_workspace_bytes(ctypes.byref(cfg)) == 0
+    cfg.n_param = 4096
+    cfg.abi_version = 99
+    assert lib.lsqamd_workspace_bytes(ctypes.byref(cfg)) == 0
+    h = ctypes.c_void_p()
+    cfg.abi_version = 1
+    assert lib.lsqamd_create(ctypes.byref(cfg), None, 0, None, ctypes.byref(h)) == -1   # EINVAL, no abort
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product refuses to fit (it must never route through the oracle)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import numpy as np
+    import lsqfit_amd
+    with pytest.raises(RuntimeError, match='no MI355X'):
+        lsqfit_amd.nonlinear_fit(data=(np.arange(4.), np.ones(4), np.ones(4)), model=lsqfit_amd.cosmix(1),
+                                 p0=np.ones(2))
+    import importlib
+    for name in ('fitter', 'fit', 'whiten', 'dist', 'models', 'synth', '_lib', 'build'):
+        mod = importlib.import_module('lsqfit_amd.' + name)
+        src = open(mod.__file__).read()
+        assert 'import oracle' not in src and 'from oracle' not in src, name

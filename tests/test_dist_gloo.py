@@ -1,0 +1,119 @@
+"""N > 1 path on CPU: world_size-2/3 gloo processes run the row-sharded fit with the
+product's shard plan and all-reduce hook; the per-shard arithmetic is the oracle's
+(the HIP kernels need a GPU).  Checks: sharded == unsharded, every rank identical."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lsqfit_amd import synth
+    from lsqfit_amd.dist import WorkspaceView, make_reduce_hook, shard_rows
+    from lsqfit_amd.whiten import Whitening
+    from oracle import lm as olm
+    from tests import gpu_util as gu
+
+    d = synth.make_cosmix(N=192, P=12, seed=77, block=32, prior_corr=True)
+    wh = Whitening(d['ymean'], d['yerr'], *d['prior'])
+    a, b = shard_rows(wh.n_data, [(k['row0'], k['size']) for k in wh.blocks], world)[rank]
+    P = d['p0'].size
+    # this rank's whitening rows (block-diagonal whitening restricted to its blocks)
+    W = np.zeros((b - a, b - a))
+    for k in wh.blocks:
+        if a <= k['row0'] < b:
+            r0 = k['row0'] - a
+            W[r0:r0 + k['size'], r0:r0 + k['size']] = k['Wt'].T
+    x, ym = d['x'][a:b], d['ymean'][a:b]
+    pm, prec = wh.prior_mean, wh.prior_prec
+    adds_prior = rank == 0                      # lsqamd_set_adds_prior convention
+
+    ws = torch.zeros(8 * (P * P + P + 1) + 64, dtype=torch.uint8)   # stands in for the device workspace
+    view = WorkspaceView(ws)
+    hook = make_reduce_hook(view, group=None, sync=None)
+    base = ws.data_ptr()
+
+    def normal_eq(p):
+        J = W @ gu.cosmix_jac(x, p)
+        r = W @ (gu.cosmix_fcn(x, p) - ym)
+        A, g, c2 = J.T @ J, J.T @ r, float(r @ r)
+        if adds_prior:
+            dp = p - pm
+            A, g, c2 = A + prec, g + prec @ dp, c2 + float(dp @ prec @ dp)
+        buf = view(base, P * P + P + 1)
+        buf[:P * P] = torch.from_numpy(A.reshape(-1))
+        buf[P * P:P * P + P] = torch.from_numpy(g)
+        buf[P * P + P] = c2
+        hook(base, P * P + P + 1)                # in-place sum over ranks
+        out = buf.numpy().copy()
+        return out[:P * P].reshape(P, P), out[P * P:P * P + P], float(out[-1])
+
+    def chi2_fn(p):
+        r = W @ (gu.cosmix_fcn(x, p) - ym)
+        c2 = float(r @ r)
+        if adds_prior:
+            dp = p - pm
+            c2 += float(dp @ prec @ dp)
+        buf = view(base, 1)
+        buf[0] = c2
+        hook(base, 1)
+        return float(buf[0])
+
+    res = olm.lm_normal(d['p0'], normal_eq, chi2_fn, tol=(1e-10, 1e-10, 1e-10))
+    np.savez(os.path.join(outdir, 'rank%d.npz' % rank), x=res.x, cov=res.cov, chi2=res.fnorm2, nit=res.nit,
+             rows=np.array([a, b]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_sharded_fit_equals_unsharded(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    outs = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
+    # every rank took identical decisions and holds identical results (replicated solve)
+    for o in outs[1:]:
+        assert np.array_equal(o['x'], outs[0]['x']) and np.array_equal(o['cov'], outs[0]['cov'])
+        assert int(o['nit']) == int(outs[0]['nit'])
+    rows = sorted(tuple(o['rows']) for o in outs)
+    assert rows[0][0] == 0 and rows[-1][1] == 192 and all(r[0] % 32 == 0 for r in rows)
+    # and they equal the unsharded oracle fit
+    sys.path.insert(0, ROOT)
+    from lsqfit_amd import synth
+    from tests import gpu_util as gu
+    d = synth.make_cosmix(N=192, P=12, seed=77, block=32, prior_corr=True)
+    ref = gu.oracle_fit(d, solver='cholesky', tol=(1e-10, 1e-10, 1e-10))
+    assert gu.relmax(outs[0]['x'], ref.pmean) < 1e-8
+    assert gu.relmax(outs[0]['cov'], ref.cov) < 1e-7
+    assert float(outs[0]['chi2']) == pytest.approx(ref.chi2, rel=1e-8)
+
+
+def test_reduce_hook_rejects_foreign_pointer():
+    import torch
+    from lsqfit_amd.dist import WorkspaceView
+    ws = torch.zeros(256, dtype=torch.uint8)
+    v = WorkspaceView(ws)
+    assert v(ws.data_ptr() + 16, 4).numel() == 4
+    with pytest.raises(ValueError):
+        v(ws.data_ptr() + 250, 4)
+    with pytest.raises(ValueError):
+        v(ws.data_ptr() - 8, 1)
