@@ -72,6 +72,8 @@ struct lsqamd_fit {
   int32_t *tape = nullptr;
   double *consts = nullptr;
   int32_t n_tape = 0;
+  int32_t *syrk_map = nullptr;
+  int32_t syrk_nwork = 0;
 
   // host mirrors of the block structure
   std::vector<int64_t> h_row0, h_size, h_modes, h_woff;
@@ -203,6 +205,8 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->info_dev = cv.take<int32_t>(16);
   f->tape = cv.take<int32_t>(1024);
   f->consts = cv.take<double>(256);
+  f->syrk_nwork = (int32_t)syrk_work_count(P, f->splits);
+  f->syrk_map = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);
   return cv.off;
 }
 
@@ -324,6 +328,8 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
     g.upper_only = 1;
     g.splits = f->splits;
     g.split_stride = P * f->ldm;
+    g.work_map = f->syrk_map;
+    g.n_work = f->syrk_nwork;
     if (f->N > 0) {
       HIPCHK(f, launch_gemm_tn(f->st, g));
     } else {
@@ -589,6 +595,15 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
     return LSQAMD_EHIP;
+  }
+  {
+    std::vector<int32_t> wm(4 * (size_t)f->syrk_nwork);
+    syrk_work_fill(f->P, f->splits, wm.data());
+    if (hipMemcpyAsync(f->syrk_map, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice, f->st) != hipSuccess ||
+        hipStreamSynchronize(f->st) != hipSuccess) {
+      delete f;
+      return LSQAMD_EHIP;
+    }
   }
   *out = f;
   return 0;

@@ -26,8 +26,12 @@ struct GemmTN {
   int32_t xy_lower_tri = 0;        // X[k][m] == 0 for m > k (and same for Y) -> k loop starts at the tile
   int32_t splits = 1;              // split-K: split s writes C + s*split_stride (beta ignored)
   int64_t split_stride = 0;
+  const int32_t *work_map = nullptr;  // device int4 list (tm, tn, split, 0), see syrk_work_fill
+  int32_t n_work = 0;
 };
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
+int64_t syrk_work_count(int64_t P, int32_t splits);
+void syrk_work_fill(int64_t P, int32_t splits, int32_t *out);
 
 // ---- Cholesky family (chol.hip) ---------------------------------------------------
 constexpr int CHOL_NB = 128;

@@ -47,6 +47,8 @@ struct GemmDev {
   int32_t tiles_n, upper_only, x_upper_tri, xy_lower_tri, splits;
   int32_t vec_x, vec_y;  // operand rows are 16-byte aligned -> dwordx4 loads
   int64_t kchunk, split_stride;
+  const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
+  int32_t n_work;
 };
 
 // Branch-free staging loads.  Out-of-range rows/columns are CLAMPED to a valid
@@ -69,16 +71,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x % g.tiles_n;
+  int tm, tn, split;
+  if (g.work_map) {
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only, never correctness).
+    // Give every XCD one contiguous run of the work list, whose neighbours share operand
+    // panels, so that the 64 workgroups resident on an XCD hit its private L2.
+    const int nw = g.n_work, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nw >> 3, r = nw & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
+    tm = e.x; tn = e.y; split = e.z;
+  } else {
+    tm = blockIdx.x / g.tiles_n;
+    tn = blockIdx.x % g.tiles_n;
+    split = blockIdx.y;
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   if (g.upper_only && n0 + BN <= m0) return;  // tile strictly below the diagonal
 
   const int64_t b = blockIdx.z;
   const double *X = g.X + b * g.sx;
   const double *Y = g.Y + b * g.sy;
-  double *C = g.C + b * g.sc + (int64_t)blockIdx.y * g.split_stride;
+  double *C = g.C + b * g.sc + (int64_t)split * g.split_stride;
 
-  int64_t kb = (int64_t)blockIdx.y * g.kchunk;
+  int64_t kb = (int64_t)split * g.kchunk;
   int64_t ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
   if (g.x_upper_tri) {  // X[k][m] = 0 for k > m
     const int64_t lim = m0 + BM;
@@ -223,12 +239,37 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (kchunk < BK) kchunk = BK;
   g.kchunk = kchunk;
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
+  g.work_map = a.work_map;
+  g.n_work = a.n_work;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
+  if (a.work_map) grid = dim3((unsigned)a.n_work, 1, 1);
   if (g.vec_x && g.vec_y)
     hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else
     hipLaunchKernelGGL(gemm_tn_f64_kernel<false>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   return hipGetLastError();
+}
+
+// Work list for the upper-triangular tiles of a P x P SYRK with `splits` K-chunks:
+// split-major, then 8 x 8 patches of tiles, then tiles of the patch.  Consecutive
+// entries share row/column panels AND the K-chunk.
+int64_t syrk_work_count(int64_t P, int32_t splits) {
+  const int64_t T = (P + BM - 1) / BM;
+  return T * (T + 1) / 2 * (splits < 1 ? 1 : splits);
+}
+
+void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
+  const int T = (int)((P + BM - 1) / BM), PS = 8;
+  const int NP = (T + PS - 1) / PS;
+  int64_t o = 0;
+  for (int s = 0; s < (splits < 1 ? 1 : splits); ++s)
+    for (int pi = 0; pi < NP; ++pi)
+      for (int pj = pi; pj < NP; ++pj)
+        for (int tm = pi * PS; tm < (pi + 1) * PS && tm < T; ++tm)
+          for (int tn = pj * PS; tn < (pj + 1) * PS && tn < T; ++tn) {
+            if (tn < tm) continue;
+            out[o++] = tm; out[o++] = tn; out[o++] = s; out[o++] = 0;
+          }
 }
 
 }  // namespace lsqamd
