@@ -224,6 +224,9 @@ int lsqamd_timing_reset(lsqamd_fit *fit);
 /* introspection for tests: bit 0 = batched (uniform-block) whitening in use,
  * bits 8..31 = split-K factor of the J^T J kernel, bits 32.. = block count */
 int64_t lsqamd_debug_flags(const lsqamd_fit *fit);
+/* developer builds (-DLSQAMD_POTF2_TIMING): device buffer of 32 int64 cycle stamps written by the
+ * diagonal-block Cholesky kernel; NULL (default) disables */
+void lsqamd_debug_set_potf2_stamps(void *dev_ptr);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,7 @@ PROTOTYPES = {
     'lsqamd_timing_get': (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(C.c_int64)]),
     'lsqamd_timing_reset': (C.c_int, [_vp]),
     'lsqamd_debug_flags': (C.c_int64, [_vp]),
+    'lsqamd_debug_set_potf2_stamps': (None, [_vp]),
 }
 
 _lib = None

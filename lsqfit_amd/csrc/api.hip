@@ -993,6 +993,8 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
   return 0;
 }
 
+void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long long *)dev_ptr; }
+
 // introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;

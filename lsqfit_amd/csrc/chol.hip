@@ -18,8 +18,12 @@
 namespace lsqamd {
 
 constexpr int NB = CHOL_NB;
-constexpr int PLD = NB;  // LDS leading dimension: every access pattern below walks rows
-constexpr int SB = 32;   // register-resident sub-block edge
+constexpr int PLD = NB + 2;  // LDS leading dimension: row walks AND 16-lane column walks
+                             // (MFMA A fragments) are both bank-conflict free at 260 dwords
+constexpr int SB = 32;       // register-resident sub-block edge
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
 
 size_t potrf_work_bytes(int64_t n) {
   const int64_t nblk = (n + NB - 1) / NB;
@@ -38,13 +42,15 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 // One workgroup (4 waves) factors a 128 x 128 block A = U^T U held in LDS and then inverts
 // U in place, in 32-wide sub-blocks so that the sequential pivot chain runs out of
 // registers inside a single wave (no workgroup barriers on the critical path):
-//   1a  wave 0: 32 x 32 Cholesky, one column per lane, pivots broadcast with v_readlane
+//   1a  wave 0: 32 x 32 Cholesky, one column per lane, pivots broadcast with v_readlane,
+//       1/sqrt by v_rsq_f64 + two Newton steps, branch-free (one basic block: the
+//       scheduler overlaps pivot j+1's rsqrt chain with pivot j's rank-1 update)
 //   1b  forward substitution of the 32-row panel, one column per thread
-//   1c  rank-32 update of the trailing block, 16 x 16 threads x (NA x NA) register tiles
+//   1c  rank-32 update of the trailing block on the matrix cores (fp64 MFMA from LDS)
 //   3a  the four 32 x 32 triangular inverses, one per wave, one column per lane
 //   3b/3c  off-diagonal blocks of the inverse by the 2 x 2 block formula
-//          inv([[a, b], [0, c]]) = [[a^-1, -a^-1 b c^-1], [0, c^-1]]  (two small matmuls,
-//          the dead strictly-lower triangle is the scratch for the intermediate product).
+//          inv([[a, b], [0, c]]) = [[a^-1, -a^-1 b c^-1], [0, c^-1]]  (MFMA products,
+//          the dead strictly-lower triangle is the scratch for the intermediate one).
 // Blocks smaller than 128 are padded with the identity.
 
 __device__ __forceinline__ void chol32_wave(double *s, int j0, double *dinv, int32_t *info, int k0,
@@ -53,90 +59,71 @@ __device__ __forceinline__ void chol32_wave(double *s, int j0, double *dinv, int
   double col[SB];
 #pragma unroll
   for (int i = 0; i < SB; ++i) col[i] = s[(j0 + i) * PLD + j0 + c];
+  int first_bad = -1;
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
     double d = readlane_d(col[j], j);
-    if (!(d > 0.0) || !(d < 1.0e300)) {  // wave-uniform: not positive definite / not finite
-      if (lane == 0) atomicCAS(info, 0, k0 + j0 + j + 1);
-      d = 1.0;
-    }
-    const double inv = 1.0 / sqrt(d);
-    const double u = (c >= j) ? col[j] * inv : 0.0;
+    const bool ok = (d > 0.0) && (d < 1.0e300);  // positive definite and finite
+    first_bad = (!ok && first_bad < 0) ? j : first_bad;
+    d = ok ? d : 1.0;
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    double e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-h * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    const double u = (c >= j) ? col[j] * y : 0.0;
     col[j] = u;
-    if (lane == 0) dinv[j0 + j] = inv;
+    if (lane == 0) dinv[j0 + j] = y;
 #pragma unroll
     for (int i = j + 1; i < SB; ++i) col[i] -= readlane_d(u, i) * u;
   }
+  if (first_bad >= 0 && lane == 0) atomicCAS(info, 0, k0 + j0 + first_bad + 1);
   if (lane < SB) {
 #pragma unroll
     for (int i = 0; i < SB; ++i) s[(j0 + i) * PLD + j0 + c] = (i <= c) ? col[i] : 0.0;
   }
 }
 
-// columns cc >= j0 + 32 of rows j0..j0+31: x <- U11^-T x
-// (`off` is threaded through an empty asm after every pivot so the LDS reads of row j+1
-// cannot be scheduled above the arithmetic of row j -- hoisting all 496 of them spills)
+// columns cc >= j0 + 32 of rows j0..j0+31: x <- U11^-T x.
+// Two address registers, each threaded through an empty asm after the arithmetic of
+// the row two back: the LDS reads run at most two rows ahead of the FMAs (hoisting all
+// 496 of them spills, serialising them exposes one LDS latency per row).
 __device__ __forceinline__ void panel32_solve(double *s, int j0, const double *dinv, int cc) {
   double x[SB];
 #pragma unroll
   for (int i = 0; i < SB; ++i) x[i] = s[(j0 + i) * PLD + cc];
-  int off = j0 * PLD + j0;
+  int off0 = j0 * PLD + j0, off1 = off0;
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
+    const int off = (j & 1) ? off1 : off0;
     x[j] *= dinv[j0 + j];
 #pragma unroll
     for (int i = j + 1; i < SB; ++i) x[i] -= s[off + j * PLD + i] * x[j];
-    if (j + 1 < SB) asm volatile("" : "+v"(off) : "v"(x[j + 1]));
+    if (j + 1 < SB) {
+      if (j & 1) asm volatile("" : "+v"(off1) : "v"(x[j + 1]));
+      else asm volatile("" : "+v"(off0) : "v"(x[j + 1]));
+    }
   }
 #pragma unroll
   for (int i = 0; i < SB; ++i) s[(j0 + i) * PLD + cc] = x[i];
-}
-
-// A22 -= U12^T U12 for the (16 NA) x (16 NA) trailing block starting at r0 = j0 + 32
-template <int NA>
-__device__ __forceinline__ void trailing32(double *s, int j0, int tid) {
-  const int r0 = j0 + SB, ty = tid >> 4, tx = tid & 15;
-  double acc[NA][NA];
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int b = 0; b < NA; ++b) acc[a][b] = 0.0;
-#pragma unroll 4
-  for (int k = 0; k < SB; ++k) {
-    const double *row = s + (j0 + k) * PLD + r0;
-    double ui[NA], uc[NA];
-#pragma unroll
-    for (int a = 0; a < NA; ++a) {
-      ui[a] = row[ty + 16 * a];
-      uc[a] = row[tx + 16 * a];
-    }
-#pragma unroll
-    for (int a = 0; a < NA; ++a)
-#pragma unroll
-      for (int b = 0; b < NA; ++b) acc[a][b] += ui[a] * uc[b];
-  }
-#pragma unroll
-  for (int a = 0; a < NA; ++a)
-#pragma unroll
-    for (int b = 0; b < NA; ++b) {
-      const int i = r0 + ty + 16 * a, c = r0 + tx + 16 * b;
-      if (c >= i) s[i * PLD + c] -= acc[a][b];
-    }
 }
 
 // in-place inverse of the upper-triangular 32 x 32 block at (j0, j0); one column per lane
 __device__ __forceinline__ void trinv32_wave(double *s, int j0, const double *dinv, int lane) {
   const int c = lane & 31;
   double v[SB];
-  int off = j0 * PLD + j0;
+  int off0 = j0 * PLD + j0, off1 = off0;
 #pragma unroll
   for (int i = SB - 1; i >= 0; --i) {
+    const int off = (i & 1) ? off1 : off0;
     double acc = 0.0;
 #pragma unroll
     for (int k = i + 1; k < SB; ++k) acc += s[off + i * PLD + k] * v[k];
     const double di = dinv[j0 + i];
     v[i] = (i < c) ? -di * acc : ((i == c) ? di : 0.0);
-    asm volatile("" : "+v"(off) : "v"(v[i]));  // serialise the rows' LDS reads (see panel32_solve)
+    if (i & 1) asm volatile("" : "+v"(off1) : "v"(v[i]));
+    else asm volatile("" : "+v"(off0) : "v"(v[i]));
   }
   // all lanes of the wave have finished reading the block before anyone overwrites it
   __builtin_amdgcn_wave_barrier();
@@ -146,106 +133,186 @@ __device__ __forceinline__ void trinv32_wave(double *s, int j0, const double *di
   }
 }
 
-// C[i][j] (+)= sign * sum_k L[i][k] R[k][j] for an n x n block triple inside s.
-// thread -> column j = tid % n, RPT consecutive rows; L rows broadcast, R rows contiguous.
-template <int N_, int RPT>
-__device__ __forceinline__ void small_matmul(const double *L, const double *R, double *Cout,
-                                             double sign, int tid) {
-  constexpr int GROUPS = N_ / RPT;
-  const int j = tid % N_, g = tid / N_;
-  if (g >= GROUPS) return;
-  double acc[RPT];
+// Small dense products on the matrix cores, operands and result in LDS (row-major, PLD):
+//   C[i][j] = (ACC ? C[i][j] : 0) + sign * sum_k A(i,k) * R[k][j]
+// with A(i,k) = L[k][i] when TA (k-major left operand) else L[i][k].  16 x 16 output tiles
+// are dealt round-robin to the 4 waves; `upper` skips tiles strictly below the diagonal;
+// `r_upper` / `l_upper` restrict k to the non-zero part of an upper-triangular R / L.
+template <bool TA, bool ACC>
+__device__ __forceinline__ void lds_mma(const double *L, const double *R, double *Cm, int mt, int nt,
+                                        int kdim, double sign, bool upper, bool r_upper,
+                                        bool l_upper, int wave, int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  int t = 0;
+  for (int ti = 0; ti < mt; ++ti)
+    for (int tj = (upper ? ti : 0); tj < nt; ++tj, ++t) {
+      if ((t & 3) != wave) continue;
+      const int i0 = ti * 16, j0 = tj * 16;
+      int klo = 0, khi = kdim;
+      if (r_upper && khi > j0 + 16) khi = j0 + 16;
+      if (l_upper && klo < i0) klo = i0;
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      for (int k = klo; k < khi; k += 4) {
+        const double a = TA ? L[(k + fq) * PLD + i0 + fr] : L[(i0 + fr) * PLD + k + fq];
+        const double b = R[(k + fq) * PLD + j0 + fr];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      }
 #pragma unroll
-  for (int r = 0; r < RPT; ++r) acc[r] = 0.0;
-#pragma unroll 4
-  for (int k = 0; k < N_; ++k) {
-    const double rk = R[k * PLD + j];
-#pragma unroll
-    for (int r = 0; r < RPT; ++r) acc[r] += L[(g * RPT + r) * PLD + k] * rk;
-  }
-#pragma unroll
-  for (int r = 0; r < RPT; ++r) Cout[(g * RPT + r) * PLD + j] = sign * acc[r];
+      for (int r = 0; r < 4; ++r) {
+        double *cp = Cm + (i0 + fq + 4 * r) * PLD + j0 + fr;
+        *cp = ACC ? *cp + sign * acc[r] : sign * acc[r];
+      }
+    }
 }
 
+#ifdef LSQAMD_POTF2_TIMING
+#define STAMP(i) do { if (tid == 0 && dbg) dbg[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, int nb, double *uinv,
-                                                        int32_t *info, int32_t k0) {
+                                                        int32_t *info, int32_t k0, long long *dbg) {
   extern __shared__ __attribute__((aligned(16))) double s[];
   double *dinv = s + NB * PLD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nsb = (nb + SB - 1) / SB;  // active 32-wide sub-blocks
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    double v = (i == j) ? 1.0 : 0.0;
-    if (i < nb && j < nb) v = (j >= i) ? A[(int64_t)i * lda + j] : 0.0;
-    s[i * PLD + j] = v;
+  // ---- load: thread -> 2 columns, 32 rows; clamped (always valid) addresses, masked after
+  {
+    const int c2 = (tid & 63) * 2, rg = tid >> 6;
+    const int cc0 = c2 < nb ? c2 : nb - 1, cc1 = c2 + 1 < nb ? c2 + 1 : nb - 1;
+    const int cv = c2 + 1 < nb ? c2 : (nb >= 2 ? (nb - 2) & ~1 : 0);
+#pragma unroll 8
+    for (int it = 0; it < 32; ++it) {
+      const int r = it * 4 + rg;
+      const int rc = r < nb ? r : nb - 1;
+      double x0, x1;
+      if (VEC && c2 + 1 < nb) {
+        const v2d v = *reinterpret_cast<const v2d *>(A + (int64_t)rc * lda + cv);
+        x0 = v.x; x1 = v.y;
+      } else {
+        x0 = A[(int64_t)rc * lda + cc0];
+        x1 = A[(int64_t)rc * lda + cc1];
+      }
+      const bool in0 = r < nb && c2 < nb, in1 = r < nb && c2 + 1 < nb;
+      x0 = in0 ? (c2 >= r ? x0 : 0.0) : (r == c2 ? 1.0 : 0.0);
+      x1 = in1 ? (c2 + 1 >= r ? x1 : 0.0) : (r == c2 + 1 ? 1.0 : 0.0);
+      *reinterpret_cast<v2d *>(s + r * PLD + c2) = (v2d){x0, x1};
+    }
   }
+  STAMP(0);
   __syncthreads();
+  STAMP(1);
   // ---- phase 1: Cholesky
   for (int jb = 0; jb < nsb; ++jb) {
     const int j0 = jb * SB;
     if (wave == 0) chol32_wave(s, j0, dinv, info, k0, lane);
     __syncthreads();
+    STAMP(2 + 3 * jb);
     const int rest = nsb * SB - (j0 + SB);
     if (rest > 0) {
       if (tid < rest) panel32_solve(s, j0, dinv, j0 + SB + tid);
       __syncthreads();
-      if (rest > 64) trailing32<6>(s, j0, tid);
-      else if (rest > 32) trailing32<4>(s, j0, tid);
-      else trailing32<2>(s, j0, tid);
+      STAMP(3 + 3 * jb);
+      // A22 -= U12^T U12 (upper tiles), U12 = rows j0..j0+31, columns from j0+32
+      const double *u12 = s + j0 * PLD + j0 + SB;
+      lds_mma<true, true>(u12, u12, s + (j0 + SB) * PLD + j0 + SB, rest / 16, rest / 16, SB, -1.0,
+                          true, false, false, wave, lane);
       __syncthreads();
+      STAMP(4 + 3 * jb);
     }
   }
+  STAMP(14);
   // U back to global (upper triangle of the block)
-  for (int idx = tid; idx < nb * NB; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    if (j >= i && j < nb) A[(int64_t)i * lda + j] = s[i * PLD + j];
+  {
+    const int c2 = (tid & 63) * 2, rg = tid >> 6;
+    for (int it = 0; it < 32; ++it) {
+      const int r = it * 4 + rg;
+      if (r >= nb || c2 + 1 < r || c2 >= nb) continue;
+      const v2d v = *reinterpret_cast<const v2d *>(s + r * PLD + c2);
+      if (VEC && c2 >= r && c2 + 1 < nb) {
+        *reinterpret_cast<v2d *>(A + (int64_t)r * lda + c2) = v;
+      } else {
+        if (c2 >= r) A[(int64_t)r * lda + c2] = v.x;
+        if (c2 + 1 < nb) A[(int64_t)r * lda + c2 + 1] = v.y;
+      }
+    }
   }
   __syncthreads();
+  STAMP(15);
   // ---- phase 3: inverse of U in place
   if (wave < nsb) trinv32_wave(s, wave * SB, dinv, lane);
   __syncthreads();
+  STAMP(16);
   if (nsb > 1) {
-    // level 1: the two 64-blocks; T = b c^-1 into the dead lower sub-block, then b' = -a^-1 T
-    const int half = tid >> 7, t = tid & 127;  // 128 threads per 64-block
-    const bool act = (half == 0) || (nsb > 3);  // the second 64-block has an off-diagonal only with 4 sub-blocks
-    const int q = half * 64;
-    if (act)
-      small_matmul<32, 8>(s + q * PLD + q + 32, s + (q + 32) * PLD + q + 32, s + (q + 32) * PLD + q, 1.0, t);
+    // level 1, both 64-blocks q = 0, 64: T = b c^-1 into the dead lower sub-block,
+    // then b' = -a^-1 T.  (The second 64-block has an off-diagonal only with 4 sub-blocks.)
+    const int nq = nsb > 3 ? 2 : 1;
+    for (int qi = 0; qi < nq; ++qi) {
+      const int q = qi * 64;
+      lds_mma<false, false>(s + q * PLD + q + 32, s + (q + 32) * PLD + q + 32, s + (q + 32) * PLD + q,
+                            2, 2, 32, 1.0, false, true, false, (wave + 2 * qi) & 3, lane);
+    }
     __syncthreads();
-    if (act)
-      small_matmul<32, 8>(s + q * PLD + q, s + (q + 32) * PLD + q, s + q * PLD + q + 32, -1.0, t);
+    for (int qi = 0; qi < nq; ++qi) {
+      const int q = qi * 64;
+      lds_mma<false, false>(s + q * PLD + q, s + (q + 32) * PLD + q, s + q * PLD + q + 32, 2, 2, 32,
+                            -1.0, false, false, true, (wave + 2 * qi) & 3, lane);
+    }
     __syncthreads();
     // the level-1 scratch sits inside the triangles level 2 multiplies with: clear it
-    if (act) {
-      for (int e = t; e < 32 * 32; e += 128) s[(q + 32 + (e >> 5)) * PLD + q + (e & 31)] = 0.0;
+    for (int e = tid; e < nq * 32 * 32; e += 256) {
+      const int q = (e >> 10) * 64, ee = e & 1023;
+      s[(q + 32 + (ee >> 5)) * PLD + q + (ee & 31)] = 0.0;
     }
     __syncthreads();
     if (nsb > 2) {
       // level 2: B = rows 0..63, cols 64..127; scratch = rows 64..127, cols 0..63
-      small_matmul<64, 16>(s + 64, s + 64 * PLD + 64, s + 64 * PLD, 1.0, tid);
+      lds_mma<false, false>(s + 64, s + 64 * PLD + 64, s + 64 * PLD, 4, 4, 64, 1.0, false, true, false,
+                            wave, lane);
       __syncthreads();
-      small_matmul<64, 16>(s, s + 64 * PLD, s + 64, -1.0, tid);
+      lds_mma<false, false>(s, s + 64 * PLD, s + 64, 4, 4, 64, -1.0, false, false, true, wave, lane);
       __syncthreads();
     }
   }
-  for (int idx = tid; idx < nb * NB; idx += 256) {
-    const int i = idx >> 7, j = idx & 127;
-    uinv[i * NB + j] = (j >= i && j < nb) ? s[i * PLD + j] : 0.0;
+  STAMP(17);
+  {
+    const int c2 = (tid & 63) * 2, rg = tid >> 6;
+    for (int it = 0; it < 32; ++it) {
+      const int r = it * 4 + rg;
+      if (r >= nb) continue;
+      v2d v = *reinterpret_cast<const v2d *>(s + r * PLD + c2);
+      v.x = (c2 >= r && c2 < nb) ? v.x : 0.0;
+      v.y = (c2 + 1 >= r && c2 + 1 < nb) ? v.y : 0.0;
+      *reinterpret_cast<v2d *>(uinv + r * NB + c2) = v;
+    }
   }
+  STAMP(18);
 }
 
 static bool g_potf2_attr = false;
+long long *g_potf2_dbg = nullptr;  // device buffer of 32 cycle stamps (LSQAMD_POTF2_TIMING builds)
 static constexpr size_t POTF2_LDS = (size_t)(NB * PLD + NB) * sizeof(double);  // 129 KiB
 
 static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, double *uinv,
                                int32_t *info, int32_t k0) {
   if (!g_potf2_attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
     if (e != hipSuccess) return e;
     g_potf2_attr = true;
   }
-  hipLaunchKernelGGL(potf2_inv_kernel, dim3(1), dim3(256), POTF2_LDS, st, A, lda, nb, uinv, info, k0);
+  const bool vec = !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15);
+  if (vec)
+    hipLaunchKernelGGL(potf2_inv_kernel<true>, dim3(1), dim3(256), POTF2_LDS, st, A, lda, nb, uinv, info,
+                       k0, g_potf2_dbg);
+  else
+    hipLaunchKernelGGL(potf2_inv_kernel<false>, dim3(1), dim3(256), POTF2_LDS, st, A, lda, nb, uinv, info,
+                       k0, g_potf2_dbg);
   return hipGetLastError();
 }
 

@@ -50,6 +50,7 @@ hipError_t trtri_upper_to_lower_T(hipStream_t st, const double *A, int64_t n, in
                                   const double *work, double *Wl, int64_t ldw);
 // sum_j log(A[j][j]) -> *dev_out (device double)
 hipError_t logdiag_sum(hipStream_t st, const double *A, int64_t n, int64_t lda, double *dev_out);
+extern long long *g_potf2_dbg;  // cycle stamps of the diagonal kernel (LSQAMD_POTF2_TIMING builds only)
 
 // ---- model kernels (model.hip) ----------------------------------------------------
 struct ModelArgs {

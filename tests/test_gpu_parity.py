@@ -251,3 +251,52 @@ def test_maxit_reports_nonconvergence(amd):
     assert fit.stopping_criterion == ref.stopping_criterion == 0
     assert fit.error == ref.error
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-8
+
+
+def test_reduce_hook_on_device_single_rank(amd):
+    """The all-reduce hook path (RCCL through torch.distributed on a float64 view of the
+    handle's workspace) with a one-rank group: identical results to the hook-free fit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from lsqfit_amd import synth
+    from lsqfit_amd.dist import cuda_sync, make_reduce_hook
+    d = synth.make_cosmix(N=512, P=32, seed=41, block=64, prior_corr=True)
+    ref = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+        pr = amd.DeviceProblem(d['model'], d['x'], wh)
+        calls = []
+        inner = make_reduce_hook(pr.view, sync=cuda_sync)
+
+        def hook(ptr, count):
+            calls.append(count)
+            inner(ptr, count)
+        pr.set_reduce(hook)
+        fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'],
+                                problem=pr)
+        assert np.array_equal(fit.pmean, ref.pmean) and np.array_equal(fit.cov, ref.cov)
+        assert fit.nit == ref.nit and fit.chi2 == ref.chi2
+        # one packed (J^T J | J^T f | chi2) exchange per Jacobian, one scalar per trial step
+        npk = 128 * 128 + 32 + 1
+        assert calls.count(npk) == fit.fitter_results.summary.njev
+        assert calls.count(1) == fit.fitter_results.summary.nfev - 1
+        # a failing hook surfaces as a Python exception, not a crash
+        def bad(ptr, count):
+            raise RuntimeError('boom')
+        pr.set_reduce(bad)
+        with pytest.raises(RuntimeError, match='boom'):
+            pr.normal(d['p0'])
+        pr.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
