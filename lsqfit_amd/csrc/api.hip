@@ -50,7 +50,7 @@ struct lsqamd_fit {
   hipStream_t st = nullptr;
   std::string err;
 
-  int64_t N = 0, P = 0, ld = 0, ldm = 0, npk = 0;
+  int64_t N = 0, P = 0, ld = 0, ldm = 0, npk = 0, ncols_aug = 0;
   int32_t splits = 1;
   int64_t npartial = 256;
 
@@ -168,7 +168,10 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->N = N;
   f->P = P;
   f->ld = rup(P + 1, 16);
-  f->ldm = rup(P + 1, 16);
+  // damped matrix [A | g | zero pad]: with P a multiple of 128 the pad makes every Cholesky
+  // panel / trailing GEMM full-tile, so they run the direct-to-LDS interior kernel
+  f->ldm = (P % 128 == 0) ? P + 128 : rup(P + 1, 16);
+  f->ncols_aug = (P % 128 == 0) ? P + 128 : P + 1;
   f->npk = packed_doubles(P);
   f->splits = choose_splits(N, P);
   f->npartial = 256;
@@ -293,6 +296,14 @@ int whiten_jacobian(lsqamd_fit *f) {
     g.M = B; g.N = ncols; g.K = B;
     g.batch = nb;
     g.x_upper_tri = f->uniform_tri;
+    if (f->P % 128 == 0 && B % 128 == 0) {
+      // full-tile bulk (interior kernel) + the residual column on its own
+      g.N = f->P;
+      HIPCHK(f, launch_gemm_tn(f->st, g));
+      g.Y += f->P; g.C += f->P; g.N = 1;
+      HIPCHK(f, launch_gemm_tn(f->st, g));
+      return 0;
+    }
     HIPCHK(f, launch_gemm_tn(f->st, g));
     return 0;
   }
@@ -373,7 +384,7 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
     Scope sc(f, LSQAMD_T_CHOLESKY);
     HIPCHK(f, hipMemcpyAsync(f->diag_dev, diag_host, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
     HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, f->diag_dev, gvec, f->M));
-    HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, P + 1, f->chol_work, f->info_dev));
+    HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev));
   }
   {
     Scope sc(f, LSQAMD_T_SOLVE);
@@ -593,6 +604,10 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.factor_up = 3.0;
   f->opt.factor_down = 2.0;
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
+    delete f;
+    return LSQAMD_EHIP;
+  }
+  if (hipMemsetAsync(f->M, 0, sizeof(double) * (size_t)(f->P * f->ldm), f->st) != hipSuccess) {
     delete f;
     return LSQAMD_EHIP;
   }

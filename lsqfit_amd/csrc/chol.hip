@@ -361,35 +361,51 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // Every workgroup recomputes v_k = inv(U_kk) y_k (128 x 128 GEMV, L2-resident) into
 // LDS; workgroup 0 publishes it; workgroups 1.. subtract U[r, k-block] . v_k from
-// their rows r < k0 of y.
+// their rows r < k0 of y.  All global loads of a phase are issued before the first
+// reduction, so a step costs about two memory round trips instead of ~40.
 __global__ __launch_bounds__(256) void backsolve_step_kernel(const double *A, int64_t lda, int64_t k0,
                                                              int nb, const double *uinv, double *y,
                                                              double *v) {
   __shared__ double vk[NB];
   __shared__ double yk[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < nb) yk[tid] = y[k0 + tid];
+  if (tid < NB) yk[tid] = tid < nb ? y[k0 + tid] : 0.0;
+  // rows wave*32 .. wave*32+31 of inv(U_kk): two coalesced 512-byte loads per row
+  double a0[32], a1[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int r = wave * 32 + i;
+    const bool ok = r < nb;
+    a0[i] = (ok && lane < nb) ? uinv[r * NB + lane] : 0.0;
+    a1[i] = (ok && lane + 64 < nb) ? uinv[r * NB + lane + 64] : 0.0;
+  }
   __syncthreads();
-  for (int r = wave; r < nb; r += 4) {
-    double acc = 0.0;
-    for (int c = r + lane; c < nb; c += 64) acc += uinv[r * NB + c] * yk[c];
-    acc = wave_sum(acc);
-    if (lane == 0) vk[r] = acc;
+  const double y0 = yk[lane], y1 = yk[lane + 64];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const double acc = wave_sum(a0[i] * y0 + a1[i] * y1);
+    if (lane == 0) vk[wave * 32 + i] = acc;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
     if (tid < nb) v[k0 + tid] = vk[tid];
     return;
   }
-  const int64_t r0 = (int64_t)(blockIdx.x - 1) * BS_ROWS;
-  for (int rr = wave; rr < BS_ROWS; rr += 4) {
-    const int64_t r = r0 + rr;
-    if (r >= k0) break;
-    const double *row = A + r * lda + k0;
-    double acc = 0.0;
-    for (int c = lane; c < nb; c += 64) acc += row[c] * vk[c];
-    acc = wave_sum(acc);
-    if (lane == 0) y[r] -= acc;
+  const int64_t r0 = (int64_t)(blockIdx.x - 1) * BS_ROWS + wave * (BS_ROWS / 4);
+  double u0[BS_ROWS / 4], u1[BS_ROWS / 4];
+#pragma unroll
+  for (int i = 0; i < BS_ROWS / 4; ++i) {
+    const int64_t r = r0 + i;
+    const bool ok = r < k0;
+    const double *row = A + (ok ? r : 0) * lda + k0;
+    u0[i] = (ok && lane < nb) ? row[lane] : 0.0;
+    u1[i] = (ok && lane + 64 < nb) ? row[lane + 64] : 0.0;
+  }
+  const double v0 = vk[lane], v1 = vk[lane + 64];
+#pragma unroll
+  for (int i = 0; i < BS_ROWS / 4; ++i) {
+    const double acc = wave_sum(u0[i] * v0 + u1[i] * v1);
+    if (lane == 0 && r0 + i < k0) y[r0 + i] -= acc;
   }
 }
 

@@ -28,6 +28,7 @@ struct GemmTN {
   int64_t split_stride = 0;
   const int32_t *work_map = nullptr;  // device int4 list (tm, tn, split, 0), see syrk_work_fill
   int32_t n_work = 0;
+  int32_t force_generic = 0;       // A/B switch: never take the direct-to-LDS interior kernel
 };
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
 int64_t syrk_work_count(int64_t P, int32_t splits);

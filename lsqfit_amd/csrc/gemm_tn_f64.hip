@@ -183,11 +183,25 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
     cur ^= 1;
   }
 
-  // epilogue: lane holds rows fq + 4r, column fr of each 16x16 sub-tile
+  // epilogue: lane holds rows fq + 4r, column fr of each 16x16 sub-tile.  With beta != 0
+  // the 16 C values of a sub-tile row are loaded together (one branch, loads in flight
+  // at once) -- a per-element "if (beta) load" costs one memory round trip per element.
   const double alpha = g.alpha;
   const double beta = g.splits > 1 ? 0.0 : g.beta;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    double cv[4][4];
+    if (beta != 0.0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t col = n0 + wn * 64 + j * 16 + fr;
+          const int64_t row = m0 + wm * 64 + i * 16 + fq + 4 * r;
+          const bool ok = col < g.N && row < g.M;
+          cv[j][r] = C[(ok ? row : 0) * g.ldc + (ok ? col : 0)];
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t col = n0 + wn * 64 + j * 16 + fr;
@@ -196,12 +210,123 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm * 64 + i * 16 + fq + 4 * r;
         if (row >= g.M) continue;
-        double *cp = C + row * g.ldc + col;
         double v = alpha * acc[i][j][r];
-        if (beta != 0.0) v += beta * *cp;
-        *cp = v;
+        if (beta != 0.0) v += beta * cv[j][r];
+        C[row * g.ldc + col] = v;
       }
     }
+  }
+}
+
+// Interior fast path: every tile full (M, N multiples of 128), every K-range a multiple of
+// BK, 16-byte aligned rows.  Operand rows go HBM -> LDS directly (global_load_lds_dwordx4:
+// one wave instruction lands one 1 KiB tile row, lane l -> bytes [16 l, 16 l + 16) of the
+// row, so the padded row stride costs nothing), no staging VGPRs, no ds_write pass, no
+// masks; row pointers advance by a constant instead of being recomputed.
+__global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int tm, tn, split;
+  if (g.work_map) {
+    const int nw = g.n_work, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nw >> 3, r = nw & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
+    tm = e.x; tn = e.y; split = e.z;
+  } else {
+    tm = blockIdx.x / g.tiles_n;
+    tn = blockIdx.x % g.tiles_n;
+    split = blockIdx.y;
+  }
+  const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+  if (g.upper_only && n0 + BN <= m0) return;
+  const int64_t b = blockIdx.z;
+  double *C = g.C + b * g.sc + (int64_t)split * g.split_stride;
+  int64_t kb = (int64_t)split * g.kchunk;
+  int64_t ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
+  if (g.x_upper_tri) {
+    const int64_t lim = m0 + BM;
+    if (ke > lim) ke = lim;
+  }
+  if (g.xy_lower_tri) {
+    int64_t lo = m0 > n0 ? m0 : n0;
+    lo -= lo % BK;
+    if (kb < lo) kb = lo;
+  }
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  // wave w stages rows w, w+4, w+8, w+12 of both tiles; lane -> 2 columns
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const double *xp = g.X + b * g.sx + (kb + wave) * g.ldx + m0 + 2 * lane;
+  const double *yp = g.Y + b * g.sy + (kb + wave) * g.ldy + n0 + 2 * lane;
+  const int64_t xstep = 4 * g.ldx, ystep = 4 * g.ldy;
+
+  auto stage = [&](int buf) {
+    double *Xs = smem + buf * STAGE + wave * LDT;
+    double *Ys = Xs + BK * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(yp + i * ystep), (lds_void *)(Ys + 4 * i * LDT), 16, 0, 0);
+    }
+    xp += 4 * xstep;
+    yp += 4 * ystep;
+  };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  if (kb < ke) stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+    if (k0 + BK < ke) stage(cur ^ 1);
+    const double *Xs = smem + cur * STAGE;
+    const double *Ys = Xs + BK * LDT;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDT + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const double alpha = g.alpha;
+  const double beta = g.splits > 1 ? 0.0 : g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double cv[4][4];
+    if (beta != 0.0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          cv[j][r] = C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * cv[j][r];
+        C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr] = v;
+      }
   }
 }
 
@@ -215,6 +340,9 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
                                        (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     g_attr_set = true;
@@ -243,7 +371,11 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.n_work = a.n_work;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
   if (a.work_map) grid = dim3((unsigned)a.n_work, 1, 1);
-  if (g.vec_x && g.vec_y)
+  const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
+                        !a.force_generic;
+  if (interior)
+    hipLaunchKernelGGL(gemm_tn_f64_interior_kernel, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  else if (g.vec_x && g.vec_y)
     hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else
     hipLaunchKernelGGL(gemm_tn_f64_kernel<false>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
