@@ -53,83 +53,99 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 //          the dead strictly-lower triangle is the scratch for the intermediate one).
 // Blocks smaller than 128 are padded with the identity.
 
-__device__ __forceinline__ void chol32_wave(double *s, int j0, double *dinv, int32_t *info, int k0,
-                                            int lane) {
+constexpr int WLD = SB + 2;  // leading dimension of the 32 x 32 scratch copy of inv(L11)
+
+__device__ __forceinline__ double rsqrt_refined(double d) {
+  double y = __builtin_amdgcn_rsq(d);  // v_rsq_f64, then two Newton steps to full precision
+  const double h = -0.5 * d;
+  double e = __builtin_fma(h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+
+// 32 x 32 Cholesky D = U^T U by ONE wave, one column per lane, entirely in registers.
+//  * lanes 0..31 hold the columns of D, lanes 32..63 the columns of the identity: the same
+//    row operations turn the identity into W = U^-T for free (the otherwise idle half of
+//    the wave does it), so the panel solve below is a matrix-core product and no separate
+//    triangular inversion of the diagonal sub-blocks is needed;
+//  * row j of U is broadcast with v_readlane in chunks of 8 fenced by sched_barrier: left
+//    alone, hipcc hoists all 31 broadcasts of a pivot to the top and spills hundreds of
+//    SGPRs through v_writelane;
+//  * the next pivot's 1/sqrt chain is started from lane j+1's own updated diagonal before
+//    the rank-1 update of pivot j, so it overlaps with that update;
+//  * branch-free (not-positive-definite is recorded, the pivot replaced by 1).
+// Results: U (upper) and the strictly-lower part of W in place, 1/U_jj in dinv, all of W in
+// wbuf (row-major, WLD).
+__device__ __noinline__ void chol32_wave(double *s, int j0, double *dinv, double *wbuf,
+                                         int32_t *info, int k0, int lane) {
   const int c = lane & 31;
+  const bool isW = lane >= SB;
   double col[SB];
 #pragma unroll
-  for (int i = 0; i < SB; ++i) col[i] = s[(j0 + i) * PLD + j0 + c];
+  for (int i = 0; i < SB; ++i) col[i] = s[(j0 + i) * PLD + j0 + c];  // all 64 lanes load
+#pragma unroll
+  for (int i = 0; i < SB; ++i) col[i] = isW ? ((i == c) ? 1.0 : 0.0) : col[i];
   int first_bad = -1;
+  double d = readlane_d(col[0], 0);
+  bool ok = (d > 0.0) && (d < 1.0e300);
+  first_bad = ok ? first_bad : 0;
+  double y = rsqrt_refined(ok ? d : 1.0);
+  double ykeep = 0.0;
 #pragma unroll
   for (int j = 0; j < SB; ++j) {
-    double d = readlane_d(col[j], j);
-    const bool ok = (d > 0.0) && (d < 1.0e300);  // positive definite and finite
-    first_bad = (!ok && first_bad < 0) ? j : first_bad;
-    d = ok ? d : 1.0;
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    double e = __builtin_fma(-h * y, y, 0.5);
-    y = __builtin_fma(y, e, y);
-    e = __builtin_fma(-h * y, y, 0.5);
-    y = __builtin_fma(y, e, y);
-    const double u = (c >= j) ? col[j] * y : 0.0;
+    double u = col[j] * y;
+    u = (!isW && c < j) ? 0.0 : u;
     col[j] = u;
-    if (lane == 0) dinv[j0 + j] = y;
+    ykeep = (c == j) ? y : ykeep;
+    double ynext = 0.0;
+    if (j + 1 < SB) {
+      const double dn = readlane_d(col[j + 1] - u * u, j + 1);
+      ok = (dn > 0.0) && (dn < 1.0e300);
+      first_bad = (!ok && first_bad < 0) ? j + 1 : first_bad;
+      ynext = rsqrt_refined(ok ? dn : 1.0);
+    }
 #pragma unroll
-    for (int i = j + 1; i < SB; ++i) col[i] -= readlane_d(u, i) * u;
+    for (int i = j + 1; i < SB; ++i) {
+      col[i] -= readlane_d(u, i) * u;
+      if (((i - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    y = ynext;
   }
   if (first_bad >= 0 && lane == 0) atomicCAS(info, 0, k0 + j0 + first_bad + 1);
-  if (lane < SB) {
+  if (!isW) dinv[j0 + c] = ykeep;
 #pragma unroll
-    for (int i = 0; i < SB; ++i) s[(j0 + i) * PLD + j0 + c] = (i <= c) ? col[i] : 0.0;
-  }
-}
-
-// columns cc >= j0 + 32 of rows j0..j0+31: x <- U11^-T x.
-// Two address registers, each threaded through an empty asm after the arithmetic of
-// the row two back: the LDS reads run at most two rows ahead of the FMAs (hoisting all
-// 496 of them spills, serialising them exposes one LDS latency per row).
-__device__ __forceinline__ void panel32_solve(double *s, int j0, const double *dinv, int cc) {
-  double x[SB];
-#pragma unroll
-  for (int i = 0; i < SB; ++i) x[i] = s[(j0 + i) * PLD + cc];
-  int off0 = j0 * PLD + j0, off1 = off0;
-#pragma unroll
-  for (int j = 0; j < SB; ++j) {
-    const int off = (j & 1) ? off1 : off0;
-    x[j] *= dinv[j0 + j];
-#pragma unroll
-    for (int i = j + 1; i < SB; ++i) x[i] -= s[off + j * PLD + i] * x[j];
-    if (j + 1 < SB) {
-      if (j & 1) asm volatile("" : "+v"(off1) : "v"(x[j + 1]));
-      else asm volatile("" : "+v"(off0) : "v"(x[j + 1]));
+  for (int i = 0; i < SB; ++i) {
+    if (isW) {
+      wbuf[i * WLD + c] = (i >= c) ? col[i] : 0.0;
+      if (i > c) s[(j0 + i) * PLD + j0 + c] = col[i];
+    } else if (i <= c) {
+      s[(j0 + i) * PLD + j0 + c] = col[i];
     }
   }
-#pragma unroll
-  for (int i = 0; i < SB; ++i) s[(j0 + i) * PLD + cc] = x[i];
 }
 
-// in-place inverse of the upper-triangular 32 x 32 block at (j0, j0); one column per lane
-__device__ __forceinline__ void trinv32_wave(double *s, int j0, const double *dinv, int lane) {
-  const int c = lane & 31;
-  double v[SB];
-  int off0 = j0 * PLD + j0, off1 = off0;
+// Row panel U12 = W * A12 (W = inv(L11), 32 x 32 lower triangular, in wbuf) on the matrix
+// cores, in place: each wave owns whole 16-column strips, so both 16-row halves of a strip
+// are accumulated before either is overwritten.
+__device__ __noinline__ void panel32_mma(double *s, int j0, const double *wbuf, int rest, int wave,
+                                            int lane) {
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int tj = wave; tj < rest / 16; tj += 4) {
+    double *A12 = s + j0 * PLD + j0 + SB + tj * 16;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int i = SB - 1; i >= 0; --i) {
-    const int off = (i & 1) ? off1 : off0;
-    double acc = 0.0;
+    for (int k = 0; k < SB; k += 4) {
+      const double b = A12[(k + fq) * PLD + fr];
+      if (k < 16) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wbuf[fr * WLD + k + fq], b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wbuf[(16 + fr) * WLD + k + fq], b, acc1, 0, 0, 0);
+    }
 #pragma unroll
-    for (int k = i + 1; k < SB; ++k) acc += s[off + i * PLD + k] * v[k];
-    const double di = dinv[j0 + i];
-    v[i] = (i < c) ? -di * acc : ((i == c) ? di : 0.0);
-    if (i & 1) asm volatile("" : "+v"(off1) : "v"(v[i]));
-    else asm volatile("" : "+v"(off0) : "v"(v[i]));
-  }
-  // all lanes of the wave have finished reading the block before anyone overwrites it
-  __builtin_amdgcn_wave_barrier();
-  if (lane < SB) {
-#pragma unroll
-    for (int i = 0; i < SB; ++i) s[(j0 + i) * PLD + j0 + c] = v[i];
+    for (int r = 0; r < 4; ++r) {
+      A12[(fq + 4 * r) * PLD + fr] = acc0[r];
+      A12[(16 + fq + 4 * r) * PLD + fr] = acc1[r];
+    }
   }
 }
 
@@ -138,24 +154,33 @@ __device__ __forceinline__ void trinv32_wave(double *s, int j0, const double *di
 // with A(i,k) = L[k][i] when TA (k-major left operand) else L[i][k].  16 x 16 output tiles
 // are dealt round-robin to the 4 waves; `upper` skips tiles strictly below the diagonal;
 // `r_upper` / `l_upper` restrict k to the non-zero part of an upper-triangular R / L.
-template <bool TA, bool ACC>
+template <bool TA, bool ACC, int KS>
 __device__ __forceinline__ void lds_mma(const double *L, const double *R, double *Cm, int mt, int nt,
-                                        int kdim, double sign, bool upper, bool r_upper,
-                                        bool l_upper, int wave, int lane) {
+                                        double sign, bool upper, bool r_upper, bool l_upper, int wave,
+                                        int lane) {
   const int fr = lane & 15, fq = lane >> 4;
   int t = 0;
   for (int ti = 0; ti < mt; ++ti)
     for (int tj = (upper ? ti : 0); tj < nt; ++tj, ++t) {
       if ((t & 3) != wave) continue;
       const int i0 = ti * 16, j0 = tj * 16;
-      int klo = 0, khi = kdim;
+      int klo = 0, khi = KS * 4;
       if (r_upper && khi > j0 + 16) khi = j0 + 16;
       if (l_upper && klo < i0) klo = i0;
+      // rolled k loop with the next fragments in flight behind the current MFMA (a fully
+      // unrolled, guarded chain made hipcc emit exec-masked MFMA variants that came out wrong)
       v4d acc = {0.0, 0.0, 0.0, 0.0};
-      for (int k = klo; k < khi; k += 4) {
-        const double a = TA ? L[(k + fq) * PLD + i0 + fr] : L[(i0 + fr) * PLD + k + fq];
-        const double b = R[(k + fq) * PLD + j0 + fr];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      if (klo < khi) {
+        double a0 = TA ? L[(klo + fq) * PLD + i0 + fr] : L[(i0 + fr) * PLD + klo + fq];
+        double b0 = R[(klo + fq) * PLD + j0 + fr];
+        for (int k = klo; k < khi; k += 4) {
+          const int kn = (k + 4 < khi) ? k + 4 : k;
+          const double a1 = TA ? L[(kn + fq) * PLD + i0 + fr] : L[(i0 + fr) * PLD + kn + fq];
+          const double b1 = R[(kn + fq) * PLD + j0 + fr];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+          a0 = a1;
+          b0 = b1;
+        }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -176,6 +201,7 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
                                                         int32_t *info, int32_t k0, long long *dbg) {
   extern __shared__ __attribute__((aligned(16))) double s[];
   double *dinv = s + NB * PLD;
+  double *wbuf = dinv + NB;          // 32 x WLD copy of inv(L11) of the current sub-block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nsb = (nb + SB - 1) / SB;  // active 32-wide sub-blocks
   // ---- load: thread -> 2 columns, 32 rows; clamped (always valid) addresses, masked after
@@ -207,18 +233,18 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
   // ---- phase 1: Cholesky
   for (int jb = 0; jb < nsb; ++jb) {
     const int j0 = jb * SB;
-    if (wave == 0) chol32_wave(s, j0, dinv, info, k0, lane);
+    if (wave == 0) chol32_wave(s, j0, dinv, wbuf, info, k0, lane);
     __syncthreads();
     STAMP(2 + 3 * jb);
     const int rest = nsb * SB - (j0 + SB);
     if (rest > 0) {
-      if (tid < rest) panel32_solve(s, j0, dinv, j0 + SB + tid);
+      panel32_mma(s, j0, wbuf, rest, wave, lane);
       __syncthreads();
       STAMP(3 + 3 * jb);
       // A22 -= U12^T U12 (upper tiles), U12 = rows j0..j0+31, columns from j0+32
       const double *u12 = s + j0 * PLD + j0 + SB;
-      lds_mma<true, true>(u12, u12, s + (j0 + SB) * PLD + j0 + SB, rest / 16, rest / 16, SB, -1.0,
-                          true, false, false, wave, lane);
+      lds_mma<true, true, 8>(u12, u12, s + (j0 + SB) * PLD + j0 + SB, rest / 16, rest / 16, -1.0, true,
+                             false, false, wave, lane);
       __syncthreads();
       STAMP(4 + 3 * jb);
     }
@@ -241,8 +267,24 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
   }
   __syncthreads();
   STAMP(15);
-  // ---- phase 3: inverse of U in place
-  if (wave < nsb) trinv32_wave(s, wave * SB, dinv, lane);
+  // ---- phase 3: inverse of U in place.  Diagonal sub-blocks: inv(U11) = W^T, W's strictly
+  // lower part sits below U11's diagonal, its diagonal in dinv.
+  {
+    double t[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;              // 4 sub-blocks x 32 x 32
+      const int sb = idx >> 10, i = (idx >> 5) & 31, k = idx & 31, q = sb * SB;
+      t[e] = (k > i) ? s[(q + k) * PLD + q + i] : ((k == i) ? dinv[q + i] : 0.0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int idx = tid + 256 * e;
+      const int sb = idx >> 10, i = (idx >> 5) & 31, k = idx & 31, q = sb * SB;
+      if (sb < nsb) s[(q + i) * PLD + q + k] = t[e];
+    }
+  }
   __syncthreads();
   STAMP(16);
   if (nsb > 1) {
@@ -251,14 +293,14 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
     const int nq = nsb > 3 ? 2 : 1;
     for (int qi = 0; qi < nq; ++qi) {
       const int q = qi * 64;
-      lds_mma<false, false>(s + q * PLD + q + 32, s + (q + 32) * PLD + q + 32, s + (q + 32) * PLD + q,
-                            2, 2, 32, 1.0, false, true, false, (wave + 2 * qi) & 3, lane);
+      lds_mma<false, false, 8>(s + q * PLD + q + 32, s + (q + 32) * PLD + q + 32, s + (q + 32) * PLD + q,
+                               2, 2, 1.0, false, true, false, (wave + 2 * qi) & 3, lane);
     }
     __syncthreads();
     for (int qi = 0; qi < nq; ++qi) {
       const int q = qi * 64;
-      lds_mma<false, false>(s + q * PLD + q, s + (q + 32) * PLD + q, s + q * PLD + q + 32, 2, 2, 32,
-                            -1.0, false, false, true, (wave + 2 * qi) & 3, lane);
+      lds_mma<false, false, 8>(s + q * PLD + q, s + (q + 32) * PLD + q, s + q * PLD + q + 32, 2, 2, -1.0,
+                               false, false, true, (wave + 2 * qi) & 3, lane);
     }
     __syncthreads();
     // the level-1 scratch sits inside the triangles level 2 multiplies with: clear it
@@ -269,10 +311,10 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
     __syncthreads();
     if (nsb > 2) {
       // level 2: B = rows 0..63, cols 64..127; scratch = rows 64..127, cols 0..63
-      lds_mma<false, false>(s + 64, s + 64 * PLD + 64, s + 64 * PLD, 4, 4, 64, 1.0, false, true, false,
-                            wave, lane);
+      lds_mma<false, false, 16>(s + 64, s + 64 * PLD + 64, s + 64 * PLD, 4, 4, 1.0, false, true, false,
+                                wave, lane);
       __syncthreads();
-      lds_mma<false, false>(s, s + 64 * PLD, s + 64, 4, 4, 64, -1.0, false, false, true, wave, lane);
+      lds_mma<false, false, 16>(s, s + 64 * PLD, s + 64, 4, 4, -1.0, false, false, true, wave, lane);
       __syncthreads();
     }
   }
@@ -293,7 +335,7 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
 
 static bool g_potf2_attr = false;
 long long *g_potf2_dbg = nullptr;  // device buffer of 32 cycle stamps (LSQAMD_POTF2_TIMING builds)
-static constexpr size_t POTF2_LDS = (size_t)(NB * PLD + NB) * sizeof(double);  // 129 KiB
+static constexpr size_t POTF2_LDS = (size_t)(NB * PLD + NB + SB * WLD) * sizeof(double);  // 140 KiB
 
 static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, double *uinv,
                                int32_t *info, int32_t k0) {
