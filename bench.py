@@ -206,6 +206,16 @@ def main():
 
     if rank == 0:
         n_local = pr.N
+        # HBM traffic of the dominant kernel is a PMC quantity (separate rocprofv3 --pmc pass,
+        # FETCH_SIZE x2 gfx950 correction): taken from the committed profile of this workload
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_syrk_pmc.json')))
+            if world == 1 and (N, P) == (65536, 4096):
+                traffic = prof['summary']['hbm_read_bytes_corrected'] + prof['summary'].get('hbm_write_bytes', 0)
+                traffic_src = 'profiles/r01_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch)'
+        except Exception:
+            pass
         syrk_ms, syrk_n = tm['syrk']
         flops = float(n_local) * P * (P + 1)          # algorithmic, upper triangle, 2 flop/MAC
         ach = (flops / (syrk_ms / syrk_n * 1e-3) / 1e12) if syrk_n else 0.0
@@ -225,7 +235,9 @@ def main():
             'phases_calls': {k: v[1] for k, v in tm.items()},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_tn_f64_kernel (J^T J)', 'achieved': ach,
                          'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_FP64_MFMA_TFLOPS, 'traffic': None,
+                         'frac': ach / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
+                         'algorithmic_bytes': 8.0 * n_local * P,
                          'flops_per_launch': flops,
                          'avg_launch_ms': (syrk_ms / syrk_n) if syrk_n else None},
         }
