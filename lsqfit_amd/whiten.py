@@ -180,6 +180,7 @@ class Whitening:
         self.logdet += 2.0 * float(np.sum(np.log(ysd[d])))
         n1 = int(np.sum(d))
         self.n_data = N
+        self.logdet_data = self.logdet          # log det of the regulated DATA covariance alone
         self.nchiv_data = n1 + sum(b['modes'] for b in self.blocks)
         # ---- prior
         self.has_prior = prior_mean is not None
