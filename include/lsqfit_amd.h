@@ -211,6 +211,31 @@ int lsqamd_get_grad(lsqamd_fit *fit, double *out, size_t cap);    /* P        : 
 int lsqamd_get_cov(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : fit.cov (gsl_multifit_nlinear_covar, _gsl.pyx:704-706) */
 int64_t lsqamd_nf(const lsqamd_fit *fit);                         /* nchiv (__init__.py:574) */
 
+/* ---- batched fits (SURVEY.md 8a row a8 / BASELINE.json config 5) --------------------
+ * B independent fits of ONE shape -- same model, x, data means and diagonal data whitening,
+ * different (diagonal) priors and starting points -- advanced in lockstep with all LM state
+ * on the device and one round of kernels captured in a hipGraph.  Device counterpart of the
+ * Python loop of whole fits in lsqfit.empbayes_fit (src/lsqfit/_extras.py:153-174); per fit
+ * the driver semantics are those of lsqamd_run. */
+typedef struct lsqamdb_fits lsqamdb_fits;
+size_t lsqamdb_workspace_bytes(const lsqamd_config *cfg, int32_t n_fits);
+int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace, size_t workspace_bytes,
+                   void *stream, lsqamdb_fits **out);
+int lsqamdb_destroy(lsqamdb_fits *fits);
+const char *lsqamdb_last_error(const lsqamdb_fits *fits);
+int lsqamdb_set_x(lsqamdb_fits *fits, const double *x, int64_t n_rows, int32_t n_x);
+int lsqamdb_set_tape(lsqamdb_fits *fits, const int32_t *code, int32_t n_code, const double *consts,
+                     int32_t n_consts);
+int lsqamdb_set_data(lsqamdb_fits *fits, const double *ymean, const double *wdiag);     /* shared, [N] each */
+int lsqamdb_set_priors(lsqamdb_fits *fits, const double *mean, const double *prec);     /* [B*P] each */
+int lsqamdb_set_options(lsqamdb_fits *fits, const lsqamd_options *opt);
+/* p0[B*P]; summaries[B] or NULL (t_setup_ms carries the number of graph-replayed rounds) */
+int lsqamdb_run(lsqamdb_fits *fits, const double *p0, lsqamd_summary *summaries, int32_t use_graph);
+int lsqamdb_get_x(lsqamdb_fits *fits, double *out, size_t cap);                         /* B*P */
+int lsqamdb_covariance(lsqamdb_fits *fits, double *logdet_jtj_out, size_t cap);         /* B */
+int lsqamdb_get_cov(lsqamdb_fits *fits, int32_t fit, double *out, size_t cap);          /* P*P */
+int32_t lsqamdb_rounds(const lsqamdb_fits *fits);
+
 /* ---- measurement ------------------------------------------------------------ */
 enum {
   LSQAMD_T_RESIDUAL = 0, LSQAMD_T_JACOBIAN = 1, LSQAMD_T_WHITEN = 2, LSQAMD_T_SYRK = 3,

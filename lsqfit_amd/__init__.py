@@ -12,6 +12,7 @@ raises.
   fitter     ``mi355x_lm``: the fitter plugin class (mirror of gsl_multifit)
   fit        ``nonlinear_fit``: problem setup + chi2/dof/Q/logGBF reduction
   sweep      ``empbayes_fit`` / prior-width sweeps on one resident problem
+  batched    ``BatchedFits``: many same-shape fits in lockstep, device-resident LM state, hipGraph
   dist       row sharding across GPUs + the all-reduce hook (torch.distributed/RCCL)
   synth      fake_fitargs-style synthetic problems (benchmark generator)
 """
@@ -20,5 +21,6 @@ from .whiten import Whitening  # noqa: F401
 from .fitter import mi355x_lm, DeviceProblem, register  # noqa: F401
 from .fit import nonlinear_fit, gammaQ  # noqa: F401
 from .sweep import empbayes_fit, prior_width_sweep  # noqa: F401
+from .batched import BatchedFits  # noqa: F401
 
 __version__ = '0.1.0'

@@ -74,6 +74,20 @@ PROTOTYPES = {
     'lsqamd_get_grad': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_get_cov': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_nf': (C.c_int64, [_vp]),
+    'lsqamdb_workspace_bytes': (C.c_size_t, [C.POINTER(Config), C.c_int32]),
+    'lsqamdb_create': (C.c_int, [C.POINTER(Config), C.c_int32, _vp, C.c_size_t, _vp, C.POINTER(_vp)]),
+    'lsqamdb_destroy': (C.c_int, [_vp]),
+    'lsqamdb_last_error': (C.c_char_p, [_vp]),
+    'lsqamdb_set_x': (C.c_int, [_vp, _dp, C.c_int64, C.c_int32]),
+    'lsqamdb_set_tape': (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int32]),
+    'lsqamdb_set_data': (C.c_int, [_vp, _dp, _dp]),
+    'lsqamdb_set_priors': (C.c_int, [_vp, _dp, _dp]),
+    'lsqamdb_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
+    'lsqamdb_run': (C.c_int, [_vp, _dp, C.POINTER(Summary), C.c_int32]),
+    'lsqamdb_get_x': (C.c_int, [_vp, _dp, C.c_size_t]),
+    'lsqamdb_covariance': (C.c_int, [_vp, _dp, C.c_size_t]),
+    'lsqamdb_get_cov': (C.c_int, [_vp, C.c_int32, _dp, C.c_size_t]),
+    'lsqamdb_rounds': (C.c_int32, [_vp]),
     'lsqamd_timing_enable': (C.c_int, [_vp, C.c_int32]),
     'lsqamd_timing_get': (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(C.c_int64)]),
     'lsqamd_timing_reset': (C.c_int, [_vp]),

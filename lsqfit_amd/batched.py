@@ -1,0 +1,131 @@
+"""``BatchedFits``: many fits of one shape in lockstep on the device (C ABI ``lsqamdb_*``).
+
+Host counterpart of running ``lsqfit.nonlinear_fit`` in a Python loop over priors /
+starting points (the inner loop of ``lsqfit.empbayes_fit``, src/lsqfit/_extras.py:153-174):
+the fits share the model, ``x`` and uncorrelated data ``(ymean, ysdev)`` and differ in their
+diagonal priors and ``p0``.  Result arrays have a leading batch dimension.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from .fit import gammaQ
+from .fitter import _SCALERS, normalize_tol
+from .models import MODEL_IDENTITY, MODEL_TAPE
+
+
+class BatchedFits:
+    def __init__(self, model, x, ymean, ysdev, prior_mean, prior_sdev, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('lsqfit_amd: no MI355X visible; the batched fitter has no CPU path')
+        self.lib = lib = _lib.load()
+        self.model = model
+        ymean = np.ascontiguousarray(ymean, np.float64).reshape(-1)
+        ysdev = np.ascontiguousarray(np.broadcast_to(np.asarray(ysdev, np.float64), ymean.shape))
+        if ysdev.ndim != 1 or np.any(ysdev <= 0):
+            raise ValueError('batched fits need uncorrelated data with positive standard deviations')
+        pm = np.ascontiguousarray(prior_mean, np.float64)
+        ps = np.ascontiguousarray(np.broadcast_to(np.asarray(prior_sdev, np.float64), pm.shape))
+        if pm.ndim != 2 or pm.shape[1] != model.n_param:
+            raise ValueError('prior_mean must be [n_fits, n_param]')
+        if np.any(ps <= 0):
+            raise ValueError('some priors have zero standard deviations')
+        self.B, self.P, self.N = pm.shape[0], model.n_param, ymean.size
+        self.ysdev, self.prior_mean, self.prior_sdev = ysdev, pm, ps
+        cfg = _lib.Config(abi_version=_lib.ABI_VERSION, model=model.kind, n_data=self.N, n_param=self.P,
+                          n_x=model.n_x, has_prior=1, prior_dense=0, n_blocks=0, max_block=0, sum_block_sq=0,
+                          want_jacobian_out=0, n_batch=self.B)
+        t0 = time.perf_counter()
+        nbytes = lib.lsqamdb_workspace_bytes(C.byref(cfg), self.B)
+        if nbytes == 0:
+            raise ValueError('lsqfit_amd: unsupported batched problem shape/model')
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.workspace = torch.empty(nbytes + 512, dtype=torch.uint8, device=self.device)
+        base = self.workspace.data_ptr()
+        off = (-base) % 256
+        h = C.c_void_p()
+        rc = lib.lsqamdb_create(C.byref(cfg), self.B, C.c_void_p(base + off), nbytes,
+                                C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream), C.byref(h))
+        if rc != 0:
+            raise RuntimeError('lsqfit_amd: lsqamdb_create failed (%s)' % _lib.ERRORS.get(rc, rc))
+        self.h = h
+        if model.kind != MODEL_IDENTITY:
+            xa = np.ascontiguousarray(np.asarray(x, np.float64).reshape(self.N, model.n_x))
+            self._check(lib.lsqamdb_set_x(h, _lib.dptr(xa), self.N, model.n_x), 'set_x')
+        if model.kind == MODEL_TAPE:
+            code = np.ascontiguousarray(model.tape, np.int32)
+            consts = np.ascontiguousarray(model.consts, np.float64)
+            self._check(lib.lsqamdb_set_tape(h, code.ctypes.data_as(C.POINTER(C.c_int32)), code.size,
+                                             _lib.dptr(consts), consts.size), 'set_tape')
+        wd = np.ascontiguousarray(1.0 / ysdev)
+        self._check(lib.lsqamdb_set_data(h, _lib.dptr(ymean), _lib.dptr(wd)), 'set_data')
+        self.set_priors(pm, ps)
+        self.t_setup = time.perf_counter() - t0
+
+    def _check(self, rc, what):
+        if rc < 0:
+            msg = self.lib.lsqamdb_last_error(self.h)
+            raise RuntimeError('lsqfit_amd: batched %s failed (%s): %s' % (
+                what, _lib.ERRORS.get(rc, rc), msg.decode() if msg else ''))
+
+    def set_priors(self, mean, sdev):
+        mean = np.ascontiguousarray(mean, np.float64)
+        sdev = np.ascontiguousarray(np.broadcast_to(np.asarray(sdev, np.float64), mean.shape))
+        prec = np.ascontiguousarray(1.0 / sdev ** 2)
+        self.prior_mean, self.prior_sdev = mean, sdev
+        self._check(self.lib.lsqamdb_set_priors(self.h, _lib.dptr(mean), _lib.dptr(prec)), 'set_priors')
+
+    def run(self, p0=None, tol=1e-8, maxit=1000, scaler='more', factor_up=3.0, factor_down=2.0,
+            use_graph=True, covariance=True):
+        """-> dict of arrays: pmean[B,P], chi2, dof, Q, logGBF, nit, stopping_criterion, status,
+        nfev (+ psdev[B,P] and cov(b) when ``covariance``)."""
+        B, P = self.B, self.P
+        if p0 is None:
+            p0 = np.where(self.prior_mean != 0.0, self.prior_mean, self.prior_mean + 0.1 * self.prior_sdev)
+        p0 = np.ascontiguousarray(np.broadcast_to(np.asarray(p0, np.float64), (B, P)))
+        xtol, gtol, ftol = normalize_tol(tol)
+        opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler], solver=0,
+                           reserved=0, factor_up=factor_up, factor_down=factor_down)
+        self._check(self.lib.lsqamdb_set_options(self.h, C.byref(opt)), 'set_options')
+        summ = (_lib.Summary * B)()
+        t0 = time.perf_counter()
+        self._check(self.lib.lsqamdb_run(self.h, _lib.dptr(p0), summ, int(bool(use_graph))), 'run')
+        t_run = time.perf_counter() - t0
+        x = np.empty(B * P)
+        self._check(self.lib.lsqamdb_get_x(self.h, _lib.dptr(x), x.size), 'get_x')
+        out = dict(pmean=x.reshape(B, P),
+                   chi2=np.array([s.chi2 for s in summ]), nit=np.array([s.nit for s in summ]),
+                   nfev=np.array([s.nfev for s in summ]), status=np.array([s.status for s in summ]),
+                   stopping_criterion=np.array([s.stopping_criterion for s in summ]),
+                   rounds=int(self.lib.lsqamdb_rounds(self.h)), graph_rounds=int(summ[0].t_setup_ms),
+                   time=t_run, device_ms=float(summ[0].t_run_ms))
+        dof = self.N          # nf - P = N + P - P
+        out['dof'] = dof
+        out['Q'] = np.array([gammaQ(dof / 2., c / 2.) for c in out['chi2']])
+        if covariance:
+            ld = np.empty(B)
+            self._check(self.lib.lsqamdb_covariance(self.h, _lib.dptr(ld), B), 'covariance')
+            out['logdet_jtj'] = ld
+            logdet_c = 2.0 * np.sum(np.log(self.ysdev)) + 2.0 * np.sum(np.log(self.prior_sdev), axis=1)
+            out['logGBF'] = 0.5 * (-ld - logdet_c - out['chi2'] - dof * np.log(2. * np.pi))
+            out['psdev'] = np.sqrt(np.array([np.diag(self.cov(b)) for b in range(B)])) if B * P * P <= 1 << 26 else None
+        return out
+
+    def cov(self, b):
+        out = np.empty(self.P * self.P)
+        self._check(self.lib.lsqamdb_get_cov(self.h, int(b), _lib.dptr(out), out.size), 'get_cov')
+        return out.reshape(self.P, self.P)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.lsqamdb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblsqfit_amd.so')
-SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'model.hip', 'vecops.hip', 'api.hip']
+SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'model.hip', 'vecops.hip', 'api.hip', 'batch.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 

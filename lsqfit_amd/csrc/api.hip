@@ -8,6 +8,7 @@
 // decisions from the identical all-reduced (J^T J, J^T f, chi2).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -152,9 +153,13 @@ void resolve_timers(lsqamd_fit *f) {
 }
 
 int32_t choose_splits(int64_t N, int64_t P) {
+  if (const char *e = getenv("LSQAMD_SYRK_SPLITS")) {  // tuning override (developer knob)
+    const int v = atoi(e);
+    if (v >= 1 && v <= 64) return v;
+  }
   const int64_t T = (P + 127) / 128;
   const int64_t tiles = T * (T + 1) / 2;
-  int64_t s = (4096 + tiles - 1) / tiles;
+  int64_t s = (8192 + tiles - 1) / tiles;
   const int64_t maxs = N / 1024 > 1 ? N / 1024 : 1;
   if (s > maxs) s = maxs;
   if (s > 16) s = 16;

@@ -1,0 +1,883 @@
+// Batched LM engine: B independent fits of one shape advance in lockstep, all LM state
+// on the device, one round of kernels captured in a hipGraph and replayed.
+//
+// This is the device counterpart of what lsqfit.empbayes_fit does with a Python loop of
+// whole fits (src/lsqfit/_extras.py:153-174, BASELINE.json config 5): the fits share the
+// model, x, the data means and their (diagonal) whitening, and differ in the prior
+// (mean / sdev per fit) and the starting point.  Per fit the GSL trust/lm/nielsen/scaling/
+// convergence logic of api.hip is restated as small per-fit device kernels (b_decide,
+// b_post); the heavy kernels are the same ones the single-fit path uses, launched with a
+// batch dimension: model kernels (grid.y), TN GEMM (grid.z) for J^T J and the Cholesky
+// panels/updates, the diagonal-block kernel (one workgroup per fit), back substitution.
+//
+// One ROUND = one trial step of every still-active fit:
+//   build (A_b + mu_b D_b^2 | g_b) -> Cholesky -> back substitution -> x_trial, v.g, |Dv|^2
+//   -> residual at x_trial -> chi2_trial -> decide (rho, accept / reject, mu, nu)
+//   -> Jacobian, J^T J, J^T f, chi2 at the fit's current x (unchanged if it rejected)
+//   -> post (scaling update, niter, convergence tests, retire finished fits).
+// Fits that have finished are masked out of every kernel through `active[b]`.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace lsqamd {
+
+constexpr int TBK = 128;  // packed tile edge (vecops.hip)
+
+__device__ __forceinline__ double bsum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ double block_sum(double v, double *sh) {
+  v = bsum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__device__ __forceinline__ double block_max(double v, double *sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+}
+
+__device__ __forceinline__ int64_t pk_diag(int64_t j, int64_t T) {  // packed offset of A[j][j]
+  const int64_t tm = j / TBK, r = j % TBK;
+  return (tm * T - tm * (tm - 1) / 2) * TBK * TBK + r * TBK + r;
+}
+
+struct BState {  // per-fit device scalars
+  double *mu, *chi2, *chi2t, *vg, *dv2;
+  int32_t *nu, *bad, *iter, *nit, *info, *status, *active, *accepted, *enoprog, *cholinfo, *nfev, *njev;
+  int32_t *n_active;
+};
+
+// ---- slabs -> packed tiles ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void b_finalize_pack_kernel(const double *slabs, int32_t splits,
+                                                              int64_t split_stride, int64_t fit_stride,
+                                                              int64_t P, int64_t ld, int64_t T, double *apk,
+                                                              int64_t apk_stride, const int32_t *active) {
+  const int b = blockIdx.z;
+  if (!active[b]) return;
+  int64_t t = blockIdx.x, tm = 0;
+  while (t >= T - tm) { t -= T - tm; ++tm; }
+  const int64_t tn = tm + t;
+  double *dst = apk + b * apk_stride + (int64_t)blockIdx.x * TBK * TBK;
+  const double *src = slabs + b * fit_stride;
+  const int c = threadIdx.x & 127;
+  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
+    const int r = blockIdx.y * 8 + rr;
+    const int64_t i = tm * TBK + r, j = tn * TBK + c;
+    double a = 0.0;
+    if (i < P && j < P)
+      for (int s = 0; s < splits; ++s) a += src[s * split_stride + i * ld + j];
+    dst[r * TBK + c] = a;
+  }
+}
+
+// ---- J^T f, |f|^2 ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void b_colsum_stage1(const double *J, int64_t nrows, int64_t ld,
+                                                       int64_t ncols, int64_t rcol, int64_t rpc,
+                                                       int64_t j_stride, double *partial,
+                                                       int64_t part_stride, const int32_t *active) {
+  const int b = blockIdx.z;
+  if (!active[b]) return;
+  J += b * j_stride;
+  partial += b * part_stride;
+  const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * rpc;
+  int64_t r1 = r0 + rpc;
+  if (r1 > nrows) r1 = nrows;
+  if (j >= ncols) return;
+  const bool two = j + 1 < ncols;
+  double a0 = 0.0, a1 = 0.0;
+  for (int64_t i = r0; i < r1; ++i) {
+    const double ri = J[i * ld + rcol];
+    a0 += J[i * ld + j] * ri;
+    if (two) a1 += J[i * ld + j + 1] * ri;
+  }
+  partial[(int64_t)blockIdx.y * ncols + j] = a0;
+  if (two) partial[(int64_t)blockIdx.y * ncols + j + 1] = a1;
+}
+
+__global__ __launch_bounds__(256) void b_colsum_stage2(const double *partial, int64_t nchunks,
+                                                       int64_t ncols, int64_t part_stride, double *gvec,
+                                                       int64_t g_stride, const int32_t *active) {
+  const int b = blockIdx.y;
+  if (!active[b]) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= ncols) return;
+  const double *p = partial + b * part_stride;
+  double a = 0.0;
+  for (int64_t c = 0; c < nchunks; ++c) a += p[c * ncols + j];
+  gvec[b * g_stride + j] = a;
+}
+
+// ---- diagonal prior into (packed A, g, chi2); one workgroup per fit ----------------------------
+__global__ __launch_bounds__(256) void b_prior_kernel(int64_t P, int64_t T, const double *prec,
+                                                      const double *pmean, const double *x, double *apk,
+                                                      int64_t apk_stride, double *gvec, int64_t g_stride,
+                                                      const int32_t *active) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  if (!active[b]) return;
+  double *A = apk + b * apk_stride, *g = gvec + b * g_stride;
+  double c2 = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double w = prec[b * P + j], d = x[b * P + j] - pmean[b * P + j];
+    A[pk_diag(j, T)] += w;
+    g[j] += w * d;
+    c2 += w * d * d;
+  }
+  c2 = block_sum(c2, sh);
+  if (threadIdx.x == 0) g[P] += c2;
+}
+
+// ---- trust_init: D, mu, nu, counters -----------------------------------------------------------
+__global__ __launch_bounds__(256) void b_init_kernel(int64_t P, int64_t T, const double *apk,
+                                                     int64_t apk_stride, const double *gvec,
+                                                     int64_t g_stride, double *diag, int scaler,
+                                                     BState s) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  const double *A = apk + b * apk_stride;
+  double mx = -1.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double a = A[pk_diag(j, T)];
+    const double cn = sqrt(a > 0.0 ? a : 0.0);
+    const double d = (scaler == LSQAMD_SCALE_LEVENBERG) ? 1.0 : (cn == 0.0 ? 1.0 : cn);
+    diag[b * P + j] = d;
+    mx = fmax(mx, cn / d);
+  }
+  mx = block_max(mx, sh);
+  if (threadIdx.x == 0) {
+    s.mu[b] = 1e-3 * mx * mx;
+    s.nu[b] = 2;
+    s.chi2[b] = gvec[b * g_stride + P];
+    s.bad[b] = 0; s.iter[b] = 0; s.nit[b] = 0; s.info[b] = 0; s.status[b] = -2;
+    s.active[b] = 1; s.accepted[b] = 0; s.enoprog[b] = 0; s.nfev[b] = 1; s.njev[b] = 1;
+  }
+}
+
+// ---- M_b = A_b + mu_b D_b^2, column P = g_b ------------------------------------------------------
+__global__ __launch_bounds__(256) void b_build_damped_kernel(const double *apk, int64_t apk_stride,
+                                                             int64_t P, int64_t T, int64_t ld,
+                                                             const double *mu, const double *diag,
+                                                             const double *gvec, int64_t g_stride,
+                                                             double *M, int64_t m_stride,
+                                                             const int32_t *active, int with_damping) {
+  const int b = blockIdx.z;
+  if (active && !active[b]) return;
+  int64_t t = blockIdx.x, tm = 0;
+  while (t >= T - tm) { t -= T - tm; ++tm; }
+  const int64_t tn = tm + t;
+  const double *src = apk + b * apk_stride + (int64_t)blockIdx.x * TBK * TBK;
+  double *Mb = M + b * m_stride;
+  const double m = with_damping ? mu[b] : 0.0;
+  const int c = threadIdx.x & 127;
+  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
+    const int r = blockIdx.y * 8 + rr;
+    const int64_t i = tm * TBK + r, j = tn * TBK + c;
+    if (i < P && j < P) {
+      double v = src[r * TBK + c];
+      if (i == j) {
+        const double d = diag[b * P + i];
+        v += m * d * d;
+      }
+      Mb[i * ld + j] = v;
+    }
+    if (tn == T - 1 && c == 0 && i < P && gvec) Mb[i * ld + P] = gvec[b * g_stride + i];
+  }
+}
+
+// y_b = column P of the factored M_b -> yv_b[0..P)
+__global__ __launch_bounds__(256) void b_extract_y_kernel(const double *M, int64_t m_stride, int64_t ld,
+                                                          int64_t P, double *yv, int64_t y_stride,
+                                                          const int32_t *active) {
+  const int b = blockIdx.y;
+  if (!active[b]) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < P) yv[b * y_stride + j] = M[b * m_stride + j * ld + P];
+}
+
+// dx = -v, x_trial = x + dx, v.g, |D v|^2 ; non-finite v marks the factorisation as failed
+__global__ __launch_bounds__(256) void b_trial_kernel(int64_t P, const double *yv, int64_t y_stride,
+                                                      const double *x, const double *gvec,
+                                                      int64_t g_stride, const double *diag, double *dx,
+                                                      double *xt, BState s) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  if (!s.active[b]) return;
+  const double *v = yv + b * y_stride + P;
+  double vg = 0.0, dv2 = 0.0, bad = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double vj = v[j];
+    if (!(fabs(vj) < 1.0e300)) bad = 1.0;
+    dx[b * P + j] = -vj;
+    xt[b * P + j] = x[b * P + j] - vj;
+    vg += vj * gvec[b * g_stride + j];
+    const double t = diag[b * P + j] * vj;
+    dv2 += t * t;
+  }
+  vg = block_sum(vg, sh);
+  dv2 = block_sum(dv2, sh);
+  bad = block_sum(bad, sh);
+  if (threadIdx.x == 0) {
+    s.vg[b] = vg;
+    s.dv2[b] = dv2;
+    if (bad > 0.0) s.cholinfo[b] = -1;
+  }
+}
+
+// chi2_trial_b = |r_b|^2 + prior term at x_trial ; two stages
+__global__ __launch_bounds__(256) void b_sumsq_stage1(const double *r, int64_t n, int64_t r_stride,
+                                                      double *partial, int nparts,
+                                                      const int32_t *active) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y;
+  if (!active[b]) return;
+  const double *rb = r + b * r_stride;
+  double a = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double v = rb[i];
+    a += v * v;
+  }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) partial[b * nparts + blockIdx.x] = a;
+}
+
+__global__ __launch_bounds__(256) void b_sumsq_stage2(const double *partial, int nparts, int64_t P,
+                                                      const double *prec, const double *pmean,
+                                                      const double *xt, int has_prior, BState s) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  if (!s.active[b]) return;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += partial[b * nparts + i];
+  if (has_prior)
+    for (int64_t j = threadIdx.x; j < P; j += 256) {
+      const double d = xt[b * P + j] - pmean[b * P + j];
+      a += prec[b * P + j] * d * d;
+    }
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) {
+    s.chi2t[b] = a;
+    s.nfev[b] += 1;
+  }
+}
+
+// trust_eval_step + nielsen accept/reject, one thread per fit
+__global__ void b_decide_kernel(int B, double factor_up, double factor_down, BState s) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B || !s.active[b]) return;
+  double rho = -1.0;
+  if (s.cholinfo[b] == 0) {
+    const double normf = sqrt(s.chi2[b]), normf_t = sqrt(s.chi2t[b]);
+    if (normf_t < normf) {
+      const double u = normf_t / normf;
+      const double actual = 1.0 - u * u;
+      const double pred = (s.vg[b] + s.mu[b] * s.dv2[b]) / s.chi2[b];
+      rho = pred > 0.0 ? actual / pred : -1.0;
+    }
+  }
+  s.accepted[b] = 0;
+  s.enoprog[b] = 0;
+  if (rho > 0.0) {
+    s.accepted[b] = 1;
+    const double bb = 2.0 * rho - 1.0;
+    s.mu[b] *= fmax(0.333333333333333, 1.0 - bb * bb * bb);
+    s.nu[b] = 2;
+    s.bad[b] = 0;
+  } else {
+    s.mu[b] *= (double)s.nu[b];
+    s.nu[b] <<= 1;
+    s.bad[b] += 1;
+    if (s.bad[b] > 15) {
+      s.enoprog[b] = 1;
+      s.bad[b] = 0;
+    }
+  }
+}
+
+// accepted fits: x <- x_trial
+__global__ __launch_bounds__(256) void b_commit_kernel(int64_t P, double *x, const double *xt, BState s) {
+  const int b = blockIdx.y;
+  if (!s.active[b] || !s.accepted[b]) return;
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < P) x[b * P + j] = xt[b * P + j];
+}
+
+// scaling update, niter, gsl_multifit_nlinear_test, retirement; one workgroup per fit
+__global__ __launch_bounds__(256) void b_post_kernel(int64_t P, int64_t T, const double *apk,
+                                                     int64_t apk_stride, const double *gvec,
+                                                     int64_t g_stride, double *diag, const double *x,
+                                                     const double *dx, int scaler, double xtol,
+                                                     double gtol, int maxit, BState s) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  if (!s.active[b]) return;
+  const bool acc = s.accepted[b] != 0, enp = s.enoprog[b] != 0;
+  if (!acc && !enp) return;  // rejected trial: stay in the inner loop
+  if (acc) {
+    const double *A = apk + b * apk_stride;
+    for (int64_t j = threadIdx.x; j < P; j += 256) {
+      const double a = A[pk_diag(j, T)];
+      const double cn = sqrt(a > 0.0 ? a : 0.0);
+      if (scaler == LSQAMD_SCALE_MORE) diag[b * P + j] = fmax(diag[b * P + j], cn);
+      else if (scaler == LSQAMD_SCALE_MARQUARDT) diag[b * P + j] = cn == 0.0 ? 1.0 : cn;
+    }
+  }
+  // convergence tests on (dx, x, g, chi2)
+  double notx = 0.0, gn = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double xj = x[b * P + j];
+    if (!(fabs(dx[b * P + j]) < xtol * xtol + xtol * fabs(xj))) notx = 1.0;
+    gn = fmax(gn, fabs(fmax(xj, 1.0) * gvec[b * g_stride + j]));
+  }
+  notx = block_sum(notx, sh);
+  gn = block_max(gn, sh);
+  if (threadIdx.x == 0) {
+    const double c2 = gvec[b * g_stride + P];
+    if (acc) {
+      s.chi2[b] = c2;
+      s.njev[b] += 1;
+    }
+    s.nit[b] += 1;
+    if (enp && s.iter[b] == 0) {  // no progress on the very first iteration
+      s.info[b] = LSQAMD_ENOPROG;
+      s.status[b] = LSQAMD_EMAXITER;
+      s.active[b] = 0;
+      return;
+    }
+    s.iter[b] += 1;
+    int info = 0;
+    if (notx == 0.0) info = 1;
+    else if (gn <= gtol * fmax(0.5 * s.chi2[b], 1.0)) info = 2;
+    if (info) {
+      s.info[b] = info;
+      s.status[b] = 0;
+      s.active[b] = 0;
+    } else if (s.iter[b] >= maxit) {
+      s.info[b] = 0;
+      s.status[b] = LSQAMD_EMAXITER;
+      s.active[b] = 0;
+    }
+  }
+}
+
+__global__ void b_count_kernel(int B, BState s) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) c += s.active[b] ? 1 : 0;
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) *s.n_active = cnt;
+}
+
+__global__ void b_logdiag_kernel(const double *M, int64_t m_stride, int64_t n, int64_t ld, double *out) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  double a = 0.0;
+  for (int64_t j = threadIdx.x; j < n; j += 256) a += log(M[b * m_stride + j * ld + j]);
+  a = block_sum(a, sh);
+  if (threadIdx.x == 0) out[b] = 2.0 * a;
+}
+
+__global__ __launch_bounds__(256) void b_symmetrize_kernel(double *A, int64_t a_stride, int64_t P,
+                                                           int64_t ld) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  double *Ab = A + (int64_t)blockIdx.z * a_stride;
+  if (j >= P || j >= i) return;
+  Ab[i * ld + j] = Ab[j * ld + i];
+}
+
+}  // namespace lsqamd
+
+// ===============================================================================================
+using namespace lsqamd;
+
+namespace {
+constexpr int64_t ALIGNB = 256;
+inline int64_t rupb(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+struct CarverB {
+  char *base;
+  size_t off = 0;
+  bool dry;
+  CarverB(void *b, bool d) : base((char *)b), dry(d) {}
+  template <typename T>
+  T *take(int64_t count) {
+    const size_t bytes = (size_t)rupb((count < 1 ? 1 : count) * (int64_t)sizeof(T), ALIGNB);
+    T *p = dry ? nullptr : reinterpret_cast<T *>(base + off);
+    off += bytes;
+    return p;
+  }
+};
+}  // namespace
+
+struct lsqamdb_fits {
+  lsqamd_config cfg;
+  lsqamd_options opt;
+  int32_t B = 0;
+  hipStream_t user_st = nullptr, st = nullptr;
+  std::string err;
+  int64_t N = 0, P = 0, ld = 0, ldm = 0, ncols_aug = 0, npk = 0, T = 0, nblk = 0;
+  int32_t splits = 1, nparts = 256, nrparts = 64;
+  // shared inputs
+  double *x = nullptr, *ymean = nullptr, *wdiag = nullptr;
+  int32_t *tape = nullptr;
+  double *consts = nullptr;
+  int32_t n_tape = 0;
+  // per fit
+  double *pmean = nullptr, *pprec = nullptr, *px = nullptr, *pxt = nullptr, *dx = nullptr, *diag = nullptr;
+  double *r = nullptr, *J = nullptr, *slabs = nullptr, *red = nullptr, *M = nullptr, *chol_work = nullptr;
+  double *yv = nullptr, *partial = nullptr, *spart = nullptr, *Wl = nullptr, *cov = nullptr, *logdet = nullptr;
+  int32_t *syrk_map = nullptr;
+  int32_t syrk_nwork = 0;
+  BState s;
+  bool have_x = false, have_data = false, have_prior = false, have_tape = false, ran = false, have_cov = false;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  int32_t graph_used = 0, rounds = 0;
+};
+
+namespace {
+
+#define BFAIL(f, code, ...)                \
+  do {                                     \
+    char _b[512];                          \
+    snprintf(_b, sizeof(_b), __VA_ARGS__); \
+    (f)->err = _b;                         \
+    return (code);                         \
+  } while (0)
+#define BHIP(f, expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) BFAIL(f, LSQAMD_EHIP, "%s: %s", #expr, hipGetErrorString(_e));  \
+  } while (0)
+
+size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
+  const lsqamd_config &c = f->cfg;
+  const int64_t N = c.n_data, P = c.n_param, B = f->B;
+  f->N = N; f->P = P;
+  f->ld = rupb(P + 1, 16);
+  f->ldm = (P % 128 == 0) ? P + 128 : rupb(P + 1, 16);
+  f->ncols_aug = (P % 128 == 0) ? P + 128 : P + 1;
+  f->npk = packed_doubles(P);
+  f->T = (P + 127) / 128;
+  f->nblk = f->T;
+  {  // split-K: enough workgroups over the whole batch
+    const int64_t tiles = f->T * (f->T + 1) / 2 * B;
+    int64_t s = (4096 + tiles - 1) / tiles;
+    const int64_t maxs = N / 1024 > 1 ? N / 1024 : 1;
+    if (s > maxs) s = maxs;
+    if (s > 8) s = 8;
+    if (s < 1) s = 1;
+    f->splits = (int32_t)s;
+  }
+  f->nparts = 64;
+  f->nrparts = 32;
+  CarverB cv(ws, dry);
+  f->x = cv.take<double>(N * (c.n_x > 0 ? c.n_x : 1));
+  f->ymean = cv.take<double>(N);
+  f->wdiag = cv.take<double>(N);
+  f->tape = cv.take<int32_t>(1024);
+  f->consts = cv.take<double>(256);
+  f->pmean = cv.take<double>(B * P);
+  f->pprec = cv.take<double>(B * P);
+  f->px = cv.take<double>(B * P);
+  f->pxt = cv.take<double>(B * P);
+  f->dx = cv.take<double>(B * P);
+  f->diag = cv.take<double>(B * P);
+  f->r = cv.take<double>(B * N);
+  f->J = cv.take<double>(B * N * f->ld);
+  f->slabs = cv.take<double>(B * f->splits * P * f->ldm);
+  f->red = cv.take<double>(B * (f->npk + P + 1));
+  f->M = cv.take<double>(B * P * f->ldm);
+  f->chol_work = cv.take<double>(B * f->nblk * 128 * 128);
+  f->yv = cv.take<double>(B * 2 * P);
+  f->partial = cv.take<double>(B * f->nparts * (P + 1));
+  f->spart = cv.take<double>(B * f->nrparts);
+  f->Wl = cv.take<double>(B * P * f->ldm);
+  f->cov = cv.take<double>(B * P * f->ldm);
+  f->logdet = cv.take<double>(B);
+  f->s.mu = cv.take<double>(B); f->s.chi2 = cv.take<double>(B); f->s.chi2t = cv.take<double>(B);
+  f->s.vg = cv.take<double>(B); f->s.dv2 = cv.take<double>(B);
+  f->s.nu = cv.take<int32_t>(B); f->s.bad = cv.take<int32_t>(B); f->s.iter = cv.take<int32_t>(B);
+  f->s.nit = cv.take<int32_t>(B); f->s.info = cv.take<int32_t>(B); f->s.status = cv.take<int32_t>(B);
+  f->s.active = cv.take<int32_t>(B); f->s.accepted = cv.take<int32_t>(B); f->s.enoprog = cv.take<int32_t>(B);
+  f->s.cholinfo = cv.take<int32_t>(B); f->s.nfev = cv.take<int32_t>(B); f->s.njev = cv.take<int32_t>(B);
+  f->s.n_active = cv.take<int32_t>(4);
+  f->syrk_nwork = (int32_t)syrk_work_count(P, f->splits);
+  f->syrk_map = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);
+  return cv.off;
+}
+
+int check_cfg_b(const lsqamd_config *c, int32_t B) {
+  if (!c || c->abi_version != LSQAMD_ABI_VERSION || B < 1) return LSQAMD_EINVAL;
+  if (c->n_data < 1 || c->n_param < 1) return LSQAMD_EINVAL;
+  if (c->n_blocks != 0 || c->prior_dense) return LSQAMD_EUNSUPPORTED;  // diagonal whitening + diagonal priors
+  if (c->model < LSQAMD_MODEL_COSMIX || c->model > LSQAMD_MODEL_IDENTITY) return LSQAMD_EINVAL;
+  if (c->model == LSQAMD_MODEL_TAPE && c->n_param > LSQAMD_TAPE_MAX_PARAM) return LSQAMD_EINVAL;
+  if ((c->model == LSQAMD_MODEL_COSMIX || c->model == LSQAMD_MODEL_MULTIEXP) && (c->n_param & 1))
+    return LSQAMD_EINVAL;
+  return 0;
+}
+
+ModelArgs model_args_b(const lsqamdb_fits *f, const double *p) {
+  ModelArgs m;
+  m.model = f->cfg.model;
+  m.n_data = f->N; m.n_param = f->P;
+  m.n_x = f->cfg.n_x > 0 ? f->cfg.n_x : 1;
+  m.x = f->x; m.ymean = f->ymean; m.wdiag = f->wdiag;
+  m.in_block = nullptr;
+  m.p = p; m.tape = f->tape; m.n_tape = f->n_tape; m.consts = f->consts;
+  m.n_batch = f->B; m.p_stride = f->P; m.batch_active = f->s.active;
+  return m;
+}
+
+// Jacobian, J^T J (packed), J^T f, chi2 for every active fit at its current x
+int normal_all(lsqamdb_fits *f) {
+  const int64_t P = f->P, N = f->N, B = f->B;
+  ModelArgs m = model_args_b(f, f->px);
+  m.out_stride = N * f->ld;
+  BHIP(f, launch_jacobian_ex(f->st, m, f->J, nullptr, f->ld));
+  GemmTN g;
+  g.X = f->J; g.Y = f->J; g.ldx = g.ldy = f->ld;
+  g.sx = g.sy = N * f->ld;
+  g.C = f->slabs; g.ldc = f->ldm; g.sc = (int64_t)f->splits * P * f->ldm;
+  g.M = P; g.N = P; g.K = N;
+  g.upper_only = 1;
+  g.splits = f->splits;
+  g.split_stride = P * f->ldm;
+  g.work_map = f->syrk_map; g.n_work = f->syrk_nwork;
+  g.batch = (int32_t)B; g.batch_active = f->s.active;
+  BHIP(f, launch_gemm_tn(f->st, g));
+  const int64_t red_stride = f->npk + P + 1;
+  hipLaunchKernelGGL(b_finalize_pack_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
+                     dim3(256), 0, f->st, f->slabs, f->splits, P * f->ldm, (int64_t)f->splits * P * f->ldm, P,
+                     f->ldm, f->T, f->red, red_stride, f->s.active);
+  int64_t nchunks = f->nparts;
+  if (nchunks > N) nchunks = N;
+  const int64_t rpc = (N + nchunks - 1) / nchunks;
+  nchunks = (N + rpc - 1) / rpc;
+  hipLaunchKernelGGL(b_colsum_stage1, dim3((unsigned)((P + 1 + 511) / 512), (unsigned)nchunks, (unsigned)B),
+                     dim3(256), 0, f->st, f->J, N, f->ld, P + 1, P, rpc, N * f->ld, f->partial,
+                     (int64_t)f->nparts * (P + 1), f->s.active);
+  hipLaunchKernelGGL(b_colsum_stage2, dim3((unsigned)((P + 1 + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
+                     f->partial, nchunks, P + 1, (int64_t)f->nparts * (P + 1), f->red + f->npk, red_stride,
+                     f->s.active);
+  if (f->cfg.has_prior)
+    hipLaunchKernelGGL(b_prior_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->pprec, f->pmean,
+                       f->px, f->red, red_stride, f->red + f->npk, red_stride, f->s.active);
+  BHIP(f, hipGetLastError());
+  return 0;
+}
+
+int round_all(lsqamdb_fits *f) {
+  const int64_t P = f->P, N = f->N, B = f->B;
+  const int64_t red_stride = f->npk + P + 1, m_stride = P * f->ldm, w_stride = f->nblk * 128 * 128;
+  const unsigned ntile = (unsigned)(f->T * (f->T + 1) / 2);
+  hipLaunchKernelGGL(b_build_damped_kernel, dim3(ntile, 16, (unsigned)B), dim3(256), 0, f->st, f->red,
+                     red_stride, P, f->T, f->ldm, f->s.mu, f->diag, f->red + f->npk, red_stride, f->M, m_stride,
+                     f->s.active, 1);
+  BHIP(f, potrf_upper_batched(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->s.cholinfo, (int32_t)B,
+                              m_stride, w_stride, f->s.active));
+  hipLaunchKernelGGL(b_extract_y_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
+                     f->M, m_stride, f->ldm, P, f->yv, 2 * P, f->s.active);
+  BHIP(f, backsolve_upper_batched(f->st, f->M, P, f->ldm, f->chol_work, f->yv, (int32_t)B, m_stride, w_stride,
+                                  2 * P, f->s.active));
+  hipLaunchKernelGGL(b_trial_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->yv, 2 * P, f->px,
+                     f->red + f->npk, red_stride, f->diag, f->dx, f->pxt, f->s);
+  ModelArgs m = model_args_b(f, f->pxt);
+  m.out_stride = N;
+  BHIP(f, launch_residual_ex(f->st, m, f->r, nullptr));
+  hipLaunchKernelGGL(b_sumsq_stage1, dim3((unsigned)f->nrparts, (unsigned)B), dim3(256), 0, f->st, f->r, N, N,
+                     f->spart, f->nrparts, f->s.active);
+  hipLaunchKernelGGL(b_sumsq_stage2, dim3((unsigned)B), dim3(256), 0, f->st, f->spart, f->nrparts, P, f->pprec,
+                     f->pmean, f->pxt, f->cfg.has_prior, f->s);
+  hipLaunchKernelGGL(b_decide_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, f->st, (int)B,
+                     f->opt.factor_up, f->opt.factor_down, f->s);
+  hipLaunchKernelGGL(b_commit_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, f->st, P,
+                     f->px, f->pxt, f->s);
+  int rc = normal_all(f);
+  if (rc) return rc;
+  hipLaunchKernelGGL(b_post_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->red, red_stride,
+                     f->red + f->npk, red_stride, f->diag, f->px, f->dx, f->opt.scaler, f->opt.xtol, f->opt.gtol,
+                     f->opt.maxit, f->s);
+  hipLaunchKernelGGL(b_count_kernel, dim3(1), dim3(256), 0, f->st, (int)B, f->s);
+  BHIP(f, hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t lsqamdb_workspace_bytes(const lsqamd_config *cfg, int32_t n_fits) {
+  if (check_cfg_b(cfg, n_fits) != 0) return 0;
+  lsqamdb_fits tmp;
+  tmp.cfg = *cfg;
+  tmp.B = n_fits;
+  return carve_b(&tmp, nullptr, true);
+}
+
+int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace, size_t workspace_bytes,
+                   void *stream, lsqamdb_fits **out) {
+  if (!out) return LSQAMD_EINVAL;
+  *out = nullptr;
+  const int rc = check_cfg_b(cfg, n_fits);
+  if (rc) return rc;
+  if (!dev_workspace || (reinterpret_cast<uintptr_t>(dev_workspace) & 255)) return LSQAMD_EINVAL;
+  lsqamdb_fits *f = new (std::nothrow) lsqamdb_fits;
+  if (!f) return LSQAMD_ENOMEM;
+  f->cfg = *cfg;
+  f->B = n_fits;
+  f->user_st = reinterpret_cast<hipStream_t>(stream);
+  if (carve_b(f, dev_workspace, true) > workspace_bytes) { delete f; return LSQAMD_ENOMEM; }
+  carve_b(f, dev_workspace, false);
+  // own (capturable) stream: the caller's may be the legacy default stream
+  if (hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) != hipSuccess) { delete f; return LSQAMD_EHIP; }
+  f->opt.xtol = 1e-8; f->opt.gtol = 1e-10; f->opt.ftol = 1e-10;
+  f->opt.maxit = 1000; f->opt.scaler = LSQAMD_SCALE_MORE; f->opt.solver = LSQAMD_SOLVER_CHOLESKY;
+  f->opt.factor_up = 3.0; f->opt.factor_down = 2.0;
+  std::vector<int32_t> wm(4 * (size_t)f->syrk_nwork);
+  syrk_work_fill(f->P, f->splits, wm.data());
+  if (hipMemcpyAsync(f->syrk_map, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice, f->st) != hipSuccess ||
+      hipMemsetAsync(f->M, 0, sizeof(double) * (size_t)(f->B * f->P * f->ldm), f->st) != hipSuccess ||
+      hipStreamSynchronize(f->st) != hipSuccess) {
+    (void)hipStreamDestroy(f->st);
+    delete f;
+    return LSQAMD_EHIP;
+  }
+  *out = f;
+  return 0;
+}
+
+int lsqamdb_destroy(lsqamdb_fits *f) {
+  if (!f) return 0;
+  (void)hipStreamSynchronize(f->st);
+  if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
+  if (f->graph) (void)hipGraphDestroy(f->graph);
+  (void)hipStreamDestroy(f->st);
+  delete f;
+  return 0;
+}
+
+const char *lsqamdb_last_error(const lsqamdb_fits *f) { return f ? f->err.c_str() : "null handle"; }
+
+int lsqamdb_set_x(lsqamdb_fits *f, const double *x, int64_t n_rows, int32_t n_x) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!x || n_rows != f->N || n_x != (f->cfg.n_x > 0 ? f->cfg.n_x : 1)) BFAIL(f, LSQAMD_EINVAL, "set_x: shape");
+  BHIP(f, hipMemcpy(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice));
+  f->have_x = true;
+  return 0;
+}
+
+int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!code || n_code < 1 || n_code > 1024 || n_consts < 0 || n_consts > 256) BFAIL(f, LSQAMD_EINVAL, "set_tape: sizes");
+  BHIP(f, hipMemcpy(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice));
+  if (n_consts > 0) BHIP(f, hipMemcpy(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice));
+  f->n_tape = n_code;
+  f->have_tape = true;
+  return 0;
+}
+
+/* shared data: ymean[N], wdiag[N] = 1/sdev (diagonal whitening only) */
+int lsqamdb_set_data(lsqamdb_fits *f, const double *ymean, const double *wdiag) {
+  if (!f || !ymean || !wdiag) return LSQAMD_EINVAL;
+  BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->wdiag, wdiag, sizeof(double) * f->N, hipMemcpyHostToDevice));
+  f->have_data = true;
+  return 0;
+}
+
+/* per-fit diagonal priors: mean[B*P], prec[B*P] = 1/sdev^2 */
+int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) {
+  if (!f || !mean || !prec) return LSQAMD_EINVAL;
+  if (!f->cfg.has_prior) BFAIL(f, LSQAMD_EINVAL, "set_priors: config has no prior");
+  BHIP(f, hipMemcpy(f->pmean, mean, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->pprec, prec, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
+  f->have_prior = true;
+  return 0;
+}
+
+int lsqamdb_set_options(lsqamdb_fits *f, const lsqamd_options *opt) {
+  if (!f || !opt) return LSQAMD_EINVAL;
+  if (opt->xtol < 0 || opt->gtol < 0 || opt->maxit < 0 || opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT)
+    BFAIL(f, LSQAMD_EINVAL, "set_options: bad value");
+  f->opt = *opt;
+  return 0;
+}
+
+/* run all fits from p0[B*P]; summaries[B] (may be NULL).  use_graph != 0: capture one round in a
+ * hipGraph after the first eager round and replay it. */
+int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, int32_t use_graph) {
+  if (!f || !p0) return LSQAMD_EINVAL;
+  if (!f->have_data || (f->cfg.has_prior && !f->have_prior) ||
+      (f->cfg.model != LSQAMD_MODEL_IDENTITY && !f->have_x) || (f->cfg.model == LSQAMD_MODEL_TAPE && !f->have_tape))
+    BFAIL(f, LSQAMD_EINVAL, "run: inputs missing");
+  const int64_t P = f->P, B = f->B;
+  (void)hipStreamSynchronize(f->user_st);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, f->st);
+  BHIP(f, hipMemcpyAsync(f->px, p0, sizeof(double) * B * P, hipMemcpyHostToDevice, f->st));
+  {  // everything active for the initial evaluation
+    std::vector<int32_t> ones((size_t)B, 1);
+    BHIP(f, hipMemcpyAsync(f->s.active, ones.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, f->st));
+    BHIP(f, hipStreamSynchronize(f->st));
+  }
+  int rc = normal_all(f);
+  if (rc) return rc;
+  hipLaunchKernelGGL(b_init_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->red, f->npk + P + 1,
+                     f->red + f->npk, f->npk + P + 1, f->diag, f->opt.scaler, f->s);
+  f->rounds = 0;
+  f->graph_used = 0;
+  // kernel arguments (tolerances, maxit, factors) are baked into graph nodes: re-capture per run
+  if (f->gexec) { (void)hipGraphExecDestroy(f->gexec); f->gexec = nullptr; }
+  if (f->graph) { (void)hipGraphDestroy(f->graph); f->graph = nullptr; }
+  int32_t n_active = (int32_t)B;
+  const int64_t max_rounds = (int64_t)(f->opt.maxit > 0 ? f->opt.maxit : 0) * 17 + 1;
+  while (n_active > 0 && f->rounds < max_rounds && f->opt.maxit > 0) {
+    if (use_graph && f->rounds >= 1) {
+      if (!f->gexec) {
+        hipError_t e = hipStreamBeginCapture(f->st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+          rc = round_all(f);
+          hipGraph_t gr = nullptr;
+          e = hipStreamEndCapture(f->st, &gr);
+          if (rc) return rc;
+          if (e == hipSuccess && gr && hipGraphInstantiate(&f->gexec, gr, nullptr, nullptr, 0) == hipSuccess) {
+            f->graph = gr;
+          } else {
+            f->gexec = nullptr;
+            use_graph = 0;
+          }
+        } else {
+          use_graph = 0;
+        }
+        (void)hipGetLastError();
+      }
+      if (f->gexec) {
+        BHIP(f, hipGraphLaunch(f->gexec, f->st));
+        f->graph_used += 1;
+      } else {
+        rc = round_all(f);
+        if (rc) return rc;
+      }
+    } else {
+      rc = round_all(f);
+      if (rc) return rc;
+    }
+    f->rounds += 1;
+    BHIP(f, hipMemcpyAsync(&n_active, f->s.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+    BHIP(f, hipStreamSynchronize(f->st));
+  }
+  (void)hipEventRecord(e1, f->st);
+  (void)hipEventSynchronize(e1);
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  f->ran = true;
+  f->have_cov = false;
+  if (summaries) {
+    std::vector<double> mu((size_t)B), chi2((size_t)B);
+    std::vector<int32_t> nit((size_t)B), info((size_t)B), status((size_t)B), nfev((size_t)B), njev((size_t)B);
+    BHIP(f, hipMemcpy(mu.data(), f->s.mu, sizeof(double) * B, hipMemcpyDeviceToHost));
+    BHIP(f, hipMemcpy(chi2.data(), f->s.chi2, sizeof(double) * B, hipMemcpyDeviceToHost));
+    BHIP(f, hipMemcpy(nit.data(), f->s.nit, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    BHIP(f, hipMemcpy(info.data(), f->s.info, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    BHIP(f, hipMemcpy(status.data(), f->s.status, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    BHIP(f, hipMemcpy(nfev.data(), f->s.nfev, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    BHIP(f, hipMemcpy(njev.data(), f->s.njev, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    for (int64_t b = 0; b < B; ++b) {
+      lsqamd_summary &s = summaries[b];
+      std::memset(&s, 0, sizeof(s));
+      s.status = status[b] == -2 ? LSQAMD_EMAXITER : status[b];
+      s.info = info[b];
+      s.stopping_criterion = (info[b] >= 0 && info[b] <= 3) ? info[b] : (info[b] == 27 ? 4 : 0);
+      s.nit = nit[b]; s.nfev = nfev[b]; s.njev = njev[b]; s.ntrial = nfev[b] - 1;
+      s.chi2 = chi2[b]; s.mu = mu[b];
+      s.logdet_jtj = NAN;
+      s.t_run_ms = ms;
+      s.t_setup_ms = (double)f->graph_used;  // rounds replayed from the captured graph
+    }
+  }
+  return 0;
+}
+
+int lsqamdb_get_x(lsqamdb_fits *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  if (cap < (size_t)(f->B * f->P)) BFAIL(f, LSQAMD_ECAPACITY, "get_x: need %lld", (long long)(f->B * f->P));
+  BHIP(f, hipMemcpy(out, f->px, sizeof(double) * f->B * f->P, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+/* (J^T J)^-1 of every fit at its final point + log det(J^T J); results stay on the device */
+int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!f->ran) BFAIL(f, LSQAMD_EINVAL, "covariance: run first");
+  const int64_t P = f->P, B = f->B, m_stride = P * f->ldm, w_stride = f->nblk * 128 * 128;
+  const int64_t red_stride = f->npk + P + 1;
+  const unsigned ntile = (unsigned)(f->T * (f->T + 1) / 2);
+  hipLaunchKernelGGL(b_build_damped_kernel, dim3(ntile, 16, (unsigned)B), dim3(256), 0, f->st, f->red,
+                     red_stride, P, f->T, f->ldm, f->s.mu, f->diag, (const double *)nullptr, red_stride, f->M,
+                     m_stride, (const int32_t *)nullptr, 0);
+  BHIP(f, potrf_upper_batched(f->st, f->M, P, f->ldm, P, f->chol_work, f->s.cholinfo, (int32_t)B, m_stride,
+                              w_stride, nullptr));
+  hipLaunchKernelGGL(b_logdiag_kernel, dim3((unsigned)B), dim3(256), 0, f->st, f->M, m_stride, P, f->ldm,
+                     f->logdet);
+  BHIP(f, trtri_upper_to_lower_T_batched(f->st, f->M, P, f->ldm, f->chol_work, f->Wl, f->ldm, (int32_t)B,
+                                         m_stride, w_stride, m_stride));
+  GemmTN g;
+  g.X = f->Wl; g.Y = f->Wl; g.ldx = g.ldy = f->ldm; g.sx = g.sy = m_stride;
+  g.C = f->cov; g.ldc = f->ldm; g.sc = m_stride;
+  g.M = P; g.N = P; g.K = P;
+  g.upper_only = 1; g.xy_lower_tri = 1;
+  g.batch = (int32_t)B;
+  BHIP(f, launch_gemm_tn(f->st, g));
+  hipLaunchKernelGGL(b_symmetrize_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)P, (unsigned)B), dim3(256), 0,
+                     f->st, f->cov, m_stride, P, f->ldm);
+  BHIP(f, hipStreamSynchronize(f->st));
+  f->have_cov = true;
+  if (logdet_out) {
+    if (cap < (size_t)B) BFAIL(f, LSQAMD_ECAPACITY, "covariance: need %lld", (long long)B);
+    BHIP(f, hipMemcpy(logdet_out, f->logdet, sizeof(double) * B, hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+int lsqamdb_get_cov(lsqamdb_fits *f, int32_t fit, double *out, size_t cap) {
+  if (!f || !out || fit < 0 || fit >= f->B) return LSQAMD_EINVAL;
+  const int64_t P = f->P;
+  if (cap < (size_t)(P * P)) BFAIL(f, LSQAMD_ECAPACITY, "get_cov: need %lld", (long long)(P * P));
+  if (!f->have_cov) {
+    const int rc = lsqamdb_covariance(f, nullptr, 0);
+    if (rc) return rc;
+  }
+  BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov + (int64_t)fit * P * f->ldm, sizeof(double) * f->ldm,
+                      sizeof(double) * P, (size_t)P, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int32_t lsqamdb_rounds(const lsqamdb_fits *f) { return f ? f->rounds : -1; }
+
+}  // extern "C"

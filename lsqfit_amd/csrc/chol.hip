@@ -198,8 +198,15 @@ __device__ __forceinline__ void lds_mma(const double *L, const double *R, double
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, int nb, double *uinv,
-                                                        int32_t *info, int32_t k0, long long *dbg) {
+                                                        int32_t *info, int32_t k0, long long *dbg,
+                                                        int64_t strideA, int64_t strideW,
+                                                        const int32_t *active) {
   extern __shared__ __attribute__((aligned(16))) double s[];
+  // batched use: workgroup b factors matrix b
+  if (active && !active[blockIdx.x]) return;
+  A += (int64_t)blockIdx.x * strideA;
+  uinv += (int64_t)blockIdx.x * strideW;
+  info += blockIdx.x;
   double *dinv = s + NB * PLD;
   double *wbuf = dinv + NB;          // 32 x WLD copy of inv(L11) of the current sub-block
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -338,7 +345,8 @@ long long *g_potf2_dbg = nullptr;  // device buffer of 32 cycle stamps (LSQAMD_P
 static constexpr size_t POTF2_LDS = (size_t)(NB * PLD + NB + SB * WLD) * sizeof(double);  // 140 KiB
 
 static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, double *uinv,
-                               int32_t *info, int32_t k0) {
+                               int32_t *info, int32_t k0, int32_t batch = 1, int64_t strideA = 0,
+                               int64_t strideW = 0, const int32_t *active = nullptr) {
   if (!g_potf2_attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
@@ -348,48 +356,57 @@ static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, d
     if (e != hipSuccess) return e;
     g_potf2_attr = true;
   }
-  const bool vec = !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15);
+  const bool vec = !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15) && !(strideA & 1);
   if (vec)
-    hipLaunchKernelGGL(potf2_inv_kernel<true>, dim3(1), dim3(256), POTF2_LDS, st, A, lda, nb, uinv, info,
-                       k0, g_potf2_dbg);
+    hipLaunchKernelGGL(potf2_inv_kernel<true>, dim3((unsigned)batch), dim3(256), POTF2_LDS, st, A, lda, nb,
+                       uinv, info, k0, g_potf2_dbg, strideA, strideW, active);
   else
-    hipLaunchKernelGGL(potf2_inv_kernel<false>, dim3(1), dim3(256), POTF2_LDS, st, A, lda, nb, uinv, info,
-                       k0, g_potf2_dbg);
+    hipLaunchKernelGGL(potf2_inv_kernel<false>, dim3((unsigned)batch), dim3(256), POTF2_LDS, st, A, lda, nb,
+                       uinv, info, k0, g_potf2_dbg, strideA, strideW, active);
   return hipGetLastError();
 }
 
-hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
-                       double *work, int32_t *dev_info) {
-  hipError_t e = hipMemsetAsync(dev_info, 0, sizeof(int32_t), st);
+hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
+                               double *work, int32_t *dev_info, int32_t batch, int64_t strideA,
+                               int64_t strideW, const int32_t *active) {
+  hipError_t e = hipMemsetAsync(dev_info, 0, sizeof(int32_t) * (size_t)batch, st);
   if (e != hipSuccess) return e;
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int nb = (int)((n - k0) < NB ? (n - k0) : NB);
     double *uinv = work + (k0 / NB) * NB * NB;
-    e = launch_potf2(st, A + k0 * lda + k0, lda, nb, uinv, dev_info, (int32_t)k0);
+    e = launch_potf2(st, A + k0 * lda + k0, lda, nb, uinv, dev_info, (int32_t)k0, batch, strideA, strideW,
+                     active);
     if (e != hipSuccess) return e;
     const int64_t rest = n_cols - (k0 + nb);
     if (rest <= 0) continue;
     GemmTN p;  // row panel: U[k, k+nb:] = inv(U_kk)^T * A[k, k+nb:]   (in place)
-    p.X = uinv; p.ldx = NB;
-    p.Y = A + k0 * lda + k0 + nb; p.ldy = lda;
-    p.C = A + k0 * lda + k0 + nb; p.ldc = lda;
+    p.X = uinv; p.ldx = NB; p.sx = strideW;
+    p.Y = A + k0 * lda + k0 + nb; p.ldy = lda; p.sy = strideA;
+    p.C = A + k0 * lda + k0 + nb; p.ldc = lda; p.sc = strideA;
     p.M = nb; p.N = rest; p.K = nb;
     p.x_upper_tri = 1;
+    p.batch = batch; p.batch_active = active;
     e = launch_gemm_tn(st, p);
     if (e != hipSuccess) return e;
     const int64_t mrest = n - (k0 + nb);
     if (mrest <= 0) continue;
     GemmTN t;  // trailing: A[k+nb:, k+nb:] -= panel^T panel  (upper tiles only)
-    t.X = p.C; t.ldx = lda;
-    t.Y = p.C; t.ldy = lda;
-    t.C = A + (k0 + nb) * lda + (k0 + nb); t.ldc = lda;
+    t.X = p.C; t.ldx = lda; t.sx = strideA;
+    t.Y = p.C; t.ldy = lda; t.sy = strideA;
+    t.C = A + (k0 + nb) * lda + (k0 + nb); t.ldc = lda; t.sc = strideA;
     t.M = mrest; t.N = rest; t.K = nb;
     t.alpha = -1.0; t.beta = 1.0;
     t.upper_only = 1;
+    t.batch = batch; t.batch_active = active;
     e = launch_gemm_tn(st, t);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
+}
+
+hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
+                       double *work, int32_t *dev_info) {
+  return potrf_upper_batched(st, A, n, lda, n_cols, work, dev_info, 1, 0, 0, nullptr);
 }
 
 // ---- back substitution U v = y ------------------------------------------------------
@@ -407,7 +424,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 // reduction, so a step costs about two memory round trips instead of ~40.
 __global__ __launch_bounds__(256) void backsolve_step_kernel(const double *A, int64_t lda, int64_t k0,
                                                              int nb, const double *uinv, double *y,
-                                                             double *v) {
+                                                             double *v, int64_t strideA, int64_t strideW,
+                                                             int64_t strideY, const int32_t *active) {
+  if (active && !active[blockIdx.y]) return;
+  A += (int64_t)blockIdx.y * strideA;
+  uinv += (int64_t)blockIdx.y * strideW;
+  y += (int64_t)blockIdx.y * strideY;
+  v += (int64_t)blockIdx.y * strideY;
   __shared__ double vk[NB];
   __shared__ double yk[NB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -451,19 +474,25 @@ __global__ __launch_bounds__(256) void backsolve_step_kernel(const double *A, in
   }
 }
 
-hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
-                           const double *work, double *y_inout) {
-  // y_inout: [0,n) = y (destroyed), [n, 2n) = v on return
+hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                                   const double *work, double *y_inout, int32_t batch, int64_t strideA,
+                                   int64_t strideW, int64_t strideY, const int32_t *active) {
+  // y_inout (per batch entry): [0,n) = y (destroyed), [n, 2n) = v on return
   double *y = y_inout, *v = y_inout + n;
   const int64_t nblk = (n + NB - 1) / NB;
   for (int64_t kb = nblk - 1; kb >= 0; --kb) {
     const int64_t k0 = kb * NB;
     const int nb = (int)((n - k0) < NB ? (n - k0) : NB);
     const unsigned grid = 1 + (unsigned)((k0 + BS_ROWS - 1) / BS_ROWS);
-    hipLaunchKernelGGL(backsolve_step_kernel, dim3(grid), dim3(256), 0, st, A, lda, k0, nb,
-                       work + kb * NB * NB, y, v);
+    hipLaunchKernelGGL(backsolve_step_kernel, dim3(grid, (unsigned)batch), dim3(256), 0, st, A, lda, k0, nb,
+                       work + kb * NB * NB, y, v, strideA, strideW, strideY, active);
   }
   return hipGetLastError();
+}
+
+hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                           const double *work, double *y_inout) {
+  return backsolve_upper_batched(st, A, n, lda, work, y_inout, 1, 0, 0, 0, nullptr);
 }
 
 // ---- W = U^-T (lower triangular, row-major) -------------------------------------------
@@ -479,33 +508,44 @@ hipError_t launch_set_identity(hipStream_t st, double *A, int64_t P, int64_t ld)
   return hipGetLastError();
 }
 
-hipError_t trtri_upper_to_lower_T(hipStream_t st, const double *A, int64_t n, int64_t lda,
-                                  const double *work, double *W, int64_t ldw) {
-  hipError_t e = launch_set_identity(st, W, n, ldw);
-  if (e != hipSuccess) return e;
+hipError_t trtri_upper_to_lower_T_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                                          const double *work, double *W, int64_t ldw, int32_t batch,
+                                          int64_t strideA, int64_t strideW, int64_t strideWl) {
+  hipError_t e = hipSuccess;
+  for (int32_t b = 0; b < batch; ++b) {
+    e = launch_set_identity(st, W + b * strideWl, n, ldw);
+    if (e != hipSuccess) return e;
+  }
   for (int64_t k0 = 0; k0 < n; k0 += NB) {
     const int nb = (int)((n - k0) < NB ? (n - k0) : NB);
     const double *uinv = work + (k0 / NB) * NB * NB;
     GemmTN p;  // W[k, 0:k0+nb] = inv(U_kk)^T R[k, 0:k0+nb]  (in place)
-    p.X = uinv; p.ldx = NB;
-    p.Y = W + k0 * ldw; p.ldy = ldw;
-    p.C = W + k0 * ldw; p.ldc = ldw;
+    p.X = uinv; p.ldx = NB; p.sx = strideW;
+    p.Y = W + k0 * ldw; p.ldy = ldw; p.sy = strideWl;
+    p.C = W + k0 * ldw; p.ldc = ldw; p.sc = strideWl;
     p.M = nb; p.N = k0 + nb; p.K = nb;
     p.x_upper_tri = 1;
+    p.batch = batch;
     e = launch_gemm_tn(st, p);
     if (e != hipSuccess) return e;
     const int64_t mrest = n - (k0 + nb);
     if (mrest <= 0) continue;
     GemmTN t;  // R[k+nb:, 0:k0+nb] -= U[k, k+nb:]^T W[k, 0:k0+nb]
-    t.X = A + k0 * lda + k0 + nb; t.ldx = lda;
-    t.Y = W + k0 * ldw; t.ldy = ldw;
-    t.C = W + (k0 + nb) * ldw; t.ldc = ldw;
+    t.X = A + k0 * lda + k0 + nb; t.ldx = lda; t.sx = strideA;
+    t.Y = W + k0 * ldw; t.ldy = ldw; t.sy = strideWl;
+    t.C = W + (k0 + nb) * ldw; t.ldc = ldw; t.sc = strideWl;
     t.M = mrest; t.N = k0 + nb; t.K = nb;
     t.alpha = -1.0; t.beta = 1.0;
+    t.batch = batch;
     e = launch_gemm_tn(st, t);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
+}
+
+hipError_t trtri_upper_to_lower_T(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                                  const double *work, double *W, int64_t ldw) {
+  return trtri_upper_to_lower_T_batched(st, A, n, lda, work, W, ldw, 1, 0, 0, 0);
 }
 
 __global__ __launch_bounds__(256) void logdiag_kernel(const double *A, int64_t n, int64_t lda,

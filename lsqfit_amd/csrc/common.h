@@ -29,6 +29,7 @@ struct GemmTN {
   const int32_t *work_map = nullptr;  // device int4 list (tm, tn, split, 0), see syrk_work_fill
   int32_t n_work = 0;
   int32_t force_generic = 0;       // A/B switch: never take the direct-to-LDS interior kernel
+  const int32_t *batch_active = nullptr;  // device flags[batch]: 0 = skip that batch entry
 };
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
 int64_t syrk_work_count(int64_t P, int32_t splits);
@@ -43,6 +44,17 @@ size_t potrf_work_bytes(int64_t n);
 // *dev_info (device int32) is set to (first failing pivot + 1) if not positive definite.
 hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
                        double *work, int32_t *dev_info);
+// batched: matrix b at A + b*strideA, block inverses at work + b*strideW, info[b];
+// entries with active[b] == 0 (if given) are skipped
+hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
+                               double *work, int32_t *dev_info, int32_t batch, int64_t strideA,
+                               int64_t strideW, const int32_t *active);
+hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                                   const double *work, double *y_inout, int32_t batch, int64_t strideA,
+                                   int64_t strideW, int64_t strideY, const int32_t *active);
+hipError_t trtri_upper_to_lower_T_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
+                                          const double *work, double *Wl, int64_t ldw, int32_t batch,
+                                          int64_t strideA, int64_t strideW, int64_t strideWl);
 // v = U^-1 y (y = column `ycol` of A rows 0..n-1), using the diagonal-block inverses in work
 hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
                            const double *work, double *y_inout);
@@ -66,6 +78,10 @@ struct ModelArgs {
   const int32_t *tape = nullptr;
   int32_t n_tape = 0;
   const double *consts = nullptr;
+  // batched fits sharing (x, ymean, wdiag): fit b uses p + b*p_stride and writes at + b*out_stride
+  int32_t n_batch = 1;
+  int64_t p_stride = 0, out_stride = 0;
+  const int32_t *batch_active = nullptr;
 };
 // r_w[i] = w_i (f(x_i;p) - y_i) for 1x1 rows; r_raw[i] = f - y for rows inside blocks
 hipError_t launch_residual_ex(hipStream_t st, const ModelArgs &m, double *r_w, double *r_raw);

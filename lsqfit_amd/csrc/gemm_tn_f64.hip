@@ -49,6 +49,7 @@ struct GemmDev {
   int64_t kchunk, split_stride;
   const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
   int32_t n_work;
+  const int32_t *batch_active;  // optional: skip batch entries whose flag is 0
 };
 
 // Branch-free staging loads.  Out-of-range rows/columns are CLAMPED to a valid
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
   if (g.upper_only && n0 + BN <= m0) return;  // tile strictly below the diagonal
 
   const int64_t b = blockIdx.z;
+  if (g.batch_active && !g.batch_active[b]) return;
   const double *X = g.X + b * g.sx;
   const double *Y = g.Y + b * g.sy;
   double *C = g.C + b * g.sc + (int64_t)split * g.split_stride;
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   if (g.upper_only && n0 + BN <= m0) return;
   const int64_t b = blockIdx.z;
+  if (g.batch_active && !g.batch_active[b]) return;
   double *C = g.C + b * g.sc + (int64_t)split * g.split_stride;
   int64_t kb = (int64_t)split * g.kchunk;
   int64_t ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
@@ -369,8 +372,9 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
   g.work_map = a.work_map;
   g.n_work = a.n_work;
+  g.batch_active = a.batch_active;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
-  if (a.work_map) grid = dim3((unsigned)a.n_work, 1, 1);
+  if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
                         !a.force_generic;
   if (interior)

@@ -36,6 +36,8 @@ struct ModelDev {
   double *out_raw;  // raw destination for rows inside correlated blocks
   int64_t ld;
   int32_t p_in_lds;
+  int64_t p_stride, out_stride;
+  const int32_t *batch_active;
 };
 
 template <int MODEL, bool JAC>
@@ -43,6 +45,10 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
   extern __shared__ __attribute__((aligned(16))) double sp[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t P = m.n_param, K = P / 2;
+  if (m.batch_active && !m.batch_active[blockIdx.y]) return;
+  m.p += (int64_t)blockIdx.y * m.p_stride;
+  m.out_w += (int64_t)blockIdx.y * m.out_stride;
+  if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const double *pp = m.p;
   if (m.p_in_lds) {
     for (int64_t i = tid; i < P; i += 256) sp[i] = m.p[i];
@@ -89,6 +95,10 @@ template <bool JAC>
 __global__ __launch_bounds__(256) void identity_model_kernel(ModelDev m) {
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= m.n_data) return;
+  if (m.batch_active && !m.batch_active[blockIdx.y]) return;
+  m.p += (int64_t)blockIdx.y * m.p_stride;
+  m.out_w += (int64_t)blockIdx.y * m.out_stride;
+  if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const bool blk = m.in_block && m.in_block[row];
   const double w = blk ? 1.0 : m.wdiag[row];
   double *dst = blk ? m.out_raw : m.out_w;
@@ -107,6 +117,10 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
   constexpr int MP = LSQAMD_TAPE_MAX_PARAM, MS = LSQAMD_TAPE_MAX_STACK;
   const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (row >= m.n_data) return;
+  if (m.batch_active && !m.batch_active[blockIdx.y]) return;
+  m.p += (int64_t)blockIdx.y * m.p_stride;
+  m.out_w += (int64_t)blockIdx.y * m.out_stride;
+  if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const int P = (int)m.n_param;
   double sv[MS];
   double sd[JAC ? MS : 1][JAC ? MP : 1];
@@ -199,6 +213,8 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
   m.in_block = a.in_block; m.tape = a.tape;
   m.out_w = out_w; m.out_raw = out_raw; m.ld = ld;
   m.p_in_lds = 0;
+  m.p_stride = a.p_stride; m.out_stride = a.out_stride; m.batch_active = a.batch_active;
+  const unsigned nb = (unsigned)(a.n_batch < 1 ? 1 : a.n_batch);
   switch (a.model) {
     case LSQAMD_MODEL_COSMIX:
     case LSQAMD_MODEL_MULTIEXP: {
@@ -210,19 +226,19 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
       int64_t blocks = (a.n_data + 3) / 4;
       if (blocks > 4096) blocks = 4096;
       if (a.model == LSQAMD_MODEL_COSMIX)
-        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_COSMIX, JAC>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_COSMIX, JAC>), dim3((unsigned)blocks, nb),
                            dim3(256), lds, st, m);
       else
-        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_MULTIEXP, JAC>), dim3((unsigned)blocks),
+        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_MULTIEXP, JAC>), dim3((unsigned)blocks, nb),
                            dim3(256), lds, st, m);
       break;
     }
     case LSQAMD_MODEL_IDENTITY:
-      hipLaunchKernelGGL((identity_model_kernel<JAC>), dim3((unsigned)((a.n_data + 255) / 256)),
+      hipLaunchKernelGGL((identity_model_kernel<JAC>), dim3((unsigned)((a.n_data + 255) / 256), nb),
                          dim3(256), 0, st, m);
       break;
     case LSQAMD_MODEL_TAPE:
-      hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64)), dim3(64),
+      hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64), nb), dim3(64),
                          0, st, m);
       break;
     default:

@@ -18,7 +18,7 @@ def libpath():
 def header_symbols():
     text = open(os.path.join(ROOT, 'include', 'lsqfit_amd.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
-    return sorted(set(re.findall(r'\b(lsqamd_[A-Za-z_0-9]+)\s*\(', text)) - {'lsqamd_reduce_fn'})
+    return sorted(set(re.findall(r'\b(lsqamdb?_[A-Za-z_0-9]+)\s*\(', text)) - {'lsqamd_reduce_fn'})
 
 
 def test_every_declared_symbol_is_exported(libpath):

@@ -4,7 +4,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/lsqfit_amd/build/dbg
 mkdir -p $OUT
-for f in gemm_tn_f64 chol model vecops api; do
+for f in gemm_tn_f64 chol model vecops api batch; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DLSQAMD_POTF2_TIMING -c $ROOT/lsqfit_amd/csrc/$f.hip -o $OUT/$f.o &
 done
 wait
