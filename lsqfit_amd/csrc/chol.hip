@@ -105,12 +105,20 @@ __device__ __noinline__ void chol32_wave(double *s, int j0, double *dinv, double
       first_bad = (!ok && first_bad < 0) ? j + 1 : first_bad;
       ynext = rsqrt_refined(ok ? dn : 1.0);
     }
+    // rank-1 update in groups of 8 rows: the 8 broadcasts first (16 distinct SGPRs), then the
+    // 8 FMAs, so no FMA waits on the readlane right in front of it
 #pragma unroll
-    for (int i = j + 1; i < SB; ++i) {
-      col[i] -= readlane_d(u, i) * u;
-      if (((i - j) & 7) == 0) __builtin_amdgcn_sched_barrier(0);
+    for (int i0 = j + 1; i0 < SB; i0 += 8) {
+      double ub[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (i0 + t < SB) ub[t] = readlane_d(u, i0 + t);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (i0 + t < SB) col[i0 + t] -= ub[t] * u;
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
     y = ynext;
   }
   if (first_bad >= 0 && lane == 0) atomicCAS(info, 0, k0 + j0 + first_bad + 1);
