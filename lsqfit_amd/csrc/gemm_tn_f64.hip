@@ -333,6 +333,144 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   }
 }
 
+// 64 x 64-tile variant for the latency-bound contractions of the Cholesky family (K = 128,
+// a handful of 128-tiles): four times the workgroups, a quarter of the MFMA chain each.
+// Same contract as gemm_tn_f64_kernel (edges, triangular flags, beta, batch).
+constexpr int TS = 64;
+constexpr int LDS_S = TS + 16;
+constexpr int STAGE_S = 2 * BK * LDS_S;
+constexpr size_t GEMM_LDS_BYTES_S = 2 * STAGE_S * sizeof(double);
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 4) void gemm_tn_f64_small_kernel(GemmDev g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x % g.tiles_n;
+  const int split = blockIdx.y;
+  const int64_t m0 = (int64_t)tm * TS, n0 = (int64_t)tn * TS;
+  if (g.upper_only && n0 + TS <= m0) return;
+  const int64_t b = blockIdx.z;
+  if (g.batch_active && !g.batch_active[b]) return;
+  const double *X = g.X + b * g.sx;
+  const double *Y = g.Y + b * g.sy;
+  double *C = g.C + b * g.sc + (int64_t)split * g.split_stride;
+  int64_t kb = (int64_t)split * g.kchunk;
+  int64_t ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
+  if (g.x_upper_tri) {
+    const int64_t lim = m0 + TS;
+    if (ke > lim) ke = lim;
+  }
+  if (g.xy_lower_tri) {
+    int64_t lo = m0 > n0 ? m0 : n0;
+    lo -= lo % BK;
+    if (kb < lo) kb = lo;
+  }
+  v4d acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+  const int c2 = (tid & 31) * 2;
+  const int rg = tid >> 5;  // 0..7 ; rows rg, rg + 8
+  const int64_t xc = m0 + c2, yc = n0 + c2;
+  const bool x0ok = xc < g.M, x1ok = xc + 1 < g.M;
+  const bool y0ok = yc < g.N, y1ok = yc + 1 < g.N;
+  const int64_t xi0 = VEC ? (xc < g.ldx - 2 ? xc : g.ldx - 2) : (xc < g.M ? xc : g.M - 1);
+  const int64_t xi1 = xc + 1 < g.M ? xc + 1 : g.M - 1;
+  const int64_t yi0 = VEC ? (yc < g.ldy - 2 ? yc : g.ldy - 2) : (yc < g.N ? yc : g.N - 1);
+  const int64_t yi1 = yc + 1 < g.N ? yc + 1 : g.N - 1;
+  v2d xr[2], yr[2];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t row = k0 + rg + 8 * i;
+      row = row < ke ? row : ke - 1;
+      xr[i] = load2<VEC>(X + row * g.ldx, xi0, xi1);
+      yr[i] = load2<VEC>(Y + row * g.ldy, yi0, yi1);
+    }
+  };
+  auto sstore = [&](int buf, int64_t k0) {
+    double *Xs = smem + buf * STAGE_S;
+    double *Ys = Xs + BK * LDS_S;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = rg + 8 * i;
+      const bool rok = k0 + row < ke;
+      v2d xv, yv;
+      xv.x = (rok && x0ok) ? xr[i].x : 0.0;
+      xv.y = (rok && x1ok) ? xr[i].y : 0.0;
+      yv.x = (rok && y0ok) ? yr[i].x : 0.0;
+      yv.y = (rok && y1ok) ? yr[i].y : 0.0;
+      *reinterpret_cast<v2d *>(Xs + row * LDS_S + c2) = xv;
+      *reinterpret_cast<v2d *>(Ys + row * LDS_S + c2) = yv;
+    }
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  if (kb < ke) {
+    gload(kb);
+    sstore(0, kb);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+    const bool more = k0 + BK < ke;
+    if (more) gload(k0 + BK);
+    const double *Xs = smem + cur * STAGE_S;
+    const double *Ys = Xs + BK * LDS_S;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double a[2], bb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = Xs[kr * LDS_S + wm * 32 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = Ys[kr * LDS_S + wn * 32 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1, k0 + BK);
+    __syncthreads();
+    cur ^= 1;
+  }
+  const double alpha = g.alpha;
+  const double beta = g.splits > 1 ? 0.0 : g.beta;
+  double cv[2][2][4];
+  if (beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t col = n0 + wn * 32 + j * 16 + fr;
+          const int64_t row = m0 + wm * 32 + i * 16 + fq + 4 * r;
+          const bool ok = col < g.N && row < g.M;
+          cv[i][j][r] = C[(ok ? row : 0) * g.ldc + (ok ? col : 0)];
+        }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 32 + j * 16 + fr;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 32 + i * 16 + fq + 4 * r;
+        if (row >= g.M) continue;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * cv[i][j][r];
+        C[row * g.ldc + col] = v;
+      }
+    }
+}
+
 static bool g_attr_set = false;
 
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
@@ -377,6 +515,18 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
                         !a.force_generic;
+  // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups)
+  const int64_t nblk128 = tiles_m * tiles_n * g.splits * (a.batch < 1 ? 1 : a.batch);
+  if (!a.work_map && a.K <= 512 && nblk128 <= 160 && !a.force_generic) {
+    const int64_t tm64 = (a.M + TS - 1) / TS, tn64 = (a.N + TS - 1) / TS;
+    g.tiles_n = (int32_t)tn64;
+    dim3 grid64((unsigned)(tm64 * tn64), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
+    if (g.vec_x && g.vec_y)
+      hipLaunchKernelGGL(gemm_tn_f64_small_kernel<true>, grid64, dim3(256), GEMM_LDS_BYTES_S, st, g);
+    else
+      hipLaunchKernelGGL(gemm_tn_f64_small_kernel<false>, grid64, dim3(256), GEMM_LDS_BYTES_S, st, g);
+    return hipGetLastError();
+  }
   if (interior)
     hipLaunchKernelGGL(gemm_tn_f64_interior_kernel, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (g.vec_x && g.vec_y)
