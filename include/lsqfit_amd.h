@@ -209,6 +209,24 @@ int lsqamd_get_J(lsqamd_fit *fit, double *out, size_t cap);       /* nf * P   : 
 int lsqamd_get_jtj(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : J^T J  */
 int lsqamd_get_grad(lsqamd_fit *fit, double *out, size_t cap);    /* P        : J^T f  */
 int lsqamd_get_cov(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : fit.cov (gsl_multifit_nlinear_covar, _gsl.pyx:704-706) */
+
+/* ---- sensitivity of the best-fit parameters to the inputs ------------
+ * Replaces the matrix D[a,i] = d pmean[a] / d buf[i], buf = concat(y, prior), that
+ * nonlinear_fit._getp builds column by column from chivw and cov
+ * (src/lsqfit/__init__.py:897-911, `D[:, i] = chivw_i.mdotder(self.cov)`;
+ * chivw = inv(C_reg) . delta, src/lsqfit/_utilities.pyx:96-139):
+ *     D = cov . [J_f ; I]^T . inv(C_reg)          (doc/source/lsqfit.rst:105-117)
+ * evaluated at the current point from the whitened Jacobian resident on the device.
+ *   gt     host, P x m row-major: m directions in parameter space (gradients of the
+ *          outputs whose error budget is wanted); NULL = identity (m must equal P).
+ *   out_t  host, (N + P) x m row-major (N x m without a prior) = D^T . gt : rows 0..N-1
+ *          are this handle's data rows in the caller's order, then the P prior entries.
+ *   dev_scratch  device memory of lsqamd_dpdy_work_bytes(fit, m) bytes from the caller.
+ * The handle's covariance is (re)computed if needed.  Row-sharded fits: every rank gets
+ * the rows of its own shard (cov is replicated); no collective. */
+size_t lsqamd_dpdy_work_bytes(const lsqamd_fit *fit, int64_t m);
+int lsqamd_dpdy(lsqamd_fit *fit, const double *gt, int64_t m, void *dev_scratch, size_t scratch_bytes,
+                double *out_t, size_t cap);
 int64_t lsqamd_nf(const lsqamd_fit *fit);                         /* nchiv (__init__.py:574) */
 
 /* ---- batched fits (SURVEY.md 8a row a8 / BASELINE.json config 5) --------------------

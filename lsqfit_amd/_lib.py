@@ -74,6 +74,8 @@ PROTOTYPES = {
     'lsqamd_get_grad': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_get_cov': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_nf': (C.c_int64, [_vp]),
+    'lsqamd_dpdy_work_bytes': (C.c_size_t, [_vp, C.c_int64]),
+    'lsqamd_dpdy': (C.c_int, [_vp, _dp, C.c_int64, _vp, C.c_size_t, _dp, C.c_size_t]),
     'lsqamdb_workspace_bytes': (C.c_size_t, [C.POINTER(Config), C.c_int32]),
     'lsqamdb_create': (C.c_int, [C.POINTER(Config), C.c_int32, _vp, C.c_size_t, _vp, C.POINTER(_vp)]),
     'lsqamdb_destroy': (C.c_int, [_vp]),

@@ -1013,6 +1013,110 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
   return 0;
 }
 
+namespace {
+struct DpdyPlan {
+  int64_t ldv, ldn;
+  double *gt, *V, *Jt, *T, *out, *wn;
+  size_t bytes;
+};
+DpdyPlan dpdy_plan(const lsqamd_fit *f, int64_t m, void *base) {
+  DpdyPlan d;
+  d.ldv = rup(m, 16);
+  d.ldn = rup(f->N > 0 ? f->N : 1, 16);
+  Carver cv(base, 0, base == nullptr);
+  d.gt = cv.take<double>(f->P * d.ldv);
+  d.V = cv.take<double>(f->P * d.ldv);
+  d.Jt = cv.take<double>(f->P * d.ldn);
+  d.T = cv.take<double>(f->N * d.ldv);
+  d.out = cv.take<double>((f->N + f->P) * d.ldv);
+  d.wn = cv.take<double>(f->cfg.sum_block_sq);
+  d.bytes = cv.off;
+  return d;
+}
+}  // namespace
+
+size_t lsqamd_dpdy_work_bytes(const lsqamd_fit *f, int64_t m) {
+  if (!f || m < 1) return 0;
+  return dpdy_plan(f, m, nullptr).bytes + 256;
+}
+
+int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, size_t scratch_bytes,
+                double *out_t, size_t cap) {
+  if (!f || !out_t || !dev_scratch) return LSQAMD_EINVAL;
+  if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "dpdy: no fit has run");
+  const int64_t P = f->P, N = f->N;
+  if (m < 1 || (!gt && m != P)) FAIL(f, LSQAMD_EINVAL, "dpdy: gt == NULL needs m == P");
+  const int64_t nrows = N + (f->cfg.has_prior ? P : 0);
+  if (cap < (size_t)(nrows * m)) FAIL(f, LSQAMD_ECAPACITY, "dpdy: need %lld", (long long)(nrows * m));
+  char *base = (char *)dev_scratch;
+  const size_t pad = (size_t)((-(intptr_t)base) & 255);
+  DpdyPlan d = dpdy_plan(f, m, base + pad);
+  if (scratch_bytes < d.bytes + pad) FAIL(f, LSQAMD_ENOMEM, "dpdy: scratch needs %zu bytes", d.bytes + 256);
+  if (!f->have_cov) {
+    const int rc = do_covariance(f);
+    if (rc) return rc;
+  }
+  Scope sc(f, LSQAMD_T_COVAR);
+  // V = cov . gt  (P x m); identity: V is cov itself
+  const double *V = f->cov;
+  int64_t ldv = f->ldm;
+  if (gt) {
+    HIPCHK(f, hipMemcpy2DAsync(d.gt, sizeof(double) * d.ldv, gt, sizeof(double) * m, sizeof(double) * m,
+                               (size_t)P, hipMemcpyHostToDevice, f->st));
+    GemmTN g;
+    g.X = f->cov; g.ldx = f->ldm; g.Y = d.gt; g.ldy = d.ldv; g.C = d.V; g.ldc = d.ldv;
+    g.M = P; g.N = m; g.K = P;
+    HIPCHK(f, launch_gemm_tn(f->st, g));
+    V = d.V;
+    ldv = d.ldv;
+  }
+  const bool blocks = f->cfg.n_blocks > 0;
+  if (N > 0) {
+    // Jt[b][n] = w_n J[n][b]: 1x1 rows get their second factor 1/sigma here, block rows wait
+    // for W^T below
+    HIPCHK(f, launch_transpose_scale(f->st, f->J, f->ld, d.Jt, d.ldn, N, P, f->wdiag,
+                                     blocks ? f->in_block : nullptr, 1, 0, 0));
+    GemmTN g;  // T[n][o] = sum_b Jt[b][n] V[b][o]
+    g.X = d.Jt; g.ldx = d.ldn; g.Y = V; g.ldy = ldv;
+    g.C = blocks ? d.T : d.out; g.ldc = d.ldv;
+    g.M = N; g.N = m; g.K = P;
+    HIPCHK(f, launch_gemm_tn(f->st, g));
+    if (blocks) {
+      HIPCHK(f, launch_rows_scale_copy(f->st, d.T, d.ldv, d.out, d.ldv, N, m, nullptr, f->in_block));
+      // out_b[i][o] = sum_j W_b[j][i] T_b[j][o]: the X operand is W_b itself = (stored Wt_b)^T
+      for (size_t b = 0; b < f->h_size.size(); ++b) {
+        const int64_t B = f->h_size[b];
+        if (f->uniform_blocks && b > 0) break;
+        const int64_t nb = f->uniform_blocks ? (int64_t)f->h_size.size() : 1;
+        HIPCHK(f, launch_transpose_scale(f->st, f->wt + f->h_woff[b], B, d.wn + f->h_woff[b], B, B, B,
+                                         nullptr, nullptr, nb, B * B, B * B));
+        GemmTN w;
+        w.X = d.wn + f->h_woff[b]; w.ldx = B; w.sx = B * B;
+        w.Y = d.T + f->h_row0[b] * d.ldv; w.ldy = d.ldv; w.sy = B * d.ldv;
+        w.C = d.out + f->h_row0[b] * d.ldv; w.ldc = d.ldv; w.sc = B * d.ldv;
+        w.M = B; w.N = m; w.K = B;
+        w.batch = (int32_t)nb;
+        HIPCHK(f, launch_gemm_tn(f->st, w));
+      }
+    }
+  }
+  if (f->cfg.has_prior) {  // prior entries: Lambda . V
+    double *op = d.out + N * d.ldv;
+    if (f->cfg.prior_dense) {
+      GemmTN g;
+      g.X = f->prior_prec; g.ldx = P; g.Y = V; g.ldy = ldv; g.C = op; g.ldc = d.ldv;
+      g.M = P; g.N = m; g.K = P;
+      HIPCHK(f, launch_gemm_tn(f->st, g));
+    } else {
+      HIPCHK(f, launch_rows_scale_copy(f->st, V, ldv, op, d.ldv, P, m, f->prior_prec, nullptr));
+    }
+  }
+  HIPCHK(f, hipMemcpy2DAsync(out_t, sizeof(double) * m, d.out, sizeof(double) * d.ldv, sizeof(double) * m,
+                             (size_t)nrows, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
 void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long long *)dev_ptr; }
 
 // introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor

@@ -119,6 +119,15 @@ hipError_t launch_set_identity(hipStream_t st, double *A, int64_t P, int64_t ld)
 hipError_t launch_copy_strided(hipStream_t st, const double *src, int64_t lds_, double *dst,
                                int64_t ldd, int64_t rows, int64_t cols);
 
+// dst[c][r] = src[r][c] * scale[r] (rows with skip[r] != 0 unscaled); batched over blockIdx.z
+hipError_t launch_transpose_scale(hipStream_t st, const double *src, int64_t lds_, double *dst,
+                                  int64_t ldd, int64_t rows, int64_t cols, const double *scale,
+                                  const uint8_t *skip, int64_t batch, int64_t s_src, int64_t s_dst);
+// dst[r][:] = scale[r] * src[r][:] for rows with skip[r] == 0 (scale / skip may be null)
+hipError_t launch_rows_scale_copy(hipStream_t st, const double *src, int64_t lds_, double *dst,
+                                  int64_t ldd, int64_t rows, int64_t cols, const double *scale,
+                                  const uint8_t *skip);
+
 inline int64_t packed_doubles(int64_t P) {
   const int64_t T = (P + 127) / 128;
   return T * (T + 1) / 2 * 128 * 128;

@@ -351,4 +351,68 @@ hipError_t launch_copy_strided(hipStream_t st, const double *src, int64_t lds_, 
   return hipGetLastError();
 }
 
+// dst[c][r] = src[r][c] * (skip && skip[r] ? 1 : scale[r])  -- 64 x 64 tiles through LDS so
+// both the read and the write are full 512-byte row segments.  batch: blockIdx.z.
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const double *src, int64_t lds_,
+                                                              double *dst, int64_t ldd, int64_t rows,
+                                                              int64_t cols, const double *scale,
+                                                              const uint8_t *skip, int64_t s_src,
+                                                              int64_t s_dst) {
+  __shared__ double tile[64][65];
+  src += (int64_t)blockIdx.z * s_src;
+  dst += (int64_t)blockIdx.z * s_dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    double v = 0.0;
+    if (r < rows && c < cols) {
+      v = src[r * lds_ + c];
+      if (scale && !(skip && skip[r])) v *= scale[r];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[c * ldd + r] = tile[tx][i];
+  }
+}
+
+hipError_t launch_transpose_scale(hipStream_t st, const double *src, int64_t lds_, double *dst,
+                                  int64_t ldd, int64_t rows, int64_t cols, const double *scale,
+                                  const uint8_t *skip, int64_t batch, int64_t s_src, int64_t s_dst) {
+  if (rows <= 0 || cols <= 0 || batch <= 0) return hipSuccess;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64), (unsigned)batch);
+  hipLaunchKernelGGL(transpose_scale_kernel, grid, dim3(256), 0, st, src, lds_, dst, ldd, rows, cols,
+                     scale, skip, s_src, s_dst);
+  return hipGetLastError();
+}
+
+// dst[r][c] = src[r][c] * (scale ? scale[r] : 1) for the rows with skip[r] == 0
+__global__ __launch_bounds__(256) void rows_scale_copy_kernel(const double *src, int64_t lds_,
+                                                              double *dst, int64_t ldd, int64_t rows,
+                                                              int64_t cols, const double *scale,
+                                                              const uint8_t *skip) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols) return;
+  for (int64_t i = blockIdx.y; i < rows; i += gridDim.y) {
+    if (skip && skip[i]) continue;
+    const double s = scale ? scale[i] : 1.0;
+    dst[i * ldd + j] = s * src[i * lds_ + j];
+  }
+}
+
+hipError_t launch_rows_scale_copy(hipStream_t st, const double *src, int64_t lds_, double *dst,
+                                  int64_t ldd, int64_t rows, int64_t cols, const double *scale,
+                                  const uint8_t *skip) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  dim3 grid((unsigned)((cols + 255) / 256), (unsigned)(rows < 32768 ? rows : 32768));
+  hipLaunchKernelGGL(rows_scale_copy_kernel, grid, dim3(256), 0, st, src, lds_, dst, ldd, rows, cols,
+                     scale, skip);
+  return hipGetLastError();
+}
+
 }  // namespace lsqamd

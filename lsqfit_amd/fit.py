@@ -118,3 +118,30 @@ class nonlinear_fit(object):
     @property
     def J(self):
         return self.fitter_results.J
+
+    # -- fit.p with its input correlations ----------------------------------
+    def dp_dinputs(self, G=None):
+        """``D[a, i] = d pmean[a] / d buf[i]`` for ``buf = concat(y, prior)``: the matrix
+        ``_getp`` (src/lsqfit/__init__.py:897-911) turns into the derivatives of ``fit.p``
+        (``p[a].der = sum_i D[a,i] buf[i].der``).  ``cov_p = D C D^T``
+        (doc/source/lsqfit.rst:105-117).  Computed on the device from the resident whitened
+        Jacobian; ``G`` (m x P) returns ``G @ D`` for m derived quantities instead."""
+        return self.problem.dpdy(G)
+
+    def partial_sdev(self, grads, groups, cov_in):
+        """Error budget in the sense of ``gvar.fmt_errorbudget(outputs, inputs)`` as used by
+        examples/simple.py:56-61: ``grads`` maps an output name to its gradient d g / d p at
+        ``pmean``; ``groups`` maps an input-group name to indices into ``buf``; ``cov_in`` is
+        the covariance of ``buf`` (dense, or a 1-d array of variances).  Returns
+        {(output, group): partial standard deviation}."""
+        names = list(grads)
+        GD = self.dp_dinputs(np.array([np.asarray(grads[g], float) for g in names]))
+        cov_in = np.asarray(cov_in, float)
+        out = {}
+        for k, g in enumerate(names):
+            for name, idx in groups.items():
+                idx = np.asarray(idx, int)
+                d = GD[k, idx]
+                var = float(d @ cov_in[np.ix_(idx, idx)] @ d) if cov_in.ndim == 2 else float(np.sum(d * d * cov_in[idx]))
+                out[g, name] = float(np.sqrt(max(var, 0.0)))
+        return out

@@ -224,6 +224,33 @@ class DeviceProblem:
         n = self.nf_data()
         return self._get(self.lib.lsqamd_get_J, n * self.P, (n, self.P))
 
+    def dpdy(self, G=None):
+        """Sensitivity of the best-fit parameters to the inputs at the current point:
+        ``D = cov [J_f ; I]^T inv(C_reg)`` (``_getp``, src/lsqfit/__init__.py:897-911).
+
+        ``G`` None -> ``D`` itself, shape (P, N + P) (columns: this problem's data rows in the
+        caller's order, then the prior entries; (P, N) without a prior).  ``G`` of shape
+        (m, P) -> ``G @ D`` without forming ``D`` (gradients of m derived outputs)."""
+        import torch
+        P = self.P
+        ncol = self.N + (P if self.wh.has_prior else 0)
+        if G is None:
+            m, gt = P, None
+        else:
+            G = np.atleast_2d(np.asarray(G, np.float64))
+            if G.shape[1] != P:
+                raise ValueError('G must have %d columns' % P)
+            m = G.shape[0]
+            gt = np.ascontiguousarray(G.T)
+        nbytes = self.lib.lsqamd_dpdy_work_bytes(self.h, m)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        out = np.empty((ncol, m))
+        rc = self.lib.lsqamd_dpdy(self.h, None if gt is None else _lib.dptr(gt), m,
+                                  C.c_void_p(scratch.data_ptr()), nbytes, _lib.dptr(out), out.size)
+        _check(self.lib, self.h, rc, 'dpdy')
+        del scratch
+        return np.ascontiguousarray(out.T)
+
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
             self.lib.lsqamd_destroy(self.h)

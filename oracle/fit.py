@@ -149,3 +149,41 @@ def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
         fit.logdet_JtJ = float(ld)
         fit.logGBF = 0.5 * (-ld - pdf.logdet - fit.chi2 - fit.dof * np.log(2. * np.pi))
     return fit
+
+
+def dp_dinputs(fit):
+    """``D[a, i] = d pmean[a] / d buf[i]``, ``buf = concat(y, prior)`` in the
+    caller's order: the matrix ``_getp`` builds (src/lsqfit/__init__.py:897-911)
+    from ``chivw`` (src/lsqfit/_utilities.pyx:96-139), whose value is
+    ``inv(C_reg) @ delta`` -- ``wgts**2 * delta`` for the 1x1 entries (:127-129),
+    ``(sum_j w_j w_j^T) @ delta`` for each block (:130-134).  Its p-derivative
+    contracted with ``cov`` (``mdotder``, :908) gives
+    ``D = cov @ [J_f ; I]^T @ inv(C_reg)`` (doc/source/lsqfit.rst:105-117).
+
+    ``fit.J`` holds the rows of ``W @ [J_f ; I]`` in chiv order (1x1 rows first,
+    then the modes of each block), so ``D[:, iw] = cov @ J_rows^T @ W``.
+    """
+    pdf, J, cov = fit.pdf, fit.J, fit.cov
+    D = np.zeros((cov.shape[0], pdf.mean.size))
+    iw, w = pdf.i_invwgts[0]
+    i2 = len(iw)
+    if i2:
+        D[:, iw] = cov @ (J[:i2] * w[:, None]).T
+    for iw, W in pdf.i_invwgts[1:]:
+        i1, i2 = i2, i2 + len(W)
+        D[:, iw] = cov @ J[i1:i2].T @ W
+    return D
+
+
+def partial_sdev(D, grads, groups, cov_in):
+    """Error budget (gvar.fmt_errorbudget as used in examples/simple.py:56-61):
+    for output ``g`` with gradient ``grads[g]`` (d g / d p at pmean) and input group
+    ``S`` (indices into buf), the partial variance is ``d_S C_SS d_S^T`` with
+    ``d = grad @ D``.  ``cov_in`` is the (dense) covariance of buf."""
+    out = {}
+    for g, grad in grads.items():
+        d = np.asarray(grad, float) @ D
+        for name, idx in groups.items():
+            idx = np.asarray(idx, int)
+            out[g, name] = float(np.sqrt(max(d[idx] @ cov_in[np.ix_(idx, idx)] @ d[idx], 0.0)))
+    return out

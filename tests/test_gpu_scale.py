@@ -129,6 +129,18 @@ def test_config4_full_size_fit_properties(amd, c4):
     # logGBF formula with the device logdet (src/lsqfit/__init__.py:709-725)
     sign, ld = np.linalg.slogdet(A)
     assert sign > 0 and fit.fitter_results.logdet_jtj == pytest.approx(ld, rel=1e-10)
+    # f1 at full size, through a size-independent property: for directions G,
+    # (G D) C (G D)^T = G cov G^T  (cov_p = D C D^T, doc/source/lsqfit.rst:112-113)
+    G = np.random.default_rng(7).standard_normal((4, P))
+    GD = fit.dp_dinputs(G)
+    assert GD.shape == (4, 65536 + P)
+    GDC = np.empty_like(GD)
+    sd2 = np.asarray(d['yerr']['sdev']) ** 2
+    GDC[:, :65536] = GD[:, :65536] * sd2
+    for r0, c in d['yerr']['blocks']:
+        GDC[:, r0:r0 + c.shape[0]] = GD[:, r0:r0 + c.shape[0]] @ c
+    GDC[:, 65536:] = GD[:, 65536:] @ np.asarray(d['prior'][1])
+    assert gu.relmax(GDC @ GD.T, G @ fit.cov @ G.T) < 1e-6
     pr.close()
 
 

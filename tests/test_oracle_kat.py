@@ -289,3 +289,74 @@ def test_simple_example_header():
     check_header(fit, KAT['simple']['out'])
     assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.253(32) 0.449(65)]'
     assert fit.nblocks == {1: 3, 2: 2}
+
+
+def _simple_fit():
+    ymean = np.array([1.376, 2.010, 1.329, 1.582, 2.0])
+    ycov = np.zeros((5, 5))
+    ycov[:2, :2] = [[0.0047, 0.01], [0.01, 0.056]]
+    ycov[2:4, 2:4] = [[0.0047, 0.0067], [0.0067, 0.0136]]
+    ycov[4, 4] = 0.25
+    x1, x2 = np.array([0.1, 1.0]), np.array([0.1, 0.5])
+
+    def fcn(p):
+        return dual.concatenate([dual.exp(p[0] + x1 * p[1]), dual.exp(p[0] + x2 * p[1]),
+                                 (p[1] / p[0]).reshape(1) if isinstance(p, dual.Dual) else np.array([p[1] / p[0]])])
+    fit = ofit.nonlinear_fit(False, ymean, ycov, fcn, prior_mean=[0.5, 0.5], prior_err=[0.5, 0.5])
+    cov_in = np.zeros((7, 7))
+    cov_in[:5, :5] = ycov
+    cov_in[5, 5] = cov_in[6, 6] = 0.25
+    return fit, cov_in
+
+
+def parse_errorbudget(out):
+    """'Partial % Errors' table of a reference .out file -> {(output, input): percent}."""
+    lines = out.split('Partial % Errors:')[1].strip().splitlines()
+    cols = lines[0].split()
+    tab = {}
+    for ln in lines[1:]:
+        if ':' not in ln:
+            continue
+        name, vals = ln.split(':')
+        for c, v in zip(cols, vals.split()):
+            tab[c, name.strip()] = float(v)
+    return tab
+
+
+def test_simple_example_error_budget():
+    """fit.p derivatives (f1): examples/simple.py:49-61 vs the 'Partial % Errors' table of
+    simple.out:24-32 -- pins D = dp/d[y, prior] (src/lsqfit/__init__.py:897-911)."""
+    fit, cov_in = _simple_fit()
+    D = ofit.dp_dinputs(fit)
+    # cov_p = D C D^T (doc/source/lsqfit.rst:112-113)
+    np.testing.assert_allclose(D @ cov_in @ D.T, fit.cov, rtol=1e-9)
+    a, b = fit.pmean
+    grads = {'a': [1.0, 0.0], 'b/a': [-b / a ** 2, 1.0 / a], 'b': [0.0, 1.0]}
+    vals = {'a': a, 'b/a': b / a, 'b': b}
+    groups = {'y': [0, 1, 2, 3, 4], 'prior': [5, 6], 'total': list(range(7))}
+    err = ofit.partial_sdev(D, grads, groups, cov_in)
+    want = parse_errorbudget(KAT['simple']['out'])
+    assert len(want) == 9
+    for (g, name), pct in want.items():
+        got = 100.0 * err[g, name] / abs(vals[g])
+        assert '%.2f' % got == '%.2f' % pct, (g, name, got, pct)
+
+
+def test_partialerr_weighted_average():
+    """tests/test_lsqfit.py:1474-1510 (test_partialerr1): three equal measurements of p['y'],
+    a wide prior on it and an unrelated prior: d p_y / d y_i = 1/ny, d p_noty / d prior = 1."""
+    ny = 3
+    fcn = lambda p: dual.concatenate([p[0].reshape(1)] * ny) if isinstance(p, dual.Dual) else np.full(ny, p[0])
+    fit = ofit.nonlinear_fit(False, np.full(ny, 2.0), np.full(ny, 0.125), fcn,
+                             prior_mean=[0.1, 3.0], prior_err=[1e4, 0.125])
+    D = ofit.dp_dinputs(fit)
+    np.testing.assert_allclose(D[0, :ny], 1.0 / ny, rtol=1e-6)
+    np.testing.assert_allclose(D[1, ny + 1], 1.0, rtol=1e-12)
+    cov_in = np.diag(np.array([0.125] * ny + [1e4, 0.125]) ** 2)
+    err = ofit.partial_sdev(D, {'y': [1, 0], 'not y': [0, 1]},
+                            {'y': [0, 1, 2], 'not y': [4], 'other prior': [3]}, cov_in)
+    wavg_sdev = 0.125 / np.sqrt(ny)
+    assert abs(err['y', 'y'] - wavg_sdev) < 1e-7
+    assert err['y', 'not y'] == 0.0 and abs(err['y', 'other prior']) < 1e-5
+    assert abs(err['not y', 'not y'] - 0.125) < 1e-12
+    assert err['not y', 'y'] == 0.0 and err['not y', 'other prior'] == 0.0
