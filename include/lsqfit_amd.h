@@ -150,6 +150,11 @@ int lsqamd_destroy(lsqamd_fit *fit);
 /* replaces gsl_strerror (_gsl.pyx:687); valid until the next call on the handle */
 const char *lsqamd_last_error(const lsqamd_fit *fit);
 
+/* Replace the data means only (same covariance / whitening): the data of a simulated or
+ * bootstrap copy of the fit (nonlinear_fit.simulated_data_iter, src/lsqfit/__init__.py:
+ * 1470-1543: `y += f - mean(y)` then gvar.bootstrap_iter keeps the covariance). */
+int lsqamd_set_ymean(lsqamd_fit *fit, const double *ymean);
+
 /* ---- problem data (copied host -> device) ----------------------------------- */
 /* x[n_data][n_x]: what the closure `flatfcn` hides (__init__.py:566-568,:1997-2042) */
 int lsqamd_set_x(lsqamd_fit *fit, const double *x, int64_t n_rows, int32_t n_x);
@@ -192,6 +197,9 @@ int lsqamd_finish(lsqamd_fit *fit, lsqamd_summary *out);
 int lsqamd_eval_residual(lsqamd_fit *fit, const double *p, double *chi2);
 /* _c_df (_gsl.pyx:742-760) + solver.init: J, then J^T J, J^T f, chi2 at p */
 int lsqamd_eval_normal(lsqamd_fit *fit, const double *p, double *chi2);
+/* out[N] = fcn(x; p), unwhitened: what simulated_data_iter evaluates at pexact
+ * (src/lsqfit/__init__.py:1524 `f = self.fcn(self.x, pexact)`) */
+int lsqamd_eval_fcn(lsqamd_fit *fit, const double *p, double *out, size_t cap);
 /* damped solve (J^T J + mu D^2) v = J^T f with D = diag (host, P); v -> host */
 int lsqamd_solve_damped(lsqamd_fit *fit, double mu, const double *diag, double *v);
 /* raw dense ops on device pointers (row-major, see gemm_tn_f64.hip) */
@@ -245,6 +253,14 @@ int lsqamdb_set_x(lsqamdb_fits *fits, const double *x, int64_t n_rows, int32_t n
 int lsqamdb_set_tape(lsqamdb_fits *fits, const int32_t *code, int32_t n_code, const double *consts,
                      int32_t n_consts);
 int lsqamdb_set_data(lsqamdb_fits *fits, const double *ymean, const double *wdiag);     /* shared, [N] each */
+/* correlated data blocks shared by the fits: arguments as in lsqamd_set_data (whitening
+ * weights of gvar.PDF, src/lsqfit/_utilities.pyx:58-61); required when cfg.n_blocks > 0 */
+int lsqamdb_set_blocks(lsqamdb_fits *fits, int32_t n_blocks, const int64_t *row0, const int64_t *size,
+                       const int64_t *modes, const int32_t *tri, const double *wt);
+/* per-fit data means ymean[B*N]: simulated / bootstrap copies of one data set keep its
+ * covariance and replace the means (simulated_fit_iter / bootstrapped_fit_iter,
+ * src/lsqfit/__init__.py:1391-1469,1548-1642) */
+int lsqamdb_set_data_means(lsqamdb_fits *fits, const double *ymean);
 int lsqamdb_set_priors(lsqamdb_fits *fits, const double *mean, const double *prec);     /* [B*P] each */
 int lsqamdb_set_options(lsqamdb_fits *fits, const lsqamd_options *opt);
 /* p0[B*P]; summaries[B] or NULL (t_setup_ms carries the number of graph-replayed rounds) */

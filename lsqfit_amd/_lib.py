@@ -53,6 +53,7 @@ PROTOTYPES = {
     'lsqamd_set_data': (C.c_int, [_vp, _dp, _dp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                   C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp]),
     'lsqamd_set_prior': (C.c_int, [_vp, _dp, _dp]),
+    'lsqamd_set_ymean': (C.c_int, [_vp, _dp]),
     'lsqamd_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
     'lsqamd_set_reduce': (C.c_int, [_vp, REDUCE_FN, _vp]),
     'lsqamd_set_adds_prior': (C.c_int, [_vp, C.c_int32]),
@@ -62,6 +63,7 @@ PROTOTYPES = {
     'lsqamd_finish': (C.c_int, [_vp, C.POINTER(Summary)]),
     'lsqamd_eval_residual': (C.c_int, [_vp, _dp, _dp]),
     'lsqamd_eval_normal': (C.c_int, [_vp, _dp, _dp]),
+    'lsqamd_eval_fcn': (C.c_int, [_vp, _dp, _dp, C.c_size_t]),
     'lsqamd_solve_damped': (C.c_int, [_vp, C.c_double, _dp, _dp]),
     'lsqamd_op_gemm_tn': (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int64, C.c_double, _vp, C.c_int64,
                                     _vp, C.c_int64, C.c_double, _vp, C.c_int64, C.c_int32, C.c_int32]),
@@ -83,6 +85,9 @@ PROTOTYPES = {
     'lsqamdb_set_x': (C.c_int, [_vp, _dp, C.c_int64, C.c_int32]),
     'lsqamdb_set_tape': (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int32]),
     'lsqamdb_set_data': (C.c_int, [_vp, _dp, _dp]),
+    'lsqamdb_set_blocks': (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp]),
+    'lsqamdb_set_data_means': (C.c_int, [_vp, _dp]),
     'lsqamdb_set_priors': (C.c_int, [_vp, _dp, _dp]),
     'lsqamdb_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
     'lsqamdb_run': (C.c_int, [_vp, _dp, C.POINTER(Summary), C.c_int32]),

@@ -2,8 +2,11 @@
 
 Host counterpart of running ``lsqfit.nonlinear_fit`` in a Python loop over priors /
 starting points (the inner loop of ``lsqfit.empbayes_fit``, src/lsqfit/_extras.py:153-174):
-the fits share the model, ``x`` and uncorrelated data ``(ymean, ysdev)`` and differ in their
-diagonal priors and ``p0``.  Result arrays have a leading batch dimension.
+the fits share the model, ``x`` and the data covariance (sdev vector, covariance matrix or
+``dict(sdev=, blocks=)`` -- whitened exactly as in :class:`lsqfit_amd.Whitening`) and differ in
+their diagonal priors, ``p0`` and -- ``ymean`` of shape (n_fits, N) -- the data means
+(simulated / bootstrap refits, src/lsqfit/__init__.py:1391-1469,1548-1642).  Result arrays
+have a leading batch dimension.
 """
 import ctypes as C
 import time
@@ -17,26 +20,46 @@ from .models import MODEL_IDENTITY, MODEL_TAPE
 
 
 class BatchedFits:
-    def __init__(self, model, x, ymean, ysdev, prior_mean, prior_sdev, device=None):
+    def __init__(self, model, x, ymean, ysdev, prior_mean, prior_sdev, device=None, svdcut=1e-12,
+                 whitening=None, n_fits=None):
         import torch
+        from .whiten import Whitening
         if not torch.cuda.is_available():
             raise RuntimeError('lsqfit_amd: no MI355X visible; the batched fitter has no CPU path')
         self.lib = lib = _lib.load()
         self.model = model
-        ymean = np.ascontiguousarray(ymean, np.float64).reshape(-1)
-        ysdev = np.ascontiguousarray(np.broadcast_to(np.asarray(ysdev, np.float64), ymean.shape))
-        if ysdev.ndim != 1 or np.any(ysdev <= 0):
-            raise ValueError('batched fits need uncorrelated data with positive standard deviations')
-        pm = np.ascontiguousarray(prior_mean, np.float64)
-        ps = np.ascontiguousarray(np.broadcast_to(np.asarray(prior_sdev, np.float64), pm.shape))
-        if pm.ndim != 2 or pm.shape[1] != model.n_param:
-            raise ValueError('prior_mean must be [n_fits, n_param]')
-        if np.any(ps <= 0):
-            raise ValueError('some priors have zero standard deviations')
-        self.B, self.P, self.N = pm.shape[0], model.n_param, ymean.size
-        self.ysdev, self.prior_mean, self.prior_sdev = ysdev, pm, ps
+        ymean = np.ascontiguousarray(ymean, np.float64)
+        ymeans = ymean if ymean.ndim == 2 else None
+        ymean = ymean[0] if ymean.ndim == 2 else ymean.reshape(-1)
+        if whitening is None:
+            yerr = ysdev if isinstance(ysdev, dict) else np.asarray(ysdev, np.float64)
+            if not isinstance(yerr, dict) and yerr.ndim < 2:
+                yerr = np.broadcast_to(yerr, ymean.shape)
+            whitening = Whitening(ymean, yerr, svdcut=svdcut)
+        self.wh = wh = whitening
+        row0, size, modes, tri, wt = wh.block_arrays()
+        self.has_prior = prior_mean is not None
+        if self.has_prior:
+            pm = np.ascontiguousarray(prior_mean, np.float64)
+            ps = np.ascontiguousarray(np.broadcast_to(np.asarray(prior_sdev, np.float64), pm.shape))
+            if pm.ndim != 2 or pm.shape[1] != model.n_param:
+                raise ValueError('prior_mean must be [n_fits, n_param]')
+            if np.any(ps <= 0):
+                raise ValueError('some priors have zero standard deviations')
+            n_fits = pm.shape[0]
+        else:
+            pm = ps = None
+            if n_fits is None:
+                n_fits = ymeans.shape[0] if ymeans is not None else None
+            if n_fits is None:
+                raise ValueError('n_fits is needed when there is no prior')
+        self.B, self.P, self.N = int(n_fits), model.n_param, ymean.size
+        if ymeans is not None and ymeans.shape[0] != self.B:
+            raise ValueError('ymean must be [N] or [n_fits, N]')
+        self.prior_mean, self.prior_sdev = pm, ps
         cfg = _lib.Config(abi_version=_lib.ABI_VERSION, model=model.kind, n_data=self.N, n_param=self.P,
-                          n_x=model.n_x, has_prior=1, prior_dense=0, n_blocks=0, max_block=0, sum_block_sq=0,
+                          n_x=model.n_x, has_prior=int(self.has_prior), prior_dense=0, n_blocks=len(size),
+                          max_block=int(size.max()) if len(size) else 0, sum_block_sq=int(np.sum(size * size)),
                           want_jacobian_out=0, n_batch=self.B)
         t0 = time.perf_counter()
         nbytes = lib.lsqamdb_workspace_bytes(C.byref(cfg), self.B)
@@ -60,9 +83,17 @@ class BatchedFits:
             consts = np.ascontiguousarray(model.consts, np.float64)
             self._check(lib.lsqamdb_set_tape(h, code.ctypes.data_as(C.POINTER(C.c_int32)), code.size,
                                              _lib.dptr(consts), consts.size), 'set_tape')
-        wd = np.ascontiguousarray(1.0 / ysdev)
+        wd = np.ascontiguousarray(wh.wdiag)
         self._check(lib.lsqamdb_set_data(h, _lib.dptr(ymean), _lib.dptr(wd)), 'set_data')
-        self.set_priors(pm, ps)
+        if len(size):
+            self._check(lib.lsqamdb_set_blocks(
+                h, len(size), row0.ctypes.data_as(C.POINTER(C.c_int64)), size.ctypes.data_as(C.POINTER(C.c_int64)),
+                modes.ctypes.data_as(C.POINTER(C.c_int64)), tri.ctypes.data_as(C.POINTER(C.c_int32)),
+                _lib.dptr(wt)), 'set_blocks')
+        if ymeans is not None:
+            self.set_data_means(ymeans)
+        if self.has_prior:
+            self.set_priors(pm, ps)
         self.t_setup = time.perf_counter() - t0
 
     def _check(self, rc, what):
@@ -70,6 +101,13 @@ class BatchedFits:
             msg = self.lib.lsqamdb_last_error(self.h)
             raise RuntimeError('lsqfit_amd: batched %s failed (%s): %s' % (
                 what, _lib.ERRORS.get(rc, rc), msg.decode() if msg else ''))
+
+    def set_data_means(self, ymeans):
+        """New data means, one row per fit (same covariance): shape (n_fits, N)."""
+        ymeans = np.ascontiguousarray(ymeans, np.float64)
+        if ymeans.shape != (self.B, self.N):
+            raise ValueError('ymeans must be [n_fits, N]')
+        self._check(self.lib.lsqamdb_set_data_means(self.h, _lib.dptr(ymeans)), 'set_data_means')
 
     def set_priors(self, mean, sdev):
         mean = np.ascontiguousarray(mean, np.float64)
@@ -83,6 +121,8 @@ class BatchedFits:
         """-> dict of arrays: pmean[B,P], chi2, dof, Q, logGBF, nit, stopping_criterion, status,
         nfev (+ psdev[B,P] and cov(b) when ``covariance``)."""
         B, P = self.B, self.P
+        if p0 is None and not self.has_prior:
+            raise ValueError('neither p0 nor prior is specified')
         if p0 is None:
             p0 = np.where(self.prior_mean != 0.0, self.prior_mean, self.prior_mean + 0.1 * self.prior_sdev)
         p0 = np.ascontiguousarray(np.broadcast_to(np.asarray(p0, np.float64), (B, P)))
@@ -102,15 +142,19 @@ class BatchedFits:
                    stopping_criterion=np.array([s.stopping_criterion for s in summ]),
                    rounds=int(self.lib.lsqamdb_rounds(self.h)), graph_rounds=int(summ[0].t_setup_ms),
                    time=t_run, device_ms=float(summ[0].t_run_ms))
-        dof = self.N          # nf - P = N + P - P
+        # nf - P: (kept data modes + P) - P with a prior, kept data modes - P without
+        dof = self.wh.nchiv_data - (0 if self.has_prior else P)
         out['dof'] = dof
         out['Q'] = np.array([gammaQ(dof / 2., c / 2.) for c in out['chi2']])
         if covariance:
             ld = np.empty(B)
             self._check(self.lib.lsqamdb_covariance(self.h, _lib.dptr(ld), B), 'covariance')
             out['logdet_jtj'] = ld
-            logdet_c = 2.0 * np.sum(np.log(self.ysdev)) + 2.0 * np.sum(np.log(self.prior_sdev), axis=1)
-            out['logGBF'] = 0.5 * (-ld - logdet_c - out['chi2'] - dof * np.log(2. * np.pi))
+            if self.has_prior:
+                logdet_c = self.wh.logdet_data + 2.0 * np.sum(np.log(self.prior_sdev), axis=1)
+                out['logGBF'] = 0.5 * (-ld - logdet_c - out['chi2'] - dof * np.log(2. * np.pi))
+            else:
+                out['logGBF'] = None              # src/lsqfit/__init__.py:711-712
             out['psdev'] = np.sqrt(np.array([np.diag(self.cov(b)) for b in range(B)])) if B * P * P <= 1 << 26 else None
         return out
 

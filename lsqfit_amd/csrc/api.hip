@@ -725,6 +725,15 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
   return 0;
 }
 
+int lsqamd_set_ymean(lsqamd_fit *f, const double *ymean) {
+  if (!f || !ymean) return LSQAMD_EINVAL;
+  if (!f->have_data) FAIL(f, LSQAMD_EINVAL, "set_ymean: call lsqamd_set_data first");
+  if (f->N > 0) HIPCHK(f, hipMemcpyAsync(f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->have_cov = false;
+  return 0;
+}
+
 int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) {
   if (!f) return LSQAMD_EINVAL;
   if (!f->cfg.has_prior) FAIL(f, LSQAMD_EINVAL, "set_prior: the config says has_prior = 0");
@@ -844,6 +853,32 @@ int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) {
   rc = eval_residual_dev(f, f->p_trial, chi2);
   if (f->timing) resolve_timers(f);
   return rc;
+}
+
+int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) {
+  if (!f || !p || !out) return LSQAMD_EINVAL;
+  int rc = ready(f);
+  if (rc) return rc;
+  const int64_t N = f->N;
+  if (cap < (size_t)N) FAIL(f, LSQAMD_ECAPACITY, "eval_fcn: need %lld", (long long)N);
+  if (N == 0) return 0;
+  // residual kernel: w (f - y) for the 1x1 rows, f - y for the rows inside blocks
+  HIPCHK(f, hipMemcpyAsync(f->p_trial, p, sizeof(double) * f->P, hipMemcpyHostToDevice, f->st));
+  ModelArgs m = model_args(f, f->p_trial);
+  HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
+  std::vector<double> r((size_t)N), rr((size_t)N, 0.0), y((size_t)N), w((size_t)N);
+  std::vector<uint8_t> inb((size_t)N, 0);
+  HIPCHK(f, hipMemcpyAsync(r.data(), f->r, sizeof(double) * N, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(y.data(), f->ymean, sizeof(double) * N, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(w.data(), f->wdiag, sizeof(double) * N, hipMemcpyDeviceToHost, f->st));
+  if (f->cfg.n_blocks > 0) {
+    HIPCHK(f, hipMemcpyAsync(rr.data(), f->r_raw, sizeof(double) * N, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipMemcpyAsync(inb.data(), f->in_block, (size_t)N, hipMemcpyDeviceToHost, f->st));
+  }
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  for (int64_t i = 0; i < N; ++i)
+    out[i] = y[(size_t)i] + (inb[(size_t)i] ? rr[(size_t)i] : r[(size_t)i] / w[(size_t)i]);
+  return 0;
 }
 
 int lsqamd_eval_normal(lsqamd_fit *f, const double *p, double *chi2) {

@@ -3,8 +3,9 @@
 //
 // This is the device counterpart of what lsqfit.empbayes_fit does with a Python loop of
 // whole fits (src/lsqfit/_extras.py:153-174, BASELINE.json config 5): the fits share the
-// model, x, the data means and their (diagonal) whitening, and differ in the prior
-// (mean / sdev per fit) and the starting point.  Per fit the GSL trust/lm/nielsen/scaling/
+// model, x and the data whitening (1/sdev for the 1x1 rows, W_b per correlated block), and
+// differ in the prior (mean / sdev per fit), the starting point and -- for simulated /
+// bootstrap refits (src/lsqfit/__init__.py:1391-1469,1548-1642) -- the data means.  Per fit the GSL trust/lm/nielsen/scaling/
 // convergence logic of api.hip is restated as small per-fit device kernels (b_decide,
 // b_post); the heavy kernels are the same ones the single-fit path uses, launched with a
 // batch dimension: model kernels (grid.y), TN GEMM (grid.z) for J^T J and the Cholesky
@@ -439,6 +440,14 @@ struct lsqamdb_fits {
   int32_t splits = 1, nparts = 256, nrparts = 64;
   // shared inputs
   double *x = nullptr, *ymean = nullptr, *wdiag = nullptr;
+  int64_t ymean_stride = 0;  // 0 shared, N per-fit
+  // correlated data blocks (shared by the fits)
+  uint8_t *in_block = nullptr;
+  int64_t *blk_row0 = nullptr, *blk_size = nullptr, *blk_woff = nullptr;
+  double *wt = nullptr, *Jraw = nullptr, *r_raw = nullptr;
+  std::vector<int64_t> h_row0, h_size, h_modes, h_woff;
+  std::vector<int32_t> h_tri;
+  bool have_blocks = false;
   int32_t *tape = nullptr;
   double *consts = nullptr;
   int32_t n_tape = 0;
@@ -493,8 +502,15 @@ size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
   f->nrparts = 32;
   CarverB cv(ws, dry);
   f->x = cv.take<double>(N * (c.n_x > 0 ? c.n_x : 1));
-  f->ymean = cv.take<double>(N);
+  f->ymean = cv.take<double>(B * N);
   f->wdiag = cv.take<double>(N);
+  f->in_block = cv.take<uint8_t>(N);
+  f->blk_row0 = cv.take<int64_t>(c.n_blocks);
+  f->blk_size = cv.take<int64_t>(c.n_blocks);
+  f->blk_woff = cv.take<int64_t>(c.n_blocks);
+  f->wt = cv.take<double>(c.sum_block_sq);
+  f->Jraw = cv.take<double>(c.n_blocks > 0 ? B * N * f->ld : 1);
+  f->r_raw = cv.take<double>(c.n_blocks > 0 ? B * N : 1);
   f->tape = cv.take<int32_t>(1024);
   f->consts = cv.take<double>(256);
   f->pmean = cv.take<double>(B * P);
@@ -530,7 +546,7 @@ size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
 int check_cfg_b(const lsqamd_config *c, int32_t B) {
   if (!c || c->abi_version != LSQAMD_ABI_VERSION || B < 1) return LSQAMD_EINVAL;
   if (c->n_data < 1 || c->n_param < 1) return LSQAMD_EINVAL;
-  if (c->n_blocks != 0 || c->prior_dense) return LSQAMD_EUNSUPPORTED;  // diagonal whitening + diagonal priors
+  if (c->n_blocks < 0 || c->prior_dense) return LSQAMD_EUNSUPPORTED;  // diagonal priors only
   if (c->model < LSQAMD_MODEL_COSMIX || c->model > LSQAMD_MODEL_IDENTITY) return LSQAMD_EINVAL;
   if (c->model == LSQAMD_MODEL_TAPE && c->n_param > LSQAMD_TAPE_MAX_PARAM) return LSQAMD_EINVAL;
   if ((c->model == LSQAMD_MODEL_COSMIX || c->model == LSQAMD_MODEL_MULTIEXP) && (c->n_param & 1))
@@ -544,7 +560,8 @@ ModelArgs model_args_b(const lsqamdb_fits *f, const double *p) {
   m.n_data = f->N; m.n_param = f->P;
   m.n_x = f->cfg.n_x > 0 ? f->cfg.n_x : 1;
   m.x = f->x; m.ymean = f->ymean; m.wdiag = f->wdiag;
-  m.in_block = nullptr;
+  m.ymean_stride = f->ymean_stride;
+  m.in_block = f->cfg.n_blocks > 0 ? f->in_block : nullptr;
   m.p = p; m.tape = f->tape; m.n_tape = f->n_tape; m.consts = f->consts;
   m.n_batch = f->B; m.p_stride = f->P; m.batch_active = f->s.active;
   return m;
@@ -555,7 +572,19 @@ int normal_all(lsqamdb_fits *f) {
   const int64_t P = f->P, N = f->N, B = f->B;
   ModelArgs m = model_args_b(f, f->px);
   m.out_stride = N * f->ld;
-  BHIP(f, launch_jacobian_ex(f->st, m, f->J, nullptr, f->ld));
+  BHIP(f, launch_jacobian_ex(f->st, m, f->J, f->cfg.n_blocks > 0 ? f->Jraw : nullptr, f->ld));
+  // block rows: J_b <- W_b . Jraw_b for every fit (W shared: X stride 0, batch = fits)
+  for (size_t k = 0; k < f->h_size.size(); ++k) {
+    const int64_t Bk = f->h_size[k];
+    GemmTN w;
+    w.X = f->wt + f->h_woff[k]; w.ldx = Bk; w.sx = 0;
+    w.Y = f->Jraw + f->h_row0[k] * f->ld; w.ldy = f->ld; w.sy = N * f->ld;
+    w.C = f->J + f->h_row0[k] * f->ld; w.ldc = f->ld; w.sc = N * f->ld;
+    w.M = Bk; w.N = P + 1; w.K = Bk;
+    w.x_upper_tri = f->h_tri[k];
+    w.batch = (int32_t)B; w.batch_active = f->s.active;
+    BHIP(f, launch_gemm_tn(f->st, w));
+  }
   GemmTN g;
   g.X = f->J; g.Y = f->J; g.ldx = g.ldy = f->ld;
   g.sx = g.sy = N * f->ld;
@@ -605,7 +634,10 @@ int round_all(lsqamdb_fits *f) {
                      f->red + f->npk, red_stride, f->diag, f->dx, f->pxt, f->s);
   ModelArgs m = model_args_b(f, f->pxt);
   m.out_stride = N;
-  BHIP(f, launch_residual_ex(f->st, m, f->r, nullptr));
+  BHIP(f, launch_residual_ex(f->st, m, f->r, f->cfg.n_blocks > 0 ? f->r_raw : nullptr));
+  if (f->cfg.n_blocks > 0)
+    BHIP(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff, f->cfg.n_blocks,
+                                    f->cfg.max_block, f->r_raw, f->r, (int32_t)B, N, f->s.active));
   hipLaunchKernelGGL(b_sumsq_stage1, dim3((unsigned)f->nrparts, (unsigned)B), dim3(256), 0, f->st, f->r, N, N,
                      f->spart, f->nrparts, f->s.active);
   hipLaunchKernelGGL(b_sumsq_stage2, dim3((unsigned)B), dim3(256), 0, f->st, f->spart, f->nrparts, P, f->pprec,
@@ -698,12 +730,59 @@ int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const
   return 0;
 }
 
-/* shared data: ymean[N], wdiag[N] = 1/sdev (diagonal whitening only) */
+/* shared data: ymean[N], wdiag[N] = 1/sdev of the 1x1 rows */
 int lsqamdb_set_data(lsqamdb_fits *f, const double *ymean, const double *wdiag) {
   if (!f || !ymean || !wdiag) return LSQAMD_EINVAL;
   BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice));
   BHIP(f, hipMemcpy(f->wdiag, wdiag, sizeof(double) * f->N, hipMemcpyHostToDevice));
+  f->ymean_stride = 0;
   f->have_data = true;
+  return 0;
+}
+
+/* per-fit data means ymean[B*N] (simulated / bootstrap copies of one data set: same
+ * covariance, new means); the whitening set by lsqamdb_set_data / _set_blocks is kept */
+int lsqamdb_set_data_means(lsqamdb_fits *f, const double *ymean) {
+  if (!f || !ymean) return LSQAMD_EINVAL;
+  if (!f->have_data) BFAIL(f, LSQAMD_EINVAL, "set_data_means: call lsqamdb_set_data first");
+  BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->B * f->N, hipMemcpyHostToDevice));
+  f->ymean_stride = f->N;
+  return 0;
+}
+
+/* correlated data blocks shared by all fits; same layout as lsqamd_set_data */
+int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, const int64_t *size,
+                       const int64_t *modes, const int32_t *tri, const double *wt) {
+  if (!f) return LSQAMD_EINVAL;
+  if (n_blocks != f->cfg.n_blocks) BFAIL(f, LSQAMD_EINVAL, "set_blocks: n_blocks differs from the config");
+  if (n_blocks == 0) { f->have_blocks = true; return 0; }
+  if (!row0 || !size || !modes || !tri || !wt) return LSQAMD_EINVAL;
+  std::vector<uint8_t> inb((size_t)f->N, 0);
+  std::vector<int64_t> woff((size_t)n_blocks);
+  f->h_row0.assign(row0, row0 + n_blocks);
+  f->h_size.assign(size, size + n_blocks);
+  f->h_modes.assign(modes, modes + n_blocks);
+  f->h_tri.assign(tri, tri + n_blocks);
+  int64_t off = 0;
+  for (int32_t k = 0; k < n_blocks; ++k) {
+    if (size[k] < 1 || size[k] > f->cfg.max_block || row0[k] < 0 || row0[k] + size[k] > f->N ||
+        modes[k] < 0 || modes[k] > size[k])
+      BFAIL(f, LSQAMD_EINVAL, "set_blocks: block %d out of range", k);
+    for (int64_t i = 0; i < size[k]; ++i) {
+      if (inb[(size_t)(row0[k] + i)]) BFAIL(f, LSQAMD_EINVAL, "set_blocks: blocks overlap");
+      inb[(size_t)(row0[k] + i)] = 1;
+    }
+    woff[(size_t)k] = off;
+    off += size[k] * size[k];
+  }
+  if (off != f->cfg.sum_block_sq) BFAIL(f, LSQAMD_EINVAL, "set_blocks: sum of squares differs from the config");
+  f->h_woff = woff;
+  BHIP(f, hipMemcpy(f->in_block, inb.data(), inb.size(), hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->blk_row0, row0, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->blk_size, size, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->blk_woff, woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->wt, wt, sizeof(double) * off, hipMemcpyHostToDevice));
+  f->have_blocks = true;
   return 0;
 }
 
@@ -729,7 +808,7 @@ int lsqamdb_set_options(lsqamdb_fits *f, const lsqamd_options *opt) {
  * hipGraph after the first eager round and replay it. */
 int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, int32_t use_graph) {
   if (!f || !p0) return LSQAMD_EINVAL;
-  if (!f->have_data || (f->cfg.has_prior && !f->have_prior) ||
+  if (!f->have_data || (f->cfg.has_prior && !f->have_prior) || (f->cfg.n_blocks > 0 && !f->have_blocks) ||
       (f->cfg.model != LSQAMD_MODEL_IDENTITY && !f->have_x) || (f->cfg.model == LSQAMD_MODEL_TAPE && !f->have_tape))
     BFAIL(f, LSQAMD_EINVAL, "run: inputs missing");
   const int64_t P = f->P, B = f->B;

@@ -81,6 +81,7 @@ struct ModelArgs {
   // batched fits sharing (x, ymean, wdiag): fit b uses p + b*p_stride and writes at + b*out_stride
   int32_t n_batch = 1;
   int64_t p_stride = 0, out_stride = 0;
+  int64_t ymean_stride = 0;  // 0: the fits share ymean; n_data: fit b reads ymean + b*n_data
   const int32_t *batch_active = nullptr;
 };
 // r_w[i] = w_i (f(x_i;p) - y_i) for 1x1 rows; r_raw[i] = f - y for rows inside blocks
@@ -99,7 +100,9 @@ hipError_t launch_sumsq(hipStream_t st, const double *r, int64_t n, double *part
 // whitened block residual: r_out[row0_b + m] = sum_j Wt_b[j][m] * delta[row0_b + j]
 hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64_t *row0,
                                    const int64_t *bsize, const int64_t *woff, int32_t n_blocks,
-                                   int64_t max_block, const double *delta, double *r_out);
+                                   int64_t max_block, const double *delta, double *r_out,
+                                   int32_t batch = 1, int64_t stride = 0,
+                                   const int32_t *batch_active = nullptr);
 // packed upper tiles <- sum over split-K slabs (matrix layout, P x ld each)
 hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
                                 int64_t split_stride, int64_t P, int64_t ld, double *apk);

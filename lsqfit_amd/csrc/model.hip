@@ -36,7 +36,7 @@ struct ModelDev {
   double *out_raw;  // raw destination for rows inside correlated blocks
   int64_t ld;
   int32_t p_in_lds;
-  int64_t p_stride, out_stride;
+  int64_t p_stride, out_stride, ymean_stride;
   const int32_t *batch_active;
 };
 
@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
   const int64_t P = m.n_param, K = P / 2;
   if (m.batch_active && !m.batch_active[blockIdx.y]) return;
   m.p += (int64_t)blockIdx.y * m.p_stride;
+  m.ymean += (int64_t)blockIdx.y * m.ymean_stride;
   m.out_w += (int64_t)blockIdx.y * m.out_stride;
   if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const double *pp = m.p;
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void identity_model_kernel(ModelDev m) {
   if (row >= m.n_data) return;
   if (m.batch_active && !m.batch_active[blockIdx.y]) return;
   m.p += (int64_t)blockIdx.y * m.p_stride;
+  m.ymean += (int64_t)blockIdx.y * m.ymean_stride;
   m.out_w += (int64_t)blockIdx.y * m.out_stride;
   if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const bool blk = m.in_block && m.in_block[row];
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
   if (row >= m.n_data) return;
   if (m.batch_active && !m.batch_active[blockIdx.y]) return;
   m.p += (int64_t)blockIdx.y * m.p_stride;
+  m.ymean += (int64_t)blockIdx.y * m.ymean_stride;
   m.out_w += (int64_t)blockIdx.y * m.out_stride;
   if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const int P = (int)m.n_param;
@@ -214,6 +217,7 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
   m.out_w = out_w; m.out_raw = out_raw; m.ld = ld;
   m.p_in_lds = 0;
   m.p_stride = a.p_stride; m.out_stride = a.out_stride; m.batch_active = a.batch_active;
+  m.ymean_stride = a.ymean_stride;
   const unsigned nb = (unsigned)(a.n_batch < 1 ? 1 : a.n_batch);
   switch (a.model) {
     case LSQAMD_MODEL_COSMIX:

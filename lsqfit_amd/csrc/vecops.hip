@@ -117,8 +117,12 @@ hipError_t launch_sumsq(hipStream_t st, const double *r, int64_t n, double *part
 __global__ __launch_bounds__(256) void block_whiten_vec_kernel(const double *wt, const int64_t *row0,
                                                                const int64_t *bsize,
                                                                const int64_t *woff,
-                                                               const double *delta, double *r_out) {
+                                                               const double *delta, double *r_out,
+                                                               int64_t stride, const int32_t *active) {
   const int b = blockIdx.y;
+  if (active && !active[blockIdx.z]) return;
+  delta += (int64_t)blockIdx.z * stride;
+  r_out += (int64_t)blockIdx.z * stride;
   const int64_t B = bsize[b], r0 = row0[b];
   const double *W = wt + woff[b];
   const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -130,11 +134,12 @@ __global__ __launch_bounds__(256) void block_whiten_vec_kernel(const double *wt,
 
 hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64_t *row0,
                                    const int64_t *bsize, const int64_t *woff, int32_t n_blocks,
-                                   int64_t max_block, const double *delta, double *r_out) {
+                                   int64_t max_block, const double *delta, double *r_out,
+                                   int32_t batch, int64_t stride, const int32_t *batch_active) {
   if (n_blocks <= 0) return hipSuccess;
-  dim3 grid((unsigned)((max_block + 255) / 256), (unsigned)n_blocks);
+  dim3 grid((unsigned)((max_block + 255) / 256), (unsigned)n_blocks, (unsigned)(batch < 1 ? 1 : batch));
   hipLaunchKernelGGL(block_whiten_vec_kernel, grid, dim3(256), 0, st, wt, row0, bsize, woff, delta,
-                     r_out);
+                     r_out, stride, batch_active);
   return hipGetLastError();
 }
 

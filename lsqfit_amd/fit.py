@@ -77,6 +77,7 @@ class nonlinear_fit(object):
         else:
             wh = problem.wh
         self.problem = problem
+        self.problem_x = x
         self.whitening = wh
         self.svdcut = svdcut
         self.svdn = wh.nmod
@@ -145,3 +146,14 @@ class nonlinear_fit(object):
                 var = float(d @ cov_in[np.ix_(idx, idx)] @ d) if cov_in.ndim == 2 else float(np.sum(d * d * cov_in[idx]))
                 out[g, name] = float(np.sqrt(max(var, 0.0)))
         return out
+
+    # -- simulated / bootstrap copies ------------------------------------------
+    def simulated_fits(self, n, pexact=None, add_priornoise=False, seed=0, **kw):
+        """``simulated_fit_iter`` (src/lsqfit/__init__.py:1391-1469) as one device batch."""
+        from .resample import simulated_fits
+        return simulated_fits(self, n, pexact, add_priornoise, seed, **kw)
+
+    def bootstrapped_fits(self, n, seed=0, **kw):
+        """``bootstrapped_fit_iter`` (src/lsqfit/__init__.py:1548-1642) as one device batch."""
+        from .resample import bootstrapped_fits
+        return bootstrapped_fits(self, n, seed, **kw)

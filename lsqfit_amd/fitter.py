@@ -127,6 +127,21 @@ class DeviceProblem:
         prec = np.ascontiguousarray(prec, np.float64)
         _check(self.lib, self.h, self.lib.lsqamd_set_prior(self.h, _lib.dptr(mean), _lib.dptr(prec)), 'set_prior')
 
+    def set_ymean(self, ymean):
+        """New data means for this problem's rows (same covariance)."""
+        ymean = np.ascontiguousarray(np.asarray(ymean, np.float64).reshape(-1)[self.rows[0]:self.rows[1]]
+                                     if np.size(ymean) == self.wh.n_data else ymean, np.float64)
+        if ymean.size != self.N:
+            raise ValueError('ymean has %d entries, expected %d' % (ymean.size, self.N))
+        _check(self.lib, self.h, self.lib.lsqamd_set_ymean(self.h, _lib.dptr(ymean)), 'set_ymean')
+
+    def fcn(self, p):
+        """Unwhitened model values f(x; p) for this problem's rows."""
+        p = np.ascontiguousarray(p, np.float64)
+        out = np.empty(self.N)
+        _check(self.lib, self.h, self.lib.lsqamd_eval_fcn(self.h, _lib.dptr(p), _lib.dptr(out), out.size), 'eval_fcn')
+        return out
+
     def set_reduce(self, hook):
         """hook(dev_ptr:int, count:int) -> None sums count doubles over ranks in place."""
         def cb(user, ptr, count):

@@ -1,0 +1,116 @@
+"""Simulated and bootstrap refits: host mirror of
+``nonlinear_fit.simulated_fit_iter`` / ``simulated_data_iter`` /
+``bootstrapped_fit_iter`` (src/lsqfit/__init__.py:1391-1469,1470-1543,1548-1642).
+
+The reference loops over whole Python fits, one per copy of the data.  Every copy
+has the structure of the original fit (same model, x, covariance, whitening; only
+the data means -- and optionally the prior means -- change), so here the copies run
+as ONE lockstep batch on the device (:class:`lsqfit_amd.BatchedFits`, C ABI
+``lsqamdb_*``).  Fits with a correlated (dense) prior are refitted one after the
+other on the resident single-fit engine instead (``lsqamd_set_ymean`` /
+``lsqamd_set_prior``): still the device path, no batching.
+
+Random numbers: ``numpy.random.Generator(PCG64(seed))`` (the reference draws from
+gvar's global RNG through ``gvar.bootstrap_iter``: mean + a N(0, C_regulated) deviate).
+"""
+import numpy as np
+
+from .batched import BatchedFits
+from .fit import gammaQ
+
+
+def simulated_data(fit, n, pexact=None, add_priornoise=False, seed=0):
+    """-> (ymeans[n, N], prior_means[n, P] or None): ``simulated_data_iter``
+    (__init__.py:1519-1543): data means = fcn(pexact) + noise with the covariance of
+    ``fit.y``; prior means move only with ``add_priornoise``."""
+    wh = fit.whitening
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pexact = fit.pmean if pexact is None else np.asarray(pexact, float)
+    f = fit.problem.fcn(pexact)
+    ymeans = f[None, :] + wh.draw_data(rng, n)
+    if not wh.has_prior:
+        return ymeans, None
+    pm = np.broadcast_to(wh.prior_mean, (n, wh.prior_mean.size)).copy()
+    if add_priornoise:
+        pm += wh.draw_prior(rng, n)
+    return ymeans, pm
+
+
+def bootstrap_data(fit, n, seed=0):
+    """-> (ymeans, prior_means): ``bootstrapped_fit_iter`` with ``datalist=None``
+    (__init__.py:1615-1626): both the data and the prior means are redrawn around
+    their original values."""
+    wh = fit.whitening
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ymeans = wh.ymean[None, :] + wh.draw_data(rng, n)
+    if not wh.has_prior:
+        return ymeans, None
+    return ymeans, wh.prior_mean[None, :] + wh.draw_prior(rng, n)
+
+
+class ResampledFits(dict):
+    """Results of n refits: arrays with a leading copy index (``pmean[n, P]``, ``chi2``,
+    ``dof``, ``Q``, ``nit``, ``stopping_criterion``, ``psdev`` ...), plus the inputs
+    ``ymeans`` / ``prior_means`` and ``engine`` ('batched' or 'sequential')."""
+    __getattr__ = dict.__getitem__
+
+
+def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
+    """Refit ``fit``'s problem for every row of ``ymeans`` (and ``prior_means``)."""
+    wh = fit.whitening
+    n, P = ymeans.shape[0], fit.pmean.size
+    tol = fit.tol if tol is None else tol
+    maxit = fit.maxit if maxit is None else maxit
+    p0 = np.broadcast_to(np.asarray(p0, float), (n, P))
+    if not (wh.has_prior and wh.prior_dense):
+        bf = BatchedFits(fit.model, fit.problem_x, ymeans, None,
+                         prior_means if wh.has_prior else None,
+                         wh.prior_sdev if wh.has_prior else None, whitening=wh, n_fits=n)
+        out = bf.run(p0=p0, tol=tol, maxit=maxit, covariance=covariance)
+        bf.close()
+        res = ResampledFits(out)
+        res['engine'] = 'batched'
+    else:
+        pr = fit.problem
+        keep_y, keep_pm = wh.ymean.copy(), wh.prior_mean.copy()
+        rows = dict(pmean=[], chi2=[], nit=[], stopping_criterion=[], status=[], psdev=[], logdet_jtj=[])
+        from .fitter import mi355x_lm
+        try:
+            for k in range(n):
+                pr.set_ymean(ymeans[k])
+                pr.set_prior(prior_means[k], wh.prior_prec)
+                lm = mi355x_lm(p0[k], wh.nchiv, None, tol=tol, maxit=maxit, problem=pr)
+                rows['pmean'].append(np.array(lm.x))
+                rows['chi2'].append(lm.chi2)
+                rows['nit'].append(lm.nit)
+                rows['stopping_criterion'].append(lm.stopping_criterion)
+                rows['status'].append(0 if lm.error is None else 1)
+                rows['psdev'].append(np.sqrt(np.diag(lm.cov)))
+                rows['logdet_jtj'].append(lm.logdet_jtj)
+        finally:
+            pr.set_ymean(keep_y)
+            pr.set_prior(keep_pm, wh.prior_prec)
+        res = ResampledFits({k: np.array(v) for k, v in rows.items()})
+        res['dof'] = wh.nchiv - P
+        res['Q'] = np.array([gammaQ(res['dof'] / 2., c / 2.) for c in res['chi2']])
+        res['engine'] = 'sequential'
+    res['ymeans'] = ymeans
+    res['prior_means'] = prior_means
+    return res
+
+
+def simulated_fits(fit, n, pexact=None, add_priornoise=False, seed=0, **kw):
+    """n simulated copies of ``fit`` refitted from ``p0 = pexact`` (``simulated_fit_iter``,
+    __init__.py:1453-1469).  ``result.pexact`` holds the generating parameters."""
+    pexact = fit.pmean if pexact is None else np.asarray(pexact, float)
+    ymeans, pm = simulated_data(fit, n, pexact, add_priornoise, seed)
+    res = refit(fit, ymeans, pm, pexact, **kw)
+    res['pexact'] = pexact
+    return res
+
+
+def bootstrapped_fits(fit, n, seed=0, **kw):
+    """n bootstrap copies of ``fit`` refitted from ``p0 = fit.pmean``
+    (``bootstrapped_fit_iter``, __init__.py:1607-1626)."""
+    ymeans, pm = bootstrap_data(fit, n, seed)
+    return refit(fit, ymeans, pm, fit.pmean, **kw)

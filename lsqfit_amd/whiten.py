@@ -54,7 +54,7 @@ def _regulate_block(cov, svdcut, force_eig=False):
         W = Linv / sd[None, :]                      # inv(chol(C)) = inv(L) D^-1
         logdet = 2.0 * float(np.sum(np.log(np.diag(L)))) + 2.0 * float(np.sum(np.log(sd)))
         return dict(Wt=np.ascontiguousarray(W.T), modes=B, tri=1, logdet=logdet, nmod=0,
-                    var_reg=sd ** 2)
+                    var_reg=sd ** 2, S=sd[:, None] * L)
     lam, vec = np.linalg.eigh(corr)
     keep = np.ones(B, bool)
     lam_reg = lam.copy()
@@ -76,7 +76,9 @@ def _regulate_block(cov, svdcut, force_eig=False):
     Wt[:, :m] = W.T
     logdet = float(np.sum(np.log(lam_k)) + 2.0 * np.sum(np.log(sd)))
     var_reg = np.einsum('ik,k,ik->i', vec_k, lam_k, vec_k) * sd ** 2 if np.all(keep) else sd ** 2
-    return dict(Wt=Wt, modes=m, tri=0, logdet=logdet, nmod=nmod, var_reg=var_reg)
+    # S S^T = regulated block covariance (restricted to the kept modes): sampling factor
+    S = sd[:, None] * (vec_k * np.sqrt(lam_k))
+    return dict(Wt=Wt, modes=m, tri=0, logdet=logdet, nmod=nmod, var_reg=var_reg, S=S)
 
 
 def _extreme_eigs(corr, L, iters=40):
@@ -199,6 +201,7 @@ class Whitening:
                     raise ValueError('some priors have zero standard deviations')
                 self.prior_prec = 1.0 / psd ** 2
                 self.prior_W = ('diag', 1.0 / psd)
+                self.prior_S = [(np.arange(P), psd)]
                 self.logdet += 2.0 * float(np.sum(np.log(psd)))
                 n1 += P
                 nprior = P
@@ -206,6 +209,7 @@ class Whitening:
                 self.prior_dense = True
                 prec = np.zeros((P, P))
                 Wrows = []
+                self.prior_S = []
                 pin = np.zeros(P, bool)
                 for r0, cov in sorted(pblocks, key=lambda b: b[0]):
                     B = cov.shape[0]
@@ -215,6 +219,7 @@ class Whitening:
                     full = np.zeros((W.shape[0], P))
                     full[:, r0:r0 + B] = W
                     Wrows.append(full)
+                    self.prior_S.append((np.arange(r0, r0 + B), reg['S']))
                     pin[r0:r0 + B] = True
                     self.logdet += reg['logdet']
                     self.nmod += reg['nmod']
@@ -225,6 +230,8 @@ class Whitening:
                 self.logdet += 2.0 * float(np.sum(np.log(psd[dd])))
                 diag_rows = np.zeros((dd.size, P))
                 diag_rows[np.arange(dd.size), dd] = 1.0 / psd[dd]
+                if dd.size:
+                    self.prior_S.append((dd, psd[dd]))
                 n1 += dd.size
                 nprior += dd.size
                 self.prior_prec = prec
@@ -233,6 +240,25 @@ class Whitening:
         if n1:
             self.nblocks[1] = n1
         self.nchiv = self.nchiv_data + nprior
+
+    # -- Gaussian draws with the regulated covariance (what gvar.bootstrap_iter produces) -----
+    def draw_data(self, rng, n):
+        """(n, N) deviates with the regulated data covariance."""
+        out = rng.standard_normal((n, self.n_data)) / self.wdiag
+        for k in self.blocks:
+            S = k['S']
+            out[:, k['row0']:k['row0'] + k['size']] = rng.standard_normal((n, S.shape[1])) @ S.T
+        return out
+
+    def draw_prior(self, rng, n):
+        """(n, P) deviates with the regulated prior covariance."""
+        out = np.zeros((n, self.prior_mean.size))
+        for idx, S in self.prior_S:
+            if S.ndim == 1:
+                out[:, idx] = rng.standard_normal((n, idx.size)) * S
+            else:
+                out[:, idx] = rng.standard_normal((n, S.shape[1])) @ S.T
+        return out
 
     # -- device-facing packing ------------------------------------------------------
     def block_arrays(self, rows=None):

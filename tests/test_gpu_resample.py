@@ -1,0 +1,162 @@
+"""-m gpu: f3 of SURVEY.md 8 -- simulated / bootstrap refits as one device batch.
+
+Mirrors tests/test_lsqfit.py:1551-1577 (test_fit_iter) and :714-770 (test_bootstrap) of the
+reference, plus parity of individual copies against the single-fit engine and the oracle
+(1e-6 relative, BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from oracle import fit as ofit
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+def test_batched_blocks_match_single_engine_and_oracle(amd):
+    """Correlated (ragged) data blocks + per-fit priors in the lockstep engine."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=333, P=10, seed=41, block=100, prior_corr=False)
+    pm, ps = d['prior']
+    B = 5
+    widths = np.linspace(0.5, 2.0, B)
+    pms = np.tile(pm, (B, 1))
+    pss = ps[None, :] * widths[:, None]
+    bf = amd.BatchedFits(d['model'], d['x'], d['ymean'], d['yerr'], pms, pss)
+    out = bf.run(p0=d['p0'])
+    for b in range(B):
+        single = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=(pm, pss[b]))
+        assert gu.relmax(out['pmean'][b], single.pmean) < 1e-6
+        assert abs(out['chi2'][b] / single.chi2 - 1) < 1e-6
+        assert gu.relmax(bf.cov(b), single.cov) < 1e-6
+        assert abs(out['logGBF'][b] - single.logGBF) < 1e-6 * abs(single.logGBF) + 1e-6
+        assert out['dof'] == single.dof
+    dd = dict(d, prior=(pm, pss[2]))
+    ref = gu.oracle_fit(dd)
+    assert gu.relmax(out['pmean'][2], ref.pmean) < 1e-6
+    assert gu.relmax(bf.cov(2), ref.cov) < 1e-6
+    assert abs(out['chi2'][2] / ref.chi2 - 1) < 1e-6
+    bf.close()
+
+
+def test_simulated_copies_match_oracle(amd):
+    """Each simulated copy refitted in the batch equals an oracle fit of the same inputs."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=256, P=8, seed=42, block=64, prior_corr=False)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    res = fit.simulated_fits(6, add_priornoise=True, seed=3)
+    assert res.engine == 'batched' and res.pmean.shape == (6, 8)
+    # model values at pexact through the C ABI
+    assert gu.relmax(fit.problem.fcn(fit.pmean), gu.cosmix_fcn(d['x'], fit.pmean)) < 1e-12
+    for k in (0, 5):
+        dd = dict(d, ymean=res.ymeans[k], prior=(res.prior_means[k], d['prior'][1]))
+        ref = gu.oracle_fit(dd, p0=fit.pmean)
+        assert gu.relmax(res.pmean[k], ref.pmean) < 1e-6
+        assert abs(res.chi2[k] / ref.chi2 - 1) < 1e-6
+        assert gu.relmax(res.psdev[k], ref.psdev) < 1e-6
+    # no-prior variant of the batch (dof = N - P)
+    fit2 = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], p0=d['p_true'])
+    res2 = fit2.bootstrapped_fits(4, seed=9)
+    assert res2.dof == 256 - 8 and res2.prior_means is None
+    ref2 = ofit.nonlinear_fit(d['x'], res2.ymeans[1], gu.dense_cov(d['yerr'], 256), gu.cosmix_fcn,
+                              p0=fit2.pmean, jac=gu.cosmix_jac, solver='cholesky')
+    assert gu.relmax(res2.pmean[1], ref2.pmean) < 1e-6
+    assert abs(res2.chi2[1] / ref2.chi2 - 1) < 1e-6
+
+
+@pytest.mark.parametrize('svdcut', [1e-12, 0.5])
+def test_fit_iter(amd, svdcut):
+    """tests/test_lsqfit.py:1551-1577: y = ['2.1(1.2)','1.7(5.2)','2.2(3)','3.2(1.5)','1.9(2)'],
+    y[1:] = (y[1:] + y[:1]) / 2, fcn = constant, prior 2(1)."""
+    m = np.array([2.1, 1.7, 2.2, 3.2, 1.9])
+    s = np.array([1.2, 5.2, 0.3, 1.5, 0.2])
+    A = np.eye(5)
+    A[1:, 0] = 0.5
+    A[1:, 1:] = 0.5 * np.eye(4)
+    ymean, ycov = A @ m, A @ np.diag(s ** 2) @ A.T
+    model = amd.expr('p0 + 0*x', ['p0'])
+    fit = amd.nonlinear_fit(data=(np.zeros(5), ymean, ycov), model=model, prior=([2.0], [1.0]), svdcut=svdcut)
+    N = 100
+    res = fit.simulated_fits(N, seed=11)
+    np.testing.assert_allclose(res.psdev[:, 0], fit.psdev[0], rtol=1e-7)
+    assert np.all(res.prior_means == 2.0)
+    assert abs(np.average(res.pmean[:, 0]) - fit.pmean[0]) < 5 * fit.psdev[0] / N ** 0.5
+    assert np.all(res.stopping_criterion > 0)
+    res = fit.simulated_fits(N, add_priornoise=True, seed=12)
+    pmn = res.prior_means[:, 0]
+    assert abs(np.average(pmn) - 2.0) < 5 * 1.0
+    assert abs(np.std(pmn) / 1.0 - 1) < 5. / N ** 0.5
+    # with prior noise chi2/dof ~ 1 +- sqrt(2/dof) on average (docstring :1427-1431)
+    assert abs(np.average(res.chi2) / res.dof - 1) < 5 * np.sqrt(2.0 / res.dof / N)
+
+
+def _bin(v):
+    return (v[:-1] + v[1:]) / 2.
+
+
+@pytest.mark.parametrize('case', ['plain', 'binned', 'binned_y', 'binned_p', 'noprior', 'noprior_binned'])
+def test_bootstrap(amd, case):
+    """tests/test_lsqfit.py:714-770: fcn = p**2; the bootstrap distribution of avg(p**2) agrees
+    with the fit (10 sigma of the mean, as there)."""
+    rng = np.random.default_rng(50)
+    ny = 3
+    y0 = 4.0 + 0.25 * rng.standard_normal(ny)
+    p20 = 4.0 + 0.25 * rng.standard_normal(ny)
+    ycov, y2cov = np.diag(np.full(ny, 0.25 ** 2)), np.diag(np.full(ny, 0.25 ** 2))
+    # prior on p = sqrt(p2): mean sqrt(p2), sdev 0.25 / (2 sqrt(p2))
+    pmean0 = np.sqrt(p20)
+    Jp = np.diag(0.5 / pmean0)
+    pcov0 = Jp @ y2cov @ Jp.T
+    Bm = np.zeros((ny - 1, ny))
+    for i in range(ny - 1):
+        Bm[i, i] = Bm[i, i + 1] = 0.5
+    Tr = np.eye(ny)[:-1]
+    ysel = Bm if case in ('binned', 'binned_y', 'noprior_binned') else Tr
+    psel = Bm if case in ('binned', 'binned_p') else Tr
+    ymean, yc = ysel @ y0, ysel @ ycov @ ysel.T
+    model = amd.expr('s0*p0**2 + s1*p1**2', ['p0', 'p1'], xnames=('s0', 's1'))
+    x = np.eye(2)
+    if case.startswith('noprior'):
+        fit = amd.nonlinear_fit(data=(x, ymean, yc), model=model, p0=np.sqrt(ymean))
+    else:
+        pm, pc = psel @ pmean0, psel @ pcov0 @ psel.T
+        fit = amd.nonlinear_fit(data=(x, ymean, yc), model=model, prior=(pm, pc))
+    nbs = 100
+    res = fit.bootstrapped_fits(nbs, seed=77)
+    dense_prior = case in ('binned', 'binned_p')
+    assert res.engine == ('sequential' if dense_prior else 'batched')
+    ok = res.status == 0
+    assert ok.sum() >= nbs - 2
+    bs = np.median(np.mean(res.pmean[ok] ** 2, axis=1))
+    g = 2 * fit.pmean / 2.0                                  # gradient of avg(p**2)
+    fit_ans, fit_sd = np.mean(fit.pmean ** 2), np.sqrt(g @ fit.cov @ g)
+    assert abs(bs - fit_ans) < 10. * fit_sd / nbs ** 0.5
+
+
+def test_config5_shape_correlated_bootstrap(amd):
+    """128 simulated copies (data and prior means redrawn around the fit) of a (4096, 512) fit
+    with 256-row correlated blocks in one batch."""
+    import time
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=4096, P=512, seed=20264, block=256, prior_corr=False)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    t0 = time.perf_counter()
+    res = fit.simulated_fits(128, add_priornoise=True, seed=5, covariance=False)
+    dt = time.perf_counter() - t0
+    print('config-5-shaped correlated simulated fits: 128 copies, %d rounds, device %.1f ms, wall %.2f s'
+          % (res['rounds'], res['device_ms'], dt))
+    assert res.engine == 'batched'
+    assert np.all(res.status == 0) and np.all(res.stopping_criterion > 0)
+    # both data and prior means redrawn: chi2/dof ~ 1 (exactly 1 +- sqrt(2/dof) for a linear
+    # model -- test_fit_iter holds that; the frequencies make this one mildly nonlinear)
+    assert abs(np.mean(res.chi2) / res.dof - 1) < 0.05
+    # spread of the copies' parameters = the fit's errors (Gaussian limit)
+    z = (res.pmean - fit.pmean) / fit.psdev
+    assert 0.9 < z.std() < 1.1
