@@ -218,6 +218,19 @@ int lsqamd_get_jtj(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : 
 int lsqamd_get_grad(lsqamd_fit *fit, double *out, size_t cap);    /* P        : J^T f  */
 int lsqamd_get_cov(lsqamd_fit *fit, double *out, size_t cap);     /* P * P    : fit.cov (gsl_multifit_nlinear_covar, _gsl.pyx:704-706) */
 
+/* ---- chi**2 at many parameter points -------------------------------------
+ * Replaces the Python loop / numpy batch behind nonlinear_fit.dchi2 / .pdf
+ * (_fit_dchi2, _fit_pdf: src/lsqfit/__init__.py:1648-1816, `sum(chiv(p)**2)`) and the
+ * batched layout of vegas_fit._chiv (src/lsqfit/_extras.py:2467-2486,
+ * `chiv[:, iw] = delta[:, iw].dot(wgt.T)`): chi2_out[i] = |chiv(p_i)|^2 for m points
+ * p[m x P] (host, row-major), prior term included.  dev_scratch: device memory from the
+ * caller; lsqamd_chi2_points_work_bytes(fit, m) processes all m points in one pass, a smaller
+ * buffer makes the call work in chunks.  Row-sharded fits: the per-point sums go through
+ * the all-reduce hook. */
+size_t lsqamd_chi2_points_work_bytes(const lsqamd_fit *fit, int64_t m);
+int lsqamd_chi2_points(lsqamd_fit *fit, const double *p, int64_t m, void *dev_scratch, size_t scratch_bytes,
+                       double *chi2_out);
+
 /* ---- sensitivity of the best-fit parameters to the inputs ------------
  * Replaces the matrix D[a,i] = d pmean[a] / d buf[i], buf = concat(y, prior), that
  * nonlinear_fit._getp builds column by column from chivw and cov

@@ -76,6 +76,8 @@ PROTOTYPES = {
     'lsqamd_get_grad': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_get_cov': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_nf': (C.c_int64, [_vp]),
+    'lsqamd_chi2_points_work_bytes': (C.c_size_t, [_vp, C.c_int64]),
+    'lsqamd_chi2_points': (C.c_int, [_vp, _dp, C.c_int64, _vp, C.c_size_t, _dp]),
     'lsqamd_dpdy_work_bytes': (C.c_size_t, [_vp, C.c_int64]),
     'lsqamd_dpdy': (C.c_int, [_vp, _dp, C.c_int64, _vp, C.c_size_t, _dp, C.c_size_t]),
     'lsqamdb_workspace_bytes': (C.c_size_t, [C.POINTER(Config), C.c_int32]),

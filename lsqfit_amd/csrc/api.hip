@@ -1152,6 +1152,78 @@ int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, s
   return 0;
 }
 
+namespace {
+struct Chi2Plan {
+  int64_t ldt;
+  double *p, *r, *r_raw, *Dt, *T, *out;
+  size_t bytes;
+};
+Chi2Plan chi2_plan(const lsqamd_fit *f, int64_t mc, void *base) {
+  Chi2Plan d;
+  d.ldt = rup(mc, 16);
+  Carver cv(base, 0, base == nullptr);
+  d.p = cv.take<double>(mc * f->P);
+  d.r = cv.take<double>(mc * f->N);
+  d.r_raw = cv.take<double>(f->cfg.n_blocks > 0 ? mc * f->N : 1);
+  const bool dense = f->cfg.has_prior && f->cfg.prior_dense;
+  d.Dt = cv.take<double>(dense ? f->P * d.ldt : 1);
+  d.T = cv.take<double>(dense ? f->P * d.ldt : 1);
+  d.out = cv.take<double>(mc);
+  d.bytes = cv.off;
+  return d;
+}
+}  // namespace
+
+size_t lsqamd_chi2_points_work_bytes(const lsqamd_fit *f, int64_t m) {
+  if (!f || m < 1) return 0;
+  return chi2_plan(f, m, nullptr).bytes + 256;
+}
+
+int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scratch, size_t scratch_bytes,
+                       double *chi2_out) {
+  if (!f || !p || !chi2_out || !dev_scratch || m < 0) return LSQAMD_EINVAL;
+  int rc = ready(f);
+  if (rc) return rc;
+  if (m == 0) return 0;
+  char *base = (char *)dev_scratch;
+  const size_t pad = (size_t)((-(intptr_t)base) & 255);
+  if (scratch_bytes <= pad) FAIL(f, LSQAMD_ENOMEM, "chi2_points: scratch too small");
+  // largest chunk that fits the scratch
+  int64_t mc = m;
+  while (mc > 1 && chi2_plan(f, mc, nullptr).bytes + pad > scratch_bytes) mc = (mc + 1) / 2;
+  if (chi2_plan(f, mc, nullptr).bytes + pad > scratch_bytes)
+    FAIL(f, LSQAMD_ENOMEM, "chi2_points: scratch needs at least %zu bytes", chi2_plan(f, 1, nullptr).bytes + 256);
+  if (mc > 65535) mc = 65535;  // grid.y of the model kernels
+  const int64_t N = f->N, P = f->P;
+  Scope sc(f, LSQAMD_T_RESIDUAL);
+  for (int64_t m0 = 0; m0 < m; m0 += mc) {
+    const int64_t mm = m - m0 < mc ? m - m0 : mc;
+    Chi2Plan d = chi2_plan(f, mc, base + pad);
+    HIPCHK(f, hipMemcpyAsync(d.p, p + m0 * P, sizeof(double) * mm * P, hipMemcpyHostToDevice, f->st));
+    if (N > 0) {
+      ModelArgs ma = model_args(f, d.p);
+      ma.n_batch = (int32_t)mm; ma.p_stride = P; ma.out_stride = N;
+      HIPCHK(f, launch_residual_ex(f->st, ma, d.r, d.r_raw));
+      if (f->cfg.n_blocks > 0)
+        HIPCHK(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff,
+                                          f->cfg.n_blocks, f->cfg.max_block, d.r_raw, d.r, (int32_t)mm, N,
+                                          nullptr));
+      HIPCHK(f, launch_rows_sumsq(f->st, d.r, N, N, mm, d.out, 0));
+    } else {
+      HIPCHK(f, hipMemsetAsync(d.out, 0, sizeof(double) * mm, f->st));
+    }
+    if (f->cfg.has_prior && f->adds_prior)
+      HIPCHK(f, launch_prior_chi2_points(f->st, P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, d.p, mm,
+                                         d.Dt, d.T, d.ldt, d.out));
+    rc = do_reduce(f, d.out, mm);
+    if (rc) return rc;
+    HIPCHK(f, hipMemcpyAsync(chi2_out + m0, d.out, sizeof(double) * mm, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    f->nfev += (int32_t)mm;
+  }
+  return 0;
+}
+
 void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long long *)dev_ptr; }
 
 // introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor

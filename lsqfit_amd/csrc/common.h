@@ -131,6 +131,14 @@ hipError_t launch_rows_scale_copy(hipStream_t st, const double *src, int64_t lds
                                   int64_t ldd, int64_t rows, int64_t cols, const double *scale,
                                   const uint8_t *skip);
 
+// out[m] (+)= |r_m|^2 for m points, r_m = r + m*stride
+hipError_t launch_rows_sumsq(hipStream_t st, const double *r, int64_t n, int64_t stride, int64_t m,
+                             double *out, int accumulate);
+// out[m] += (p_m - pmean)^T Lambda (p_m - pmean); dense: Dt, T are P x ldt scratch (ldt >= m, even)
+hipError_t launch_prior_chi2_points(hipStream_t st, int64_t P, const double *prec, int32_t dense,
+                                    const double *pmean, const double *p, int64_t m, double *Dt,
+                                    double *T, int64_t ldt, double *out);
+
 inline int64_t packed_doubles(int64_t P) {
   const int64_t T = (P + 127) / 128;
   return T * (T + 1) / 2 * 128 * 128;

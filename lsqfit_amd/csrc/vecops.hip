@@ -420,4 +420,94 @@ hipError_t launch_rows_scale_copy(hipStream_t st, const double *src, int64_t lds
   return hipGetLastError();
 }
 
+// ---- chi2 of many parameter points -------------------------------------------
+__device__ __forceinline__ double wsum64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// out[m] (+)= sum_i r[m*stride + i]^2 ; one workgroup per point
+__global__ __launch_bounds__(256) void rows_sumsq_kernel(const double *r, int64_t n, int64_t stride,
+                                                         double *out, int accumulate) {
+  __shared__ double sh[4];
+  const double *rm = r + (int64_t)blockIdx.x * stride;
+  double a = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double v = rm[i];
+    a += v * v;
+  }
+  a = wsum64(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = sh[0] + sh[1] + sh[2] + sh[3];
+    out[blockIdx.x] = accumulate ? out[blockIdx.x] + t : t;
+  }
+}
+
+hipError_t launch_rows_sumsq(hipStream_t st, const double *r, int64_t n, int64_t stride, int64_t m,
+                             double *out, int accumulate) {
+  if (m <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rows_sumsq_kernel, dim3((unsigned)m), dim3(256), 0, st, r, n, stride, out, accumulate);
+  return hipGetLastError();
+}
+
+// out[m] += sum_j prec[j] (p[m][j] - pmean[j])^2
+__global__ __launch_bounds__(256) void prior_chi2_points_diag_kernel(int64_t P, const double *prec,
+                                                                     const double *pmean,
+                                                                     const double *p, double *out) {
+  __shared__ double sh[4];
+  const double *pm = p + (int64_t)blockIdx.x * P;
+  double a = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double d = pm[j] - pmean[j];
+    a += prec[j] * d * d;
+  }
+  a = wsum64(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] += sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// Dt[k][m] = p[m][k] - pmean[k]
+__global__ __launch_bounds__(256) void delta_transpose_kernel(const double *p, const double *pmean,
+                                                              double *Dt, int64_t ldt, int64_t M,
+                                                              int64_t P) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t k = blockIdx.y;
+  if (m < M) Dt[k * ldt + m] = p[m * P + k] - pmean[k];
+}
+
+// out[m] += sum_k A[k][m] * B[k][m]
+__global__ __launch_bounds__(256) void coldot_accum_kernel(const double *A, const double *B, int64_t ld,
+                                                           int64_t K, int64_t M, double *out) {
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  double a = 0.0;
+  for (int64_t k = 0; k < K; ++k) a += A[k * ld + m] * B[k * ld + m];
+  out[m] += a;
+}
+
+hipError_t launch_prior_chi2_points(hipStream_t st, int64_t P, const double *prec, int32_t dense,
+                                    const double *pmean, const double *p, int64_t m, double *Dt,
+                                    double *T, int64_t ldt, double *out) {
+  if (m <= 0) return hipSuccess;
+  if (!dense) {
+    hipLaunchKernelGGL(prior_chi2_points_diag_kernel, dim3((unsigned)m), dim3(256), 0, st, P, prec, pmean,
+                       p, out);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(delta_transpose_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)P), dim3(256), 0,
+                     st, p, pmean, Dt, ldt, m, P);
+  GemmTN g;  // T = Lambda . Dt  (Lambda symmetric: its rows are the k-major operand)
+  g.X = prec; g.ldx = P; g.Y = Dt; g.ldy = ldt; g.C = T; g.ldc = ldt;
+  g.M = P; g.N = m; g.K = P;
+  hipError_t e = launch_gemm_tn(st, g);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(coldot_accum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, Dt, T, ldt,
+                     P, m, out);
+  return hipGetLastError();
+}
+
 }  // namespace lsqamd

@@ -157,3 +157,21 @@ class nonlinear_fit(object):
         """``bootstrapped_fit_iter`` (src/lsqfit/__init__.py:1548-1642) as one device batch."""
         from .resample import bootstrapped_fits
         return bootstrapped_fits(self, n, seed, **kw)
+
+    # -- chi2(p) / pdf(p) at arbitrary points (SURVEY.md 8 f2) -----------------------------------
+    def dchi2(self, p):
+        """``chi**2(p) - fit.chi2`` (``_fit_dchi2``, src/lsqfit/__init__.py:1648-1670); ``p`` of
+        shape (P,) -> float, (m, P) -> array of m values evaluated in one device pass (the
+        lbatch layout of ``vegas_fit._chiv``, src/lsqfit/_extras.py:2467-2486)."""
+        p = np.asarray(p, float)
+        c = self.problem.chi2_points(p.reshape(-1, self.pmean.size)) - self.chi2
+        return float(c[0]) if p.ndim == 1 else c
+
+    def pdf(self, p):
+        """``exp(-(chi**2(p) - fit.chi2)/2)`` (``_fit_pdf``, src/lsqfit/__init__.py:1803-1816)."""
+        return np.exp(-0.5 * self.dchi2(p))
+
+    @property
+    def pdf_lognorm(self):
+        """``fit.pdf.lognorm`` (src/lsqfit/__init__.py:1806-1809)."""
+        return 0.5 * (self.whitening.logdet + np.log(2 * np.pi) * (self.dof + self.pmean.size)) + self.chi2 / 2

@@ -239,6 +239,25 @@ class DeviceProblem:
         n = self.nf_data()
         return self._get(self.lib.lsqamd_get_J, n * self.P, (n, self.P))
 
+    def chi2_points(self, ps, max_scratch_bytes=1 << 30):
+        """chi**2 at every row of ``ps`` (m x P) in one device pass (chunked to the scratch)."""
+        import torch
+        ps = np.ascontiguousarray(np.atleast_2d(np.asarray(ps, np.float64)))
+        if ps.shape[1] != self.P:
+            raise ValueError('points must have %d columns' % self.P)
+        m = ps.shape[0]
+        out = np.empty(m)
+        if m == 0:
+            return out
+        nbytes = min(self.lib.lsqamd_chi2_points_work_bytes(self.h, m),
+                     max(int(max_scratch_bytes), self.lib.lsqamd_chi2_points_work_bytes(self.h, 1)))
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        rc = self.lib.lsqamd_chi2_points(self.h, _lib.dptr(ps), m, C.c_void_p(scratch.data_ptr()), nbytes,
+                                         _lib.dptr(out))
+        self._raise_reduce()
+        _check(self.lib, self.h, rc, 'chi2_points')
+        return out
+
     def dpdy(self, G=None):
         """Sensitivity of the best-fit parameters to the inputs at the current point:
         ``D = cov [J_f ; I]^T inv(C_reg)`` (``_getp``, src/lsqfit/__init__.py:897-911).

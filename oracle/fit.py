@@ -130,6 +130,7 @@ def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
     fit.svdcut = svdcut
     lm = gsl_multifit(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
     fit.lm = lm
+    fit.chiv = chiv
     fit.error = lm.error
     fit.cov = lm.cov
     fit.chi2 = float(np.sum(lm.f ** 2))
@@ -187,3 +188,23 @@ def partial_sdev(D, grads, groups, cov_in):
             idx = np.asarray(idx, int)
             out[g, name] = float(np.sqrt(max(d[idx] @ cov_in[np.ix_(idx, idx)] @ d[idx], 0.0)))
     return out
+
+
+def dchi2(fit, p):
+    """``chi**2(p) - fit.chi2`` (``_fit_dchi2.__call__``, src/lsqfit/__init__.py:1664-1669);
+    ``p`` (P,) or (m, P) -- the latter is vegas_fit._chiv's lbatch layout
+    (src/lsqfit/_extras.py:2467-2486)."""
+    p = np.asarray(p, float)
+    if p.ndim == 1:
+        return float(np.sum(fit.chiv.residual(p) ** 2) - fit.chi2)
+    return np.array([np.sum(fit.chiv.residual(q) ** 2) for q in p]) - fit.chi2
+
+
+def pdf(fit, p):
+    """``exp(-dchi2/2)`` (``_fit_pdf.__call__``, src/lsqfit/__init__.py:1811-1816)."""
+    return np.exp(-0.5 * dchi2(fit, p))
+
+
+def pdf_lognorm(fit):
+    """``_fit_pdf.lognorm`` (src/lsqfit/__init__.py:1806-1809)."""
+    return 0.5 * (fit.pdf.logdet + np.log(2 * np.pi) * (fit.dof + fit.pmean.size)) + fit.chi2 / 2

@@ -360,3 +360,25 @@ def test_partialerr_weighted_average():
     assert err['y', 'not y'] == 0.0 and abs(err['y', 'other prior']) < 1e-5
     assert abs(err['not y', 'not y'] - 0.125) < 1e-12
     assert err['not y', 'y'] == 0.0 and err['not y', 'other prior'] == 0.0
+
+
+def test_pdf_dchi2():
+    """tests/test_lsqfit.py:415-454 (test_pdf_dchi2): for a linear fit dchi2(pmean + psdev) equals
+    the number of parameters moved by one sigma... as asserted there."""
+    ymean, ysd = np.array([1.5, 0.8, 12.0]), np.array([1.0, 0.5, 13.0])
+    fcn = lambda p: dual.concatenate([p[0].reshape(1)] * 3) if isinstance(p, dual.Dual) else np.full(3, p[0])
+    fit = ofit.nonlinear_fit(False, ymean, ysd, fcn, prior_mean=[0.0, 0.0], prior_err=[2.0, 5.0])
+    assert abs(ofit.pdf(fit, fit.pmean) - 1.0) < 1e-7
+    assert abs(ofit.dchi2(fit, fit.pmean)) < 1e-7
+    p = fit.pmean + fit.psdev
+    assert abs(ofit.dchi2(fit, p) - 2) < 1e-7               # fit.prior.size
+    assert abs(ofit.pdf(fit, p) - np.exp(-ofit.dchi2(fit, p) / 2)) < 1e-12
+    p[0] = fit.pmean[0]
+    assert abs(ofit.dchi2(fit, p) - 1) < 1e-7
+    # one-parameter case (:445-454)
+    fit = ofit.nonlinear_fit(False, ymean, ysd, fcn, prior_mean=[0.0], prior_err=[2.0])
+    assert abs(ofit.dchi2(fit, fit.pmean + fit.psdev) - 1) < 1e-7
+    # batched (lbatch) layout agrees with the single-point call
+    pts = fit.pmean + np.linspace(-2, 2, 7)[:, None] * fit.psdev
+    np.testing.assert_allclose(ofit.dchi2(fit, pts), [ofit.dchi2(fit, q) for q in pts], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(ofit.dchi2(fit, pts), np.linspace(-2, 2, 7) ** 2, atol=1e-7)
