@@ -161,3 +161,38 @@ def test_synth_generator_is_fake_fitargs_like():
     fit = ofit.nonlinear_fit(d['x'], d['ymean'], cov, fcn, prior_mean=d['prior'][0], prior_err=d['prior'][1])
     assert fit.chi2 / fit.dof < 6
     assert np.all(np.abs(fit.pmean - d['p_true']) < 6 * fit.psdev)
+
+
+def test_draws_have_the_regulated_covariance():
+    """Whitening.draw_data / draw_prior (what gvar.bootstrap_iter supplies to
+    simulated_data_iter, src/lsqfit/__init__.py:1534-1543): sample covariance -> C_reg, and
+    whitened draws are unit normal (W S = orthogonal)."""
+    from lsqfit_amd.whiten import Whitening
+    rng = np.random.default_rng(3)
+    N = 12
+    sd = rng.uniform(0.5, 2.0, N)
+    U = rng.uniform(0.1, 0.9, (5, 10))
+    c1 = U @ U.T
+    U = rng.uniform(0.1, 0.9, (4, 8))
+    c2 = U @ U.T
+    c2[1] = c2[0] * (1 + 1e-9)          # nearly singular: the svdcut floors one mode
+    c2[:, 1] = c2[1]
+    c2[1, 1] = c2[0, 0] * (1 + 2e-9)
+    yerr = dict(sdev=sd, blocks=[(2, c1), (8, c2)])
+    pcov = np.array([[1.0, 0.3], [0.3, 0.5]])
+    wh = Whitening(np.zeros(N), yerr, np.zeros(2), pcov, svdcut=1e-4)
+    assert wh.nmod >= 1
+    for k in wh.blocks:
+        W = k['Wt'].T[:k['modes']]
+        np.testing.assert_allclose(W @ k['S'] @ k['S'].T @ W.T, np.eye(k['modes']), atol=1e-8)
+    n = 200000
+    draws = wh.draw_data(np.random.default_rng(4), n)
+    emp = draws.T @ draws / n
+    want = np.diag(1.0 / wh.wdiag ** 2)
+    for k in wh.blocks:
+        sl = slice(k['row0'], k['row0'] + k['size'])
+        want[sl, sl] = k['S'] @ k['S'].T
+    scale = np.sqrt(np.outer(np.diag(want), np.diag(want)))
+    assert np.abs((emp - want) / scale).max() < 0.02
+    pd = wh.draw_prior(np.random.default_rng(5), n)
+    assert np.abs(pd.T @ pd / n - pcov).max() < 0.01
