@@ -26,6 +26,27 @@ convergence,qr,cholesky,covar}.c):
 Iteration counts are pinned nowhere in the reference; only the
 converged (x, cov, f) and ``stopping_criterion`` are.
 
+Other trust-region sub-problem solvers (``alg`` = lmaccel / dogleg / ddogleg /
+subspace2D, _gsl.pyx:622-635), restated from
+multifit_nlinear/{lm,dogleg,subspace2D,fdfvv}.c:
+
+  lmaccel    velocity v as in lm; fvv = (2/h)((F(x+hv)-F(x))/h - J v), h = h_fvv = 0.02
+             (no analytic fvv is ever supplied: fdf.fvv = NULL, _gsl.pyx:662);
+             acceleration a: (J^T J + mu D^2) a = -J^T fvv; dx = v + a/2;
+             the step is rejected when |a|/|v| > avmax (trust_eval_step); the predicted
+             reduction is lm's, evaluated on dx.
+  dogleg     dx_sd = -alpha D^-2 g, alpha = |D^-1 g|^2/|J D^-2 g|^2; dx_gn from mu = 0;
+             |D dx_sd| >= delta: dx_sd scaled to the boundary; |D dx_gn| <= delta: dx_gn;
+             else dx_sd + beta (dx_gn - dx_sd) on the boundary.
+  ddogleg    as dogleg with the Gauss-Newton leg shortened by t = 1 - 0.8 (1 - c),
+             c = |D^-1 g|^4 / (|J D^-2 g|^2 |g^T dx_gn|); t |D dx_gn| <= delta:
+             dx_gn scaled to the boundary.
+  subspace2D exact minimiser of the quadratic model over span(D dx_sd, D dx_gn) on the
+             trust-region boundary (GSL: roots of a quartic; here the equivalent secular
+             equation of the 2x2 problem); dx_gn inside: dx_gn; parallel legs: dx_sd scaled.
+  dogleg-family predicted reduction: -(|J dx|^2 + 2 g.dx)/|f|^2; delta is updated by
+  factor_up/factor_down exactly as for lm (where it is inert).
+
 A second entry point, ``lm_normal``, runs the identical driver from the
 normal equations (A=J^T J, g=J^T f, |f|^2) supplied by a callback; it is the
 form a row-sharded evaluation reduces to (one sum over shards per Jacobian)
@@ -87,6 +108,20 @@ class _DenseLin:
     def norm_Jv2(self, v):
         w = self.J @ v
         return float(w @ w)
+
+    def step_rhs(self, mu, diag, fvec):
+        """min |J a + fvec|^2 + mu |D a|^2 (the acceleration solve of lm_step)."""
+        keep_f, keep_g = self.f, self.g
+        self.f, self.g = fvec, self.J.T @ fvec
+        try:
+            return self.step(mu, diag)
+        finally:
+            self.f, self.g = keep_f, keep_g
+
+    def fvv(self, x, v, h, eval_fvec):
+        """fdfvv.c: finite-difference second directional derivative."""
+        fp = eval_fvec(x + h * v)
+        return (2.0 / h) * ((fp - self.f) / h - self.J @ v)
 
     def covar(self):
         """gsl_multifit_nlinear_covar(J, epsrel=0): pivoted QR, (R^T R)^-1."""
@@ -150,7 +185,32 @@ class LMResult:
     pass
 
 
-def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down):
+def _solve_tr_2d(B, g, delta):
+    """argmin g.q + q.B.q/2 subject to |q| = delta for a 2x2 positive semi-definite B with
+    the unconstrained minimiser outside the ball: q = -(B + lam I)^-1 g, lam > 0 from the
+    secular equation (bisection + Newton on 1/|q(lam)|)."""
+    w, V = np.linalg.eigh(B)
+    gt = V.T @ g
+
+    def qnorm(lam):
+        return float(np.sqrt(np.sum((gt / (w + lam)) ** 2)))
+    lo, hi = 0.0, max(1.0, float(np.linalg.norm(g)) / delta)
+    while qnorm(hi) > delta:
+        hi *= 2.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        if qnorm(mid) > delta:
+            lo = mid
+        else:
+            hi = mid
+        if hi - lo <= 1e-16 * hi:
+            break
+    lam = 0.5 * (lo + hi)
+    return V @ (-gt / (w + lam))
+
+
+def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down,
+           alg='lm', avmax=0.75, h_fvv=0.02, eval_fvec=None):
     """Shared trust.c/fdf.c logic.  ``evaluate(x)`` refreshes ``lin`` with the
     Jacobian-level quantities at x and returns |f|^2; ``eval_fnorm2(x)`` is the
     cheap trial evaluation."""
@@ -171,12 +231,104 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
     delta = 0.3 * max(1.0, float(np.linalg.norm(diag * x)))
     dx = np.zeros(P)
 
+    if alg not in ('lm', 'lmaccel', 'dogleg', 'ddogleg', 'subspace2D'):
+        raise ValueError('unkown algorithm ' + str(alg))
+    if alg == 'lmaccel' and (eval_fvec is None or not hasattr(lin, 'fvv')):
+        raise ValueError('lmaccel needs residual-level access (dense driver only)')
+    leg = {}
+
+    def dogleg_preloop():
+        # dogleg_preloop / subspace2D_preloop: steepest-descent leg; Gauss-Newton leg lazily
+        g = lin.g
+        w1 = g / diag
+        leg['norm_Dinvg'] = float(np.linalg.norm(w1))
+        w2 = w1 / diag
+        leg['norm_JDinv2g'] = float(np.sqrt(lin.norm_Jv2(w2)))
+        uu = leg['norm_Dinvg'] / leg['norm_JDinv2g']
+        leg['dx_sd'] = -(uu * uu) * w2
+        leg['norm_Dsd'] = float(np.linalg.norm(diag * leg['dx_sd']))
+        leg['norm_Dgn'] = -1.0
+        leg.pop('sub', None)
+
+    def calc_gn():
+        if leg['norm_Dgn'] < 0.0:
+            leg['dx_gn'] = lin.step(0.0, diag)
+            leg['norm_Dgn'] = float(np.linalg.norm(diag * leg['dx_gn']))
+
+    def dogleg_beta(t):
+        w = t * leg['dx_gn'] - leg['dx_sd']
+        a = float(np.sum((diag * w) ** 2))
+        b = 2.0 * float(leg['dx_sd'] @ (diag * diag * w))
+        c = (leg['norm_Dsd'] + delta) * (leg['norm_Dsd'] - delta)
+        disc = np.sqrt(b * b - 4.0 * a * c)
+        return (-2.0 * c) / (b + disc) if b > 0.0 else (-b + disc) / (2.0 * a)
+
+    def trs_step():
+        """-> (dx, avratio)"""
+        if alg in ('lm', 'lmaccel'):
+            v = lin.step(mu, diag)                        # lm_step
+            if alg == 'lm':
+                return v, 0.0
+            a = lin.step_rhs(mu, diag, lin.fvv(x, v, h_fvv, eval_fvec))
+            res.nfev += 1
+            return v + 0.5 * a, float(np.linalg.norm(a) / np.linalg.norm(v))
+        if alg == 'subspace2D':
+            calc_gn()
+            if leg['norm_Dgn'] <= delta:
+                return leg['dx_gn'], 0.0
+            if 'sub' not in leg:
+                W = np.column_stack([diag * leg['dx_sd'] / leg['norm_Dsd'],
+                                     diag * leg['dx_gn'] / leg['norm_Dgn']])
+                Q, R, _ = sla.qr(W, mode='economic', pivoting=True)
+                rank = int(np.sum(np.abs(np.diag(R)) > np.finfo(float).eps * 2 * abs(R[0, 0]))) if R[0, 0] != 0 else 0
+                if rank == 2:
+                    DQ = Q / diag[:, None]
+                    subB = np.array([[lin_quad(DQ[:, i], DQ[:, j]) for j in range(2)] for i in range(2)])
+                    leg['sub'] = (Q, DQ.T @ lin.g, subB)
+                else:
+                    leg['sub'] = None
+            if leg['sub'] is None:
+                return leg['dx_sd'] * (delta / leg['norm_Dsd']), 0.0
+            Q, subg, subB = leg['sub']
+            return (Q @ _solve_tr_2d(subB, subg, delta)) / diag, 0.0
+        # dogleg / ddogleg
+        if leg['norm_Dsd'] >= delta:
+            return leg['dx_sd'] * (delta / leg['norm_Dsd']), 0.0
+        calc_gn()
+        if leg['norm_Dgn'] <= delta:
+            return leg['dx_gn'], 0.0
+        t = 1.0
+        if alg == 'ddogleg':
+            uu = (leg['norm_Dinvg'] / leg['norm_JDinv2g']) ** 2
+            gd = float(lin.g @ leg['dx_gn'])
+            c = uu * (leg['norm_Dinvg'] / abs(gd)) * leg['norm_Dinvg']
+            t = 1.0 - 0.8 * (1.0 - c)
+            if t * leg['norm_Dgn'] <= delta:
+                return leg['dx_gn'] * (delta / leg['norm_Dgn']), 0.0
+        beta = dogleg_beta(t)
+        return leg['dx_sd'] + beta * (t * leg['dx_gn'] - leg['dx_sd']), 0.0
+
+    def lin_quad(a, b):
+        # a^T J^T J b from the norm interface (polarisation)
+        if a is b:
+            return lin.norm_Jv2(a)
+        return 0.25 * (lin.norm_Jv2(a + b) - lin.norm_Jv2(a - b))
+
+    def preduction(step, normf):
+        if alg in ('lm', 'lmaccel'):
+            un = np.sqrt(lin.norm_Jv2(step)) / normf      # lm_preduction
+            vn = float(np.linalg.norm(diag * step)) / normf
+            return un * un + 2.0 * mu * vn * vn
+        # quadratic_preduction
+        return -(lin.norm_Jv2(step) + 2.0 * float(lin.g @ step)) / (normf * normf)
+
     def iterate():
         nonlocal x, fnorm2, diag, mu, nu, delta, dx
         bad_steps = 0
+        if alg in ('dogleg', 'ddogleg', 'subspace2D'):
+            dogleg_preloop()
         while True:
-            v = lin.step(mu, diag)                        # lm_step
-            dx = v
+            dx, avratio = trs_step()
             x_trial = x + dx
             ft2 = eval_fnorm2(x_trial)
             res.nfev += 1
@@ -188,15 +340,14 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
             else:
                 u = normf_trial / normf
                 actual = 1.0 - u * u
-                un = np.sqrt(lin.norm_Jv2(v)) / normf     # lm_preduction
-                vn = float(np.linalg.norm(diag * v)) / normf
-                pred = un * un + 2.0 * mu * vn * vn
+                pred = preduction(dx, normf)
                 rho = actual / pred if pred > 0.0 else -1.0
             if rho > 0.75:
                 delta *= factor_up
             elif rho < 0.25:
                 delta /= factor_down
-            if rho > 0.0:
+            # trust_eval_step: geodesic acceleration must stay small next to the velocity
+            if rho > 0.0 and not (alg == 'lmaccel' and avratio > avmax):
                 fnorm2 = evaluate(x_trial)                # J <- J(x+dx), g
                 res.njev += 1
                 x = x_trial
@@ -205,7 +356,7 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
                 mu *= max(0.333333333333333, 1.0 - b * b * b)
                 nu = 2
                 return GSL_SUCCESS
-            mu *= nu                                      # nielsen_reject
+            mu = float(mu) * nu                           # nielsen_reject
             nu <<= 1
             bad_steps += 1
             if bad_steps > 15:
@@ -266,12 +417,10 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
 
 
 def gsl_multifit(x0, n, f, df, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm',
-                 solver='qr', scaler='more', factor_up=3.0, factor_down=2.0):
+                 solver='qr', scaler='more', factor_up=3.0, factor_down=2.0, avmax=0.75):
     """Counterpart of ``lsqfit.gsl_multifit`` with an explicit Jacobian callback
     ``df`` in place of the reference's GVar trick.  Returns an object with the
     attributes nonlinear_fit reads (__init__.py:665-679)."""
-    if alg != 'lm':
-        raise ValueError('oracle restates alg="lm" only (got %r)' % (alg,))
     tol = normalize_tol(tol)
     lin = _DenseLin(solver)
     cache = {}
@@ -289,18 +438,21 @@ def gsl_multifit(x0, n, f, df, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm',
         cache['f'] = fv
         return float(fv @ fv)
 
-    res = _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down)
+    res = _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down,
+                 alg=alg, avmax=avmax, eval_fvec=lambda xx: np.asarray(f(xx), float))
     res.tol = tol
     res.f = lin.f
     res.J = lin.J
     res.cov = lin.covar()
     res.description = 'methods = {}/{}/{}'.format(alg, scaler, solver)
+    if alg == 'lmaccel':
+        res.description += '    avmax = {}'.format(avmax)        # _gsl.pyx:617-618
     res.results = None
     return res
 
 
 def lm_normal(x0, normal_eq, chi2_fn, tol=(1e-5, 0.0, 0.0), maxit=1000,
-              scaler='more', factor_up=3.0, factor_down=2.0):
+              scaler='more', factor_up=3.0, factor_down=2.0, alg='lm'):
     """Same driver fed by ``normal_eq(x) -> (A, g, chi2)`` and ``chi2_fn(x)``."""
     tol = normalize_tol(tol)
     lin = _NormalLin()
@@ -311,11 +463,11 @@ def lm_normal(x0, normal_eq, chi2_fn, tol=(1e-5, 0.0, 0.0), maxit=1000,
         return float(c2)
 
     res = _drive(x0, evaluate, lambda x: float(chi2_fn(x)), lin, tol, maxit,
-                 scaler, factor_up, factor_down)
+                 scaler, factor_up, factor_down, alg=alg)
     res.tol = tol
     res.A = lin.A
     res.g = lin.g
     res.cov = lin.covar()
-    res.description = 'methods = lm/{}/cholesky'.format(scaler)
+    res.description = 'methods = {}/{}/cholesky'.format(alg, scaler)
     res.results = None
     return res

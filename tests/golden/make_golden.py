@@ -140,7 +140,9 @@ def make_kat():
     ]
     # tests/test_lsqfit.py:1700-1725 (test_gsl_multifit): f=(x-x*)^2+(x-x*)^4
     kat['gsl_multifit'] = dict(xans=[1., 2., 3.], cases=[
-        dict(x0=[1., 1., 1.], alg='lm', tol=[1e-10, 0.0, 0.0], stopping_criterion=1, rtol=1e-3)])
+        dict(x0=[1., 1., 1.], alg='lm', tol=[1e-10, 0.0, 0.0], stopping_criterion=1, rtol=1e-3),
+        dict(x0=[0., 0., 0.], alg='lmaccel', tol=[0.0, 1e-10, 0.0], stopping_criterion=2, rtol=1e-3),
+        dict(x0=[0., 0., 0.], alg='subspace2D', tol=[1e-10, 0.0, 0.0], stopping_criterion=1, rtol=1e-3)])
     # tests/test_lsqfit.py:257-283 (test_format case 1): header + parameter line
     kat['format1'] = dict(y=[[1.5, 1.0], [0.8, 0.5]], prior=[[0.0, 2.0]], svdcut=1e-15,
                           tol=[1e-15, 1e-15, 1e-15],

@@ -67,7 +67,8 @@ def test_gammaQ():
 
 
 def test_gsl_multifit_direct():
-    """tests/test_lsqfit.py:1700-1715: singular-J^T J double root, stops on xtol."""
+    """tests/test_lsqfit.py:1700-1725: singular-J^T J double root; lm stops on xtol, lmaccel on
+    gtol, subspace2D on xtol."""
     k = KAT['gsl_multifit']
     xans = np.array(k['xans'])
     f = lambda x: (x - xans) ** 2 + (x - xans) ** 4
@@ -78,10 +79,17 @@ def test_gsl_multifit_direct():
                                    solver=solver)
             np.testing.assert_allclose(ans.x, xans, rtol=c['rtol'])
             assert ans.stopping_criterion == c['stopping_criterion']
-    # gtol route (the reference's 2nd case uses lmaccel; same criterion with lm)
     ans = olm.gsl_multifit(np.zeros(3), 3, f, df, tol=(0.0, 1e-10, 0.0))
     np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
     assert ans.stopping_criterion == 2
+    for alg in ['dogleg', 'ddogleg']:
+        ans = olm.gsl_multifit(np.zeros(3), 3, f, df, alg=alg, tol=(1e-10, 0.0, 0.0))
+        np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+        assert ans.stopping_criterion == 1
+    assert olm.gsl_multifit(np.zeros(3), 3, f, df, alg='lmaccel').description == \
+        'methods = lmaccel/more/qr    avmax = 0.75'                # _gsl.pyx:614-618
+    with pytest.raises(ValueError):
+        olm.gsl_multifit(np.zeros(3), 3, f, df, alg='cgst')        # _gsl.pyx:632-635
 
 
 def test_tol_normalisation():

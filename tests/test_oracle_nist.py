@@ -65,3 +65,19 @@ def test_misra1a_headline_numbers():
     np.testing.assert_allclose(fit.chi2, pr['rss'] / pr['rsd'] ** 2, rtol=1e-4)
     np.testing.assert_allclose(fit.pmean, pr['certified'], rtol=1e-7)
     np.testing.assert_allclose(fit.psdev, pr['certified_sd'], rtol=1e-5)
+
+
+@pytest.mark.parametrize('alg', ['lmaccel', 'dogleg', 'ddogleg', 'subspace2D'])
+@pytest.mark.parametrize('name', ['misra1a', 'chwirut2', 'danwood', 'rat42', 'thurber', 'boxbod'])
+def test_nist_other_trust_region_methods(name, alg):
+    """every trust-region sub-solver of _gsl.pyx:622-635 reaches the certified
+    NIST minimum (converged values are what the reference pins; trajectories are not)."""
+    pr = nist_problem(name, NIST)
+    kw = dict(prior_mean=pr['prior_mean'], prior_err=pr['prior_sd'], p0=pr['p0'], tol=pr['tol'])
+    a = ofit.nonlinear_fit(pr['x'], pr['y'], pr['ysd'], pr['fcn'], **kw)
+    b = ofit.nonlinear_fit(pr['x'], pr['y'], pr['ysd'], pr['fcn'], alg=alg, **kw)
+    assert b.error is None and b.stopping_criterion in (1, 2)
+    np.testing.assert_allclose(b.pmean, a.pmean, rtol=1e-6)
+    np.testing.assert_allclose(b.chi2, a.chi2, rtol=1e-8)
+    np.testing.assert_allclose(b.cov, a.cov, rtol=1e-5)
+    np.testing.assert_allclose(b.pmean, pr['certified'], rtol=1e-5)
