@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQAMD_ABI_VERSION 1
+#define LSQAMD_ABI_VERSION 2
 
 /* error codes (negative = backend, positive = GSL numbering) */
 #define LSQAMD_SUCCESS 0
@@ -70,6 +70,9 @@ enum {
 
 enum { LSQAMD_SCALE_MORE = 0, LSQAMD_SCALE_LEVENBERG = 1, LSQAMD_SCALE_MARQUARDT = 2 }; /* _gsl.pyx:637-644 */
 enum { LSQAMD_SOLVER_CHOLESKY = 0 };                                                    /* _gsl.pyx:646-653 */
+/* trust-region sub-problem solvers: gsl_multifit's `alg` keyword (_gsl.pyx:622-635) */
+enum { LSQAMD_TRS_LM = 0, LSQAMD_TRS_LMACCEL = 1, LSQAMD_TRS_DOGLEG = 2, LSQAMD_TRS_DDOGLEG = 3,
+       LSQAMD_TRS_SUBSPACE2D = 4 };
 
 /* tape opcodes (LSQAMD_MODEL_TAPE); operands in `arg` */
 enum {
@@ -110,9 +113,10 @@ typedef struct {
   int32_t maxit;            /* _gsl.pyx:568 */
   int32_t scaler;           /* LSQAMD_SCALE_* */
   int32_t solver;           /* LSQAMD_SOLVER_* */
-  int32_t reserved;
+  int32_t trs;              /* LSQAMD_TRS_*: alg, _gsl.pyx:569,:622-635 */
   double factor_up;         /* 3.0, _gsl.pyx:573 */
   double factor_down;       /* 2.0, _gsl.pyx:574 */
+  double avmax;             /* 0.75, _gsl.pyx:575,:658 (lmaccel: reject when |a|/|v| exceeds it) */
 } lsqamd_options;
 
 /* What nonlinear_fit reads from the plugin (__init__.py:665-679) plus the

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'liblsqfit_amd.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 T_NAMES = ['residual', 'jacobian', 'whiten', 'syrk', 'grad', 'reduce', 'cholesky', 'solve', 'covar']
 
@@ -25,8 +25,8 @@ class Config(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [('xtol', C.c_double), ('gtol', C.c_double), ('ftol', C.c_double), ('maxit', C.c_int32),
-                ('scaler', C.c_int32), ('solver', C.c_int32), ('reserved', C.c_int32),
-                ('factor_up', C.c_double), ('factor_down', C.c_double)]
+                ('scaler', C.c_int32), ('solver', C.c_int32), ('trs', C.c_int32),
+                ('factor_up', C.c_double), ('factor_down', C.c_double), ('avmax', C.c_double)]
 
 
 class Summary(C.Structure):

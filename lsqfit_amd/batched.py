@@ -128,7 +128,7 @@ class BatchedFits:
         p0 = np.ascontiguousarray(np.broadcast_to(np.asarray(p0, np.float64), (B, P)))
         xtol, gtol, ftol = normalize_tol(tol)
         opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler], solver=0,
-                           reserved=0, factor_up=factor_up, factor_down=factor_down)
+                           trs=0, factor_up=factor_up, factor_down=factor_down, avmax=0.75)
         self._check(self.lib.lsqamdb_set_options(self.h, C.byref(opt)), 'set_options')
         summ = (_lib.Summary * B)()
         t0 = time.perf_counter()

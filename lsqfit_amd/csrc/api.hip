@@ -92,7 +92,7 @@ struct lsqamd_fit {
   std::vector<double> hx, hg, hdiag, hdx, hv, hcoln, htmp;
   double chi2 = 0.0, mu = 0.0, delta = 0.0;
   long nu = 2;
-  bool initialised = false, have_cov = false;
+  bool initialised = false, have_cov = false, have_dense_A = false;
   int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
   double logdet = NAN;
 
@@ -376,6 +376,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
   f->chi2 = f->htmp[P];
   f->njev++;
   f->have_cov = false;
+  f->have_dense_A = false;
   if (!std::isfinite(f->chi2)) FAIL(f, LSQAMD_ENONFINITE, "chi2 is not finite at this point");
   return 0;
 }
@@ -426,41 +427,328 @@ void scale_update(lsqamd_fit *f) {
   }
 }
 
+// ---- pieces shared by the trust-region sub-problem solvers -------------------
+// y = A x with A = the reduced J^T J (+ prior): dense symmetric copy kept in f->Wl
+int symv_host(lsqamd_fit *f, const double *x, double *y) {
+  const int64_t P = f->P;
+  if (!f->have_dense_A) {
+    HIPCHK(f, launch_unpack_sym(f->st, f->redbuf, P, f->Wl, f->ldm));
+    f->have_dense_A = true;
+  }
+  HIPCHK(f, hipMemcpyAsync(f->tvec, x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, launch_gemv_rows(f->st, f->Wl, f->ldm, P, P, f->tvec, f->yv));
+  HIPCHK(f, hipMemcpyAsync(y, f->yv, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
+double dot_h(const std::vector<double> &a, const std::vector<double> &b) {
+  double s = 0.0;
+  for (size_t i = 0; i < a.size(); ++i) s += a[i] * b[i];
+  return s;
+}
+
+// (A + mu D^2) out = rhs with the factor U already in f->M (lmaccel's second solve, lm.c lm_step):
+// forward substitution block by block through the TN GEMM (X = inv(U_kk), then X = U[k, k+1:]),
+// then the usual back substitution.
+int solve_with_factor(lsqamd_fit *f, const double *rhs, double *out) {
+  const int64_t P = f->P;
+  HIPCHK(f, hipMemcpyAsync(f->yv, rhs, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+  for (int64_t k0 = 0; k0 < P; k0 += 128) {
+    const int64_t nb = P - k0 < 128 ? P - k0 : 128;
+    GemmTN a;  // y_k <- inv(U_kk)^T y_k
+    a.X = f->chol_work + (k0 / 128) * 128 * 128; a.ldx = 128;
+    a.Y = f->yv + k0; a.ldy = 1; a.C = f->yv + k0; a.ldc = 1;
+    a.M = nb; a.N = 1; a.K = nb;
+    a.x_upper_tri = 1;
+    HIPCHK(f, launch_gemm_tn(f->st, a));
+    const int64_t rest = P - (k0 + nb);
+    if (rest <= 0) continue;
+    GemmTN b;  // y_rest -= U[k, rest]^T y_k
+    b.X = f->M + k0 * f->ldm + k0 + nb; b.ldx = f->ldm;
+    b.Y = f->yv + k0; b.ldy = 1; b.C = f->yv + k0 + nb; b.ldc = 1;
+    b.M = rest; b.N = 1; b.K = nb;
+    b.alpha = -1.0; b.beta = 1.0;
+    HIPCHK(f, launch_gemm_tn(f->st, b));
+  }
+  HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
+  HIPCHK(f, hipMemcpyAsync(out, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
+// G_h = J(x)^T r(x_h) + Lambda (x_h - pbar): the gradient-like vector the finite-difference
+// second directional derivative needs (fdfvv.c), all-reduced like the gradient
+int grad_like_at(lsqamd_fit *f, const double *xh, double *out) {
+  const int64_t P = f->P;
+  HIPCHK(f, hipMemcpyAsync(f->p_trial, xh, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+  double c2 = 0.0;
+  int rc = eval_residual_dev(f, f->p_trial, &c2);  // f->r = whitened residual at x_h
+  if (rc) return rc;
+  HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P, P, f->partial, f->npartial, f->yv, f->r));
+  if (f->cfg.has_prior && f->adds_prior)
+    HIPCHK(f, launch_add_prior(f->st, nullptr, P, f->prior_prec, f->cfg.prior_dense, f->prior_mean,
+                               f->p_trial, f->tvec, f->yv, 0));
+  rc = do_reduce(f, f->yv, P);
+  if (rc) return rc;
+  HIPCHK(f, hipMemcpyAsync(out, f->yv, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
+struct Legs {  // dogleg.c / subspace2D.c state for one trust_iterate
+  std::vector<double> dx_sd, dx_gn, q0, q1;
+  double norm_Dsd = 0.0, norm_Dgn = -1.0, norm_Dinvg = 0.0, norm_JDinv2g = 0.0;
+  bool gn_failed = false;
+  int sub = -1;  // subspace2D basis: -1 not built, 0 legs parallel, 1 ready
+  double subg[2] = {0, 0}, subB[2][2] = {{0, 0}, {0, 0}};
+};
+
+double scaled_norm(const std::vector<double> &d, const std::vector<double> &v) {
+  double s = 0.0;
+  for (size_t i = 0; i < v.size(); ++i) s += d[i] * v[i] * d[i] * v[i];
+  return std::sqrt(s);
+}
+
+// dogleg_preloop: steepest-descent leg dx_sd = -alpha D^-2 g, alpha = |D^-1 g|^2 / |J D^-2 g|^2
+int legs_preloop(lsqamd_fit *f, Legs &L) {
+  const int64_t P = f->P;
+  std::vector<double> w2(P), Aw(P);
+  double n1 = 0.0;
+  for (int64_t j = 0; j < P; ++j) {
+    const double w1 = f->hg[j] / f->hdiag[j];
+    n1 += w1 * w1;
+    w2[j] = w1 / f->hdiag[j];
+  }
+  L.norm_Dinvg = std::sqrt(n1);
+  int rc = symv_host(f, w2.data(), Aw.data());
+  if (rc) return rc;
+  const double q = dot_h(w2, Aw);
+  L.norm_JDinv2g = std::sqrt(q > 0.0 ? q : 0.0);
+  const double u = L.norm_Dinvg / L.norm_JDinv2g;
+  L.dx_sd.resize(P);
+  for (int64_t j = 0; j < P; ++j) L.dx_sd[j] = -(u * u) * w2[j];
+  L.norm_Dsd = scaled_norm(f->hdiag, L.dx_sd);
+  L.norm_Dgn = -1.0;
+  L.gn_failed = false;
+  L.sub = -1;
+  return 0;
+}
+
+// Gauss-Newton leg: the damped solve at mu = 0 (dogleg_calc_gn)
+int legs_gn(lsqamd_fit *f, Legs &L) {
+  if (L.norm_Dgn >= 0.0 || L.gn_failed) return 0;
+  const int rc = solve_damped_dev(f, 0.0, f->hdiag.data());
+  if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+  if (rc == LSQAMD_ENOTPD) {  // singular J^T J: no Gauss-Newton point, stay on the gradient leg
+    L.gn_failed = true;
+    return 0;
+  }
+  L.dx_gn.resize(f->P);
+  for (int64_t j = 0; j < f->P; ++j) L.dx_gn[j] = -f->hv[j];
+  L.norm_Dgn = scaled_norm(f->hdiag, L.dx_gn);
+  return 0;
+}
+
+double dogleg_beta(const lsqamd_fit *f, const Legs &L, double t, double delta) {
+  double a = 0.0, b = 0.0;
+  for (int64_t j = 0; j < f->P; ++j) {
+    const double w = t * L.dx_gn[j] - L.dx_sd[j];
+    const double d2 = f->hdiag[j] * f->hdiag[j];
+    a += d2 * w * w;
+    b += L.dx_sd[j] * d2 * w;
+  }
+  b *= 2.0;
+  const double c = (L.norm_Dsd + delta) * (L.norm_Dsd - delta);
+  const double disc = std::sqrt(b * b - 4.0 * a * c);
+  return b > 0.0 ? (-2.0 * c) / (b + disc) : (-b + disc) / (2.0 * a);
+}
+
+// argmin g.q + q.B.q/2 on |q| = delta for a 2 x 2 positive semi-definite B (secular equation)
+void solve_tr_2d(const double B[2][2], const double g[2], double delta, double q[2]) {
+  const double tr = B[0][0] + B[1][1], df = B[0][0] - B[1][1];
+  const double rad = std::sqrt(0.25 * df * df + B[0][1] * B[0][1]);
+  const double w0 = 0.5 * tr - rad, w1 = 0.5 * tr + rad;
+  double v0[2], v1[2];  // eigenvectors
+  if (std::fabs(B[0][1]) > 0.0) {
+    v1[0] = w1 - B[1][1]; v1[1] = B[0][1];
+    const double n = std::hypot(v1[0], v1[1]);
+    v1[0] /= n; v1[1] /= n;
+  } else if (B[0][0] >= B[1][1]) { v1[0] = 1.0; v1[1] = 0.0; }
+  else { v1[0] = 0.0; v1[1] = 1.0; }
+  v0[0] = -v1[1]; v0[1] = v1[0];
+  const double g0 = v0[0] * g[0] + v0[1] * g[1], g1 = v1[0] * g[0] + v1[1] * g[1];
+  auto qnorm = [&](double lam) { return std::hypot(g0 / (w0 + lam), g1 / (w1 + lam)); };
+  double lo = 0.0, hi = std::fmax(1.0, std::hypot(g[0], g[1]) / delta);
+  while (qnorm(hi) > delta) hi *= 2.0;
+  for (int it = 0; it < 200; ++it) {
+    const double mid = 0.5 * (lo + hi);
+    if (qnorm(mid) > delta) lo = mid; else hi = mid;
+    if (hi - lo <= 1e-16 * hi) break;
+  }
+  const double lam = 0.5 * (lo + hi);
+  const double c0 = -g0 / (w0 + lam), c1 = -g1 / (w1 + lam);
+  q[0] = v0[0] * c0 + v1[0] * c1;
+  q[1] = v0[1] * c0 + v1[1] * c1;
+}
+
+// orthonormal basis of span(D dx_sd, D dx_gn) and the 2 x 2 model in it (subspace2D_preloop)
+int legs_subspace(lsqamd_fit *f, Legs &L) {
+  if (L.sub >= 0) return 0;
+  const int64_t P = f->P;
+  L.q0.resize(P); L.q1.resize(P);
+  double c = 0.0;
+  for (int64_t j = 0; j < P; ++j) {
+    L.q0[j] = f->hdiag[j] * L.dx_sd[j] / L.norm_Dsd;
+    L.q1[j] = f->hdiag[j] * L.dx_gn[j] / L.norm_Dgn;
+    c += L.q0[j] * L.q1[j];
+  }
+  double r = 0.0;
+  for (int64_t j = 0; j < P; ++j) { L.q1[j] -= c * L.q0[j]; r += L.q1[j] * L.q1[j]; }
+  r = std::sqrt(r);
+  if (!(r > 20.0 * (double)(P + 2) * 2.220446049250313e-16)) {  // gsl_linalg_QRPT_rank default tolerance
+    L.sub = 0;
+    return 0;
+  }
+  for (int64_t j = 0; j < P; ++j) L.q1[j] /= r;
+  std::vector<double> d0(P), d1(P), A0(P), A1(P);
+  for (int64_t j = 0; j < P; ++j) { d0[j] = L.q0[j] / f->hdiag[j]; d1[j] = L.q1[j] / f->hdiag[j]; }
+  int rc = symv_host(f, d0.data(), A0.data());
+  if (rc) return rc;
+  rc = symv_host(f, d1.data(), A1.data());
+  if (rc) return rc;
+  L.subB[0][0] = dot_h(d0, A0); L.subB[0][1] = L.subB[1][0] = dot_h(d0, A1); L.subB[1][1] = dot_h(d1, A1);
+  L.subg[0] = dot_h(d0, f->hg); L.subg[1] = dot_h(d1, f->hg);
+  L.sub = 1;
+  return 0;
+}
+
+// trs->step for the dogleg family: dx for the current trust radius
+int legs_step(lsqamd_fit *f, Legs &L, std::vector<double> &dx) {
+  const int64_t P = f->P;
+  const double delta = f->delta;
+  const int trs = f->opt.trs;
+  auto scaled = [&](const std::vector<double> &v, double s) { for (int64_t j = 0; j < P; ++j) dx[j] = s * v[j]; };
+  if (trs == LSQAMD_TRS_SUBSPACE2D) {
+    int rc = legs_gn(f, L);
+    if (rc) return rc;
+    if (L.gn_failed) { scaled(L.dx_sd, delta / L.norm_Dsd); return 0; }
+    if (L.norm_Dgn <= delta) { dx = L.dx_gn; return 0; }
+    rc = legs_subspace(f, L);
+    if (rc) return rc;
+    if (L.sub == 0) { scaled(L.dx_sd, delta / L.norm_Dsd); return 0; }
+    double q[2];
+    solve_tr_2d(L.subB, L.subg, delta, q);
+    for (int64_t j = 0; j < P; ++j) dx[j] = (L.q0[j] * q[0] + L.q1[j] * q[1]) / f->hdiag[j];
+    return 0;
+  }
+  if (L.norm_Dsd >= delta) { scaled(L.dx_sd, delta / L.norm_Dsd); return 0; }
+  int rc = legs_gn(f, L);
+  if (rc) return rc;
+  if (L.gn_failed) { dx = L.dx_sd; return 0; }
+  if (L.norm_Dgn <= delta) { dx = L.dx_gn; return 0; }
+  double t = 1.0;
+  if (trs == LSQAMD_TRS_DDOGLEG) {
+    const double u = L.norm_Dinvg / L.norm_JDinv2g;
+    const double gd = dot_h(f->hg, L.dx_gn);
+    const double c = u * u * (L.norm_Dinvg / std::fabs(gd)) * L.norm_Dinvg;
+    t = 1.0 - 0.8 * (1.0 - c);
+    if (t * L.norm_Dgn <= delta) { scaled(L.dx_gn, delta / L.norm_Dgn); return 0; }
+  }
+  const double beta = dogleg_beta(f, L, t, delta);
+  for (int64_t j = 0; j < P; ++j) dx[j] = L.dx_sd[j] + beta * (t * L.dx_gn[j] - L.dx_sd[j]);
+  return 0;
+}
+
 // one trust_iterate: GSL_SUCCESS (0) or LSQAMD_ENOPROG; negative on backend failure
 int iterate(lsqamd_fit *f) {
   const int64_t P = f->P;
+  const int trs = f->opt.trs;
+  const bool lm_family = trs == LSQAMD_TRS_LM || trs == LSQAMD_TRS_LMACCEL;
   int bad_steps = 0;
-  std::vector<double> xt(P);
+  std::vector<double> xt(P), dx(P), tmp(P);
+  Legs L;
+  if (!lm_family) {
+    const int rc = legs_preloop(f, L);
+    if (rc) return rc;
+  }
   while (true) {
-    double rho = -1.0;
-    int rc = solve_damped_dev(f, f->mu, f->hdiag.data());
-    if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
-    if (rc == 0) {
-      double vg = 0.0, dv2 = 0.0;
+    double rho = -1.0, avratio = 0.0;
+    bool have_step = false;
+    double pred_num = 0.0;  // predicted reduction * chi2
+    if (lm_family) {
+      int rc = solve_damped_dev(f, f->mu, f->hdiag.data());
+      if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+      if (rc == 0) {
+        have_step = true;
+        double vg = 0.0, dv2 = 0.0;
+        for (int64_t j = 0; j < P; ++j) {
+          dx[j] = -f->hv[j];
+          vg += f->hv[j] * f->hg[j];
+          const double t = f->hdiag[j] * f->hv[j];
+          dv2 += t * t;
+        }
+        // |J v|^2 = v^T A v = v^T g - mu |D v|^2  since (A + mu D^2) v = g
+        pred_num = vg + f->mu * dv2;
+        if (trs == LSQAMD_TRS_LMACCEL) {
+          // geodesic acceleration (lm.c lm_step, fdfvv.c): fvv by finite differences, h = 0.02
+          const double h = 0.02;
+          std::vector<double> vel(dx), xh(P), Gh(P), Av(P), rhs(P), acc(P);
+          for (int64_t j = 0; j < P; ++j) xh[j] = f->hx[j] + h * vel[j];
+          rc = grad_like_at(f, xh.data(), Gh.data());
+          if (rc) return rc;
+          rc = symv_host(f, vel.data(), Av.data());
+          if (rc) return rc;
+          // J^T fvv = (2/h) ((G_h - g)/h - A v); the acceleration solves (A + mu D^2) a = -J^T fvv
+          for (int64_t j = 0; j < P; ++j) rhs[j] = (2.0 / h) * ((Gh[j] - f->hg[j]) / h - Av[j]);
+          rc = solve_with_factor(f, rhs.data(), acc.data());
+          if (rc) return rc;
+          double an = 0.0, vn = 0.0;
+          for (int64_t j = 0; j < P; ++j) {
+            const double a = -acc[j];
+            an += a * a;
+            vn += vel[j] * vel[j];
+            dx[j] = vel[j] + 0.5 * a;
+          }
+          avratio = std::sqrt(an) / std::sqrt(vn);
+          // lm_preduction on dx: |J dx|^2 + 2 mu |D dx|^2
+          rc = symv_host(f, dx.data(), tmp.data());
+          if (rc) return rc;
+          const double dn = scaled_norm(f->hdiag, dx);
+          pred_num = dot_h(dx, tmp) + 2.0 * f->mu * dn * dn;
+        }
+      }
+    } else {
+      const int rc = legs_step(f, L, dx);
+      if (rc) return rc;
+      have_step = true;
+      // quadratic_preduction: -(|J dx|^2 + 2 g.dx)
+      const int rc2 = symv_host(f, dx.data(), tmp.data());
+      if (rc2) return rc2;
+      pred_num = -(dot_h(dx, tmp) + 2.0 * dot_h(f->hg, dx));
+    }
+    if (have_step) {
       for (int64_t j = 0; j < P; ++j) {
-        f->hdx[j] = -f->hv[j];
-        xt[j] = f->hx[j] + f->hdx[j];
-        vg += f->hv[j] * f->hg[j];
-        const double t = f->hdiag[j] * f->hv[j];
-        dv2 += t * t;
+        f->hdx[j] = dx[j];
+        xt[j] = f->hx[j] + dx[j];
       }
       HIPCHK(f, hipMemcpyAsync(f->p_trial, xt.data(), sizeof(double) * P, hipMemcpyHostToDevice, f->st));
       double chi2_t = 0.0;
-      rc = eval_residual_dev(f, f->p_trial, &chi2_t);
+      const int rc = eval_residual_dev(f, f->p_trial, &chi2_t);
       if (rc) return rc;
       const double normf = std::sqrt(f->chi2), normf_t = std::sqrt(chi2_t);
       if (normf_t < normf) {  // NaN-safe: anything else rejects
         const double u = normf_t / normf;
         const double actual = 1.0 - u * u;
-        // |J v|^2 = v^T A v = v^T g - mu |D v|^2  since (A + mu D^2) v = g
-        const double pred = (vg + f->mu * dv2) / f->chi2;
+        const double pred = pred_num / f->chi2;
         rho = pred > 0.0 ? actual / pred : -1.0;
       }
     }
     if (rho > 0.75) f->delta *= f->opt.factor_up;
     else if (rho < 0.25) f->delta /= f->opt.factor_down;
-    if (rho > 0.0) {
-      rc = eval_normal_dev(f, f->p_trial);
+    // trust_eval_step: with geodesic acceleration the step must also satisfy |a|/|v| <= avmax
+    if (rho > 0.0 && !(trs == LSQAMD_TRS_LMACCEL && avratio > f->opt.avmax)) {
+      const int rc = eval_normal_dev(f, f->p_trial);
       if (rc) return rc;
       f->hx = xt;
       std::swap(f->p_dev, f->p_trial);
@@ -547,6 +835,7 @@ int do_covariance(lsqamd_fit *f) {
   HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, 0.0, f->diag_dev, nullptr, f->M));
   HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, P, f->chol_work, f->info_dev));
   HIPCHK(f, logdiag_sum(f->st, f->M, P, f->ldm, f->scal));
+  f->have_dense_A = false;  // Wl is reused below
   HIPCHK(f, trtri_upper_to_lower_T(f->st, f->M, P, f->ldm, f->chol_work, f->Wl, f->ldm));
   GemmTN g;
   g.X = f->Wl; g.Y = f->Wl; g.ldx = g.ldy = f->ldm;
@@ -608,6 +897,8 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.solver = LSQAMD_SOLVER_CHOLESKY;
   f->opt.factor_up = 3.0;
   f->opt.factor_down = 2.0;
+  f->opt.trs = LSQAMD_TRS_LM;
+  f->opt.avmax = 0.75;
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
     return LSQAMD_EHIP;
@@ -753,6 +1044,7 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
   if (opt->solver != LSQAMD_SOLVER_CHOLESKY) FAIL(f, LSQAMD_EUNSUPPORTED, "set_options: only the cholesky solver runs on the device");
   if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
+  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_SUBSPACE2D) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
   f->opt = *opt;
   return 0;
 }

@@ -686,7 +686,7 @@ int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace
   if (hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) != hipSuccess) { delete f; return LSQAMD_EHIP; }
   f->opt.xtol = 1e-8; f->opt.gtol = 1e-10; f->opt.ftol = 1e-10;
   f->opt.maxit = 1000; f->opt.scaler = LSQAMD_SCALE_MORE; f->opt.solver = LSQAMD_SOLVER_CHOLESKY;
-  f->opt.factor_up = 3.0; f->opt.factor_down = 2.0;
+  f->opt.factor_up = 3.0; f->opt.factor_down = 2.0; f->opt.trs = LSQAMD_TRS_LM; f->opt.avmax = 0.75;
   std::vector<int32_t> wm(4 * (size_t)f->syrk_nwork);
   syrk_work_fill(f->P, f->splits, wm.data());
   if (hipMemcpyAsync(f->syrk_map, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice, f->st) != hipSuccess ||
@@ -800,6 +800,7 @@ int lsqamdb_set_options(lsqamdb_fits *f, const lsqamd_options *opt) {
   if (!f || !opt) return LSQAMD_EINVAL;
   if (opt->xtol < 0 || opt->gtol < 0 || opt->maxit < 0 || opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT)
     BFAIL(f, LSQAMD_EINVAL, "set_options: bad value");
+  if (opt->trs != LSQAMD_TRS_LM) BFAIL(f, LSQAMD_EUNSUPPORTED, "set_options: the batched engine runs alg='lm' only");
   f->opt = *opt;
   return 0;
 }

@@ -94,7 +94,10 @@ hipError_t launch_jacobian_ex(hipStream_t st, const ModelArgs &m, double *J_w, d
 // out[j] = sum_i J[i][j] * J[i][rcol] for j in [0, ncols)   (ncols = P+1 gives grad and chi2)
 hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
-                             double *out);
+                             double *out, const double *rvec = nullptr);  // rvec: weights instead of J[:, rcol]
+// y = A x (row-major, one wave per row)
+hipError_t launch_gemv_rows(hipStream_t st, const double *A, int64_t ld, int64_t rows, int64_t cols,
+                            const double *x, double *y);
 // out[0] = sum_i r[i]^2   (partial: >= 1024 doubles)
 hipError_t launch_sumsq(hipStream_t st, const double *r, int64_t n, double *partial, double *out);
 // whitened block residual: r_out[row0_b + m] = sum_j Wt_b[j][m] * delta[row0_b + j]

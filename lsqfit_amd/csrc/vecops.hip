@@ -27,8 +27,9 @@ __host__ __device__ inline int64_t packed_tile_index(int64_t tm, int64_t tn, int
 // ---- J^T f and |f|^2 in one pass over J ------------------------------------------------
 // stage 1: partial[rc][j] = sum_{i in row chunk rc} J[i][j] * J[i][rcol]
 __global__ __launch_bounds__(256) void colsum_dot_stage1(const double *J, int64_t nrows, int64_t ld,
-                                                         int64_t ncols, int64_t rcol,
-                                                         int64_t rows_per_chunk, double *partial) {
+                                                         int64_t ncols, const double *rv,
+                                                         int64_t rs, int64_t rows_per_chunk,
+                                                         double *partial) {
   const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
   int64_t r1 = r0 + rows_per_chunk;
@@ -38,14 +39,14 @@ __global__ __launch_bounds__(256) void colsum_dot_stage1(const double *J, int64_
   double a0 = 0.0, a1 = 0.0;
   if ((ld & 1) == 0 && two) {
     for (int64_t i = r0; i < r1; ++i) {
-      const double ri = J[i * ld + rcol];
+      const double ri = rv[i * rs];
       const double2 v = *reinterpret_cast<const double2 *>(J + i * ld + j);
       a0 += v.x * ri;
       a1 += v.y * ri;
     }
   } else {
     for (int64_t i = r0; i < r1; ++i) {
-      const double ri = J[i * ld + rcol];
+      const double ri = rv[i * rs];
       a0 += J[i * ld + j] * ri;
       if (two) a1 += J[i * ld + j + 1] * ri;
     }
@@ -65,14 +66,16 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double *partial, int6
 
 hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
-                             double *out) {
+                             double *out, const double *rvec) {
+  const double *rv = rvec ? rvec : J + rcol;
+  const int64_t rs = rvec ? 1 : ld;
   int64_t nchunks = npartial;
   if (nchunks > nrows) nchunks = nrows > 0 ? nrows : 1;
   const int64_t rpc = nrows > 0 ? (nrows + nchunks - 1) / nchunks : 1;
   nchunks = nrows > 0 ? (nrows + rpc - 1) / rpc : 0;
   if (nchunks > 0) {
     dim3 grid((unsigned)((ncols + 511) / 512), (unsigned)nchunks);
-    hipLaunchKernelGGL(colsum_dot_stage1, grid, dim3(256), 0, st, J, nrows, ld, ncols, rcol, rpc,
+    hipLaunchKernelGGL(colsum_dot_stage1, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc,
                        partial);
   }
   hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, partial,
@@ -507,6 +510,27 @@ hipError_t launch_prior_chi2_points(hipStream_t st, int64_t P, const double *pre
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(coldot_accum_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, Dt, T, ldt,
                      P, m, out);
+  return hipGetLastError();
+}
+
+// y[i] = sum_j A[i][j] x[j] : one wave per row
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double *A, int64_t ld, int64_t rows,
+                                                        int64_t cols, const double *x, double *y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= rows) return;
+  const double *a = A + i * ld;
+  double acc = 0.0;
+  for (int64_t j = lane; j < cols; j += 64) acc += a[j] * x[j];
+  acc = wsum64(acc);
+  if (lane == 0) y[i] = acc;
+}
+
+hipError_t launch_gemv_rows(hipStream_t st, const double *A, int64_t ld, int64_t rows, int64_t cols,
+                            const double *x, double *y) {
+  if (rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, A, ld, rows,
+                     cols, x, y);
   return hipGetLastError();
 }
 

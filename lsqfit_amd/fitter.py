@@ -22,6 +22,7 @@ from .models import MODEL_IDENTITY, MODEL_TAPE, Model
 from .whiten import Whitening
 
 _SCALERS = dict(more=0, levenberg=1, marquardt=2)
+_ALGS = dict(lm=0, lmaccel=1, dogleg=2, ddogleg=3, subspace2D=4)      # _gsl.pyx:622-635
 
 
 def _check(lib, h, rc, what):
@@ -160,12 +161,15 @@ class DeviceProblem:
         from .dist import WorkspaceView
         return WorkspaceView(self.workspace)(dev_ptr, count)
 
-    def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0):
+    def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', avmax=0.75):
         xtol, gtol, ftol = normalize_tol(tol)
         if scaler not in _SCALERS:
             raise ValueError('unkown scaler ' + str(scaler))
+        if alg not in _ALGS:
+            raise ValueError('unkown algorithm ' + str(alg))          # _gsl.pyx:634-635
         opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler],
-                           solver=0, reserved=0, factor_up=factor_up, factor_down=factor_down)
+                           solver=0, trs=_ALGS[alg], factor_up=factor_up, factor_down=factor_down,
+                           avmax=avmax)
         _check(self.lib, self.h, self.lib.lsqamd_set_options(self.h, C.byref(opt)), 'set_options')
 
     def timing(self, on=True):
@@ -313,8 +317,8 @@ class mi355x_lm(object):
         if problem is None:
             raise ValueError("mi355x_lm needs problem=DeviceProblem(...): the fit function must be "
                              "given as a device model, the Python callable cannot run on the GPU")
-        if alg != 'lm':
-            raise NotImplementedError("mi355x_lm implements alg='lm' (got %r)" % (alg,))
+        if alg not in _ALGS:
+            raise ValueError('unkown algorithm ' + str(alg))            # _gsl.pyx:634-635
         if solver != 'cholesky':
             raise NotImplementedError("mi355x_lm solves the normal equations (solver='cholesky'); "
                                       "got %r" % (solver,))
@@ -326,13 +330,15 @@ class mi355x_lm(object):
         self.n = n
         self.error = None
         self.description = 'methods = {}/{}/{}'.format(alg, scaler, solver)
+        if alg == 'lmaccel':
+            self.description += '    avmax = {}'.format(avmax)          # _gsl.pyx:617-618
         pr = self.problem = problem
         if self.x0.size != pr.P:
             raise ValueError('len(x0) = %d but the model has %d parameters' % (self.x0.size, pr.P))
         nf_total = pr.wh.nchiv
         if n is not None and int(n) != nf_total:
             raise ValueError('n = %d but the whitened residual has %d entries' % (n, nf_total))
-        pr.set_options(self.tol, maxit, scaler, factor_up, factor_down)
+        pr.set_options(self.tol, maxit, scaler, factor_up, factor_down, alg=alg, avmax=avmax)
         lib = pr.lib
         s = _lib.Summary()
         rc = lib.lsqamd_run(pr.h, _lib.dptr(self.x0), C.byref(s))

@@ -54,7 +54,7 @@ def test_struct_layouts_match_header():
 def test_workspace_sizing_and_config_validation(libpath):
     from lsqfit_amd import _lib
     lib = _lib.load()
-    cfg = _lib.Config(abi_version=1, model=1, n_data=65536, n_param=4096, n_x=1, has_prior=1, prior_dense=1,
+    cfg = _lib.Config(abi_version=_lib.ABI_VERSION, model=1, n_data=65536, n_param=4096, n_x=1, has_prior=1, prior_dense=1,
                       n_blocks=256, max_block=256, sum_block_sq=256 * 256 * 256, want_jacobian_out=1, n_batch=1)
     nbytes = lib.lsqamd_workspace_bytes(ctypes.byref(cfg))
     assert 4e9 < nbytes < 12e9          # two Jacobian-sized buffers dominate (2 x 2.16 GB)
@@ -64,7 +64,7 @@ def test_workspace_sizing_and_config_validation(libpath):
     cfg.abi_version = 99
     assert lib.lsqamd_workspace_bytes(ctypes.byref(cfg)) == 0
     h = ctypes.c_void_p()
-    cfg.abi_version = 1
+    cfg.abi_version = _lib.ABI_VERSION
     assert lib.lsqamd_create(ctypes.byref(cfg), None, 0, None, ctypes.byref(h)) == -1   # EINVAL, no abort
 
 
