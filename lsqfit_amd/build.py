@@ -14,7 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblsqfit_amd.so')
-SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'model.hip', 'vecops.hip', 'api.hip', 'batch.hip']
+SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'potf2_mfma.hip', 'model.hip', 'vecops.hip', 'api.hip', 'batch.hip']
+# per-file code-generation switches (reasons in the files' headers)
+EXTRA = {'potf2_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 
 
@@ -36,7 +38,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, src.replace('.hip', '.o'))
         objs.append(o)
         if force or not _newer(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ['-c', s, '-o', o])
+            jobs.append([hipcc] + FLAGS + EXTRA.get(src, []) + ['-c', s, '-o', o])
 
     def run(cmd):
         if verbose:

@@ -13,6 +13,8 @@
 //   trailing update  A[k+nb:, k+nb:] -= U[k, k+nb:]^T U[k, k+nb:]    (TN GEMM, upper tiles)
 // Extra columns to the right of the n x n block ride along in the row panels, so
 // appending the gradient as column n yields the forward substitution U^-T g for free.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lsqamd {
@@ -363,6 +365,13 @@ static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, d
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
     if (e != hipSuccess) return e;
     g_potf2_attr = true;
+  }
+  static const bool use_mfma = [] {
+    const char *e = getenv("LSQAMD_POTF2");
+    return !(e && e[0] == 'l');   // LSQAMD_POTF2=lds selects the LDS-resident kernel (developer knob)
+  }();
+  if (use_mfma) {
+    return launch_potf2_mfma(st, A, lda, nb, uinv, info, k0, batch, strideA, strideW, active);
   }
   const bool vec = !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15) && !(strideA & 1);
   if (vec)

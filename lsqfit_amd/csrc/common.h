@@ -45,6 +45,12 @@ size_t potrf_work_bytes(int64_t n);
 hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
                        double *work, int32_t *dev_info);
 // batched: matrix b at A + b*strideA, block inverses at work + b*strideW, info[b];
+// diagonal block (nb <= 128) of the blocked Cholesky: A_kk -> U_kk in place, inv(U_kk) -> uinv
+// (128 x 128, row-major); one workgroup per batch entry (potf2_mfma.hip)
+hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, double *uinv, int32_t *info,
+                             int32_t k0, int32_t batch, int64_t strideA, int64_t strideW,
+                             const int32_t *active);
+
 // entries with active[b] == 0 (if given) are skipped
 hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
                                double *work, int32_t *dev_info, int32_t batch, int64_t strideA,

@@ -1,0 +1,286 @@
+// Diagonal-block Cholesky + triangular inverse, matrix-core formulation (gfx950).
+//
+// Replaces the LDS-resident diagonal kernel of chol.hip on the critical path of
+// potrf_upper (the damped normal-equation solve that stands in for GSL's
+// solver->init/presolve/solve, src/lsqfit/_gsl.pyx:646-653,:677).  Compiled with
+// -mllvm -amdgpu-mfma-vgpr-form (see build.py): with the whole tile file in
+// architectural VGPRs the sweep is straight-line MFMA code; hipcc's default
+// heuristic parks the tiles in AccVGPRs and spends 10k v_accvgpr_read/_mov on them.
+#include "common.h"
+
+namespace lsqamd {
+
+constexpr int NB = CHOL_NB;
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+
+__device__ __forceinline__ double rsqrt_refined(double d) {
+  double y = __builtin_amdgcn_rsq(d);  // v_rsq_f64, then two Newton steps to full precision
+  const double h = -0.5 * d;
+  double e = __builtin_fma(h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+
+// ---- diagonal-block kernel, matrix-core formulation -------------------------------------------
+// The fp64 MFMA accumulator layout (16 x 16 tile: lane l, register r <-> row 4r + (l >> 4),
+// column l & 15) makes register r of a tile a 4-row slab whose lane mapping IS the k-major
+// operand layout of v_mfma_f64_16x16x4 (k = l >> 4, m or n = l & 15).  So with the augmented
+// block [A | I] (8 x 16 tiles of 16 x 16) resident in accumulator layout, blocked elimination
+// with block size 4 needs no data movement at all:
+//     slab  <- D_u^-T slab            one MFMA per tile of the slab row (A operand = D_u^-T)
+//     tile(i, j) -= slab_i^T slab_j   one MFMA per trailing tile, operands = slab registers
+// [A | I] -> [U | U^-T]: the inverse the row-panel GEMMs need falls out of the same sweep.
+// Tile columns are dealt to the 4 waves (wave w: columns w and w + 4 of both halves = 18 live
+// tiles, 72 fp64 registers per lane); per slab the owner of the diagonal tile factors the 4 x 4
+// pivot block (scalar-uniform arithmetic on 10 broadcast values), everyone scales its part of
+// the slab, the negated slab goes through LDS (4 KiB) as A operands, everyone updates its tiles.
+// Two workgroup barriers per slab, 32 slabs; the matrix itself never touches LDS.
+struct TileRegs {
+  v4d X[2][8];  // slot c <-> tile column tj = wave + 4c; X[c][ti]: A-part tile (ti, tj) if ti < tj,
+                // E-part tile (ti, tj) if ti > tj (unused for ti == tj)
+  v4d DA[2];    // A-part diagonal tile (tj, tj)
+  v4d DE[2];    // E-part diagonal tile (tj, tj)
+};
+
+__device__ __forceinline__ v4d mfma4(double a, double b, v4d c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// 4 x 4 pivot block D = Du^T Du and V = Du^-1 -> mop: scalar-uniform arithmetic on ten broadcast values.
+// (Slotting the wave's pending update MFMAs between the stages of this chain was measured and
+// is slower: fp64 MFMA and fp64 VALU do not overlap usefully within one wave.)
+template <int R>
+__device__ __forceinline__ void pivot4(double reg, double *mop, int32_t *info, int32_t row0, int lane) {
+  const double d00 = readlane_d(reg, 0 * 16 + 4 * R + 0), d01 = readlane_d(reg, 0 * 16 + 4 * R + 1);
+  const double d02 = readlane_d(reg, 0 * 16 + 4 * R + 2), d03 = readlane_d(reg, 0 * 16 + 4 * R + 3);
+  const double d11 = readlane_d(reg, 1 * 16 + 4 * R + 1), d12 = readlane_d(reg, 1 * 16 + 4 * R + 2);
+  const double d13 = readlane_d(reg, 1 * 16 + 4 * R + 3), d22 = readlane_d(reg, 2 * 16 + 4 * R + 2);
+  const double d23 = readlane_d(reg, 2 * 16 + 4 * R + 3), d33 = readlane_d(reg, 3 * 16 + 4 * R + 3);
+  int bad = -1;
+  const bool ok0 = (d00 > 0.0) && (d00 < 1.0e300);
+  bad = ok0 ? bad : 0;
+  const double y0 = rsqrt_refined(ok0 ? d00 : 1.0);
+  const double u01 = d01 * y0, u02 = d02 * y0, u03 = d03 * y0;
+  const double t11 = __builtin_fma(-u01, u01, d11);
+  const bool ok1 = (t11 > 0.0) && (t11 < 1.0e300);
+  bad = (!ok1 && bad < 0) ? 1 : bad;
+  const double y1 = rsqrt_refined(ok1 ? t11 : 1.0);
+  const double u12 = __builtin_fma(-u01, u02, d12) * y1, u13 = __builtin_fma(-u01, u03, d13) * y1;
+  const double t22 = __builtin_fma(-u12, u12, __builtin_fma(-u02, u02, d22));
+  const bool ok2 = (t22 > 0.0) && (t22 < 1.0e300);
+  bad = (!ok2 && bad < 0) ? 2 : bad;
+  const double y2 = rsqrt_refined(ok2 ? t22 : 1.0);
+  const double u23 = __builtin_fma(-u12, u13, __builtin_fma(-u02, u03, d23)) * y2;
+  const double t33 = __builtin_fma(-u23, u23, __builtin_fma(-u13, u13, __builtin_fma(-u03, u03, d33)));
+  const bool ok3 = (t33 > 0.0) && (t33 < 1.0e300);
+  bad = (!ok3 && bad < 0) ? 3 : bad;
+  const double y3 = rsqrt_refined(ok3 ? t33 : 1.0);
+  if (bad >= 0 && lane == 0) atomicCAS(info, 0, row0 + bad + 1);
+  // V = Du^-1 (upper), v_ii = y_i
+  const double v01 = -y0 * (u01 * y1);
+  const double v12 = -y1 * (u12 * y2);
+  const double v23 = -y2 * (u23 * y3);
+  const double v02 = -y0 * __builtin_fma(u01, v12, u02 * y2);
+  const double v13 = -y1 * __builtin_fma(u12, v23, u13 * y3);
+  const double v03 = -y0 * __builtin_fma(u01, v13, __builtin_fma(u02, v23, u03 * y3));
+  // A operand of the scaling product: M[m][k] = V[k][m] (m = lane & 15 < 4, k = lane >> 4 <= m);
+  // two-level select (by k, then by m) instead of a ten-deep chain
+  const int col = lane & 15, q = lane >> 4;
+  const double r0 = col == 0 ? y0 : (col == 1 ? v01 : (col == 2 ? v02 : v03));
+  const double r1 = col == 1 ? y1 : (col == 2 ? v12 : v13);
+  const double r2 = col == 2 ? y2 : v23;
+  double m = q == 0 ? r0 : (q == 1 ? r1 : (q == 2 ? r2 : y3));
+  m = (col < 4 && q <= col) ? m : 0.0;
+  mop[lane] = m;
+}
+
+// ---- the update list of one (slab S, wave W): position p <-> tile row TI + p / 2, slot p % 2
+constexpr bool upd_valid(int S, int W, int p) {
+  const int TI = S / 4, tr = TI + p / 2, tj = W + 4 * (p % 2);
+  if (tr > 7) return false;
+  if (tr < tj) return true;                 // A-part tile
+  if (tr > tj) return tj <= TI;             // E-part tile: its slab piece is zero for tj > TI
+  return true;                              // diagonal slot
+}
+constexpr int upd_count(int S, int W, int skip) {
+  int n = 0;
+  for (int p = 0; p < 16; ++p) n += (p != skip && upd_valid(S, W, p)) ? 1 : 0;
+  return n;
+}
+constexpr int upd_nth(int S, int W, int skip, int k) {  // position of the k-th entry, -1 past the end
+  for (int p = 0; p < 16; ++p)
+    if (p != skip && upd_valid(S, W, p)) {
+      if (k == 0) return p;
+      --k;
+    }
+  return -1;
+}
+
+template <int S, int W, int P>
+__device__ __forceinline__ void upd_at(TileRegs &T, const double *slabA, int lane) {
+  if constexpr (P >= 0) {
+    constexpr int TI = S / 4, R = S % 4, tr = TI + P / 2, c = P % 2, tj = W + 4 * c;
+    const double a = slabA[tr * 64 + lane];
+    if constexpr (tr < tj) {          // A-part tile (tr, tj); slab piece: A-part (TI, tj), TI <= tr < tj
+      T.X[c][tr] = mfma4(a, T.X[c][TI][R], T.X[c][tr]);
+    } else if constexpr (tr > tj) {   // E-part tile (tr, tj); slab piece: E-part (TI, tj), tj <= TI
+      if constexpr (tj < TI) T.X[c][tr] = mfma4(a, T.X[c][TI][R], T.X[c][tr]);
+      else T.X[c][tr] = mfma4(a, T.DE[c][R], T.X[c][tr]);
+    } else {                          // diagonal slot tr == tj
+      if constexpr (TI < tj) T.DA[c] = mfma4(a, T.X[c][TI][R], T.DA[c]);
+      else { T.DA[c] = mfma4(a, T.DA[c][R], T.DA[c]); T.DE[c] = mfma4(a, T.DE[c][R], T.DE[c]); }
+    }
+  }
+}
+
+template <int S, int W, int SKIP, int K0, int K1>
+__device__ __forceinline__ void upd_range(TileRegs &T, const double *slabA, int lane) {
+  if constexpr (K0 < K1) {
+    upd_at<S, W, upd_nth(S, W, SKIP, K0)>(T, slabA, lane);
+    upd_range<S, W, SKIP, K0 + 1, K1>(T, slabA, lane);
+  }
+}
+
+// One slab: pivot block (owner of the diagonal tile), scale, publish, update.
+template <int S, int W>
+__device__ __forceinline__ void slab_step(TileRegs &T, double *mop, double *slabA, int32_t *info,
+                                          int32_t k0, int lane) {
+  constexpr int TI = S / 4, R = S % 4;
+  const int col = lane & 15;
+  if constexpr (TI % 4 == W) pivot4<R>(T.DA[TI / 4][R], mop, info, k0 + 4 * S, lane);
+  __syncthreads();
+  const double mo = mop[lane];
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  // ---- scale this wave's pieces of the slab row; publish the negated A-part as A operands
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tj = W + 4 * c;
+    if (tj != TI) {
+      const v4d t = mfma4(mo, T.X[c][TI][R], zero);
+      T.X[c][TI][R] = t[0];
+      if (tj > TI) slabA[tj * 64 + lane] = -t[0];
+    } else {
+      const v4d ta = mfma4(mo, T.DA[c][R], zero);
+      const v4d te = mfma4(mo, T.DE[c][R], zero);
+      T.DA[c][R] = ta[0];
+      T.DE[c][R] = te[0];
+      // rows at and above the slab must not be touched by the update: drop the pivot block
+      // and everything left of it from the operand
+      slabA[tj * 64 + lane] = (col > 4 * R + 3) ? -ta[0] : 0.0;
+    }
+  }
+  __syncthreads();
+  // ---- rank-4 update of the tiles in tile rows TI..7 (the next pivot block's tile is early in
+  // the list: its owner goes straight from these MFMAs into the next pivot chain)
+  upd_range<S, W, -1, 0, upd_count(S, W, -1)>(T, slabA, lane);
+}
+
+template <int S, int W>
+struct SlabLoop {
+  static __device__ __forceinline__ void run(TileRegs &T, double *mop, double *slabA, int32_t *info,
+                                             int32_t k0, int nb, int lane) {
+    if (4 * S >= nb) return;  // identity padding: nothing left to eliminate (uniform)
+    slab_step<S, W>(T, mop, slabA, info, k0, lane);
+    SlabLoop<S + 1, W>::run(T, mop, slabA, info, k0, nb, lane);
+  }
+};
+template <int W>
+struct SlabLoop<32, W> {
+  static __device__ __forceinline__ void run(TileRegs &, double *, double *, int32_t *, int32_t, int, int) {}
+};
+
+// One wave's whole job with its tile columns known at compile time: every ownership test
+// folds away, the sweep is straight-line code (the four variants execute the same sequence
+// of workgroup barriers).
+template <int W>
+__device__ __forceinline__ void potf2_wave(double *A, int64_t lda, int nb, double *uinv, int32_t *info,
+                                           int32_t k0, double *mop, double *slabA, int lane) {
+  constexpr int wave = W;
+  const int col = lane & 15, q = lane >> 4;
+  TileRegs T;
+  // ---- load [A | I] in accumulator layout; outside the nb x nb block: identity
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tj = wave + 4 * c;
+    const int gc = 16 * tj + col;
+    const int gcc = gc < nb ? gc : nb - 1;
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = 16 * ti + 4 * r + q;
+        const int grc = gr < nb ? gr : nb - 1;
+        double a = 0.0;
+        if (ti <= tj) a = A[(int64_t)grc * lda + gcc];
+        a = (gr < nb && gc < nb) ? a : (gr == gc ? 1.0 : 0.0);
+        if (ti < tj) T.X[c][ti][r] = a;
+        else if (ti > tj) T.X[c][ti][r] = 0.0;
+        else {
+          T.DA[c][r] = a;
+          T.DE[c][r] = (4 * r + q == col) ? 1.0 : 0.0;
+        }
+      }
+    }
+  }
+  SlabLoop<0, W>::run(T, mop, slabA, info, k0, nb, lane);
+  // ---- store U (upper triangle of the block) and inv(U) = (U^-T)^T (whole 128 x 128 tile)
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tj = wave + 4 * c;
+    const int gc = 16 * tj + col;
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = 16 * ti + 4 * r + q;
+        if (ti <= tj) {
+          const double u = (ti < tj) ? T.X[c][ti][r] : T.DA[c][r];
+          if (gr < nb && gc < nb && gc >= gr) A[(int64_t)gr * lda + gc] = u;
+        }
+        // E(gr, gc) = W[gr][gc], lower triangular  ->  uinv[gc][gr]; the rest of row gc is zero
+        double w = 0.0;
+        if (ti > tj) w = T.X[c][ti][r];
+        else if (ti == tj) w = T.DE[c][r];
+        w = (gr >= gc && gr < nb && gc < nb) ? w : 0.0;
+        if (gc < nb) uinv[gc * NB + gr] = w;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void potf2_mfma_kernel(double *A, int64_t lda, int nb, double *uinv,
+                                                         int32_t *info, int32_t k0, int64_t strideA,
+                                                         int64_t strideW, const int32_t *active) {
+  __shared__ double mop[64];
+  __shared__ double slabA[8 * 64];
+  if (active && !active[blockIdx.x]) return;
+  A += (int64_t)blockIdx.x * strideA;
+  uinv += (int64_t)blockIdx.x * strideW;
+  info += blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction (readfirstlane tells the compiler): scalar dispatch
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == 0) potf2_wave<0>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
+  else if (wave == 1) potf2_wave<1>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
+  else if (wave == 2) potf2_wave<2>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
+  else potf2_wave<3>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
+}
+
+hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, double *uinv, int32_t *info,
+                             int32_t k0, int32_t batch, int64_t strideA, int64_t strideW,
+                             const int32_t *active) {
+  hipLaunchKernelGGL(potf2_mfma_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info,
+                     k0, strideA, strideW, active);
+  return hipGetLastError();
+}
+
+}  // namespace lsqamd
