@@ -26,6 +26,8 @@
 //     issued before the MFMAs of stage t and written to LDS after them.
 //   * split-K over rows (the long dimension, N_data) into per-split slabs summed
 //     by a second pass: deterministic, and gives >> 256 workgroups.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lsqamd {
@@ -515,9 +517,14 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
                         !a.force_generic;
-  // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups)
+  // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups); threshold from a
+  // sweep of potrf_upper at P = 4096 (160: 2.67 ms, 600: 2.56 ms, 1000: 2.56 ms)
   const int64_t nblk128 = tiles_m * tiles_n * g.splits * (a.batch < 1 ? 1 : a.batch);
-  if (!a.work_map && a.K <= 512 && nblk128 <= 160 && !a.force_generic) {
+  static const int64_t small_max = [] {
+    const char *e = getenv("LSQAMD_SMALL_GEMM_MAX");  // developer knob
+    return e ? (int64_t)atoll(e) : (int64_t)600;
+  }();
+  if (!a.work_map && a.K <= 512 && nblk128 <= small_max && !a.force_generic) {
     const int64_t tm64 = (a.M + TS - 1) / TS, tn64 = (a.N + TS - 1) / TS;
     g.tiles_n = (int32_t)tn64;
     dim3 grid64((unsigned)(tm64 * tn64), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
