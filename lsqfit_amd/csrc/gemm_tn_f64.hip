@@ -524,7 +524,12 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
     const char *e = getenv("LSQAMD_SMALL_GEMM_MAX");  // developer knob
     return e ? (int64_t)atoll(e) : (int64_t)600;
   }();
-  if (!a.work_map && a.K <= 512 && nblk128 <= small_max && !a.force_generic) {
+  // in-place products (C aliases an operand: the Cholesky row panel, the triangular inverse) are
+  // only safe when ONE workgroup owns a whole column range of the operand, i.e. a single tile row
+  const bool inplace = (a.C == a.Y) || (a.C == a.X);
+  if (inplace && tiles_m > 1) return hipErrorInvalidValue;
+  const bool small_ok = !inplace || a.M <= TS;
+  if (!a.work_map && a.K <= 512 && nblk128 <= small_max && !a.force_generic && small_ok) {
     const int64_t tm64 = (a.M + TS - 1) / TS, tn64 = (a.N + TS - 1) / TS;
     g.tiles_n = (int32_t)tn64;
     dim3 grid64((unsigned)(tm64 * tn64), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
