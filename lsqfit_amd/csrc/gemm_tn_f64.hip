@@ -473,6 +473,134 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f64_small_kernel(GemmDev g) {
     }
 }
 
+// 128 x 64-tile variant for IN-PLACE row panels (C aliases Y, M <= 128: the Cholesky row panel
+// U[k, k+1:] = inv(U_kk)^T A[k, k+1:]): one workgroup still owns whole columns of the operand --
+// which is what makes the in-place update safe -- but there are twice as many of them as with
+// 128 x 128 tiles and each carries half the MFMA chain.  Single tile row only (blockIdx.x = tile
+// column).  Same edge / triangular / beta / batch contract as the other kernels.
+constexpr int PN = 64;
+constexpr int LDS_PX = BM + 16;   // 144
+constexpr int LDS_PY = PN + 16;   // 80
+constexpr int STAGE_P = BK * (LDS_PX + LDS_PY);
+constexpr size_t GEMM_LDS_BYTES_P = 2 * STAGE_P * sizeof(double);
+
+template <bool VEC>
+__global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;   // wave tile: 64 rows x 32 columns
+  const int64_t m0 = 0, n0 = (int64_t)blockIdx.x * PN;
+  const int64_t b = blockIdx.z;
+  if (g.batch_active && !g.batch_active[b]) return;
+  const double *X = g.X + b * g.sx;
+  const double *Y = g.Y + b * g.sy;
+  double *C = g.C + b * g.sc;
+  int64_t kb = 0, ke = g.K;
+  if (g.x_upper_tri && ke > BM) ke = BM;
+  v4d acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  // X stage: 16 x 128 -> thread: column pair (tid & 63) * 2, rows (tid >> 6) + 4 i
+  // Y stage: 16 x 64  -> thread: column pair (tid & 31) * 2, rows (tid >> 5) + 8 i
+  const int xc2 = (tid & 63) * 2, xrg = tid >> 6;
+  const int yc2 = (tid & 31) * 2, yrg = tid >> 5;
+  const int64_t xc = m0 + xc2, yc = n0 + yc2;
+  const bool x0ok = xc < g.M, x1ok = xc + 1 < g.M;
+  const bool y0ok = yc < g.N, y1ok = yc + 1 < g.N;
+  const int64_t xi0 = VEC ? (xc < g.ldx - 2 ? xc : g.ldx - 2) : (xc < g.M ? xc : g.M - 1);
+  const int64_t xi1 = xc + 1 < g.M ? xc + 1 : g.M - 1;
+  const int64_t yi0 = VEC ? (yc < g.ldy - 2 ? yc : g.ldy - 2) : (yc < g.N ? yc : g.N - 1);
+  const int64_t yi1 = yc + 1 < g.N ? yc + 1 : g.N - 1;
+  v2d xr[4], yr[2];
+  auto gload = [&](int64_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = k0 + xrg + 4 * i;
+      row = row < ke ? row : ke - 1;
+      xr[i] = load2<VEC>(X + row * g.ldx, xi0, xi1);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int64_t row = k0 + yrg + 8 * i;
+      row = row < ke ? row : ke - 1;
+      yr[i] = load2<VEC>(Y + row * g.ldy, yi0, yi1);
+    }
+  };
+  auto sstore = [&](int buf, int64_t k0) {
+    double *Xs = smem + buf * STAGE_P;
+    double *Ys = Xs + BK * LDS_PX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = xrg + 4 * i;
+      const bool rok = k0 + row < ke;
+      v2d xv;
+      xv.x = (rok && x0ok) ? xr[i].x : 0.0;
+      xv.y = (rok && x1ok) ? xr[i].y : 0.0;
+      *reinterpret_cast<v2d *>(Xs + row * LDS_PX + xc2) = xv;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = yrg + 8 * i;
+      const bool rok = k0 + row < ke;
+      v2d yv;
+      yv.x = (rok && y0ok) ? yr[i].x : 0.0;
+      yv.y = (rok && y1ok) ? yr[i].y : 0.0;
+      *reinterpret_cast<v2d *>(Ys + row * LDS_PY + yc2) = yv;
+    }
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  if (kb < ke) {
+    gload(kb);
+    sstore(0, kb);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+    const bool more = k0 + BK < ke;
+    if (more) gload(k0 + BK);
+    const double *Xs = smem + cur * STAGE_P;
+    const double *Ys = Xs + BK * LDS_PX;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double a[4], bb[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDS_PX + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bb[j] = Ys[kr * LDS_PY + wn * 32 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) sstore(cur ^ 1, k0 + BK);
+    __syncthreads();
+    cur ^= 1;
+  }
+  // every read of the operand columns this workgroup owns has happened (the loop's last barrier);
+  // only now may C, which may alias Y, be written
+  const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 32 + j * 16 + fr;
+      if (col >= g.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t row = m0 + wm * 64 + i * 16 + fq + 4 * r;
+        if (row >= g.M) continue;
+        double v = alpha * acc[i][j][r];
+        if (beta != 0.0) v += beta * C[row * g.ldc + col];
+        C[row * g.ldc + col] = v;
+      }
+    }
+}
+
 static bool g_attr_set = false;
 
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
@@ -529,6 +657,16 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   const bool inplace = (a.C == a.Y) || (a.C == a.X);
   if (inplace && tiles_m > 1) return hipErrorInvalidValue;
   const bool small_ok = !inplace || a.M <= TS;
+  if (inplace && a.C == a.Y && a.M > TS && a.K <= BM && g.splits == 1 && !a.force_generic) {
+    // row panel: 128 x 64 tiles, one workgroup per 64 operand columns
+    g.tiles_n = (int32_t)((a.N + PN - 1) / PN);
+    dim3 gridp((unsigned)g.tiles_n, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
+    if (g.vec_x && g.vec_y)
+      hipLaunchKernelGGL(gemm_tn_f64_panel_kernel<true>, gridp, dim3(256), GEMM_LDS_BYTES_P, st, g);
+    else
+      hipLaunchKernelGGL(gemm_tn_f64_panel_kernel<false>, gridp, dim3(256), GEMM_LDS_BYTES_P, st, g);
+    return hipGetLastError();
+  }
   if (!a.work_map && a.K <= 512 && nblk128 <= small_max && !a.force_generic && small_ok) {
     const int64_t tm64 = (a.M + TS - 1) / TS, tn64 = (a.N + TS - 1) / TS;
     g.tiles_n = (int32_t)tn64;

@@ -116,3 +116,34 @@ def test_potrf_flags_indefinite(env):
     assert rc == 0
     torch.cuda.synchronize()
     assert int(info[0]) > 0
+
+
+@pytest.mark.parametrize('M,N', [(128, 4224), (128, 77), (100, 1000), (64, 512), (33, 129)])
+def test_gemm_tn_in_place_row_panel(env, M, N):
+    """C aliases Y (the Cholesky row panel U[k, k+1:] = inv(U_kk)^T A[k, k+1:]): every shape the
+    launcher accepts must be computed by workgroups that own whole operand columns -- wide N makes
+    workgroups outnumber the CUs, the situation in which a two-tile-row split corrupts the panel."""
+    torch, lib = env
+    rng = np.random.default_rng(M + N)
+    ld = N + (N & 1) + 2
+    X = np.triu(rng.standard_normal((M, M))) + 3 * np.eye(M)       # upper triangular, k-major
+    Y = rng.standard_normal((M, ld))
+    dX, dY = dev(torch, X), dev(torch, Y)
+    for rep in range(3):
+        dY.copy_(torch.from_numpy(Y))
+        rc = lib.lsqamd_op_gemm_tn(None, M, N, M, 1.0, dX.data_ptr(), M, dY.data_ptr(), ld, 0.0,
+                                   dY.data_ptr(), ld, 0, 1)
+        assert rc == 0
+        torch.cuda.synchronize()
+        want = X.T @ Y[:, :N]
+        np.testing.assert_allclose(dY.cpu().numpy()[:, :N], want, rtol=1e-12, atol=1e-12 * np.abs(want).max())
+
+
+def test_gemm_tn_rejects_unsafe_in_place(env):
+    """Two tile rows of an in-place product would race: the launcher refuses instead."""
+    torch, lib = env
+    X = dev(torch, np.eye(256))
+    Y = dev(torch, np.ones((256, 512)))
+    rc = lib.lsqamd_op_gemm_tn(None, 256, 512, 256, 1.0, X.data_ptr(), 256, Y.data_ptr(), 512, 0.0,
+                               Y.data_ptr(), 512, 0, 0)
+    assert rc != 0
