@@ -227,6 +227,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
 // one wave instruction lands one 1 KiB tile row, lane l -> bytes [16 l, 16 l + 16) of the
 // row, so the padded row stride costs nothing), no staging VGPRs, no ds_write pass, no
 // masks; row pointers advance by a constant instead of being recomputed.
+// XTRI (X upper triangular, the whitening product with X = W_b^T): the 16-row MFMA strips of
+// the two wave rows are interleaved (strip 2i + wm instead of 4 wm + i) and a strip skips the
+// k-steps that lie entirely below its rows -- X is zero there.  Interleaving matters: with
+// contiguous 64-row halves the lower half would still do 81 % of the k-steps of a diagonal tile
+// while the upper half idles; interleaved, the busier wave row does 62 %.
+template <bool XTRI>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
@@ -299,14 +305,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
       const int kr = kk * 4 + fq;
       double a[4], bb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDT + wm * 64 + i * 16 + fr];
+      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDT + (XTRI ? (2 * i + wm) * 16 : wm * 64 + i * 16) + fr];
 #pragma unroll
       for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + wn * 64 + j * 16 + fr];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        // X[k][m] = 0 for k > m: strip rows m0 + 16 s .. + 15 see nothing from k-steps beyond them
+        if (XTRI && k0 + kk * 4 > m0 + (2 * i + wm) * 16 + 15) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
     cur ^= 1;
@@ -316,13 +325,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const double beta = g.splits > 1 ? 0.0 : g.beta;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
+    const int64_t rbase = m0 + (XTRI ? (2 * i + wm) * 16 : wm * 64 + i * 16) + fq;
     double cv[4][4];
     if (beta != 0.0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          cv[j][r] = C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr];
+          cv[j][r] = C[(rbase + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
       for (int r = 0; r < 4; ++r) {
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * cv[j][r];
-        C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr] = v;
+        C[(rbase + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr] = v;
       }
   }
 }
@@ -613,7 +623,10 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     g_attr_set = true;
@@ -677,8 +690,10 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
       hipLaunchKernelGGL(gemm_tn_f64_small_kernel<false>, grid64, dim3(256), GEMM_LDS_BYTES_S, st, g);
     return hipGetLastError();
   }
-  if (interior)
-    hipLaunchKernelGGL(gemm_tn_f64_interior_kernel, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  if (interior && a.x_upper_tri)
+    hipLaunchKernelGGL(gemm_tn_f64_interior_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  else if (interior)
+    hipLaunchKernelGGL(gemm_tn_f64_interior_kernel<false>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (g.vec_x && g.vec_y)
     hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else
