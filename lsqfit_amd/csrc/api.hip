@@ -96,6 +96,12 @@ struct lsqamd_fit {
   int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
   double logdet = NAN;
 
+  // pinned host staging for the per-step transfers (pageable copies go through a blit
+  // kernel and cost ~40 us each): [g | chi2](P+1), coln(P), v(P), diag(P), x_trial(P), scalars(8)
+  double *pin = nullptr;
+  double *pin_g = nullptr, *pin_c = nullptr, *pin_v = nullptr, *pin_d = nullptr, *pin_x = nullptr, *pin_s = nullptr;
+  std::vector<hipEvent_t> event_pool;
+
   // timing
   bool timing = false;
   TimerSlot timers[LSQAMD_T_COUNT];
@@ -117,14 +123,25 @@ namespace {
     if (_e != hipSuccess) FAIL(fit, LSQAMD_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
   } while (0)
 
+hipEvent_t take_event(lsqamd_fit *f) {  // events are recycled: creating one costs ~10 us
+  hipEvent_t e = nullptr;
+  if (!f->event_pool.empty()) {
+    e = f->event_pool.back();
+    f->event_pool.pop_back();
+  } else {
+    (void)hipEventCreate(&e);
+  }
+  return e;
+}
+
 struct Scope {  // HIP-event bracket for one phase
   lsqamd_fit *f;
   int which;
   hipEvent_t a = nullptr, b = nullptr;
   Scope(lsqamd_fit *fit, int w) : f(fit), which(w) {
     if (f->timing) {
-      (void)hipEventCreate(&a);
-      (void)hipEventCreate(&b);
+      a = take_event(f);
+      b = take_event(f);
       (void)hipEventRecord(a, f->st);
     }
   }
@@ -145,8 +162,8 @@ void resolve_timers(lsqamd_fit *f) {
         t.total_ms += ms;
         t.count += 1;
       }
-      (void)hipEventDestroy(pr.first);
-      (void)hipEventDestroy(pr.second);
+      f->event_pool.push_back(pr.first);
+      f->event_pool.push_back(pr.second);
     }
     t.pending.clear();
   }
@@ -279,10 +296,9 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
   }
   int rc = do_reduce(f, f->red_scalar, 1);
   if (rc) return rc;
-  double c2 = 0.0;
-  HIPCHK(f, hipMemcpyAsync(&c2, f->red_scalar, sizeof(double), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_s, f->red_scalar, sizeof(double), hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
-  *chi2_out = c2;
+  *chi2_out = f->pin_s[0];
   f->nfev++;
   return 0;
 }
@@ -365,15 +381,14 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
   rc = do_reduce(f, f->redbuf, f->npk + P + 1);
   if (rc) return rc;
   HIPCHK(f, launch_packed_diag(f->st, f->redbuf, P, f->diag_dev));
-  f->htmp.resize(P + 1);
-  HIPCHK(f, hipMemcpyAsync(f->htmp.data(), gvec, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, f->st));
-  HIPCHK(f, hipMemcpyAsync(f->hcoln.data(), f->diag_dev, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_g, gvec, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_c, f->diag_dev, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
   for (int64_t j = 0; j < P; ++j) {
-    f->hg[j] = f->htmp[j];
-    f->hcoln[j] = std::sqrt(f->hcoln[j] > 0.0 ? f->hcoln[j] : 0.0);
+    f->hg[j] = f->pin_g[j];
+    f->hcoln[j] = std::sqrt(f->pin_c[j] > 0.0 ? f->pin_c[j] : 0.0);
   }
-  f->chi2 = f->htmp[P];
+  f->chi2 = f->pin_g[P];
   f->njev++;
   f->have_cov = false;
   f->have_dense_A = false;
@@ -388,7 +403,8 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
   int32_t info = 0;
   {
     Scope sc(f, LSQAMD_T_CHOLESKY);
-    HIPCHK(f, hipMemcpyAsync(f->diag_dev, diag_host, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+    std::memcpy(f->pin_d, diag_host, sizeof(double) * P);
+    HIPCHK(f, hipMemcpyAsync(f->diag_dev, f->pin_d, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
     HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, f->diag_dev, gvec, f->M));
     HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev));
   }
@@ -396,9 +412,11 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
     Scope sc(f, LSQAMD_T_SOLVE);
     HIPCHK(f, launch_copy_strided(f->st, f->M + P, f->ldm, f->yv, 1, P, 1));
     HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
-    HIPCHK(f, hipMemcpyAsync(f->hv.data(), f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
-    HIPCHK(f, hipMemcpyAsync(&info, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->pin_s + 4, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
     HIPCHK(f, hipStreamSynchronize(f->st));
+    std::memcpy(f->hv.data(), f->pin_v, sizeof(double) * P);
+    std::memcpy(&info, f->pin_s + 4, sizeof(int32_t));
   }
   f->ntrial++;
   if (info != 0) {
@@ -732,7 +750,8 @@ int iterate(lsqamd_fit *f) {
         f->hdx[j] = dx[j];
         xt[j] = f->hx[j] + dx[j];
       }
-      HIPCHK(f, hipMemcpyAsync(f->p_trial, xt.data(), sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      std::memcpy(f->pin_x, xt.data(), sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
       double chi2_t = 0.0;
       const int rc = eval_residual_dev(f, f->p_trial, &chi2_t);
       if (rc) return rc;
@@ -899,6 +918,15 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.factor_down = 2.0;
   f->opt.trs = LSQAMD_TRS_LM;
   f->opt.avmax = 0.75;
+  {
+    const size_t P1 = (size_t)f->P + 1;
+    if (hipHostMalloc((void **)&f->pin, sizeof(double) * (5 * P1 + 8), hipHostMallocDefault) != hipSuccess) {
+      delete f;
+      return LSQAMD_ENOMEM;
+    }
+    f->pin_g = f->pin; f->pin_c = f->pin_g + P1; f->pin_v = f->pin_c + P1; f->pin_d = f->pin_v + P1;
+    f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1;
+  }
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
     return LSQAMD_EHIP;
@@ -924,6 +952,8 @@ int lsqamd_destroy(lsqamd_fit *fit) {
   if (!fit) return 0;
   (void)hipStreamSynchronize(fit->st);
   resolve_timers(fit);
+  for (hipEvent_t e : fit->event_pool) (void)hipEventDestroy(e);
+  if (fit->pin) (void)hipHostFree(fit->pin);
   delete fit;
   return 0;
 }
