@@ -53,6 +53,48 @@ def test_config3_like_dense_block_2048x256(amd):
     assert fit.nblocks == {2048: 1, 256: 1}
 
 
+def test_config3_full_size_dense_block_8192x1024(amd):
+    """configs[2] at its full size: ONE dense 8192 x 8192 data covariance + dense 1024 x 1024
+    prior ("full correlated-prior Cholesky whitening").  The oracle's eigen-decomposition route
+    takes minutes here, so the normal equations are checked against a direct numpy restatement
+    with the Cholesky factor (any W with W^T W = C^-1 gives the same J^T J, J^T f, chi2), and the
+    converged fit through its own properties."""
+    import scipy.linalg as sla
+    from lsqfit_amd import synth
+    N, P = 8192, 1024
+    d = synth.make_cosmix(N=N, P=P, seed=20262, block=N, prior_corr=True)
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    assert wh.nblocks == {N: 1, P: 1} and wh.nmod == 0
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    # (a start 1e-3 away is already chi2 ~ 1e13 in this landscape -- 512 frequencies, 0.1 % data
+    # errors -- and LM then crawls through local structure for hundreds of iterations)
+    p = d['p_true'] * (1 + 1e-6 * np.random.default_rng(3).standard_normal(P))
+    chi2 = pr.normal(p)
+    A, g = pr.get_jtj(), pr.get_grad()
+    cov = d['yerr']['blocks'][0][1]
+    L = sla.cholesky(cov, lower=True)
+    Jw = sla.solve_triangular(L, gu.cosmix_jac(d['x'], p), lower=True)
+    rw = sla.solve_triangular(L, gu.cosmix_fcn(d['x'], p) - d['ymean'], lower=True)
+    prec = np.linalg.inv(d['prior'][1])
+    dp = p - d['prior'][0]
+    assert gu.relmax(A, Jw.T @ Jw + prec) < 1e-8           # cond(C) ~ 4.5e5: Cholesky-level agreement
+    assert gu.relmax(g, Jw.T @ rw + prec @ dp) < 1e-8
+    assert chi2 == pytest.approx(rw @ rw + dp @ prec @ dp, rel=1e-8)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'],
+                            p0=p, problem=pr)
+    assert fit.error is None and fit.stopping_criterion in (1, 2)
+    assert fit.dof == N and 0.9 < fit.chi2 / fit.dof < 1.2
+    pull = (fit.pmean - d['p_true']) / fit.psdev
+    assert np.abs(pull).max() < 6 and 0.8 < pull.std() < 1.2
+    Af = pr.get_jtj()
+    dd = np.sqrt(np.diag(Af))
+    R = (Af / np.outer(dd, dd)) @ (fit.cov * np.outer(dd, dd)) - np.eye(P)
+    assert np.abs(R).max() < 1e-8
+    sign, ld = np.linalg.slogdet(Af)
+    assert sign > 0 and fit.fitter_results.logdet_jtj == pytest.approx(ld, rel=1e-10)
+    pr.close()
+
+
 def test_config4_like_blocks_8192x1024(amd):
     """configs[3] scaled 8x down in both dimensions: 256-row blocks + dense prior."""
     from lsqfit_amd import synth
