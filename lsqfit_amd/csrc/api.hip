@@ -286,9 +286,22 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
     Scope sc(f, LSQAMD_T_RESIDUAL);
     ModelArgs m = model_args(f, p);
     HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
-    if (f->cfg.n_blocks > 0)
+    if (f->cfg.n_blocks > 0) {
+      // small blocks: one thread per output row; large ones (a single 8192-row block would keep
+      // 32 workgroups busy for milliseconds): r_b = Wt_b^T delta_b as a two-stage column sum at
+      // HBM speed, staged through the raw-Jacobian buffer (idle during a residual evaluation)
+      constexpr int64_t BIG = 1024;
       HIPCHK(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff,
-                                        f->cfg.n_blocks, f->cfg.max_block, f->r_raw, f->r));
+                                        f->cfg.n_blocks, f->cfg.max_block, f->r_raw, f->r, 1, 0, nullptr, BIG));
+      for (size_t b = 0; b < f->h_size.size(); ++b) {
+        const int64_t B = f->h_size[b];
+        if (B < BIG) continue;
+        int64_t nch = (f->N * f->ld) / B;
+        if (nch > 256) nch = 256;
+        HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->Jraw, nch,
+                                    f->r + f->h_row0[b], f->r_raw + f->h_row0[b]));
+      }
+    }
     HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, f->red_scalar));
     if (f->cfg.has_prior && f->adds_prior)
       HIPCHK(f, launch_prior_chi2(f->st, f->P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, p,
@@ -321,6 +334,22 @@ int whiten_jacobian(lsqamd_fit *f) {
       // full-tile bulk (interior kernel) + the residual column on its own
       g.N = f->P;
       HIPCHK(f, launch_gemm_tn(f->st, g));
+      if (B >= 1024) {
+        // the residual column of a large block is a GEMV: two-stage column sum at HBM speed
+        // (as a one-column GEMM it would keep B/128 workgroups busy for over a millisecond)
+        const int64_t slab_doubles = (int64_t)f->splits * f->P * f->ldm;
+        for (int b = 0; b < nb; ++b) {
+          int64_t nch = slab_doubles / B;
+          if (nch > 256) nch = 256;
+          if (nch < 1) { nch = 0; }
+          if (nch == 0) break;
+          const int64_t r0 = f->h_row0[b];
+          HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->slabs, nch, f->r + r0,
+                                      f->Jraw + r0 * f->ld + f->P, f->ld));
+          HIPCHK(f, launch_copy_strided(f->st, f->r + r0, 1, f->J + r0 * f->ld + f->P, f->ld, B, 1));
+        }
+        if (slab_doubles / B >= 1) return 0;
+      }
       g.Y += f->P; g.C += f->P; g.N = 1;
       HIPCHK(f, launch_gemm_tn(f->st, g));
       return 0;

@@ -100,7 +100,8 @@ hipError_t launch_jacobian_ex(hipStream_t st, const ModelArgs &m, double *J_w, d
 // out[j] = sum_i J[i][j] * J[i][rcol] for j in [0, ncols)   (ncols = P+1 gives grad and chi2)
 hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
-                             double *out, const double *rvec = nullptr);  // rvec: weights instead of J[:, rcol]
+                             double *out, const double *rvec = nullptr,   // rvec: weights instead of J[:, rcol]
+                             int64_t rvec_stride = 1);
 // y = A x (row-major, one wave per row)
 hipError_t launch_gemv_rows(hipStream_t st, const double *A, int64_t ld, int64_t rows, int64_t cols,
                             const double *x, double *y);
@@ -111,7 +112,8 @@ hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64
                                    const int64_t *bsize, const int64_t *woff, int32_t n_blocks,
                                    int64_t max_block, const double *delta, double *r_out,
                                    int32_t batch = 1, int64_t stride = 0,
-                                   const int32_t *batch_active = nullptr);
+                                   const int32_t *batch_active = nullptr,
+                                   int64_t skip_from = INT64_MAX);  // blocks of >= skip_from rows are left out
 // packed upper tiles <- sum over split-K slabs (matrix layout, P x ld each)
 hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
                                 int64_t split_stride, int64_t P, int64_t ld, double *apk);

@@ -47,6 +47,7 @@ struct GemmDev {
   double alpha, beta;
   int64_t sx, sy, sc;
   int32_t tiles_n, upper_only, x_upper_tri, xy_lower_tri, splits;
+  int32_t tiles_m, pair_rows;
   int32_t vec_x, vec_y;  // operand rows are 16-byte aligned -> dwordx4 loads
   int64_t kchunk, split_stride;
   const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
@@ -250,6 +251,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
     tn = blockIdx.x % g.tiles_n;
     split = blockIdx.y;
   }
+  // pair_rows (triangular X with many tile rows): this workgroup does tile rows tm and
+  // T-1-tm one after the other, so every workgroup sees the same total K (the k-range of a
+  // tile row grows with tm: unpaired, the last rows take 64x as long as the first)
+  const int tm_other = (XTRI && g.pair_rows) ? g.tiles_m - 1 - tm : tm;
+  const int npass = tm_other != tm ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  if (pass == 1) { tm = tm_other; __syncthreads(); }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   if (g.upper_only && n0 + BN <= m0) return;
   const int64_t b = blockIdx.z;
@@ -343,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
         C[(rbase + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr] = v;
       }
   }
+  }  // pass
 }
 
 // 64 x 64-tile variant for the latency-bound contractions of the Cholesky family (K = 128,
@@ -642,6 +651,8 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   const int64_t tiles_m = (a.M + BM - 1) / BM;
   const int64_t tiles_n = (a.N + BN - 1) / BN;
   g.tiles_n = (int32_t)tiles_n;
+  g.tiles_m = (int32_t)tiles_m;
+  g.pair_rows = 0;
   g.upper_only = a.upper_only;
   g.x_upper_tri = a.x_upper_tri;
   g.xy_lower_tri = a.xy_lower_tri;
@@ -690,8 +701,13 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
       hipLaunchKernelGGL(gemm_tn_f64_small_kernel<false>, grid64, dim3(256), GEMM_LDS_BYTES_S, st, g);
     return hipGetLastError();
   }
-  if (interior && a.x_upper_tri)
+  if (interior && a.x_upper_tri) {
+    if (tiles_m >= 4 && g.splits == 1 && !a.work_map) {  // balance the growing k-ranges (see kernel)
+      g.pair_rows = 1;
+      grid.x = (unsigned)(((tiles_m + 1) / 2) * tiles_n);
+    }
     hipLaunchKernelGGL(gemm_tn_f64_interior_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  }
   else if (interior)
     hipLaunchKernelGGL(gemm_tn_f64_interior_kernel<false>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (g.vec_x && g.vec_y)

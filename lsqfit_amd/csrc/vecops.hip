@@ -66,9 +66,9 @@ __global__ __launch_bounds__(256) void colsum_stage2(const double *partial, int6
 
 hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
-                             double *out, const double *rvec) {
+                             double *out, const double *rvec, int64_t rvec_stride) {
   const double *rv = rvec ? rvec : J + rcol;
-  const int64_t rs = rvec ? 1 : ld;
+  const int64_t rs = rvec ? rvec_stride : ld;
   int64_t nchunks = npartial;
   if (nchunks > nrows) nchunks = nrows > 0 ? nrows : 1;
   const int64_t rpc = nrows > 0 ? (nrows + nchunks - 1) / nchunks : 1;
@@ -121,9 +121,11 @@ __global__ __launch_bounds__(256) void block_whiten_vec_kernel(const double *wt,
                                                                const int64_t *bsize,
                                                                const int64_t *woff,
                                                                const double *delta, double *r_out,
-                                                               int64_t stride, const int32_t *active) {
+                                                               int64_t stride, const int32_t *active,
+                                                               int64_t skip_from) {
   const int b = blockIdx.y;
   if (active && !active[blockIdx.z]) return;
+  if (bsize[b] >= skip_from) return;  // large blocks go through the two-stage column-sum kernel
   delta += (int64_t)blockIdx.z * stride;
   r_out += (int64_t)blockIdx.z * stride;
   const int64_t B = bsize[b], r0 = row0[b];
@@ -138,11 +140,12 @@ __global__ __launch_bounds__(256) void block_whiten_vec_kernel(const double *wt,
 hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64_t *row0,
                                    const int64_t *bsize, const int64_t *woff, int32_t n_blocks,
                                    int64_t max_block, const double *delta, double *r_out,
-                                   int32_t batch, int64_t stride, const int32_t *batch_active) {
+                                   int32_t batch, int64_t stride, const int32_t *batch_active,
+                                   int64_t skip_from) {
   if (n_blocks <= 0) return hipSuccess;
   dim3 grid((unsigned)((max_block + 255) / 256), (unsigned)n_blocks, (unsigned)(batch < 1 ? 1 : batch));
   hipLaunchKernelGGL(block_whiten_vec_kernel, grid, dim3(256), 0, st, wt, row0, bsize, woff, delta,
-                     r_out, stride, batch_active);
+                     r_out, stride, batch_active, skip_from);
   return hipGetLastError();
 }
 
