@@ -177,7 +177,7 @@ int32_t choose_splits(int64_t N, int64_t P) {
   const int64_t T = (P + 127) / 128;
   const int64_t tiles = T * (T + 1) / 2;
   int64_t s = (8192 + tiles - 1) / tiles;
-  const int64_t maxs = N / 1024 > 1 ? N / 1024 : 1;
+  const int64_t maxs = N / 256 > 1 ? N / 256 : 1;  // K-chunks of at least 256 rows
   if (s > maxs) s = maxs;
   if (s > 16) s = 16;
   if (s < 1) s = 1;
