@@ -90,6 +90,31 @@ class nonlinear_fit(object):
         self.dof = nf - self.p0.size
         self._chiv = _Chiv(problem)
         t1 = clock()
+        if maxit == 0:
+            # src/lsqfit/__init__.py:683-706: no fit -- parameters are the prior (or p0 with infinite
+            # errors); chi2 is still evaluated on the device
+            self.fitter_results = None
+            self.error = None
+            if prior is None:
+                self.pmean = self.p0.copy()
+                self.psdev = np.full(self.p0.size, np.inf)
+                self.cov = np.diag(self.psdev ** 2)
+            else:
+                self.pmean = np.array(wh.prior_mean)
+                self.psdev = np.array(wh.prior_sdev)
+                perr = np.asarray(perr, float)
+                self.cov = perr.copy() if perr.ndim == 2 else np.diag(self.psdev ** 2)
+            self.chi2 = problem.chi2(self.pmean)
+            self.Q = gammaQ(self.dof / 2., self.chi2 / 2.)
+            self.nit, self.tol, self.maxit, self.stopping_criterion, self.description = 0, tol, 0, 0, ''
+            if prior is None:
+                self.logGBF = None
+            else:                                   # :718-725 without J: logdet(cov)
+                sign, ld = np.linalg.slogdet(self.cov)
+                self.logGBF = 0.5 * (ld - wh.logdet - self.chi2 - self.dof * np.log(2. * np.pi))
+            self.time = clock() - t0
+            self.time_setup, self.time_fit = t1 - t0, self.time - (t1 - t0)
+            return
         fit = FITTERS[self.fitter](self.p0, nf, self._chiv, tol=tol, maxit=maxit, problem=problem,
                                    **fitterargs)
         self.fitter_results = fit

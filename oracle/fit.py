@@ -128,6 +128,28 @@ def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
     fit.svdn = pdf.nmod
     fit.nblocks = pdf.nblocks
     fit.svdcut = svdcut
+    if maxit == 0:
+        # src/lsqfit/__init__.py:683-706: no fit; parameters = prior (or p0 with infinite errors)
+        if noprior:
+            fit.pmean = np.array(p0)
+            fit.psdev = np.full(p0.size, np.inf)
+            fit.cov = np.diag(fit.psdev ** 2)
+        else:
+            pm, psd, pcov = _spec(prior_mean, prior_err)
+            fit.pmean, fit.psdev = pm, psd
+            fit.cov = pcov if pcov is not None else np.diag(psd ** 2)
+        fit.chiv = chiv
+        fit.error = None
+        fit.residuals = chiv.residual(fit.pmean)
+        fit.chi2 = float(np.sum(fit.residuals ** 2))
+        fit.Q = gammaQ(fit.dof / 2., fit.chi2 / 2.)
+        fit.nit, fit.tol, fit.stopping_criterion, fit.description = 0, tol, 0, ''
+        if noprior:
+            fit.logGBF = None
+        else:   # :718-725 without J: logdet(cov)
+            sign, ld = np.linalg.slogdet(fit.cov)
+            fit.logGBF = 0.5 * (ld - pdf.logdet - fit.chi2 - fit.dof * np.log(2. * np.pi))
+        return fit
     lm = gsl_multifit(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
     fit.lm = lm
     fit.chiv = chiv

@@ -1,0 +1,116 @@
+"""-m gpu: edge cases of the path, as the reference tests them: maxit = 0
+(tests/test_lsqfit.py:405-413), scalar data / prior and x-less two-point data (:455-470), one
+parameter, one data row, more parameters than data, ragged block layouts with 1 x 1 rows between
+blocks, P just off the tile sizes, zero-width errors rejected, block sizes that are not multiples
+of anything."""
+import numpy as np
+import pytest
+
+from oracle import fit as ofit
+from oracle import gvar_lite
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+def wavg(m, s):
+    w = 1.0 / np.asarray(s, float) ** 2
+    return float(np.sum(w * m) / np.sum(w)), float(np.sum(w) ** -0.5)
+
+
+def test_maxit0_on_device(amd):
+    model = amd.expr('p + 0*x', ['p'])
+    fit = amd.nonlinear_fit(data=(np.zeros(2), [1.5, 0.8], [1.0, 0.5]), model=model, prior=([0.0], [2.0]), maxit=0)
+    np.testing.assert_allclose(fit.pmean, [0.0]); np.testing.assert_allclose(fit.psdev, [2.0])
+    assert fit.nit == 0 and fit.error is None and fit.stopping_criterion == 0
+    assert abs(fit.chi2 - (1.5 ** 2 + (0.8 / 0.5) ** 2)) < 1e-12
+    fit = amd.nonlinear_fit(data=(np.zeros(2), [1.5, 0.8], [1.0, 0.5]), model=model, p0=[0.0], maxit=0)
+    np.testing.assert_allclose(fit.pmean, [0.0])
+    assert np.all(np.isinf(fit.psdev)) and fit.logGBF is None
+
+
+def test_unusual_cases_on_device(amd):
+    model = amd.expr('p + 0*x', ['p'])
+    fit = amd.nonlinear_fit(data=(np.zeros(1), [1.5], [0.1]), model=model, prior=([2.0], [0.5]))
+    m, s = wavg([1.5, 2.0], [0.1, 0.5])
+    assert gvar_lite.fmt(fit.pmean[0], fit.psdev[0]) == gvar_lite.fmt(m, s)
+    assert abs(fit.pmean[0] - m) < 1e-9 and abs(fit.psdev[0] - s) < 1e-12      # LM stops on xtol = 1e-8
+    fit = amd.nonlinear_fit(data=(np.zeros(2), [1.5, 1.7], [0.1, 0.2]), model=model, prior=([2.0], [0.5]), tol=1e-8)
+    m, s = wavg([1.5, 1.7, 2.0], [0.1, 0.2, 0.5])
+    assert abs(fit.pmean[0] - m) < 1e-9 and abs(fit.psdev[0] - s) < 1e-12
+    assert fit.dof == 2
+
+
+def test_more_parameters_than_data(amd):
+    """P > N is legal with a prior (dof = N): 3 data rows, 10 parameters."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=3, P=10, seed=71, block=0, prior_corr=True)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    ref = gu.oracle_fit(d)
+    assert fit.dof == 3 and fit.error is None
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert abs(fit.chi2 - ref.chi2) < 1e-6 * max(1.0, ref.chi2)
+
+
+@pytest.mark.parametrize('P', [2, 126, 130, 254, 258])
+def test_parameter_counts_around_tile_edges(amd, P):
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=400, P=P, seed=72 + P, block=0, prior_corr=(P < 200))
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=d['p_true'])
+    ref = gu.oracle_fit(d, p0=d['p_true'])
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
+
+
+def test_ragged_blocks_with_gaps(amd):
+    """Blocks of sizes 3, 17, 130 and 64 separated by 1 x 1 rows, the last one ending the data."""
+    from lsqfit_amd import synth
+    N, P = 300, 12
+    d = synth.make_cosmix(N=N, P=P, seed=80, block=0, prior_corr=True)
+    rng = np.random.default_rng(81)
+    sd = np.asarray(d['yerr'])
+    blocks = []
+    for r0, B in ((5, 3), (20, 17), (60, 130), (236, 64)):
+        U = rng.uniform(0.1, 0.9, (B, 2 * B))
+        c = U @ U.T
+        dd = 1.0 / np.sqrt(np.diag(c))
+        c *= np.outer(dd, dd)
+        blocks.append((r0, c * np.outer(sd[r0:r0 + B], sd[r0:r0 + B])))
+    d['yerr'] = dict(sdev=sd, blocks=blocks)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=d['p_true'])
+    ref = gu.oracle_fit(d, p0=d['p_true'])
+    assert fit.nblocks == ref.nblocks
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
+    D = fit.dp_dinputs()
+    assert gu.relmax(D[:, :N], ofit.dp_dinputs(ref)[:, :N]) < 1e-6
+
+
+def test_bad_inputs_are_rejected(amd):
+    model = amd.expr('p + 0*x', ['p'])
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(np.zeros(2), [1.0, 2.0], [1.0, 0.0]), model=model, prior=([0.0], [1.0]))
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(np.zeros(2), [1.0, 2.0], [1.0, 1.0]), model=model, prior=([0.0], [0.0]))
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(np.zeros(2), [1.0, 2.0], [1.0, 1.0]), model=model)        # neither p0 nor prior
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(np.zeros(2), [1.0, 2.0], [1.0, 1.0]), model=model, prior=([0.0, 1.0], [1.0, 1.0]))
+    # non-finite model values surface as an error, not as a crash
+    bad = amd.expr('log(p)*x', ['p'])
+    fit = None
+    try:
+        fit = amd.nonlinear_fit(data=(np.ones(3), [1.0, 2.0, 3.0], [1.0, 1.0, 1.0]), model=bad, p0=[-1.0])
+    except RuntimeError as e:
+        assert 'finite' in str(e)
+    if fit is not None:
+        assert fit.error is not None

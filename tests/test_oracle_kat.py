@@ -390,3 +390,27 @@ def test_pdf_dchi2():
     pts = fit.pmean + np.linspace(-2, 2, 7)[:, None] * fit.psdev
     np.testing.assert_allclose(ofit.dchi2(fit, pts), [ofit.dchi2(fit, q) for q in pts], rtol=0, atol=1e-12)
     np.testing.assert_allclose(ofit.dchi2(fit, pts), np.linspace(-2, 2, 7) ** 2, atol=1e-7)
+
+
+def test_maxit0_and_unusual_cases():
+    """tests/test_lsqfit.py:405-413 (maxit=0: the prior comes back untouched) and :455-470
+    (scalar y and prior; two data points without x): closed-form weighted averages."""
+    fcn = lambda p: dual.concatenate([p[0].reshape(1)] * 2) if isinstance(p, dual.Dual) else np.full(2, p[0])
+    fit = ofit.nonlinear_fit(False, [1.5, 0.8], [1.0, 0.5], fcn, prior_mean=[0.0], prior_err=[2.0], maxit=0)
+    np.testing.assert_allclose(fit.pmean, [0.0]); np.testing.assert_allclose(fit.psdev, [2.0])
+    assert fit.nit == 0 and fit.error is None and fit.stopping_criterion == 0
+    assert abs(fit.chi2 - (1.5 ** 2 + (0.8 / 0.5) ** 2)) < 1e-12
+    fit = ofit.nonlinear_fit(False, [1.5, 0.8], [1.0, 0.5], fcn, p0=[0.0], maxit=0)
+    np.testing.assert_allclose(fit.pmean, [0.0])
+    assert np.all(np.isinf(fit.psdev)) and fit.logGBF is None
+
+    def wavg(m, s):
+        w = 1.0 / np.asarray(s, float) ** 2
+        return float(np.sum(w * m) / np.sum(w)), float(np.sum(w) ** -0.5)
+    ident = lambda p: p[:1] if isinstance(p, dual.Dual) else np.array(p[:1])
+    fit = ofit.nonlinear_fit(False, [1.5], [0.1], ident, prior_mean=[2.0], prior_err=[0.5])
+    m, s = wavg([1.5, 2.0], [0.1, 0.5])
+    assert gvar_lite.fmt(fit.pmean[0], fit.psdev[0]) == gvar_lite.fmt(m, s)
+    fit = ofit.nonlinear_fit(False, [1.5, 1.7], [0.1, 0.2], fcn, prior_mean=[2.0], prior_err=[0.5], tol=1e-8)
+    m, s = wavg([1.5, 1.7, 2.0], [0.1, 0.2, 0.5])
+    assert gvar_lite.fmt(fit.pmean[0], fit.psdev[0]) == gvar_lite.fmt(m, s)
