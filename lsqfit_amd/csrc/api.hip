@@ -68,6 +68,7 @@ struct lsqamd_fit {
   double *redbuf = nullptr;  // [packed J^T J | J^T f | chi2]
   double *red_scalar = nullptr;
   double *M = nullptr, *chol_work = nullptr, *yv = nullptr, *diag_dev = nullptr, *tvec = nullptr;
+  double *dscale = nullptr;  // the scaling matrix D, device-resident mirror of hdiag
   double *partial = nullptr, *Wl = nullptr, *cov = nullptr, *scal = nullptr;
   int32_t *info_dev = nullptr;
   int32_t *tape = nullptr;
@@ -221,6 +222,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->chol_work = cv.take<double>((int64_t)(potrf_work_bytes(P) / sizeof(double)));
   f->yv = cv.take<double>(2 * P);
   f->diag_dev = cv.take<double>(P);
+  f->dscale = cv.take<double>(P);
   f->tvec = cv.take<double>(P + 1);
   const int64_t part = f->npartial * (P + 1);
   f->partial = cv.take<double>(part > 2048 ? part : 2048);
@@ -426,15 +428,21 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
 }
 
 // (A + mu D^2) v = g  -> f->hv ; returns LSQAMD_ENOTPD when a pivot fails
-int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
+// launches only: factor (A + mu D^2 | g) and back-substitute; v lands in f->yv[P..2P).
+// diag_host == nullptr: D is the device-resident mirror (no host-to-device copy: on this platform
+// an SDMA upload followed by a dependent kernel costs ~100 us of cross-engine synchronisation)
+int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
-  int32_t info = 0;
   {
     Scope sc(f, LSQAMD_T_CHOLESKY);
-    std::memcpy(f->pin_d, diag_host, sizeof(double) * P);
-    HIPCHK(f, hipMemcpyAsync(f->diag_dev, f->pin_d, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, f->diag_dev, gvec, f->M));
+    const double *dd = f->dscale;
+    if (diag_host) {
+      std::memcpy(f->pin_d, diag_host, sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->diag_dev, f->pin_d, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      dd = f->diag_dev;
+    }
+    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M));
     HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev));
   }
   {
@@ -443,10 +451,16 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
     HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
     HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
     HIPCHK(f, hipMemcpyAsync(f->pin_s + 4, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
-    HIPCHK(f, hipStreamSynchronize(f->st));
-    std::memcpy(f->hv.data(), f->pin_v, sizeof(double) * P);
-    std::memcpy(&info, f->pin_s + 4, sizeof(int32_t));
   }
+  return 0;
+}
+
+// after the stream has been synchronised: v -> f->hv; LSQAMD_ENOTPD when a pivot failed
+int solve_damped_collect(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  int32_t info = 0;
+  std::memcpy(f->hv.data(), f->pin_v, sizeof(double) * P);
+  std::memcpy(&info, f->pin_s + 4, sizeof(int32_t));
   f->ntrial++;
   if (info != 0) {
     f->chol_fail++;
@@ -460,7 +474,16 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
   return 0;
 }
 
+// (A + mu D^2) v = g  -> f->hv ; returns LSQAMD_ENOTPD when a pivot fails
+int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
+  const int rc = solve_damped_launch(f, mu, diag_host);
+  if (rc) return rc;
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return solve_damped_collect(f);
+}
+
 void scale_init(lsqamd_fit *f) {
+  (void)launch_scale_update(f->st, f->P, f->opt.scaler, 1, f->diag_dev, f->dscale);  // diag_dev = coln^2
   for (int64_t j = 0; j < f->P; ++j) {
     if (f->opt.scaler == LSQAMD_SCALE_LEVENBERG) f->hdiag[j] = 1.0;
     else f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
@@ -468,6 +491,7 @@ void scale_init(lsqamd_fit *f) {
 }
 
 void scale_update(lsqamd_fit *f) {
+  (void)launch_scale_update(f->st, f->P, f->opt.scaler, 0, f->diag_dev, f->dscale);
   for (int64_t j = 0; j < f->P; ++j) {
     if (f->opt.scaler == LSQAMD_SCALE_MORE) f->hdiag[j] = std::fmax(f->hdiag[j], f->hcoln[j]);
     else if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT) f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
@@ -723,8 +747,25 @@ int iterate(lsqamd_fit *f) {
     double rho = -1.0, avratio = 0.0;
     bool have_step = false;
     double pred_num = 0.0;  // predicted reduction * chi2
+    bool residual_done = false;
+    double chi2_fast = 0.0;
     if (lm_family) {
-      int rc = solve_damped_dev(f, f->mu, f->hdiag.data());
+      int rc;
+      if (trs == LSQAMD_TRS_LM) {
+        // plain lm: everything up to the trial chi2 is queued without a host round trip --
+        // solve, x_trial = x - v on the device, residual there; one synchronisation collects
+        // v, the factorisation status and chi2(x_trial)
+        rc = solve_damped_launch(f, f->mu, nullptr);
+        if (rc) return rc;
+        HIPCHK(f, launch_trial_point(f->st, P, f->p_dev, f->yv + P, f->p_trial));
+        rc = eval_residual_dev(f, f->p_trial, &chi2_fast);
+        if (rc) return rc;
+        rc = solve_damped_collect(f);
+        if (rc == LSQAMD_ENOTPD) f->nfev--;  // that residual was evaluated at garbage: not a trial
+        residual_done = rc == 0;
+      } else {
+        rc = solve_damped_dev(f, f->mu, f->hdiag.data());
+      }
       if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
       if (rc == 0) {
         have_step = true;
@@ -779,11 +820,13 @@ int iterate(lsqamd_fit *f) {
         f->hdx[j] = dx[j];
         xt[j] = f->hx[j] + dx[j];
       }
-      std::memcpy(f->pin_x, xt.data(), sizeof(double) * P);
-      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
-      double chi2_t = 0.0;
-      const int rc = eval_residual_dev(f, f->p_trial, &chi2_t);
-      if (rc) return rc;
+      double chi2_t = chi2_fast;
+      if (!residual_done) {
+        std::memcpy(f->pin_x, xt.data(), sizeof(double) * P);
+        HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+        const int rc = eval_residual_dev(f, f->p_trial, &chi2_t);
+        if (rc) return rc;
+      }
       const double normf = std::sqrt(f->chi2), normf_t = std::sqrt(chi2_t);
       if (normf_t < normf) {  // NaN-safe: anything else rejects
         const double u = normf_t / normf;

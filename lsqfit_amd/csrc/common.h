@@ -150,6 +150,12 @@ hipError_t launch_prior_chi2_points(hipStream_t st, int64_t P, const double *pre
                                     const double *pmean, const double *p, int64_t m, double *Dt,
                                     double *T, int64_t ldt, double *out);
 
+// scaling matrix D on the device (scaling.c): init / update from the squared column norms
+hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, const double *coln2,
+                               double *dscale);
+// xt = x - v
+hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt);
+
 inline int64_t packed_doubles(int64_t P) {
   const int64_t T = (P + 127) / 128;
   return T * (T + 1) / 2 * 128 * 128;

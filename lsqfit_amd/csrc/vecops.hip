@@ -537,4 +537,38 @@ hipError_t launch_gemv_rows(hipStream_t st, const double *A, int64_t ld, int64_t
   return hipGetLastError();
 }
 
+// ---- device-resident pieces of the LM step (no host-to-device traffic inside a step) ------------
+// scaling.c on the device: D from the column norms sqrt(diag(J^T J)) (coln2 = their squares)
+__global__ __launch_bounds__(256) void scale_update_kernel(int64_t P, int scaler, int init,
+                                                           const double *coln2, double *dscale) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  const double c2 = coln2[j];
+  const double cn = sqrt(c2 > 0.0 ? c2 : 0.0);
+  double d;
+  if (scaler == LSQAMD_SCALE_LEVENBERG) d = init ? 1.0 : dscale[j];
+  else if (scaler == LSQAMD_SCALE_MORE) d = init ? (cn == 0.0 ? 1.0 : cn) : fmax(dscale[j], cn);
+  else d = cn == 0.0 ? 1.0 : cn;
+  dscale[j] = d;
+}
+
+hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, const double *coln2,
+                               double *dscale) {
+  hipLaunchKernelGGL(scale_update_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, P, scaler,
+                     init, coln2, dscale);
+  return hipGetLastError();
+}
+
+// x_trial = x - v
+__global__ __launch_bounds__(256) void trial_point_kernel(int64_t P, const double *x, const double *v,
+                                                          double *xt) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < P) xt[j] = x[j] - v[j];
+}
+
+hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt) {
+  hipLaunchKernelGGL(trial_point_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, P, x, v, xt);
+  return hipGetLastError();
+}
+
 }  // namespace lsqamd
