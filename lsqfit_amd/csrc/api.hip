@@ -318,7 +318,11 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
   return 0;
 }
 
-int whiten_jacobian(lsqamd_fit *f) {
+// Whitening of the block rows of the Jacobian (and of its residual column).  *fused_chunks > 0 on
+// return: the bulk GEMM also left per-tile-row partial sums of J^T f in f->slabs
+// (fused_chunks x P, to be reduced before the SYRK reuses the slabs).
+int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks) {
+  *fused_chunks = 0;
   const int nb = f->cfg.n_blocks;
   if (nb <= 0) return 0;
   Scope sc(f, LSQAMD_T_WHITEN);
@@ -333,27 +337,47 @@ int whiten_jacobian(lsqamd_fit *f) {
     g.batch = nb;
     g.x_upper_tri = f->uniform_tri;
     if (f->P % 128 == 0 && B % 128 == 0) {
-      // full-tile bulk (interior kernel) + the residual column on its own
-      g.N = f->P;
-      HIPCHK(f, launch_gemm_tn(f->st, g));
+      // full-tile bulk (interior kernel) + the residual column on its own, the column FIRST: the
+      // bulk's epilogue can then form its share of J^T f from the tile it still holds
+      const int64_t slab_doubles = (int64_t)f->splits * f->P * f->ldm;
+      bool col_done = false;
       if (B >= 1024) {
         // the residual column of a large block is a GEMV: two-stage column sum at HBM speed
         // (as a one-column GEMM it would keep B/128 workgroups busy for over a millisecond)
-        const int64_t slab_doubles = (int64_t)f->splits * f->P * f->ldm;
-        for (int b = 0; b < nb; ++b) {
-          int64_t nch = slab_doubles / B;
-          if (nch > 256) nch = 256;
-          if (nch < 1) { nch = 0; }
-          if (nch == 0) break;
-          const int64_t r0 = f->h_row0[b];
-          HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->slabs, nch, f->r + r0,
-                                      f->Jraw + r0 * f->ld + f->P, f->ld));
-          HIPCHK(f, launch_copy_strided(f->st, f->r + r0, 1, f->J + r0 * f->ld + f->P, f->ld, B, 1));
+        int64_t nch = slab_doubles / B;
+        if (nch > 256) nch = 256;
+        if (nch >= 1) {
+          for (int b = 0; b < nb; ++b) {
+            const int64_t r0 = f->h_row0[b];
+            HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->slabs, nch, f->r + r0,
+                                        f->Jraw + r0 * f->ld + f->P, f->ld));
+            HIPCHK(f, launch_copy_strided(f->st, f->r + r0, 1, f->J + r0 * f->ld + f->P, f->ld, B, 1));
+          }
+          col_done = true;
         }
-        if (slab_doubles / B >= 1) return 0;
       }
-      g.Y += f->P; g.C += f->P; g.N = 1;
+      if (!col_done) {
+        GemmTN c = g;
+        c.Y += f->P; c.C += f->P; c.N = 1;
+        HIPCHK(f, launch_gemm_tn(f->st, c));
+      }
+      g.N = f->P;
+      const int64_t chunks = (int64_t)nb * (B / 128);
+      if (f->h_row0[0] == 0 && (int64_t)nb * B == f->N && chunks * f->P <= slab_doubles) {
+        g.colsum_out = f->slabs;
+        g.colsum_ld = f->P;
+        g.colsum_rcol = f->P;
+        if (gemm_tn_fuses_colsum(g)) *fused_chunks = chunks;
+        else g.colsum_out = nullptr;
+      }
       HIPCHK(f, launch_gemm_tn(f->st, g));
+      if (*fused_chunks > 0) {
+        // J^T f = sum of the per-tile-row pieces; |f|^2 from the residual column
+        double *gvec = f->redbuf + f->npk;
+        HIPCHK(f, launch_colsum_reduce(f->st, f->slabs, *fused_chunks, f->P, gvec));
+        HIPCHK(f, launch_copy_strided(f->st, f->J + f->P, f->ld, f->r, 1, f->N, 1));
+        HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, gvec + f->P));
+      }
       return 0;
     }
     HIPCHK(f, launch_gemm_tn(f->st, g));
@@ -380,7 +404,8 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
     ModelArgs m = model_args(f, p);
     HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
   }
-  int rc = whiten_jacobian(f);
+  int64_t fused_chunks = 0;
+  int rc = whiten_jacobian(f, &fused_chunks);
   if (rc) return rc;
   {
     Scope sc(f, LSQAMD_T_SYRK);
@@ -404,7 +429,8 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
     Scope sc(f, LSQAMD_T_GRAD);
     // when splits == 1 the kernel ignored split_stride and wrote slab 0 directly
     HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf));
-    HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
+    if (fused_chunks == 0)
+      HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
     if (f->cfg.has_prior && f->adds_prior)
       HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
                                  f->prior_mean, p, f->tvec, gvec, 1));

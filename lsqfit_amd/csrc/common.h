@@ -30,7 +30,15 @@ struct GemmTN {
   int32_t n_work = 0;
   int32_t force_generic = 0;       // A/B switch: never take the direct-to-LDS interior kernel
   const int32_t *batch_active = nullptr;  // device flags[batch]: 0 = skip that batch entry
+  // fused column sums (triangular-X interior path only; ignored elsewhere -- check
+  // gemm_tn_fuses_colsum()): colsum_out[(b * tiles_m + tm) * colsum_ld + n] = sum over the 128
+  // rows of tile row tm of C[row][n] * C_b[row][colsum_rcol]   (the weights are a column of the
+  // output matrix itself, written by an earlier launch: J^T f from the whitened Jacobian)
+  double *colsum_out = nullptr;
+  int64_t colsum_ld = 0, colsum_rcol = 0;
 };
+// true when launch_gemm_tn would take the kernel that honours colsum_out for this call
+bool gemm_tn_fuses_colsum(const GemmTN &g);
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
 int64_t syrk_work_count(int64_t P, int32_t splits);
 void syrk_work_fill(int64_t P, int32_t splits, int32_t *out);
@@ -102,6 +110,9 @@ hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
                              double *out, const double *rvec = nullptr,   // rvec: weights instead of J[:, rcol]
                              int64_t rvec_stride = 1);
+// out[j] = sum over nchunks rows of partial[chunk][j] (partial row stride = ncols)
+hipError_t launch_colsum_reduce(hipStream_t st, const double *partial, int64_t nchunks, int64_t ncols,
+                                double *out);
 // y = A x (row-major, one wave per row)
 hipError_t launch_gemv_rows(hipStream_t st, const double *A, int64_t ld, int64_t rows, int64_t cols,
                             const double *x, double *y);

@@ -53,6 +53,8 @@ struct GemmDev {
   const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
   int32_t n_work;
   const int32_t *batch_active;  // optional: skip batch entries whose flag is 0
+  double *colsum_out;           // optional (XTRI interior kernel): fused column sums, see GemmTN
+  int64_t colsum_ld, colsum_rcol;
 };
 
 // Branch-free staging loads.  Out-of-range rows/columns are CLAMPED to a valid
@@ -300,6 +302,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
     yp += 4 * ystep;
   };
 
+  // weights of the fused column sums: fetched now, used in the epilogue (latency hidden by the k loop)
+  const bool fuse = XTRI && g.colsum_out != nullptr;
+  double wreg = 0.0;
+  if (fuse && tid < BM) wreg = (g.C + b * g.sc)[(m0 + tid) * g.ldc + g.colsum_rcol];
   const int fr = lane & 15, fq = lane >> 4;
   if (kb < ke) stage(0);
   __syncthreads();
@@ -331,9 +337,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
 
   const double alpha = g.alpha;
   const double beta = g.splits > 1 ? 0.0 : g.beta;
+  double *wcol = smem;             // [128] weights of this tile's rows (LDS is free after the k loop)
+  double *red = smem + 128;        // [4 waves][64] partial column sums
+  if (fuse) {
+    if (tid < BM) wcol[tid] = wreg;
+    __syncthreads();
+  }
+  double sj[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int64_t rbase = m0 + (XTRI ? (2 * i + wm) * 16 : wm * 64 + i * 16) + fq;
+    const int rloc = (XTRI ? (2 * i + wm) * 16 : wm * 64 + i * 16) + fq;
+    const int64_t rbase = m0 + rloc;
     double cv[4][4];
     if (beta != 0.0) {
 #pragma unroll
@@ -343,13 +357,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
           cv[j][r] = C[(rbase + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr];
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int r = 0; r < 4; ++r) {
+      const double w = fuse ? wcol[rloc + 4 * r] : 0.0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int j = 0; j < 4; ++j) {
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * cv[j][r];
         C[(rbase + 4 * r) * g.ldc + n0 + wn * 64 + j * 16 + fr] = v;
+        if (XTRI) sj[j] += v * w;
       }
+    }
+  }
+  if (fuse) {
+    // fused J^T f: the tile times the weight column of its rows, summed over the rows -- in-thread
+    // over (i, r) above, across the four 16-lane groups by two butterfly steps, across the two
+    // wave rows through LDS
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      sj[j] += __shfl_xor(sj[j], 16, 64);
+      sj[j] += __shfl_xor(sj[j], 32, 64);
+    }
+    if (fq == 0) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave * 64 + j * 16 + fr] = sj[j];
+    }
+    __syncthreads();
+    if (wm == 0 && fq == 0) {
+      double *out = g.colsum_out + (b * g.tiles_m + tm) * g.colsum_ld + n0 + wn * 64;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) out[j * 16 + fr] = red[wave * 64 + j * 16 + fr] + red[(wave + 2) * 64 + j * 16 + fr];
+    }
   }
   }  // pass
 }
@@ -622,6 +659,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
 
 static bool g_attr_set = false;
 
+static int64_t small_gemm_max() {
+  static const int64_t v = [] {
+    const char *e = getenv("LSQAMD_SMALL_GEMM_MAX");  // developer knob
+    return e ? (int64_t)atoll(e) : (int64_t)600;
+  }();
+  return v;
+}
+
+static bool interior_eligible(const GemmTN &a) {
+  const bool vx = !(a.ldx & 1) && !(reinterpret_cast<uintptr_t>(a.X) & 15) && !(a.sx & 1);
+  const bool vy = !(a.ldy & 1) && !(reinterpret_cast<uintptr_t>(a.Y) & 15) && !(a.sy & 1);
+  return vx && vy && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) && !a.force_generic;
+}
+
+bool gemm_tn_fuses_colsum(const GemmTN &a) {
+  // the conditions under which launch_gemm_tn reaches gemm_tn_f64_interior_kernel<true>
+  const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  const int64_t nblk128 = tiles_m * tiles_n * (a.splits < 1 ? 1 : a.splits) * (a.batch < 1 ? 1 : a.batch);
+  const bool small = !a.work_map && a.K <= 512 && nblk128 <= small_gemm_max();
+  return interior_eligible(a) && a.x_upper_tri && a.splits <= 1 && !a.work_map && !small &&
+         a.C != a.Y && a.C != a.X && a.alpha != 0.0;
+}
+
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (!g_attr_set) {
@@ -665,6 +725,9 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.work_map = a.work_map;
   g.n_work = a.n_work;
   g.batch_active = a.batch_active;
+  g.colsum_out = a.colsum_out;
+  g.colsum_ld = a.colsum_ld;
+  g.colsum_rcol = a.colsum_rcol;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
   if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
@@ -672,10 +735,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups); threshold from a
   // sweep of potrf_upper at P = 4096 (160: 2.67 ms, 600: 2.56 ms, 1000: 2.56 ms)
   const int64_t nblk128 = tiles_m * tiles_n * g.splits * (a.batch < 1 ? 1 : a.batch);
-  static const int64_t small_max = [] {
-    const char *e = getenv("LSQAMD_SMALL_GEMM_MAX");  // developer knob
-    return e ? (int64_t)atoll(e) : (int64_t)600;
-  }();
+  const int64_t small_max = small_gemm_max();
   // in-place products (C aliases an operand: the Cholesky row panel, the triangular inverse) are
   // only safe when ONE workgroup owns a whole column range of the operand, i.e. a single tile row
   const bool inplace = (a.C == a.Y) || (a.C == a.X);

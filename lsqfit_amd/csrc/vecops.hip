@@ -83,6 +83,14 @@ hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int
   return hipGetLastError();
 }
 
+// out[j] = sum_c partial[c][j]  (second stage on its own: the first may have been fused elsewhere)
+hipError_t launch_colsum_reduce(hipStream_t st, const double *partial, int64_t nchunks, int64_t ncols,
+                                double *out) {
+  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, st, partial,
+                     nchunks, ncols, out, 0);
+  return hipGetLastError();
+}
+
 // ---- |r|^2 ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_stage1(const double *r, int64_t n, double *partial) {
   __shared__ double part[4];
