@@ -138,24 +138,31 @@ hipError_t launch_sumsq(hipStream_t st, const double *r, int64_t n, double *part
 }
 
 // ---- whitening of the residual inside correlated blocks -----------------------------------
+// 64 output rows per workgroup, the sum over the block's rows split four ways across the
+// workgroup (coalesced 512-byte reads of W^T rows, four of them in flight per output row)
 __global__ __launch_bounds__(256) void block_whiten_vec_kernel(const double *wt, const int64_t *row0,
                                                                const int64_t *bsize,
                                                                const int64_t *woff,
                                                                const double *delta, double *r_out,
                                                                int64_t stride, const int32_t *active,
                                                                int64_t skip_from) {
+  __shared__ double sh[4][64];
   const int b = blockIdx.y;
   if (active && !active[blockIdx.z]) return;
   if (bsize[b] >= skip_from) return;  // large blocks go through the two-stage column-sum kernel
+  const int64_t B = bsize[b], r0 = row0[b];
+  if ((int64_t)blockIdx.x * 64 >= B) return;
   delta += (int64_t)blockIdx.z * stride;
   r_out += (int64_t)blockIdx.z * stride;
-  const int64_t B = bsize[b], r0 = row0[b];
   const double *W = wt + woff[b];
-  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (m >= B) return;
+  const int ml = threadIdx.x & 63, jg = threadIdx.x >> 6;
+  const int64_t m = (int64_t)blockIdx.x * 64 + ml;
   double a = 0.0;
-  for (int64_t j = 0; j < B; ++j) a += W[j * B + m] * delta[r0 + j];
-  r_out[r0 + m] = a;
+  if (m < B)
+    for (int64_t j = jg; j < B; j += 4) a += W[j * B + m] * delta[r0 + j];
+  sh[jg][ml] = a;
+  __syncthreads();
+  if (jg == 0 && m < B) r_out[r0 + m] = (sh[0][ml] + sh[1][ml]) + (sh[2][ml] + sh[3][ml]);
 }
 
 hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64_t *row0,
@@ -164,7 +171,7 @@ hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64
                                    int32_t batch, int64_t stride, const int32_t *batch_active,
                                    int64_t skip_from) {
   if (n_blocks <= 0) return hipSuccess;
-  dim3 grid((unsigned)((max_block + 255) / 256), (unsigned)n_blocks, (unsigned)(batch < 1 ? 1 : batch));
+  dim3 grid((unsigned)((max_block + 63) / 64), (unsigned)n_blocks, (unsigned)(batch < 1 ? 1 : batch));
   hipLaunchKernelGGL(block_whiten_vec_kernel, grid, dim3(256), 0, st, wt, row0, bsize, woff, delta,
                      r_out, stride, batch_active, skip_from);
   return hipGetLastError();
