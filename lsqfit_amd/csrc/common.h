@@ -53,6 +53,10 @@ size_t potrf_work_bytes(int64_t n);
 hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
                        double *work, int32_t *dev_info);
 // batched: matrix b at A + b*strideA, block inverses at work + b*strideW, info[b];
+// trailing update C -= P^T P (upper tiles; P = 128 x rest panel, C = mrest x rest, both multiples of
+// 128, 16-byte aligned rows) fused with the diagonal block of the next step (= tile (0, 0) of C)
+hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_t lda, int64_t mrest,
+                              int64_t rest, int nb_next, double *uinv_next, int32_t *info, int32_t k0_next);
 // diagonal block (nb <= 128) of the blocked Cholesky: A_kk -> U_kk in place, inv(U_kk) -> uinv
 // (128 x 128, row-major); one workgroup per batch entry (potf2_mfma.hip)
 hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, double *uinv, int32_t *info,

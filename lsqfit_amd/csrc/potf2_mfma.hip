@@ -275,6 +275,138 @@ __global__ __launch_bounds__(256) void potf2_mfma_kernel(double *A, int64_t lda,
   else potf2_wave<3>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
 }
 
+// ---- trailing update of step k with the diagonal block of step k + 1 riding along -------------
+// The diagonal kernel needs ONE tile of the trailing update (the next diagonal tile) and occupies
+// one CU; the workgroup that computes that tile goes straight on to factor it while the other 255
+// CUs finish the update: the pivot chain leaves the critical path and a kernel boundary per step
+// goes with it.  (The same overlap through a second stream and events was measured and is
+// slower than no overlap at all: cross-stream waits cost more than the diagonal kernel.)
+// Tile workgroups: the direct-to-LDS 128 x 128 x 16 pipeline of gemm_tn_f64_interior_kernel,
+// specialised to C -= P[:, m]^T P[:, n] with P the 128-row panel (K = 128), upper tiles only.
+struct TrailArgs {
+  const double *P;   // panel: row block k, starting at column k0 + nb   (128 x rest, lda)
+  double *C;         // A[(k0 + nb).., (k0 + nb)..]
+  int64_t lda;
+  int32_t tiles_m, tiles_n;   // mrest / 128, rest / 128
+};
+
+constexpr int TBK = 16, TLD = 128 + 16, TSTAGE = 2 * TBK * TLD;
+constexpr size_t TRAIL_LDS_BYTES = 2 * TSTAGE * sizeof(double);
+
+__device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, double *smem, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)tm * 128, n0 = (int64_t)tn * 128;
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const double *xp = t.P + (int64_t)wave * t.lda + m0 + 2 * lane;
+  const double *yp = t.P + (int64_t)wave * t.lda + n0 + 2 * lane;
+  const int64_t step4 = 4 * t.lda;
+  auto stage = [&](int buf) {
+    double *Xs = smem + buf * TSTAGE + wave * TLD;
+    double *Ys = Xs + TBK * TLD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * step4), (lds_void *)(Xs + 4 * i * TLD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void *)(yp + i * step4), (lds_void *)(Ys + 4 * i * TLD), 16, 0, 0);
+    }
+    xp += 4 * step4;
+    yp += 4 * step4;
+  };
+  const int fr = lane & 15, fq = lane >> 4;
+  stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int k0 = 0; k0 < 128; k0 += TBK) {
+    if (k0 + TBK < 128) stage(cur ^ 1);
+    const double *Xs = smem + cur * TSTAGE;
+    const double *Ys = Xs + TBK * TLD;
+#pragma unroll
+    for (int kk = 0; kk < TBK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * TLD + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * TLD + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = mfma4(a[i], bb[j], acc[i][j]);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    double cv[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        cv[j][r] = t.C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * t.lda + n0 + wn * 64 + j * 16 + fr];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        t.C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * t.lda + n0 + wn * 64 + j * 16 + fr] = cv[j][r] - acc[i][j][r];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void trail_potf2_kernel(TrailArgs t, double *Adiag, int nb, double *uinv,
+                                                             int32_t *info, int32_t k0n) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ double mop[64];
+  __shared__ double slabA[8 * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  // workgroup 0: tile (0, 0) of the update -- the next diagonal block -- and then its factorisation,
+  // back to back in the same workgroup (no hand-over between workgroups, nothing to wait for);
+  // dispatched first, it works while the other CUs do the remaining tiles.  Its waves run at raised
+  // priority: the tile workgroup sharing the CU fills the stalls of the pivot chain instead of
+  // competing with it.
+  if (blockIdx.x > 0) {
+    const int bid = (int)blockIdx.x;   // tile (0, 0) belongs to workgroup 0
+    const int tm = bid / t.tiles_n, tn = bid % t.tiles_n;
+    if (tn < tm) return;  // upper tiles only
+    trail_tile(t, tm, tn, smem, tid);
+    return;
+  }
+  __builtin_amdgcn_s_setprio(3);
+  trail_tile(t, 0, 0, smem, tid);
+  __syncthreads();   // the tile is re-read below in a different thread layout
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == 0) potf2_wave<0>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
+  else if (wave == 1) potf2_wave<1>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
+  else if (wave == 2) potf2_wave<2>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
+  else potf2_wave<3>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
+}
+
+static bool g_trail_attr = false;
+
+// trailing update of the step whose panel is P (128 x rest), fused with the diagonal block of the
+// next step.  Requires mrest and rest multiples of 128 and 16-byte aligned rows.
+hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_t lda, int64_t mrest,
+                              int64_t rest, int nb_next, double *uinv_next, int32_t *info, int32_t k0_next) {
+  if (!g_trail_attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trail_potf2_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRAIL_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    g_trail_attr = true;
+  }
+  TrailArgs t;
+  t.P = P; t.C = C; t.lda = lda;
+  t.tiles_m = (int32_t)(mrest / 128);
+  t.tiles_n = (int32_t)(rest / 128);
+  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)(t.tiles_m * t.tiles_n)), dim3(256), TRAIL_LDS_BYTES,
+                     st, t, C, nb_next, uinv_next, info, k0_next);
+  return hipGetLastError();
+}
+
 hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, double *uinv, int32_t *info,
                              int32_t k0, int32_t batch, int64_t strideA, int64_t strideW,
                              const int32_t *active) {
