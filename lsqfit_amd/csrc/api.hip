@@ -106,6 +106,16 @@ struct lsqamd_fit {
   // timing
   bool timing = false;
   TimerSlot timers[LSQAMD_T_COUNT];
+
+  ~lsqamd_fit() {  // every exit path (including the failure returns of lsqamd_create) ends here
+    for (auto &t : timers)
+      for (auto &pr : t.pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+      }
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    if (pin) (void)hipHostFree(pin);
+  }
 };
 
 namespace {
@@ -1055,8 +1065,6 @@ int lsqamd_destroy(lsqamd_fit *fit) {
   if (!fit) return 0;
   (void)hipStreamSynchronize(fit->st);
   resolve_timers(fit);
-  for (hipEvent_t e : fit->event_pool) (void)hipEventDestroy(e);
-  if (fit->pin) (void)hipHostFree(fit->pin);
   delete fit;
   return 0;
 }
