@@ -131,9 +131,17 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    dev_index = local_rank % ndev            # one process per GPU on a real node; wraps on smaller boxes
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        # "nccl" IS RCCL on ROCm.  LSQAMD_DIST_BACKEND=gloo lets the N > 1 code path be smoke-tested on
+        # a 1-GPU box (RCCL refuses two ranks on one device); it is never the measured configuration.
+        backend = os.environ.get('LSQAMD_DIST_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', dev_index))
+        else:
+            dist.init_process_group(backend)
     import lsqfit_amd
     from lsqfit_amd import _lib, synth
     from lsqfit_amd.dist import sharded_problem

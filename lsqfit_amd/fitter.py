@@ -159,7 +159,13 @@ class DeviceProblem:
     def view(self, dev_ptr, count):
         """float64 torch view of a region of the workspace (what the reduce hook sums)."""
         from .dist import WorkspaceView
-        return WorkspaceView(self.workspace)(dev_ptr, count)
+        # the region is inside the handle's workspace, or inside a scratch tensor a running call
+        # (chi2_points) handed to the library
+        for t in [self.workspace] + list(getattr(self, '_aux_tensors', [])):
+            base = t.data_ptr()
+            if base <= int(dev_ptr) and int(dev_ptr) + 8 * int(count) <= base + t.numel():
+                return WorkspaceView(t)(dev_ptr, count)
+        raise ValueError('pointer outside the workspace')
 
     def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', avmax=0.75):
         xtol, gtol, ftol = normalize_tol(tol)
@@ -256,8 +262,12 @@ class DeviceProblem:
         nbytes = min(self.lib.lsqamd_chi2_points_work_bytes(self.h, m),
                      max(int(max_scratch_bytes), self.lib.lsqamd_chi2_points_work_bytes(self.h, 1)))
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        rc = self.lib.lsqamd_chi2_points(self.h, _lib.dptr(ps), m, C.c_void_p(scratch.data_ptr()), nbytes,
-                                         _lib.dptr(out))
+        self._aux_tensors = [scratch]         # the per-point sums are all-reduced in place in there
+        try:
+            rc = self.lib.lsqamd_chi2_points(self.h, _lib.dptr(ps), m, C.c_void_p(scratch.data_ptr()), nbytes,
+                                             _lib.dptr(out))
+        finally:
+            self._aux_tensors = []
         self._raise_reduce()
         _check(self.lib, self.h, rc, 'chi2_points')
         return out
