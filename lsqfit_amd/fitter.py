@@ -161,10 +161,17 @@ class DeviceProblem:
         from .dist import WorkspaceView
         # the region is inside the handle's workspace, or inside a scratch tensor a running call
         # (chi2_points) handed to the library
+        cache = self.__dict__.setdefault('_view_cache', {})
+        hit = cache.get((int(dev_ptr), int(count)))      # the same two regions recur every LM step
+        if hit is not None:
+            return hit
         for t in [self.workspace] + list(getattr(self, '_aux_tensors', [])):
             base = t.data_ptr()
             if base <= int(dev_ptr) and int(dev_ptr) + 8 * int(count) <= base + t.numel():
-                return WorkspaceView(t)(dev_ptr, count)
+                v = WorkspaceView(t)(dev_ptr, count)
+                if t is self.workspace and len(cache) < 8:
+                    cache[(int(dev_ptr), int(count))] = v
+                return v
         raise ValueError('pointer outside the workspace')
 
     def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', avmax=0.75):
