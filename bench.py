@@ -241,7 +241,7 @@ def main():
                        'setup_s': round(t_setup, 3), 'chi2_dof_last': s.chi2 / max(1, wh.nchiv - P)},
             'phases_ms_per_call': {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()},
             'phases_calls': {k: v[1] for k, v in tm.items()},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_tn_f64_interior_kernel (J^T J)', 'achieved': ach,
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm_tn_f64_interior_kernel<false, true> (J^T J; the name in profiles/*kernel_stats*.csv)', 'achieved': ach,
                          'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic,
                          'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,

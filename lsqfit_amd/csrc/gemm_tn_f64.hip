@@ -235,14 +235,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
 // k-steps that lie entirely below its rows -- X is zero there.  Interleaving matters: with
 // contiguous 64-row halves the lower half would still do 81 % of the k-steps of a diagonal tile
 // while the upper half idles; interleaved, the busier wave row does 62 %.
-template <bool XTRI>
+// WORKMAP: the split-K J^T J launch (XCD-aware work list).  A separate instantiation so that it
+// shows up under its own name in kernel traces (the Cholesky's trailing updates use <false, false>).
+template <bool XTRI, bool WORKMAP>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn, split;
-  if (g.work_map) {
+  if (WORKMAP) {
     const int nw = g.n_work, bid = blockIdx.x;
     const int xcd = bid & 7, q = nw >> 3, r = nw & 7;
     const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -692,10 +694,13 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     g_attr_set = true;
@@ -731,7 +736,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
   if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
-                        !a.force_generic;
+                        !a.force_generic && !(a.x_upper_tri && a.work_map);  // no <XTRI, WORKMAP> instantiation
   // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups); threshold from a
   // sweep of potrf_upper at P = 4096 (160: 2.67 ms, 600: 2.56 ms, 1000: 2.56 ms)
   const int64_t nblk128 = tiles_m * tiles_n * g.splits * (a.batch < 1 ? 1 : a.batch);
@@ -766,10 +771,12 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
       g.pair_rows = 1;
       grid.x = (unsigned)(((tiles_m + 1) / 2) * tiles_n);
     }
-    hipLaunchKernelGGL(gemm_tn_f64_interior_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<true, false>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   }
+  else if (interior && a.work_map)
+    hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (interior)
-    hipLaunchKernelGGL(gemm_tn_f64_interior_kernel<false>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
+    hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, false>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (g.vec_x && g.vec_y)
     hipLaunchKernelGGL(gemm_tn_f64_kernel<true>, grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else
