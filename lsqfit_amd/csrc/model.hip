@@ -93,6 +93,30 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
     const double w = blk ? 1.0 : m.wdiag[row];
     double *dst = blk ? m.out_raw : m.out_w;
     double f = 0.0;
+    if (JAC && !(K & 1)) {
+      // two terms per lane: the two half-rows of J go out as 16-byte stores (1 KiB per wave instruction)
+      typedef double v2d __attribute__((ext_vector_type(2)));
+      for (int64_t k = 2 * lane; k < K; k += 128) {
+        double t[2], dq[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const double a = pp[k + u], q = pp[K + k + u];
+          if (MODEL == LSQAMD_MODEL_COSMIX) {
+            double s, c;
+            sincos_moderate(q * x, &s, &c);
+            t[u] = c;
+            dq[u] = -a * x * s;
+          } else {
+            const double e = exp(-q * x);
+            t[u] = e;
+            dq[u] = -a * x * e;
+          }
+          f += a * t[u];
+        }
+        *reinterpret_cast<v2d *>(dst + row * m.ld + k) = (v2d){w * t[0], w * t[1]};
+        *reinterpret_cast<v2d *>(dst + row * m.ld + K + k) = (v2d){w * dq[0], w * dq[1]};
+      }
+    } else {
     for (int64_t k = lane; k < K; k += 64) {
       const double a = pp[k], q = pp[K + k];
       double term, dq;
@@ -111,6 +135,7 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
         dst[row * m.ld + k] = w * term;
         dst[row * m.ld + K + k] = w * dq;
       }
+    }
     }
     f = wave_sum_all(f);
     if (lane == 0) {
