@@ -19,6 +19,7 @@
 // Fits that have finished are masked out of every kernel through `active[b]`.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -496,6 +497,10 @@ size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
     if (s > maxs) s = maxs;
     if (s > 8) s = 8;
     if (s < 1) s = 1;
+    if (const char *e = getenv("LSQAMD_BATCH_SPLITS")) {  // developer knob
+      const int v = atoi(e);
+      if (v >= 1 && v <= 16) s = v;
+    }
     f->splits = (int32_t)s;
   }
   f->nparts = 64;
