@@ -85,7 +85,8 @@ enum {
   LSQAMD_OP_COS = 12, LSQAMD_OP_ATAN = 13, LSQAMD_OP_SQRT = 14,
   LSQAMD_OP_POWI = 15  /* a ** (int)arg */
 };
-#define LSQAMD_TAPE_MAX_PARAM 16
+#define LSQAMD_TAPE_MAX_PARAM 4096 /* parameters of a tape model */
+#define LSQAMD_TAPE_CHUNK 16       /* ... differentiated 16 at a time: ceil(P/16) passes over the tape per row */
 #define LSQAMD_TAPE_MAX_STACK 16
 
 typedef struct lsqamd_fit lsqamd_fit; /* opaque handle (replaces gsl_multifit_nlinear_workspace, _gsl.pyx:672) */

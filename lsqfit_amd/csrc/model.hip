@@ -15,7 +15,7 @@
 // afterwards by the TN GEMM (X = W_b^T).
 //
 // Tape model: one lane per data row runs an RPN program over (x_i, p) with dual
-// numbers of width P <= 16 -- the NIST StRD / examples-sized problems.
+// numbers, 16 parameters per pass -- any model expressible as a formula in x and p.
 #include "common.h"
 
 namespace lsqamd {
@@ -169,10 +169,12 @@ __global__ __launch_bounds__(256) void identity_model_kernel(ModelDev m) {
   }
 }
 
-// RPN tape with forward-mode duals; one lane per row.
+// RPN tape with forward-mode duals; one lane per row.  Derivatives are carried for
+// LSQAMD_TAPE_CHUNK parameters at a time: a model with P parameters costs ceil(P / 16) passes over
+// the tape per row (values are recomputed in every pass; the residual needs a single one).
 template <bool JAC>
 __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
-  constexpr int MP = LSQAMD_TAPE_MAX_PARAM, MS = LSQAMD_TAPE_MAX_STACK;
+  constexpr int MP = LSQAMD_TAPE_CHUNK, MS = LSQAMD_TAPE_MAX_STACK;
   const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (row >= m.n_data) return;
   if (m.batch_active && !m.batch_active[blockIdx.y]) return;
@@ -181,84 +183,88 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
   m.out_w += (int64_t)blockIdx.y * m.out_stride;
   if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const int P = (int)m.n_param;
-  double sv[MS];
-  double sd[JAC ? MS : 1][JAC ? MP : 1];
-  int sp = 0;
-  for (int t = 0; t < m.n_tape; ++t) {
-    const int32_t ins = m.tape[t];
-    const int op = ins & 0xff, arg = ins >> 8;
-    switch (op) {
-      case LSQAMD_OP_CONST:
-        sv[sp] = m.consts[arg];
-        if (JAC) for (int j = 0; j < P; ++j) sd[sp][j] = 0.0;
-        ++sp;
-        break;
-      case LSQAMD_OP_X:
-        sv[sp] = m.x[row * m.n_x + arg];
-        if (JAC) for (int j = 0; j < P; ++j) sd[sp][j] = 0.0;
-        ++sp;
-        break;
-      case LSQAMD_OP_P:
-        sv[sp] = m.p[arg];
-        if (JAC) for (int j = 0; j < P; ++j) sd[sp][j] = (j == arg) ? 1.0 : 0.0;
-        ++sp;
-        break;
-      case LSQAMD_OP_ADD:
-      case LSQAMD_OP_SUB:
-      case LSQAMD_OP_MUL:
-      case LSQAMD_OP_DIV:
-      case LSQAMD_OP_POW: {
-        const double b = sv[sp - 1], a = sv[sp - 2];
-        double v, da, db;  // d/da, d/db
-        if (op == LSQAMD_OP_ADD) { v = a + b; da = 1.0; db = 1.0; }
-        else if (op == LSQAMD_OP_SUB) { v = a - b; da = 1.0; db = -1.0; }
-        else if (op == LSQAMD_OP_MUL) { v = a * b; da = b; db = a; }
-        else if (op == LSQAMD_OP_DIV) { v = a / b; da = 1.0 / b; db = -v / b; }
-        else {
-          v = pow(a, b);
-          da = b * pow(a, b - 1.0);
-          db = (a > 0.0) ? v * log(a) : 0.0;
-        }
-        if (JAC) for (int j = 0; j < P; ++j) sd[sp - 2][j] = da * sd[sp - 2][j] + db * sd[sp - 1][j];
-        sv[sp - 2] = v;
-        --sp;
-        break;
-      }
-      default: {
-        const double a = sv[sp - 1];
-        double v, da;
-        switch (op) {
-          case LSQAMD_OP_NEG: v = -a; da = -1.0; break;
-          case LSQAMD_OP_EXP: v = exp(a); da = v; break;
-          case LSQAMD_OP_LOG: v = log(a); da = 1.0 / a; break;
-          case LSQAMD_OP_SIN: v = sin(a); da = cos(a); break;
-          case LSQAMD_OP_COS: v = cos(a); da = -sin(a); break;
-          case LSQAMD_OP_ATAN: v = atan(a); da = 1.0 / (1.0 + a * a); break;
-          case LSQAMD_OP_SQRT: v = sqrt(a); da = 0.5 / v; break;
-          case LSQAMD_OP_POWI: {
-            const int n = arg;  // sign-extended by the arithmetic shift
-            v = pow(a, (double)n);
-            da = (n == 0) ? 0.0 : n * pow(a, (double)(n - 1));
-            break;
-          }
-          default: v = a; da = 1.0; break;
-        }
-        if (JAC) for (int j = 0; j < P; ++j) sd[sp - 1][j] *= da;
-        sv[sp - 1] = v;
-        break;
-      }
-    }
-  }
   const bool blk = m.in_block && m.in_block[row];
   const double w = blk ? 1.0 : m.wdiag[row];
   double *dst = blk ? m.out_raw : m.out_w;
-  const double delta = sv[0] - m.ymean[row];
-  if (JAC) {
-    for (int j = 0; j < P; ++j) dst[row * m.ld + j] = w * sd[0][j];
-    dst[row * m.ld + P] = w * delta;
-  } else {
-    dst[row] = w * delta;
+  double sv[MS];
+  double sd[JAC ? MS : 1][JAC ? MP : 1];
+  const int npass = JAC ? (P + MP - 1) / MP : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+    const int c0 = pass * MP;                       // this pass differentiates p[c0 .. c0 + MP)
+    const int nc = JAC ? (P - c0 < MP ? P - c0 : MP) : 0;
+    int sp = 0;
+    for (int t = 0; t < m.n_tape; ++t) {
+      const int32_t ins = m.tape[t];
+      const int op = ins & 0xff, arg = ins >> 8;
+      switch (op) {
+        case LSQAMD_OP_CONST:
+          sv[sp] = m.consts[arg];
+          if (JAC) for (int j = 0; j < MP; ++j) sd[sp][j] = 0.0;
+          ++sp;
+          break;
+        case LSQAMD_OP_X:
+          sv[sp] = m.x[row * m.n_x + arg];
+          if (JAC) for (int j = 0; j < MP; ++j) sd[sp][j] = 0.0;
+          ++sp;
+          break;
+        case LSQAMD_OP_P:
+          sv[sp] = m.p[arg];
+          if (JAC) for (int j = 0; j < MP; ++j) sd[sp][j] = (c0 + j == arg) ? 1.0 : 0.0;
+          ++sp;
+          break;
+        case LSQAMD_OP_ADD:
+        case LSQAMD_OP_SUB:
+        case LSQAMD_OP_MUL:
+        case LSQAMD_OP_DIV:
+        case LSQAMD_OP_POW: {
+          const double b = sv[sp - 1], a = sv[sp - 2];
+          double v, da, db;  // d/da, d/db
+          if (op == LSQAMD_OP_ADD) { v = a + b; da = 1.0; db = 1.0; }
+          else if (op == LSQAMD_OP_SUB) { v = a - b; da = 1.0; db = -1.0; }
+          else if (op == LSQAMD_OP_MUL) { v = a * b; da = b; db = a; }
+          else if (op == LSQAMD_OP_DIV) { v = a / b; da = 1.0 / b; db = -v / b; }
+          else {
+            v = pow(a, b);
+            da = b * pow(a, b - 1.0);
+            db = (a > 0.0) ? v * log(a) : 0.0;
+          }
+          if (JAC) for (int j = 0; j < MP; ++j) sd[sp - 2][j] = da * sd[sp - 2][j] + db * sd[sp - 1][j];
+          sv[sp - 2] = v;
+          --sp;
+          break;
+        }
+        default: {
+          const double a = sv[sp - 1];
+          double v, da;
+          switch (op) {
+            case LSQAMD_OP_NEG: v = -a; da = -1.0; break;
+            case LSQAMD_OP_EXP: v = exp(a); da = v; break;
+            case LSQAMD_OP_LOG: v = log(a); da = 1.0 / a; break;
+            case LSQAMD_OP_SIN: v = sin(a); da = cos(a); break;
+            case LSQAMD_OP_COS: v = cos(a); da = -sin(a); break;
+            case LSQAMD_OP_ATAN: v = atan(a); da = 1.0 / (1.0 + a * a); break;
+            case LSQAMD_OP_SQRT: v = sqrt(a); da = 0.5 / v; break;
+            case LSQAMD_OP_POWI: {
+              const int n = arg;  // sign-extended by the arithmetic shift
+              v = pow(a, (double)n);
+              da = (n == 0) ? 0.0 : n * pow(a, (double)(n - 1));
+              break;
+            }
+            default: v = a; da = 1.0; break;
+          }
+          if (JAC) for (int j = 0; j < MP; ++j) sd[sp - 1][j] *= da;
+          sv[sp - 1] = v;
+          break;
+        }
+      }
+    }
+    if (JAC) {
+      for (int j = 0; j < nc; ++j) dst[row * m.ld + c0 + j] = w * sd[0][j];
+    }
   }
+  const double delta = sv[0] - m.ymean[row];
+  if (JAC) dst[row * m.ld + P] = w * delta;
+  else dst[row] = w * delta;
 }
 
 template <bool JAC>

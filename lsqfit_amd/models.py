@@ -12,7 +12,7 @@ import ast
 import numpy as np
 
 MODEL_COSMIX, MODEL_MULTIEXP, MODEL_TAPE, MODEL_IDENTITY = 1, 2, 3, 4
-TAPE_MAX_PARAM, TAPE_MAX_STACK = 16, 16
+TAPE_MAX_PARAM, TAPE_MAX_STACK = 4096, 16
 
 OP = dict(CONST=0, X=1, P=2, ADD=3, SUB=4, MUL=5, DIV=6, POW=7, NEG=8, EXP=9, LOG=10,
           SIN=11, COS=12, ATAN=13, SQRT=14, POWI=15)

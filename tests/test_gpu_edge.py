@@ -114,3 +114,36 @@ def test_bad_inputs_are_rejected(amd):
         assert 'finite' in str(e)
     if fit is not None:
         assert fit.error is not None
+
+
+def test_expression_model_with_many_parameters(amd):
+    """Expression-tape models are differentiated 16 parameters per pass: a 20-term multi-exponential
+    written out as an expression (P = 40, three passes) must reproduce the built-in multiexp model
+    (same J^T J, J^T f to rounding) and the oracle fit."""
+    K = 20
+    rng = np.random.default_rng(90)
+    x = np.linspace(0.1, 3.0, 150)
+    a = rng.uniform(0.5, 1.5, K)
+    e = 0.3 + 0.25 * np.arange(K)
+    p_true = np.concatenate([a, e])
+    y = gu.multiexp_fcn(x, p_true)
+    ysd = 1e-3 * np.abs(y)
+    ymean = y + ysd * rng.standard_normal(x.size)
+    names = ['a%d' % k for k in range(K)] + ['e%d' % k for k in range(K)]
+    text = ' + '.join('a%d*exp(-e%d*x)' % (k, k) for k in range(K))
+    tape = amd.expr(text, names)
+    pm, ps = p_true * (1 + 0.01 * rng.standard_normal(2 * K)), 0.05 * p_true
+    wh = amd.Whitening(ymean, ysd, pm, ps)
+    pa = amd.DeviceProblem(tape, x, wh)
+    pb = amd.DeviceProblem(amd.multiexp(K), x, wh)
+    ca, cb = pa.normal(pm), pb.normal(pm)
+    assert abs(ca / cb - 1) < 1e-12
+    assert gu.relmax(pa.get_jtj(), pb.get_jtj()) < 1e-12
+    assert gu.relmax(pa.get_grad(), pb.get_grad()) < 1e-11
+    fit = amd.nonlinear_fit(data=(x, ymean, ysd), model=tape, prior=(pm, ps), problem=pa)
+    ref = ofit.nonlinear_fit(x, ymean, ysd, gu.multiexp_fcn, prior_mean=pm, prior_err=ps, jac=gu.multiexp_jac,
+                             solver='cholesky')
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
+    pa.close(); pb.close()
