@@ -279,7 +279,9 @@ int lsqamdb_set_blocks(lsqamdb_fits *fits, int32_t n_blocks, const int64_t *row0
  * covariance and replace the means (simulated_fit_iter / bootstrapped_fit_iter,
  * src/lsqfit/__init__.py:1391-1469,1548-1642) */
 int lsqamdb_set_data_means(lsqamdb_fits *fits, const double *ymean);
-int lsqamdb_set_priors(lsqamdb_fits *fits, const double *mean, const double *prec);     /* [B*P] each */
+/* mean[B*P]; prec[B*P] = 1/sdev^2 per fit, or -- cfg.prior_dense -- ONE dense P x P precision shared by
+ * all fits (simulated / bootstrap copies differ in their prior means, not in the prior covariance) */
+int lsqamdb_set_priors(lsqamdb_fits *fits, const double *mean, const double *prec);
 int lsqamdb_set_options(lsqamdb_fits *fits, const lsqamd_options *opt);
 /* p0[B*P]; summaries[B] or NULL (t_setup_ms carries the number of graph-replayed rounds) */
 int lsqamdb_run(lsqamdb_fits *fits, const double *p0, lsqamd_summary *summaries, int32_t use_graph);

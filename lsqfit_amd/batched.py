@@ -21,7 +21,10 @@ from .models import MODEL_IDENTITY, MODEL_TAPE
 
 class BatchedFits:
     def __init__(self, model, x, ymean, ysdev, prior_mean, prior_sdev, device=None, svdcut=1e-12,
-                 whitening=None, n_fits=None):
+                 whitening=None, n_fits=None, prior_prec=None, prior_logdet=None):
+        """``prior_sdev``: per-fit diagonal priors ([n_fits, P] or broadcastable).  Alternatively
+        ``prior_prec`` (P x P) + ``prior_logdet``: ONE correlated prior covariance shared by all
+        fits (its inverse and log-determinant, e.g. from :class:`Whitening`), per-fit means only."""
         import torch
         from .whiten import Whitening
         if not torch.cuda.is_available():
@@ -39,13 +42,22 @@ class BatchedFits:
         self.wh = wh = whitening
         row0, size, modes, tri, wt = wh.block_arrays()
         self.has_prior = prior_mean is not None
+        self.prior_dense = prior_prec is not None
         if self.has_prior:
             pm = np.ascontiguousarray(prior_mean, np.float64)
-            ps = np.ascontiguousarray(np.broadcast_to(np.asarray(prior_sdev, np.float64), pm.shape))
             if pm.ndim != 2 or pm.shape[1] != model.n_param:
                 raise ValueError('prior_mean must be [n_fits, n_param]')
-            if np.any(ps <= 0):
-                raise ValueError('some priors have zero standard deviations')
+            if self.prior_dense:
+                ps = None
+                self.prior_prec = np.ascontiguousarray(prior_prec, np.float64)
+                if self.prior_prec.shape != (model.n_param, model.n_param):
+                    raise ValueError('prior_prec must be [n_param, n_param]')
+                self.prior_logdet = float(prior_logdet) if prior_logdet is not None else \
+                    -float(np.linalg.slogdet(self.prior_prec)[1])
+            else:
+                ps = np.ascontiguousarray(np.broadcast_to(np.asarray(prior_sdev, np.float64), pm.shape))
+                if np.any(ps <= 0):
+                    raise ValueError('some priors have zero standard deviations')
             n_fits = pm.shape[0]
         else:
             pm = ps = None
@@ -58,7 +70,7 @@ class BatchedFits:
             raise ValueError('ymean must be [N] or [n_fits, N]')
         self.prior_mean, self.prior_sdev = pm, ps
         cfg = _lib.Config(abi_version=_lib.ABI_VERSION, model=model.kind, n_data=self.N, n_param=self.P,
-                          n_x=model.n_x, has_prior=int(self.has_prior), prior_dense=0, n_blocks=len(size),
+                          n_x=model.n_x, has_prior=int(self.has_prior), prior_dense=int(self.prior_dense), n_blocks=len(size),
                           max_block=int(size.max()) if len(size) else 0, sum_block_sq=int(np.sum(size * size)),
                           want_jacobian_out=0, n_batch=self.B)
         t0 = time.perf_counter()
@@ -92,7 +104,9 @@ class BatchedFits:
                 _lib.dptr(wt)), 'set_blocks')
         if ymeans is not None:
             self.set_data_means(ymeans)
-        if self.has_prior:
+        if self.has_prior and self.prior_dense:
+            self.set_prior_means(pm)
+        elif self.has_prior:
             self.set_priors(pm, ps)
         self.t_setup = time.perf_counter() - t0
 
@@ -109,7 +123,15 @@ class BatchedFits:
             raise ValueError('ymeans must be [n_fits, N]')
         self._check(self.lib.lsqamdb_set_data_means(self.h, _lib.dptr(ymeans)), 'set_data_means')
 
+    def set_prior_means(self, mean):
+        """Dense shared prior: new per-fit means (the shared precision is re-sent with them)."""
+        mean = np.ascontiguousarray(mean, np.float64)
+        self.prior_mean = mean
+        self._check(self.lib.lsqamdb_set_priors(self.h, _lib.dptr(mean), _lib.dptr(self.prior_prec)), 'set_priors')
+
     def set_priors(self, mean, sdev):
+        if self.prior_dense:
+            raise ValueError('this batch has a dense shared prior: use set_prior_means')
         mean = np.ascontiguousarray(mean, np.float64)
         sdev = np.ascontiguousarray(np.broadcast_to(np.asarray(sdev, np.float64), mean.shape))
         prec = np.ascontiguousarray(1.0 / sdev ** 2)
@@ -123,7 +145,9 @@ class BatchedFits:
         B, P = self.B, self.P
         if p0 is None and not self.has_prior:
             raise ValueError('neither p0 nor prior is specified')
-        if p0 is None:
+        if p0 is None and self.prior_dense:
+            p0 = self.prior_mean
+        elif p0 is None:
             p0 = np.where(self.prior_mean != 0.0, self.prior_mean, self.prior_mean + 0.1 * self.prior_sdev)
         p0 = np.ascontiguousarray(np.broadcast_to(np.asarray(p0, np.float64), (B, P)))
         xtol, gtol, ftol = normalize_tol(tol)
@@ -151,7 +175,8 @@ class BatchedFits:
             self._check(self.lib.lsqamdb_covariance(self.h, _lib.dptr(ld), B), 'covariance')
             out['logdet_jtj'] = ld
             if self.has_prior:
-                logdet_c = self.wh.logdet_data + 2.0 * np.sum(np.log(self.prior_sdev), axis=1)
+                logdet_c = self.wh.logdet_data + (self.prior_logdet if self.prior_dense else
+                                                  2.0 * np.sum(np.log(self.prior_sdev), axis=1))
                 out['logGBF'] = 0.5 * (-ld - logdet_c - out['chi2'] - dof * np.log(2. * np.pi))
             else:
                 out['logGBF'] = None              # src/lsqfit/__init__.py:711-712

@@ -146,6 +146,58 @@ __global__ __launch_bounds__(256) void b_prior_kernel(int64_t P, int64_t T, cons
   if (threadIdx.x == 0) g[P] += c2;
 }
 
+// ---- dense prior precision shared by the fits (per-fit means): A_b += Lambda, g_b += Lambda d_b,
+// chi2_b += d_b^T Lambda d_b with d_b = x_b - pbar_b --------------------------------------------------
+__global__ __launch_bounds__(256) void b_prior_matrix_dense_kernel(double *apk, int64_t apk_stride, int64_t P,
+                                                                   int64_t T, const double *prec,
+                                                                   const int32_t *active) {
+  const int b = blockIdx.z;
+  if (!active[b]) return;
+  int64_t t = blockIdx.x, tm = 0;
+  while (t >= T - tm) { t -= T - tm; ++tm; }
+  const int64_t tn = tm + t;
+  double *dst = apk + b * apk_stride + (int64_t)blockIdx.x * TBK * TBK;
+  const int c = threadIdx.x & 127;
+  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
+    const int r = blockIdx.y * 8 + rr;
+    const int64_t i = tm * TBK + r, j = tn * TBK + c;
+    if (i < P && j < P) dst[r * TBK + c] += prec[i * P + j];
+  }
+}
+
+// tvec[b][j] = sum_k Lambda[j][k] (x_b[k] - pbar_b[k]); one wave per row j
+__global__ __launch_bounds__(256) void b_prior_vec_dense_kernel(int64_t P, const double *prec,
+                                                                const double *pmean, const double *x,
+                                                                double *tvec, const int32_t *active) {
+  const int b = blockIdx.y;
+  if (!active[b]) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= P) return;
+  double a = 0.0;
+  for (int64_t k = lane; k < P; k += 64) a += prec[j * P + k] * (x[b * P + k] - pmean[b * P + k]);
+  a = bsum(a);
+  if (lane == 0) tvec[b * P + j] = a;
+}
+
+// g_b += t_b ; g_b[P] += d_b . t_b ; one workgroup per fit
+__global__ __launch_bounds__(256) void b_prior_apply_kernel(int64_t P, const double *pmean, const double *x,
+                                                            const double *tvec, double *gvec, int64_t g_stride,
+                                                            const int32_t *active) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  if (!active[b]) return;
+  double *g = gvec + b * g_stride;
+  double c2 = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double t = tvec[b * P + j];
+    g[j] += t;
+    c2 += (x[b * P + j] - pmean[b * P + j]) * t;
+  }
+  c2 = block_sum(c2, sh);
+  if (threadIdx.x == 0) g[P] += c2;
+}
+
 // ---- trust_init: D, mu, nu, counters -----------------------------------------------------------
 __global__ __launch_bounds__(256) void b_init_kernel(int64_t P, int64_t T, const double *apk,
                                                      int64_t apk_stride, const double *gvec,
@@ -261,7 +313,8 @@ __global__ __launch_bounds__(256) void b_sumsq_stage1(const double *r, int64_t n
 
 __global__ __launch_bounds__(256) void b_sumsq_stage2(const double *partial, int nparts, int64_t P,
                                                       const double *prec, const double *pmean,
-                                                      const double *xt, int has_prior, BState s) {
+                                                      const double *xt, int has_prior, const double *tvec,
+                                                      BState s) {
   __shared__ double sh[4];
   const int b = blockIdx.x;
   if (!s.active[b]) return;
@@ -270,7 +323,7 @@ __global__ __launch_bounds__(256) void b_sumsq_stage2(const double *partial, int
   if (has_prior)
     for (int64_t j = threadIdx.x; j < P; j += 256) {
       const double d = xt[b * P + j] - pmean[b * P + j];
-      a += prec[b * P + j] * d * d;
+      a += tvec ? d * tvec[b * P + j] : prec[b * P + j] * d * d;   // tvec = Lambda d (dense prior)
     }
   a = block_sum(a, sh);
   if (threadIdx.x == 0) {
@@ -453,6 +506,7 @@ struct lsqamdb_fits {
   double *consts = nullptr;
   int32_t n_tape = 0;
   // per fit
+  double *ptvec = nullptr;  // dense prior: Lambda (x - pbar) per fit
   double *pmean = nullptr, *pprec = nullptr, *px = nullptr, *pxt = nullptr, *dx = nullptr, *diag = nullptr;
   double *r = nullptr, *J = nullptr, *slabs = nullptr, *red = nullptr, *M = nullptr, *chol_work = nullptr;
   double *yv = nullptr, *partial = nullptr, *spart = nullptr, *Wl = nullptr, *cov = nullptr, *logdet = nullptr;
@@ -519,7 +573,8 @@ size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
   f->tape = cv.take<int32_t>(1024);
   f->consts = cv.take<double>(256);
   f->pmean = cv.take<double>(B * P);
-  f->pprec = cv.take<double>(B * P);
+  f->pprec = cv.take<double>(c.prior_dense ? P * P : B * P);
+  f->ptvec = cv.take<double>(c.prior_dense ? B * P : 1);
   f->px = cv.take<double>(B * P);
   f->pxt = cv.take<double>(B * P);
   f->dx = cv.take<double>(B * P);
@@ -551,7 +606,7 @@ size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
 int check_cfg_b(const lsqamd_config *c, int32_t B) {
   if (!c || c->abi_version != LSQAMD_ABI_VERSION || B < 1) return LSQAMD_EINVAL;
   if (c->n_data < 1 || c->n_param < 1) return LSQAMD_EINVAL;
-  if (c->n_blocks < 0 || c->prior_dense) return LSQAMD_EUNSUPPORTED;  // diagonal priors only
+  if (c->n_blocks < 0) return LSQAMD_EUNSUPPORTED;
   if (c->model < LSQAMD_MODEL_COSMIX || c->model > LSQAMD_MODEL_IDENTITY) return LSQAMD_EINVAL;
   if (c->model == LSQAMD_MODEL_TAPE && c->n_param > LSQAMD_TAPE_MAX_PARAM) return LSQAMD_EINVAL;
   if ((c->model == LSQAMD_MODEL_COSMIX || c->model == LSQAMD_MODEL_MULTIEXP) && (c->n_param & 1))
@@ -615,7 +670,14 @@ int normal_all(lsqamdb_fits *f) {
   hipLaunchKernelGGL(b_colsum_stage2, dim3((unsigned)((P + 1 + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
                      f->partial, nchunks, P + 1, (int64_t)f->nparts * (P + 1), f->red + f->npk, red_stride,
                      f->s.active);
-  if (f->cfg.has_prior)
+  if (f->cfg.has_prior && f->cfg.prior_dense) {
+    hipLaunchKernelGGL(b_prior_matrix_dense_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
+                       dim3(256), 0, f->st, f->red, red_stride, P, f->T, f->pprec, f->s.active);
+    hipLaunchKernelGGL(b_prior_vec_dense_kernel, dim3((unsigned)((P + 3) / 4), (unsigned)B), dim3(256), 0, f->st,
+                       P, f->pprec, f->pmean, f->px, f->ptvec, f->s.active);
+    hipLaunchKernelGGL(b_prior_apply_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->pmean, f->px, f->ptvec,
+                       f->red + f->npk, red_stride, f->s.active);
+  } else if (f->cfg.has_prior)
     hipLaunchKernelGGL(b_prior_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->pprec, f->pmean,
                        f->px, f->red, red_stride, f->red + f->npk, red_stride, f->s.active);
   BHIP(f, hipGetLastError());
@@ -645,8 +707,12 @@ int round_all(lsqamdb_fits *f) {
                                     f->cfg.max_block, f->r_raw, f->r, (int32_t)B, N, f->s.active));
   hipLaunchKernelGGL(b_sumsq_stage1, dim3((unsigned)f->nrparts, (unsigned)B), dim3(256), 0, f->st, f->r, N, N,
                      f->spart, f->nrparts, f->s.active);
+  const bool dense_prior = f->cfg.has_prior && f->cfg.prior_dense;
+  if (dense_prior)
+    hipLaunchKernelGGL(b_prior_vec_dense_kernel, dim3((unsigned)((P + 3) / 4), (unsigned)B), dim3(256), 0, f->st,
+                       P, f->pprec, f->pmean, f->pxt, f->ptvec, f->s.active);
   hipLaunchKernelGGL(b_sumsq_stage2, dim3((unsigned)B), dim3(256), 0, f->st, f->spart, f->nrparts, P, f->pprec,
-                     f->pmean, f->pxt, f->cfg.has_prior, f->s);
+                     f->pmean, f->pxt, f->cfg.has_prior, dense_prior ? f->ptvec : nullptr, f->s);
   hipLaunchKernelGGL(b_decide_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, f->st, (int)B,
                      f->opt.factor_up, f->opt.factor_down, f->s);
   hipLaunchKernelGGL(b_commit_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, f->st, P,
@@ -791,12 +857,14 @@ int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, c
   return 0;
 }
 
-/* per-fit diagonal priors: mean[B*P], prec[B*P] = 1/sdev^2 */
+/* per-fit priors: mean[B*P]; prec[B*P] = 1/sdev^2 per fit (diagonal), or -- cfg.prior_dense -- ONE dense
+ * P x P precision shared by all fits (copies of a fit differ in their prior means, not its covariance) */
 int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) {
   if (!f || !mean || !prec) return LSQAMD_EINVAL;
   if (!f->cfg.has_prior) BFAIL(f, LSQAMD_EINVAL, "set_priors: config has no prior");
   BHIP(f, hipMemcpy(f->pmean, mean, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->pprec, prec, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->pprec, prec, sizeof(double) * (f->cfg.prior_dense ? f->P * f->P : f->B * f->P),
+                    hipMemcpyHostToDevice));
   f->have_prior = true;
   return 0;
 }

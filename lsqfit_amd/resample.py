@@ -6,9 +6,8 @@ The reference loops over whole Python fits, one per copy of the data.  Every cop
 has the structure of the original fit (same model, x, covariance, whitening; only
 the data means -- and optionally the prior means -- change), so here the copies run
 as ONE lockstep batch on the device (:class:`lsqfit_amd.BatchedFits`, C ABI
-``lsqamdb_*``).  Fits with a correlated (dense) prior are refitted one after the
-other on the resident single-fit engine instead (``lsqamd_set_ymean`` /
-``lsqamd_set_prior``): still the device path, no batching.
+``lsqamdb_*``): correlated data blocks and a correlated (dense) prior are shared by
+the copies, data and prior MEANS are per copy.
 
 Random numbers: ``numpy.random.Generator(PCG64(seed))`` (the reference draws from
 gvar's global RNG through ``gvar.bootstrap_iter``: mean + a N(0, C_regulated) deviate).
@@ -16,7 +15,6 @@ gvar's global RNG through ``gvar.bootstrap_iter``: mean + a N(0, C_regulated) de
 import numpy as np
 
 from .batched import BatchedFits
-from .fit import gammaQ
 
 
 def simulated_data(fit, n, pexact=None, add_priornoise=False, seed=0):
@@ -51,7 +49,7 @@ def bootstrap_data(fit, n, seed=0):
 class ResampledFits(dict):
     """Results of n refits: arrays with a leading copy index (``pmean[n, P]``, ``chi2``,
     ``dof``, ``Q``, ``nit``, ``stopping_criterion``, ``psdev`` ...), plus the inputs
-    ``ymeans`` / ``prior_means`` and ``engine`` ('batched' or 'sequential')."""
+    ``ymeans`` / ``prior_means`` and ``engine`` ('batched')."""
     __getattr__ = dict.__getitem__
 
 
@@ -62,38 +60,16 @@ def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
     tol = fit.tol if tol is None else tol
     maxit = fit.maxit if maxit is None else maxit
     p0 = np.broadcast_to(np.asarray(p0, float), (n, P))
-    if not (wh.has_prior and wh.prior_dense):
-        bf = BatchedFits(fit.model, fit.problem_x, ymeans, None,
-                         prior_means if wh.has_prior else None,
-                         wh.prior_sdev if wh.has_prior else None, whitening=wh, n_fits=n)
-        out = bf.run(p0=p0, tol=tol, maxit=maxit, covariance=covariance)
-        bf.close()
-        res = ResampledFits(out)
-        res['engine'] = 'batched'
-    else:
-        pr = fit.problem
-        keep_y, keep_pm = wh.ymean.copy(), wh.prior_mean.copy()
-        rows = dict(pmean=[], chi2=[], nit=[], stopping_criterion=[], status=[], psdev=[], logdet_jtj=[])
-        from .fitter import mi355x_lm
-        try:
-            for k in range(n):
-                pr.set_ymean(ymeans[k])
-                pr.set_prior(prior_means[k], wh.prior_prec)
-                lm = mi355x_lm(p0[k], wh.nchiv, None, tol=tol, maxit=maxit, problem=pr)
-                rows['pmean'].append(np.array(lm.x))
-                rows['chi2'].append(lm.chi2)
-                rows['nit'].append(lm.nit)
-                rows['stopping_criterion'].append(lm.stopping_criterion)
-                rows['status'].append(0 if lm.error is None else 1)
-                rows['psdev'].append(np.sqrt(np.diag(lm.cov)))
-                rows['logdet_jtj'].append(lm.logdet_jtj)
-        finally:
-            pr.set_ymean(keep_y)
-            pr.set_prior(keep_pm, wh.prior_prec)
-        res = ResampledFits({k: np.array(v) for k, v in rows.items()})
-        res['dof'] = wh.nchiv - P
-        res['Q'] = np.array([gammaQ(res['dof'] / 2., c / 2.) for c in res['chi2']])
-        res['engine'] = 'sequential'
+    dense = wh.has_prior and wh.prior_dense
+    bf = BatchedFits(fit.model, fit.problem_x, ymeans, None,
+                     prior_means if wh.has_prior else None,
+                     None if (dense or not wh.has_prior) else wh.prior_sdev, whitening=wh, n_fits=n,
+                     prior_prec=wh.prior_prec if dense else None,
+                     prior_logdet=(wh.logdet - wh.logdet_data) if dense else None)
+    out = bf.run(p0=p0, tol=tol, maxit=maxit, covariance=covariance)
+    bf.close()
+    res = ResampledFits(out)
+    res['engine'] = 'batched'
     res['ymeans'] = ymeans
     res['prior_means'] = prior_means
     return res

@@ -130,8 +130,7 @@ def test_bootstrap(amd, case):
         fit = amd.nonlinear_fit(data=(x, ymean, yc), model=model, prior=(pm, pc))
     nbs = 100
     res = fit.bootstrapped_fits(nbs, seed=77)
-    dense_prior = case in ('binned', 'binned_p')
-    assert res.engine == ('sequential' if dense_prior else 'batched')
+    assert res.engine == 'batched'          # correlated (dense) priors are shared by the batch too
     ok = res.status == 0
     assert ok.sum() >= nbs - 2
     bs = np.median(np.mean(res.pmean[ok] ** 2, axis=1))
@@ -160,3 +159,25 @@ def test_config5_shape_correlated_bootstrap(amd):
     # spread of the copies' parameters = the fit's errors (Gaussian limit)
     z = (res.pmean - fit.pmean) / fit.psdev
     assert 0.9 < z.std() < 1.1
+
+
+def test_dense_prior_batch_matches_single_engine_and_oracle(amd):
+    """Correlated data blocks AND a correlated prior in the lockstep engine: every simulated copy
+    equals a single-engine / oracle fit of the same inputs."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=512, P=32, seed=95, block=128, prior_corr=True)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    res = fit.simulated_fits(5, add_priornoise=True, seed=4)
+    assert res.engine == 'batched' and np.all(res.status == 0)
+    for k in (0, 4):
+        dd = dict(d, ymean=res.ymeans[k], prior=(res.prior_means[k], d['prior'][1]))
+        single = amd.nonlinear_fit(data=(d['x'], res.ymeans[k], d['yerr']), model=d['model'],
+                                   prior=(res.prior_means[k], d['prior'][1]), p0=fit.pmean)
+        assert gu.relmax(res.pmean[k], single.pmean) < 1e-9
+        assert abs(res.chi2[k] / single.chi2 - 1) < 1e-9
+        assert abs(res.logGBF[k] - single.logGBF) < 1e-8 * abs(single.logGBF)
+        assert res.nit[k] == single.nit
+        ref = gu.oracle_fit(dd, p0=fit.pmean)
+        assert gu.relmax(res.pmean[k], ref.pmean) < 1e-6
+        assert gu.relmax(res.psdev[k], ref.psdev) < 1e-6
+        assert abs(res.chi2[k] / ref.chi2 - 1) < 1e-6
