@@ -299,12 +299,15 @@ class DeviceProblem:
             gt = np.ascontiguousarray(G.T)
         nbytes = self.lib.lsqamd_dpdy_work_bytes(self.h, m)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        out = np.empty((ncol, m))
+        # pinned destination (the full D at the north-star shape is 2.3 GB) and a transposed VIEW of
+        # it as the result: no pageable staging, no host-side transpose
+        out_t = torch.empty((ncol, m), dtype=torch.float64, pin_memory=True)
+        out = out_t.numpy()
         rc = self.lib.lsqamd_dpdy(self.h, None if gt is None else _lib.dptr(gt), m,
                                   C.c_void_p(scratch.data_ptr()), nbytes, _lib.dptr(out), out.size)
         _check(self.lib, self.h, rc, 'dpdy')
         del scratch
-        return np.ascontiguousarray(out.T)
+        return out.T
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
