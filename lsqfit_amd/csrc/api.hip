@@ -5,7 +5,11 @@
 // equations (solver='cholesky').  All O(N P), O(N P^2) and O(P^3) work is on the
 // device; the host keeps only O(P) vectors (x, g, D, dx) and the scalars
 // (mu, nu, rho), so that every rank of a row-sharded fit takes identical
-// decisions from the identical all-reduced (J^T J, J^T f, chi2).
+// decisions from the identical all-reduced (J^T J, J^T f, chi2).  Nothing is uploaded
+// inside a step (D and the trial point are mirrored / formed on the device); one stream
+// synchronisation per trial step and one per Jacobian.  Also here: the other trust-region
+// sub-problem solvers (lmaccel, dogleg, ddogleg, subspace2D), fit.p sensitivities
+// (lsqamd_dpdy), chi2 at many points (lsqamd_chi2_points).
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -8,9 +8,12 @@
 // Layout choice: the matrix is row-major, so the factorisation is the UPPER,
 // row-panel-oriented right-looking one (A = U^T U).  Then every bulk update is a
 // k-major "TN" contraction for gemm_tn_f64 (no transposes, coalesced rows):
-//   diagonal block   potf2 + in-place triangular inverse, one workgroup, in LDS
-//   row panel        U[k, k+nb:] = inv(U_kk)^T A[k, k+nb:]          (TN GEMM)
-//   trailing update  A[k+nb:, k+nb:] -= U[k, k+nb:]^T U[k, k+nb:]    (TN GEMM, upper tiles)
+//   diagonal block   factor + triangular inverse by one workgroup: potf2_mfma.hip (tiles
+//                    resident in the MFMA accumulator layout; default) or the LDS-resident
+//                    kernel below (LSQAMD_POTF2=lds)
+//   row panel        U[k, k+nb:] = inv(U_kk)^T A[k, k+nb:]          (in-place TN GEMM, 128 x 64 tiles)
+//   trailing update  A[k+nb:, k+nb:] -= U[k, k+nb:]^T U[k, k+nb:]    (TN GEMM, upper tiles; while it
+//                    is large, one launch with the next diagonal block: trail_potf2_kernel)
 // Extra columns to the right of the n x n block ride along in the row panels, so
 // appending the gradient as column n yields the forward substitution U^-T g for free.
 #include <cstdlib>
