@@ -1,0 +1,48 @@
+"""-m gpu: bench.py's contract on small shapes -- one JSON line with the required keys, for one
+process and for the torch.distributed.run launch line the driver uses (two ranks sharing the box's
+GPU, gloo standing in for RCCL, which refuses two ranks per device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {'metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+        'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'}
+
+
+def last_json(out):
+    lines = [l for l in out.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_process_line():
+    r = subprocess.run([sys.executable, 'bench.py', '--steps', '3', '--warmup', '1', '--ndata', '4096', '--nparam',
+                        '256', '--cpu-seconds', '1'], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert KEYS <= set(d)
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['warmup'] == 1 and d['dtype'] == 'f64'
+    assert d['value'] > 0 and abs(d['value'] * d['ms_per_step'] / 1e3 - 1) < 1e-9
+    rf = d['roofline']
+    assert rf['bound'] == 'mfma' and rf['unit'] == 'TFLOP/s' and 0 < rf['frac'] < 1
+    assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
+    cb = d['cpu_baseline']
+    assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0
+
+
+def test_two_rank_launch_line():
+    env = dict(os.environ, LSQAMD_DIST_BACKEND='gloo')
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                        '--master-addr', '127.0.0.1', '--master-port', '29533', 'bench.py', '--gpus', '2', '--steps',
+                        '3', '--warmup', '1', '--ndata', '4096', '--nparam', '256'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert KEYS <= set(d) and d['n_gpus'] == 2 and d['scaling'] == 'strong'
+    assert d['phases_calls']['reduce'] >= 2 * d['phases_calls']['jacobian']     # packed normal eqs + trial chi2
+    assert d['cpu_baseline'] is None and d['value'] > 0
