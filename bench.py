@@ -216,9 +216,10 @@ def main():
         n_local = pr.N
         # HBM traffic of the dominant kernel is a PMC quantity (separate rocprofv3 --pmc pass,
         # FETCH_SIZE x2 gfx950 correction): taken from the committed profile of this workload
-        traffic, traffic_src = None, None
+        traffic, traffic_src, clk = None, None, None
         try:
             prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_syrk_pmc.json')))
+            clk = prof['summary'].get('effective_clock_GHz')
             if world == 1 and (N, P) == (65536, 4096):
                 traffic = prof['summary']['hbm_read_bytes_corrected'] + prof['summary'].get('hbm_write_bytes', 0)
                 traffic_src = 'profiles/r01_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch)'
@@ -247,7 +248,12 @@ def main():
                          'traffic_unit': 'bytes/launch', 'traffic_source': traffic_src,
                          'algorithmic_bytes': 8.0 * n_local * P,
                          'flops_per_launch': flops,
-                         'avg_launch_ms': (syrk_ms / syrk_n) if syrk_n else None},
+                         'avg_launch_ms': (syrk_ms / syrk_n) if syrk_n else None,
+                         # informational: the chip sustains ~2.18 GHz (not the nominal 2.4) under this
+                         # kernel (GRBM_GUI_ACTIVE in the committed PMC profile); frac stays vs nominal
+                         'sustained_clock_GHz': clk,
+                         'frac_of_peak_at_sustained_clock':
+                             (ach / (128 * 256 * clk * 1e9 / 1e12)) if clk else None},
         }
         if not args.no_cpu_baseline and world == 1:
             try:
