@@ -183,6 +183,13 @@ def make_kat():
                            out=open(os.path.join(REF, 'examples/empbayes.out')).read())
     # examples/simple.py / .out
     kat['simple'] = dict(out=open(os.path.join(REF, 'examples/simple.out')).read())
+    # examples/x-err.py:21-42 / x-err.out ("x has error bars": the x_i are fit parameters with the
+    # measured x as their priors; 4 + 15 parameters): data literals are lines 22-26 and 27-31
+    src = open(os.path.join(REF, 'examples/x-err.py')).read()
+    lists = re.findall(r"gv\.gvar\(\[(.*?)\]\s*\)", src, flags=re.S)
+    strs = [re.findall(r"'([^']+)'", l) for l in lists]
+    kat['x_err'] = dict(x=strs[0], y=strs[1], prior_b=strs[2],
+                        out=open(os.path.join(REF, 'examples/x-err.out')).read())
     json.dump(kat, open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     print('kat.json:', len(kat), 'entries')
 

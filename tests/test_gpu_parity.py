@@ -332,3 +332,18 @@ def test_empbayes_example_on_device(amd):
         assert f.chi2 == pytest.approx(ref.chi2, rel=1e-6)
     assert int(np.argmax([f.logGBF for f in fits])) == 3
     pr.close()
+
+
+def test_x_err_example_on_device(amd):
+    """examples/x-err.py / x-err.out on the device: 19 parameters through the expression tape (two
+    derivative passes), each row selecting its own x_i parameter with an indicator column."""
+    from tests.test_oracle_kat import _x_err_inputs, parse_parameter_table, check_header
+    ym, ys, pm, ps, out = _x_err_inputs()
+    names = ['b0', 'b1', 'b2', 'b3'] + ['x%d' % i for i in range(15)]
+    sel = ' + '.join('s%d*x%d' % (i, i) for i in range(15))
+    model = amd.expr('b0/(1 + exp(b1 - b2*(%s)))**(1/b3)' % sel, names, xnames=tuple('s%d' % i for i in range(15)))
+    fit = amd.nonlinear_fit(data=(np.eye(15), ym, ys), model=model, prior=(pm, ps))
+    check_header(fit, out)
+    got = [gvar_lite.fmt(m, s) for m, s in zip(fit.pmean, fit.psdev)]
+    assert got == parse_parameter_table(out)
+    assert fit.nit == 13

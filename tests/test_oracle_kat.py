@@ -414,3 +414,39 @@ def test_maxit0_and_unusual_cases():
     fit = ofit.nonlinear_fit(False, [1.5, 1.7], [0.1, 0.2], fcn, prior_mean=[2.0], prior_err=[0.5], tol=1e-8)
     m, s = wavg([1.5, 1.7, 2.0], [0.1, 0.2, 0.5])
     assert gvar_lite.fmt(fit.pmean[0], fit.psdev[0]) == gvar_lite.fmt(m, s)
+
+
+def _x_err_inputs():
+    k = KAT['x_err']
+    xm, xs = gvar_lite.parse_array(k['x'])
+    ym, ys = gvar_lite.parse_array(k['y'])
+    bm, bs = gvar_lite.parse_array(k['prior_b'])
+    return ym, ys, np.concatenate([bm, xm]), np.concatenate([bs, xs]), k['out']
+
+
+def parse_parameter_table(out):
+    """Mean(sdev) strings of the 'Parameters:' table of a reference .out file, in order."""
+    body = out.split('Parameters:')[1].split('Settings:')[0]
+    vals = []
+    for ln in body.strip().splitlines():
+        m = re.search(r'(-?[\d.]+(?:e[-+]?\d+)?) \((\d[\d.]*)\)\s+\[', ln)
+        assert m, ln
+        vals.append('%s(%s)' % (m.group(1), m.group(2)))
+    return vals
+
+
+def test_x_err_example():
+    """examples/x-err.py:21-48 vs x-err.out: the x_i are parameters (priors = the measured x), so row
+    i of the model depends on its own parameter; 19 parameters, 15 data points, 13 iterations."""
+    ym, ys, pm, ps, out = _x_err_inputs()
+
+    def fcn(p):
+        b0, b1, b2, b3 = p[0], p[1], p[2], p[3]
+        return b0 / ((1. + dual.exp(b1 - b2 * p[4:])) ** (1. / b3))
+    fit = ofit.nonlinear_fit(False, ym, ys, fcn, prior_mean=pm, prior_err=ps)
+    check_header(fit, out)
+    want = parse_parameter_table(out)
+    assert len(want) == 19
+    got = [gvar_lite.fmt(m, s) for m, s in zip(fit.pmean, fit.psdev)]
+    assert got == want
+    assert fit.nit == 13                       # 'itns/time = 13/...' in x-err.out
