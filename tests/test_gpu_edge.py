@@ -147,3 +147,30 @@ def test_expression_model_with_many_parameters(amd):
     assert gu.relmax(fit.cov, ref.cov) < 1e-6
     assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
     pa.close(); pb.close()
+
+
+def test_noprior_zero_dof_on_device(amd):
+    """tests/test_lsqfit.py:671-713 on the device: f_i = p_i**2 (row i selects its own parameter),
+    8 correlated data, 8 parameters, no prior."""
+    from tests.test_oracle_kat import _noprior_data
+    ymean, ycov = _noprior_data()
+    model = amd.expr(' + '.join('s%d*p%d**2' % (i, i) for i in range(8)), ['p%d' % i for i in range(8)],
+                     xnames=tuple('s%d' % i for i in range(8)))
+    fit = amd.nonlinear_fit(data=(np.eye(8), ymean, ycov), model=model, p0=np.full(8, 0.1), tol=1e-14)
+    assert fit.logGBF is None and fit.dof == 0
+    assert abs(fit.chi2) < 1e-4
+    np.testing.assert_allclose(fit.pmean ** 2, ymean, rtol=1e-4)
+    g = np.diag(2 * fit.pmean)
+    np.testing.assert_allclose(g @ fit.cov @ g.T, ycov, rtol=1e-4, atol=1e-4 * np.abs(ycov).max())
+
+
+def test_uncorrelated_data_flag_on_device(amd):
+    """tests/test_lsqfit.py:1152-1167: udata=... drops the data correlations."""
+    from tests.test_oracle_kat import _udata_inputs
+    m, cov = _udata_inputs()
+    model = amd.expr('p + 0*x', ['p'])
+    for kw in (dict(prior=([1.0], [1.0])), dict(p0=[1.0])):
+        f1 = amd.nonlinear_fit(udata=(np.zeros(4), m, cov), model=model, **kw)
+        f2 = amd.nonlinear_fit(data=(np.zeros(4), m, cov), model=model, **kw)
+        assert abs(f1.pmean[0] - f2.pmean[0]) < 5e-4
+        assert abs(2 * f1.psdev[0] - f2.psdev[0]) < 5e-4

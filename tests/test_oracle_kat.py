@@ -450,3 +450,45 @@ def test_x_err_example():
     got = [gvar_lite.fmt(m, s) for m, s in zip(fit.pmean, fit.psdev)]
     assert got == want
     assert fit.nit == 13                       # 'itns/time = 13/...' in x-err.out
+
+
+def _noprior_data(seed=7):
+    """tests/test_lsqfit.py:671-683: nine draws of 4.00(25), neighbours averaged -> 8 correlated values."""
+    rng = np.random.default_rng(seed)
+    y9 = 4.0 + 0.25 * rng.standard_normal(9)
+    B = np.zeros((8, 9))
+    for i in range(8):
+        B[i, i] = B[i, i + 1] = 0.5
+    return B @ y9, B @ (0.25 ** 2 * np.eye(9)) @ B.T
+
+
+def test_noprior_zero_dof():
+    """tests/test_lsqfit.py:671-713 (test_noprior): fcn = p**2, as many parameters as correlated data,
+    no prior: dof 0, chi2 0, logGBF None, and the fit reproduces the data with its covariance."""
+    ymean, ycov = _noprior_data()
+    sq = lambda p: p * p
+    fit = ofit.nonlinear_fit(False, ymean, ycov, sq, p0=np.full(8, 0.1), tol=1e-14)
+    assert fit.logGBF is None and fit.dof == 0
+    assert abs(fit.chi2) < 1e-4
+    np.testing.assert_allclose(fit.pmean ** 2, ymean, rtol=1e-4)
+    g = np.diag(2 * fit.pmean)
+    np.testing.assert_allclose(g @ fit.cov @ g.T, ycov, rtol=1e-4, atol=1e-4 * np.abs(ycov).max())
+
+
+def _udata_inputs():
+    """tests/test_lsqfit.py:1152-1167: y = 1.01(1) * [1.000(1)] * 4 -- almost fully correlated."""
+    m = np.full(4, 1.01)
+    cov = np.full((4, 4), 0.01 ** 2) + np.diag(np.full(4, (1.01 * 0.001) ** 2))
+    return m, cov
+
+
+def test_uncorrelated_data_flag():
+    """tests/test_lsqfit.py:1152-1167 (udata drops the correlations, src/lsqfit/__init__.py:1892-1893):
+    same mean, half the error for four (nearly) fully correlated points."""
+    m, cov = _udata_inputs()
+    const = lambda p: dual.concatenate([p[0].reshape(1)] * 4) if isinstance(p, dual.Dual) else np.full(4, p[0])
+    for kw in (dict(prior_mean=[1.0], prior_err=[1.0]), dict(p0=[1.0])):
+        f1 = ofit.nonlinear_fit(False, m, cov, const, udata=True, **kw)
+        f2 = ofit.nonlinear_fit(False, m, cov, const, **kw)
+        assert abs(f1.pmean[0] - f2.pmean[0]) < 5e-4
+        assert abs(2 * f1.psdev[0] - f2.psdev[0]) < 5e-4
