@@ -174,3 +174,17 @@ def test_uncorrelated_data_flag_on_device(amd):
         f2 = amd.nonlinear_fit(data=(np.zeros(4), m, cov), model=model, **kw)
         assert abs(f1.pmean[0] - f2.pmean[0]) < 5e-4
         assert abs(2 * f1.psdev[0] - f2.psdev[0]) < 5e-4
+
+
+@pytest.mark.parametrize('svdcut', [1e-20, 1e-2])
+def test_svd_cut_floor_on_device(amd, svdcut):
+    """tests/test_lsqfit.py:773-826 on the device (eigen-mode whitening of the floored blocks)."""
+    from tests.test_oracle_kat import _svd_case, check_svd_fit
+    y, ycov, pm, pcov, sig1, sig2 = _svd_case()
+    model = amd.expr('s0*p0**2 + s1*p1**2', ['p0', 'p1'], xnames=('s0', 's1'))
+    fit = amd.nonlinear_fit(data=(np.eye(2), y, ycov), model=model, prior=(pm, pcov), svdcut=svdcut)
+    check_svd_fit(fit, svdcut, sig1, sig2)
+    ref = ofit.nonlinear_fit(False, y, ycov, lambda p: p * p, prior_mean=pm, prior_err=pcov, svdcut=svdcut)
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert abs(fit.chi2 - ref.chi2) < 1e-6 * max(1.0, ref.chi2)
+    assert abs(fit.logGBF - ref.logGBF) < 1e-6 * abs(ref.logGBF)

@@ -492,3 +492,44 @@ def test_uncorrelated_data_flag():
         f2 = ofit.nonlinear_fit(False, m, cov, const, **kw)
         assert abs(f1.pmean[0] - f2.pmean[0]) < 5e-4
         assert abs(2 * f1.psdev[0] - f2.psdev[0]) < 5e-4
+
+
+def _svd_case(seed=11):
+    """tests/test_lsqfit.py:773-790: two strongly correlated pairs, y ~ [1.1, 0.9] and p**2 likewise,
+    error 1e-2 on the symmetric and 1e-4 on the antisymmetric combination."""
+    fac = 100.
+    sig1, sig2 = 1. / fac, 1e-2 / fac
+    cov = sig1 ** 2 * np.array([[1., 1.], [1., 1.]]) + sig2 ** 2 * np.array([[1., -1.], [-1., 1.]])
+    mean = np.array([1.1, 0.9])
+    rng = np.random.default_rng(seed)
+    L = np.linalg.cholesky(cov)
+    y = mean + L @ rng.standard_normal(2)
+    p2 = mean + L @ rng.standard_normal(2)
+    pm = np.sqrt(p2)
+    Jp = np.diag(0.5 / pm)
+    return y, cov, pm, Jp @ cov @ Jp.T, sig1, sig2
+
+
+def check_svd_fit(fit, svdcut, sig1, sig2):
+    G = np.array([[fit.pmean[0], fit.pmean[1]], [fit.pmean[0], -fit.pmean[1]]])   # d[(p0^2 +- p1^2)/2]/dp
+    c = G @ fit.cov @ G.T
+    sd = np.sqrt(np.diag(c))
+    s2 = max(sd[0] * sig2 / sig1, svdcut ** 0.5 * sd[0])
+    assert abs(sd[1] / s2 - 1.) < 0.005                       # assertAlmostEqual(..., places=2)
+    assert fit.svdn == (0 if svdcut < 1e-10 else 2)
+    assert fit.nblocks[2] == 2
+
+
+@pytest.mark.parametrize('svdcut', [1e-20, 1e-2])
+def test_svd_cut_floor(svdcut):
+    """tests/test_lsqfit.py:773-826 (cases 1, 2, 5, 6): with svdcut = 1e-2 the error of the
+    antisymmetric combination is set by the eigenvalue floor, sqrt(svdcut) times the symmetric one;
+    svdn counts the two modified modes."""
+    y, ycov, pm, pcov, sig1, sig2 = _svd_case()
+    sq = lambda p: p * p
+    fit = ofit.nonlinear_fit(False, y, ycov, sq, prior_mean=pm, prior_err=pcov, svdcut=svdcut)
+    check_svd_fit(fit, svdcut, sig1, sig2)
+    # the symmetric combination is (to 1 %) the weighted average of data and prior
+    ans_p = 0.5 * (fit.pmean[0] ** 2 + fit.pmean[1] ** 2)
+    ans_y, ans_pr = 0.5 * (y[0] + y[1]), 0.5 * (pm[0] ** 2 + pm[1] ** 2)
+    assert abs(ans_p / (0.5 * (ans_y + ans_pr)) - 1) < 1e-2
