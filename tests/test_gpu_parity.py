@@ -347,3 +347,23 @@ def test_x_err_example_on_device(amd):
     got = [gvar_lite.fmt(m, s) for m, s in zip(fit.pmean, fit.psdev)]
     assert got == parse_parameter_table(out)
     assert fit.nit == 13
+
+
+def test_empbayes_polynomial_on_device(amd):
+    """tests/test_lsqfit.py:871-887 on the device: the 25-coefficient polynomial as an expression tape
+    (P = 25: two derivative passes), lsqfit_amd.empbayes_fit over the log prior width."""
+    from tests.test_oracle_kat import EMPBAYES_X, EMPBAYES_Y
+    ym, ys = gvar_lite.parse_array(EMPBAYES_Y)
+    x = np.array(EMPBAYES_X)
+    names = ['c%d' % n for n in range(25)]
+    model = amd.expr(' + '.join(['c0'] + ['c%d*x**%d' % (n, n) for n in range(1, 25)]), names)
+
+    def fitargs(z):
+        return dict(data=(x, ym, ys), model=model, prior=(np.zeros(25), np.full(25, float(np.exp(z)))))
+    fit, z = amd.empbayes_fit(float(np.log(0.7)), fitargs, tol=1e-3)
+    assert abs(np.exp(z) - 0.6012) < 0.05
+    V = x[:, None] ** np.arange(25)[None, :]
+    ref = ofit.nonlinear_fit(x, ym, ys, lambda x, p: V @ p, prior_mean=np.zeros(25),
+                             prior_err=np.full(25, float(np.exp(z))), jac=lambda x, p: V, solver='cholesky')
+    assert abs(fit.logGBF - ref.logGBF) < 1e-6 * abs(ref.logGBF)
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6

@@ -533,3 +533,26 @@ def test_svd_cut_floor(svdcut):
     ans_p = 0.5 * (fit.pmean[0] ** 2 + fit.pmean[1] ** 2)
     ans_y, ans_pr = 0.5 * (y[0] + y[1]), 0.5 * (pm[0] ** 2 + pm[1] ** 2)
     assert abs(ans_p / (0.5 * (ans_y + ans_pr)) - 1) < 1e-2
+
+
+EMPBAYES_Y = ['0.5351(54)', '0.6762(67)', '0.9227(91)', '1.3803(131)', '4.0145(399)']    # test_lsqfit.py:873-877
+EMPBAYES_X = [0.1, 0.3, 0.5, 0.7, 0.95]
+
+
+def test_empbayes_polynomial_prior_width():
+    """tests/test_lsqfit.py:871-887 (test_empbayes): 25-coefficient polynomial, priors 0 +- exp(z);
+    maximising logGBF over z gives exp(z) = 0.6012 to one decimal place."""
+    from scipy.optimize import minimize
+    ym, ys = gvar_lite.parse_array(EMPBAYES_Y)
+    x = np.array(EMPBAYES_X)
+    V = x[:, None] ** np.arange(25)[None, :]
+    last = dict(p0=None)
+
+    def neg(z):
+        w = float(np.exp(z[0]))
+        fit = ofit.nonlinear_fit(x, ym, ys, lambda x, p: V @ p, prior_mean=np.zeros(25), prior_err=np.full(25, w),
+                                 jac=lambda x, p: V, p0=last['p0'])
+        last['p0'] = fit.pmean
+        return -fit.logGBF
+    res = minimize(neg, [np.log(0.7)], method='Nelder-Mead', tol=1e-3)
+    assert abs(np.exp(res.x[0]) - 0.6012) < 0.05
