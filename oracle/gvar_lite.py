@@ -48,8 +48,8 @@ def parse_array(strs):
     return a[:, 0].copy(), a[:, 1].copy()
 
 
-def _ndec(x):
-    return int(math.floor(-math.log10(x))) + 2
+def _ndec(x, offset=2):
+    return int(math.floor(-math.log10(x))) + offset
 
 
 def fmt(mean, sdev):
@@ -92,7 +92,9 @@ def fmt(mean, sdev):
             return '%.1f(%.1f)' % (v, dv)
         nd = _ndec(abs(v))
         return '%.*f(%.*f)' % (nd, v, nd, dv)
-    nd = max(_ndec(abs(v)), _ndec(dv))
+    # the mean contributes one digit less than the error (pinned by tests/test_lsqfit.py:1592,
+    # '0.004(18)', and :1640, '0.010(13)': an error larger than the mean fixes the decimals)
+    nd = max(_ndec(abs(v), 1), _ndec(dv))
     return '%.*f(%.0f)' % (nd, v, dv * 10. ** nd)
 
 

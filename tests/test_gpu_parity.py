@@ -367,3 +367,27 @@ def test_empbayes_polynomial_on_device(amd):
                              prior_err=np.full(25, float(np.exp(z))), jac=lambda x, p: V, solver='cholesky')
     assert abs(fit.logGBF - ref.logGBF) < 1e-6 * abs(ref.logGBF)
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+
+
+@pytest.mark.parametrize('kind,text,da', [('normal', 'u + 0*x', lambda u: 1.0),
+                                          ('lognormal', 'exp(u) + 0*x', lambda u: np.exp(u)),
+                                          ('sqrtnormal', 'u**2 + 0*x', lambda u: 2 * u)])
+def test_transformed_priors_on_device(amd, kind, text, da):
+    """tests/test_lsqfit.py:1579-1640 through the device: the printed fit.p['a'] strings."""
+    from tests.test_oracle_kat import NORMAL_Y, TRANSFORMED_PRIOR_CASES
+    a_of, um, us, _, want = TRANSFORMED_PRIOR_CASES[kind]
+    ym, ys = gvar_lite.parse_array(NORMAL_Y)
+    fit = amd.nonlinear_fit(data=(np.zeros(ym.size), ym, ys), model=amd.expr(text, ['u']), prior=([um], [us]))
+    u = fit.pmean[0]
+    assert gvar_lite.fmt(float(a_of(u)), abs(da(u)) * fit.psdev[0]) == want
+
+
+def test_lognormal_array_case_on_device(amd):
+    """tests/test_lsqfit.py:1613-1622: '0.147(69)', '1.64(69)'."""
+    ym = np.array([0.1, 1.0, 0.2, 2.0])
+    ys = np.array([0.1, 1.0, 0.1, 1.0])
+    x = np.array([[1.0, 0.0], [0.0, 1.0], [1.0, 0.0], [0.0, 1.0]])
+    model = amd.expr('s0*exp(u0) + s1*exp(u1)', ['u0', 'u1'], xnames=('s0', 's1'))
+    fit = amd.nonlinear_fit(data=(x, ym, ys), model=model, prior=(np.log([0.1, 10.0]), [2.0, 2.0]))
+    a = np.exp(fit.pmean)
+    assert [gvar_lite.fmt(a[i], a[i] * fit.psdev[i]) for i in range(2)] == ['0.147(69)', '1.64(69)']

@@ -556,3 +556,47 @@ def test_empbayes_polynomial_prior_width():
         return -fit.logGBF
     res = minimize(neg, [np.log(0.7)], method='Nelder-Mead', tol=1e-3)
     assert abs(np.exp(res.x[0]) - 0.6012) < 0.05
+
+
+NORMAL_Y = ['-0.17(20)', '-0.03(20)', '-0.39(20)', '0.10(20)', '-0.03(20)', '0.06(20)', '-0.23(20)', '-0.23(20)',
+            '-0.15(20)', '-0.01(20)', '-0.12(20)', '0.05(20)', '-0.09(20)', '-0.36(20)', '0.09(20)', '-0.07(20)',
+            '-0.31(20)', '0.12(20)', '0.11(20)', '0.13(20)']          # tests/test_lsqfit.py:1581-1586
+
+# (expression of a in terms of the fitted parameter u, prior mean/sdev of u given a = 0.02(2),
+#  da/du, expected fit.p['a'].fmt())  -- tests/test_lsqfit.py:1579-1640
+TRANSFORMED_PRIOR_CASES = {
+    'normal': (lambda u: u, 0.02, 0.02, lambda u: 1.0, '0.004(18)'),
+    'lognormal': (lambda u: dual.exp(u) if isinstance(u, dual.Dual) else np.exp(u), np.log(0.02), 0.02 / 0.02,
+                  lambda u: np.exp(u), '0.012(11)'),
+    'sqrtnormal': (lambda u: u * u, np.sqrt(0.02), 0.02 / (2 * np.sqrt(0.02)), lambda u: 2 * u, '0.010(13)'),
+}
+
+
+@pytest.mark.parametrize('kind', sorted(TRANSFORMED_PRIOR_CASES))
+def test_transformed_priors(kind):
+    """tests/test_lsqfit.py:1579-1640 (test_normal / test_lognormal / test_sqrtnormal): the parameter is
+    u = a, log(a) or sqrt(a) with the prior of a = 0.02(2) pushed through; fit.p['a'] = a(u) is printed."""
+    a_of, um, us, da, want = TRANSFORMED_PRIOR_CASES[kind]
+    ym, ys = gvar_lite.parse_array(NORMAL_Y)
+
+    def fcn(p):
+        a = a_of(p[0])
+        return dual.concatenate([a.reshape(1)] * ym.size) if isinstance(a, dual.Dual) else np.full(ym.size, a)
+    fit = ofit.nonlinear_fit(False, ym, ys, fcn, prior_mean=[um], prior_err=[us])
+    u = fit.pmean[0]
+    a = a_of(u)
+    assert gvar_lite.fmt(float(a), abs(da(u)) * fit.psdev[0]) == want
+
+
+def test_lognormal_array_case():
+    """tests/test_lsqfit.py:1613-1622: y = [[0.1(1), 1(1)], [0.2(1), 2(1)]], log(a) = log([0.1(2), 10(20)])."""
+    ym = np.array([0.1, 1.0, 0.2, 2.0])
+    ys = np.array([0.1, 1.0, 0.1, 1.0])
+    um, us = np.log([0.1, 10.0]), np.array([2.0, 2.0])
+
+    def fcn(p):
+        a = dual.exp(p) if isinstance(p, dual.Dual) else np.exp(p)
+        return dual.concatenate([a, a]) if isinstance(a, dual.Dual) else np.concatenate([a, a])
+    fit = ofit.nonlinear_fit(False, ym, ys, fcn, prior_mean=um, prior_err=us)
+    a = np.exp(fit.pmean)
+    assert [gvar_lite.fmt(a[i], a[i] * fit.psdev[i]) for i in range(2)] == ['0.147(69)', '1.64(69)']
