@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQAMD_ABI_VERSION 2
+#define LSQAMD_ABI_VERSION 3
 
 /* error codes (negative = backend, positive = GSL numbering) */
 #define LSQAMD_SUCCESS 0
@@ -72,7 +72,15 @@ enum { LSQAMD_SCALE_MORE = 0, LSQAMD_SCALE_LEVENBERG = 1, LSQAMD_SCALE_MARQUARDT
 enum { LSQAMD_SOLVER_CHOLESKY = 0 };                                                    /* _gsl.pyx:646-653 */
 /* trust-region sub-problem solvers: gsl_multifit's `alg` keyword (_gsl.pyx:622-635) */
 enum { LSQAMD_TRS_LM = 0, LSQAMD_TRS_LMACCEL = 1, LSQAMD_TRS_DOGLEG = 2, LSQAMD_TRS_DDOGLEG = 3,
-       LSQAMD_TRS_SUBSPACE2D = 4 };
+       LSQAMD_TRS_SUBSPACE2D = 4,
+       /* scipy_least_squares' method='trf' (src/lsqfit/_scipy.py:56-60,:135-139): Trust Region
+        * Reflective, the one method that honours lsqamd_set_bounds.  With it: maxit is the cap on
+        * function evaluations (max_nfev, _scipy.py:157), scaler LEVENBERG = x_scale 1.0 (default
+        * there) and MORE = x_scale 'jac', summary.nit counts function evaluations (:161) and
+        * summary.info = LSQAMD_INFO_TRF + scipy's status (0 max_nfev, 1 gtol, 2 ftol, 3 xtol,
+        * 4 ftol and xtol), mapped to stopping_criterion as at :176-181. */
+       LSQAMD_TRS_TRF = 5 };
+#define LSQAMD_INFO_TRF 100
 
 /* tape opcodes (LSQAMD_MODEL_TAPE); operands in `arg` */
 enum {
@@ -181,6 +189,11 @@ int lsqamd_set_data(lsqamd_fit *fit, const double *ymean, const double *wdiag, i
  * chiv (_utilities.pyx:76-77) enter J^T J / J^T f / chi2 through it. */
 int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);
 int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
+/* Box bounds lower[P] < upper[P] (+-INFINITY = open side; NULL array = open everywhere; both
+ * NULL clears them): the flattened `bounds` pair nonlinear_fit hands to scipy_least_squares
+ * (src/lsqfit/__init__.py:641-655, tests/test_lsqfit.py:1780-1808).  Only LSQAMD_TRS_TRF reads
+ * them; p0 must lie inside (else lsqamd_run returns LSQAMD_EINVAL, as scipy raises). */
+int lsqamd_set_bounds(lsqamd_fit *fit, const double *lower, const double *upper);
 int lsqamd_set_reduce(lsqamd_fit *fit, lsqamd_reduce_fn fn, void *user);
 /* Row-sharded fits: exactly one rank (on != 0) contributes the replicated prior
  * terms to the sums before the all-reduce.  Default on. */

@@ -9,7 +9,8 @@ raises.
 
   models     row models the kernels can differentiate (replaces user fcn + gvar AD)
   whiten     host mirror of gvar.PDF: block structure, svdcut, whitening weights
-  fitter     ``mi355x_lm``: the fitter plugin class (mirror of gsl_multifit)
+  fitter     ``mi355x_lm``: the fitter plugin class (mirror of gsl_multifit);
+             ``mi355x_trf``: bounded fits (mirror of scipy_least_squares, method 'trf')
   fit        ``nonlinear_fit``: problem setup + chi2/dof/Q/logGBF reduction
   sweep      ``empbayes_fit`` / prior-width sweeps on one resident problem
   batched    ``BatchedFits``: many same-shape fits in lockstep, device-resident LM state, hipGraph
@@ -18,7 +19,7 @@ raises.
 """
 from .models import Model, cosmix, multiexp, identity, expr  # noqa: F401
 from .whiten import Whitening  # noqa: F401
-from .fitter import mi355x_lm, DeviceProblem, register  # noqa: F401
+from .fitter import mi355x_lm, mi355x_trf, DeviceProblem, register  # noqa: F401
 from .fit import nonlinear_fit, gammaQ  # noqa: F401
 from .sweep import empbayes_fit, prior_width_sweep  # noqa: F401
 from .batched import BatchedFits  # noqa: F401

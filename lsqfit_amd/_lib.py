@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'liblsqfit_amd.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 T_NAMES = ['residual', 'jacobian', 'whiten', 'syrk', 'grad', 'reduce', 'cholesky', 'solve', 'covar']
 
@@ -55,6 +55,7 @@ PROTOTYPES = {
     'lsqamd_set_prior': (C.c_int, [_vp, _dp, _dp]),
     'lsqamd_set_ymean': (C.c_int, [_vp, _dp]),
     'lsqamd_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
+    'lsqamd_set_bounds': (C.c_int, [_vp, _dp, _dp]),
     'lsqamd_set_reduce': (C.c_int, [_vp, REDUCE_FN, _vp]),
     'lsqamd_set_adds_prior': (C.c_int, [_vp, C.c_int32]),
     'lsqamd_run': (C.c_int, [_vp, _dp, C.POINTER(Summary)]),

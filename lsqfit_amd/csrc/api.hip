@@ -93,6 +93,9 @@ struct lsqamd_fit {
   void *reduce_user = nullptr;
   bool adds_prior = true;
 
+  // box bounds of the reflective trust-region method (empty: none)
+  std::vector<double> lb, ub;
+
   // LM state (host)
   std::vector<double> hx, hg, hdiag, hdx, hv, hcoln, htmp;
   double chi2 = 0.0, mu = 0.0, delta = 0.0;
@@ -954,12 +957,390 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
   else if (info == 31) s->stopping_criterion = 2;
   else if (info == 29) s->stopping_criterion = 3;
   else if (info == 27) s->stopping_criterion = 4;
-  else s->stopping_criterion = 0;
+  else if (info >= LSQAMD_INFO_TRF && info <= LSQAMD_INFO_TRF + 4) {
+    static const int map[5] = {0, 2, 3, 1, 1};   // _scipy.py:176-181
+    s->stopping_criterion = map[info - LSQAMD_INFO_TRF];
+  } else s->stopping_criterion = 0;
   s->nit = f->nit; s->nfev = f->nfev; s->njev = f->njev; s->ntrial = f->ntrial;
   s->chol_fail = f->chol_fail;
   s->chi2 = f->chi2;
   s->mu = f->mu;
   s->logdet_jtj = f->logdet;
+}
+
+// ---- Trust Region Reflective with box bounds --------------------------
+// What src/lsqfit/_scipy.py:115-181 gets from scipy.optimize.least_squares(method='trf', bounds=...)
+// (Branch, Coleman and Li), restated on the normal equations this library already forms: scipy's
+// exact sub-problem solver works from the SVD of the scaled, augmented Jacobian (J d | sqrt C);
+// every quantity it takes from that SVD is a function of B = d A d + C with A = J^T J, so here
+//   p(alpha)   = -(A + E)^-1 g,  E = (C + alpha) / d^2           (Cholesky on the device)
+//   phi(alpha) = |p_h| - Delta,  phi' = -p_h.(B + alpha)^-1 p_h / |p_h|   (second solve, same factor)
+// and the model values come from A-products (one device GEMV each) or, for the sub-problem
+// solution itself, from the linear system it satisfies.  Coleman-Li scaling, step selection
+// (cut back / reflected / gradient), radius update and the ftol / xtol / gtol tests are O(P)
+// host work on vectors that are already on the host.
+struct TrfOuter {       // fixed during the trial steps of one outer iteration
+  std::vector<double> d, C, gh, Aag;   // Aag = A (d ag_h), ag_h = -g_h (lazily)
+  bool have_Aag = false;
+  bool gn_tried = false, full_rank = false;
+  std::vector<double> p_gn;            // Gauss-Newton point (original variables)
+  double gn_norm = 0.0, phi0_slope = 0.0;   // |p_gn,h| and phi'(0)
+  double theta = 0.0;
+};
+
+double norm_h(const std::vector<double> &v) { return std::sqrt(dot_h(v, v)); }
+
+// (A + (C + alpha)/d^2) p = -g -> p (original variables); LSQAMD_ENOTPD when the factorisation fails
+int trf_solve(lsqamd_fit *f, const TrfOuter &o, double alpha, std::vector<double> &p) {
+  const int64_t P = f->P;
+  std::vector<double> e(P);
+  for (int64_t j = 0; j < P; ++j) e[j] = std::sqrt((o.C[j] + alpha)) / o.d[j];
+  const int rc = solve_damped_dev(f, 1.0, e.data());
+  if (rc) return rc;
+  for (int64_t j = 0; j < P; ++j) p[j] = -f->hv[j];
+  return 0;
+}
+
+// with the factor of (A + E) still in place: -> p_h.(B + alpha)^-1 p_h  for p_h = p / d
+int trf_slope_term(lsqamd_fit *f, const TrfOuter &o, const std::vector<double> &p, double *out) {
+  const int64_t P = f->P;
+  std::vector<double> rhs(P), z(P);
+  for (int64_t j = 0; j < P; ++j) rhs[j] = p[j] / (o.d[j] * o.d[j]);
+  const int rc = solve_with_factor(f, rhs.data(), z.data());
+  if (rc) return rc;
+  *out = dot_h(rhs, z);
+  return 0;
+}
+
+// solve_lsq_trust_region: p_h with |p_h| <= Delta; *quad = p_h.B p_h of the returned step
+int trf_subproblem(lsqamd_fit *f, TrfOuter &o, double Delta, double *alpha_io, std::vector<double> &p_h,
+                   double *quad) {
+  const int64_t P = f->P;
+  std::vector<double> p(P);
+  auto to_hat = [&](const std::vector<double> &v) { for (int64_t j = 0; j < P; ++j) p_h[j] = v[j] / o.d[j]; };
+  if (!o.gn_tried) {
+    o.gn_tried = true;
+    o.p_gn.assign(P, 0.0);
+    int rc = trf_solve(f, o, 0.0, o.p_gn);
+    if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+    o.full_rank = rc == 0;
+    if (o.full_rank) {
+      to_hat(o.p_gn);
+      o.gn_norm = norm_h(p_h);
+      double t = 0.0;
+      rc = trf_slope_term(f, o, o.p_gn, &t);
+      if (rc) return rc;
+      o.phi0_slope = -t / o.gn_norm;
+    }
+  }
+  if (o.full_rank && o.gn_norm <= Delta) {
+    to_hat(o.p_gn);
+    *alpha_io = 0.0;
+    *quad = -dot_h(f->hg, o.p_gn);          // B p_h = -g_h
+    return 0;
+  }
+  double hi = norm_h(o.gh) / Delta;
+  double lo = o.full_rank ? -(o.gn_norm - Delta) / o.phi0_slope : 0.0;
+  auto restart = [&]() { return std::fmax(0.001 * hi, std::sqrt(lo * hi)); };
+  double alpha = (!o.full_rank && *alpha_io == 0.0) ? restart() : *alpha_io;
+  // A singular B (a dead Jacobian column, say) is where scipy's SVD iteration may wander to
+  // negative shifts; a Cholesky factorisation needs B + alpha positive definite, so the shift is
+  // kept in (lo, hi] and the last successfully factored one is the fallback.
+  double good_alpha = -1.0;
+  for (int it = 0; it < 10; ++it) {
+    if (alpha < lo || alpha > hi || (!o.full_rank && !(alpha > 0.0))) alpha = restart();
+    int rc = trf_solve(f, o, alpha, p);
+    if (rc == LSQAMD_ENOTPD) {               // not positive definite at this shift: move up
+      lo = std::fmax(lo, alpha);
+      alpha = std::fmax(2.0 * alpha, restart());
+      continue;
+    }
+    if (rc) return rc;
+    good_alpha = alpha;
+    to_hat(p);
+    const double pn = norm_h(p_h);
+    double t = 0.0;
+    rc = trf_slope_term(f, o, p, &t);
+    if (rc) return rc;
+    const double phi = pn - Delta, slope = -t / pn;
+    if (phi < 0.0) hi = alpha;
+    const double ratio = phi / slope;
+    lo = std::fmax(lo, alpha - ratio);
+    alpha -= (phi + Delta) * ratio / Delta;
+    if (std::fabs(phi) < 0.01 * Delta) break;
+  }
+  if (!o.full_rank && !(alpha > 0.0)) alpha = good_alpha > 0.0 ? good_alpha : restart();
+  int rc = trf_solve(f, o, alpha, p);
+  if (rc == LSQAMD_ENOTPD && good_alpha >= 0.0 && good_alpha != alpha) {
+    alpha = good_alpha;
+    rc = trf_solve(f, o, alpha, p);
+  }
+  if (rc == LSQAMD_ENOTPD) FAIL(f, LSQAMD_ENOTPD, "trf: the shifted normal matrix is not positive definite");
+  if (rc) return rc;
+  to_hat(p);
+  const double pn = norm_h(p_h);
+  // B p_h = -g_h - alpha p_h before the rescaling onto the boundary
+  double gp = 0.0;
+  for (int64_t j = 0; j < P; ++j) gp += o.gh[j] * p_h[j];
+  const double c = Delta / pn;
+  *quad = c * c * (-gp - alpha * pn * pn);
+  for (int64_t j = 0; j < P; ++j) p_h[j] *= c;
+  *alpha_io = alpha;
+  return 0;
+}
+
+// largest t with x + t s inside the box; hit[j] != 0 where that bound is reached first
+double trf_to_bound(const lsqamd_fit *f, const std::vector<double> &x, const std::vector<double> &s,
+                    std::vector<char> *hit) {
+  const int64_t P = f->P;
+  double t = INFINITY;
+  std::vector<double> steps(P, INFINITY);
+  for (int64_t j = 0; j < P; ++j) {
+    if (s[j] == 0.0) continue;
+    steps[j] = std::fmax((f->lb[j] - x[j]) / s[j], (f->ub[j] - x[j]) / s[j]);
+    if (steps[j] < t) t = steps[j];
+  }
+  if (hit) {
+    hit->assign(P, 0);
+    for (int64_t j = 0; j < P; ++j) (*hit)[j] = (steps[j] == t && s[j] != 0.0) ? 1 : 0;
+  }
+  return t;
+}
+
+void quad_min_1d(double a, double b, double lo, double hi, double c, double *t_out, double *y_out) {
+  double ts[3] = {lo, hi, 0.0};
+  int n = 2;
+  if (a != 0.0) {
+    const double t0 = -0.5 * b / a;
+    if (lo < t0 && t0 < hi) ts[n++] = t0;
+  }
+  int best = 0;
+  double yb = ts[0] * (a * ts[0] + b) + c;
+  for (int k = 1; k < n; ++k) {
+    const double y = ts[k] * (a * ts[k] + b) + c;
+    if (y < yb) { yb = y; best = k; }
+  }
+  *t_out = ts[best];
+  *y_out = yb;
+}
+
+// s_h.B t_h given A (d t_h)
+double trf_curv(const TrfOuter &o, const std::vector<double> &s_h, const std::vector<double> &t_h,
+                const std::vector<double> &A_dt) {
+  double q = 0.0;
+  for (size_t j = 0; j < s_h.size(); ++j) q += o.d[j] * s_h[j] * A_dt[j] + s_h[j] * o.C[j] * t_h[j];
+  return q;
+}
+
+// select_step: step (original variables), step_h, predicted reduction
+int trf_choose_step(lsqamd_fit *f, TrfOuter &o, const std::vector<double> &p_h_in, double quad_pp, double Delta,
+                    std::vector<double> &step, std::vector<double> &step_h, double *predicted) {
+  const int64_t P = f->P;
+  std::vector<double> p(P), p_h(p_h_in);
+  bool inside = true;
+  for (int64_t j = 0; j < P; ++j) {
+    p[j] = o.d[j] * p_h[j];
+    const double xn = f->hx[j] + p[j];
+    if (!(xn >= f->lb[j] && xn <= f->ub[j])) inside = false;
+  }
+  const double g_p = dot_h(o.gh, p_h);
+  if (inside) {
+    step = p; step_h = p_h;
+    *predicted = -(0.5 * quad_pp + g_p);
+    return 0;
+  }
+  std::vector<char> hit;
+  const double t_hit = trf_to_bound(f, f->hx, p, &hit);
+  std::vector<double> r_h(p_h), r(P), x_hit(P), tmp(P), A_r(P);
+  for (int64_t j = 0; j < P; ++j) {
+    if (hit[j]) r_h[j] = -r_h[j];
+    r[j] = o.d[j] * r_h[j];
+    p[j] *= t_hit; p_h[j] *= t_hit;
+    x_hit[j] = f->hx[j] + p[j];
+  }
+  const double pp = t_hit * t_hit * quad_pp, gp = t_hit * g_p;   // p_h.B p_h and g_h.p_h after the cut
+  // exit of the reflected ray from the trust region (intersect_trust_region, larger root)
+  double t_tr;
+  {
+    const double a = dot_h(r_h, r_h), b = dot_h(p_h, r_h), c = dot_h(p_h, p_h) - Delta * Delta;
+    const double disc = std::sqrt(b * b - a * c);
+    const double q = -(b + std::copysign(disc, b));
+    t_tr = std::fmax(q / a, c / q);
+  }
+  const double t_box = trf_to_bound(f, x_hit, r, nullptr);
+  const double t_r = std::fmin(t_box, t_tr);
+  double r_lo = 0.0, r_hi = -1.0;
+  if (t_r > 0.0) {
+    r_lo = (1.0 - o.theta) * t_hit / t_r;
+    r_hi = t_r == t_box ? o.theta * t_box : t_tr;
+  }
+  double r_value = INFINITY;
+  if (r_lo <= r_hi) {
+    for (int64_t j = 0; j < P; ++j) tmp[j] = o.d[j] * r_h[j];
+    const int rc = symv_host(f, tmp.data(), A_r.data());
+    if (rc) return rc;
+    const double rr = trf_curv(o, r_h, r_h, A_r), pr = trf_curv(o, p_h, r_h, A_r);
+    const double a = 0.5 * rr, b = dot_h(o.gh, r_h) + pr, c = 0.5 * pp + gp;
+    double t;
+    quad_min_1d(a, b, r_lo, r_hi, c, &t, &r_value);
+    for (int64_t j = 0; j < P; ++j) {
+      r_h[j] = p_h[j] + t * r_h[j];
+      r[j] = r_h[j] * o.d[j];
+    }
+  }
+  for (int64_t j = 0; j < P; ++j) { p[j] *= o.theta; p_h[j] *= o.theta; }   // strictly interior
+  const double p_value = 0.5 * o.theta * o.theta * pp + o.theta * gp;
+  // scaled anti-gradient
+  std::vector<double> ag_h(P), ag(P);
+  for (int64_t j = 0; j < P; ++j) { ag_h[j] = -o.gh[j]; ag[j] = o.d[j] * ag_h[j]; }
+  if (!o.have_Aag) {
+    o.Aag.assign(P, 0.0);
+    const int rc = symv_host(f, ag.data(), o.Aag.data());
+    if (rc) return rc;
+    o.have_Aag = true;
+  }
+  const double t_tr_ag = Delta / norm_h(ag_h);
+  const double t_box_ag = trf_to_bound(f, f->hx, ag, nullptr);
+  const double t_max = t_box_ag < t_tr_ag ? o.theta * t_box_ag : t_tr_ag;
+  double t_ag, ag_value;
+  quad_min_1d(0.5 * trf_curv(o, ag_h, ag_h, o.Aag), dot_h(o.gh, ag_h), 0.0, t_max, 0.0, &t_ag, &ag_value);
+  if (p_value < r_value && p_value < ag_value) {
+    step = p; step_h = p_h; *predicted = -p_value;
+  } else if (r_value < p_value && r_value < ag_value) {
+    step = r; step_h = r_h; *predicted = -r_value;
+  } else {
+    for (int64_t j = 0; j < P; ++j) { ag[j] *= t_ag; ag_h[j] *= t_ag; }
+    step = ag; step_h = ag_h; *predicted = -ag_value;
+  }
+  return 0;
+}
+
+// make_strictly_feasible
+void trf_feasible(const lsqamd_fit *f, std::vector<double> &x, double rstep) {
+  for (size_t j = 0; j < x.size(); ++j) {
+    const double lb = f->lb[j], ub = f->ub[j];
+    if (rstep == 0.0) {
+      if (x[j] >= ub) x[j] = std::nextafter(ub, lb);
+      else if (x[j] <= lb) x[j] = std::nextafter(lb, ub);
+    } else {
+      const double dlo = x[j] - lb, dhi = ub - x[j];
+      const bool hi = std::isfinite(ub) && dhi <= std::fmin(dlo, rstep * std::fmax(1.0, std::fabs(ub)));
+      const bool lo = std::isfinite(lb) && dlo <= std::fmin(dhi, rstep * std::fmax(1.0, std::fabs(lb)));
+      if (hi) x[j] = ub - rstep * std::fmax(1.0, std::fabs(ub));
+      else if (lo) x[j] = lb + rstep * std::fmax(1.0, std::fabs(lb));
+    }
+    if (x[j] < lb || x[j] > ub) x[j] = 0.5 * (lb + ub);
+  }
+}
+
+// Coleman-Li scaling vector at (x, g): -> v, dv; returns |g v|_inf
+double trf_cl_scaling(const lsqamd_fit *f, std::vector<double> &v, std::vector<double> &dv) {
+  double gn = 0.0;
+  for (int64_t j = 0; j < f->P; ++j) {
+    v[j] = 1.0; dv[j] = 0.0;
+    const double g = f->hg[j];
+    if (g < 0.0 && std::isfinite(f->ub[j])) { v[j] = f->ub[j] - f->hx[j]; dv[j] = -1.0; }
+    if (g > 0.0 && std::isfinite(f->lb[j])) { v[j] = f->hx[j] - f->lb[j]; dv[j] = 1.0; }
+    gn = std::fmax(gn, std::fabs(g * v[j]));
+  }
+  return gn;
+}
+
+// trf_bounds / trf_no_bounds.  *status_out: 0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol and xtol
+int run_trf(lsqamd_fit *f, const double *p0, int *status_out) {
+  const int64_t P = f->P;
+  if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT)
+    FAIL(f, LSQAMD_EINVAL, "trf: x_scale is 1 (scaler levenberg) or 'jac' (scaler more)");
+  if (f->lb.empty()) { f->lb.assign(P, -INFINITY); f->ub.assign(P, INFINITY); }
+  const double xtol = f->opt.xtol, gtol = f->opt.gtol, ftol = f->opt.ftol;
+  const double eps = 2.220446049250313e-16;
+  if (ftol < eps && xtol < eps && gtol < eps)
+    FAIL(f, LSQAMD_EINVAL, "trf: at least one of the tolerances must be higher than machine epsilon");
+  std::vector<double> x0(p0, p0 + P);
+  for (int64_t j = 0; j < P; ++j)
+    if (!(x0[j] >= f->lb[j] && x0[j] <= f->ub[j]))
+      FAIL(f, LSQAMD_EINVAL, "trf: initial guess is outside of provided bounds (parameter %lld)", (long long)j);
+  trf_feasible(f, x0, 1e-10);
+  int rc = do_init(f, x0.data());     // f, J, A = J^T J, g, column norms at x0; nfev = njev = 1
+  if (rc) return rc;
+  const int max_nfev = f->opt.maxit;
+  const bool jac_scale = f->opt.scaler == LSQAMD_SCALE_MORE;   // hdiag = 1 / scale (scale_init / scale_update)
+  std::vector<double> v(P), dv(P), p_h(P), step(P), step_h(P), x_new(P);
+  (void)trf_cl_scaling(f, v, dv);
+  double Delta = 0.0;
+  for (int64_t j = 0; j < P; ++j) {
+    if (dv[j] != 0.0) v[j] *= f->hdiag[j];
+    const double t = f->hx[j] * f->hdiag[j] / std::sqrt(v[j]);
+    Delta += t * t;
+  }
+  Delta = std::sqrt(Delta);
+  if (Delta == 0.0) Delta = 1.0;
+  double alpha = 0.0;
+  int status = -1;
+  TrfOuter o;
+  o.d.resize(P); o.C.resize(P); o.gh.resize(P);
+  while (true) {
+    const double g_norm = trf_cl_scaling(f, v, dv);
+    if (g_norm < gtol) status = 1;
+    if (status >= 0 || f->nfev >= max_nfev) break;
+    for (int64_t j = 0; j < P; ++j) {
+      if (dv[j] != 0.0) v[j] *= f->hdiag[j];
+      o.d[j] = std::sqrt(v[j]) / f->hdiag[j];
+      o.C[j] = f->hg[j] * dv[j] / f->hdiag[j];
+      o.gh[j] = o.d[j] * f->hg[j];
+    }
+    o.have_Aag = false;
+    o.gn_tried = false;
+    o.theta = std::fmax(0.995, 1.0 - g_norm);
+    const double cost = 0.5 * f->chi2;
+    double actual = -1.0, cost_new = cost;
+    while (actual <= 0.0 && f->nfev < max_nfev) {
+      double quad = 0.0, predicted = 0.0;
+      rc = trf_subproblem(f, o, Delta, &alpha, p_h, &quad);
+      if (rc) return rc;
+      rc = trf_choose_step(f, o, p_h, quad, Delta, step, step_h, &predicted);
+      if (rc) return rc;
+      for (int64_t j = 0; j < P; ++j) x_new[j] = f->hx[j] + step[j];
+      trf_feasible(f, x_new, 0.0);
+      std::memcpy(f->pin_x, x_new.data(), sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      double chi2_new = 0.0;
+      rc = eval_residual_dev(f, f->p_trial, &chi2_new);
+      if (rc) return rc;
+      const double sh_norm = norm_h(step_h);
+      if (!std::isfinite(chi2_new)) {
+        Delta = 0.25 * sh_norm;
+        continue;
+      }
+      cost_new = 0.5 * chi2_new;
+      actual = cost - cost_new;
+      double ratio;
+      if (predicted > 0.0) ratio = actual / predicted;
+      else if (predicted == 0.0 && actual == 0.0) ratio = 1.0;
+      else ratio = 0.0;
+      double Delta_new = Delta;
+      if (ratio < 0.25) Delta_new = 0.25 * sh_norm;
+      else if (ratio > 0.75 && sh_norm > 0.95 * Delta) Delta_new = 2.0 * Delta;
+      const bool f_ok = actual < ftol * cost && ratio > 0.25;
+      const bool x_ok = norm_h(step) < xtol * (xtol + norm_h(f->hx));
+      if (f_ok && x_ok) status = 4;
+      else if (f_ok) status = 2;
+      else if (x_ok) status = 3;
+      if (status >= 0) break;
+      alpha *= Delta / Delta_new;
+      Delta = Delta_new;
+    }
+    if (actual > 0.0) {
+      rc = eval_normal_dev(f, f->p_trial);
+      if (rc) return rc;
+      f->hx = x_new;
+      f->hdx = step;
+      std::swap(f->p_dev, f->p_trial);
+      if (jac_scale) scale_update(f);
+    }
+  }
+  *status_out = status < 0 ? 0 : status;
+  return 0;
 }
 
 // covariance + logdet at the current point: factor A (mu = 0), invert
@@ -1189,8 +1570,29 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
   if (opt->solver != LSQAMD_SOLVER_CHOLESKY) FAIL(f, LSQAMD_EUNSUPPORTED, "set_options: only the cholesky solver runs on the device");
   if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
-  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_SUBSPACE2D) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
+  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
   f->opt = *opt;
+  return 0;
+}
+
+int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!lower && !upper) {
+    f->lb.clear();
+    f->ub.clear();
+    return 0;
+  }
+  const int64_t P = f->P;
+  std::vector<double> lb(P, -INFINITY), ub(P, INFINITY);
+  for (int64_t j = 0; j < P; ++j) {
+    if (lower) lb[j] = lower[j];
+    if (upper) ub[j] = upper[j];
+    if (!(lb[j] < ub[j]))
+      FAIL(f, LSQAMD_EINVAL, "set_bounds: each lower bound must be strictly less than each upper bound (parameter %lld)",
+           (long long)j);
+  }
+  f->lb.swap(lb);
+  f->ub.swap(ub);
   return 0;
 }
 
@@ -1216,6 +1618,7 @@ int lsqamd_init(lsqamd_fit *f, const double *p0) {
 int lsqamd_step(lsqamd_fit *f, int32_t *info) {
   if (!f) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_step before lsqamd_init");
+  if (f->opt.trs == LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the trf method runs through lsqamd_run only");
   const int rc = iterate(f);
   if (rc < 0) return rc;
   f->nit++;
@@ -1243,13 +1646,20 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
   (void)hipEventRecord(e0, f->st);
-  int rc = do_init(f, p0);
-  if (rc) return rc;
-  // gsl_multifit_nlinear_driver
+  int rc = 0;
   int iter = 0, info = 0, status = -2;
   bool early = false;
   const int maxit = f->opt.maxit;
-  if (maxit > 0) {
+  if (f->opt.trs == LSQAMD_TRS_TRF) {
+    int st = 0;
+    rc = run_trf(f, p0, &st);
+    if (rc) return rc;
+    f->nit = f->nfev;                      // _scipy.py:161: nit = number of function evaluations
+    info = LSQAMD_INFO_TRF + st;
+    status = 0;
+  } else if ((rc = do_init(f, p0)) != 0) {
+    return rc;
+  } else if (maxit > 0) {  // gsl_multifit_nlinear_driver
     do {
       rc = iterate(f);
       if (rc < 0) return rc;

@@ -15,10 +15,10 @@ import time
 
 import numpy as np
 
-from .fitter import DeviceProblem, mi355x_lm
+from .fitter import DeviceProblem, mi355x_lm, mi355x_trf
 from .whiten import Whitening
 
-FITTERS = {'mi355x_lm': mi355x_lm}
+FITTERS = {'mi355x_lm': mi355x_lm, 'mi355x_trf': mi355x_trf}
 DEFAULTS = dict(tol=1e-8, svdcut=1e-12, maxit=1000, fitter='mi355x_lm')   # __init__.py:100-107
 
 
@@ -115,6 +115,11 @@ class nonlinear_fit(object):
             self.time = clock() - t0
             self.time_setup, self.time_fit = t1 - t0, self.time - (t1 - t0)
             return
+        if fitterargs.get('bounds') is not None:   # __init__.py:641-655: flattened like p0
+            if self.fitter != 'mi355x_trf':
+                raise ValueError("bounds need fitter='mi355x_trf'")
+            lower, upper = fitterargs['bounds']
+            fitterargs['bounds'] = (np.reshape(lower, -1), np.reshape(upper, -1))
         fit = FITTERS[self.fitter](self.p0, nf, self._chiv, tol=tol, maxit=maxit, problem=problem,
                                    **fitterargs)
         self.fitter_results = fit

@@ -23,6 +23,7 @@ from .whiten import Whitening
 
 _SCALERS = dict(more=0, levenberg=1, marquardt=2)
 _ALGS = dict(lm=0, lmaccel=1, dogleg=2, ddogleg=3, subspace2D=4)      # _gsl.pyx:622-635
+_TRF = 5                                                               # LSQAMD_TRS_TRF
 
 
 def _check(lib, h, rc, what):
@@ -178,12 +179,27 @@ class DeviceProblem:
         xtol, gtol, ftol = normalize_tol(tol)
         if scaler not in _SCALERS:
             raise ValueError('unkown scaler ' + str(scaler))
-        if alg not in _ALGS:
+        if alg != 'trf' and alg not in _ALGS:
             raise ValueError('unkown algorithm ' + str(alg))          # _gsl.pyx:634-635
         opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler],
-                           solver=0, trs=_ALGS[alg], factor_up=factor_up, factor_down=factor_down,
-                           avmax=avmax)
+                           solver=0, trs=_TRF if alg == 'trf' else _ALGS[alg], factor_up=factor_up,
+                           factor_down=factor_down, avmax=avmax)
         _check(self.lib, self.h, self.lib.lsqamd_set_options(self.h, C.byref(opt)), 'set_options')
+
+    def set_bounds(self, bounds=None):
+        """(lower, upper) for the 'trf' method, each a scalar or length-P array (+-inf = open);
+        None clears them (src/lsqfit/__init__.py:641-655)."""
+        if bounds is None:
+            rc = self.lib.lsqamd_set_bounds(self.h, None, None)
+        else:
+            if len(bounds) != 2:
+                raise ValueError('`bounds` must contain 2 elements.')
+            lo = np.ascontiguousarray(np.broadcast_to(np.asarray(bounds[0], np.float64).reshape(-1), (self.P,)))
+            hi = np.ascontiguousarray(np.broadcast_to(np.asarray(bounds[1], np.float64).reshape(-1), (self.P,)))
+            rc = self.lib.lsqamd_set_bounds(self.h, _lib.dptr(lo), _lib.dptr(hi))
+        if rc == -1:
+            raise ValueError(self.lib.lsqamd_last_error(self.h).decode())
+        _check(self.lib, self.h, rc, 'set_bounds')
 
     def timing(self, on=True):
         self.lib.lsqamd_timing_enable(self.h, int(on))
@@ -421,8 +437,73 @@ class mi355x_lm(object):
         return self._J
 
 
+class mi355x_trf(mi355x_lm):
+    r"""MI355X counterpart of :class:`lsqfit.scipy_least_squares` (src/lsqfit/_scipy.py:20-181)
+    for its default method, the Trust Region Reflective algorithm with optional box bounds.
+
+    ``x0, n, f, tol, maxit`` as there (``tol`` default ``(1e-8, 1e-8, 1e-8)``, ``maxit`` = cap on
+    function evaluations); ``method`` None or ``'trf'`` (``'dogbox'`` and MINPACK's ``'lm'`` are not
+    rebuilt: ``'lm'`` ignores bounds, use :class:`mi355x_lm`); ``bounds=(lower, upper)``;
+    ``x_scale`` 1.0 or ``'jac'``.  ``nit`` counts function evaluations (:161),
+    ``stopping_criterion`` follows :176-181, ``cov`` is ``inv(J^T J)`` at the fit point (what
+    :165-169 gives for a full-rank Jacobian; a rank-deficient one is an error here).
+    """
+
+    def __init__(self, x0, n, f=None, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method=None, bounds=None,
+                 x_scale=1.0, problem=None):
+        if problem is None:
+            raise ValueError("mi355x_trf needs problem=DeviceProblem(...)")
+        if method not in (None, 'trf'):
+            raise NotImplementedError("mi355x_trf runs method='trf'; got %r" % (method,))
+        if isinstance(x_scale, str):
+            if x_scale != 'jac':
+                raise ValueError("`x_scale` must be 'jac' or 1.0")
+            scaler = 'more'
+        elif np.all(np.asarray(x_scale, float) == 1.0):
+            scaler = 'levenberg'
+        else:
+            raise NotImplementedError("x_scale is 1.0 or 'jac' on the device")
+        if maxit is not None and maxit <= 0:
+            raise ValueError('`max_nfev` must be None or positive integer.')
+        self.tol = normalize_tol(tol)
+        self.maxit = maxit
+        self.method, self.x_scale = 'trf', x_scale
+        self.x0 = np.ascontiguousarray(x0, np.float64)
+        self.n = n
+        self.error = None
+        self.description = 'method = trf'                                  # _scipy.py:134-139
+        pr = self.problem = problem
+        if self.x0.size != pr.P:
+            raise ValueError('len(x0) = %d but the model has %d parameters' % (self.x0.size, pr.P))
+        if n is not None and int(n) != pr.wh.nchiv:
+            raise ValueError('n = %d but the whitened residual has %d entries' % (n, pr.wh.nchiv))
+        pr.set_options(self.tol, 100 * pr.P if maxit is None else maxit, scaler, alg='trf')
+        pr.set_bounds(bounds)
+        lib = pr.lib
+        s = _lib.Summary()
+        try:
+            rc = lib.lsqamd_run(pr.h, _lib.dptr(self.x0), C.byref(s))
+            pr._raise_reduce()
+            if rc == -1:                     # infeasible x0 / tolerances: scipy raises ValueError
+                raise ValueError(lib.lsqamd_last_error(pr.h).decode())
+            _check(lib, pr.h, rc, 'run')
+        finally:
+            pr.set_bounds(None)
+        self.summary = s
+        self.nit = s.nit
+        self.chi2 = s.chi2
+        self.logdet_jtj = s.logdet_jtj
+        self.stopping_criterion = s.stopping_criterion
+        self.status = s.info - 100           # scipy's OptimizeResult.status
+        self.x = pr.get_x()
+        self.cov = pr.get_cov()
+        self.results = None
+        self._f = self._J = None
+
+
 def register(lsqfit_module):
-    """``lsqfit.nonlinear_fit.FITTERS['mi355x_lm'] = mi355x_lm`` when lsqfit is importable
-    (src/lsqfit/__init__.py:110-126,:453)."""
+    """``lsqfit.nonlinear_fit.FITTERS['mi355x_lm'] = mi355x_lm`` (and ``'mi355x_trf'``) when
+    lsqfit is importable (src/lsqfit/__init__.py:110-126,:453)."""
     lsqfit_module.nonlinear_fit.FITTERS['mi355x_lm'] = mi355x_lm
+    lsqfit_module.nonlinear_fit.FITTERS['mi355x_trf'] = mi355x_trf
     return 'mi355x_lm'

@@ -81,7 +81,7 @@ class FitResult:
 
 def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
                   svdcut=1e-12, tol=1e-8, maxit=1000, udata=False, extra_cov=None,
-                  jac=None, **fitterargs):
+                  jac=None, fitter='gsl_multifit', **fitterargs):
     """``fcn(x, p)`` must accept float arrays and ``oracle.dual.Dual`` arrays
     (or pass ``jac(x, p)`` returning d fcn / d p explicitly)."""
     from .dual import Dual
@@ -150,7 +150,14 @@ def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
             sign, ld = np.linalg.slogdet(fit.cov)
             fit.logGBF = 0.5 * (ld - pdf.logdet - fit.chi2 - fit.dof * np.log(2. * np.pi))
         return fit
-    lm = gsl_multifit(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
+    if fitter == 'scipy_least_squares':     # _scipy.py:115-181 (bounds: __init__.py:641-655)
+        from .trf import scipy_least_squares
+        if fitterargs.get('bounds') is not None:
+            lo, hi = fitterargs['bounds']
+            fitterargs['bounds'] = (np.reshape(lo, -1), np.reshape(hi, -1))
+        lm = scipy_least_squares(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
+    else:
+        lm = gsl_multifit(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
     fit.lm = lm
     fit.chiv = chiv
     fit.error = lm.error

@@ -1,0 +1,102 @@
+"""-m "not gpu": the TRF restatement (oracle/trf.py) pinned on scipy itself (same iterates) and on
+the reference's own scipy-plugin tests (tests/test_lsqfit.py:1754-1808,:1811-1838)."""
+import numpy as np
+import pytest
+
+from oracle import fit as ofit
+from oracle import gvar_lite, trf
+
+scipy_opt = pytest.importorskip('scipy.optimize')
+
+
+def exp_problem(seed, m=40, k=3, noise=0.01):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(0.0, 3.0, m)
+    a = rng.uniform(0.5, 1.5, k)
+    e = np.arange(1, k + 1) * 0.7 + rng.uniform(-0.1, 0.1, k)
+    y = (a[:, None] * np.exp(-e[:, None] * t)).sum(0) + noise * rng.standard_normal(m)
+
+    def fun(p):
+        return (p[:k, None] * np.exp(-p[k:, None] * t)).sum(0) - y
+
+    def jac(p):
+        ex = np.exp(-p[k:, None] * t)
+        return np.concatenate([ex, -p[:k, None] * t * ex]).T
+    return fun, jac, np.concatenate([a, e])
+
+
+CASES = []
+for seed in range(6):
+    fun, jac, truth = exp_problem(100 + seed, k=1 + seed % 3)
+    n = truth.size
+    x0 = truth * (1.0 + 0.3 * np.cos(np.arange(n) + seed))
+    lo = np.minimum(truth, x0) - 0.5
+    hi = np.maximum(truth, x0) + 0.5
+    CASES.append(('free%d' % seed, fun, jac, x0, None))
+    CASES.append(('loose%d' % seed, fun, jac, x0, (lo, hi)))
+    # bounds that cut the optimum off: some parameters end on a bound
+    hi2 = hi.copy()
+    hi2[0] = 0.5 * (truth[0] + x0[0]) if x0[0] < truth[0] else hi[0]
+    lo2 = lo.copy()
+    lo2[-1] = 0.5 * (truth[-1] + x0[-1]) if x0[-1] > truth[-1] else lo[-1]
+    CASES.append(('active%d' % seed, fun, jac, x0, (lo2, hi2)))
+    CASES.append(('semi%d' % seed, fun, jac, x0, (lo2, np.full(n, np.inf))))
+
+
+@pytest.mark.parametrize('x_scale', [1.0, 'jac'])
+@pytest.mark.parametrize('name,fun,jac,x0,bounds', CASES, ids=[c[0] for c in CASES])
+def test_same_iterates_as_scipy(name, fun, jac, x0, bounds, x_scale):
+    kw = dict(xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=200, x_scale=x_scale)   # stops above the rounding floor
+    ref = scipy_opt.least_squares(fun, x0, jac=jac, method='trf',
+                                  bounds=(-np.inf, np.inf) if bounds is None else bounds, **kw)
+    got = trf.trf(fun, jac, x0, bounds=bounds, **kw)
+    assert got.nfev == ref.nfev and got.njev == ref.njev and got.status == ref.status
+    np.testing.assert_allclose(got.x, ref.x, rtol=1e-9, atol=1e-12)
+    assert abs(got.cost - ref.cost) <= 1e-9 * ref.cost
+    assert abs(got.optimality - ref.optimality) <= 1e-4 * ref.optimality + 1e-12
+
+
+def test_max_nfev_and_start_on_bound():
+    fun, jac, truth = exp_problem(7, k=2)
+    lo, hi = truth - 1.0, truth + 1.0
+    x0 = truth.copy()
+    x0[0] = lo[0]                       # on the bound: moved 1e-10 inside
+    x0[1] = hi[1]
+    for nmax in (1, 3, 50):
+        ref = scipy_opt.least_squares(fun, x0, jac=jac, bounds=(lo, hi), max_nfev=nmax)
+        got = trf.trf(fun, jac, x0, bounds=(lo, hi), max_nfev=nmax)
+        assert (got.nfev, got.status) == (ref.nfev, ref.status)
+        np.testing.assert_allclose(got.x, ref.x, rtol=1e-9)
+    with pytest.raises(ValueError, match='outside'):
+        trf.trf(fun, jac, truth + 5.0, bounds=(lo, hi))
+    with pytest.raises(ValueError, match='strictly less'):
+        trf.trf(fun, jac, truth, bounds=(hi, lo))
+
+
+def test_reference_scipy_least_squares_case():
+    """tests/test_lsqfit.py:1754-1767: f = (x - xans)^2 + (x - xans)^4, method trf stops on gtol."""
+    xans = np.arange(3) + 1.0
+    f = lambda x: (x - xans) ** 2 + (x - xans) ** 4
+    df = lambda x: np.diag(2 * (x - xans) + 4 * (x - xans) ** 3)
+    ans = trf.scipy_least_squares(np.ones(3), 3, f, df, tol=(1e-15, 1e-8, 1e-15), method='trf')
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 2
+    assert ans.description == 'method = trf'
+
+
+def test_reference_bounds_case():
+    """tests/test_lsqfit.py:1780-1808: data 0.9(1), 2.2(2), fcn(p) = p, bounds [0, 0.5] x [0, 1]:
+    the fit ends on the upper bounds (assertAlmostEqual, 7 places)."""
+    ym, ys = gvar_lite.parse_array(['0.9(1)', '2.2(2)'])
+    fit = ofit.nonlinear_fit(False, ym, ys, lambda p: p, p0=[0.25, 0.5], jac=lambda p: np.eye(2),
+                             fitter='scipy_least_squares', bounds=([0.0, 0.0], [0.5, 1.0]))
+    assert abs(fit.pmean[0] - 0.5) < 5e-8 and abs(fit.pmean[1] - 1.0) < 5e-8
+
+
+def test_reference_fitters_case():
+    """tests/test_lsqfit.py:1811-1838: every fitter prints fit.p = [0.904(98) 2.17(19)]."""
+    ym, ys = gvar_lite.parse_array(['0.9(1)', '2.2(2)'])
+    pm, ps = gvar_lite.parse_array(['1.0(5)', '2.0(5)'])
+    fit = ofit.nonlinear_fit(False, ym, ys, lambda p: p, prior_mean=pm, prior_err=ps, jac=lambda p: np.eye(2),
+                             fitter='scipy_least_squares', method='trf')
+    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
