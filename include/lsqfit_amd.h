@@ -74,12 +74,15 @@ enum { LSQAMD_SOLVER_CHOLESKY = 0 };                                            
 enum { LSQAMD_TRS_LM = 0, LSQAMD_TRS_LMACCEL = 1, LSQAMD_TRS_DOGLEG = 2, LSQAMD_TRS_DDOGLEG = 3,
        LSQAMD_TRS_SUBSPACE2D = 4,
        /* scipy_least_squares' method='trf' (src/lsqfit/_scipy.py:56-60,:135-139): Trust Region
-        * Reflective, the one method that honours lsqamd_set_bounds.  With it: maxit is the cap on
+        * Reflective; honours lsqamd_set_bounds.  With it: maxit is the cap on
         * function evaluations (max_nfev, _scipy.py:157), scaler LEVENBERG = x_scale 1.0 (default
         * there) and MORE = x_scale 'jac', summary.nit counts function evaluations (:161) and
         * summary.info = LSQAMD_INFO_TRF + scipy's status (0 max_nfev, 1 gtol, 2 ftol, 3 xtol,
         * 4 ftol and xtol), mapped to stopping_criterion as at :176-181. */
-       LSQAMD_TRS_TRF = 5 };
+       LSQAMD_TRS_TRF = 5,
+       /* method='dogbox' (_scipy.py:62-63): dogleg in a rectangular trust region with an active set;
+        * same conventions as LSQAMD_TRS_TRF (bounds, maxit, scaler, nit, info). */
+       LSQAMD_TRS_DOGBOX = 6 };
 #define LSQAMD_INFO_TRF 100
 
 /* tape opcodes (LSQAMD_MODEL_TAPE); operands in `arg` */
@@ -191,8 +194,8 @@ int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);
 int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
 /* Box bounds lower[P] < upper[P] (+-INFINITY = open side; NULL array = open everywhere; both
  * NULL clears them): the flattened `bounds` pair nonlinear_fit hands to scipy_least_squares
- * (src/lsqfit/__init__.py:641-655, tests/test_lsqfit.py:1780-1808).  Only LSQAMD_TRS_TRF reads
- * them; p0 must lie inside (else lsqamd_run returns LSQAMD_EINVAL, as scipy raises). */
+ * (src/lsqfit/__init__.py:641-655, tests/test_lsqfit.py:1780-1808).  LSQAMD_TRS_TRF and
+ * LSQAMD_TRS_DOGBOX read them; p0 must lie inside (else lsqamd_run returns LSQAMD_EINVAL, as scipy raises). */
 int lsqamd_set_bounds(lsqamd_fit *fit, const double *lower, const double *upper);
 int lsqamd_set_reduce(lsqamd_fit *fit, lsqamd_reduce_fn fn, void *user);
 /* Row-sharded fits: exactly one rank (on != 0) contributes the replicated prior

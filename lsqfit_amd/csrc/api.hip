@@ -479,18 +479,20 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
 // launches only: factor (A + mu D^2 | g) and back-substitute; v lands in f->yv[P..2P).
 // diag_host == nullptr: D is the device-resident mirror (no host-to-device copy: on this platform
 // an SDMA upload followed by a dependent kernel costs ~100 us of cross-engine synchronisation)
-int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host) {
+// frozen_host (with mu = 0, dogbox): flags of the parameters taken out of the system
+int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
   {
     Scope sc(f, LSQAMD_T_CHOLESKY);
-    const double *dd = f->dscale;
-    if (diag_host) {
-      std::memcpy(f->pin_d, diag_host, sizeof(double) * P);
+    const double *dd = f->dscale, *frozen = nullptr;
+    if (diag_host || frozen_host) {
+      std::memcpy(f->pin_d, diag_host ? diag_host : frozen_host, sizeof(double) * P);
       HIPCHK(f, hipMemcpyAsync(f->diag_dev, f->pin_d, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
-      dd = f->diag_dev;
+      if (diag_host) dd = f->diag_dev;
+      else frozen = f->diag_dev;
     }
-    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M));
+    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M, frozen));
     HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev));
   }
   {
@@ -523,8 +525,8 @@ int solve_damped_collect(lsqamd_fit *f) {
 }
 
 // (A + mu D^2) v = g  -> f->hv ; returns LSQAMD_ENOTPD when a pivot fails
-int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host) {
-  const int rc = solve_damped_launch(f, mu, diag_host);
+int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr) {
+  const int rc = solve_damped_launch(f, mu, diag_host, frozen_host);
   if (rc) return rc;
   HIPCHK(f, hipStreamSynchronize(f->st));
   return solve_damped_collect(f);
@@ -1279,8 +1281,10 @@ int run_trf(lsqamd_fit *f, const double *p0, int *status_out) {
   int status = -1;
   TrfOuter o;
   o.d.resize(P); o.C.resize(P); o.gh.resize(P);
+  const bool trace = std::getenv("LSQAMD_TRF_TRACE") != nullptr;   // developer knob
   while (true) {
     const double g_norm = trf_cl_scaling(f, v, dv);
+    if (trace) fprintf(stderr, "trf nfev %d cost %.12e optimality %.3e Delta %.3e alpha %.3e\n", f->nfev, 0.5 * f->chi2, g_norm, Delta, alpha);
     if (g_norm < gtol) status = 1;
     if (status >= 0 || f->nfev >= max_nfev) break;
     for (int64_t j = 0; j < P; ++j) {
@@ -1323,6 +1327,7 @@ int run_trf(lsqamd_fit *f, const double *p0, int *status_out) {
       else if (ratio > 0.75 && sh_norm > 0.95 * Delta) Delta_new = 2.0 * Delta;
       const bool f_ok = actual < ftol * cost && ratio > 0.25;
       const bool x_ok = norm_h(step) < xtol * (xtol + norm_h(f->hx));
+      if (trace) fprintf(stderr, "    trial: actual %.3e predicted %.3e ratio %.3f |step_h| %.3e Delta %.3e -> %.3e\n", actual, predicted, ratio, sh_norm, Delta, Delta_new);
       if (f_ok && x_ok) status = 4;
       else if (f_ok) status = 2;
       else if (x_ok) status = 3;
@@ -1331,6 +1336,181 @@ int run_trf(lsqamd_fit *f, const double *p0, int *status_out) {
       Delta = Delta_new;
     }
     if (actual > 0.0) {
+      rc = eval_normal_dev(f, f->p_trial);
+      if (rc) return rc;
+      f->hx = x_new;
+      f->hdx = step;
+      std::swap(f->p_dev, f->p_trial);
+      if (jac_scale) scale_update(f);
+    }
+  }
+  *status_out = status < 0 ? 0 : status;
+  return 0;
+}
+
+// ---- dogbox: dogleg in a rectangular trust region with an active set ----------
+// scipy_least_squares' method='dogbox' (src/lsqfit/_scipy.py:62-63; scipy optimize/_lsq/dogbox.py).
+// Per outer iteration the device does ONE factorisation -- the Gauss-Newton step of the free
+// parameters, (A_ff) n = -g_f, as the full system with the active rows/columns replaced by the
+// identity -- and one A g product for the Cauchy step; every trial step lies in span(n, g), so its
+// predicted reduction follows from three scalars (n.A n = -n.g, n.A g = -g.g, g.A g) and a
+// trial costs one residual evaluation.
+void dogbox_step(const std::vector<double> &x, const std::vector<double> &newton, const std::vector<double> &g,
+                 const std::vector<char> &free_set, double a, double b, double Delta,
+                 const std::vector<double> &scale_inv, const std::vector<double> &lb, const std::vector<double> &ub,
+                 std::vector<double> &step, std::vector<int> &lands, bool *tr_hit, double *alpha_n, double *beta_g) {
+  const size_t P = x.size();
+  std::vector<double> lo_t(P), hi_t(P), lo_c(P), hi_c(P), trb(P);
+  bool newton_inside = true;
+  for (size_t j = 0; j < P; ++j) {
+    lands[j] = 0;
+    step[j] = 0.0;
+    if (!free_set[j]) continue;
+    trb[j] = Delta / scale_inv[j];
+    lo_c[j] = lb[j] - x[j]; hi_c[j] = ub[j] - x[j];
+    lo_t[j] = std::fmax(lo_c[j], -trb[j]); hi_t[j] = std::fmin(hi_c[j], trb[j]);
+    if (!(newton[j] >= lo_t[j] && newton[j] <= hi_t[j])) newton_inside = false;
+  }
+  *tr_hit = false;
+  if (newton_inside) {
+    for (size_t j = 0; j < P; ++j) if (free_set[j]) step[j] = newton[j];
+    *alpha_n = 1.0; *beta_g = 0.0;
+    return;
+  }
+  // largest t with t * (-g) inside the region
+  double t_max = INFINITY;
+  for (size_t j = 0; j < P; ++j) {
+    if (!free_set[j] || g[j] == 0.0) continue;
+    const double s = -g[j];
+    t_max = std::fmin(t_max, std::fmax(lo_t[j] / s, hi_t[j] / s));
+  }
+  double t_c, y;
+  quad_min_1d(a, b, 0.0, t_max, 0.0, &t_c, &y);
+  // from the Cauchy point towards the Newton point until the region's edge
+  double t = INFINITY;
+  std::vector<double> steps(P, INFINITY);
+  for (size_t j = 0; j < P; ++j) {
+    if (!free_set[j]) continue;
+    const double c = -t_c * g[j], dj = newton[j] - c;
+    if (dj == 0.0) continue;
+    steps[j] = std::fmax((lo_t[j] - c) / dj, (hi_t[j] - c) / dj);
+    if (steps[j] < t) t = steps[j];
+  }
+  for (size_t j = 0; j < P; ++j) {
+    if (!free_set[j]) continue;
+    const double c = -t_c * g[j], dj = newton[j] - c;
+    step[j] = c + t * dj;
+    if (steps[j] == t && dj != 0.0) {
+      if (dj < 0.0) {
+        if (lo_t[j] == lo_c[j]) lands[j] = -1;
+        if (lo_t[j] == -trb[j]) *tr_hit = true;
+      } else {
+        if (hi_t[j] == hi_c[j]) lands[j] = 1;
+        if (hi_t[j] == trb[j]) *tr_hit = true;
+      }
+    }
+  }
+  *alpha_n = t;
+  *beta_g = -t_c * (1.0 - t);
+}
+
+int run_dogbox(lsqamd_fit *f, const double *p0, int *status_out) {
+  const int64_t P = f->P;
+  if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT)
+    FAIL(f, LSQAMD_EINVAL, "dogbox: x_scale is 1 (scaler levenberg) or 'jac' (scaler more)");
+  if (f->lb.empty()) { f->lb.assign(P, -INFINITY); f->ub.assign(P, INFINITY); }
+  const double xtol = f->opt.xtol, gtol = f->opt.gtol, ftol = f->opt.ftol;
+  const double eps = 2.220446049250313e-16;
+  if (ftol < eps && xtol < eps && gtol < eps)
+    FAIL(f, LSQAMD_EINVAL, "dogbox: at least one of the tolerances must be higher than machine epsilon");
+  for (int64_t j = 0; j < P; ++j)
+    if (!(p0[j] >= f->lb[j] && p0[j] <= f->ub[j]))
+      FAIL(f, LSQAMD_EINVAL, "dogbox: initial guess is outside of provided bounds (parameter %lld)", (long long)j);
+  int rc = do_init(f, p0);
+  if (rc) return rc;
+  const int max_nfev = f->opt.maxit;
+  const bool jac_scale = f->opt.scaler == LSQAMD_SCALE_MORE;   // hdiag = 1 / scale
+  double Delta = 0.0;
+  for (int64_t j = 0; j < P; ++j) Delta = std::fmax(Delta, std::fabs(f->hx[j] * f->hdiag[j]));
+  if (Delta == 0.0) Delta = 1.0;
+  std::vector<int> on_bound(P, 0), lands(P, 0);
+  for (int64_t j = 0; j < P; ++j) {
+    if (f->hx[j] == f->lb[j]) on_bound[j] = -1;
+    if (f->hx[j] == f->ub[j]) on_bound[j] = 1;
+  }
+  std::vector<char> free_set(P, 1);
+  std::vector<double> gz(P), frozen(P), newton(P), Ag(P), step(P), x_new(P);
+  int status = -1;
+  while (true) {
+    bool any_active = false;
+    double g_norm = 0.0;
+    for (int64_t j = 0; j < P; ++j) {
+      const bool active = on_bound[j] * f->hg[j] < 0.0;
+      free_set[j] = !active;
+      frozen[j] = active ? 1.0 : 0.0;
+      any_active |= active;
+      gz[j] = active ? 0.0 : f->hg[j];
+      g_norm = std::fmax(g_norm, std::fabs(gz[j]));
+    }
+    if (g_norm < gtol) status = 1;
+    if (status >= 0 || f->nfev >= max_nfev) break;
+    rc = solve_damped_dev(f, 0.0, nullptr, any_active ? frozen.data() : nullptr);
+    if (rc == LSQAMD_ENOTPD)
+      FAIL(f, LSQAMD_ENOTPD, "dogbox: J^T J of the free parameters is not positive definite (rank-deficient Jacobian)");
+    if (rc) return rc;
+    for (int64_t j = 0; j < P; ++j) newton[j] = free_set[j] ? -f->hv[j] : 0.0;
+    rc = symv_host(f, gz.data(), Ag.data());
+    if (rc) return rc;
+    const double gAg = dot_h(gz, Ag), gg = dot_h(gz, gz), ng = dot_h(newton, gz);
+    const double a = 0.5 * gAg, b = -gg;
+    const double nAn = -ng, nAg = -gg;      // (A n)_free = -g_free
+    const double cost = 0.5 * f->chi2;
+    double actual = -1.0;
+    while (actual <= 0.0 && f->nfev < max_nfev) {
+      bool tr_hit = false;
+      double al = 0.0, be = 0.0;
+      dogbox_step(f->hx, newton, gz, free_set, a, b, Delta, f->hdiag, f->lb, f->ub, step, lands, &tr_hit, &al, &be);
+      // step = al n + be g on the free set
+      const double sAs = al * al * nAn + 2.0 * al * be * nAg + be * be * gAg;
+      const double predicted = -(0.5 * sAs + al * ng + be * gg);
+      double sh_norm = 0.0, s_norm = 0.0;
+      for (int64_t j = 0; j < P; ++j) {
+        x_new[j] = std::fmin(std::fmax(f->hx[j] + step[j], f->lb[j]), f->ub[j]);
+        sh_norm = std::fmax(sh_norm, std::fabs(step[j] * f->hdiag[j]));
+        s_norm += step[j] * step[j];
+      }
+      s_norm = std::sqrt(s_norm);
+      std::memcpy(f->pin_x, x_new.data(), sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      double chi2_new = 0.0;
+      rc = eval_residual_dev(f, f->p_trial, &chi2_new);
+      if (rc) return rc;
+      if (!std::isfinite(chi2_new)) {
+        Delta = 0.25 * sh_norm;
+        continue;
+      }
+      actual = cost - 0.5 * chi2_new;
+      double ratio;
+      if (predicted > 0.0) ratio = actual / predicted;
+      else if (predicted == 0.0 && actual == 0.0) ratio = 1.0;
+      else ratio = 0.0;
+      if (ratio < 0.25) Delta = 0.25 * sh_norm;
+      else if (ratio > 0.75 && tr_hit) Delta *= 2.0;
+      const bool f_ok = actual < ftol * cost && ratio > 0.25;
+      const bool x_ok = s_norm < xtol * (xtol + norm_h(f->hx));
+      if (f_ok && x_ok) status = 4;
+      else if (f_ok) status = 2;
+      else if (x_ok) status = 3;
+      if (status >= 0) break;
+    }
+    if (actual > 0.0) {
+      for (int64_t j = 0; j < P; ++j) {
+        if (free_set[j]) on_bound[j] = lands[j];
+        if (on_bound[j] == -1) x_new[j] = f->lb[j];
+        if (on_bound[j] == 1) x_new[j] = f->ub[j];
+      }
+      std::memcpy(f->pin_x, x_new.data(), sizeof(double) * P);   // variables set exactly on their walls
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
       rc = eval_normal_dev(f, f->p_trial);
       if (rc) return rc;
       f->hx = x_new;
@@ -1570,7 +1750,7 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
   if (opt->solver != LSQAMD_SOLVER_CHOLESKY) FAIL(f, LSQAMD_EUNSUPPORTED, "set_options: only the cholesky solver runs on the device");
   if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
-  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
+  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_DOGBOX) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
   f->opt = *opt;
   return 0;
 }
@@ -1618,7 +1798,7 @@ int lsqamd_init(lsqamd_fit *f, const double *p0) {
 int lsqamd_step(lsqamd_fit *f, int32_t *info) {
   if (!f) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_step before lsqamd_init");
-  if (f->opt.trs == LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the trf method runs through lsqamd_run only");
+  if (f->opt.trs >= LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the trf / dogbox methods run through lsqamd_run only");
   const int rc = iterate(f);
   if (rc < 0) return rc;
   f->nit++;
@@ -1650,9 +1830,9 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   int iter = 0, info = 0, status = -2;
   bool early = false;
   const int maxit = f->opt.maxit;
-  if (f->opt.trs == LSQAMD_TRS_TRF) {
+  if (f->opt.trs == LSQAMD_TRS_TRF || f->opt.trs == LSQAMD_TRS_DOGBOX) {
     int st = 0;
-    rc = run_trf(f, p0, &st);
+    rc = f->opt.trs == LSQAMD_TRS_TRF ? run_trf(f, p0, &st) : run_dogbox(f, p0, &st);
     if (rc) return rc;
     f->nit = f->nfev;                      // _scipy.py:161: nit = number of function evaluations
     info = LSQAMD_INFO_TRF + st;

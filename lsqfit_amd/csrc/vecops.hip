@@ -295,10 +295,11 @@ hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int3
 }
 
 // ---- packed tiles -> dense working copies ------------------------------------------------------
-// M[i][j] = A[i][j] + mu d_i^2 [i==j] for the upper tiles; M[i][P] = g[i]
+// M[i][j] = A[i][j] + mu d_i^2 [i==j] for the upper tiles; M[i][P] = g[i].  frozen (nullable):
+// parameters with frozen[i] != 0 are taken out of the system (unit row/column, zero right-hand side)
 __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, int64_t P, int64_t T,
                                                            int64_t ld, double mu, const double *diag,
-                                                           const double *g, double *M) {
+                                                           const double *g, double *M, const double *frozen) {
   int64_t t = blockIdx.x, tm = 0;
   while (t >= T - tm) { t -= T - tm; ++tm; }
   const int64_t tn = tm + t;
@@ -313,17 +314,18 @@ __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, in
         const double d = diag[i];
         v += mu * d * d;
       }
+      if (frozen && (frozen[i] != 0.0 || frozen[j] != 0.0)) v = i == j ? 1.0 : 0.0;
       M[i * ld + j] = v;
     }
-    if (tn == T - 1 && c == 0 && i < P && g) M[i * ld + P] = g[i];
+    if (tn == T - 1 && c == 0 && i < P && g) M[i * ld + P] = (frozen && frozen[i] != 0.0) ? 0.0 : g[i];
   }
 }
 
 hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
-                               const double *diag, const double *g, double *Mout) {
+                               const double *diag, const double *g, double *Mout, const double *frozen) {
   const int64_t T = (P + TB - 1) / TB;
   dim3 grid((unsigned)(T * (T + 1) / 2), 16);
-  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout);
+  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout, frozen);
   return hipGetLastError();
 }
 

@@ -23,7 +23,7 @@ from .whiten import Whitening
 
 _SCALERS = dict(more=0, levenberg=1, marquardt=2)
 _ALGS = dict(lm=0, lmaccel=1, dogleg=2, ddogleg=3, subspace2D=4)      # _gsl.pyx:622-635
-_TRF = 5                                                               # LSQAMD_TRS_TRF
+_BOUNDED = dict(trf=5, dogbox=6)                                      # LSQAMD_TRS_TRF, _DOGBOX
 
 
 def _check(lib, h, rc, what):
@@ -179,10 +179,10 @@ class DeviceProblem:
         xtol, gtol, ftol = normalize_tol(tol)
         if scaler not in _SCALERS:
             raise ValueError('unkown scaler ' + str(scaler))
-        if alg != 'trf' and alg not in _ALGS:
+        if alg not in _BOUNDED and alg not in _ALGS:
             raise ValueError('unkown algorithm ' + str(alg))          # _gsl.pyx:634-635
         opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler],
-                           solver=0, trs=_TRF if alg == 'trf' else _ALGS[alg], factor_up=factor_up,
+                           solver=0, trs=_BOUNDED[alg] if alg in _BOUNDED else _ALGS[alg], factor_up=factor_up,
                            factor_down=factor_down, avmax=avmax)
         _check(self.lib, self.h, self.lib.lsqamd_set_options(self.h, C.byref(opt)), 'set_options')
 
@@ -439,11 +439,12 @@ class mi355x_lm(object):
 
 class mi355x_trf(mi355x_lm):
     r"""MI355X counterpart of :class:`lsqfit.scipy_least_squares` (src/lsqfit/_scipy.py:20-181)
-    for its default method, the Trust Region Reflective algorithm with optional box bounds.
+    for the two methods that honour box bounds: the Trust Region Reflective algorithm (default)
+    and the dogleg method in a rectangular trust region.
 
     ``x0, n, f, tol, maxit`` as there (``tol`` default ``(1e-8, 1e-8, 1e-8)``, ``maxit`` = cap on
-    function evaluations); ``method`` None or ``'trf'`` (``'dogbox'`` and MINPACK's ``'lm'`` are not
-    rebuilt: ``'lm'`` ignores bounds, use :class:`mi355x_lm`); ``bounds=(lower, upper)``;
+    function evaluations); ``method`` None / ``'trf'`` or ``'dogbox'`` (MINPACK's ``'lm'`` is not
+    rebuilt: it ignores bounds, use :class:`mi355x_lm`); ``bounds=(lower, upper)``;
     ``x_scale`` 1.0 or ``'jac'``.  ``nit`` counts function evaluations (:161),
     ``stopping_criterion`` follows :176-181, ``cov`` is ``inv(J^T J)`` at the fit point (what
     :165-169 gives for a full-rank Jacobian; a rank-deficient one is an error here).
@@ -453,8 +454,10 @@ class mi355x_trf(mi355x_lm):
                  x_scale=1.0, problem=None):
         if problem is None:
             raise ValueError("mi355x_trf needs problem=DeviceProblem(...)")
-        if method not in (None, 'trf'):
-            raise NotImplementedError("mi355x_trf runs method='trf'; got %r" % (method,))
+        if method is None:
+            method = 'trf'                                                 # _scipy.py:135-139
+        if method not in _BOUNDED:
+            raise NotImplementedError("mi355x_trf runs method 'trf' or 'dogbox'; got %r" % (method,))
         if isinstance(x_scale, str):
             if x_scale != 'jac':
                 raise ValueError("`x_scale` must be 'jac' or 1.0")
@@ -467,17 +470,17 @@ class mi355x_trf(mi355x_lm):
             raise ValueError('`max_nfev` must be None or positive integer.')
         self.tol = normalize_tol(tol)
         self.maxit = maxit
-        self.method, self.x_scale = 'trf', x_scale
+        self.method, self.x_scale = method, x_scale
         self.x0 = np.ascontiguousarray(x0, np.float64)
         self.n = n
         self.error = None
-        self.description = 'method = trf'                                  # _scipy.py:134-139
+        self.description = 'method = {}'.format(method)                    # _scipy.py:134-139
         pr = self.problem = problem
         if self.x0.size != pr.P:
             raise ValueError('len(x0) = %d but the model has %d parameters' % (self.x0.size, pr.P))
         if n is not None and int(n) != pr.wh.nchiv:
             raise ValueError('n = %d but the whitened residual has %d entries' % (n, pr.wh.nchiv))
-        pr.set_options(self.tol, 100 * pr.P if maxit is None else maxit, scaler, alg='trf')
+        pr.set_options(self.tol, 100 * pr.P if maxit is None else maxit, scaler, alg=method)
         pr.set_bounds(bounds)
         lib = pr.lib
         s = _lib.Summary()

@@ -327,19 +327,156 @@ def trf(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=Non
     return res
 
 
+def _dogleg_in_box(x, newton, g, a, b, tr, lb, ub):
+    """Dogleg step inside the intersection of the box with the rectangular trust region |s_i| <= tr_i.
+    -> (step, which original bound each coordinate lands on (-1, 0, 1), trust region hit?)"""
+    lo_c, hi_c = lb - x, ub - x
+    lo_t, hi_t = np.maximum(lo_c, -tr), np.minimum(hi_c, tr)
+    lands = np.zeros(x.shape, dtype=int)
+    if np.all((newton >= lo_t) & (newton <= hi_t)):
+        return newton, lands, False
+    zero = np.zeros_like(x)
+    t_max, _ = to_bound(zero, -g, lo_t, hi_t)
+    t, _ = quad_min_1d(a, b, 0.0, t_max)
+    cauchy = -t * g
+    diff = newton - cauchy
+    t, hits = to_bound(cauchy, diff, lo_t, hi_t)
+    lands[(hits < 0) & (lo_t == lo_c)] = -1
+    lands[(hits > 0) & (hi_t == hi_c)] = 1
+    tr_hit = bool(np.any(((hits < 0) & (lo_t == -tr)) | ((hits > 0) & (hi_t == tr))))
+    return cauchy + t * diff, lands, tr_hit
+
+
+def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=None, x_scale=1.0):
+    """Counterpart of ``least_squares(..., method='dogbox')`` (dense Jacobian, linear loss): dogleg
+    steps in a rectangular trust region, variables that reach a wall with the gradient pushing
+    outwards leave the active problem (optimize/_lsq/dogbox.py)."""
+    x0 = np.atleast_1d(np.asarray(x0, float))
+    n = x0.size
+    if bounds is None:
+        lb, ub = np.full(n, -np.inf), np.full(n, np.inf)
+    else:
+        lb = np.broadcast_to(np.asarray(bounds[0], float), (n,)).copy()
+        ub = np.broadcast_to(np.asarray(bounds[1], float), (n,)).copy()
+    if np.any(lb >= ub):
+        raise ValueError('Each lower bound must be strictly less than each upper bound.')
+    if not np.all((x0 >= lb) & (x0 <= ub)):
+        raise ValueError('Initial guess is outside of provided bounds')
+    if ftol < EPS and xtol < EPS and gtol < EPS:
+        raise ValueError('At least one of the tolerances must be higher than machine epsilon')
+    x = x0.copy()
+    f = np.atleast_1d(np.asarray(fun(x), float))
+    if not np.all(np.isfinite(f)):
+        raise ValueError('Residuals are not finite in the initial point.')
+    nfev = njev = 1
+    J = np.atleast_2d(np.asarray(jac(x), float))
+    cost = 0.5 * (f @ f)
+    g = J.T @ f
+    jac_scale = isinstance(x_scale, str) and x_scale == 'jac'
+
+    def jscale(J, old=None):
+        si = np.sum(J ** 2, axis=0) ** 0.5
+        if old is None:
+            si[si == 0] = 1.0
+        else:
+            si = np.maximum(si, old)
+        return 1.0 / si, si
+
+    if jac_scale:
+        scale, scale_inv = jscale(J)
+    else:
+        scale = np.broadcast_to(np.asarray(x_scale, float), (n,)).copy()
+        scale_inv = 1.0 / scale
+    Delta = np.linalg.norm(x0 * scale_inv, ord=np.inf)
+    if Delta == 0:
+        Delta = 1.0
+    on_bound = np.zeros(n, dtype=int)
+    on_bound[x0 == lb] = -1
+    on_bound[x0 == ub] = 1
+    if max_nfev is None:
+        max_nfev = 100 * n
+    status = None
+    g_norm = None
+    while True:
+        active = on_bound * g < 0
+        free = ~active
+        g_full = g.copy()
+        g = g.copy()
+        g[active] = 0.0
+        g_norm = np.linalg.norm(g, ord=np.inf)
+        if g_norm < gtol:
+            status = 1
+        if status is not None or nfev == max_nfev:
+            break
+        Jf, gf = J[:, free], g[free]
+        newton = np.linalg.lstsq(Jf, -f, rcond=-1)[0]
+        v = Jf @ gf
+        a, b = 0.5 * (v @ v), -(gf @ gf)           # model along -g_free
+        actual = -1.0
+        while actual <= 0 and nfev < max_nfev:
+            sf, lands, tr_hit = _dogleg_in_box(x[free], newton, gf, a, b, Delta * scale[free], lb[free], ub[free])
+            step = np.zeros(n)
+            step[free] = sf
+            Js = Jf @ sf
+            predicted = -(0.5 * (Js @ Js) + gf @ sf)
+            x_new = np.clip(x + step, lb, ub)
+            f_new = np.atleast_1d(np.asarray(fun(x_new), float))
+            nfev += 1
+            sh_norm = np.linalg.norm(step * scale_inv, ord=np.inf)
+            if not np.all(np.isfinite(f_new)):
+                Delta = 0.25 * sh_norm
+                continue
+            cost_new = 0.5 * (f_new @ f_new)
+            actual = cost - cost_new
+            if predicted > 0:
+                ratio = actual / predicted
+            elif predicted == actual == 0:
+                ratio = 1.0
+            else:
+                ratio = 0.0
+            if ratio < 0.25:
+                Delta = 0.25 * sh_norm
+            elif ratio > 0.75 and tr_hit:
+                Delta *= 2.0
+            f_ok = actual < ftol * cost and ratio > 0.25
+            x_ok = np.linalg.norm(step) < xtol * (xtol + np.linalg.norm(x))
+            status = 4 if (f_ok and x_ok) else 2 if f_ok else 3 if x_ok else None
+            if status is not None:
+                break
+        if actual > 0:
+            on_bound[free] = lands
+            x = x_new
+            x[on_bound == -1] = lb[on_bound == -1]
+            x[on_bound == 1] = ub[on_bound == 1]
+            f, cost = f_new, cost_new
+            J = np.atleast_2d(np.asarray(jac(x), float))
+            njev += 1
+            g = J.T @ f
+            if jac_scale:
+                scale, scale_inv = jscale(J, scale_inv)
+        else:
+            g = g_full
+    res = TRFResult()
+    res.x, res.cost, res.fun, res.jac, res.grad = x, cost, f, J, g_full
+    res.optimality, res.nfev, res.njev = g_norm, nfev, njev
+    res.status = 0 if status is None else status
+    res.active_mask = on_bound
+    return res
+
+
 def scipy_least_squares(x0, n, f, df, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method=None, bounds=None,
                         x_scale=1.0):
     """Counterpart of ``lsqfit.scipy_least_squares`` (src/lsqfit/_scipy.py:115-181) for
     method 'trf', with an explicit Jacobian callback in place of the GVar trick."""
     from .lm import normalize_tol
-    if method not in (None, 'trf'):
-        raise NotImplementedError('the oracle restates method="trf" only')
+    if method not in (None, 'trf', 'dogbox'):
+        raise NotImplementedError('the oracle restates methods "trf" and "dogbox" (MINPACK "lm" is not)')
     tol = normalize_tol(tol)
-    fit = trf(f, df, x0, bounds=bounds, xtol=tol[0], gtol=tol[1], ftol=tol[2], max_nfev=maxit,
-              x_scale=x_scale)
+    fit = (dogbox if method == 'dogbox' else trf)(f, df, x0, bounds=bounds, xtol=tol[0], gtol=tol[1],
+                                                  ftol=tol[2], max_nfev=maxit, x_scale=x_scale)
     res = TRFResult()
     res.tol = tol
-    res.description = 'method = trf'
+    res.description = 'method = {}'.format('trf' if method is None else method)      # :134-139
     res.x = fit.x
     res.f = np.asarray(f(res.x), float)
     res.J = np.asarray(df(res.x), float)

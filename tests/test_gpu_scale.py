@@ -186,6 +186,53 @@ def test_config4_full_size_fit_properties(amd, c4):
     pr.close()
 
 
+def test_config4_full_size_reflective_method(amd, c4):
+    """fitter='mi355x_trf' at N=65536, P=4096 through size-independent properties:
+    (1) unbounded, it lands on the LM optimum (same chi2, parameters to a small fraction of their
+    errors, same covariance); (2) with a finite box that stays inactive (Coleman-Li scaling and its
+    diagonal term switched on for every amplitude) it still does; (3) with 48 walls that cut the
+    optimum off, every iterate is strictly inside the box and chi2 only goes down -- scipy's
+    method itself needs hundreds of evaluations on this problem (tools/trace_trf.py), so (3) is
+    stopped after 40 and first-order optimality is checked at the sizes the oracle can follow
+    (tests/test_gpu_trf.py)."""
+    d, wh = c4
+    P, K = 4096, 2048
+    rng = np.random.default_rng(8)
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    data = (d['x'], d['ymean'], d['yerr'])
+    lm = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=d['p0'], problem=pr, tol=1e-12)
+    tol = (1e-14, 1e-10, 1e-10)
+    free = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=d['p0'], problem=pr,
+                             fitter='mi355x_trf', tol=tol)
+    assert free.stopping_criterion != 0 and free.nit < 15
+    assert abs(free.chi2 / lm.chi2 - 1) < 1e-8
+    assert np.max(np.abs(free.pmean - lm.pmean) / lm.psdev) < 1e-2
+    assert gu.relmax(free.cov, lm.cov) < 1e-6
+    lo = np.concatenate([lm.pmean[:K] - 0.6, np.full(K, -np.inf)])
+    hi = np.concatenate([lm.pmean[:K] + 0.6, np.full(K, np.inf)])
+    near = lm.pmean + 0.5 * lm.psdev * rng.standard_normal(P)     # (far from the optimum the Coleman-Li
+    # term |g| swamps the curvature of every boxed parameter and the method crawls, in scipy too)
+    boxed = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=near, problem=pr,
+                              fitter='mi355x_trf', tol=tol, bounds=(lo, hi), maxit=60)
+    assert boxed.stopping_criterion != 0, boxed.nit
+    assert abs(boxed.chi2 / lm.chi2 - 1) < 1e-8
+    assert np.max(np.abs(boxed.pmean - lm.pmean) / lm.psdev) < 1e-2
+    walled = rng.choice(K, 48, replace=False)
+    hi[walled[:24]] = lm.pmean[walled[:24]] - 0.5 * lm.psdev[walled[:24]]
+    lo[walled[24:]] = lm.pmean[walled[24:]] + 0.5 * lm.psdev[walled[24:]]
+    p0 = d['p0'].copy()
+    p0[:K] = np.clip(p0[:K], lo[:K] + 0.05, hi[:K] - 0.05)
+    chi2_prev = pr.chi2(p0)
+    for maxit in (10, 40):
+        fit = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=p0, problem=pr,
+                                fitter='mi355x_trf', tol=tol, bounds=(lo, hi), maxit=maxit)
+        assert fit.nit == maxit and fit.stopping_criterion == 0
+        assert np.all(fit.pmean > lo) and np.all(fit.pmean < hi)
+        assert lm.chi2 < fit.chi2 < chi2_prev
+        chi2_prev = fit.chi2
+    pr.close()
+
+
 def test_lm_descent_is_monotone(amd):
     """Every accepted LM step lowers chi2 (trust_eval_step: rho > 0), far from the minimum."""
     import ctypes as C

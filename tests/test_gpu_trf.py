@@ -64,27 +64,33 @@ def bounds_for(kind, truth, p0):
     return lo2, np.where(hi2 < hi, hi2, np.inf)                                   # 'semi': open elsewhere
 
 
+@pytest.mark.parametrize('method', ['trf', 'dogbox'])
 @pytest.mark.parametrize('x_scale', [1.0, 'jac'])
 @pytest.mark.parametrize('kind', ['free', 'loose', 'active', 'semi'])
 @pytest.mark.parametrize('seed,K', [(1, 1), (2, 2), (3, 3)])
-def test_trf_matches_oracle(amd, seed, K, kind, x_scale):
+def test_trf_matches_oracle(amd, seed, K, kind, x_scale, method):
     x, y, ysd, pm, psd, truth, fcn, jac = multiexp_case(seed, K)
     p0 = pm * (1.0 + 0.2 * np.cos(np.arange(2 * K) + seed))
     b = bounds_for(kind, truth, p0)
-    kw = dict(tol=(1e-8, 1e-8, 1e-8), maxit=300, x_scale=x_scale)
+    kw = dict(tol=(1e-8, 1e-8, 1e-8), maxit=300, x_scale=x_scale, method=method)
     ref = ofit.nonlinear_fit(x, y, ysd, fcn, prior_mean=pm, prior_err=psd, p0=p0, jac=jac,
                              fitter='scipy_least_squares', bounds=b, **kw)
     fit = amd.nonlinear_fit(data=(x, y, ysd), model=amd.multiexp(K), prior=(pm, psd), p0=p0,
                             fitter='mi355x_trf', bounds=b, **kw)
     assert fit.error is None
-    assert fit.description == 'method = trf'
+    assert fit.description == 'method = ' + method
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
     assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
     assert gu.relmax(fit.cov, ref.cov) < 1e-6
     assert fit.stopping_criterion == ref.stopping_criterion
     assert abs(fit.nit - ref.nit) <= max(1, ref.nit // 10), (fit.nit, ref.nit)
     if b is not None:
-        assert np.all(fit.pmean > b[0]) and np.all(fit.pmean < b[1])      # strictly feasible
+        if method == 'trf':
+            assert np.all(fit.pmean > b[0]) and np.all(fit.pmean < b[1])      # strictly feasible
+        else:
+            assert np.all(fit.pmean >= b[0]) and np.all(fit.pmean <= b[1])
+            on = (fit.pmean == b[0]) | (fit.pmean == b[1])                    # exactly on the walls
+            assert np.array_equal(on, (ref.pmean == b[0]) | (ref.pmean == b[1]))
         if kind in ('active', 'semi'):
             assert np.any(np.minimum(fit.pmean - b[0], b[1] - fit.pmean) < 1e-6)
 
@@ -105,9 +111,10 @@ def test_reference_fitters_case_on_device(amd):
     """tests/test_lsqfit.py:1811-1838: str(fit.p) == '[0.904(98) 2.17(19)]' for method='trf'."""
     ym, ys = gvar_lite.parse_array(['0.9(1)', '2.2(2)'])
     pm, ps = gvar_lite.parse_array(['1.0(5)', '2.0(5)'])
-    fit = amd.nonlinear_fit(data=(np.zeros(2), ym, ys), model=amd.identity(2), prior=(pm, ps),
-                            fitter='mi355x_trf', method='trf')
-    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
+    for method in ('trf', 'dogbox'):
+        fit = amd.nonlinear_fit(data=(np.zeros(2), ym, ys), model=amd.identity(2), prior=(pm, ps),
+                                fitter='mi355x_trf', method=method)
+        assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
 
 
 def test_reference_scipy_least_squares_case_on_device(amd):
@@ -127,8 +134,13 @@ def test_reference_scipy_least_squares_case_on_device(amd):
     # x0[0] sits exactly on its optimum: a zero Jacobian column, where scipy's SVD iteration takes
     # negative shifts; the device keeps B + alpha positive definite, so only the end point is compared
     assert gu.relmax(ans.x, ref.x) < 2e-3
+    ans = amd.mi355x_trf(np.zeros(3), 3, None, tol=(1e-15, 1e-8, 1e-15), method='dogbox', problem=pr)   # :1771-1775
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 2 and ans.description == 'method = dogbox'
+    ref = trf.scipy_least_squares(np.zeros(3), 3, f, df, tol=(1e-15, 1e-8, 1e-15), method='dogbox')
+    assert ans.nit == ref.nit and gu.relmax(ans.x, ref.x) < 1e-9
     with pytest.raises(NotImplementedError):
-        amd.mi355x_trf(np.ones(3), 3, None, method='dogbox', problem=pr)
+        amd.mi355x_trf(np.ones(3), 3, None, method='lm', problem=pr)
     with pytest.raises(ValueError, match='outside'):
         amd.mi355x_trf(np.ones(3), 3, None, bounds=(2.0, 3.0), problem=pr)
     with pytest.raises(ValueError, match='strictly less'):
@@ -162,8 +174,9 @@ def test_nist_with_positivity_bounds(amd, name):
     assert gu.relmax(fit.pmean, cert) < 1e-4
 
 
+@pytest.mark.parametrize('method', ['trf'])      # scipy's dogbox does not converge here within 400 evaluations
 @pytest.mark.parametrize('block,prior_corr', [(0, False), (256, True)])
-def test_trf_bounded_cosmix_1024x128(amd, block, prior_corr):
+def test_trf_bounded_cosmix_1024x128(amd, block, prior_corr, method):
     """A bench-type problem (cosmix, P = 128; uncorrelated, and 256-row covariance blocks with a
     dense correlated prior) with the amplitudes boxed into [0.8, 1.2]: about 40% of them end on a
     wall.  Fit point, chi2, covariance and the evaluation count against the oracle."""
@@ -172,7 +185,7 @@ def test_trf_bounded_cosmix_1024x128(amd, block, prior_corr):
     K = 64
     lo = np.concatenate([np.full(K, 0.8), np.full(K, -np.inf)])
     hi = np.concatenate([np.full(K, 1.2), np.full(K, np.inf)])
-    kw = dict(tol=(1e-10, 1e-10, 1e-10), maxit=400)
+    kw = dict(tol=(1e-10, 1e-10, 1e-10), maxit=400, method=method)
     fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=d['p0'],
                             fitter='mi355x_trf', bounds=(lo, hi), **kw)
     ref = ofit.nonlinear_fit(d['x'], d['ymean'], gu.dense_cov(d['yerr'], 1024), gu.cosmix_fcn,
@@ -186,3 +199,35 @@ def test_trf_bounded_cosmix_1024x128(amd, block, prior_corr):
     assert fit.stopping_criterion == ref.stopping_criterion
     # ~100 reflections off the walls: the iterates drift apart at rounding level, the count a little
     assert abs(fit.nit - ref.nit) <= max(2, ref.nit // 4), (fit.nit, ref.nit)
+
+
+@pytest.mark.parametrize('method', ['trf'])      # scipy's dogbox: 400 evaluations are not enough here either
+def test_half_sigma_walls_cosmix_1024x128(amd, method):
+    """cosmix (1024, 128), 256-row covariance blocks, dense correlated prior; eight amplitudes get a
+    wall half a standard deviation short of their unconstrained optimum; the fit starts from the
+    prior mean.  Against the oracle, evaluation count included."""
+    from lsqfit_amd import synth
+    N, P, K = 1024, 128, 64
+    d = synth.make_cosmix(N=N, P=P, seed=4242, block=256, prior_corr=True)
+    rng = np.random.default_rng(8)
+    data = (d['x'], d['ymean'], d['yerr'])
+    free = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=d['p0'], tol=1e-12)
+    lo = np.concatenate([free.pmean[:K] - 0.5, np.full(K, -np.inf)])
+    hi = np.concatenate([free.pmean[:K] + 0.5, np.full(K, np.inf)])
+    walled = rng.choice(K, 8, replace=False)
+    hi[walled[:4]] = free.pmean[walled[:4]] - 0.5 * free.psdev[walled[:4]]
+    lo[walled[4:]] = free.pmean[walled[4:]] + 0.5 * free.psdev[walled[4:]]
+    p0 = d['p0'].copy()                       # the prior mean, kept 0.05 (thousands of sigma) off the walls
+    p0[:K] = np.clip(p0[:K], lo[:K] + 0.05, hi[:K] - 0.05)
+    kw = dict(tol=(1e-14, 1e-10, 1e-10), maxit=400, method=method)
+    fit = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=p0, fitter='mi355x_trf',
+                            bounds=(lo, hi), **kw)
+    ref = ofit.nonlinear_fit(d['x'], d['ymean'], gu.dense_cov(d['yerr'], N), gu.cosmix_fcn, prior_mean=d['prior'][0],
+                             prior_err=d['prior'][1], p0=p0, jac=gu.cosmix_jac, fitter='scipy_least_squares',
+                             bounds=(lo, hi), **kw)
+    assert fit.stopping_criterion == ref.stopping_criterion and fit.stopping_criterion != 0
+    assert abs(fit.nit - ref.nit) <= max(1, ref.nit // 10), (fit.nit, ref.nit)
+    assert np.max(np.abs(fit.pmean - ref.pmean) / free.psdev) < 1e-5
+    assert abs(fit.chi2 / ref.chi2 - 1) < 1e-9
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert 0 < fit.chi2 - free.chi2 < 50

@@ -43,17 +43,20 @@ for seed in range(6):
     CASES.append(('semi%d' % seed, fun, jac, x0, (lo2, np.full(n, np.inf))))
 
 
+@pytest.mark.parametrize('method', ['trf', 'dogbox'])
 @pytest.mark.parametrize('x_scale', [1.0, 'jac'])
 @pytest.mark.parametrize('name,fun,jac,x0,bounds', CASES, ids=[c[0] for c in CASES])
-def test_same_iterates_as_scipy(name, fun, jac, x0, bounds, x_scale):
+def test_same_iterates_as_scipy(name, fun, jac, x0, bounds, x_scale, method):
     kw = dict(xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=200, x_scale=x_scale)   # stops above the rounding floor
-    ref = scipy_opt.least_squares(fun, x0, jac=jac, method='trf',
+    ref = scipy_opt.least_squares(fun, x0, jac=jac, method=method,
                                   bounds=(-np.inf, np.inf) if bounds is None else bounds, **kw)
-    got = trf.trf(fun, jac, x0, bounds=bounds, **kw)
+    got = getattr(trf, method)(fun, jac, x0, bounds=bounds, **kw)
     assert got.nfev == ref.nfev and got.njev == ref.njev and got.status == ref.status
     np.testing.assert_allclose(got.x, ref.x, rtol=1e-9, atol=1e-12)
     assert abs(got.cost - ref.cost) <= 1e-9 * ref.cost
     assert abs(got.optimality - ref.optimality) <= 1e-4 * ref.optimality + 1e-12
+    if method == 'dogbox':
+        assert np.array_equal(got.active_mask, ref.active_mask)
 
 
 def test_max_nfev_and_start_on_bound():
@@ -63,10 +66,11 @@ def test_max_nfev_and_start_on_bound():
     x0[0] = lo[0]                       # on the bound: moved 1e-10 inside
     x0[1] = hi[1]
     for nmax in (1, 3, 50):
-        ref = scipy_opt.least_squares(fun, x0, jac=jac, bounds=(lo, hi), max_nfev=nmax)
-        got = trf.trf(fun, jac, x0, bounds=(lo, hi), max_nfev=nmax)
-        assert (got.nfev, got.status) == (ref.nfev, ref.status)
-        np.testing.assert_allclose(got.x, ref.x, rtol=1e-9)
+        for method in ('trf', 'dogbox'):
+            ref = scipy_opt.least_squares(fun, x0, jac=jac, bounds=(lo, hi), max_nfev=nmax, method=method)
+            got = getattr(trf, method)(fun, jac, x0, bounds=(lo, hi), max_nfev=nmax)
+            assert (got.nfev, got.status) == (ref.nfev, ref.status)
+            np.testing.assert_allclose(got.x, ref.x, rtol=1e-9)
     with pytest.raises(ValueError, match='outside'):
         trf.trf(fun, jac, truth + 5.0, bounds=(lo, hi))
     with pytest.raises(ValueError, match='strictly less'):
@@ -82,6 +86,10 @@ def test_reference_scipy_least_squares_case():
     np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
     assert ans.stopping_criterion == 2
     assert ans.description == 'method = trf'
+    ans = trf.scipy_least_squares(np.zeros(3), 3, f, df, tol=(1e-15, 1e-8, 1e-15), method='dogbox')   # :1771-1775
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 2
+    assert ans.description == 'method = dogbox'
 
 
 def test_reference_bounds_case():
@@ -97,6 +105,7 @@ def test_reference_fitters_case():
     """tests/test_lsqfit.py:1811-1838: every fitter prints fit.p = [0.904(98) 2.17(19)]."""
     ym, ys = gvar_lite.parse_array(['0.9(1)', '2.2(2)'])
     pm, ps = gvar_lite.parse_array(['1.0(5)', '2.0(5)'])
-    fit = ofit.nonlinear_fit(False, ym, ys, lambda p: p, prior_mean=pm, prior_err=ps, jac=lambda p: np.eye(2),
-                             fitter='scipy_least_squares', method='trf')
-    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
+    for method in ('trf', 'dogbox'):
+        fit = ofit.nonlinear_fit(False, ym, ys, lambda p: p, prior_mean=pm, prior_err=ps, jac=lambda p: np.eye(2),
+                                 fitter='scipy_least_squares', method=method)
+        assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
