@@ -119,7 +119,32 @@ def cpu_baseline(d, wh_blocks_from, budget_s):
         cores = os.cpu_count() or 1
     return dict(value=steps / elapsed, unit='LM steps/s', cores=int(cores), kind='port',
                 sample='%d full-size LM step(s) of the same workload (N=%d, P=%d), numpy/OpenBLAS oracle, '
-                       'whitening setup excluded' % (steps, ymean.size, P)), res
+                       'whitening setup excluded' % (steps, ymean.size, P),
+                faithful_qr_1thread=faithful_qr_estimate(ymean.size + P, P)), res
+
+
+def faithful_qr_estimate(n, P):
+    """SURVEY.md 8d "faithful" mode: what the reference's default solver costs per LM step -- one
+    thread, pivoted Householder QR of the n x P Jacobian (lm/more/qr, src/lsqfit/__init__.py:1336;
+    GSL's is unblocked, LAPACK's dgeqp3 here is kinder).  Far too slow to run at full size inside a
+    bench, so the rate is measured on a small sample and scaled by the flop count 2 n P^2 - 2/3 P^3;
+    Jacobian assembly (Python-object AD in the reference) is not included."""
+    try:
+        import scipy.linalg as sla
+        import threadpoolctl
+        m, q = 3072, 2048
+        A = np.random.default_rng(0).standard_normal((m, q))
+        with threadpoolctl.threadpool_limits(1):
+            t0 = time.perf_counter()
+            sla.qr(A, mode='r', pivoting=True)
+            dt = time.perf_counter() - t0
+        rate = (2.0 * m * q * q - 2.0 / 3.0 * q ** 3) / dt
+        flops = 2.0 * n * P * P - 2.0 / 3.0 * P ** 3
+        return dict(value=rate / flops, unit='LM steps/s', cores=1, extrapolated=True,
+                    sample='dgeqp3 of a %d x %d sample on one thread: %.1f GFLOP/s, scaled to the %d x %d '
+                           'Jacobian (%.2e flop per step); QR only' % (m, q, rate / 1e9, n, P, flops))
+    except Exception as e:
+        return dict(value=None, unit='LM steps/s', cores=1, extrapolated=True, sample='failed: %r' % (e,))
 
 
 def main():

@@ -33,6 +33,8 @@ def test_single_process_line():
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0
+    fq = cb['faithful_qr_1thread']
+    assert fq['cores'] == 1 and fq['extrapolated'] and 0 < fq['value'] < cb['value'] * 100
 
 
 def test_two_rank_launch_line():
