@@ -82,7 +82,11 @@ enum { LSQAMD_TRS_LM = 0, LSQAMD_TRS_LMACCEL = 1, LSQAMD_TRS_DOGLEG = 2, LSQAMD_
        LSQAMD_TRS_TRF = 5,
        /* method='dogbox' (_scipy.py:62-63): dogleg in a rectangular trust region with an active set;
         * same conventions as LSQAMD_TRS_TRF (bounds, maxit, scaler, nit, info). */
-       LSQAMD_TRS_DOGBOX = 6 };
+       LSQAMD_TRS_DOGBOX = 6,
+       /* method='lm' (_scipy.py:64-67): MINPACK's lmder as scipy calls it (factor 100; scaler
+        * LEVENBERG = diag 1/x_scale = 1, MORE = MINPACK's own column-norm scaling for x_scale 'jac');
+        * no bounds; all three tolerances must exceed machine epsilon; maxit, nit, info as for TRF. */
+       LSQAMD_TRS_MINPACK_LM = 7 };
 #define LSQAMD_INFO_TRF 100
 
 /* tape opcodes (LSQAMD_MODEL_TAPE); operands in `arg` */

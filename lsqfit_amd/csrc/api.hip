@@ -1523,6 +1523,179 @@ int run_dogbox(lsqamd_fit *f, const double *p0, int *status_out) {
   return 0;
 }
 
+// ---- MINPACK's lmder (scipy_least_squares' method='lm') ------------------------
+// src/lsqfit/_scipy.py:64-67: scipy hands method 'lm' to MINPACK (lmder.f / lmpar.f, factor = 100,
+// diag = 1/x_scale or MINPACK's own column-norm scaling).  qrfac / qrsolv only ever deliver the
+// solution of [J; sqrt(par) D] x = [f; 0] and triangular solves with its R factor -- functions of
+// A = J^T J, g = J^T f and D -- so lmpar runs on the device's Cholesky: per Newton step on the
+// secular equation one factorisation of A + par D^2, the solve, and a second solve for
+// q.(A + par D^2)^-1 q with q = D^2 x / |D x|; |J p|^2 comes from the system p satisfies.
+struct LmparOuter {   // par = 0 quantities, fixed while the Jacobian is
+  bool tried = false, full_rank = false;
+  std::vector<double> x_gn;
+  double dx_gn = 0.0, form_gn = 0.0;   // |D x_gn| and q.A^-1 q
+};
+
+// q.(A + par D^2)^-1 q, q = D^2 x / |D x|, factor of the matrix in place
+int lmpar_form(lsqamd_fit *f, const std::vector<double> &x, double dxnorm, double *out) {
+  const int64_t P = f->P;
+  std::vector<double> q(P), z(P);
+  for (int64_t j = 0; j < P; ++j) q[j] = f->hdiag[j] * f->hdiag[j] * x[j] / dxnorm;
+  const int rc = solve_with_factor(f, q.data(), z.data());
+  if (rc) return rc;
+  *out = dot_h(q, z);
+  return 0;
+}
+
+// lmpar: x with |D x| within 10 % of delta (or the Gauss-Newton step when that is shorter)
+int lmpar_dev(lsqamd_fit *f, LmparOuter &o, double delta, double *par_io, std::vector<double> &x) {
+  const int64_t P = f->P;
+  const double dwarf = 2.2250738585072014e-308;
+  double par = *par_io;
+  if (!o.tried) {
+    o.tried = true;
+    const int rc = solve_damped_dev(f, 0.0, f->hdiag.data());
+    if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+    o.full_rank = rc == 0;
+    if (o.full_rank) {
+      o.x_gn = f->hv;
+      o.dx_gn = scaled_norm(f->hdiag, o.x_gn);
+      const int rc2 = lmpar_form(f, o.x_gn, o.dx_gn, &o.form_gn);
+      if (rc2) return rc2;
+    }
+  }
+  double dxnorm = INFINITY, fp = INFINITY, parl = 0.0;
+  if (o.full_rank) {
+    dxnorm = o.dx_gn;
+    fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) {
+      x = o.x_gn;
+      *par_io = 0.0;
+      return 0;
+    }
+    parl = (fp / delta) / o.form_gn;
+  }
+  double gn = 0.0;
+  for (int64_t j = 0; j < P; ++j) { const double t = f->hg[j] / f->hdiag[j]; gn += t * t; }
+  gn = std::sqrt(gn);
+  double paru = gn / delta;
+  if (paru == 0.0) paru = dwarf / std::fmin(delta, 0.1);
+  par = std::fmin(std::fmax(par, parl), paru);
+  if (par == 0.0) par = gn / dxnorm;
+  for (int it = 1; it <= 10; ++it) {
+    if (par == 0.0) par = std::fmax(dwarf, 0.001 * paru);
+    int rc = solve_damped_dev(f, par, f->hdiag.data());
+    if (rc == LSQAMD_ENOTPD) FAIL(f, LSQAMD_ENOTPD, "minpack lm: J^T J + par D^2 is not positive definite (par %.3e)", par);
+    if (rc) return rc;
+    x = f->hv;
+    dxnorm = scaled_norm(f->hdiag, x);
+    const double prev = fp;
+    fp = dxnorm - delta;
+    if (std::fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= prev && prev < 0.0) || it == 10) break;
+    double form = 0.0;
+    rc = lmpar_form(f, x, dxnorm, &form);
+    if (rc) return rc;
+    const double parc = (fp / delta) / form;
+    if (fp > 0.0) parl = std::fmax(parl, par);
+    if (fp < 0.0) paru = std::fmin(paru, par);
+    par = std::fmax(parl, par + parc);
+  }
+  *par_io = par;
+  return 0;
+}
+
+// lmder.  *status_out in scipy's numbering (FROM_MINPACK_TO_COMMON): info 1, 2, 3, 4, 5 -> 2, 3, 4, 1, 0
+int run_minpack(lsqamd_fit *f, const double *p0, int *status_out) {
+  const int64_t P = f->P;
+  if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT)
+    FAIL(f, LSQAMD_EINVAL, "minpack lm: x_scale is 1 (scaler levenberg) or 'jac' (scaler more)");
+  const double xtol = f->opt.xtol, gtol = f->opt.gtol, ftol = f->opt.ftol;
+  const double epsmch = 2.220446049250313e-16, factor = 100.0;
+  if (ftol < epsmch || xtol < epsmch || gtol < epsmch)
+    FAIL(f, LSQAMD_EINVAL, "minpack lm: all tolerances must be higher than machine epsilon");
+  if (!f->lb.empty())
+    for (int64_t j = 0; j < P; ++j)
+      if (std::isfinite(f->lb[j]) || std::isfinite(f->ub[j]))
+        FAIL(f, LSQAMD_EINVAL, "minpack lm: method 'lm' doesn't support bounds");
+  int rc = do_init(f, p0);   // fvec, J, A, g, column norms, D (mode 1: column norms, 1 where 0); nfev = njev = 1
+  if (rc) return rc;
+  const int maxfev = f->opt.maxit;
+  const bool mode1 = f->opt.scaler == LSQAMD_SCALE_MORE;
+  double fnorm = std::sqrt(f->chi2);
+  double xnorm = scaled_norm(f->hdiag, f->hx);
+  double delta = factor * xnorm;
+  if (delta == 0.0) delta = factor;
+  double par = 0.0;
+  int iter = 1, info = 0;
+  std::vector<double> p(P), xt(P);
+  while (true) {
+    double gnorm = 0.0;
+    if (fnorm != 0.0)
+      for (int64_t j = 0; j < P; ++j)
+        if (f->hcoln[j] != 0.0) gnorm = std::fmax(gnorm, std::fabs(f->hg[j] / fnorm / f->hcoln[j]));
+    if (gnorm <= gtol) { info = 4; break; }
+    LmparOuter o;
+    while (true) {
+      rc = lmpar_dev(f, o, delta, &par, p);
+      if (rc) return rc;
+      double pg = 0.0;
+      for (int64_t j = 0; j < P; ++j) { xt[j] = f->hx[j] - p[j]; pg += p[j] * f->hg[j]; }
+      const double pnorm = scaled_norm(f->hdiag, p);
+      if (iter == 1) delta = std::fmin(delta, pnorm);
+      std::memcpy(f->pin_x, xt.data(), sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      double chi2_t = 0.0;
+      rc = eval_residual_dev(f, f->p_trial, &chi2_t);
+      if (rc) return rc;
+      const double fnorm1 = std::sqrt(chi2_t);     // NaN compares false everywhere below: rejected
+      double actred = -1.0;
+      if (0.1 * fnorm1 < fnorm) actred = 1.0 - (fnorm1 / fnorm) * (fnorm1 / fnorm);
+      // |J p|^2 = p.g - par |D p|^2 since (A + par D^2) p = g
+      const double jp2 = std::fmax(pg - par * pnorm * pnorm, 0.0);
+      const double t1sq = jp2 / (fnorm * fnorm), t2sq = par * pnorm * pnorm / (fnorm * fnorm);
+      const double prered = t1sq + t2sq / 0.5, dirder = -(t1sq + t2sq);
+      const double ratio = prered != 0.0 ? actred / prered : 0.0;
+      if (ratio <= 0.25) {
+        double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+        delta = temp * std::fmin(delta, pnorm / 0.1);
+        par /= temp;
+      } else if (par == 0.0 || ratio >= 0.75) {
+        delta = pnorm / 0.5;
+        par *= 0.5;
+      }
+      const bool accepted = ratio >= 1e-4;
+      if (accepted) {
+        rc = eval_normal_dev(f, f->p_trial);    // also the Jacobian of the next outer pass
+        if (rc) return rc;
+        f->hx = xt;
+        for (int64_t j = 0; j < P; ++j) f->hdx[j] = -p[j];
+        std::swap(f->p_dev, f->p_trial);
+        xnorm = scaled_norm(f->hdiag, f->hx);   // with the D of this pass (lmder.f), before its update
+        if (mode1) scale_update(f);
+        fnorm = fnorm1;
+        ++iter;
+      }
+      const bool small = std::fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+      if (small) info = 1;
+      if (delta <= xtol * xnorm) info = 2;
+      if (small && info == 2) info = 3;
+      if (info != 0) break;
+      if (f->nfev >= maxfev) info = 5;
+      if (std::fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) info = 6;
+      if (delta <= epsmch * xnorm) info = 7;
+      if (gnorm <= epsmch) info = 8;
+      if (info != 0 || accepted) break;
+    }
+    if (info != 0) break;
+  }
+  // lmder stops BEFORE evaluating the Jacobian at an accepted final point; here it is already in
+  // place (one evaluation more than MINPACK counts -- the caller needs J there anyway, _scipy.py:160)
+  static const int to_scipy[9] = {-1, 2, 3, 4, 1, 0, 2, 3, 1};   // 6, 7, 8: the tests 1, 2, 4 at machine precision
+  *status_out = to_scipy[info];
+  return 0;
+}
+
 // covariance + logdet at the current point: factor A (mu = 0), invert
 int do_covariance(lsqamd_fit *f) {
   const int64_t P = f->P;
@@ -1750,7 +1923,7 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
   if (opt->solver != LSQAMD_SOLVER_CHOLESKY) FAIL(f, LSQAMD_EUNSUPPORTED, "set_options: only the cholesky solver runs on the device");
   if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
-  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_DOGBOX) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
+  if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_MINPACK_LM) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
   f->opt = *opt;
   return 0;
 }
@@ -1798,7 +1971,7 @@ int lsqamd_init(lsqamd_fit *f, const double *p0) {
 int lsqamd_step(lsqamd_fit *f, int32_t *info) {
   if (!f) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_step before lsqamd_init");
-  if (f->opt.trs >= LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the trf / dogbox methods run through lsqamd_run only");
+  if (f->opt.trs >= LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the scipy-plugin methods (trf, dogbox, minpack lm) run through lsqamd_run only");
   const int rc = iterate(f);
   if (rc < 0) return rc;
   f->nit++;
@@ -1830,9 +2003,10 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   int iter = 0, info = 0, status = -2;
   bool early = false;
   const int maxit = f->opt.maxit;
-  if (f->opt.trs == LSQAMD_TRS_TRF || f->opt.trs == LSQAMD_TRS_DOGBOX) {
+  if (f->opt.trs >= LSQAMD_TRS_TRF) {
     int st = 0;
-    rc = f->opt.trs == LSQAMD_TRS_TRF ? run_trf(f, p0, &st) : run_dogbox(f, p0, &st);
+    rc = f->opt.trs == LSQAMD_TRS_TRF ? run_trf(f, p0, &st)
+         : f->opt.trs == LSQAMD_TRS_DOGBOX ? run_dogbox(f, p0, &st) : run_minpack(f, p0, &st);
     if (rc) return rc;
     f->nit = f->nfev;                      // _scipy.py:161: nit = number of function evaluations
     info = LSQAMD_INFO_TRF + st;

@@ -23,7 +23,7 @@ from .whiten import Whitening
 
 _SCALERS = dict(more=0, levenberg=1, marquardt=2)
 _ALGS = dict(lm=0, lmaccel=1, dogleg=2, ddogleg=3, subspace2D=4)      # _gsl.pyx:622-635
-_BOUNDED = dict(trf=5, dogbox=6)                                      # LSQAMD_TRS_TRF, _DOGBOX
+_BOUNDED = dict(trf=5, dogbox=6, minpack_lm=7)                        # LSQAMD_TRS_TRF, _DOGBOX, _MINPACK_LM
 
 
 def _check(lib, h, rc, what):
@@ -439,12 +439,12 @@ class mi355x_lm(object):
 
 class mi355x_trf(mi355x_lm):
     r"""MI355X counterpart of :class:`lsqfit.scipy_least_squares` (src/lsqfit/_scipy.py:20-181)
-    for the two methods that honour box bounds: the Trust Region Reflective algorithm (default)
-    and the dogleg method in a rectangular trust region.
+    with its three methods: the Trust Region Reflective algorithm (default) and the dogleg method
+    in a rectangular trust region, which honour box bounds, and MINPACK's Levenberg-Marquardt.
 
     ``x0, n, f, tol, maxit`` as there (``tol`` default ``(1e-8, 1e-8, 1e-8)``, ``maxit`` = cap on
-    function evaluations); ``method`` None / ``'trf'`` or ``'dogbox'`` (MINPACK's ``'lm'`` is not
-    rebuilt: it ignores bounds, use :class:`mi355x_lm`); ``bounds=(lower, upper)``;
+    function evaluations); ``method`` None / ``'trf'``, ``'dogbox'`` or ``'lm'`` (no bounds, all
+    tolerances above machine epsilon); ``bounds=(lower, upper)``;
     ``x_scale`` 1.0 or ``'jac'``.  ``nit`` counts function evaluations (:161),
     ``stopping_criterion`` follows :176-181, ``cov`` is ``inv(J^T J)`` at the fit point (what
     :165-169 gives for a full-rank Jacobian; a rank-deficient one is an error here).
@@ -456,8 +456,8 @@ class mi355x_trf(mi355x_lm):
             raise ValueError("mi355x_trf needs problem=DeviceProblem(...)")
         if method is None:
             method = 'trf'                                                 # _scipy.py:135-139
-        if method not in _BOUNDED:
-            raise NotImplementedError("mi355x_trf runs method 'trf' or 'dogbox'; got %r" % (method,))
+        if method not in ('trf', 'dogbox', 'lm'):
+            raise ValueError("`method` must be 'trf', 'dogbox' or 'lm'.")
         if isinstance(x_scale, str):
             if x_scale != 'jac':
                 raise ValueError("`x_scale` must be 'jac' or 1.0")
@@ -480,7 +480,8 @@ class mi355x_trf(mi355x_lm):
             raise ValueError('len(x0) = %d but the model has %d parameters' % (self.x0.size, pr.P))
         if n is not None and int(n) != pr.wh.nchiv:
             raise ValueError('n = %d but the whitened residual has %d entries' % (n, pr.wh.nchiv))
-        pr.set_options(self.tol, 100 * pr.P if maxit is None else maxit, scaler, alg=method)
+        pr.set_options(self.tol, 100 * pr.P if maxit is None else maxit, scaler,
+                       alg='minpack_lm' if method == 'lm' else method)
         pr.set_bounds(bounds)
         lib = pr.lib
         s = _lib.Summary()

@@ -469,11 +469,17 @@ def scipy_least_squares(x0, n, f, df, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method
     """Counterpart of ``lsqfit.scipy_least_squares`` (src/lsqfit/_scipy.py:115-181) for
     method 'trf', with an explicit Jacobian callback in place of the GVar trick."""
     from .lm import normalize_tol
-    if method not in (None, 'trf', 'dogbox'):
-        raise NotImplementedError('the oracle restates methods "trf" and "dogbox" (MINPACK "lm" is not)')
+    if method not in (None, 'trf', 'dogbox', 'lm'):
+        raise ValueError("`method` must be 'trf', 'dogbox' or 'lm'.")
     tol = normalize_tol(tol)
-    fit = (dogbox if method == 'dogbox' else trf)(f, df, x0, bounds=bounds, xtol=tol[0], gtol=tol[1],
-                                                  ftol=tol[2], max_nfev=maxit, x_scale=x_scale)
+    if method == 'lm':
+        from .minpack import least_squares_lm
+        if bounds is not None and not (np.all(np.isneginf(bounds[0])) and np.all(np.isposinf(bounds[1]))):
+            raise ValueError("Method 'lm' doesn't support bounds.")
+        fit = least_squares_lm(f, df, x0, xtol=tol[0], gtol=tol[1], ftol=tol[2], max_nfev=maxit, x_scale=x_scale)
+    else:
+        fit = (dogbox if method == 'dogbox' else trf)(f, df, x0, bounds=bounds, xtol=tol[0], gtol=tol[1],
+                                                      ftol=tol[2], max_nfev=maxit, x_scale=x_scale)
     res = TRFResult()
     res.tol = tol
     res.description = 'method = {}'.format('trf' if method is None else method)      # :134-139

@@ -111,7 +111,7 @@ def test_reference_fitters_case_on_device(amd):
     """tests/test_lsqfit.py:1811-1838: str(fit.p) == '[0.904(98) 2.17(19)]' for method='trf'."""
     ym, ys = gvar_lite.parse_array(['0.9(1)', '2.2(2)'])
     pm, ps = gvar_lite.parse_array(['1.0(5)', '2.0(5)'])
-    for method in ('trf', 'dogbox'):
+    for method in ('trf', 'dogbox', 'lm'):
         fit = amd.nonlinear_fit(data=(np.zeros(2), ym, ys), model=amd.identity(2), prior=(pm, ps),
                                 fitter='mi355x_trf', method=method)
         assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
@@ -139,8 +139,17 @@ def test_reference_scipy_least_squares_case_on_device(amd):
     assert ans.stopping_criterion == 2 and ans.description == 'method = dogbox'
     ref = trf.scipy_least_squares(np.zeros(3), 3, f, df, tol=(1e-15, 1e-8, 1e-15), method='dogbox')
     assert ans.nit == ref.nit and gu.relmax(ans.x, ref.x) < 1e-9
-    with pytest.raises(NotImplementedError):
-        amd.mi355x_trf(np.ones(3), 3, None, method='lm', problem=pr)
+    ans = amd.mi355x_trf(np.zeros(3), 3, None, tol=(1e-8, 1e-15, 1e-15), method='lm', problem=pr)      # :1768-1772
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 1 and ans.description == 'method = lm'
+    ref = trf.scipy_least_squares(np.zeros(3), 3, f, df, tol=(1e-8, 1e-15, 1e-15), method='lm')
+    assert ans.nit == ref.nit and gu.relmax(ans.x, ref.x) < 1e-9
+    with pytest.raises(ValueError, match="doesn't support bounds"):
+        amd.mi355x_trf(np.ones(3), 3, None, method='lm', bounds=(0.0, 5.0), problem=pr)
+    with pytest.raises(ValueError, match='machine epsilon'):
+        amd.mi355x_trf(np.ones(3), 3, None, method='lm', tol=(1e-8, 1e-17, 1e-8), problem=pr)
+    with pytest.raises(ValueError, match='`method`'):
+        amd.mi355x_trf(np.ones(3), 3, None, method='cg', problem=pr)
     with pytest.raises(ValueError, match='outside'):
         amd.mi355x_trf(np.ones(3), 3, None, bounds=(2.0, 3.0), problem=pr)
     with pytest.raises(ValueError, match='strictly less'):
@@ -231,3 +240,41 @@ def test_half_sigma_walls_cosmix_1024x128(amd, method):
     assert abs(fit.chi2 / ref.chi2 - 1) < 1e-9
     assert gu.relmax(fit.cov, ref.cov) < 1e-6
     assert 0 < fit.chi2 - free.chi2 < 50
+
+
+@pytest.mark.parametrize('x_scale', [1.0, 'jac'])
+@pytest.mark.parametrize('start', [1.0, 1.3])
+@pytest.mark.parametrize('seed,K', [(1, 1), (2, 2), (4, 2)])
+def test_minpack_lm_matches_oracle(amd, seed, K, start, x_scale):
+    """method='lm' (MINPACK's lmder through scipy, src/lsqfit/_scipy.py:64-67) on the device against
+    oracle/minpack.py (pinned on scipy): fit point, chi2, covariance, stopping criterion and the
+    evaluation count."""
+    x, y, ysd, pm, psd, truth, fcn, jac = multiexp_case(seed, K)
+    p0 = start * pm * (1.0 + 0.2 * np.cos(np.arange(2 * K) + seed))
+    kw = dict(tol=(1e-8, 1e-8, 1e-8), maxit=300, x_scale=x_scale, method='lm')
+    ref = ofit.nonlinear_fit(x, y, ysd, fcn, prior_mean=pm, prior_err=psd, p0=p0, jac=jac,
+                             fitter='scipy_least_squares', **kw)
+    fit = amd.nonlinear_fit(data=(x, y, ysd), model=amd.multiexp(K), prior=(pm, psd), p0=p0,
+                            fitter='mi355x_trf', **kw)
+    assert fit.error is None and fit.description == 'method = lm'
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.stopping_criterion == ref.stopping_criterion
+    assert abs(fit.nit - ref.nit) <= 1, (fit.nit, ref.nit)
+
+
+@pytest.mark.parametrize('name', ['misra1a', 'chwirut2', 'danwood', 'rat42', 'thurber', 'boxbod'])
+def test_nist_minpack_lm(amd, name):
+    pr = nist_problem(name, NIST)
+    model = amd.expr(pr['expr'], ['b%d' % (i + 1) for i in range(pr['P'])], xnames=tuple(pr['columns'][1:]))
+    x = np.column_stack([pr['x'][c] for c in pr['columns'][1:]])
+    kw = dict(tol=(1e-10, 1e-10, 1e-10), maxit=2000, method='lm')
+    fit = amd.nonlinear_fit(data=(x, pr['y'], pr['ysd']), model=model, prior=(pr['prior_mean'], pr['prior_sd']),
+                            p0=pr['p0'], fitter='mi355x_trf', **kw)
+    ref = ofit.nonlinear_fit(pr['x'], pr['y'], pr['ysd'], pr['fcn'], prior_mean=pr['prior_mean'],
+                             prior_err=pr['prior_sd'], p0=pr['p0'], fitter='scipy_least_squares', **kw)
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert abs(fit.chi2 / ref.chi2 - 1) < 1e-6
+    assert gu.relmax(fit.cov, ref.cov) < 1e-5
+    assert gu.relmax(fit.pmean, np.asarray(pr['certified'])) < 1e-4

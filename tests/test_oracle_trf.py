@@ -109,3 +109,45 @@ def test_reference_fitters_case():
         fit = ofit.nonlinear_fit(False, ym, ys, lambda p: p, prior_mean=pm, prior_err=ps, jac=lambda p: np.eye(2),
                                  fitter='scipy_least_squares', method=method)
         assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[0.904(98) 2.17(19)]'
+
+
+# ---- method='lm': MINPACK's lmder (oracle/minpack.py) ----------------------------------------------
+from oracle import minpack   # noqa: E402
+
+# (the three-exponential problems collapse onto nearly equal exponents with amplitudes of +-500:
+# the counts still agree there, the end points only to a few per cent, so they pin nothing)
+LM_CASES = [(c[0] + s, c[1], c[2], c[3] * sc) for c in CASES if c[4] is None and c[3].size < 6
+            for s, sc in (('', 1.0), ('_far', 1.6), ('_near', 1.02))]
+
+
+@pytest.mark.parametrize('x_scale', [1.0, 'jac'])
+@pytest.mark.parametrize('name,fun,jac,x0', LM_CASES, ids=[c[0] for c in LM_CASES])
+def test_minpack_lm_same_iterates_as_scipy(name, fun, jac, x0, x_scale):
+    kw = dict(xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=300, x_scale=x_scale)
+    ref = scipy_opt.least_squares(fun, x0, jac=jac, method='lm', **kw)
+    got = minpack.least_squares_lm(fun, jac, x0, **kw)
+    assert (got.nfev, got.njev, got.status) == (ref.nfev, ref.njev, ref.status)
+    # (the restatement goes through J^T J, MINPACK through a pivoted QR: the three-exponential
+    # problems are ill-conditioned enough to show that at the 1e-8 level)
+    np.testing.assert_allclose(got.x, ref.x, rtol=1e-7, atol=1e-12)
+    assert abs(got.cost - ref.cost) <= 1e-9 * ref.cost
+
+
+def test_minpack_lm_reference_case_and_limits():
+    """tests/test_lsqfit.py:1768-1772: method 'lm', tol (1e-8, 1e-15, 1e-15) -> criterion 1 (xtol)."""
+    xans = np.arange(3) + 1.0
+    f = lambda x: (x - xans) ** 2 + (x - xans) ** 4
+    df = lambda x: np.diag(2 * (x - xans) + 4 * (x - xans) ** 3)
+    ref = scipy_opt.least_squares(f, np.zeros(3), jac=df, method='lm', xtol=1e-8, gtol=1e-15, ftol=1e-15)
+    got = minpack.least_squares_lm(f, df, np.zeros(3), xtol=1e-8, gtol=1e-15, ftol=1e-15)
+    assert (got.nfev, got.status) == (ref.nfev, ref.status) and ref.status == 3
+    np.testing.assert_allclose(got.x, ref.x, rtol=1e-9)
+    ans = trf.scipy_least_squares(np.zeros(3), 3, f, df, tol=(1e-8, 1e-15, 1e-15), method='lm')
+    np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
+    assert ans.stopping_criterion == 1 and ans.description == 'method = lm'
+    for nmax in (1, 2, 7):
+        ref = scipy_opt.least_squares(f, np.zeros(3), jac=df, method='lm', max_nfev=nmax)
+        got = minpack.least_squares_lm(f, df, np.zeros(3), max_nfev=nmax)
+        assert (got.nfev, got.status) == (ref.nfev, ref.status)
+    with pytest.raises(ValueError, match='machine epsilon'):
+        minpack.least_squares_lm(f, df, np.zeros(3), xtol=1e-17)
