@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblsqfit_amd.so')
-SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'potf2_mfma.hip', 'model.hip', 'vecops.hip', 'api.hip', 'batch.hip']
+SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'potf2_mfma.hip', 'model.hip', 'vecops.hip', 'api.hip', 'scipy_methods.hip',
+           'batch.hip']
 # per-file code-generation switches (reasons in the files' headers)
 EXTRA = {'potf2_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
@@ -30,7 +31,8 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(HERE, '..', 'include', 'lsqfit_amd.h')]
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fit_state.h'),
+               os.path.join(HERE, '..', 'include', 'lsqfit_amd.h')]
     jobs = []
     objs = []
     for src in SOURCES:

@@ -1,0 +1,160 @@
+// Internal to the host side of the library (api.hip, scipy_methods.hip): the fit handle and the
+// device-side building blocks the trust-region drivers share.  Not part of the C ABI.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "common.h"
+
+namespace lsqamd_host {
+
+struct TimerSlot {
+  double total_ms = 0.0;
+  int64_t count = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+}  // namespace lsqamd_host
+
+struct lsqamd_fit {
+  lsqamd_config cfg;
+  lsqamd_options opt;
+  hipStream_t st = nullptr;
+  std::string err;
+
+  int64_t N = 0, P = 0, ld = 0, ldm = 0, npk = 0, ncols_aug = 0;
+  int32_t splits = 1;
+  int64_t npartial = 256;
+
+  // device buffers
+  double *x = nullptr, *ymean = nullptr, *wdiag = nullptr;
+  uint8_t *in_block = nullptr;
+  int64_t *blk_row0 = nullptr, *blk_size = nullptr, *blk_woff = nullptr;
+  double *wt = nullptr;
+  double *prior_mean = nullptr, *prior_prec = nullptr;
+  double *p_dev = nullptr, *p_trial = nullptr;
+  double *r = nullptr, *r_raw = nullptr;
+  double *J = nullptr, *Jraw = nullptr;
+  double *slabs = nullptr;
+  double *redbuf = nullptr;  // [packed J^T J | J^T f | chi2]
+  double *red_scalar = nullptr;
+  double *M = nullptr, *chol_work = nullptr, *yv = nullptr, *diag_dev = nullptr, *tvec = nullptr;
+  double *dscale = nullptr;  // the scaling matrix D, device-resident mirror of hdiag
+  double *partial = nullptr, *Wl = nullptr, *cov = nullptr, *scal = nullptr;
+  int32_t *info_dev = nullptr;
+  int32_t *tape = nullptr;
+  double *consts = nullptr;
+  int32_t n_tape = 0;
+  int32_t *syrk_map = nullptr;
+  int32_t syrk_nwork = 0;
+
+  // host mirrors of the block structure
+  std::vector<int64_t> h_row0, h_size, h_modes, h_woff;
+  std::vector<int32_t> h_tri;
+  bool uniform_blocks = false;
+  int32_t uniform_tri = 0;
+  bool have_x = false, have_data = false, have_prior = false, have_tape = false;
+
+  // reduce hook
+  lsqamd_reduce_fn reduce = nullptr;
+  void *reduce_user = nullptr;
+  bool adds_prior = true;
+
+  // box bounds of the reflective trust-region method (empty: none)
+  std::vector<double> lb, ub;
+
+  // LM state (host)
+  std::vector<double> hx, hg, hdiag, hdx, hv, hcoln, htmp;
+  double chi2 = 0.0, mu = 0.0, delta = 0.0;
+  long nu = 2;
+  bool initialised = false, have_cov = false, have_dense_A = false;
+  int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
+  double logdet = NAN;
+
+  // pinned host staging for the per-step transfers (pageable copies go through a blit
+  // kernel and cost ~40 us each): [g | chi2](P+1), coln(P), v(P), diag(P), x_trial(P), scalars(8)
+  double *pin = nullptr;
+  double *pin_g = nullptr, *pin_c = nullptr, *pin_v = nullptr, *pin_d = nullptr, *pin_x = nullptr, *pin_s = nullptr;
+  std::vector<hipEvent_t> event_pool;
+
+  // timing
+  bool timing = false;
+  lsqamd_host::TimerSlot timers[LSQAMD_T_COUNT];
+
+  ~lsqamd_fit() {  // every exit path (including the failure returns of lsqamd_create) ends here
+    for (auto &t : timers)
+      for (auto &pr : t.pending) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+      }
+    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
+    if (pin) (void)hipHostFree(pin);
+  }
+};
+
+#define FAIL(fit, code, ...)                         \
+  do {                                               \
+    char _b[512];                                    \
+    snprintf(_b, sizeof(_b), __VA_ARGS__);           \
+    (fit)->err = _b;                                 \
+    return (code);                                   \
+  } while (0)
+
+#define HIPCHK(fit, expr)                                                              \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) FAIL(fit, LSQAMD_EHIP, "%s: %s", #expr, hipGetErrorString(_e)); \
+  } while (0)
+
+namespace lsqamd_host {
+
+hipEvent_t take_event(lsqamd_fit *f);  // events are recycled: creating one costs ~10 us
+
+struct Scope {  // HIP-event bracket for one phase
+  lsqamd_fit *f;
+  int which;
+  hipEvent_t a = nullptr, b = nullptr;
+  Scope(lsqamd_fit *fit, int w) : f(fit), which(w) {
+    if (f->timing) {
+      a = take_event(f);
+      b = take_event(f);
+      (void)hipEventRecord(a, f->st);
+    }
+  }
+  ~Scope() {
+    if (f->timing) {
+      (void)hipEventRecord(b, f->st);
+      f->timers[which].pending.emplace_back(a, b);
+    }
+  }
+};
+
+// ---- device-side building blocks (api.hip) ----------------------------------------------------
+// whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return; counts one nfev
+int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out);
+// J, A = J^T J (+ prior), g, chi2, column norms at device parameters p (all-reduced); counts one njev
+int eval_normal_dev(lsqamd_fit *f, const double *p);
+// (A + mu D^2) v = g -> f->hv ; LSQAMD_ENOTPD when a pivot fails.  diag_host nullptr: the
+// device-resident D.  frozen_host (with mu = 0): flags of parameters taken out of the system.
+int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr);
+// second right-hand side with the factor of the last solve_damped_dev still in place
+int solve_with_factor(lsqamd_fit *f, const double *rhs, double *out);
+// y = A x (one device GEMV on a dense copy of A)
+int symv_host(lsqamd_fit *f, const double *x, double *y);
+// f, J, A, g, D, mu, delta at p0 (gsl_multifit_nlinear_init); nfev = njev = 1
+int do_init(lsqamd_fit *f, const double *p0);
+void scale_update(lsqamd_fit *f);
+double dot_h(const std::vector<double> &a, const std::vector<double> &b);
+double scaled_norm(const std::vector<double> &d, const std::vector<double> &v);
+
+// ---- scipy_least_squares' methods (scipy_methods.hip); *status_out in scipy's numbering --------
+int run_trf(lsqamd_fit *f, const double *p0, int *status_out);
+int run_dogbox(lsqamd_fit *f, const double *p0, int *status_out);
+int run_minpack(lsqamd_fit *f, const double *p0, int *status_out);
+
+}  // namespace lsqamd_host
