@@ -391,3 +391,17 @@ def test_lognormal_array_case_on_device(amd):
     fit = amd.nonlinear_fit(data=(x, ym, ys), model=model, prior=(np.log([0.1, 10.0]), [2.0, 2.0]))
     a = np.exp(fit.pmean)
     assert [gvar_lite.fmt(a[i], a[i] * fit.psdev[i]) for i in range(2)] == ['0.147(69)', '1.64(69)']
+
+
+@pytest.mark.parametrize('yfac,pfac', [(1e22, 1.0), (1.0, 1e22)])
+def test_basicfit_extremes_on_device(amd, yfac, pfac):
+    """tests/test_lsqfit.py:126-180 (t_basicfit): y = [1, 4], p = [4, 16], fcn = p**2, with the data or
+    the prior covariance scaled by 1e22 -- the fit reproduces the prior (or the data), chi2 = 0, Q = 1."""
+    from tests.test_oracle_kat import BASICFIT_PCOV, BASICFIT_YCOV, basicfit_checks
+    model = amd.expr('s0*p0**2 + s1*p1**2', ['p0', 'p1'], xnames=('s0', 's1'))
+    fit = amd.nonlinear_fit(data=(np.eye(2), np.array([1., 4.]), BASICFIT_YCOV * yfac), model=model,
+                            prior=(np.array([4., 16.]), BASICFIT_PCOV * pfac))
+    basicfit_checks(fit, yfac, pfac, fit.pmean, fit.cov)
+    ref = ofit.nonlinear_fit(False, np.array([1., 4.]), BASICFIT_YCOV * yfac, lambda p: p ** 2,
+                             prior_mean=np.array([4., 16.]), prior_err=BASICFIT_PCOV * pfac)
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6

@@ -600,3 +600,27 @@ def test_lognormal_array_case():
     fit = ofit.nonlinear_fit(False, ym, ys, fcn, prior_mean=um, prior_err=us)
     a = np.exp(fit.pmean)
     assert [gvar_lite.fmt(a[i], a[i] * fit.psdev[i]) for i in range(2)] == ['0.147(69)', '1.64(69)']
+
+
+BASICFIT_YCOV = np.array([[2., .25], [.25, 4.]])
+BASICFIT_PCOV = np.array([[2., .5], [.5, 1.]])
+
+
+def basicfit_checks(fit, yfac, pfac, pmean, cov):
+    """tests/test_lsqfit.py:126-168 (t_basicfit): prior-dominated and data-dominated extremes."""
+    assert fit.dof == 2 and abs(fit.Q - 1.0) < 5e-8 and abs(fit.chi2) < 5e-8
+    rel = lambda a, b: np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(np.concatenate([np.ravel(a), np.ravel(b)])))
+    if yfac > 100 * pfac:
+        assert rel(pmean, [4., 16.]) < 1e-5
+        assert rel(cov, BASICFIT_PCOV * pfac) < 1e-5
+    else:
+        assert rel(np.asarray(pmean) ** 2, [1., 4.]) < 1e-5
+        Jsq = np.diag(2 * np.asarray(pmean))                 # cov of p**2 by linear propagation
+        assert rel(Jsq @ cov @ Jsq.T, BASICFIT_YCOV * yfac) < 1e-5
+
+
+@pytest.mark.parametrize('yfac,pfac', [(1e22, 1.0), (1.0, 1e22)])
+def test_basicfit_extremes(yfac, pfac):
+    fit = ofit.nonlinear_fit(False, np.array([1., 4.]), BASICFIT_YCOV * yfac, lambda p: p ** 2,
+                             prior_mean=np.array([4., 16.]), prior_err=BASICFIT_PCOV * pfac)
+    basicfit_checks(fit, yfac, pfac, fit.pmean, fit.cov)
