@@ -418,12 +418,23 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const do
   return solve_damped_collect(f);
 }
 
+// nonlinear_fit's linear= parameters (lsqamd_set_linear): their entries of D are zero, on the host
+// and in the device mirror the fast path reads
+void scale_mask_linear(lsqamd_fit *f) {
+  if (f->linear.empty()) return;
+  for (int64_t j = 0; j < f->P; ++j)
+    if (f->linear[j]) f->hdiag[j] = 0.0;
+  std::memcpy(f->pin_d, f->hdiag.data(), sizeof(double) * f->P);
+  (void)hipMemcpyAsync(f->dscale, f->pin_d, sizeof(double) * f->P, hipMemcpyHostToDevice, f->st);
+}
+
 void scale_init(lsqamd_fit *f) {
   (void)launch_scale_update(f->st, f->P, f->opt.scaler, 1, f->diag_dev, f->dscale);  // diag_dev = coln^2
   for (int64_t j = 0; j < f->P; ++j) {
     if (f->opt.scaler == LSQAMD_SCALE_LEVENBERG) f->hdiag[j] = 1.0;
     else f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
   }
+  scale_mask_linear(f);
 }
 
 void scale_update(lsqamd_fit *f) {
@@ -432,6 +443,7 @@ void scale_update(lsqamd_fit *f) {
     if (f->opt.scaler == LSQAMD_SCALE_MORE) f->hdiag[j] = std::fmax(f->hdiag[j], f->hcoln[j]);
     else if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT) f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
   }
+  scale_mask_linear(f);
 }
 
 // ---- pieces shared by the trust-region sub-problem solvers -------------------
@@ -811,6 +823,8 @@ int do_init(lsqamd_fit *f, const double *p0) {
   int rc = ready(f);
   if (rc) return rc;
   const int64_t P = f->P;
+  if (!f->linear.empty() && f->opt.trs != LSQAMD_TRS_LM)
+    FAIL(f, LSQAMD_EINVAL, "linear parameters (lsqamd_set_linear) need the plain lm method");
   f->hx.assign(p0, p0 + P);
   f->hg.assign(P, 0.0);
   f->hdiag.assign(P, 1.0);
@@ -824,8 +838,9 @@ int do_init(lsqamd_fit *f, const double *p0) {
   if (rc) return rc;
   f->nfev++;
   scale_init(f);
-  double mx = -1.0;
-  for (int64_t j = 0; j < P; ++j) mx = std::fmax(mx, f->hcoln[j] / f->hdiag[j]);
+  double mx = 0.0;   // over the damped parameters (all of them unless lsqamd_set_linear was used)
+  for (int64_t j = 0; j < P; ++j)
+    if (f->hdiag[j] > 0.0) mx = std::fmax(mx, f->hcoln[j] / f->hdiag[j]);
   f->mu = 1e-3 * mx * mx;
   f->nu = 2;
   double dxn = 0.0;
@@ -1108,6 +1123,20 @@ int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
   }
   f->lb.swap(lb);
   f->ub.swap(ub);
+  return 0;
+}
+
+int lsqamd_set_linear(lsqamd_fit *f, const int32_t *index, int32_t n) {
+  if (!f || n < 0 || (n > 0 && !index)) return LSQAMD_EINVAL;
+  std::vector<char> mask;
+  if (n > 0) {
+    mask.assign(f->P, 0);
+    for (int32_t k = 0; k < n; ++k) {
+      if (index[k] < 0 || index[k] >= f->P) FAIL(f, LSQAMD_EINVAL, "set_linear: index %d out of range", index[k]);
+      mask[index[k]] = 1;
+    }
+  }
+  f->linear.swap(mask);
   return 0;
 }
 

@@ -67,6 +67,8 @@ struct lsqamd_fit {
 
   // box bounds of the reflective trust-region method (empty: none)
   std::vector<double> lb, ub;
+  // parameters the residual is linear in (empty: none): left out of the LM damping
+  std::vector<char> linear;
 
   // LM state (host)
   std::vector<double> hx, hg, hdiag, hdx, hv, hcoln, htmp;

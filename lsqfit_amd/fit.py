@@ -52,7 +52,7 @@ class nonlinear_fit(object):
     model = :class:`lsqfit_amd.Model`."""
 
     def __init__(self, data=None, model=None, prior=None, p0=None, svdcut=False, tol=None,
-                 maxit=None, udata=None, fitter=None, problem=None, **fitterargs):
+                 maxit=None, udata=None, fitter=None, problem=None, linear=None, **fitterargs):
         if data is None and udata is None:
             raise ValueError('neither data nor udata is specified')
         if model is None:
@@ -120,8 +120,19 @@ class nonlinear_fit(object):
                 raise ValueError("bounds need fitter='mi355x_trf'")
             lower, upper = fitterargs['bounds']
             fitterargs['bounds'] = (np.reshape(lower, -1), np.reshape(upper, -1))
-        fit = FITTERS[self.fitter](self.p0, nf, self._chiv, tol=tol, maxit=maxit, problem=problem,
-                                   **fitterargs)
+        # __init__.py:656-661,:738-787: parameters the fit function is linear in.  The reference
+        # projects them out of the function the plugin sees; the device leaves them undamped
+        # (include/lsqfit_amd.h, lsqamd_set_linear) -- same minimum, chi2 and covariance
+        self.linear = [] if linear is None else [int(i) for i in np.reshape(linear, -1)]
+        if self.linear and (self.fitter != 'mi355x_lm' or fitterargs.get('alg', 'lm') != 'lm'):
+            raise ValueError("linear= needs fitter='mi355x_lm' with alg='lm'")
+        problem.set_linear(self.linear)
+        try:
+            fit = FITTERS[self.fitter](self.p0, nf, self._chiv, tol=tol, maxit=maxit, problem=problem,
+                                       **fitterargs)
+        finally:
+            if self.linear:
+                problem.set_linear(None)
         self.fitter_results = fit
         self.error = fit.error
         self.cov = fit.cov

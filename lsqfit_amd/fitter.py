@@ -201,6 +201,15 @@ class DeviceProblem:
             raise ValueError(self.lib.lsqamd_last_error(self.h).decode())
         _check(self.lib, self.h, rc, 'set_bounds')
 
+    def set_linear(self, index=None):
+        """Parameters the fit function is linear in (nonlinear_fit's ``linear=``,
+        src/lsqfit/__init__.py:738-787); None or empty clears."""
+        idx = np.ascontiguousarray([] if index is None else index, np.int32).reshape(-1)
+        rc = self.lib.lsqamd_set_linear(self.h, idx.ctypes.data_as(C.POINTER(C.c_int32)), idx.size)
+        if rc == -1:
+            raise ValueError(self.lib.lsqamd_last_error(self.h).decode() or 'set_linear: bad index')
+        _check(self.lib, self.h, rc, 'set_linear')
+
     def timing(self, on=True):
         self.lib.lsqamd_timing_enable(self.h, int(on))
 

@@ -81,7 +81,7 @@ class FitResult:
 
 def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
                   svdcut=1e-12, tol=1e-8, maxit=1000, udata=False, extra_cov=None,
-                  jac=None, fitter='gsl_multifit', **fitterargs):
+                  jac=None, fitter='gsl_multifit', linear=None, **fitterargs):
     """``fcn(x, p)`` must accept float arrays and ``oracle.dual.Dual`` arrays
     (or pass ``jac(x, p)`` returning d fcn / d p explicitly)."""
     from .dual import Dual
@@ -157,6 +157,14 @@ def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
             fitterargs['bounds'] = (np.reshape(lo, -1), np.reshape(hi, -1))
         lm = scipy_least_squares(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
     else:
+        if linear is not None and len(linear) > 0:
+            # src/lsqfit/__init__.py:738-787 (_varpro_fit): parameters the fit function is linear in.
+            # The reference wraps the fit function so that every evaluation solves for them
+            # exactly; here they are left out of the LM damping (oracle/lm.py), which takes the
+            # same Gauss-Newton step for the others and reaches the same minimum.
+            mask = np.zeros(p0.size, bool)
+            mask[np.asarray(linear, int)] = True
+            fitterargs = dict(fitterargs, undamped=mask)
         lm = gsl_multifit(p0, nf, chiv.residual, dchiv, tol=tol, maxit=maxit, **fitterargs)
     fit.lm = lm
     fit.chiv = chiv

@@ -210,7 +210,7 @@ def _solve_tr_2d(B, g, delta):
 
 
 def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down,
-           alg='lm', avmax=0.75, h_fvv=0.02, eval_fvec=None):
+           alg='lm', avmax=0.75, h_fvv=0.02, eval_fvec=None, undamped=None):
     """Shared trust.c/fdf.c logic.  ``evaluate(x)`` refreshes ``lin`` with the
     Jacobian-level quantities at x and returns |f|^2; ``eval_fnorm2(x)`` is the
     cheap trial evaluation."""
@@ -226,7 +226,17 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
     res.nfev += 1
     res.njev += 1
     diag = _scale_init(scaler, lin.colnorm)
-    mu = 1e-3 * float(np.max(lin.colnorm / diag)) ** 2 if P else 0.0   # nielsen_init
+    if undamped is not None:
+        # parameters the residual is LINEAR in (nonlinear_fit's ``linear=``): their block of the
+        # damping matrix is zero, so each step solves for them exactly given the step of the
+        # others -- by block elimination the others move by the Gauss-Newton/LM step of the
+        # variable-projection functional (Kaufman's form)
+        if alg != 'lm':
+            raise ValueError("linear parameters need alg='lm'")
+        undamped = np.asarray(undamped, bool)
+        diag = np.where(undamped, 0.0, diag)
+    damped = diag > 0
+    mu = 1e-3 * float(np.max(lin.colnorm[damped] / diag[damped])) ** 2 if np.any(damped) else 0.0   # nielsen_init
     nu = 2
     delta = 0.3 * max(1.0, float(np.linalg.norm(diag * x)))
     dx = np.zeros(P)
@@ -352,6 +362,8 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
                 res.njev += 1
                 x = x_trial
                 diag = _scale_update(scaler, lin.colnorm, diag)
+                if undamped is not None:
+                    diag = np.where(undamped, 0.0, diag)
                 b = 2.0 * rho - 1.0                       # nielsen_accept
                 mu *= max(0.333333333333333, 1.0 - b * b * b)
                 nu = 2
@@ -417,7 +429,7 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
 
 
 def gsl_multifit(x0, n, f, df, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm',
-                 solver='qr', scaler='more', factor_up=3.0, factor_down=2.0, avmax=0.75):
+                 solver='qr', scaler='more', factor_up=3.0, factor_down=2.0, avmax=0.75, undamped=None):
     """Counterpart of ``lsqfit.gsl_multifit`` with an explicit Jacobian callback
     ``df`` in place of the reference's GVar trick.  Returns an object with the
     attributes nonlinear_fit reads (__init__.py:665-679)."""
@@ -439,7 +451,7 @@ def gsl_multifit(x0, n, f, df, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm',
         return float(fv @ fv)
 
     res = _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down,
-                 alg=alg, avmax=avmax, eval_fvec=lambda xx: np.asarray(f(xx), float))
+                 alg=alg, avmax=avmax, eval_fvec=lambda xx: np.asarray(f(xx), float), undamped=undamped)
     res.tol = tol
     res.f = lin.f
     res.J = lin.J

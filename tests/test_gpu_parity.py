@@ -405,3 +405,49 @@ def test_basicfit_extremes_on_device(amd, yfac, pfac):
     ref = ofit.nonlinear_fit(False, np.array([1., 4.]), BASICFIT_YCOV * yfac, lambda p: p ** 2,
                              prior_mean=np.array([4., 16.]), prior_err=BASICFIT_PCOV * pfac)
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+
+
+def test_linear_parameters_on_device(amd):
+    """tests/test_lsqfit.py:1642-1682 (test_linear_dict / test_linear_array): linear=[0, 1] gives the
+    same chi2 (7 places) and the same means (rtol 1e-5) as the plain fit; against the oracle too."""
+    from tests.test_oracle_kat import LINEAR_DATA, linear_case_fcn
+    ym, ys = gvar_lite.parse_array(LINEAR_DATA)
+    pm, ps = gvar_lite.parse_array(2 * ['1.00(1)'] + 2 * ['0.500(1)'])
+    t = np.arange(0., 1., 0.2)
+    model = amd.expr('c0*exp(-E0*t) + c1*exp(-(E0 + dE1)*t)', ['c0', 'c1', 'E0', 'dE1'], xnames=('t',))
+    fita = amd.nonlinear_fit(data=(t, ym, ys), model=model, prior=(pm, ps))
+    fitb = amd.nonlinear_fit(data=(t, ym, ys), model=model, prior=(pm, ps), linear=[0, 1])
+    assert abs(fita.chi2 - fitb.chi2) < 5e-8
+    np.testing.assert_allclose(fita.pmean, fitb.pmean, rtol=1e-5)
+    np.testing.assert_allclose(fita.cov, fitb.cov, rtol=1e-4, atol=1e-12)
+    ref = ofit.nonlinear_fit(False, ym, ys, linear_case_fcn, prior_mean=pm, prior_err=ps, linear=[0, 1], solver='cholesky')
+    assert gu.relmax(fitb.pmean, ref.pmean) < 1e-6 and abs(fitb.chi2 - ref.chi2) < 1e-6 and abs(fitb.nit - ref.nit) <= 1
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(t, ym, ys), model=model, prior=(pm, ps), linear=[0, 1], alg='dogleg')
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(t, ym, ys), model=model, prior=(pm, ps), linear=[7])
+    again = amd.nonlinear_fit(data=(t, ym, ys), model=model, prior=(pm, ps))      # the mask does not outlive the fit
+    assert again.nit == fita.nit and np.array_equal(again.pmean, fita.pmean)
+
+
+def test_linear_amplitudes_cosmix(amd):
+    """The canonical use: all amplitudes of a sum model declared linear (config-2 type problem,
+    P = 256).  Same optimum as the plain fit and as the oracle's undamped-block LM, fewer or equal
+    iterations."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=2048, P=256, seed=20261, block=0, prior_corr=False)
+    data = (d['x'], d['ymean'], d['yerr'])
+    plain = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=d['p0'], tol=1e-10)
+    lin = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], p0=d['p0'], tol=1e-10,
+                            linear=np.arange(128))
+    assert lin.error is None and lin.nit <= plain.nit
+    assert np.max(np.abs(lin.pmean - plain.pmean) / plain.psdev) < 1e-4
+    assert abs(lin.chi2 / plain.chi2 - 1) < 1e-9 and gu.relmax(lin.cov, plain.cov) < 1e-6
+    ref = gu.oracle_fit(d, solver='cholesky', tol=1e-10)
+    mask = np.zeros(256, bool)
+    mask[:128] = True
+    refl = ofit.nonlinear_fit(d['x'], d['ymean'], d['yerr'], gu.cosmix_fcn, prior_mean=d['prior'][0],
+                              prior_err=d['prior'][1], p0=d['p0'], tol=1e-10, jac=gu.cosmix_jac,
+                              solver='cholesky', linear=np.arange(128))
+    assert gu.relmax(lin.pmean, refl.pmean) < 1e-6 and abs(lin.nit - refl.nit) <= 1
+    assert gu.relmax(refl.pmean, ref.pmean) < 1e-6

@@ -624,3 +624,32 @@ def test_basicfit_extremes(yfac, pfac):
     fit = ofit.nonlinear_fit(False, np.array([1., 4.]), BASICFIT_YCOV * yfac, lambda p: p ** 2,
                              prior_mean=np.array([4., 16.]), prior_err=BASICFIT_PCOV * pfac)
     basicfit_checks(fit, yfac, pfac, fit.pmean, fit.cov)
+
+
+LINEAR_DATA = ['2.0008(10)', '1.72452(86)', '1.49030(75)', '1.29009(65)', '1.12017(57)']
+
+
+def linear_case_fcn(p, t=np.arange(0., 1., 0.2)):
+    """tests/test_lsqfit.py:1663-1670: c = p[:2], E = cumsum(p[2:]), sum_i c_i exp(-E_i t)."""
+    c = p[:2]
+    E0, E1 = p[2], p[2] + p[3]
+    return c[0] * dual.exp(-E0 * t) + c[1] * dual.exp(-E1 * t)
+
+
+def test_linear_array_case():
+    """tests/test_lsqfit.py:1663-1682 (and :1642-1661 with dict keys): linear=[0, 1] gives the same
+    chi2 (7 places), the same means (rtol 1e-5) and errors as the plain fit."""
+    ym, ys = gvar_lite.parse_array(LINEAR_DATA)
+    pm, ps = gvar_lite.parse_array(2 * ['1.00(1)'] + 2 * ['0.500(1)'])
+    fita = ofit.nonlinear_fit(False, ym, ys, linear_case_fcn, prior_mean=pm, prior_err=ps)
+    fitb = ofit.nonlinear_fit(False, ym, ys, linear_case_fcn, prior_mean=pm, prior_err=ps, linear=[0, 1])
+    assert abs(fita.chi2 - fitb.chi2) < 5e-8
+    np.testing.assert_allclose(fita.pmean, fitb.pmean, rtol=1e-5)
+    np.testing.assert_allclose(fita.cov, fitb.cov, rtol=1e-4, atol=1e-12)
+    # all parameters linear: one exact step (the reference skips the fitter altogether, :765-781)
+    M = np.array([[1., 1.], [1., -2.], [3., 0.]])
+    kw = dict(prior_mean=np.zeros(2), prior_err=np.ones(2) * 10, jac=lambda p: M)
+    f1 = ofit.nonlinear_fit(False, np.array([1., 2., 3.]), np.ones(3), lambda p: M @ p, **kw)
+    f2 = ofit.nonlinear_fit(False, np.array([1., 2., 3.]), np.ones(3), lambda p: M @ p, linear=[0, 1], **kw)
+    np.testing.assert_allclose(f1.pmean, f2.pmean, rtol=1e-9)
+    assert f2.nit <= 2 and abs(f1.chi2 - f2.chi2) < 1e-10
