@@ -19,15 +19,18 @@ Ah[:, :n] = np.triu(A)
 Ah[:, n] = rng.standard_normal(n)
 src = torch.from_numpy(Ah).cuda()
 dA = src.clone()
-st = torch.cuda.current_stream().cuda_stream
+stream = torch.cuda.Stream()          # a real stream (the product runs on one; graph capture needs one)
+torch.cuda.set_stream(stream)
+st = stream.cuda_stream
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
 for rep in range(6):
     dA.copy_(src)
     torch.cuda.synchronize()
     ev0.record()
-    lib.lsqamd_op_potrf_upper(C.c_void_p(st), C.c_void_p(dA.data_ptr()), n, ld, n + 128, C.c_void_p(work.data_ptr()), wb,
-                              C.c_void_p(info.data_ptr()))
+    rc = lib.lsqamd_op_potrf_upper(C.c_void_p(st), C.c_void_p(dA.data_ptr()), n, ld, n + 128, C.c_void_p(work.data_ptr()), wb,
+                                   C.c_void_p(info.data_ptr()))
+    assert rc == 0, rc
     ev1.record()
     torch.cuda.synchronize()
     ts.append(ev0.elapsed_time(ev1))
