@@ -202,12 +202,13 @@ int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
  * LSQAMD_TRS_DOGBOX read them; p0 must lie inside (else lsqamd_run returns LSQAMD_EINVAL, as scipy raises). */
 int lsqamd_set_bounds(lsqamd_fit *fit, const double *lower, const double *upper);
 /* nonlinear_fit's `linear=` (src/lsqfit/__init__.py:738-787, _varpro_fit; tests/test_lsqfit.py:1642-1682):
- * index[n] names the parameters the fit function is linear in (n = 0 clears).  The reference wraps
- * the residual so that every evaluation solves for them exactly (variable projection) before the
- * plugin sees it; here they are left out of the LM damping matrix instead (D_jj = 0), so each step
- * solves for them exactly given the step of the others -- by block elimination the others take the
- * Gauss-Newton/LM step of the projected functional (Kaufman's form).  Same minimum, covariance and
- * chi2; plain LSQAMD_TRS_LM only. */
+ * index[n] names the parameters the fit function is linear in (n = 0 clears): variable projection.
+ * The reference wraps the residual so that every evaluation first solves for them exactly; so does
+ * the device -- every trial point gets a full evaluation followed by the exact linear solve
+ * A_aa da = -g_a, and the step of the other parameters is the LM step of the projected functional
+ * (Schur complement of the normal matrix; Kaufman's form).  Same minimum, covariance and chi2 as
+ * the plain fit in fewer iterations on multi-exponential problems, at two evaluations per
+ * accepted step.  Plain LSQAMD_TRS_LM only; nfev / njev count every full evaluation. */
 int lsqamd_set_linear(lsqamd_fit *fit, const int32_t *index, int32_t n);
 int lsqamd_set_reduce(lsqamd_fit *fit, lsqamd_reduce_fn fn, void *user);
 /* Row-sharded fits: exactly one rank (on != 0) contributes the replicated prior

@@ -418,23 +418,12 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const do
   return solve_damped_collect(f);
 }
 
-// nonlinear_fit's linear= parameters (lsqamd_set_linear): their entries of D are zero, on the host
-// and in the device mirror the fast path reads
-void scale_mask_linear(lsqamd_fit *f) {
-  if (f->linear.empty()) return;
-  for (int64_t j = 0; j < f->P; ++j)
-    if (f->linear[j]) f->hdiag[j] = 0.0;
-  std::memcpy(f->pin_d, f->hdiag.data(), sizeof(double) * f->P);
-  (void)hipMemcpyAsync(f->dscale, f->pin_d, sizeof(double) * f->P, hipMemcpyHostToDevice, f->st);
-}
-
 void scale_init(lsqamd_fit *f) {
   (void)launch_scale_update(f->st, f->P, f->opt.scaler, 1, f->diag_dev, f->dscale);  // diag_dev = coln^2
   for (int64_t j = 0; j < f->P; ++j) {
     if (f->opt.scaler == LSQAMD_SCALE_LEVENBERG) f->hdiag[j] = 1.0;
     else f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
   }
-  scale_mask_linear(f);
 }
 
 void scale_update(lsqamd_fit *f) {
@@ -443,7 +432,6 @@ void scale_update(lsqamd_fit *f) {
     if (f->opt.scaler == LSQAMD_SCALE_MORE) f->hdiag[j] = std::fmax(f->hdiag[j], f->hcoln[j]);
     else if (f->opt.scaler == LSQAMD_SCALE_MARQUARDT) f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
   }
-  scale_mask_linear(f);
 }
 
 // ---- pieces shared by the trust-region sub-problem solvers -------------------
@@ -679,8 +667,105 @@ int legs_step(lsqamd_fit *f, Legs &L, std::vector<double> &dx) {
   return 0;
 }
 
+// ---- variable projection (nonlinear_fit's linear=, src/lsqfit/__init__.py:738-787) -------------
+// The residual is linear in the masked parameters a, and the reference hands the plugin
+// phi(theta) = min_a chi2(a, theta): its wrapped fit function solves for a at EVERY evaluation.
+// Here: every trial point gets a full evaluation (A_t, g_t, chi2_t) followed by the exact linear
+// solve A_aa da = -g_a (the masked build of the damped matrix, theta frozen) and
+// chi2(a + da, theta_t) = chi2_t + g_a.da; the step in theta is the LM step of the projected
+// functional, (S + mu D_t^2) dtheta = -g_t with the Schur complement S = A_tt - A_ta A_aa^-1 A_at,
+// obtained by solving the full system with the a-block of the damping matrix set to zero
+// (Kaufman's form of the Golub-Pereyra Jacobian; the reference differentiates through its lstsq
+// and keeps the second term too: same minimum, slightly different iterates).  An accepted point
+// is evaluated once more at the projected a; a rejected trial restores (A, g) from a device copy.
+int iterate_varpro(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  const int64_t nstash = f->npk + P + 1;
+  const bool dev_stash = P * f->ldm >= nstash;       // tiny P: the tile padding exceeds P x ldm
+  std::vector<double> host_stash, dt(P), frozen(P), xt(P), v(P), keep_g, keep_c;
+  for (int64_t j = 0; j < P; ++j) frozen[j] = f->linear[j] ? 0.0 : 1.0;
+  int bad_steps = 0;
+  while (true) {
+    for (int64_t j = 0; j < P; ++j) dt[j] = f->linear[j] ? 0.0 : f->hdiag[j];
+    double rho = -1.0;
+    int rc = solve_damped_dev(f, f->mu, dt.data());
+    if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+    bool stashed = false;
+    const double chi2_cur = f->chi2;
+    if (rc == 0) {
+      double vg = 0.0, dv2 = 0.0;
+      for (int64_t j = 0; j < P; ++j) {
+        v[j] = f->hv[j];
+        vg += v[j] * f->hg[j];
+        dv2 += dt[j] * v[j] * dt[j] * v[j];
+        xt[j] = f->hx[j] - v[j];
+      }
+      const double pred_num = vg + f->mu * dv2;      // |J v|^2 + 2 mu |D v|^2 by the system v solves
+      keep_g = f->hg; keep_c = f->hcoln;
+      if (dev_stash) {
+        HIPCHK(f, hipMemcpyAsync(f->cov, f->redbuf, sizeof(double) * nstash, hipMemcpyDeviceToDevice, f->st));
+      } else {
+        host_stash.resize(nstash);
+        HIPCHK(f, hipMemcpyAsync(host_stash.data(), f->redbuf, sizeof(double) * nstash, hipMemcpyDeviceToHost, f->st));
+        HIPCHK(f, hipStreamSynchronize(f->st));
+      }
+      stashed = true;
+      std::memcpy(f->pin_x, xt.data(), sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      rc = eval_normal_dev(f, f->p_trial);           // full evaluation at the trial point ...
+      f->nfev++;
+      if (rc < 0 && rc != LSQAMD_ENONFINITE) return rc;
+      if (rc == 0) {
+        rc = solve_damped_dev(f, 0.0, nullptr, frozen.data());   // ... and the exact linear solve there
+        if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+      }
+      if (rc == 0) {
+        double chi2_t = f->chi2;
+        for (int64_t j = 0; j < P; ++j)
+          if (f->linear[j]) { chi2_t -= f->hg[j] * f->hv[j]; xt[j] -= f->hv[j]; }
+        for (int64_t j = 0; j < P; ++j) f->hdx[j] = xt[j] - f->hx[j];   // trial steps count for the xtol test
+        const double normf = std::sqrt(chi2_cur), normf_t = std::sqrt(chi2_t > 0.0 ? chi2_t : 0.0);
+        if (normf_t < normf) {
+          const double u = normf_t / normf;
+          const double pred = pred_num / chi2_cur;
+          rho = pred > 0.0 ? (1.0 - u * u) / pred : -1.0;
+        }
+      }
+    }
+    if (rho > 0.0) {
+      std::memcpy(f->pin_x, xt.data(), sizeof(double) * P);
+      HIPCHK(f, hipMemcpyAsync(f->p_trial, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+      rc = eval_normal_dev(f, f->p_trial);           // J, A, g at the projected point
+      f->nfev++;
+      if (rc) return rc;
+      f->hx = xt;
+      std::swap(f->p_dev, f->p_trial);
+      scale_update(f);
+      const double b = 2.0 * rho - 1.0;
+      f->mu *= std::fmax(0.333333333333333, 1.0 - b * b * b);
+      f->nu = 2;
+      return 0;
+    }
+    if (stashed) {                                   // back to the current point's A, g
+      if (dev_stash) HIPCHK(f, hipMemcpyAsync(f->redbuf, f->cov, sizeof(double) * nstash, hipMemcpyDeviceToDevice, f->st));
+      else HIPCHK(f, hipMemcpy(f->redbuf, host_stash.data(), sizeof(double) * nstash, hipMemcpyHostToDevice));
+      f->hg = keep_g; f->hcoln = keep_c;
+      f->chi2 = chi2_cur;
+      f->have_dense_A = false;
+    }
+    f->mu *= (double)f->nu;
+    f->nu <<= 1;
+    if (++bad_steps > 15) {
+      const int rc2 = eval_normal_dev(f, f->p_dev);  // leave J, f of the CURRENT point behind
+      if (rc2) return rc2;
+      return LSQAMD_ENOPROG;
+    }
+  }
+}
+
 // one trust_iterate: GSL_SUCCESS (0) or LSQAMD_ENOPROG; negative on backend failure
 int iterate(lsqamd_fit *f) {
+  if (!f->linear.empty()) return iterate_varpro(f);
   const int64_t P = f->P;
   const int trs = f->opt.trs;
   const bool lm_family = trs == LSQAMD_TRS_LM || trs == LSQAMD_TRS_LMACCEL;
@@ -837,10 +922,26 @@ int do_init(lsqamd_fit *f, const double *p0) {
   rc = eval_normal_dev(f, f->p_dev);
   if (rc) return rc;
   f->nfev++;
+  if (!f->linear.empty()) {
+    // nonlinear_fit's linear= (lsqamd_set_linear): variable projection (iterate_varpro) starts from
+    // the projected point -- A_aa da = -g_a with the others frozen, one more evaluation
+    std::vector<double> frozen(P);
+    for (int64_t j = 0; j < P; ++j) frozen[j] = f->linear[j] ? 0.0 : 1.0;
+    rc = solve_damped_dev(f, 0.0, nullptr, frozen.data());
+    if (rc == LSQAMD_ENOTPD) FAIL(f, LSQAMD_ENOTPD, "linear parameters: their block of J^T J is not positive definite");
+    if (rc) return rc;
+    for (int64_t j = 0; j < P; ++j)
+      if (f->linear[j]) f->hx[j] -= f->hv[j];
+    std::memcpy(f->pin_x, f->hx.data(), sizeof(double) * P);
+    HIPCHK(f, hipMemcpyAsync(f->p_dev, f->pin_x, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
+    rc = eval_normal_dev(f, f->p_dev);
+    if (rc) return rc;
+    f->nfev++;
+  }
   scale_init(f);
   double mx = 0.0;   // over the damped parameters (all of them unless lsqamd_set_linear was used)
   for (int64_t j = 0; j < P; ++j)
-    if (f->hdiag[j] > 0.0) mx = std::fmax(mx, f->hcoln[j] / f->hdiag[j]);
+    if (f->linear.empty() || !f->linear[j]) mx = std::fmax(mx, f->hcoln[j] / f->hdiag[j]);
   f->mu = 1e-3 * mx * mx;
   f->nu = 2;
   double dxn = 0.0;

@@ -67,7 +67,7 @@ struct lsqamd_fit {
 
   // box bounds of the reflective trust-region method (empty: none)
   std::vector<double> lb, ub;
-  // parameters the residual is linear in (empty: none): left out of the LM damping
+  // parameters the residual is linear in (empty: none): variable projection (api.hip iterate_varpro)
   std::vector<char> linear;
 
   // LM state (host)

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, in
     const int64_t i = tm * TB + r, j = tn * TB + c;
     if (i < P && j < P) {
       double v = src[r * TB + c];
-      if (i == j) {
+      if (i == j && mu != 0.0) {  // (mu = 0 callers may pass a D that is not set up yet)
         const double d = diag[i];
         v += mu * d * d;
       }

@@ -121,8 +121,8 @@ class nonlinear_fit(object):
             lower, upper = fitterargs['bounds']
             fitterargs['bounds'] = (np.reshape(lower, -1), np.reshape(upper, -1))
         # __init__.py:656-661,:738-787: parameters the fit function is linear in.  The reference
-        # projects them out of the function the plugin sees; the device leaves them undamped
-        # (include/lsqfit_amd.h, lsqamd_set_linear) -- same minimum, chi2 and covariance
+        # projects them out of the function the plugin sees at every evaluation; so does the device
+        # (include/lsqfit_amd.h, lsqamd_set_linear; api.hip iterate_varpro)
         self.linear = [] if linear is None else [int(i) for i in np.reshape(linear, -1)]
         if self.linear and (self.fitter != 'mi355x_lm' or fitterargs.get('alg', 'lm') != 'lm'):
             raise ValueError("linear= needs fitter='mi355x_lm' with alg='lm'")

@@ -160,8 +160,8 @@ def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
         if linear is not None and len(linear) > 0:
             # src/lsqfit/__init__.py:738-787 (_varpro_fit): parameters the fit function is linear in.
             # The reference wraps the fit function so that every evaluation solves for them
-            # exactly; here they are left out of the LM damping (oracle/lm.py), which takes the
-            # same Gauss-Newton step for the others and reaches the same minimum.
+            # exactly (variable projection); oracle/lm.py iterate_varpro does the same on the
+            # normal equations.
             mask = np.zeros(p0.size, bool)
             mask[np.asarray(linear, int)] = True
             fitterargs = dict(fitterargs, undamped=mask)

@@ -105,6 +105,10 @@ class _DenseLin:
             return -np.linalg.lstsq(aug, rhs, rcond=None)[0]
         raise ValueError('unkown solver ' + str(self.solver))
 
+    def step_subset(self, mask):
+        """argmin over the masked parameters alone of |J da + f|^2 (the others held)"""
+        return -np.linalg.lstsq(self.J[:, mask], self.f, rcond=None)[0]
+
     def norm_Jv2(self, v):
         w = self.J @ v
         return float(w @ w)
@@ -151,6 +155,9 @@ class _NormalLin:
         M = self.A + mu * np.diag(diag ** 2)
         c = sla.cho_factor(M, lower=True)
         return -sla.cho_solve(c, self.g)
+
+    def step_subset(self, mask):
+        return -np.linalg.solve(self.A[np.ix_(mask, mask)], self.g[mask])
 
     def norm_Jv2(self, v):
         return float(v @ (self.A @ v))
@@ -225,16 +232,35 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
     fnorm2 = evaluate(x)
     res.nfev += 1
     res.njev += 1
-    diag = _scale_init(scaler, lin.colnorm)
-    if undamped is not None:
-        # parameters the residual is LINEAR in (nonlinear_fit's ``linear=``): their block of the
-        # damping matrix is zero, so each step solves for them exactly given the step of the
-        # others -- by block elimination the others move by the Gauss-Newton/LM step of the
-        # variable-projection functional (Kaufman's form)
+    lin_mask = None
+    if undamped is not None and np.any(undamped):
+        # nonlinear_fit's ``linear=`` (src/lsqfit/__init__.py:738-787, _varpro_fit): variable
+        # projection.  The residual is linear in the masked parameters a, so the fitter works on
+        # phi(theta) = min_a chi2(a, theta): EVERY evaluation first solves A_aa da = -g_a exactly
+        # (the reference: lstsq inside the wrapped fit function), and the step in theta is the LM
+        # step of the projected functional, (S + mu D_theta^2) dtheta = -g_theta with the Schur
+        # complement S = A_tt - A_ta A_aa^-1 A_at -- obtained by solving the full system with
+        # the a-block of the damping matrix set to zero (Kaufman's form of the Golub-Pereyra
+        # Jacobian; the reference differentiates through lstsq and keeps the second term too:
+        # same minimum, slightly different iterates).
         if alg != 'lm':
             raise ValueError("linear parameters need alg='lm'")
-        undamped = np.asarray(undamped, bool)
-        diag = np.where(undamped, 0.0, diag)
+        lin_mask = np.asarray(undamped, bool)
+
+        def project(xx, f2):
+            """-> (x with a re-solved, chi2 there); lin must hold the evaluation at xx"""
+            da = lin.step_subset(lin_mask)
+            xx = xx.copy()
+            xx[lin_mask] += da
+            return xx, f2 + float(lin.g[lin_mask] @ da)
+
+        x, _ = project(x, fnorm2)
+        fnorm2 = evaluate(x)
+        res.nfev += 1
+        res.njev += 1
+    diag = _scale_init(scaler, lin.colnorm)
+    if lin_mask is not None:
+        diag = np.where(lin_mask, 0.0, diag)
     damped = diag > 0
     mu = 1e-3 * float(np.max(lin.colnorm[damped] / diag[damped])) ** 2 if np.any(damped) else 0.0   # nielsen_init
     nu = 2
@@ -362,8 +388,6 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
                 res.njev += 1
                 x = x_trial
                 diag = _scale_update(scaler, lin.colnorm, diag)
-                if undamped is not None:
-                    diag = np.where(undamped, 0.0, diag)
                 b = 2.0 * rho - 1.0                       # nielsen_accept
                 mu *= max(0.333333333333333, 1.0 - b * b * b)
                 nu = 2
@@ -373,6 +397,49 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
             bad_steps += 1
             if bad_steps > 15:
                 return GSL_ENOPROG
+
+    def iterate_varpro():
+        nonlocal x, fnorm2, diag, mu, nu, dx
+        bad_steps = 0
+        while True:
+            v = lin.step(mu, diag)                        # a-block undamped: Schur-complement step
+            normf = np.sqrt(fnorm2)
+            pred = preduction(v, normf)
+            keep = dict(lin.__dict__)
+            with np.errstate(all='ignore'):
+                ft2 = evaluate(x + v)                     # full evaluation at the trial point ...
+            res.nfev += 1
+            res.njev += 1
+            res.ntrial += 1
+            finite = np.isfinite(ft2) and np.all(np.isfinite(lin.g)) and np.all(np.isfinite(lin.colnorm))
+            x_trial = x + v
+            if finite:
+                x_trial, ft2 = project(x_trial, ft2)      # ... then the exact linear solve there
+            dx = x_trial - x                              # what the convergence test sees (trial steps too)
+            normf_trial = np.sqrt(max(ft2, 0.0)) if finite else np.inf
+            rho = -1.0
+            if normf_trial < normf:
+                u = normf_trial / normf
+                rho = (1.0 - u * u) / pred if pred > 0.0 else -1.0
+            if rho > 0.0:
+                fnorm2 = evaluate(x_trial)                # J, g at the projected point
+                res.nfev += 1
+                res.njev += 1
+                x = x_trial
+                diag = np.where(lin_mask, 0.0, _scale_update(scaler, lin.colnorm, np.where(lin_mask, 1.0, diag)))
+                b = 2.0 * rho - 1.0
+                mu *= max(0.333333333333333, 1.0 - b * b * b)
+                nu = 2
+                return GSL_SUCCESS
+            lin.__dict__.update(keep)                     # back to the current point's J, g
+            mu = float(mu) * nu
+            nu <<= 1
+            bad_steps += 1
+            if bad_steps > 15:
+                return GSL_ENOPROG
+
+    if lin_mask is not None:
+        iterate = iterate_varpro
 
     def test():
         if np.all(np.abs(dx) < xtol * xtol + xtol * np.abs(x)):     # test_delta
