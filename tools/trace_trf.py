@@ -1,5 +1,5 @@
 """Developer script: convergence trace of a bounded fit (LSQAMD_TRF_TRACE=1 prints every outer
-iteration).  usage: trace_trf.py N P nwall maxit [jac]"""
+iteration).  usage: trace_trf.py N P nwall maxit [jac] [dogbox]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, '.')
@@ -31,12 +31,3 @@ if 'dogbox' in sys.argv:
 fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=p0,
                         fitter='mi355x_trf', bounds=(lo, hi), tol=tol, maxit=int(sys.argv[4]), x_scale=xs)
 print('bounded: nit', fit.nit, 'crit', fit.stopping_criterion, 'time', fit.time_fit, 'chi2', fit.chi2, 'free chi2', free.chi2)
-if 'oracle' in sys.argv:
-    from oracle import fit as ofit
-    from tests import gpu_util as gu
-    t0 = time.time()
-    ref = ofit.nonlinear_fit(d['x'], d['ymean'], gu.dense_cov(d['yerr'], N), gu.cosmix_fcn, prior_mean=d['prior'][0],
-                             prior_err=d['prior'][1], p0=p0, jac=gu.cosmix_jac, fitter='scipy_least_squares',
-                             bounds=(lo, hi), tol=tol, maxit=int(sys.argv[4]))
-    print('oracle : nit', ref.nit, 'crit', ref.stopping_criterion, 'time', time.time() - t0, 'chi2', ref.chi2,
-          'max |dp|/sd', np.max(np.abs(ref.pmean - fit.pmean) / free.psdev))
