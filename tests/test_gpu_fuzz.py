@@ -64,6 +64,8 @@ def make_case(seed):
     y = ybar + np.linalg.cholesky(cov) @ rng.standard_normal(N)
     yerr = dict(sdev=sd, blocks=blocks) if blocks else sd
     prior_kind = ['diag', 'dense', 'none'][int(rng.integers(0, 3))]
+    if prior_kind == 'none' and family == 'multiexp' and K >= 3:
+        prior_kind = 'diag'          # three free exponentials without a prior: not a well-posed fit
     perr = psd if prior_kind != 'dense' else random_spd(rng, psd)
     p0 = pm * (1 + 0.05 * rng.standard_normal(P))
     return dict(family=family, K=K, x=x, y=y, yerr=yerr, cov=cov, pm=pm, perr=perr, prior_kind=prior_kind,
