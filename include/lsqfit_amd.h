@@ -104,6 +104,12 @@ enum {
 #define LSQAMD_TAPE_CHUNK 16       /* ... differentiated 16 at a time: ceil(P/16) passes over the tape per row */
 #define LSQAMD_TAPE_MAX_STACK 16
 
+/* Devices this process can use (one process per GPU; a host in another language picks its
+ * device with the HIP runtime before lsqamd_create).  *count <- visible devices (0 without a GPU:
+ * not an error); for device `index`, when it exists: arch[cap] <- its gfx name ("gfx950:..."),
+ * *hbm_bytes <- its memory.  arch / hbm_bytes may be NULL. */
+int lsqamd_query_devices(int32_t *count, int32_t index, char *arch, size_t cap, int64_t *hbm_bytes);
+
 typedef struct lsqamd_fit lsqamd_fit; /* opaque handle (replaces gsl_multifit_nlinear_workspace, _gsl.pyx:672) */
 
 /* Problem shape.  n_data rows are the LOCAL rows of this process when the fit

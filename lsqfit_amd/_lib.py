@@ -55,6 +55,8 @@ PROTOTYPES = {
     'lsqamd_set_prior': (C.c_int, [_vp, _dp, _dp]),
     'lsqamd_set_ymean': (C.c_int, [_vp, _dp]),
     'lsqamd_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
+    'lsqamd_query_devices': (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_size_t,
+                                       C.POINTER(C.c_int64)]),
     'lsqamd_set_bounds': (C.c_int, [_vp, _dp, _dp]),
     'lsqamd_set_linear': (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32]),
     'lsqamd_set_reduce': (C.c_int, [_vp, REDUCE_FN, _vp]),

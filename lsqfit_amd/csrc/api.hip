@@ -1015,6 +1015,21 @@ extern "C" {
 
 int lsqamd_abi_version(void) { return LSQAMD_ABI_VERSION; }
 
+int lsqamd_query_devices(int32_t *count, int32_t index, char *arch, size_t cap, int64_t *hbm_bytes) {
+  if (!count) return LSQAMD_EINVAL;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) n = 0;   // no driver / no GPU: zero devices
+  *count = n;
+  if (arch && cap) arch[0] = 0;
+  if (hbm_bytes) *hbm_bytes = 0;
+  if (index < 0 || index >= n) return 0;
+  hipDeviceProp_t pr;
+  if (hipGetDeviceProperties(&pr, index) != hipSuccess) return LSQAMD_EHIP;
+  if (arch && cap) snprintf(arch, cap, "%s", pr.gcnArchName);
+  if (hbm_bytes) *hbm_bytes = (int64_t)pr.totalGlobalMem;
+  return 0;
+}
+
 size_t lsqamd_workspace_bytes(const lsqamd_config *cfg) {
   if (check_cfg(cfg) != 0) return 0;
   lsqamd_fit tmp;

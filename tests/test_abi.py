@@ -69,6 +69,21 @@ def test_workspace_sizing_and_config_validation(libpath):
     assert lib.lsqamd_create(ctypes.byref(cfg), None, 0, None, ctypes.byref(h)) == -1   # EINVAL, no abort
 
 
+def test_query_devices_without_compute(libpath):
+    import torch
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    n, mem = ctypes.c_int32(-1), ctypes.c_int64(-1)
+    buf = ctypes.create_string_buffer(64)
+    assert lib.lsqamd_query_devices(ctypes.byref(n), 0, buf, 64, ctypes.byref(mem)) == 0
+    assert n.value == torch.cuda.device_count()
+    if n.value:
+        assert buf.value.startswith(b'gfx') and mem.value > 1 << 30
+    else:
+        assert buf.value == b'' and mem.value == 0
+    assert lib.lsqamd_query_devices(None, 0, None, 0, None) == -1
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product refuses to fit (it must never route through the oracle)."""
     import torch

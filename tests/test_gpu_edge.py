@@ -188,3 +188,13 @@ def test_svd_cut_floor_on_device(amd, svdcut):
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
     assert abs(fit.chi2 - ref.chi2) < 1e-6 * max(1.0, ref.chi2)
     assert abs(fit.logGBF - ref.logGBF) < 1e-6 * abs(ref.logGBF)
+
+
+def test_query_devices_reports_the_mi355x():
+    import ctypes
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    n, mem = ctypes.c_int32(0), ctypes.c_int64(0)
+    buf = ctypes.create_string_buffer(64)
+    assert lib.lsqamd_query_devices(ctypes.byref(n), 0, buf, 64, ctypes.byref(mem)) == 0
+    assert n.value >= 1 and buf.value.startswith(b'gfx950') and mem.value > 200 * (1 << 30)
