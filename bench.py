@@ -254,7 +254,8 @@ def main():
         flops = float(n_local) * P * (P + 1)          # algorithmic, upper triangle, 2 flop/MAC
         ach = (flops / (syrk_ms / syrk_n * 1e-3) / 1e12) if syrk_n else 0.0
         out = {
-            'metric': 'fp64 LM steps/sec at (N_data,N_param)=(%d,%d)' % (N, P),
+            # BASELINE.json's metric string; the "chi2 match" half is config.chi2_match below
+            'metric': 'fp64 LM steps/sec at (N_data,N_param)=(%d,%d); chi2 match vs GSL' % (N, P),
             'value': args.steps / elapsed, 'unit': 'LM steps/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -282,8 +283,21 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                cb, _ = cpu_baseline(d, wh, args.cpu_seconds)
+                cb, res = cpu_baseline(d, wh, args.cpu_seconds)
                 out['cpu_baseline'] = cb
+                # the parity half of the metric, at the bench's own size: the device repeats, from the
+                # same start, the LM iterations the CPU port (the GSL restatement) just took; chi2 must
+                # agree to the north_star tolerance (outside the timed region)
+                rc = lib.lsqamd_init(h, _lib.dptr(np.ascontiguousarray(d['p0'])))
+                for _ in range(res.nit):
+                    if rc == 0:
+                        rc = lib.lsqamd_step(h, None)
+                s2 = _lib.Summary()
+                lib.lsqamd_finish(h, C.byref(s2))
+                rel = abs(s2.chi2 - res.fnorm2) / res.fnorm2
+                out['config']['chi2_match'] = {'after_lm_steps': int(res.nit), 'device_chi2': s2.chi2,
+                                               'cpu_port_chi2': float(res.fnorm2), 'rel_diff': rel,
+                                               'ok': bool(rc == 0 and rel < 1e-6)}
             except Exception as e:   # the baseline must never take the measurement down
                 out['cpu_baseline'] = {'value': None, 'unit': 'LM steps/s', 'cores': 0, 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}

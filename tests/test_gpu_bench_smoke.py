@@ -33,6 +33,9 @@ def test_single_process_line():
     assert abs(rf['frac'] - rf['achieved'] / rf['peak']) < 1e-12
     cb = d['cpu_baseline']
     assert cb['kind'] == 'port' and cb['cores'] >= 1 and cb['value'] > 0
+    cm = d['config']['chi2_match']
+    assert cm['ok'] and cm['rel_diff'] < 1e-6 and cm['after_lm_steps'] >= 1
+    assert d['metric'].endswith('chi2 match vs GSL')
     fq = cb['faithful_qr_1thread']
     assert fq['cores'] == 1 and fq['extrapolated'] and 0 < fq['value'] < cb['value'] * 100
 
