@@ -63,6 +63,7 @@ struct BState {  // per-fit device scalars
   double *mu, *chi2, *chi2t, *vg, *dv2;
   int32_t *nu, *bad, *iter, *nit, *info, *status, *active, *accepted, *enoprog, *cholinfo, *nfev, *njev;
   int32_t *n_active;
+  int32_t *moved;   // active and accepted this round: the only fits whose normal equations change
 };
 
 // ---- slabs -> packed tiles ---------------------------------------------------------------
@@ -335,7 +336,9 @@ __global__ __launch_bounds__(256) void b_sumsq_stage2(const double *partial, int
 // trust_eval_step + nielsen accept/reject, one thread per fit
 __global__ void b_decide_kernel(int B, double factor_up, double factor_down, BState s) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B || !s.active[b]) return;
+  if (b >= B) return;
+  s.moved[b] = 0;
+  if (!s.active[b]) return;
   double rho = -1.0;
   if (s.cholinfo[b] == 0) {
     const double normf = sqrt(s.chi2[b]), normf_t = sqrt(s.chi2t[b]);
@@ -350,6 +353,7 @@ __global__ void b_decide_kernel(int B, double factor_up, double factor_down, BSt
   s.enoprog[b] = 0;
   if (rho > 0.0) {
     s.accepted[b] = 1;
+    s.moved[b] = 1;
     const double bb = 2.0 * rho - 1.0;
     s.mu[b] *= fmax(0.333333333333333, 1.0 - bb * bb * bb);
     s.nu[b] = 2;
@@ -598,6 +602,7 @@ size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
   f->s.active = cv.take<int32_t>(B); f->s.accepted = cv.take<int32_t>(B); f->s.enoprog = cv.take<int32_t>(B);
   f->s.cholinfo = cv.take<int32_t>(B); f->s.nfev = cv.take<int32_t>(B); f->s.njev = cv.take<int32_t>(B);
   f->s.n_active = cv.take<int32_t>(4);
+  f->s.moved = cv.take<int32_t>(B);
   f->syrk_nwork = (int32_t)syrk_work_count(P, f->splits);
   f->syrk_map = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);
   return cv.off;
@@ -627,10 +632,12 @@ ModelArgs model_args_b(const lsqamdb_fits *f, const double *p) {
   return m;
 }
 
-// Jacobian, J^T J (packed), J^T f, chi2 for every active fit at its current x
-int normal_all(lsqamdb_fits *f) {
+// Jacobian, J^T J (packed), J^T f, chi2 for every fit flagged in `mask` at its current x (inside a
+// round: the fits whose trial was accepted -- a rejected trial leaves x, J and the sums as they are)
+int normal_all(lsqamdb_fits *f, const int32_t *mask) {
   const int64_t P = f->P, N = f->N, B = f->B;
   ModelArgs m = model_args_b(f, f->px);
+  m.batch_active = mask;
   m.out_stride = N * f->ld;
   BHIP(f, launch_jacobian_ex(f->st, m, f->J, f->cfg.n_blocks > 0 ? f->Jraw : nullptr, f->ld));
   // block rows: J_b <- W_b . Jraw_b for every fit (W shared: X stride 0, batch = fits)
@@ -642,7 +649,7 @@ int normal_all(lsqamdb_fits *f) {
     w.C = f->J + f->h_row0[k] * f->ld; w.ldc = f->ld; w.sc = N * f->ld;
     w.M = Bk; w.N = P + 1; w.K = Bk;
     w.x_upper_tri = f->h_tri[k];
-    w.batch = (int32_t)B; w.batch_active = f->s.active;
+    w.batch = (int32_t)B; w.batch_active = mask;
     BHIP(f, launch_gemm_tn(f->st, w));
   }
   GemmTN g;
@@ -654,32 +661,32 @@ int normal_all(lsqamdb_fits *f) {
   g.splits = f->splits;
   g.split_stride = P * f->ldm;
   g.work_map = f->syrk_map; g.n_work = f->syrk_nwork;
-  g.batch = (int32_t)B; g.batch_active = f->s.active;
+  g.batch = (int32_t)B; g.batch_active = mask;
   BHIP(f, launch_gemm_tn(f->st, g));
   const int64_t red_stride = f->npk + P + 1;
   hipLaunchKernelGGL(b_finalize_pack_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
                      dim3(256), 0, f->st, f->slabs, f->splits, P * f->ldm, (int64_t)f->splits * P * f->ldm, P,
-                     f->ldm, f->T, f->red, red_stride, f->s.active);
+                     f->ldm, f->T, f->red, red_stride, mask);
   int64_t nchunks = f->nparts;
   if (nchunks > N) nchunks = N;
   const int64_t rpc = (N + nchunks - 1) / nchunks;
   nchunks = (N + rpc - 1) / rpc;
   hipLaunchKernelGGL(b_colsum_stage1, dim3((unsigned)((P + 1 + 511) / 512), (unsigned)nchunks, (unsigned)B),
                      dim3(256), 0, f->st, f->J, N, f->ld, P + 1, P, rpc, N * f->ld, f->partial,
-                     (int64_t)f->nparts * (P + 1), f->s.active);
+                     (int64_t)f->nparts * (P + 1), mask);
   hipLaunchKernelGGL(b_colsum_stage2, dim3((unsigned)((P + 1 + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
                      f->partial, nchunks, P + 1, (int64_t)f->nparts * (P + 1), f->red + f->npk, red_stride,
-                     f->s.active);
+                     mask);
   if (f->cfg.has_prior && f->cfg.prior_dense) {
     hipLaunchKernelGGL(b_prior_matrix_dense_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
-                       dim3(256), 0, f->st, f->red, red_stride, P, f->T, f->pprec, f->s.active);
+                       dim3(256), 0, f->st, f->red, red_stride, P, f->T, f->pprec, mask);
     hipLaunchKernelGGL(b_prior_vec_dense_kernel, dim3((unsigned)((P + 3) / 4), (unsigned)B), dim3(256), 0, f->st,
-                       P, f->pprec, f->pmean, f->px, f->ptvec, f->s.active);
+                       P, f->pprec, f->pmean, f->px, f->ptvec, mask);
     hipLaunchKernelGGL(b_prior_apply_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->pmean, f->px, f->ptvec,
-                       f->red + f->npk, red_stride, f->s.active);
+                       f->red + f->npk, red_stride, mask);
   } else if (f->cfg.has_prior)
     hipLaunchKernelGGL(b_prior_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->pprec, f->pmean,
-                       f->px, f->red, red_stride, f->red + f->npk, red_stride, f->s.active);
+                       f->px, f->red, red_stride, f->red + f->npk, red_stride, mask);
   BHIP(f, hipGetLastError());
   return 0;
 }
@@ -717,7 +724,7 @@ int round_all(lsqamdb_fits *f) {
                      f->opt.factor_up, f->opt.factor_down, f->s);
   hipLaunchKernelGGL(b_commit_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, f->st, P,
                      f->px, f->pxt, f->s);
-  int rc = normal_all(f);
+  int rc = normal_all(f, f->s.moved);
   if (rc) return rc;
   hipLaunchKernelGGL(b_post_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->red, red_stride,
                      f->red + f->npk, red_stride, f->diag, f->px, f->dx, f->opt.scaler, f->opt.xtol, f->opt.gtol,
@@ -897,7 +904,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     BHIP(f, hipMemcpyAsync(f->s.active, ones.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, f->st));
     BHIP(f, hipStreamSynchronize(f->st));
   }
-  int rc = normal_all(f);
+  int rc = normal_all(f, f->s.active);
   if (rc) return rc;
   hipLaunchKernelGGL(b_init_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->red, f->npk + P + 1,
                      f->red + f->npk, f->npk + P + 1, f->diag, f->opt.scaler, f->s);
