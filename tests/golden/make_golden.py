@@ -190,6 +190,16 @@ def make_kat():
     strs = [re.findall(r"'([^']+)'", l) for l in lists]
     kat['x_err'] = dict(x=strs[0], y=strs[1], prior_b=strs[2],
                         out=open(os.path.join(REF, 'examples/x-err.out')).read())
+    # examples/y-noerr.py:82-90 / y-noerr.out ("y has no error bars": 100 - nexp exponentials of a
+    # 100-term prior are marginalised into the data, which makes data and fit prior CORRELATED
+    # through E = cumsum(dE)): data literals only; the prior is a[i] = 0.5(5), dE[i] = 1.0(1) (:74-79)
+    src = open(os.path.join(REF, 'examples/y-noerr.py')).read()
+    body = src[src.index('def make_data'):]
+    xs = [float(v) for v in re.findall(FLOAT, re.search(r'x = np\.array\(\[(.*?)\]\)', body, re.S).group(1))]
+    ys = [float(v) for v in re.findall(FLOAT, re.search(r'y = np\.array\(\[(.*?)\]\)', body, re.S).group(1))]
+    assert len(xs) == 9 and len(ys) == 9
+    kat['y_noerr'] = dict(x=xs, y=ys, n_terms=100, prior_a='0.5(5)', prior_dE='1.0(1)', tol=1e-15, svdcut=1e-12,
+                          out=open(os.path.join(REF, 'examples/y-noerr.out')).read())
     json.dump(kat, open(os.path.join(OUT, 'kat.json'), 'w'), indent=1)
     print('kat.json:', len(kat), 'entries')
 

@@ -653,3 +653,37 @@ def test_linear_array_case():
     f2 = ofit.nonlinear_fit(False, np.array([1., 2., 3.]), np.ones(3), lambda p: M @ p, linear=[0, 1], **kw)
     np.testing.assert_allclose(f1.pmean, f2.pmean, rtol=1e-9)
     assert f2.nit <= 2 and abs(f1.chi2 - f2.chi2) < 1e-10
+
+
+def y_noerr_fcn(x, p):
+    n = p.size // 2
+    return dual.stack_sum(p[i] * dual.exp(-p[n + i] * x) for i in range(n))
+
+
+def test_y_noerr_out_data_prior_correlations():
+    """examples/y-noerr.out: marginalising 100 - nexp exponentials into the data correlates the data
+    with the fit prior (E = cumsum(dE)); concat(y, prior) is ONE dense block whose correlation matrix
+    has 2-3 modes on the svdcut floor.  Every printed parameter string, chi2/dof, Q, svdn and (nexp <=
+    4; the last one sits on the floor's rounding) logGBF to 4-5 digits; iteration counts within 15 %."""
+    from tests.helpers import y_noerr_expected, y_noerr_joint
+    k = KAT['y_noerr']
+    exp = y_noerr_expected(k)
+    assert len(exp) == 5
+    p0 = None
+    for nexp in range(1, 6):
+        x, mean, cov = y_noerr_joint(k, nexp)
+        P, n = 2 * nexp, len(k['x'])
+        extra = [((i, n + j), cov[i, n + j]) for i in range(n) for j in range(P) if cov[i, n + j] != 0.0]
+        assert extra                                                   # the cross-correlations are there
+        if p0 is not None:                                             # p0 = previous fit.pmean (:46) + prior means
+            p0 = np.concatenate([p0[:nexp - 1], [mean[n + nexp - 1]], p0[nexp - 1:], [mean[n + P - 1]]])
+        fit = ofit.nonlinear_fit(x, mean[:n], cov[:n, :n], y_noerr_fcn, prior_mean=mean[n:], prior_err=cov[n:, n:],
+                                 p0=p0, tol=k['tol'], svdcut=k['svdcut'], extra_cov=extra)
+        e = exp[nexp - 1]
+        assert fit.dof == e['dof'] and fit.svdn == e['svdn']
+        assert '%.2g' % (fit.chi2 / fit.dof) == e['chi2dof'] and '%.2g' % fit.Q == e['Q']
+        assert [gvar_lite.fmt(m, s) for m, s in zip(fit.pmean, fit.psdev)] == e['pars']
+        if nexp <= 4:
+            assert abs(fit.logGBF - e['logGBF']) < 2e-3
+        assert abs(fit.nit - e['nit']) <= max(2, 0.15 * e['nit'])
+        p0 = fit.pmean
