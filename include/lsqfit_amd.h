@@ -201,6 +201,13 @@ int lsqamd_set_data(lsqamd_fit *fit, const double *ymean, const double *wdiag, i
  * prec[P*P] (dense, symmetric) as cfg.prior_dense says.  The prior rows of
  * chiv (_utilities.pyx:76-77) enter J^T J / J^T f / chi2 through it. */
 int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);
+/* Data-prior cross-correlations (the reference whitens concat(y, prior) as ONE vector,
+ * src/lsqfit/__init__.py:1892-1900; examples/y-noerr.py): create the fit with has_prior = 0 and
+ * n_data = N + (number of prior entries), give the prior entries as extra rows of ymean / wdiag /
+ * the covariance blocks (any block may mix both kinds), and flag them here: row_param[n_data] holds
+ * -1 for a model row and j >= 0 for a row whose "model" is the parameter p_j itself (its x is
+ * ignored).  NULL clears.  Single-device fits only; lsqamd_eval_fcn / _dpdy / _chi2_points decline. */
+int lsqamd_set_param_rows(lsqamd_fit *fit, const int32_t *row_param);
 int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
 /* Box bounds lower[P] < upper[P] (+-INFINITY = open side; NULL array = open everywhere; both
  * NULL clears them): the flattened `bounds` pair nonlinear_fit hands to scipy_least_squares

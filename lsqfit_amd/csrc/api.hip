@@ -111,6 +111,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->ymean = cv.take<double>(N);
   f->wdiag = cv.take<double>(N);
   f->in_block = cv.take<uint8_t>(N);
+  f->row_param = cv.take<int32_t>(N);
   f->blk_row0 = cv.take<int64_t>(c.n_blocks);
   f->blk_size = cv.take<int64_t>(c.n_blocks);
   f->blk_woff = cv.take<int64_t>(c.n_blocks);
@@ -196,6 +197,9 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
     Scope sc(f, LSQAMD_T_RESIDUAL);
     ModelArgs m = model_args(f, p);
     HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
+    if (f->have_param_rows)
+      HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, 1, p, f->ymean, f->wdiag,
+                                  f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->r, f->r_raw, 0));
     if (f->cfg.n_blocks > 0) {
       // small blocks: one thread per output row; large ones (a single 8192-row block would keep
       // 32 workgroups busy for milliseconds): r_b = Wt_b^T delta_b as a two-stage column sum at
@@ -311,6 +315,9 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
     Scope sc(f, LSQAMD_T_JACOBIAN);
     ModelArgs m = model_args(f, p);
     HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
+    if (f->have_param_rows)
+      HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, f->ld, p, f->ymean, f->wdiag,
+                                  f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->J, f->Jraw, 1));
   }
   int64_t fused_chunks = 0;
   int rc = whiten_jacobian(f, &fused_chunks);
@@ -1242,6 +1249,24 @@ int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
   return 0;
 }
 
+int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!row_param) {
+    f->have_param_rows = false;
+    return 0;
+  }
+  if (f->cfg.has_prior) FAIL(f, LSQAMD_EINVAL, "set_param_rows: the prior is given as rows OR through lsqamd_set_prior, not both");
+  bool any = false;
+  for (int64_t i = 0; i < f->N; ++i) {
+    if (row_param[i] >= f->P) FAIL(f, LSQAMD_EINVAL, "set_param_rows: row %lld names parameter %d", (long long)i, row_param[i]);
+    any |= row_param[i] >= 0;
+  }
+  if (f->N > 0) HIPCHK(f, hipMemcpy(f->row_param, row_param, sizeof(int32_t) * f->N, hipMemcpyHostToDevice));
+  f->have_param_rows = any;
+  f->initialised = false;
+  return 0;
+}
+
 int lsqamd_set_linear(lsqamd_fit *f, const int32_t *index, int32_t n) {
   if (!f || n < 0 || (n > 0 && !index)) return LSQAMD_EINVAL;
   std::vector<char> mask;
@@ -1365,6 +1390,7 @@ int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) {
 
 int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) {
   if (!f || !p || !out) return LSQAMD_EINVAL;
+  if (f->have_param_rows) FAIL(f, LSQAMD_EUNSUPPORTED, "eval_fcn: not available with parameter rows (lsqamd_set_param_rows)");
   int rc = ready(f);
   if (rc) return rc;
   const int64_t N = f->N;
@@ -1585,6 +1611,7 @@ size_t lsqamd_dpdy_work_bytes(const lsqamd_fit *f, int64_t m) {
 
 int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, size_t scratch_bytes,
                 double *out_t, size_t cap) {
+  if (f && f->have_param_rows) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_dpdy: not available with parameter rows (lsqamd_set_param_rows)");
   if (!f || !out_t || !dev_scratch) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "dpdy: no fit has run");
   const int64_t P = f->P, N = f->N;
@@ -1689,6 +1716,7 @@ size_t lsqamd_chi2_points_work_bytes(const lsqamd_fit *f, int64_t m) {
 
 int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scratch, size_t scratch_bytes,
                        double *chi2_out) {
+  if (f && f->have_param_rows) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_chi2_points: not available with parameter rows (lsqamd_set_param_rows)");
   if (!f || !p || !chi2_out || !dev_scratch || m < 0) return LSQAMD_EINVAL;
   int rc = ready(f);
   if (rc) return rc;

@@ -34,6 +34,8 @@ struct lsqamd_fit {
   // device buffers
   double *x = nullptr, *ymean = nullptr, *wdiag = nullptr;
   uint8_t *in_block = nullptr;
+  int32_t *row_param = nullptr;  // >= 0: parameter row f_i = p_j (lsqamd_set_param_rows)
+  bool have_param_rows = false;
   int64_t *blk_row0 = nullptr, *blk_size = nullptr, *blk_woff = nullptr;
   double *wt = nullptr;
   double *prior_mean = nullptr, *prior_prec = nullptr;

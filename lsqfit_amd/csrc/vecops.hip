@@ -294,6 +294,38 @@ hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int3
   return hipGetLastError();
 }
 
+// ---- parameter rows (data-prior cross-correlations) ---------------------------------------------
+// Rows flagged row_param[i] = j >= 0 are not model rows: f_i = p_j (the prior entries of the
+// reference's concat(y, prior) vector, src/lsqfit/_utilities.pyx:74-77).  Written after the model
+// kernel, same conventions: rows inside a covariance block go unweighted to the raw buffers, the
+// others weighted by wdiag; column P of a Jacobian row holds the residual.
+__global__ __launch_bounds__(256) void param_rows_kernel(const int32_t *row_param, int64_t N, int64_t P, int64_t ld,
+                                                         const double *p, const double *ymean, const double *wdiag,
+                                                         const uint8_t *in_block, double *out_w, double *out_raw,
+                                                         int jac) {
+  const int64_t i = blockIdx.x;
+  const int32_t j = row_param[i];
+  if (j < 0) return;
+  const bool blk = in_block && in_block[i];
+  const double w = blk ? 1.0 : wdiag[i];
+  double *dst = blk ? out_raw : out_w;
+  const double delta = w * (p[j] - ymean[i]);
+  if (!jac) {
+    if (threadIdx.x == 0) dst[i] = delta;
+    return;
+  }
+  for (int64_t c = threadIdx.x; c <= P; c += 256) dst[i * ld + c] = c == P ? delta : (c == j ? w : 0.0);
+}
+
+hipError_t launch_param_rows(hipStream_t st, const int32_t *row_param, int64_t N, int64_t P, int64_t ld,
+                             const double *p, const double *ymean, const double *wdiag, const uint8_t *in_block,
+                             double *out_w, double *out_raw, int jac) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(param_rows_kernel, dim3((unsigned)N), dim3(jac ? 256 : 64), 0, st, row_param, N, P, ld, p, ymean,
+                     wdiag, in_block, out_w, out_raw, jac);
+  return hipGetLastError();
+}
+
 // ---- packed tiles -> dense working copies ------------------------------------------------------
 // M[i][j] = A[i][j] + mu d_i^2 [i==j] for the upper tiles; M[i][P] = g[i].  frozen (nullable):
 // parameters with frozen[i] != 0 are taken out of the system (unit row/column, zero right-hand side)

@@ -52,7 +52,7 @@ class nonlinear_fit(object):
     model = :class:`lsqfit_amd.Model`."""
 
     def __init__(self, data=None, model=None, prior=None, p0=None, svdcut=False, tol=None,
-                 maxit=None, udata=None, fitter=None, problem=None, linear=None, **fitterargs):
+                 maxit=None, udata=None, fitter=None, problem=None, linear=None, cross=None, **fitterargs):
         if data is None and udata is None:
             raise ValueError('neither data nor udata is specified')
         if model is None:
@@ -72,7 +72,16 @@ class nonlinear_fit(object):
         x, ymean, yerr = udata if uncorrelated else data
         pm, perr = (None, None) if prior is None else prior
         if problem is None:
-            wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, udata=uncorrelated)
+            if cross is not None:
+                # data correlated with the prior (examples/y-noerr.py): ``cross`` is the N x P
+                # covariance between y and the prior; concat(y, prior) is whitened as one vector
+                # (src/lsqfit/__init__.py:1892-1900)
+                if prior is None or uncorrelated:
+                    raise ValueError('cross needs data= and prior=')
+                from .whiten import joint_whitening
+                wh = joint_whitening(ymean, yerr, pm, perr, cross, svdcut=svdcut)
+            else:
+                wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, udata=uncorrelated)
             problem = DeviceProblem(model, x, wh)
         else:
             wh = problem.wh
@@ -90,6 +99,8 @@ class nonlinear_fit(object):
         self.dof = nf - self.p0.size
         self._chiv = _Chiv(problem)
         t1 = clock()
+        if getattr(wh, 'joint', False) and maxit == 0:
+            raise NotImplementedError('maxit = 0 with data-prior cross-correlations')
         if maxit == 0:
             # src/lsqfit/__init__.py:683-706: no fit -- parameters are the prior (or p0 with infinite
             # errors); chi2 is still evaluated on the device
@@ -162,12 +173,17 @@ class nonlinear_fit(object):
         return self.fitter_results.J
 
     # -- fit.p with its input correlations ----------------------------------
+    def _no_joint(self):
+        if getattr(self.whitening, 'joint', False):
+            raise NotImplementedError('not available for fits with data-prior cross-correlations')
+
     def dp_dinputs(self, G=None):
         """``D[a, i] = d pmean[a] / d buf[i]`` for ``buf = concat(y, prior)``: the matrix
         ``_getp`` (src/lsqfit/__init__.py:897-911) turns into the derivatives of ``fit.p``
         (``p[a].der = sum_i D[a,i] buf[i].der``).  ``cov_p = D C D^T``
         (doc/source/lsqfit.rst:105-117).  Computed on the device from the resident whitened
         Jacobian; ``G`` (m x P) returns ``G @ D`` for m derived quantities instead."""
+        self._no_joint()
         return self.problem.dpdy(G)
 
     def partial_sdev(self, grads, groups, cov_in):
@@ -191,11 +207,13 @@ class nonlinear_fit(object):
     # -- simulated / bootstrap copies ------------------------------------------
     def simulated_fits(self, n, pexact=None, add_priornoise=False, seed=0, **kw):
         """``simulated_fit_iter`` (src/lsqfit/__init__.py:1391-1469) as one device batch."""
+        self._no_joint()
         from .resample import simulated_fits
         return simulated_fits(self, n, pexact, add_priornoise, seed, **kw)
 
     def bootstrapped_fits(self, n, seed=0, **kw):
         """``bootstrapped_fit_iter`` (src/lsqfit/__init__.py:1548-1642) as one device batch."""
+        self._no_joint()
         from .resample import bootstrapped_fits
         return bootstrapped_fits(self, n, seed, **kw)
 
@@ -204,6 +222,7 @@ class nonlinear_fit(object):
         """``chi**2(p) - fit.chi2`` (``_fit_dchi2``, src/lsqfit/__init__.py:1648-1670); ``p`` of
         shape (P,) -> float, (m, P) -> array of m values evaluated in one device pass (the
         lbatch layout of ``vegas_fit._chiv``, src/lsqfit/_extras.py:2467-2486)."""
+        self._no_joint()
         p = np.asarray(p, float)
         c = self.problem.chi2_points(p.reshape(-1, self.pmean.size)) - self.chi2
         return float(c[0]) if p.ndim == 1 else c

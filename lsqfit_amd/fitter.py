@@ -64,6 +64,14 @@ class DeviceProblem:
         self.model = model
         self.wh = whitening
         a, b = (0, whitening.n_data) if rows is None else rows
+        joint = getattr(whitening, 'joint', False)     # concat(y, prior) whitened as one vector
+        if joint:
+            if rows is not None or model.kind == MODEL_IDENTITY:
+                raise ValueError('data-prior cross-correlations: unsharded fits of x-dependent models only')
+            xe = np.zeros((whitening.n_data, model.n_x))
+            xe[whitening.model_rows] = np.asarray(x, np.float64).reshape(whitening.n_model, model.n_x)[
+                whitening.row_src[whitening.model_rows]]
+            x = xe
         self.rows = (a, b)
         N = b - a
         P = model.n_param
@@ -117,6 +125,9 @@ class DeviceProblem:
             _lib.dptr(wt)), 'set_data')
         if whitening.has_prior:
             self.set_prior(whitening.prior_mean, whitening.prior_prec)
+        if joint:
+            rp = np.ascontiguousarray(whitening.row_param, np.int32)
+            _check(lib, h, lib.lsqamd_set_param_rows(h, rp.ctypes.data_as(C.POINTER(C.c_int32))), 'set_param_rows')
         self._reduce_cb = None
         if reduce_hook is not None:
             self.set_reduce(reduce_hook)

@@ -19,8 +19,10 @@ path consumes through ``lsqamd_set_data`` / ``lsqamd_set_prior``:
     ``nblocks``, ``nchiv``.
 
 Blocks must be contiguous row ranges (true for every layout the benchmark and
-the reference's example fixtures use); data-prior cross-correlations are not
-supported on the device path and raise.
+the reference's example fixtures use).  Data-prior cross-correlations
+(examples/y-noerr.py) go through :func:`joint_whitening`: concat(y, prior) is
+whitened as ONE vector, exactly as the reference does, and the prior entries
+travel to the device as extra "parameter rows" (lsqamd_set_param_rows).
 """
 import numpy as np
 import scipy.linalg as sla
@@ -286,3 +288,73 @@ class Whitening:
             return w * d, np.diag(w)
         _, diag_rows, Wrows = self.prior_W
         return diag_rows @ d, diag_rows, [W @ d for W in Wrows], Wrows
+
+
+def _components(cov):
+    """Connected components of the off-diagonal pattern of a symmetric matrix, each sorted, ordered
+    by their first index (gvar.evalcov_blocks)."""
+    n = cov.shape[0]
+    seen = np.zeros(n, bool)
+    adj = cov != 0.0
+    out = []
+    for i in range(n):
+        if seen[i]:
+            continue
+        comp, stack = [], [i]
+        seen[i] = True
+        while stack:
+            u = stack.pop()
+            comp.append(u)
+            for v in np.nonzero(adj[u] & ~seen)[0]:
+                seen[v] = True
+                stack.append(int(v))
+        out.append(np.array(sorted(comp)))
+    return out
+
+
+def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12):
+    """Whitening of concat(y, prior) when data and prior are correlated (``cross`` = the N x P
+    covariance between them): what src/lsqfit/__init__.py:1892-1900 hands to gvar.PDF.
+
+    The joint vector is permuted so that every covariance block (which may mix data and prior
+    entries) is a contiguous row range, then regulated block by block like any data vector.  The
+    result is a :class:`Whitening` WITHOUT a device-side prior: ``row_param[i] >= 0`` marks the rows
+    that are prior entries (the device evaluates them as f_i = p_j), ``row_src[i]`` is the index of
+    row i in concat(y, prior), ``model_rows`` the permuted positions of the data rows."""
+    ymean = np.array(ymean, float).reshape(-1)
+    pm = np.array(prior_mean, float).reshape(-1)
+    N, P = ymean.size, pm.size
+    cross = np.asarray(cross, float)
+    if cross.shape != (N, P):
+        raise ValueError('cross must be the %d x %d covariance between data and prior' % (N, P))
+
+    def dense(err, n):
+        sd, blocks = _as_blocks(err, n)
+        c = np.diag(sd ** 2)
+        for r0, b in blocks:
+            c[r0:r0 + b.shape[0], r0:r0 + b.shape[0]] = b
+        return c
+    full = np.zeros((N + P, N + P))
+    full[:N, :N] = dense(yerr, N)
+    full[N:, N:] = dense(prior_err, P)
+    full[:N, N:] = cross
+    full[N:, :N] = cross.T
+    comps = _components(full)
+    perm = np.concatenate(comps)
+    z = np.concatenate([ymean, pm])[perm]
+    sd = np.sqrt(np.diag(full))[perm]
+    blocks, r0 = [], 0
+    for c in comps:
+        if c.size > 1:
+            blocks.append((r0, full[np.ix_(c, c)]))
+        r0 += c.size
+    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut)
+    wh.joint = True
+    wh.row_src = perm
+    wh.row_param = np.where(perm >= N, perm - N, -1).astype(np.int32)
+    wh.model_rows = np.nonzero(perm < N)[0]
+    wh.n_model = N
+    wh.prior_mean_host = pm                       # host-side bookkeeping only (default p0, maxit = 0)
+    wh.prior_sdev = np.sqrt(np.diag(full))[N:]
+    wh.prior_cov_host = full[N:, N:]
+    return wh

