@@ -196,3 +196,41 @@ def test_draws_have_the_regulated_covariance():
     assert np.abs((emp - want) / scale).max() < 0.02
     pd = wh.draw_prior(np.random.default_rng(5), n)
     assert np.abs(pd.T @ pd / n - pcov).max() < 0.01
+
+
+def test_joint_whitening_of_correlated_data_and_prior():
+    """whiten.joint_whitening: concat(y, prior) with data-prior cross-covariance is permuted so that
+    each covariance block is contiguous; the weights reproduce inv(C) of the joint vector and the
+    bookkeeping (row_src, row_param, model_rows) maps rows back."""
+    from lsqfit_amd.whiten import joint_whitening
+    rng = np.random.default_rng(5)
+    N, P = 7, 3
+    A = rng.standard_normal((N + P, N + P))
+    full = A @ A.T + (N + P) * np.eye(N + P)
+    # make data rows 0, 1 and prior entry 2 independent of everything (1x1 components)
+    for i in (0, 1, N + 2):
+        full[i, :] = 0.0
+        full[:, i] = 0.0
+        full[i, i] = 1.0 + i
+    ym, pm = rng.standard_normal(N), rng.standard_normal(P)
+    wh = joint_whitening(ym, full[:N, :N], pm, full[N:, N:], full[:N, N:], svdcut=1e-12)
+    assert wh.n_data == N + P and not wh.has_prior and wh.nmod == 0
+    assert wh.nblocks == {1: 3, N + P - 3: 1}
+    assert sorted(wh.row_src) == list(range(N + P))
+    assert np.array_equal(wh.row_src[wh.model_rows], np.sort(wh.row_src[wh.model_rows]))   # data keep their order
+    assert np.array_equal(wh.row_param >= 0, wh.row_src >= N)
+    assert np.array_equal(wh.row_param[wh.row_param >= 0], wh.row_src[wh.row_src >= N] - N)
+    np.testing.assert_allclose(wh.ymean, np.concatenate([ym, pm])[wh.row_src])
+    # chi2 of a random deviation through the weights == delta^T inv(C) delta
+    delta = rng.standard_normal(N + P)
+    dperm = delta[wh.row_src]
+    in_block = np.zeros(N + P, bool)
+    chi2 = 0.0
+    for b in wh.blocks:
+        r0, B, m = b['row0'], b['size'], b['modes']
+        in_block[r0:r0 + B] = True
+        chi2 += float(np.sum((b['Wt'].T[:m] @ dperm[r0:r0 + B]) ** 2))
+    chi2 += float(np.sum((wh.wdiag[~in_block] * dperm[~in_block]) ** 2))
+    assert chi2 == pytest.approx(float(delta @ np.linalg.solve(full, delta)), rel=1e-10)
+    sign, ld = np.linalg.slogdet(full)
+    assert wh.logdet == pytest.approx(ld, rel=1e-10)
