@@ -523,6 +523,13 @@ def test_y_noerr_out_on_device(amd):
         # equations is good to ~1e-4 here (the printed error bars above agree digit for digit)
         assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 2e-3
         assert abs(fit.chi2 - ref.chi2) < 1e-6 * max(ref.chi2, 1.0) and abs(fit.logGBF - ref.logGBF) < 1e-3
+        if nexp == 2:      # the scipy-plugin methods and variable projection see the parameter rows too
+            for kw in (dict(fitter='mi355x_trf', tol=(1e-12, 1e-12, 1e-12)), dict(fitter='mi355x_trf', method='lm', tol=(1e-12, 1e-12, 1e-12)),
+                       dict(linear=[0, 1], tol=1e-12)):
+                alt = amd.nonlinear_fit(data=(x, mean[:n], cov[:n, :n]), model=amd.multiexp(nexp), prior=(mean[n:], cov[n:, n:]),
+                                        cross=cov[:n, n:], p0=p0, svdcut=k['svdcut'], maxit=5000, **kw)
+                assert np.max(np.abs(alt.pmean - fit.pmean) / fit.psdev) < 1e-3, kw
+                assert abs(alt.chi2 - fit.chi2) < 1e-6
         p0 = fit.pmean
     with pytest.raises(NotImplementedError):
         fit.dp_dinputs()
