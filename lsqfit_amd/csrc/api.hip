@@ -1611,7 +1611,6 @@ size_t lsqamd_dpdy_work_bytes(const lsqamd_fit *f, int64_t m) {
 
 int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, size_t scratch_bytes,
                 double *out_t, size_t cap) {
-  if (f && f->have_param_rows) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_dpdy: not available with parameter rows (lsqamd_set_param_rows)");
   if (!f || !out_t || !dev_scratch) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "dpdy: no fit has run");
   const int64_t P = f->P, N = f->N;

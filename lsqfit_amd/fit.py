@@ -183,8 +183,13 @@ class nonlinear_fit(object):
         (``p[a].der = sum_i D[a,i] buf[i].der``).  ``cov_p = D C D^T``
         (doc/source/lsqfit.rst:105-117).  Computed on the device from the resident whitened
         Jacobian; ``G`` (m x P) returns ``G @ D`` for m derived quantities instead."""
-        self._no_joint()
-        return self.problem.dpdy(G)
+        D = self.problem.dpdy(G)
+        wh = self.whitening
+        if getattr(wh, 'joint', False):          # device rows are the permuted joint vector
+            out = np.empty_like(D)
+            out[:, wh.row_src] = D
+            return out
+        return D
 
     def partial_sdev(self, grads, groups, cov_in):
         """Error budget in the sense of ``gvar.fmt_errorbudget(outputs, inputs)`` as used by

@@ -532,6 +532,40 @@ def test_y_noerr_out_on_device(amd):
                 assert abs(alt.chi2 - fit.chi2) < 1e-6
         p0 = fit.pmean
     with pytest.raises(NotImplementedError):
-        fit.dp_dinputs()
+        fit.simulated_fits(2)
     with pytest.raises(RuntimeError, match='parameter rows'):
         fit.problem.chi2_points(np.atleast_2d(fit.pmean))
+
+
+def test_cross_correlated_fit_sensitivities(amd):
+    """fit.p sensitivities (f1) for a fit whose data are correlated with its prior: with buf = concat(y,
+    prior) and C its full covariance, cov_p = D C D^T (doc/source/lsqfit.rst:105-117) -- columns come back
+    in concat order although the device works on the permuted joint vector."""
+    rng = np.random.default_rng(11)
+    N, P = 12, 3
+    A = rng.standard_normal((N + P, N + P))
+    full = (A @ A.T + (N + P) * np.eye(N + P)) * 1e-8     # small errors: D is the first-order (Gauss-Newton)
+    # sensitivity, the finite difference below sees the residual-curvature term too
+    full[3, :] = full[:, 3] = 0.0                       # one data point independent of everything
+    full[3, 3] = 2e-8
+    x = np.linspace(0.1, 2.0, N)
+    truth = np.array([1.0, 0.7, 0.3])
+    model = amd.expr('b1*exp(-b2*x) + b3', ['b1', 'b2', 'b3'])
+    dev = np.linalg.cholesky(full) @ rng.standard_normal(N + P)
+    y = truth[0] * np.exp(-truth[1] * x) + truth[2] + dev[:N]
+    pm = truth + dev[N:]
+    fit = amd.nonlinear_fit(data=(x, y, full[:N, :N]), model=model, prior=(pm, full[N:, N:]), cross=full[:N, N:], tol=1e-12)
+    assert fit.error is None and fit.nblocks == {1: 1, N + P - 1: 1}
+    D = fit.dp_dinputs()
+    assert D.shape == (P, N + P)
+    assert gu.relmax(D @ full @ D.T, fit.cov) < 1e-8
+    # and against a finite difference of the whole fit in one datum and one prior mean
+    for idx in (5, N + 1):
+        h, pms = 1e-5, []
+        for sgn in (1.0, -1.0):
+            z = np.concatenate([y, pm])
+            z[idx] += sgn * h
+            f2 = amd.nonlinear_fit(data=(x, z[:N], full[:N, :N]), model=model, prior=(z[N:], full[N:, N:]),
+                                   cross=full[:N, N:], tol=1e-12, p0=fit.pmean)
+            pms.append(f2.pmean)
+        assert np.max(np.abs((pms[0] - pms[1]) / (2 * h) - D[:, idx])) < 1e-3 * np.max(np.abs(D[:, idx]))
