@@ -569,3 +569,12 @@ def test_cross_correlated_fit_sensitivities(amd):
                                    cross=full[:N, N:], tol=1e-12, p0=fit.pmean)
             pms.append(f2.pmean)
         assert np.max(np.abs((pms[0] - pms[1]) / (2 * h) - D[:, idx])) < 1e-3 * np.max(np.abs(D[:, idx]))
+
+
+def test_wavg_svd_literal_on_device(amd):
+    """tests/test_lsqfit.py:581-588: var 0.4561552812808828 with svdcut = 1 - 1e-16, 1/3 with 1e-18."""
+    from tests.test_oracle_kat import WAVG_SVD_COV
+    for svdcut, var, nmod in ((1 - 1e-16, 0.4561552812808828, 2), (1e-18, 1. / 3., 0)):
+        fit = amd.nonlinear_fit(data=(np.zeros(3), np.ones(3), WAVG_SVD_COV), model=amd.expr('p + 0*x', ['p']), p0=[1.0],
+                                svdcut=svdcut)
+        assert round(abs(fit.cov[0, 0] - var), 7) == 0 and fit.svdn == nmod

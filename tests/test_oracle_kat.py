@@ -687,3 +687,16 @@ def test_y_noerr_out_data_prior_correlations():
             assert abs(fit.logGBF - e['logGBF']) < 2e-3
         assert abs(fit.nit - e['nit']) <= max(2, 0.15 * e['nit'])
         p0 = fit.pmean
+
+
+WAVG_SVD_COV = np.array([[.5, .25, .5], [.25, .5, .5], [.5, .5, 1.]])     # cov of [(a+b)/2, (a+c)/2, a], a, b, c = 1(1)
+
+
+def test_wavg_svd_literal():
+    """tests/test_lsqfit.py:581-588 (test_wavg_svd): the weighted average of three correlated values is a
+    one-parameter fit without a prior; svdcut = 1 - 1e-16 floors two of the three correlation
+    eigenvalues -> var 0.4561552812808828; a tiny svdcut leaves 1/3."""
+    for svdcut, var, nmod in ((1 - 1e-16, 0.4561552812808828, 2), (1e-18, 1. / 3., 0)):
+        fit = ofit.nonlinear_fit(False, np.ones(3), WAVG_SVD_COV, lambda p: p[0] * np.ones(3), p0=[1.0],
+                                 jac=lambda p: np.ones((3, 1)), svdcut=svdcut)
+        assert abs(fit.cov[0, 0] - var) < 5e-8 and fit.svdn == nmod
