@@ -135,3 +135,24 @@ def test_dp_dinputs_c3_like(amd):
     Dref = ofit.dp_dinputs(ref)
     assert gu.relmax(D[:, :2048], Dref[:, :2048]) < 1e-6
     assert gu.relmax(D[:, 2048:], Dref[:, 2048:]) < 1e-6
+
+
+def test_partialerr2_on_device(amd):
+    """tests/test_lsqfit.py:1513-1549 (test_partialerr2): three measurements of p['y'] (sdev 0.125), priors
+    y = 0.1(1e4) and 'not y' = 3.0(0.125).  d p_y / d y_0 = 1/3, d p_noty / d prior_noty = 1; the error
+    budget puts all of p_y's error on the data (= the weighted average's) and all of p_noty's on its prior."""
+    rng = np.random.default_rng(17)
+    ny, sd = 3, 0.125
+    y = 2.0 + sd * rng.standard_normal(ny)
+    model = amd.expr('py + 0*pn + 0*x', ['py', 'pn'])
+    fit = amd.nonlinear_fit(data=(np.zeros(ny), y, np.full(ny, sd)), model=model, prior=([0.1, 3.0], [1e4, sd]))
+    assert abs(fit.pmean[0] / np.mean(y) - 1) < 1e-6 and abs(fit.pmean[1] / 3.0 - 1) < 1e-6
+    D = fit.dp_dinputs()                                    # columns: y_0..y_2, prior_y, prior_noty
+    assert abs(D[0, 0] - 1. / ny) < 5e-8 and abs(D[1, ny + 1] - 1.0) < 5e-8
+    cov_in = np.array([sd ** 2] * ny + [1e8, sd ** 2])
+    err = fit.partial_sdev({'y': [1.0, 0.0], 'not y': [0.0, 1.0]},
+                           {'y': [0, 1, 2], 'not y': [ny + 1], 'other prior': [ny]}, cov_in)
+    assert abs(err['y', 'y'] - sd / np.sqrt(ny)) < 5e-8
+    assert abs(err['y', 'not y']) < 5e-8 and abs(err['y', 'other prior']) < 5e-6
+    assert abs(err['not y', 'not y'] - sd) < 5e-8
+    assert abs(err['not y', 'y']) < 5e-8 and abs(err['not y', 'other prior']) < 5e-8
