@@ -536,19 +536,28 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_f64_small_kernel(GemmDev g) {
 // which is what makes the in-place update safe -- but there are twice as many of them as with
 // 128 x 128 tiles and each carries half the MFMA chain.  Single tile row only (blockIdx.x = tile
 // column).  Same edge / triangular / beta / batch contract as the other kernels.
+// PNW = 64, 32 or 16 columns per workgroup: late in a factorisation the panel has a handful of
+// 64-column tiles for 256 CUs, and what it costs is the length of one workgroup's MFMA chain --
+// narrower tiles spread the same columns over more CUs and shorten that chain.
 constexpr int PN = 64;
 constexpr int LDS_PX = BM + 16;   // 144
-constexpr int LDS_PY = PN + 16;   // 80
+constexpr int LDS_PY = PN + 16;   // 80 (widest variant)
 constexpr int STAGE_P = BK * (LDS_PX + LDS_PY);
 constexpr size_t GEMM_LDS_BYTES_P = 2 * STAGE_P * sizeof(double);
 
-template <bool VEC>
+template <bool VEC, int PNW>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
+  constexpr int WN = PNW >= 32 ? 2 : 1, WM = 4 / WN;       // waves along n / m
+  constexpr int RW = BM / WM, NI = RW / 16;                  // rows per wave, 16-row blocks
+  constexpr int CW = PNW / WN, NJ = CW / 16;                 // columns per wave, 16-column blocks
+  constexpr int YT = PNW / 2, YROWS = 256 / YT;              // Y stage: column pairs, rows per pass
+  constexpr int YP = (BK + YROWS - 1) / YROWS;               // passes over the 16 stage rows
+  constexpr int LDY = PNW + 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;   // wave tile: 64 rows x 32 columns
-  const int64_t m0 = 0, n0 = (int64_t)blockIdx.x * PN;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  const int64_t m0 = 0, n0 = (int64_t)blockIdx.x * PNW;
   const int64_t b = blockIdx.z;
   if (g.batch_active && !g.batch_active[b]) return;
   const double *X = g.X + b * g.sx;
@@ -556,15 +565,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
   double *C = g.C + b * g.sc;
   int64_t kb = 0, ke = g.K;
   if (g.x_upper_tri && ke > BM) ke = BM;
-  v4d acc[4][2];
+  v4d acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
   // X stage: 16 x 128 -> thread: column pair (tid & 63) * 2, rows (tid >> 6) + 4 i
   // Y stage: 16 x 64  -> thread: column pair (tid & 31) * 2, rows (tid >> 5) + 8 i
   const int xc2 = (tid & 63) * 2, xrg = tid >> 6;
-  const int yc2 = (tid & 31) * 2, yrg = tid >> 5;
+  const int yc2 = (tid % YT) * 2, yrg = tid / YT;
   const int64_t xc = m0 + xc2, yc = n0 + yc2;
   const bool x0ok = xc < g.M, x1ok = xc + 1 < g.M;
   const bool y0ok = yc < g.N, y1ok = yc + 1 < g.N;
@@ -572,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
   const int64_t xi1 = xc + 1 < g.M ? xc + 1 : g.M - 1;
   const int64_t yi0 = VEC ? (yc < g.ldy - 2 ? yc : g.ldy - 2) : (yc < g.N ? yc : g.N - 1);
   const int64_t yi1 = yc + 1 < g.N ? yc + 1 : g.N - 1;
-  v2d xr[4], yr[2];
+  v2d xr[4], yr[YP];
   auto gload = [&](int64_t k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -581,8 +590,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
       xr[i] = load2<VEC>(X + row * g.ldx, xi0, xi1);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int64_t row = k0 + yrg + 8 * i;
+    for (int i = 0; i < YP; ++i) {
+      int64_t row = k0 + yrg + YROWS * i;
       row = row < ke ? row : ke - 1;
       yr[i] = load2<VEC>(Y + row * g.ldy, yi0, yi1);
     }
@@ -600,13 +609,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
       *reinterpret_cast<v2d *>(Xs + row * LDS_PX + xc2) = xv;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = yrg + 8 * i;
+    for (int i = 0; i < YP; ++i) {
+      const int row = yrg + YROWS * i;
+      if (row >= BK) continue;            // narrow variants: the upper thread rows have nothing to stage
       const bool rok = k0 + row < ke;
       v2d yv;
       yv.x = (rok && y0ok) ? yr[i].x : 0.0;
       yv.y = (rok && y1ok) ? yr[i].y : 0.0;
-      *reinterpret_cast<v2d *>(Ys + row * LDS_PY + yc2) = yv;
+      *reinterpret_cast<v2d *>(Ys + row * LDY + yc2) = yv;
     }
   };
   const int fr = lane & 15, fq = lane >> 4;
@@ -624,15 +634,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       const int kr = kk * 4 + fq;
-      double a[4], bb[2];
+      double a[NI], bb[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDS_PX + wm * 64 + i * 16 + fr];
+      for (int i = 0; i < NI; ++i) a[i] = Xs[kr * LDS_PX + wm * RW + i * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bb[j] = Ys[kr * LDS_PY + wn * 32 + j * 16 + fr];
+      for (int j = 0; j < NJ; ++j) bb[j] = Ys[kr * LDY + wn * CW + j * 16 + fr];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
     if (more) sstore(cur ^ 1, k0 + BK);
@@ -643,14 +653,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
   // only now may C, which may alias Y, be written
   const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 32 + j * 16 + fr;
+    for (int j = 0; j < NJ; ++j) {
+      const int64_t col = n0 + wn * CW + j * 16 + fr;
       if (col >= g.N) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = m0 + wm * 64 + i * 16 + fq + 4 * r;
+        const int64_t row = m0 + wm * RW + i * 16 + fq + 4 * r;
         if (row >= g.M) continue;
         double v = alpha * acc[i][j][r];
         if (beta != 0.0) v += beta * C[row * g.ldc + col];
@@ -747,13 +757,20 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (inplace && tiles_m > 1) return hipErrorInvalidValue;
   const bool small_ok = !inplace || a.M <= TS;
   if (inplace && a.C == a.Y && a.M > TS && a.K <= BM && g.splits == 1 && !a.force_generic) {
-    // row panel: 128 x 64 tiles, one workgroup per 64 operand columns
-    g.tiles_n = (int32_t)((a.N + PN - 1) / PN);
-    dim3 gridp((unsigned)g.tiles_n, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
-    if (g.vec_x && g.vec_y)
-      hipLaunchKernelGGL(gemm_tn_f64_panel_kernel<true>, gridp, dim3(256), GEMM_LDS_BYTES_P, st, g);
-    else
-      hipLaunchKernelGGL(gemm_tn_f64_panel_kernel<false>, gridp, dim3(256), GEMM_LDS_BYTES_P, st, g);
+    // row panel: 128 x PNW tiles, one workgroup per PNW operand columns; PNW shrinks until there
+    // are a few hundred workgroups (LSQAMD_PANEL_PN forces 64 / 32 / 16: developer knob)
+    static const int force_pn = [] { const char *e = getenv("LSQAMD_PANEL_PN"); return e ? atoi(e) : 0; }();
+    const int64_t nb_ = a.batch < 1 ? 1 : a.batch;
+    int pn = (a.N * nb_ >= 200 * 64) ? 64 : ((a.N * nb_ >= 200 * 32) ? 32 : 16);
+    if (force_pn == 64 || force_pn == 32 || force_pn == 16) pn = force_pn;
+    g.tiles_n = (int32_t)((a.N + pn - 1) / pn);
+    dim3 gridp((unsigned)g.tiles_n, 1, (unsigned)nb_);
+    const bool vec = g.vec_x && g.vec_y;
+#define LSQAMD_PANEL(V, W) hipLaunchKernelGGL((gemm_tn_f64_panel_kernel<V, W>), gridp, dim3(256), GEMM_LDS_BYTES_P, st, g)
+    if (pn == 64) { if (vec) LSQAMD_PANEL(true, 64); else LSQAMD_PANEL(false, 64); }
+    else if (pn == 32) { if (vec) LSQAMD_PANEL(true, 32); else LSQAMD_PANEL(false, 32); }
+    else { if (vec) LSQAMD_PANEL(true, 16); else LSQAMD_PANEL(false, 16); }
+#undef LSQAMD_PANEL
     return hipGetLastError();
   }
   if (!a.work_map && a.K <= 512 && nblk128 <= small_max && !a.force_generic && small_ok) {
