@@ -147,13 +147,35 @@ def faithful_qr_estimate(n, P):
         return dict(value=None, unit='LM steps/s', cores=1, extrapolated=True, sample='failed: %r' % (e,))
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per
+    GPU, torch.distributed.run on 127.0.0.1) BEFORE anything in this process touches the GPU, hand
+    their output through and exit with their code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if have < args.gpus and os.environ.get('LSQAMD_DIST_BACKEND', 'nccl') == 'nccl':
+        raise SystemExit('bench.py: --gpus %d but only %d GPU(s) are visible' % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        launch_ranks(args)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     import torch
     import torch.distributed as dist
     ndev = max(1, torch.cuda.device_count())
@@ -181,7 +203,32 @@ def main():
     t0 = time.perf_counter()
     d = synth.make_cosmix(N=N, P=P, seed=seed, block=block, prior_corr=dense_prior)
     wh = lsqfit_amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
-    pr = sharded_problem(d['model'], d['x'], wh, rank, world)
+    # N > 1: the sums run inside the library (RCCL reduce-scatter + all-gather on the handle's
+    # stream).  LSQAMD_COLLECTIVE=hook selects the torch.distributed hook instead; without the
+    # variable a failed communicator set-up falls back to the hook on ALL ranks and says so.
+    want = os.environ.get('LSQAMD_COLLECTIVE') or None
+    if world > 1 and os.environ.get('LSQAMD_DIST_BACKEND', 'nccl') != 'nccl':
+        want = 'hook'
+    note = None
+    try:
+        pr = sharded_problem(d['model'], d['x'], wh, rank, world, collective=want)
+        ok = 1
+    except RuntimeError as e:
+        if want is not None or world == 1:
+            raise
+        ok, note = 0, repr(e)
+    if world > 1 and want is None:
+        flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if ok:
+                pr.close()
+            pr = sharded_problem(d['model'], d['x'], wh, rank, world, collective='hook')
+            note = note or 'another rank could not join the library communicator'
+    collective = {None: 'none (one rank)', 'rccl': 'RCCL reduce-scatter + all-gather inside the library, on the step\'s stream',
+                  'hook': 'torch.distributed all_reduce through the C-ABI hook'}[pr.collective]
+    if note:
+        collective += ' (fallback: %s)' % note
     pr.set_options((1e-8, 1e-10, 1e-10), 1000)
     t_setup = time.perf_counter() - t0
     lib, h = pr.lib, pr.h
@@ -264,7 +311,7 @@ def main():
                                        args.workload, N, P,
                                        ('%d-row block-diagonal' % block) if block > 1 else 'diagonal',
                                        'dense correlated' if dense_prior else 'diagonal', world),
-                       'solver': 'lm/more/cholesky', 'restarts_in_timed_region': state['reinits'],
+                       'solver': 'lm/more/cholesky', 'collective': collective, 'restarts_in_timed_region': state['reinits'],
                        'setup_s': round(t_setup, 3), 'chi2_dof_last': s.chi2 / max(1, wh.nchiv - P)},
             'phases_ms_per_call': {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()},
             'phases_calls': {k: v[1] for k, v in tm.items()},

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQAMD_ABI_VERSION 3
+#define LSQAMD_ABI_VERSION 4
 
 /* error codes (negative = backend, positive = GSL numbering) */
 #define LSQAMD_SUCCESS 0
@@ -152,6 +152,10 @@ typedef struct {
   int32_t njev;               /* Jacobian evaluations */
   int32_t ntrial;             /* damped solves attempted */
   int32_t chol_fail;          /* factorizations that hit a non-positive pivot */
+  int32_t cov_status;         /* 0, or LSQAMD_ENOTPD: J^T J is not positive definite at the end point --
+                               * cov and logdet_jtj (NaN) are undefined (gsl_multifit_nlinear_covar has no
+                               * such report: its QR-based inverse returns garbage silently) */
+  int32_t reserved0;
   double chi2;                /* sum f**2, __init__.py:667 */
   double mu;                  /* final LM parameter */
   double logdet_jtj;          /* log det(J^T J) at the end (for logGBF, __init__.py:719) */
@@ -225,6 +229,24 @@ int lsqamd_set_bounds(lsqamd_fit *fit, const double *lower, const double *upper)
  * accepted step.  Plain LSQAMD_TRS_LM only; nfev / njev count every full evaluation. */
 int lsqamd_set_linear(lsqamd_fit *fit, const int32_t *index, int32_t n);
 int lsqamd_set_reduce(lsqamd_fit *fit, lsqamd_reduce_fn fn, void *user);
+/* The exchange inside the library (what a host in any language uses; the hook above stays for
+ * transports RCCL does not cover, e.g. the CPU-side gloo tests): a persistent RCCL communicator
+ * per handle, one rank per GPU.  Rank 0 calls lsqamd_comm_unique_id and ships the
+ * LSQAMD_COMM_ID_BYTES bytes to the other ranks by whatever channel the host has (MPI, a file,
+ * torch.distributed); then EVERY rank calls lsqamd_comm_init (collective: returns when all
+ * nranks have joined).  From then on the sums of the row-sharded fit -- the packed
+ * [J^T J | J^T f | chi2] buffer per Jacobian evaluation, one scalar per trial step -- are
+ * enqueued on the handle's stream as ncclReduceScatter + ncclAllGather (short vectors:
+ * ncclAllReduce): no stream synchronisation, no host callback, every rank receives identical
+ * bytes.  Takes precedence over lsqamd_set_reduce.  LSQAMD_EUNSUPPORTED: no librccl.so in the
+ * process or on the loader path (LSQAMD_RCCL_PATH names one).  (No counterpart in the
+ * reference, which has no distributed path: SURVEY.md 5, 8e.) */
+#define LSQAMD_COMM_ID_BYTES 128
+int lsqamd_comm_unique_id(void *id_out, size_t cap);
+int lsqamd_comm_init(lsqamd_fit *fit, const void *id, size_t id_bytes, int32_t rank, int32_t nranks);
+int lsqamd_comm_destroy(lsqamd_fit *fit);
+/* *rank / *nranks of the handle's communicator (-1 / 0 when there is none) */
+int lsqamd_comm_info(const lsqamd_fit *fit, int32_t *rank, int32_t *nranks);
 /* Row-sharded fits: exactly one rank (on != 0) contributes the replicated prior
  * terms to the sums before the all-reduce.  Default on. */
 int lsqamd_set_adds_prior(lsqamd_fit *fit, int32_t on);

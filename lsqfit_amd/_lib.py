@@ -8,7 +8,9 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'liblsqfit_amd.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
+
+COMM_ID_BYTES = 128
 
 T_NAMES = ['residual', 'jacobian', 'whiten', 'syrk', 'grad', 'reduce', 'cholesky', 'solve', 'covar']
 
@@ -32,7 +34,8 @@ class Options(C.Structure):
 class Summary(C.Structure):
     _fields_ = [('status', C.c_int32), ('info', C.c_int32), ('stopping_criterion', C.c_int32),
                 ('nit', C.c_int32), ('nfev', C.c_int32), ('njev', C.c_int32), ('ntrial', C.c_int32),
-                ('chol_fail', C.c_int32), ('chi2', C.c_double), ('mu', C.c_double),
+                ('chol_fail', C.c_int32), ('cov_status', C.c_int32), ('reserved0', C.c_int32),
+                ('chi2', C.c_double), ('mu', C.c_double),
                 ('logdet_jtj', C.c_double), ('t_setup_ms', C.c_double), ('t_run_ms', C.c_double)]
 
 
@@ -62,6 +65,10 @@ PROTOTYPES = {
     'lsqamd_set_param_rows': (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     'lsqamd_set_reduce': (C.c_int, [_vp, REDUCE_FN, _vp]),
     'lsqamd_set_adds_prior': (C.c_int, [_vp, C.c_int32]),
+    'lsqamd_comm_unique_id': (C.c_int, [_vp, C.c_size_t]),
+    'lsqamd_comm_init': (C.c_int, [_vp, _vp, C.c_size_t, C.c_int32, C.c_int32]),
+    'lsqamd_comm_destroy': (C.c_int, [_vp]),
+    'lsqamd_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'lsqamd_run': (C.c_int, [_vp, _dp, C.POINTER(Summary)]),
     'lsqamd_init': (C.c_int, [_vp, _dp]),
     'lsqamd_step': (C.c_int, [_vp, C.POINTER(C.c_int32)]),

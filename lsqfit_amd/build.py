@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblsqfit_amd.so')
 SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'potf2_mfma.hip', 'model.hip', 'vecops.hip', 'api.hip', 'scipy_methods.hip',
-           'batch.hip']
+           'batch.hip', 'comm.hip']
 # per-file code-generation switches (reasons in the files' headers)
 EXTRA = {'potf2_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
@@ -55,7 +55,7 @@ def build(force=False, verbose=False):
             if verbose and out.strip():
                 print(out)
     if jobs or not os.path.exists(LIB):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs)
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + ['-ldl'])
     return LIB
 
 

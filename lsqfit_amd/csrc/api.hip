@@ -183,6 +183,10 @@ int ready(lsqamd_fit *f) {
 }
 
 int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
+  if (f->comm) {   // RCCL on the handle's stream: nothing to wait for on the host
+    Scope sc(f, LSQAMD_T_REDUCE);
+    return comm_all_reduce(f, buf, count);
+  }
   if (!f->reduce) return 0;
   Scope sc(f, LSQAMD_T_REDUCE);
   HIPCHK(f, hipStreamSynchronize(f->st));
@@ -1152,6 +1156,8 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
   if (!f) return LSQAMD_EINVAL;
   if (n_blocks != f->cfg.n_blocks) FAIL(f, LSQAMD_EINVAL, "set_data: n_blocks differs from the config");
   if (f->N > 0 && (!ymean || !wdiag)) FAIL(f, LSQAMD_EINVAL, "set_data: null ymean/wdiag");
+  if (n_blocks > 0 && (!block_row0 || !block_size || !block_modes || !wt))
+    FAIL(f, LSQAMD_EINVAL, "set_data: null block arrays with n_blocks = %d", n_blocks);
   const int64_t N = f->N;
   std::vector<uint8_t> inb((size_t)(N > 0 ? N : 1), 0);
   f->h_row0.assign(block_row0, block_row0 + n_blocks);
@@ -1261,7 +1267,10 @@ int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) {
     if (row_param[i] >= f->P) FAIL(f, LSQAMD_EINVAL, "set_param_rows: row %lld names parameter %d", (long long)i, row_param[i]);
     any |= row_param[i] >= 0;
   }
-  if (f->N > 0) HIPCHK(f, hipMemcpy(f->row_param, row_param, sizeof(int32_t) * f->N, hipMemcpyHostToDevice));
+  if (f->N > 0) {
+    HIPCHK(f, hipMemcpyAsync(f->row_param, row_param, sizeof(int32_t) * f->N, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+  }
   f->have_param_rows = any;
   f->initialised = false;
   return 0;
@@ -1322,15 +1331,19 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
   const int rc = do_covariance(f);
   if (f->timing) resolve_timers(f);
   fill_summary(f, out, 0, 0);
+  if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : 0;
   return rc == LSQAMD_ENOTPD ? 0 : rc;
 }
 
 int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   if (!f || !p0) return LSQAMD_EINVAL;
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  (void)hipEventRecord(e0, f->st);
+  struct Pair {   // recycled events: every return path hands them back
+    lsqamd_fit *f;
+    hipEvent_t a, b;
+    explicit Pair(lsqamd_fit *fit) : f(fit), a(take_event(fit)), b(take_event(fit)) {}
+    ~Pair() { f->event_pool.push_back(a); f->event_pool.push_back(b); }
+  } ev(f);
+  (void)hipEventRecord(ev.a, f->st);
   int rc = 0;
   int iter = 0, info = 0, status = -2;
   bool early = false;
@@ -1366,15 +1379,16 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   }
   rc = do_covariance(f);
   if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
-  (void)hipEventRecord(e1, f->st);
-  (void)hipEventSynchronize(e1);
+  (void)hipEventRecord(ev.b, f->st);
+  (void)hipEventSynchronize(ev.b);
   float ms = 0.f;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  (void)hipEventElapsedTime(&ms, ev.a, ev.b);
   if (f->timing) resolve_timers(f);
   fill_summary(f, out, status, info);
-  if (out) out->t_run_ms = ms;
+  if (out) {
+    out->t_run_ms = ms;
+    out->cov_status = rc;   // LSQAMD_ENOTPD: J^T J singular at the end point, cov / logdet undefined
+  }
   return 0;
 }
 

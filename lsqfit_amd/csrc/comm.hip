@@ -1,0 +1,170 @@
+// RCCL collective of the row-sharded fit, inside the library.
+//
+// chi2 is a sum over covariance blocks, so a fit whose data rows are spread over the GPUs of one
+// node needs ONE exchange per Jacobian evaluation -- the sum of the packed [J^T J | J^T f | chi2]
+// buffer (69 MB at P = 4096) -- and one scalar per trial step.  The reference has no distributed
+// path; there is nothing to mirror.  Design:
+//   * a persistent communicator per handle (lsqamd_comm_init: ncclCommInitRank with an id made by
+//     rank 0's lsqamd_comm_unique_id and carried to the other ranks by ANY host-side channel:
+//     torch.distributed in lsqfit_amd/dist.py, MPI / a file / a socket for another host);
+//   * the sum is enqueued on the handle's stream as reduce-scatter + all-gather over 256-byte
+//     aligned slices (every xGMI link carries 1/n of the buffer in each phase; every rank ends
+//     up with the SAME bytes, which is what lets all ranks take identical LM decisions), the few
+//     leftover elements and short vectors as one all-reduce;
+//   * no stream synchronisation, no host callback: the kernels queued behind the collective on
+//     the same stream see the sums.
+// RCCL is bound at run time (dlopen): inside a PyTorch process the librccl.so torch already
+// loaded is reused (one RCCL per process), elsewhere LSQAMD_RCCL_PATH or the loader's search
+// path decide; a build without RCCL on the box still loads and every other entry point works.
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "fit_state.h"
+
+namespace {
+
+// the slice of the NCCL/RCCL C API this file uses (stable since NCCL 2.0)
+struct UniqueId { char internal[LSQAMD_COMM_ID_BYTES]; };
+typedef void *Comm;
+enum { RESULT_SUCCESS = 0 };
+enum { DT_FLOAT64 = 8 };   // ncclDouble / ncclFloat64
+enum { OP_SUM = 0 };       // ncclSum
+
+struct Api {
+  void *lib = nullptr;
+  int (*GetUniqueId)(UniqueId *) = nullptr;
+  int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string why;
+  bool ok = false;
+};
+
+Api &api() {
+  static Api a = [] {
+    Api t;
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names)   // the copy already in the process (PyTorch's), if any
+      if (!t.lib) t.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    if (!t.lib) {
+      const char *path = getenv("LSQAMD_RCCL_PATH");
+      if (path && *path) t.lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+      for (const char *n : names)
+        if (!t.lib) t.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!t.lib) {
+      t.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+      return t;
+    }
+    struct { const char *name; void **slot; } syms[] = {
+        {"ncclGetUniqueId", (void **)&t.GetUniqueId},   {"ncclCommInitRank", (void **)&t.CommInitRank},
+        {"ncclCommDestroy", (void **)&t.CommDestroy},   {"ncclAllReduce", (void **)&t.AllReduce},
+        {"ncclReduceScatter", (void **)&t.ReduceScatter}, {"ncclAllGather", (void **)&t.AllGather},
+        {"ncclGetErrorString", (void **)&t.GetErrorString}};
+    for (auto &s : syms) {
+      *s.slot = dlsym(t.lib, s.name);
+      if (!*s.slot) {
+        t.why = std::string("librccl.so lacks ") + s.name;
+        return t;
+      }
+    }
+    t.ok = true;
+    return t;
+  }();
+  return a;
+}
+
+// LSQAMD_COMM_ALGO=allreduce: one ncclAllReduce for everything (A/B switch, developer knob)
+bool use_rsag() {   // read per call (a getenv next to a 69 MB collective is free): tests flip it
+  const char *e = getenv("LSQAMD_COMM_ALGO");
+  return !(e && e[0] == 'a');
+}
+
+}  // namespace
+
+#define NCCLCHK(fit, expr)                                                                       \
+  do {                                                                                           \
+    const int _r = (expr);                                                                       \
+    if (_r != RESULT_SUCCESS) FAIL(fit, LSQAMD_EREDUCE, "%s: %s", #expr, api().GetErrorString(_r)); \
+  } while (0)
+
+namespace lsqamd_host {
+
+int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count) {
+  Api &a = api();
+  Comm c = (Comm)f->comm;
+  const int64_t n = f->comm_nranks;
+  // slices of whole 256-byte lines; below 64 KiB per rank the latency-optimised all-reduce wins
+  const int64_t slice = (count / n) / 32 * 32;
+  if (!use_rsag() || slice < 8192) {
+    NCCLCHK(f, a.AllReduce(buf, buf, (size_t)count, DT_FLOAT64, OP_SUM, c, f->st));
+    return 0;
+  }
+  double *mine = buf + (int64_t)f->comm_rank * slice;
+  NCCLCHK(f, a.ReduceScatter(buf, mine, (size_t)slice, DT_FLOAT64, OP_SUM, c, f->st));
+  NCCLCHK(f, a.AllGather(mine, buf, (size_t)slice, DT_FLOAT64, c, f->st));
+  const int64_t done = slice * n;
+  if (done < count) NCCLCHK(f, a.AllReduce(buf + done, buf + done, (size_t)(count - done), DT_FLOAT64, OP_SUM, c, f->st));
+  return 0;
+}
+
+void comm_release(lsqamd_fit *f) {
+  if (f->comm) {
+    (void)api().CommDestroy((Comm)f->comm);
+    f->comm = nullptr;
+  }
+  f->comm_rank = 0;
+  f->comm_nranks = 1;
+}
+
+}  // namespace lsqamd_host
+
+extern "C" {
+
+int lsqamd_comm_unique_id(void *id_out, size_t cap) {
+  if (!id_out || cap < LSQAMD_COMM_ID_BYTES) return LSQAMD_EINVAL;
+  Api &a = api();
+  if (!a.ok) return LSQAMD_EUNSUPPORTED;
+  UniqueId id;
+  if (a.GetUniqueId(&id) != RESULT_SUCCESS) return LSQAMD_EREDUCE;
+  std::memcpy(id_out, id.internal, LSQAMD_COMM_ID_BYTES);
+  return 0;
+}
+
+int lsqamd_comm_init(lsqamd_fit *f, const void *id, size_t id_bytes, int32_t rank, int32_t nranks) {
+  if (!f) return LSQAMD_EINVAL;
+  if (!id || id_bytes != LSQAMD_COMM_ID_BYTES || nranks < 1 || rank < 0 || rank >= nranks)
+    FAIL(f, LSQAMD_EINVAL, "comm_init: need the %d-byte id of lsqamd_comm_unique_id and 0 <= rank < nranks", LSQAMD_COMM_ID_BYTES);
+  Api &a = api();
+  if (!a.ok) FAIL(f, LSQAMD_EUNSUPPORTED, "comm_init: %s", a.why.c_str());
+  lsqamd_host::comm_release(f);
+  UniqueId u;
+  std::memcpy(u.internal, id, LSQAMD_COMM_ID_BYTES);
+  Comm c = nullptr;
+  NCCLCHK(f, a.CommInitRank(&c, nranks, u, rank));
+  f->comm = c;
+  f->comm_rank = rank;
+  f->comm_nranks = nranks;
+  return 0;
+}
+
+int lsqamd_comm_destroy(lsqamd_fit *f) {
+  if (!f) return LSQAMD_EINVAL;
+  (void)hipStreamSynchronize(f->st);
+  lsqamd_host::comm_release(f);
+  return 0;
+}
+
+int lsqamd_comm_info(const lsqamd_fit *f, int32_t *rank, int32_t *nranks) {
+  if (!f) return LSQAMD_EINVAL;
+  if (rank) *rank = f->comm ? f->comm_rank : -1;
+  if (nranks) *nranks = f->comm ? f->comm_nranks : 0;
+  return 0;
+}
+
+}  // extern "C"

@@ -13,6 +13,9 @@
 
 namespace lsqamd_host {
 
+void comm_release(lsqamd_fit *f);                                  // comm.hip
+int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count);   // sums enqueued on f->st
+
 struct TimerSlot {
   double total_ms = 0.0;
   int64_t count = 0;
@@ -66,6 +69,9 @@ struct lsqamd_fit {
   lsqamd_reduce_fn reduce = nullptr;
   void *reduce_user = nullptr;
   bool adds_prior = true;
+  // in-library RCCL communicator (comm.hip); takes precedence over the hook
+  void *comm = nullptr;
+  int32_t comm_rank = 0, comm_nranks = 1;
 
   // box bounds of the reflective trust-region method (empty: none)
   std::vector<double> lb, ub;
@@ -98,6 +104,7 @@ struct lsqamd_fit {
       }
     for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
     if (pin) (void)hipHostFree(pin);
+    lsqamd_host::comm_release(this);
   }
 };
 

@@ -7,9 +7,17 @@ per trial step.  One process per GPU; ``torch.distributed`` (backend "nccl" =
 RCCL over xGMI on the GPU box, "gloo" in the CPU tests) carries the sums.  The
 reference has no distributed path at all; this is new design.
 
-The exchange is the all-reduce hook of the C ABI (``lsqamd_reduce_fn``): the
-library hands the hook a device address inside the torch-owned workspace and the
-hook all-reduces a float64 view of exactly that region in place.
+Two transports behind the same sums:
+
+  * ``collective='rccl'`` (default when torch.distributed runs on the "nccl" = RCCL
+    backend): the library owns a persistent RCCL communicator per handle
+    (``lsqamd_comm_init``) and enqueues reduce-scatter + all-gather on the handle's
+    stream -- no Python, no stream synchronisation inside an LM step.
+    torch.distributed only carries the 128-byte communicator id at setup;
+  * ``collective='hook'``: the all-reduce hook of the C ABI (``lsqamd_reduce_fn``):
+    the library hands the hook a device address inside the torch-owned workspace and
+    the hook all-reduces a float64 view of exactly that region in place.  This is what
+    the gloo tests use (CPU box, or several ranks sharing one GPU, which RCCL refuses).
 """
 import numpy as np
 
@@ -70,11 +78,30 @@ def cuda_sync():
     torch.cuda.current_stream().synchronize()
 
 
-def sharded_problem(model, x, whitening, rank, world, group=None):
-    """DeviceProblem for this rank's rows with the RCCL all-reduce hook installed."""
+def attach_rccl(problem, rank, world, group=None):
+    """Library-side communicator for this handle: rank 0 makes the id, torch.distributed
+    carries it (setup only), every rank joins."""
+    import torch.distributed as dist
+    box = [problem.comm_unique_id() if rank == 0 else None]
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast_object_list(box, src=src, group=group)
+    problem.comm_init(box[0], rank, world)
+
+
+def sharded_problem(model, x, whitening, rank, world, group=None, collective=None):
+    """DeviceProblem for this rank's rows, its sums wired to the other ranks."""
+    import torch.distributed as dist
     from .fitter import DeviceProblem
     ranges = shard_rows(whitening.n_data, [(b['row0'], b['size']) for b in whitening.blocks], world)
     pr = DeviceProblem(model, x, whitening, rows=ranges[rank], adds_prior=(rank == 0))
     if world > 1:
-        pr.set_reduce(make_reduce_hook(pr.view, group=group, sync=cuda_sync))
+        if collective is None:
+            collective = 'rccl' if dist.get_backend(group) == 'nccl' else 'hook'
+        if collective == 'rccl':
+            attach_rccl(pr, rank, world, group)
+        elif collective == 'hook':
+            pr.set_reduce(make_reduce_hook(pr.view, group=group, sync=cuda_sync))
+        else:
+            raise ValueError("collective must be 'rccl' or 'hook'")
+    pr.collective = collective if world > 1 else None
     return pr

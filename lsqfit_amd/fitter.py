@@ -48,6 +48,15 @@ def normalize_tol(tol):
     return tuple(tol)
 
 
+def _cov_failed(fit, summary):
+    """A rank-deficient J^T J at the end point must not look like a clean fit."""
+    if summary.cov_status != 0:
+        msg = 'J^T J is not positive definite at the solution: covariance and logGBF are undefined'
+        warnings.warn('lsqfit_amd: ' + msg)
+        if fit.error is None:
+            fit.error = msg
+
+
 class DeviceProblem:
     """Model + data + whitening resident on one GPU (one C-ABI handle).
 
@@ -136,8 +145,22 @@ class DeviceProblem:
 
     # -- knobs ------------------------------------------------------------------------
     def set_prior(self, mean, prec):
-        mean = np.ascontiguousarray(mean, np.float64)
+        """Prior mean (P) and precision: P entries (diagonal) or P x P (dense).  A diagonal given
+        to a handle created with a dense prior is expanded; the reverse is refused (the library
+        copies exactly what the handle's config promises)."""
+        P = self.P
+        mean = np.ascontiguousarray(mean, np.float64).reshape(-1)
         prec = np.ascontiguousarray(prec, np.float64)
+        if mean.size != P:
+            raise ValueError('prior mean has %d entries, the model has %d parameters' % (mean.size, P))
+        if self.cfg.prior_dense:
+            if prec.size == P:
+                prec = np.ascontiguousarray(np.diag(prec.reshape(-1)))
+            elif prec.shape != (P, P):
+                raise ValueError('prior precision must have %d or %d x %d entries' % (P, P, P))
+        elif prec.size != P:
+            raise ValueError('this problem was created with a diagonal prior: the precision must have '
+                             '%d entries, got %s' % (P, prec.shape))
         _check(self.lib, self.h, self.lib.lsqamd_set_prior(self.h, _lib.dptr(mean), _lib.dptr(prec)), 'set_prior')
 
     def set_ymean(self, ymean):
@@ -167,6 +190,30 @@ class DeviceProblem:
         self._reduce_error = None
         self._reduce_cb = _lib.REDUCE_FN(cb)
         _check(self.lib, self.h, self.lib.lsqamd_set_reduce(self.h, self._reduce_cb, None), 'set_reduce')
+
+    # -- in-library RCCL communicator (include/lsqfit_amd.h, lsqamd_comm_*) ------------------
+    def comm_unique_id(self):
+        """bytes: the id rank 0 creates and ships to the other ranks."""
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        rc = self.lib.lsqamd_comm_unique_id(buf, _lib.COMM_ID_BYTES)
+        if rc != 0:
+            raise RuntimeError('lsqfit_amd: comm_unique_id failed (%s)' % _lib.ERRORS.get(rc, rc))
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        """Join the communicator (collective over all ranks); afterwards the sums of the sharded
+        fit run as RCCL reduce-scatter + all-gather on this handle's stream."""
+        uid = bytes(uid)
+        _check(self.lib, self.h, self.lib.lsqamd_comm_init(self.h, uid, len(uid), int(rank), int(nranks)),
+               'comm_init')
+
+    def comm_info(self):
+        r, n = C.c_int32(), C.c_int32()
+        self.lib.lsqamd_comm_info(self.h, C.byref(r), C.byref(n))
+        return r.value, n.value
+
+    def comm_destroy(self):
+        self.lib.lsqamd_comm_destroy(self.h)
 
     def view(self, dev_ptr, count):
         """float64 torch view of a region of the workspace (what the reduce hook sums)."""
@@ -416,6 +463,7 @@ class mi355x_lm(object):
             self.error = "gsl_multifit can't improve on starting value; may have converged already."
         if s.info == 0 and self.error is None and maxit > 0:
             self.error = "gsl_multifit didn't converge in {} iterations".format(maxit)
+        _cov_failed(self, s)
         self.x = pr.get_x()
         self.cov = pr.get_cov()
         self.results = None
@@ -519,6 +567,7 @@ class mi355x_trf(mi355x_lm):
         self.logdet_jtj = s.logdet_jtj
         self.stopping_criterion = s.stopping_criterion
         self.status = s.info - 100           # scipy's OptimizeResult.status
+        _cov_failed(self, s)
         self.x = pr.get_x()
         self.cov = pr.get_cov()
         self.results = None

@@ -304,7 +304,8 @@ def test_reduce_hook_on_device_single_rank(amd):
 
 def test_empbayes_example_on_device(amd):
     """examples/empbayes.py / .out (logGBF 21.274 at prior width 5.3) through the device
-    fits, and a config-5-style prior-width sweep on one resident problem vs the oracle."""
+    fits (the z search runs its candidate fits as lockstep batches), and a config-5-style
+    prior-width sweep as one batch vs the oracle."""
     from oracle import dual
     k = KAT['empbayes']
     x = np.array(k['src_inputs']['x'])
@@ -318,20 +319,19 @@ def test_empbayes_example_on_device(amd):
     assert '%.5g' % fit.logGBF == '21.274'
     assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[2.5904(22) -6.530(22) 7.832(65) -1.688(55)]'
     assert '%.2g' % (fit.chi2 / fit.dof) == '0.81' and fit.dof == 7
-    # sweep: same data, 6 prior widths, one DeviceProblem; each fit equals the oracle's
-    wh = amd.Whitening(ym, ys, np.zeros(4), np.full(4, 1.0))
-    pr = amd.DeviceProblem(model, x, wh)
+    # sweep: same data, 6 prior widths as ONE lockstep batch; each fit equals the oracle's
     widths = [0.5, 1.0, 2.0, 5.3, 10.0, 50.0]
-    fits = amd.prior_width_sweep(pr, (x, ym, ys), model, np.zeros(4), widths, p0=np.array([2.6, -6.5, 7.8, -1.7]))
+    fits = amd.prior_width_sweep((x, ym, ys), model, np.zeros(4), widths, p0=np.array([2.6, -6.5, 7.8, -1.7]))
     fcn = lambda xx, p: dual.exp(-p[0] - p[1] * xx - p[2] * xx ** 2 - p[3] * xx ** 3)
     for w, f in zip(widths, fits):
         ref = ofit.nonlinear_fit(x, ym, ys, fcn, prior_mean=np.zeros(4), prior_err=np.full(4, w),
                                  p0=np.array([2.6, -6.5, 7.8, -1.7]), solver='cholesky')
+        assert f.width == w
         assert gu.relmax(f.pmean, ref.pmean) < 1e-6
+        assert gu.relmax(f.psdev, ref.psdev) < 1e-6
         assert f.logGBF == pytest.approx(ref.logGBF, rel=1e-7, abs=1e-6)
         assert f.chi2 == pytest.approx(ref.chi2, rel=1e-6)
     assert int(np.argmax([f.logGBF for f in fits])) == 3
-    pr.close()
 
 
 def test_x_err_example_on_device(amd):

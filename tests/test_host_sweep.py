@@ -1,0 +1,57 @@
+"""Host logic of lsqfit_amd.sweep that needs no GPU: the batched-candidate simplex search takes
+the iterates of the textbook Nelder-Mead method (checked against scipy's implementation of it, a
+third-party package -- not the reference), and bench.py's launch guard."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from lsqfit_amd.sweep import simplex_search
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = [
+    (lambda z: (z[0] - 1.7) ** 2 + 0.3 * np.cos(3 * z[0]), [0.4]),
+    (lambda z: (1 - z[0]) ** 2 + 100 * (z[1] - z[0] ** 2) ** 2, [-1.2, 1.0]),
+    (lambda z: np.sum((z - np.array([0.5, -2.0, 3.0])) ** 2 * np.array([1.0, 10.0, 0.1])) + np.sin(z[0] * z[2]), [0.0, 0.0, 0.0]),
+]
+
+
+@pytest.mark.parametrize('k', range(len(CASES)))
+def test_simplex_search_follows_nelder_mead(k):
+    f, z0 = CASES[k]
+    calls = []
+
+    def fmany(pts):
+        calls.append(len(pts))
+        return np.array([f(p) for p in np.atleast_2d(pts)])
+    z, val = simplex_search(fmany, z0, tol=1e-6, maxit=400)
+    ref = minimize(f, np.array(z0, float), method='Nelder-Mead', tol=1e-6, options=dict(maxiter=400))
+    assert np.allclose(z, ref.x, rtol=0, atol=1e-9)
+    assert val == pytest.approx(ref.fun, abs=1e-12)
+    assert calls[0] == len(z0) + 1 and set(calls[1:]) <= {4, len(z0)}   # whole simplex, then candidate batches
+
+
+def test_simplex_search_skips_undefined_values():
+    """inf marks a z whose logGBF is undefined: never selected, the search goes on."""
+    f = lambda z: np.inf if z[0] > 2.0 else (z[0] - 1.9) ** 2
+    z, val = simplex_search(lambda pts: np.array([f(p) for p in pts]), [1.0], tol=1e-8)
+    assert abs(z[0] - 1.9) < 1e-6 and val < 1e-10
+
+
+def test_bench_refuses_a_mismatched_launch():
+    env = dict(os.environ, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2'], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_bench_self_launch_needs_the_gpus():
+    import torch
+    if torch.cuda.device_count() >= 4:
+        pytest.skip('4 GPUs present')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '4'], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and 'visible' in (r.stderr + r.stdout)
