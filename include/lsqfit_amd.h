@@ -185,6 +185,29 @@ const char *lsqamd_last_error(const lsqamd_fit *fit);
  * 1470-1543: `y += f - mean(y)` then gvar.bootstrap_iter keeps the covariance). */
 int lsqamd_set_ymean(lsqamd_fit *fit, const double *ymean);
 
+/* ---- whitening set-up on the device ------------------------------------------------------
+ * The O(B^3) part of what nonlinear_fit obtains from gvar.PDF(...) (src/lsqfit/__init__.py:
+ * 1892-1900; svdcut semantics doc/source/overview.rst:1546-1606), for n_blocks covariance
+ * blocks of ONE size B given back to back (cov[n_blocks][B][B], row-major, host or device
+ * memory): correlation matrix -> Cholesky -> triangular inverse, all on the device.  Outputs:
+ *   wt_out      device, [n_blocks][B][B]: the TRANSPOSED weights lsqamd_set_data takes
+ *               (Wt_b = D^-1 inv(U_b), upper triangular; W_b^T W_b = inv(C_b));
+ *   prec_out    device, [n_blocks][B][B] or NULL: inv(C_b) (what lsqamd_set_prior takes for a
+ *               correlated prior block);
+ *   logdet_out  host [n_blocks]: log det C_b;
+ *   lam_min_out / lam_max_out  host [n_blocks] or NULL: a lower / an upper bound on the extreme
+ *               eigenvalues of the block's correlation matrix;
+ *   status_out  host [n_blocks]: 0 = weights valid and no eigenvalue lies below
+ *               |svdcut| * lambda_max (gvar would leave the block untouched too); 1 = the svdcut
+ *               floor may bind: the caller must take the eigen-mode route for this block;
+ *               2 = not positive definite (same remedy, or an error).
+ * lsqamd_set_data / lsqamd_set_prior / lsqamdb_set_blocks accept device pointers for their
+ * weight / precision arguments, so the results never visit the host. */
+size_t lsqamd_whiten_work_bytes(int64_t block_size, int32_t n_blocks);
+int lsqamd_whiten_blocks(void *stream, int64_t block_size, int32_t n_blocks, const double *cov, double svdcut,
+                         double *wt_out, double *prec_out, void *dev_work, size_t work_bytes,
+                         double *logdet_out, double *lam_min_out, double *lam_max_out, int32_t *status_out);
+
 /* ---- problem data (copied host -> device) ----------------------------------- */
 /* x[n_data][n_x]: what the closure `flatfcn` hides (__init__.py:566-568,:1997-2042) */
 int lsqamd_set_x(lsqamd_fit *fit, const double *x, int64_t n_rows, int32_t n_x);
@@ -197,14 +220,15 @@ int lsqamd_set_tape(lsqamd_fit *fit, const int32_t *code, int32_t n_code,
  *   block_modes[b] <= block_size[b] kept modes; wt holds, back to back, each
  *   block's TRANSPOSED weights Wt_b[B_b][B_b] (row j = column j of W_b,
  *   columns >= block_modes[b] zero) so that W_b^T W_b = inv(C_b regulated).
- *   block_tri[b] != 0 promises Wt_b is upper triangular (W_b = inv(chol)). */
+ *   block_tri[b] != 0 promises Wt_b is upper triangular (W_b = inv(chol)).
+ *   wt may point to host or device memory (lsqamd_whiten_blocks leaves its result on the device). */
 int lsqamd_set_data(lsqamd_fit *fit, const double *ymean, const double *wdiag, int32_t n_blocks,
                     const int64_t *block_row0, const int64_t *block_size,
                     const int64_t *block_modes, const int32_t *block_tri, const double *wt);
 /* Prior: mean[P] and precision = inv(C_prior regulated): prec[P] (diagonal) or
  * prec[P*P] (dense, symmetric) as cfg.prior_dense says.  The prior rows of
  * chiv (_utilities.pyx:76-77) enter J^T J / J^T f / chi2 through it. */
-int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);
+int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);   /* prec: host or device memory */
 /* Data-prior cross-correlations (the reference whitens concat(y, prior) as ONE vector,
  * src/lsqfit/__init__.py:1892-1900; examples/y-noerr.py): create the fit with has_prior = 0 and
  * n_data = N + (number of prior entries), give the prior entries as extra rows of ymean / wdiag /

@@ -51,11 +51,14 @@ PROTOTYPES = {
     'lsqamd_create': (C.c_int, [C.POINTER(Config), _vp, C.c_size_t, _vp, C.POINTER(_vp)]),
     'lsqamd_destroy': (C.c_int, [_vp]),
     'lsqamd_last_error': (C.c_char_p, [_vp]),
+    'lsqamd_whiten_work_bytes': (C.c_size_t, [C.c_int64, C.c_int32]),
+    'lsqamd_whiten_blocks': (C.c_int, [_vp, C.c_int64, C.c_int32, _vp, C.c_double, _vp, _vp, _vp, C.c_size_t,
+                                       _dp, _dp, _dp, C.POINTER(C.c_int32)]),
     'lsqamd_set_x': (C.c_int, [_vp, _dp, C.c_int64, C.c_int32]),
     'lsqamd_set_tape': (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int32]),
     'lsqamd_set_data': (C.c_int, [_vp, _dp, _dp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp]),
-    'lsqamd_set_prior': (C.c_int, [_vp, _dp, _dp]),
+                                  C.POINTER(C.c_int64), C.POINTER(C.c_int32), _vp]),
+    'lsqamd_set_prior': (C.c_int, [_vp, _dp, _vp]),
     'lsqamd_set_ymean': (C.c_int, [_vp, _dp]),
     'lsqamd_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
     'lsqamd_query_devices': (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_size_t,
@@ -100,9 +103,9 @@ PROTOTYPES = {
     'lsqamdb_set_tape': (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int32]),
     'lsqamdb_set_data': (C.c_int, [_vp, _dp, _dp]),
     'lsqamdb_set_blocks': (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
-                                     C.POINTER(C.c_int64), C.POINTER(C.c_int32), _dp]),
+                                     C.POINTER(C.c_int64), C.POINTER(C.c_int32), _vp]),
     'lsqamdb_set_data_means': (C.c_int, [_vp, _dp]),
-    'lsqamdb_set_priors': (C.c_int, [_vp, _dp, _dp]),
+    'lsqamdb_set_priors': (C.c_int, [_vp, _dp, _vp]),
     'lsqamdb_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
     'lsqamdb_run': (C.c_int, [_vp, _dp, C.POINTER(Summary), C.c_int32]),
     'lsqamdb_get_x': (C.c_int, [_vp, _dp, C.c_size_t]),
@@ -142,3 +145,11 @@ def load():
 
 def dptr(a):
     return a.ctypes.data_as(_dp)
+
+
+def anyptr(a):
+    """void* of a numpy array (host) or a torch tensor (device): the arguments of the C ABI that
+    accept either kind of memory."""
+    if hasattr(a, 'data_ptr'):
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)

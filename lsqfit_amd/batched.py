@@ -101,7 +101,7 @@ class BatchedFits:
             self._check(lib.lsqamdb_set_blocks(
                 h, len(size), row0.ctypes.data_as(C.POINTER(C.c_int64)), size.ctypes.data_as(C.POINTER(C.c_int64)),
                 modes.ctypes.data_as(C.POINTER(C.c_int64)), tri.ctypes.data_as(C.POINTER(C.c_int32)),
-                _lib.dptr(wt)), 'set_blocks')
+                _lib.anyptr(wt)), 'set_blocks')
         if ymeans is not None:
             self.set_data_means(ymeans)
         if self.has_prior and self.prior_dense:
@@ -127,7 +127,7 @@ class BatchedFits:
         """Dense shared prior: new per-fit means (the shared precision is re-sent with them)."""
         mean = np.ascontiguousarray(mean, np.float64)
         self.prior_mean = mean
-        self._check(self.lib.lsqamdb_set_priors(self.h, _lib.dptr(mean), _lib.dptr(self.prior_prec)), 'set_priors')
+        self._check(self.lib.lsqamdb_set_priors(self.h, _lib.dptr(mean), _lib.anyptr(self.prior_prec)), 'set_priors')
 
     def set_priors(self, mean, sdev):
         if self.prior_dense:
@@ -136,7 +136,7 @@ class BatchedFits:
         sdev = np.ascontiguousarray(np.broadcast_to(np.asarray(sdev, np.float64), mean.shape))
         prec = np.ascontiguousarray(1.0 / sdev ** 2)
         self.prior_mean, self.prior_sdev = mean, sdev
-        self._check(self.lib.lsqamdb_set_priors(self.h, _lib.dptr(mean), _lib.dptr(prec)), 'set_priors')
+        self._check(self.lib.lsqamdb_set_priors(self.h, _lib.dptr(mean), _lib.anyptr(prec)), 'set_priors')
 
     def run(self, p0=None, tol=1e-8, maxit=1000, scaler='more', factor_up=3.0, factor_down=2.0,
             use_graph=True, covariance=True):

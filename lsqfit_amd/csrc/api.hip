@@ -1194,7 +1194,7 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
     HIPCHK(f, hipMemcpyAsync(f->blk_row0, f->h_row0.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
     HIPCHK(f, hipMemcpyAsync(f->blk_size, f->h_size.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
     HIPCHK(f, hipMemcpyAsync(f->blk_woff, f->h_woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->wt, wt, sizeof(double) * off, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipMemcpyAsync(f->wt, wt, sizeof(double) * off, hipMemcpyDefault, f->st));   // host or device source
   }
   HIPCHK(f, hipStreamSynchronize(f->st));
   f->have_data = true;
@@ -1217,7 +1217,7 @@ int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) {
   const int64_t P = f->P;
   HIPCHK(f, hipMemcpyAsync(f->prior_mean, mean, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
   HIPCHK(f, hipMemcpyAsync(f->prior_prec, prec, sizeof(double) * (f->cfg.prior_dense ? P * P : P),
-                           hipMemcpyHostToDevice, f->st));
+                           hipMemcpyDefault, f->st));   // host or device source
   HIPCHK(f, hipStreamSynchronize(f->st));
   f->have_prior = true;
   return 0;

@@ -859,7 +859,7 @@ int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, c
   BHIP(f, hipMemcpy(f->blk_row0, row0, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
   BHIP(f, hipMemcpy(f->blk_size, size, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
   BHIP(f, hipMemcpy(f->blk_woff, woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->wt, wt, sizeof(double) * off, hipMemcpyHostToDevice));
+  BHIP(f, hipMemcpy(f->wt, wt, sizeof(double) * off, hipMemcpyDefault));   // host or device source
   f->have_blocks = true;
   return 0;
 }
@@ -871,7 +871,7 @@ int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) 
   if (!f->cfg.has_prior) BFAIL(f, LSQAMD_EINVAL, "set_priors: config has no prior");
   BHIP(f, hipMemcpy(f->pmean, mean, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
   BHIP(f, hipMemcpy(f->pprec, prec, sizeof(double) * (f->cfg.prior_dense ? f->P * f->P : f->B * f->P),
-                    hipMemcpyHostToDevice));
+                    hipMemcpyDefault));   // host or device source
   f->have_prior = true;
   return 0;
 }

@@ -131,9 +131,11 @@ class DeviceProblem:
             h, _lib.dptr(ym), _lib.dptr(wd), len(size),
             row0.ctypes.data_as(C.POINTER(C.c_int64)), size.ctypes.data_as(C.POINTER(C.c_int64)),
             modes.ctypes.data_as(C.POINTER(C.c_int64)), tri.ctypes.data_as(C.POINTER(C.c_int32)),
-            _lib.dptr(wt)), 'set_data')
+            _lib.anyptr(wt)), 'set_data')
+        del wt
         if whitening.has_prior:
-            self.set_prior(whitening.prior_mean, whitening.prior_prec)
+            dev = getattr(whitening, 'prior_prec_dev', None)      # made on the device: stays there
+            self.set_prior(whitening.prior_mean, whitening.prior_prec if dev is None else dev)
         if joint:
             rp = np.ascontiguousarray(whitening.row_param, np.int32)
             _check(lib, h, lib.lsqamd_set_param_rows(h, rp.ctypes.data_as(C.POINTER(C.c_int32))), 'set_param_rows')
@@ -150,10 +152,16 @@ class DeviceProblem:
         copies exactly what the handle's config promises)."""
         P = self.P
         mean = np.ascontiguousarray(mean, np.float64).reshape(-1)
-        prec = np.ascontiguousarray(prec, np.float64)
+        if hasattr(prec, 'data_ptr'):                # a CUDA tensor (lsqamd_whiten_blocks' inv(C))
+            if not (self.cfg.prior_dense and tuple(prec.shape) == (P, P) and prec.is_contiguous()):
+                raise ValueError('a device-resident prior precision must be a contiguous %d x %d tensor' % (P, P))
+        else:
+            prec = np.ascontiguousarray(prec, np.float64)
         if mean.size != P:
             raise ValueError('prior mean has %d entries, the model has %d parameters' % (mean.size, P))
-        if self.cfg.prior_dense:
+        if hasattr(prec, 'data_ptr'):
+            pass
+        elif self.cfg.prior_dense:
             if prec.size == P:
                 prec = np.ascontiguousarray(np.diag(prec.reshape(-1)))
             elif prec.shape != (P, P):
@@ -161,7 +169,7 @@ class DeviceProblem:
         elif prec.size != P:
             raise ValueError('this problem was created with a diagonal prior: the precision must have '
                              '%d entries, got %s' % (P, prec.shape))
-        _check(self.lib, self.h, self.lib.lsqamd_set_prior(self.h, _lib.dptr(mean), _lib.dptr(prec)), 'set_prior')
+        _check(self.lib, self.h, self.lib.lsqamd_set_prior(self.h, _lib.dptr(mean), _lib.anyptr(prec)), 'set_prior')
 
     def set_ymean(self, ymean):
         """New data means for this problem's rows (same covariance)."""

@@ -1,10 +1,18 @@
-"""Host-side whitening setup: the product's mirror of what ``nonlinear_fit``
-obtains from ``gvar.PDF`` (src/lsqfit/__init__.py:1892-1900, read back at
-:553-561,:574,:723 and src/lsqfit/_utilities.pyx:58-61).
+"""Whitening setup: the product's mirror of what ``nonlinear_fit`` obtains from
+``gvar.PDF`` (src/lsqfit/__init__.py:1892-1900, read back at :553-561,:574,:723 and
+src/lsqfit/_utilities.pyx:58-61).
 
-Runs once per fit on the host (in the reference it is host code too: gvar's
-block search + per-block eigen-decomposition).  It produces what the device
-path consumes through ``lsqamd_set_data`` / ``lsqamd_set_prior``:
+Runs once per fit.  The host keeps what is bookkeeping in the reference too -- the
+block search, the svdcut policy, ``nmod`` / ``nblocks`` / ``nchiv`` -- and the
+O(B^3) factorisations run ON THE DEVICE (``lsqamd_whiten_blocks``: batched
+Cholesky of the correlation matrices, triangular inverses, log-determinants, the
+test whether the svdcut floor can bind; the weights stay in HBM and go straight
+into ``lsqamd_set_data`` / ``lsqamd_set_prior``).  Only a block whose floor DOES
+bind (or that is not positive definite) takes the eigen-mode route of
+doc/source/overview.rst:1546-1606 in LAPACK on the host -- which is what gvar does
+for every block.  Without a visible GPU (the host-logic tests) everything takes the
+LAPACK route; nothing can be fitted there anyway.  It produces what the device path
+consumes through ``lsqamd_set_data`` / ``lsqamd_set_prior``:
 
   * ``wdiag``   1/sdev for the 1x1 rows;
   * per correlated data block the TRANSPOSED whitening matrix ``Wt`` with
@@ -83,6 +91,93 @@ def _regulate_block(cov, svdcut, force_eig=False):
     return dict(Wt=Wt, modes=m, tri=0, logdet=logdet, nmod=nmod, var_reg=var_reg, S=S)
 
 
+class _Block(dict):
+    """One covariance block.  ``Wt`` (host copy of the transposed weights) and ``S`` (sampling
+    factor, S S^T = regulated covariance) are made on first use: the device path needs neither."""
+
+    def __missing__(self, key):
+        if key == 'Wt':
+            v = self['Wt_dev'].cpu().numpy()
+        elif key == 'S':
+            cov = np.asarray(self['cov'], float)
+            sd = np.sqrt(np.diag(cov))
+            v = sd[:, None] * sla.cholesky(cov / np.outer(sd, sd), lower=True)
+        elif key == 'prec':
+            v = self['prec_dev'].cpu().numpy()
+        else:
+            raise KeyError(key)
+        self[key] = v
+        return v
+
+
+def device_available():
+    try:
+        import torch
+        return bool(torch.cuda.is_available())
+    except Exception:
+        return False
+
+
+def _device_regulate(covs, svdcut, want_prec):
+    """Same-size covariance blocks -> [_Block or None] through ``lsqamd_whiten_blocks``; None marks
+    a block the device hands back (svdcut floor may bind / not positive definite)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    nb, B = len(covs), covs[0].shape[0]
+    stack = np.ascontiguousarray(covs[0] if nb == 1 else np.stack(covs), np.float64)
+    dev = torch.device('cuda', torch.cuda.current_device())
+    wt = torch.empty((nb, B, B), dtype=torch.float64, device=dev)
+    prec = torch.empty((nb, B, B), dtype=torch.float64, device=dev) if want_prec else None
+    nbytes = lib.lsqamd_whiten_work_bytes(B, nb)
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    logdet, lmin, lmax = np.empty(nb), np.empty(nb), np.empty(nb)
+    status = np.empty(nb, np.int32)
+    rc = lib.lsqamd_whiten_blocks(
+        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, nb, C.c_void_p(stack.ctypes.data),
+        0.0 if svdcut is None else float(svdcut), C.c_void_p(wt.data_ptr()),
+        C.c_void_p(prec.data_ptr()) if want_prec else None, C.c_void_p(work.data_ptr()), nbytes,
+        _lib.dptr(logdet), _lib.dptr(lmin), _lib.dptr(lmax), status.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc != 0:
+        raise RuntimeError('lsqfit_amd: lsqamd_whiten_blocks failed (%s)' % _lib.ERRORS.get(rc, rc))
+    del work
+    out = []
+    for b in range(nb):
+        if status[b] != 0:
+            out.append(None)
+            continue
+        k = _Block(Wt_dev=wt[b], modes=B, tri=1, logdet=float(logdet[b]), nmod=0,
+                   var_reg=np.diag(covs[b]).copy(), cov=covs[b], lam_bounds=(float(lmin[b]), float(lmax[b])))
+        if want_prec:
+            k['prec_dev'] = prec[b]
+        out.append(k)
+    return out
+
+
+def regulate_blocks(covs, svdcut, want_prec=False, engine=None):
+    """[cov] -> [_Block]: the factorisations of every correlated block, on the device when one is
+    visible (``engine`` None), grouped by block size; LAPACK eigen route for what the device hands
+    back and for ``engine='host'``."""
+    if engine is None:
+        engine = 'device' if device_available() else 'host'
+    if engine not in ('device', 'host'):
+        raise ValueError("engine must be 'device' or 'host'")
+    out = [None] * len(covs)
+    if engine == 'device':
+        by_size = {}
+        for i, c in enumerate(covs):
+            by_size.setdefault(c.shape[0], []).append(i)
+        for B, idx in by_size.items():
+            for i, k in zip(idx, _device_regulate([np.asarray(covs[i], float) for i in idx], svdcut, want_prec)):
+                out[i] = k
+    for i, c in enumerate(covs):
+        if out[i] is None:
+            out[i] = _Block(_regulate_block(c, svdcut, force_eig=(engine == 'device')))
+            out[i]['cov'] = np.asarray(c, float)
+    return out
+
+
 def _extreme_eigs(corr, L, iters=40):
     """(lambda_max, lambda_min) of an SPD matrix: exact for small blocks, power /
     inverse-power iteration through its Cholesky factor for large ones."""
@@ -152,9 +247,10 @@ class Whitening:
     """Everything the device path needs to know about concat(y, prior)."""
 
     def __init__(self, ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12, eps=None,
-                 udata=False):
+                 udata=False, engine=None):
         if eps is not None:
             raise NotImplementedError('eps regulation is not available on the device path')
+        self.engine = engine
         self.svdcut = svdcut
         self.eps = None
         self.ymean = np.array(ymean, float).reshape(-1)
@@ -168,9 +264,9 @@ class Whitening:
         self.wdiag = np.ones(N)
         self.blocks = []                      # dicts: row0, size, modes, tri, Wt
         in_block = np.zeros(N, bool)
-        for r0, cov in sorted(yblocks, key=lambda b: b[0]):
+        yblocks = sorted(yblocks, key=lambda b: b[0])
+        for (r0, cov), reg in zip(yblocks, regulate_blocks([c for _, c in yblocks], svdcut, engine=engine)):
             B = cov.shape[0]
-            reg = _regulate_block(cov, svdcut)
             reg.update(row0=int(r0), size=int(B))
             self.blocks.append(reg)
             in_block[r0:r0 + B] = True
@@ -189,9 +285,10 @@ class Whitening:
         # ---- prior
         self.has_prior = prior_mean is not None
         self.prior_mean = None
-        self.prior_prec = None
+        self._prior_prec = self.prior_prec_dev = None
         self.prior_dense = False
-        self.prior_W = None                   # rows of the whitened prior residual (for fit.f / fit.J)
+        self.prior_blocks = []                # dense prior blocks (dicts like self.blocks, row0 = first parameter)
+        self._prior_diag = None               # (indices, sdev) of the uncorrelated prior entries
         nprior = 0
         if self.has_prior:
             pm = np.array(prior_mean, float).reshape(-1)
@@ -201,47 +298,91 @@ class Whitening:
             if not pblocks:
                 if np.any(psd <= 0):
                     raise ValueError('some priors have zero standard deviations')
-                self.prior_prec = 1.0 / psd ** 2
-                self.prior_W = ('diag', 1.0 / psd)
-                self.prior_S = [(np.arange(P), psd)]
+                self._prior_prec = 1.0 / psd ** 2
+                self._prior_diag = (np.arange(P), psd)
                 self.logdet += 2.0 * float(np.sum(np.log(psd)))
                 n1 += P
                 nprior = P
             else:
                 self.prior_dense = True
-                prec = np.zeros((P, P))
-                Wrows = []
-                self.prior_S = []
+                pblocks = sorted(pblocks, key=lambda b: b[0])
                 pin = np.zeros(P, bool)
-                for r0, cov in sorted(pblocks, key=lambda b: b[0]):
+                for (r0, cov), reg in zip(pblocks, regulate_blocks([c for _, c in pblocks], svdcut,
+                                                                   want_prec=True, engine=engine)):
                     B = cov.shape[0]
-                    reg = _regulate_block(cov, svdcut)
-                    W = reg['Wt'].T[:reg['modes']]
-                    prec[r0:r0 + B, r0:r0 + B] = W.T @ W
-                    full = np.zeros((W.shape[0], P))
-                    full[:, r0:r0 + B] = W
-                    Wrows.append(full)
-                    self.prior_S.append((np.arange(r0, r0 + B), reg['S']))
+                    reg.update(row0=int(r0), size=int(B))
+                    self.prior_blocks.append(reg)
                     pin[r0:r0 + B] = True
                     self.logdet += reg['logdet']
                     self.nmod += reg['nmod']
                     self.nblocks[B] = self.nblocks.get(B, 0) + 1
                     nprior += reg['modes']
                 dd = np.nonzero(~pin)[0]
-                prec[dd, dd] = 1.0 / psd[dd] ** 2
+                if np.any(psd[dd] <= 0):
+                    raise ValueError('some priors have zero standard deviations')
+                self._prior_diag = (dd, psd[dd])
                 self.logdet += 2.0 * float(np.sum(np.log(psd[dd])))
-                diag_rows = np.zeros((dd.size, P))
-                diag_rows[np.arange(dd.size), dd] = 1.0 / psd[dd]
-                if dd.size:
-                    self.prior_S.append((dd, psd[dd]))
                 n1 += dd.size
                 nprior += dd.size
-                self.prior_prec = prec
-                self.prior_W = ('dense', diag_rows, Wrows)
+                k0 = self.prior_blocks[0]
+                if len(self.prior_blocks) == 1 and k0['size'] == P and 'prec_dev' in k0:
+                    self.prior_prec_dev = k0['prec_dev']      # one block over all parameters: stays in HBM
             self.prior_sdev = psd
         if n1:
             self.nblocks[1] = n1
         self.nchiv = self.nchiv_data + nprior
+
+    # -- prior pieces the host needs only now and then (made on first use) ---------------------
+    @property
+    def prior_prec(self):
+        """inv(C_prior regulated): P entries (diagonal prior) or P x P."""
+        if self._prior_prec is None and self.has_prior:
+            P = self.prior_mean.size
+            prec = np.zeros((P, P))
+            for k in self.prior_blocks:
+                r0, B = k['row0'], k['size']
+                if 'prec_dev' in k:
+                    prec[r0:r0 + B, r0:r0 + B] = k['prec']
+                else:
+                    W = k['Wt'].T[:k['modes']]
+                    prec[r0:r0 + B, r0:r0 + B] = W.T @ W
+            dd, sd = self._prior_diag
+            prec[dd, dd] = 1.0 / sd ** 2
+            self._prior_prec = prec
+        return self._prior_prec
+
+    @prior_prec.setter
+    def prior_prec(self, value):
+        self._prior_prec, self.prior_prec_dev = value, None
+
+    @property
+    def prior_W(self):
+        """Rows of the whitened prior residual (for fit.f / fit.J): ('diag', w) or
+        ('dense', rows of the uncorrelated entries, [rows of each block])."""
+        if not self.has_prior:
+            return None
+        dd, sd = self._prior_diag
+        if not self.prior_dense:
+            return ('diag', 1.0 / sd)
+        P = self.prior_mean.size
+        diag_rows = np.zeros((dd.size, P))
+        diag_rows[np.arange(dd.size), dd] = 1.0 / sd
+        Wrows = []
+        for k in self.prior_blocks:
+            W = k['Wt'].T[:k['modes']]
+            full = np.zeros((W.shape[0], P))
+            full[:, k['row0']:k['row0'] + k['size']] = W
+            Wrows.append(full)
+        return ('dense', diag_rows, Wrows)
+
+    @property
+    def prior_S(self):
+        """[(indices, sampling factor)]: S S^T = regulated prior covariance."""
+        out = [(np.arange(k['row0'], k['row0'] + k['size']), k['S']) for k in self.prior_blocks]
+        dd, sd = self._prior_diag
+        if dd.size:
+            out.append((dd, sd))
+        return out
 
     # -- Gaussian draws with the regulated covariance (what gvar.bootstrap_iter produces) -----
     def draw_data(self, rng, n):
@@ -265,7 +406,8 @@ class Whitening:
     # -- device-facing packing ------------------------------------------------------
     def block_arrays(self, rows=None):
         """(row0, size, modes, tri, wt_flat) for the blocks inside rows [a, b)
-        (row0 relative to a)."""
+        (row0 relative to a); wt_flat is a CUDA tensor when every block's weights were made on
+        the device, a numpy array otherwise."""
         a, b = (0, self.n_data) if rows is None else rows
         sel = [k for k in self.blocks if k['row0'] >= a and k['row0'] + k['size'] <= b]
         for k in self.blocks:
@@ -277,6 +419,10 @@ class Whitening:
         size = np.array([k['size'] for k in sel], np.int64)
         modes = np.array([k['modes'] for k in sel], np.int64)
         tri = np.array([k['tri'] for k in sel], np.int32)
+        if sel and all('Wt_dev' in k for k in sel):
+            import torch                                  # weights made on the device stay there
+            wt = sel[0]['Wt_dev'].reshape(-1) if len(sel) == 1 else torch.cat([k['Wt_dev'].reshape(-1) for k in sel])
+            return row0, size, modes, tri, wt.contiguous()
         wt = (np.concatenate([k['Wt'].reshape(-1) for k in sel]) if sel else np.zeros(0))
         return row0, size, modes, tri, np.ascontiguousarray(wt, np.float64)
 
