@@ -217,10 +217,11 @@ def _solve_tr_2d(B, g, delta):
 
 
 def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down,
-           alg='lm', avmax=0.75, h_fvv=0.02, eval_fvec=None, undamped=None):
+           alg='lm', avmax=0.75, h_fvv=0.02, eval_fvec=None, undamped=None, stop=None):
     """Shared trust.c/fdf.c logic.  ``evaluate(x)`` refreshes ``lin`` with the
     Jacobian-level quantities at x and returns |f|^2; ``eval_fnorm2(x)`` is the
-    cheap trial evaluation."""
+    cheap trial evaluation.  ``stop()`` (bench.py's time box), asked after every iteration,
+    ends the run as ``maxit`` would."""
     xtol, gtol, ftol = tol
     x = np.array(x0, float)
     P = x.size
@@ -466,7 +467,7 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
             break
         it += 1
         status, info = test()
-        if not (status == GSL_CONTINUE and it < maxit):
+        if not (status == GSL_CONTINUE and it < maxit) or (stop is not None and stop()):
             break
     if not early and it >= maxit and status != GSL_SUCCESS:
         status = GSL_EMAXITER
@@ -531,7 +532,7 @@ def gsl_multifit(x0, n, f, df, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm',
 
 
 def lm_normal(x0, normal_eq, chi2_fn, tol=(1e-5, 0.0, 0.0), maxit=1000,
-              scaler='more', factor_up=3.0, factor_down=2.0, alg='lm'):
+              scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', stop=None):
     """Same driver fed by ``normal_eq(x) -> (A, g, chi2)`` and ``chi2_fn(x)``."""
     tol = normalize_tol(tol)
     lin = _NormalLin()
@@ -542,7 +543,7 @@ def lm_normal(x0, normal_eq, chi2_fn, tol=(1e-5, 0.0, 0.0), maxit=1000,
         return float(c2)
 
     res = _drive(x0, evaluate, lambda x: float(chi2_fn(x)), lin, tol, maxit,
-                 scaler, factor_up, factor_down, alg=alg)
+                 scaler, factor_up, factor_down, alg=alg, stop=stop)
     res.tol = tol
     res.A = lin.A
     res.g = lin.g

@@ -138,6 +138,42 @@ def test_config4_full_size_shard_additivity(amd, c4):
     assert np.array_equal(A_full, A_full.T)
 
 
+def test_config4_full_size_normal_equations_vs_numpy(amd, c4):
+    """configs[3] at its full size (N=65536, P=4096, 256-row covariance blocks, dense correlated
+    prior) against an independent restatement: J^T J, J^T f and chi2 from numpy / LAPACK with the
+    Cholesky factor of every block (any W with W^T W = inv(C) gives the same sums), at 1e-8 --
+    what test_config3_full_size... does for config 3.  The whitening on the device side is the
+    device-built one (lsqamd_whiten_blocks)."""
+    import scipy.linalg as sla
+    d, wh = c4
+    N, P = 65536, 4096
+    assert all('Wt_dev' in k for k in wh.blocks) and wh.prior_prec_dev is not None
+    p = d['p_true'] * (1 + 1e-5 * np.random.default_rng(11).standard_normal(P))
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    chi2 = pr.normal(p)
+    A, g = pr.get_jtj(), pr.get_grad()
+    pr.close()
+    J = gu.cosmix_jac(d['x'], p)
+    r = gu.cosmix_fcn(d['x'], p) - d['ymean']
+    logdet = 0.0
+    for r0, c in d['yerr']['blocks']:
+        L = sla.cholesky(c, lower=True)
+        B = c.shape[0]
+        J[r0:r0 + B] = sla.solve_triangular(L, J[r0:r0 + B], lower=True)
+        r[r0:r0 + B] = sla.solve_triangular(L, r[r0:r0 + B], lower=True)
+        logdet += 2.0 * np.sum(np.log(np.diag(L)))
+    pcov = np.asarray(d['prior'][1])
+    Lp = sla.cholesky(pcov, lower=True)
+    prec = sla.cho_solve((Lp, True), np.eye(P))
+    logdet += 2.0 * np.sum(np.log(np.diag(Lp)))
+    dp = p - d['prior'][0]
+    A_ref = J.T @ J + prec
+    assert gu.relmax(A, A_ref) < 1e-8
+    assert gu.relmax(g, J.T @ r + prec @ dp) < 1e-8
+    assert chi2 == pytest.approx(r @ r + dp @ prec @ dp, rel=1e-8)
+    assert wh.logdet == pytest.approx(logdet, rel=1e-10)
+
+
 def test_config4_full_size_fit_properties(amd, c4):
     d, wh = c4
     P = 4096
