@@ -69,7 +69,12 @@ enum {
 };
 
 enum { LSQAMD_SCALE_MORE = 0, LSQAMD_SCALE_LEVENBERG = 1, LSQAMD_SCALE_MARQUARDT = 2 }; /* _gsl.pyx:637-644 */
-enum { LSQAMD_SOLVER_CHOLESKY = 0 };                                                    /* _gsl.pyx:646-653 */
+/* _gsl.pyx:646-653.  CHOLESKY: damped normal equations, covariance from their factor.  QR (the
+ * reference's default; 'svd' maps here too): LM steps on the normal equations, the post-fit
+ * covariance and log det J^T J through a column-equilibrated CholeskyQR factorisation of the
+ * whitened Jacobian with re-orthogonalisation -- error ~ cond(J) eps like gsl's QR route, where the
+ * normal equations give cond(J)^2 eps (examples/y-noerr.out at nexp = 5).  Needs lsqamd_set_qr_work. */
+enum { LSQAMD_SOLVER_CHOLESKY = 0, LSQAMD_SOLVER_QR = 1 };
 /* trust-region sub-problem solvers: gsl_multifit's `alg` keyword (_gsl.pyx:622-635) */
 enum { LSQAMD_TRS_LM = 0, LSQAMD_TRS_LMACCEL = 1, LSQAMD_TRS_DOGLEG = 2, LSQAMD_TRS_DDOGLEG = 3,
        LSQAMD_TRS_SUBSPACE2D = 4,
@@ -238,6 +243,13 @@ int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);  
  * lsqamd_dpdy returns columns for the rows as given (data and prior entries alike). */
 int lsqamd_set_param_rows(lsqamd_fit *fit, const int32_t *row_param);
 int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
+/* Device scratch of the QR-grade covariance (LSQAMD_SOLVER_QR): a transposed copy of J, the
+ * orthogonalised Q and a few P x P matrices -- lsqamd_qr_work_bytes(fit) bytes the caller owns and
+ * lends to the handle (NULL takes it back).  lsqamd_qr_info: orthogonalisation passes of the last
+ * covariance and max |Q^T Q - I| seen before the final factor. */
+size_t lsqamd_qr_work_bytes(const lsqamd_fit *fit);
+int lsqamd_set_qr_work(lsqamd_fit *fit, void *dev_work, size_t work_bytes);
+int lsqamd_qr_info(const lsqamd_fit *fit, int32_t *passes, double *delta);
 /* Box bounds lower[P] < upper[P] (+-INFINITY = open side; NULL array = open everywhere; both
  * NULL clears them): the flattened `bounds` pair nonlinear_fit hands to scipy_least_squares
  * (src/lsqfit/__init__.py:641-655, tests/test_lsqfit.py:1780-1808).  LSQAMD_TRS_TRF and

@@ -61,6 +61,9 @@ PROTOTYPES = {
     'lsqamd_set_prior': (C.c_int, [_vp, _dp, _vp]),
     'lsqamd_set_ymean': (C.c_int, [_vp, _dp]),
     'lsqamd_set_options': (C.c_int, [_vp, C.POINTER(Options)]),
+    'lsqamd_qr_work_bytes': (C.c_size_t, [_vp]),
+    'lsqamd_set_qr_work': (C.c_int, [_vp, _vp, C.c_size_t]),
+    'lsqamd_qr_info': (C.c_int, [_vp, C.POINTER(C.c_int32), _dp]),
     'lsqamd_query_devices': (C.c_int, [C.POINTER(C.c_int32), C.c_int32, C.c_char_p, C.c_size_t,
                                        C.POINTER(C.c_int64)]),
     'lsqamd_set_bounds': (C.c_int, [_vp, _dp, _dp]),

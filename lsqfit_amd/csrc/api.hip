@@ -985,6 +985,7 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
 
 // covariance + logdet at the current point: factor A (mu = 0), invert
 int do_covariance(lsqamd_fit *f) {
+  if (f->opt.solver == LSQAMD_SOLVER_QR) return do_covariance_qr(f);
   const int64_t P = f->P;
   Scope sc(f, LSQAMD_T_COVAR);
   int32_t info = 0;
@@ -1227,10 +1228,27 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   if (!f || !opt) return LSQAMD_EINVAL;
   if (opt->xtol < 0 || opt->gtol < 0 || opt->maxit < 0) FAIL(f, LSQAMD_EINVAL, "set_options: negative tolerance/maxit");
   if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
-  if (opt->solver != LSQAMD_SOLVER_CHOLESKY) FAIL(f, LSQAMD_EUNSUPPORTED, "set_options: only the cholesky solver runs on the device");
+  if (opt->solver != LSQAMD_SOLVER_CHOLESKY && opt->solver != LSQAMD_SOLVER_QR) FAIL(f, LSQAMD_EINVAL, "set_options: unknown solver");
   if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
   if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_MINPACK_LM) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
   f->opt = *opt;
+  return 0;
+}
+
+size_t lsqamd_qr_work_bytes(const lsqamd_fit *f) { return f ? qr_work_bytes(f) : 0; }
+
+int lsqamd_set_qr_work(lsqamd_fit *f, void *dev_work, size_t work_bytes) {
+  if (!f) return LSQAMD_EINVAL;
+  if (dev_work && work_bytes < qr_work_bytes(f)) FAIL(f, LSQAMD_ENOMEM, "set_qr_work: need %zu bytes", qr_work_bytes(f));
+  f->qr_work = dev_work;
+  f->qr_work_bytes = dev_work ? work_bytes : 0;
+  return 0;
+}
+
+int lsqamd_qr_info(const lsqamd_fit *f, int32_t *passes, double *delta) {
+  if (!f) return LSQAMD_EINVAL;
+  if (passes) *passes = f->qr_passes;
+  if (delta) *delta = f->qr_delta;
   return 0;
 }
 

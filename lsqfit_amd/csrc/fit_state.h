@@ -73,6 +73,12 @@ struct lsqamd_fit {
   void *comm = nullptr;
   int32_t comm_rank = 0, comm_nranks = 1;
 
+  // solver = qr: caller-provided device scratch (lsqamd_set_qr_work) and what the last run did
+  void *qr_work = nullptr;
+  size_t qr_work_bytes = 0;
+  int32_t qr_passes = 0;
+  double qr_delta = NAN;
+
   // box bounds of the reflective trust-region method (empty: none)
   std::vector<double> lb, ub;
   // parameters the residual is linear in (empty: none): variable projection (api.hip iterate_varpro)
@@ -146,6 +152,12 @@ struct Scope {  // HIP-event bracket for one phase
 };
 
 // ---- device-side building blocks (api.hip) ----------------------------------------------------
+// sum count doubles over the ranks of a sharded fit, in place (RCCL communicator or the hook)
+int do_reduce(lsqamd_fit *f, double *buf, int64_t count);
+// (J^T J)^-1 and log det J^T J at the current point: normal equations (api.hip) / CholeskyQR (qr.hip)
+int do_covariance(lsqamd_fit *f);
+int do_covariance_qr(lsqamd_fit *f);
+size_t qr_work_bytes(const lsqamd_fit *f);
 // whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return; counts one nfev
 int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out);
 // J, A = J^T J (+ prior), g, chi2, column norms at device parameters p (all-reduced); counts one njev

@@ -22,6 +22,7 @@ from .models import MODEL_IDENTITY, MODEL_TAPE, Model
 from .whiten import Whitening
 
 _SCALERS = dict(more=0, levenberg=1, marquardt=2)
+_SOLVERS = dict(cholesky=0, qr=1, svd=1)                               # _gsl.pyx:646-653; svd -> the QR-grade route
 _ALGS = dict(lm=0, lmaccel=1, dogleg=2, ddogleg=3, subspace2D=4)      # _gsl.pyx:622-635
 _BOUNDED = dict(trf=5, dogbox=6, minpack_lm=7)                        # LSQAMD_TRS_TRF, _DOGBOX, _MINPACK_LM
 
@@ -241,14 +242,23 @@ class DeviceProblem:
                 return v
         raise ValueError('pointer outside the workspace')
 
-    def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', avmax=0.75):
+    def set_options(self, tol, maxit, scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', avmax=0.75,
+                    solver='cholesky'):
         xtol, gtol, ftol = normalize_tol(tol)
+        if solver not in _SOLVERS:
+            raise ValueError('unkown solver ' + str(solver))           # _gsl.pyx:652-653
+        if _SOLVERS[solver] == 1 and getattr(self, '_qr_work', None) is None:
+            import torch                                                # scratch of the QR-grade covariance
+            nbytes = self.lib.lsqamd_qr_work_bytes(self.h)
+            self._qr_work = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            _check(self.lib, self.h, self.lib.lsqamd_set_qr_work(self.h, C.c_void_p(self._qr_work.data_ptr()), nbytes),
+                   'set_qr_work')
         if scaler not in _SCALERS:
             raise ValueError('unkown scaler ' + str(scaler))
         if alg not in _BOUNDED and alg not in _ALGS:
             raise ValueError('unkown algorithm ' + str(alg))          # _gsl.pyx:634-635
         opt = _lib.Options(xtol=xtol, gtol=gtol, ftol=ftol, maxit=int(maxit), scaler=_SCALERS[scaler],
-                           solver=0, trs=_BOUNDED[alg] if alg in _BOUNDED else _ALGS[alg], factor_up=factor_up,
+                           solver=_SOLVERS[solver], trs=_BOUNDED[alg] if alg in _BOUNDED else _ALGS[alg], factor_up=factor_up,
                            factor_down=factor_down, avmax=avmax)
         _check(self.lib, self.h, self.lib.lsqamd_set_options(self.h, C.byref(opt)), 'set_options')
 
@@ -275,6 +285,13 @@ class DeviceProblem:
         if rc == -1:
             raise ValueError(self.lib.lsqamd_last_error(self.h).decode() or 'set_linear: bad index')
         _check(self.lib, self.h, rc, 'set_linear')
+
+    def qr_info(self):
+        """(orthogonalisation passes, max |Q^T Q - I| before the last factor) of the last
+        QR-grade covariance."""
+        n, d = C.c_int32(), C.c_double()
+        self.lib.lsqamd_qr_info(self.h, C.byref(n), C.byref(d))
+        return n.value, d.value
 
     def timing(self, on=True):
         self.lib.lsqamd_timing_enable(self.h, int(on))
@@ -421,7 +438,10 @@ class mi355x_lm(object):
 
     Args mirror :class:`lsqfit.gsl_multifit` (src/lsqfit/_gsl.pyx:563-575):
     ``x0, n, f, tol, maxit, alg, solver, scaler, factor_up, factor_down, avmax``
-    plus ``problem`` (a :class:`DeviceProblem`).  Attributes: ``x cov f J nit
+    plus ``problem`` (a :class:`DeviceProblem`).  ``solver``: ``'cholesky'`` (default here: damped
+    normal equations throughout) or ``'qr'`` (the reference's default; ``'svd'`` is taken as
+    ``'qr'``): same LM steps, the covariance and ``logdet_jtj`` from a CholeskyQR factorisation of
+    the whitened Jacobian -- accurate to cond(J) eps instead of cond(J)^2 eps (qr.hip).  Attributes: ``x cov f J nit
     tol stopping_criterion error description results`` (+ ``chi2``,
     ``logdet_jtj``, ``summary``).  ``f`` and ``J`` are fetched from the device on
     first access (J is n x P float64 -- 2.3 GB at the north-star shape).
@@ -434,9 +454,8 @@ class mi355x_lm(object):
                              "given as a device model, the Python callable cannot run on the GPU")
         if alg not in _ALGS:
             raise ValueError('unkown algorithm ' + str(alg))            # _gsl.pyx:634-635
-        if solver != 'cholesky':
-            raise NotImplementedError("mi355x_lm solves the normal equations (solver='cholesky'); "
-                                      "got %r" % (solver,))
+        if solver not in _SOLVERS:
+            raise ValueError('unkown solver ' + str(solver))            # _gsl.pyx:652-653
         self.tol = normalize_tol(tol)
         self.maxit = maxit
         self.alg, self.solver, self.scaler = alg, solver, scaler
@@ -453,7 +472,7 @@ class mi355x_lm(object):
         nf_total = pr.wh.nchiv
         if n is not None and int(n) != nf_total:
             raise ValueError('n = %d but the whitened residual has %d entries' % (n, nf_total))
-        pr.set_options(self.tol, maxit, scaler, factor_up, factor_down, alg=alg, avmax=avmax)
+        pr.set_options(self.tol, maxit, scaler, factor_up, factor_down, alg=alg, avmax=avmax, solver=solver)
         lib = pr.lib
         s = _lib.Summary()
         rc = lib.lsqamd_run(pr.h, _lib.dptr(self.x0), C.byref(s))

@@ -26,7 +26,7 @@ def _free_port():
 
 def _problem(case):
     from lsqfit_amd import synth
-    if case in ('blocks', 'trf', 'varpro'):
+    if case in ('blocks', 'trf', 'varpro', 'qr'):
         return synth.make_cosmix(N=1536, P=128, seed=91, block=256, prior_corr=True)
     return synth.make_cosmix(N=1000, P=30, seed=92, block=0, prior_corr=False)
 
@@ -39,6 +39,8 @@ def _fit_kw(case, P):
         return dict(fitter='mi355x_trf', bounds=(lo, hi), tol=(1e-10, 1e-10, 1e-10))
     if case == 'varpro':     # variable projection of the amplitudes on the shards
         return dict(linear=np.arange(P // 2), tol=1e-10)
+    if case == 'qr':         # QR-grade covariance: every Gram matrix of the orthogonalisation is all-reduced
+        return dict(solver='qr')
     return dict(alg=('lm' if case == 'blocks' else 'dogleg'))
 
 
@@ -67,7 +69,7 @@ def _worker(rank, world, port, outdir, case):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('case,world', [('blocks', 2), ('blocks', 3), ('diag', 2), ('trf', 2), ('varpro', 2)])
+@pytest.mark.parametrize('case,world', [('blocks', 2), ('blocks', 3), ('diag', 2), ('trf', 2), ('varpro', 2), ('qr', 2)])
 def test_sharded_device_fit(case, world, tmp_path):
     import torch.multiprocessing as mp
     import lsqfit_amd as amd

@@ -1,0 +1,73 @@
+"""-m gpu: solver='qr' on the device (qr.hip): the post-fit covariance and log det J^T J from a
+column-equilibrated CholeskyQR factorisation of the whitened Jacobian, against the oracle's QR route
+(the reference's default solver, src/lsqfit/_gsl.pyx:571,646-647) -- on problems where the normal
+equations lose the covariance, and on ordinary ones where both routes must agree.  (Sharded: tests/test_gpu_dist2.py[qr-2].)"""
+import numpy as np
+import pytest
+
+from oracle import fit as ofit
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+@pytest.mark.parametrize('shape', [dict(N=512, P=32, block=64, prior_corr=True),       # blocks + dense prior
+                                   dict(N=300, P=16, block=0, prior_corr=False),        # diagonal everything
+                                   dict(N=1024, P=256, block=128, prior_corr=True),     # tile-aligned (interior kernels)
+                                   dict(N=200, P=130, block=100, prior_corr=False)])    # ragged tiles
+def test_qr_route_equals_cholesky_route_on_well_conditioned_fits(amd, shape):
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(seed=17, **shape)
+    kw = dict(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    a = amd.nonlinear_fit(solver='cholesky', **kw)
+    b = amd.nonlinear_fit(solver='qr', **kw)
+    assert np.array_equal(a.pmean, b.pmean) and a.chi2 == b.chi2 and a.nit == b.nit     # same LM steps
+    assert gu.relmax(b.cov, a.cov) < 1e-9
+    assert b.logGBF == pytest.approx(a.logGBF, rel=1e-11, abs=1e-8)
+    assert b.description == 'methods = lm/more/qr' and b.problem.qr_info()[0] == 2
+    ref = gu.oracle_fit(d, solver='qr')
+    assert gu.relmax(b.pmean, ref.pmean) < 1e-6 and gu.relmax(b.cov, ref.cov) < 1e-6
+    assert b.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    assert np.array_equal(b.cov, b.cov.T)
+
+
+def hilbert_like(P):
+    """polynomial fit in the monomial basis on [0, 1]: cond(J) grows like 10^(1.5 P)"""
+    x = np.linspace(0.0, 1.0, 4 * P)
+    return x, ' + '.join(['c0'] + ['c%d*x**%d' % (n, n) for n in range(1, P)]), x[:, None] ** np.arange(P)[None, :]
+
+
+@pytest.mark.parametrize('P,prior', [(6, False), (7, True), (8, False)])
+def test_ill_conditioned_covariance(amd, P, prior):
+    """cond(J) ~ 1e6 ... 1e9 after column scaling: cond^2 eps is 1e-4 ... O(1) for the normal
+    equations; the QR-grade route must hold 1e-6 against the oracle's Householder QR."""
+    x, text, V = hilbert_like(P)
+    rng = np.random.default_rng(P)
+    truth = rng.standard_normal(P)
+    ysd = np.full(x.size, 1e-3)
+    y = V @ truth + ysd * rng.standard_normal(x.size)
+    model = amd.expr(text, ['c%d' % n for n in range(P)])
+    pri = (np.zeros(P), np.full(P, 1e6)) if prior else None
+    kw = dict(prior=pri) if prior else dict(p0=np.zeros(P))
+    fit = amd.nonlinear_fit(data=(x, y, ysd), model=model, solver='qr', tol=1e-12, **kw)
+    chol = amd.nonlinear_fit(data=(x, y, ysd), model=model, solver='cholesky', tol=1e-12, **kw)
+    ref = ofit.nonlinear_fit(x, y, ysd, lambda xx, p: V @ p, jac=lambda xx, p: V, solver='qr', tol=1e-12,
+                             prior_mean=pri[0] if prior else None, prior_err=pri[1] if prior else None,
+                             p0=None if prior else np.zeros(P))
+    Jw = V / ysd[:, None]
+    cond = np.linalg.cond(Jw / np.linalg.norm(Jw, axis=0))
+    err_qr, err_ch = gu.relmax(fit.cov, ref.cov), gu.relmax(chol.cov, ref.cov)
+    print('P = %d: cond(J D) = %.1e, cov error qr route %.1e, normal equations %.1e, passes %d'
+          % (P, cond, err_qr, err_ch, fit.problem.qr_info()[0]))
+    assert err_qr < 1e-6
+    assert np.max(np.abs(fit.pmean - ref.pmean) / ref.psdev) < 1e-5
+    if prior:
+        assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-9, abs=1e-6)
