@@ -233,7 +233,8 @@ class DeviceProblem:
         hit = cache.get((int(dev_ptr), int(count)))      # the same two regions recur every LM step
         if hit is not None:
             return hit
-        for t in [self.workspace] + list(getattr(self, '_aux_tensors', [])):
+        for t in [self.workspace] + list(getattr(self, '_aux_tensors', [])) + \
+                [w for w in [getattr(self, '_qr_work', None)] if w is not None]:
             base = t.data_ptr()
             if base <= int(dev_ptr) and int(dev_ptr) + 8 * int(count) <= base + t.numel():
                 v = WorkspaceView(t)(dev_ptr, count)
