@@ -545,6 +545,61 @@ constexpr int LDS_PY = PN + 16;   // 80 (widest variant)
 constexpr int STAGE_P = BK * (LDS_PX + LDS_PY);
 constexpr size_t GEMM_LDS_BYTES_P = 2 * STAGE_P * sizeof(double);
 
+// ---- one-shot row panel -----------------------------------------------------------------------
+// The Cholesky row panel U[k, k+1:] = inv(U_kk)^T A[k, k+1:] at full tile size (M = K = 128, X upper
+// triangular, in place) is latency, not work: 36 MFMAs per wave behind EIGHT dependent K stages of
+// the kernel above (9.4 us at P = 4096, 35 launches per factorisation).  Here the whole inverse
+// block (128 KiB, the same for every workgroup: L2 hits) and the workgroup's 16 operand columns go
+// to LDS with ALL loads in flight at once -- one memory round trip -- then the MFMAs, balanced over
+// the waves (16-row blocks i and 7 - i need 4 (i + 1) and 4 (8 - i) k-chunks of the triangle).
+constexpr int OS_LDX = 136, OS_PN = 16;
+constexpr size_t GEMM_LDS_BYTES_OS = (size_t)(128 * OS_LDX + 128 * OS_PN) * sizeof(double);
+
+__global__ __launch_bounds__(256) void gemm_tn_f64_panel_oneshot_kernel(GemmDev g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t b = blockIdx.z;
+  if (g.batch_active && !g.batch_active[b]) return;
+  const double *X = g.X + b * g.sx;
+  const int64_t n0 = (int64_t)blockIdx.x * OS_PN;
+  double *Yg = g.C + b * g.sc + n0;              // C aliases Y
+  double *Xs = smem, *Ys = smem + 128 * OS_LDX;
+  // X: row k = 1 KiB = one wave-instruction (lane -> 2 doubles); 32 rows per wave
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {
+    const int k = wave * 32 + i;
+    __builtin_amdgcn_global_load_lds((glb_void *)(X + (int64_t)k * g.ldx + 2 * lane), (lds_void *)(Xs + k * OS_LDX), 16, 0, 0);
+  }
+  // Y: 8 rows of 16 doubles per wave-instruction (lane -> row lane / 8, doubles 2 (lane % 8) ..)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k8 = (wave * 4 + i) * 8;
+    __builtin_amdgcn_global_load_lds((glb_void *)(Yg + (int64_t)(k8 + (lane >> 3)) * g.ldc + 2 * (lane & 7)),
+                                     (lds_void *)(Ys + k8 * OS_PN), 16, 0, 0);
+  }
+  __syncthreads();   // (s_waitcnt vmcnt(0) is part of it)
+  const int col = lane & 15, q = lane >> 4;
+  const int i0 = wave, i1 = 7 - wave;            // this wave's two 16-row blocks of the output
+  v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+  const int n0c = 4 * (i0 + 1), n1c = 4 * (i1 + 1);
+  for (int kc = 0; kc < n1c; ++kc) {
+    const double bb = Ys[(4 * kc + q) * OS_PN + col];
+    const double a1 = Xs[(4 * kc + q) * OS_LDX + 16 * i1 + col];
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bb, acc1, 0, 0, 0);
+    if (kc < n0c) {
+      const double a0 = Xs[(4 * kc + q) * OS_LDX + 16 * i0 + col];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bb, acc0, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    Yg[(int64_t)(16 * i0 + 4 * r + q) * g.ldc + col] = acc0[r];
+    Yg[(int64_t)(16 * i1 + 4 * r + q) * g.ldc + col] = acc1[r];
+  }
+}
+
 template <bool VEC, int PNW>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
   constexpr int WN = PNW >= 32 ? 2 : 1, WM = 4 / WN;       // waves along n / m
@@ -761,6 +816,19 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
     // are a few hundred workgroups (LSQAMD_PANEL_PN forces 64 / 32 / 16: developer knob)
     static const int force_pn = [] { const char *e = getenv("LSQAMD_PANEL_PN"); return e ? atoi(e) : 0; }();
     const int64_t nb_ = a.batch < 1 ? 1 : a.batch;
+    if (force_pn == 0 && a.M == BM && a.K == BM && a.N % OS_PN == 0 && a.x_upper_tri && g.vec_x && g.vec_y &&
+        a.alpha == 1.0 && a.beta == 0.0 && a.ldx >= BM) {
+      static bool attr = false;
+      if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_panel_oneshot_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES_OS);
+        if (e != hipSuccess) return e;
+        attr = true;
+      }
+      dim3 grido((unsigned)(a.N / OS_PN), 1, (unsigned)nb_);
+      hipLaunchKernelGGL(gemm_tn_f64_panel_oneshot_kernel, grido, dim3(256), GEMM_LDS_BYTES_OS, st, g);
+      return hipGetLastError();
+    }
     int pn = (a.N * nb_ >= 200 * 64) ? 64 : ((a.N * nb_ >= 200 * 32) ? 32 : 16);
     if (force_pn == 64 || force_pn == 32 || force_pn == 16) pn = force_pn;
     g.tiles_n = (int32_t)((a.N + pn - 1) / pn);

@@ -6,6 +6,8 @@
 // -mllvm -amdgpu-mfma-vgpr-form (see build.py): with the whole tile file in
 // architectural VGPRs the sweep is straight-line MFMA code; hipcc's default
 // heuristic parks the tiles in AccVGPRs and spends 10k v_accvgpr_read/_mov on them.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lsqamd {
@@ -28,6 +30,16 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   y = __builtin_fma(y, e, y);
   e = __builtin_fma(h * y, y, 0.5);
   return __builtin_fma(y, e, y);
+}
+
+// The same to full precision with a shorter dependent chain (4 operations after v_rsq_f64 instead
+// of 6): with e = 1 - d y0^2,  1/sqrt(d) = y0 (1 - e)^-1/2 = y0 (1 + e/2 + 3 e^2/8 + O(e^3)); the
+// hardware estimate is good to ~2^-23, so the cubic term is below 2^-66.
+__device__ __forceinline__ double rsqrt_cubic(double d) {
+  const double y0 = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-(d * y0), y0, 1.0);
+  const double p = __builtin_fma(0.375, e, 0.5);
+  return __builtin_fma(y0 * e, p, y0);
 }
 
 // ---- diagonal-block kernel, matrix-core formulation -------------------------------------------
@@ -201,13 +213,12 @@ struct SlabLoop<32, W> {
 // One wave's whole job with its tile columns known at compile time: every ownership test
 // folds away, the sweep is straight-line code (the four variants execute the same sequence
 // of workgroup barriers).
+// ---- [A | I] in accumulator layout: load / store of one wave's tile columns ----------------------
 template <int W>
-__device__ __forceinline__ void potf2_wave(double *A, int64_t lda, int nb, double *uinv, int32_t *info,
-                                           int32_t k0, double *mop, double *slabA, int lane) {
+__device__ __forceinline__ void load_tiles(TileRegs &T, const double *A, int64_t lda, int nb, int lane) {
   constexpr int wave = W;
   const int col = lane & 15, q = lane >> 4;
-  TileRegs T;
-  // ---- load [A | I] in accumulator layout; outside the nb x nb block: identity
+  // outside the nb x nb block: identity
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int tj = wave + 4 * c;
@@ -231,8 +242,13 @@ __device__ __forceinline__ void potf2_wave(double *A, int64_t lda, int nb, doubl
       }
     }
   }
-  SlabLoop<0, W>::run(T, mop, slabA, info, k0, nb, lane);
-  // ---- store U (upper triangle of the block) and inv(U) = (U^-T)^T (whole 128 x 128 tile)
+}
+
+// U (upper triangle of the block) and inv(U) = (U^-T)^T (whole 128 x 128 tile)
+template <int W>
+__device__ __forceinline__ void store_tiles(const TileRegs &T, double *A, int64_t lda, int nb, double *uinv, int lane) {
+  constexpr int wave = W;
+  const int col = lane & 15, q = lane >> 4;
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     const int tj = wave + 4 * c;
@@ -255,6 +271,297 @@ __device__ __forceinline__ void potf2_wave(double *A, int64_t lda, int nb, doubl
       }
     }
   }
+}
+
+// One wave's whole job with its tile columns known at compile time: every ownership test
+// folds away, the sweep is straight-line code (the four variants execute the same sequence
+// of workgroup barriers).
+template <int W>
+__device__ __forceinline__ void potf2_wave(double *A, int64_t lda, int nb, double *uinv, int32_t *info,
+                                           int32_t k0, double *mop, double *slabA, int lane) {
+  TileRegs T;
+  load_tiles<W>(T, A, lda, nb, lane);
+  SlabLoop<0, W>::run(T, mop, slabA, info, k0, nb, lane);
+  store_tiles<W>(T, A, lda, nb, uinv, lane);
+}
+
+// ================================================================================================
+// Second formulation (default): 16-row slabs.
+//
+// The 4-row sweep above costs two workgroup barriers and one dependent scale -> update MFMA pair per
+// FOUR rows in every tile.  Here the owner of the diagonal tile factors the whole 16 x 16 leaf
+// [D | I] -> [U | W = U^-T] by itself (four rounds of: pivot chain in registers, 2 scaling MFMAs, 2
+// update MFMAs -- no LDS, no barrier), publishes U and W, and the tile waves work in 16-row slabs:
+//   scale    tile <- W x tile: 4 MFMAs with K = 16 (register j of a tile in accumulator layout IS
+//            the k-chunk j operand), independent of each other across tiles;
+//   update   tile(tr, tj) -= S(TI, tr)^T S(TI, tj): 4 MFMAs per tile, A operands = the negated
+//            scaled slab tiles from LDS;
+// the same MFMA count as 32 rank-4 steps, a quarter of the barriers, and the final store of inv(U)
+// goes out in whole 128-byte segments.  Measured (s_memtime, 128 x 128 block): 79 k -> 62 k cycles,
+// of which 33 k are the eight leaves -- a chain of 128 dependent pivots at ~260 cycles each (fp64
+// MFMA and fp64 VALU share the DP datapath: a fifth wave that does nothing but pivots, with
+// look-ahead, was built and measured and bought nothing -- whatever shares its SIMD slows down by
+// what the leaf gains).
+constexpr int LW = 17;  // LDS leading dimension of the 16 x 16 leaf buffers
+
+struct LeafShared {
+  double Ul[16 * LW];         // leaf factor U (upper), row-major
+  double Wl[16 * LW];         // leaf W = U^-T (lower), row-major
+  double slabA[8 * 4 * 64];   // negated scaled slab tiles (TI, tr), register j, lane: A operands of the update
+  double stage[4][16 * LW];   // per wave: transposition buffer of the final store
+#ifdef LSQAMD_POTF2_TIMING
+  long long stamps[64];
+#endif
+};
+
+#ifdef LSQAMD_POTF2_TIMING
+// stamps go to LDS and are dumped at the end: a global store in front of a barrier would make the
+// barrier's s_waitcnt vmcnt(0) wait a microsecond for it
+#define V3STAMP(i) do { if (dbg && (lane == 0)) sh.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define V3STAMP(i) do { } while (0)
+#endif
+
+// 4 x 4 pivot block as in pivot4 above, tuned for the leaf: the operand stays in a register, the
+// positivity test is off the dependent chain (the pivot is clamped with one v_max_f64; a
+// non-positive one is recorded and makes the results meaningless, as the caller knows from info).
+template <int R>
+__device__ __forceinline__ double pivot4_reg(double reg, int &bad, int lane) {
+  const double d00 = readlane_d(reg, 0 * 16 + 4 * R + 0), d01 = readlane_d(reg, 0 * 16 + 4 * R + 1);
+  const double d02 = readlane_d(reg, 0 * 16 + 4 * R + 2), d03 = readlane_d(reg, 0 * 16 + 4 * R + 3);
+  const double d11 = readlane_d(reg, 1 * 16 + 4 * R + 1), d12 = readlane_d(reg, 1 * 16 + 4 * R + 2);
+  const double d13 = readlane_d(reg, 1 * 16 + 4 * R + 3), d22 = readlane_d(reg, 2 * 16 + 4 * R + 2);
+  const double d23 = readlane_d(reg, 2 * 16 + 4 * R + 3), d33 = readlane_d(reg, 3 * 16 + 4 * R + 3);
+  constexpr double TINY = 1.0e-300;
+  const double y0 = rsqrt_cubic(__builtin_fmax(d00, TINY));
+  const double u01 = d01 * y0, u02 = d02 * y0, u03 = d03 * y0;
+  const double t11 = __builtin_fma(-u01, u01, d11);
+  const double y1 = rsqrt_cubic(__builtin_fmax(t11, TINY));
+  const double u12 = __builtin_fma(-u01, u02, d12) * y1, u13 = __builtin_fma(-u01, u03, d13) * y1;
+  const double t22 = __builtin_fma(-u12, u12, __builtin_fma(-u02, u02, d22));
+  const double y2 = rsqrt_cubic(__builtin_fmax(t22, TINY));
+  const double u23 = __builtin_fma(-u12, u13, __builtin_fma(-u02, u03, d23)) * y2;
+  const double t33 = __builtin_fma(-u23, u23, __builtin_fma(-u13, u13, __builtin_fma(-u03, u03, d33)));
+  const double y3 = rsqrt_cubic(__builtin_fmax(t33, TINY));
+  const bool ok0 = (d00 > 0.0) && (d00 < 1.0e300), ok1 = (t11 > 0.0) && (t11 < 1.0e300);
+  const bool ok2 = (t22 > 0.0) && (t22 < 1.0e300), ok3 = (t33 > 0.0) && (t33 < 1.0e300);
+  const int b = !ok0 ? 0 : (!ok1 ? 1 : (!ok2 ? 2 : (!ok3 ? 3 : -1)));
+  bad = (bad < 0 && b >= 0) ? 4 * R + b : bad;
+  const double v01 = -y0 * (u01 * y1);
+  const double v12 = -y1 * (u12 * y2);
+  const double v23 = -y2 * (u23 * y3);
+  const double v02 = -y0 * __builtin_fma(u01, v12, u02 * y2);
+  const double v13 = -y1 * __builtin_fma(u12, v23, u13 * y3);
+  const double v03 = -y0 * __builtin_fma(u01, v13, __builtin_fma(u02, v23, u03 * y3));
+  const int col = lane & 15, q = lane >> 4;
+  const double r0 = col == 0 ? y0 : (col == 1 ? v01 : (col == 2 ? v02 : v03));
+  const double r1 = col == 1 ? y1 : (col == 2 ? v12 : v13);
+  const double r2 = col == 2 ? y2 : v23;
+  const double m = q == 0 ? r0 : (q == 1 ? r1 : (q == 2 ? r2 : y3));
+  return (col < 4 && q <= col) ? m : 0.0;
+}
+
+template <int R>
+__device__ __forceinline__ void leaf_slab(v4d &DA, v4d &DE, int &bad, int lane) {
+  const int col = lane & 15;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  const double mo = pivot4_reg<R>(DA[R], bad, lane);
+  const v4d ta = mfma4(mo, DA[R], zero);
+  const v4d te = mfma4(mo, DE[R], zero);
+  DA[R] = ta[0];
+  DE[R] = te[0];
+  if constexpr (R < 3) {
+    const double a = (col > 4 * R + 3) ? -ta[0] : 0.0;   // rows at and above the slab stay untouched
+    DA = mfma4(a, DA[R], DA);
+    DE = mfma4(a, DE[R], DE);
+  }
+}
+
+// 16 x 16 leaf [D | I] -> [U | U^-T] in place in the owner's registers (accumulator layout), then
+// published row-major for the other waves
+__device__ __forceinline__ void leaf16(v4d &DA, v4d &DE, LeafShared &sh, int32_t *info, int32_t row0, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+  int bad = -1;
+  leaf_slab<0>(DA, DE, bad, lane);
+  leaf_slab<1>(DA, DE, bad, lane);
+  leaf_slab<2>(DA, DE, bad, lane);
+  leaf_slab<3>(DA, DE, bad, lane);
+  if (bad >= 0 && lane == 0) atomicCAS(info, 0, row0 + bad + 1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    DA[r] = (col >= 4 * r + q) ? DA[r] : 0.0;
+    DE[r] = (col <= 4 * r + q) ? DE[r] : 0.0;
+    sh.Ul[(4 * r + q) * LW + col] = DA[r];
+    sh.Wl[(4 * r + q) * LW + col] = DE[r];
+  }
+}
+
+__device__ __forceinline__ v4d mfma4x4(const double (&a)[4], v4d b, v4d c) {
+  c = mfma4(a[0], b[0], c);
+  c = mfma4(a[1], b[1], c);
+  c = mfma4(a[2], b[2], c);
+  return mfma4(a[3], b[3], c);
+}
+
+// rank-16 update of ONE tile (TR, tj = W + 4 C) with slab TI; no-op when the tile is not live
+template <int TI, int W, int TR, int C>
+__device__ __forceinline__ void upd16_tile(TileRegs &T, const LeafShared &sh, int lane) {
+  constexpr int tj = W + 4 * C;
+  constexpr bool live = (TR < tj) || (TR == tj) || (tj <= TI);   // A part, diagonal slot, E part
+  if constexpr (live) {
+    double a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] = sh.slabA[(TR * 4 + j) * 64 + lane];
+    if constexpr (TR < tj) T.X[C][TR] = mfma4x4(a, T.X[C][TI], T.X[C][TR]);
+    else if constexpr (TR == tj) T.DA[C] = mfma4x4(a, T.X[C][TI], T.DA[C]);
+    else if constexpr (tj < TI) T.X[C][TR] = mfma4x4(a, T.X[C][TI], T.X[C][TR]);
+    else T.X[C][TR] = mfma4x4(a, T.DE[C], T.X[C][TR]);           // tj == TI: the slab piece is W itself
+  }
+}
+
+template <int TI, int W, int TR, int C, int SKIP_TR, int SKIP_C>
+__device__ __forceinline__ void upd16_rest(TileRegs &T, const LeafShared &sh, int lane) {
+  if constexpr (TR <= 7) {
+    if constexpr (!(TR == SKIP_TR && C == SKIP_C)) upd16_tile<TI, W, TR, C>(T, sh, lane);
+    if constexpr (C == 0) upd16_rest<TI, W, TR, 1, SKIP_TR, SKIP_C>(T, sh, lane);
+    else upd16_rest<TI, W, TR + 1, 0, SKIP_TR, SKIP_C>(T, sh, lane);
+  }
+}
+
+template <int TI, int W>
+__device__ __forceinline__ void slab16_step(TileRegs &T, LeafShared &sh, int32_t *info, int32_t k0, int lane,
+                                            long long *dbg) {
+  const int col = lane & 15, q = lane >> 4;
+  if constexpr (TI % 4 == W) {
+    V3STAMP(3 * TI);
+    leaf16(T.DA[TI / 4], T.DE[TI / 4], sh, info, k0 + 16 * TI, lane);
+    V3STAMP(3 * TI + 1);
+  }
+  __syncthreads();   // B1: U, W of leaf TI are in LDS; every wave is done reading slab TI - 1
+  double wop[4];     // A operand of the scaling: W[m][k], m = lane & 15, k = 4 j + (lane >> 4)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wop[j] = sh.Wl[col * LW + 4 * j + q];
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tj = W + 4 * c;
+    if (tj != TI) {
+      const v4d t = mfma4x4(wop, T.X[c][TI], zero);
+      T.X[c][TI] = t;
+      if (tj > TI) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sh.slabA[(tj * 4 + j) * 64 + lane] = -t[j];
+      }
+    }
+  }
+  if constexpr (W == 0) V3STAMP(32 + 3 * TI);
+  __syncthreads();   // B2: the scaled slab row is published
+  if constexpr (W == 0) V3STAMP(33 + 3 * TI);
+  if constexpr (TI < 7) {
+    // the next diagonal tile first: its owner goes from these MFMAs straight into the next leaf
+    constexpr int NT = TI + 1, NW = NT % 4, NC = NT / 4;
+    if constexpr (NW == W) {
+      upd16_tile<TI, W, NT, NC>(T, sh, lane);
+      upd16_rest<TI, W, TI + 1, 0, NT, NC>(T, sh, lane);
+    } else {
+      upd16_rest<TI, W, TI + 1, 0, -1, -1>(T, sh, lane);
+    }
+  }
+  if constexpr (W == 0) V3STAMP(34 + 3 * TI);
+}
+
+template <int TI, int W>
+struct Slab16Loop {
+  static __device__ __forceinline__ void run(TileRegs &T, LeafShared &sh, int32_t *info, int32_t k0, int nb, int lane,
+                                             long long *dbg) {
+    if (16 * TI >= nb) return;  // identity padding: nothing left to eliminate (uniform)
+    slab16_step<TI, W>(T, sh, info, k0, lane, dbg);
+    Slab16Loop<TI + 1, W>::run(T, sh, info, k0, nb, lane, dbg);
+  }
+};
+template <int W>
+struct Slab16Loop<8, W> {
+  static __device__ __forceinline__ void run(TileRegs &, LeafShared &, int32_t *, int32_t, int, int, long long *) {}
+};
+
+// Final store of the 16-slab kernel.  U as in store_tiles; inv(U)[gc][gr] = E(gr, gc) goes through a
+// per-wave LDS tile so that every store instruction writes whole 128-byte row segments (lane ->
+// row gc = 16 tj + lane / 4, four consecutive gr) instead of 64 scattered doubles a kilobyte apart:
+// the scattered form cost 16 k cycles, a fifth of the kernel.
+template <int W>
+__device__ __forceinline__ void store_tiles_v3(const TileRegs &T, double *A, int64_t lda, int nb, double *uinv,
+                                               double *stage, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+  const int jj = lane >> 2, i4 = 4 * (lane & 3);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const int tj = W + 4 * c;
+    const int gc = 16 * tj + col;
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) {
+      if (ti <= tj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gr = 16 * ti + 4 * r + q;
+          const double u = (ti < tj) ? T.X[c][ti][r] : T.DA[c][r];
+          if (gr < nb && gc < nb && gc >= gr) A[(int64_t)gr * lda + gc] = u;
+        }
+      }
+      v4d w4 = {0.0, 0.0, 0.0, 0.0};
+      if (ti >= tj) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(4 * r + q) * LW + col] = (ti > tj) ? T.X[c][ti][r] : T.DE[c][r];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w4[t] = stage[(i4 + t) * LW + jj];
+      }
+      const int gcw = 16 * tj + jj;                    // uinv row this lane writes
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int gr = 16 * ti + i4 + t;
+        w4[t] = (gr >= gcw && gr < nb && gcw < nb) ? w4[t] : 0.0;
+      }
+      if (gcw < nb) *reinterpret_cast<v4d *>(uinv + gcw * NB + 16 * ti + i4) = w4;
+    }
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void potf2v3_wave(double *A, int64_t lda, int nb, double *uinv, int32_t *info, int32_t k0,
+                                             LeafShared &sh, int lane, long long *dbg) {
+  TileRegs T;
+  if constexpr (W == 0) V3STAMP(60);
+  load_tiles<W>(T, A, lda, nb, lane);
+  if constexpr (W == 0) V3STAMP(61);
+  Slab16Loop<0, W>::run(T, sh, info, k0, nb, lane, dbg);
+  if constexpr (W == 0) V3STAMP(62);
+  store_tiles_v3<W>(T, A, lda, nb, uinv, sh.stage[W], lane);
+  if constexpr (W == 0) V3STAMP(63);
+}
+
+// the whole job of a 4-wave workgroup (all 256 threads call it)
+__device__ __forceinline__ void potf2v3_run(double *A, int64_t lda, int nb, double *uinv, int32_t *info, int32_t k0,
+                                            LeafShared &sh, int tid, long long *dbg = nullptr) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave == 0) potf2v3_wave<0>(A, lda, nb, uinv, info, k0, sh, lane, dbg);
+  else if (wave == 1) potf2v3_wave<1>(A, lda, nb, uinv, info, k0, sh, lane, dbg);
+  else if (wave == 2) potf2v3_wave<2>(A, lda, nb, uinv, info, k0, sh, lane, dbg);
+  else potf2v3_wave<3>(A, lda, nb, uinv, info, k0, sh, lane, dbg);
+}
+
+__global__ __launch_bounds__(256) void potf2_v3_kernel(double *A, int64_t lda, int nb, double *uinv, int32_t *info,
+                                                       int32_t k0, int64_t strideA, int64_t strideW,
+                                                       const int32_t *active, long long *dbg) {
+  __shared__ LeafShared sh;
+  if (active && !active[blockIdx.x]) return;
+  A += (int64_t)blockIdx.x * strideA;
+  uinv += (int64_t)blockIdx.x * strideW;
+  info += blockIdx.x;
+  potf2v3_run(A, lda, nb, uinv, info, k0, sh, threadIdx.x, dbg);
+#ifdef LSQAMD_POTF2_TIMING
+  __syncthreads();
+  if (dbg && threadIdx.x < 64) dbg[threadIdx.x] = sh.stamps[threadIdx.x];
+#endif
 }
 
 __global__ __launch_bounds__(256) void potf2_mfma_kernel(double *A, int64_t lda, int nb, double *uinv,
@@ -358,17 +665,63 @@ __device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, d
   }
 }
 
-__global__ __launch_bounds__(256, 2) void trail_potf2_kernel(TrailArgs t, double *Adiag, int nb, double *uinv,
-                                                             int32_t *info, int32_t k0n) {
+// The next diagonal block, updated where it is factored: workgroup 0 loads the block in the
+// accumulator layout of the 16-slab sweep (load_tiles), DMAs the 128 panel rows over its 128 columns
+// into LDS in one shot (all loads in flight at once), applies C -= P^T P to the tiles it holds --
+// upper 16 x 16 tiles only, 32 k-chunks each, operands straight from LDS -- and goes on to the
+// factorisation without the block ever returning to memory.  (Before: a full 128 x 128 x 128 tile
+// product through eight dependent DMA stages, a store and a reload: 15.6 us of MFMA alone.)
+constexpr int DLD = 128 + 16;                                  // LDS row of the one-shot panel tile
+constexpr size_t DIAG_LDS_BYTES = (size_t)128 * DLD * sizeof(double);
+
+template <int W>
+__device__ __forceinline__ void diag_update_from_panel(TileRegs &T, const double *Ps, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+  for (int kc = 0; kc < 32; ++kc) {
+    const double *row = Ps + (4 * kc + q) * DLD + col;
+    double a[8];
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti)
+      if (ti <= W + 4) a[ti] = -row[16 * ti];
+    const double b0 = row[16 * W], b1 = row[16 * (W + 4)];
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) {
+      if (ti < W) T.X[0][ti] = mfma4(a[ti], b0, T.X[0][ti]);
+      if (ti < W + 4) T.X[1][ti] = mfma4(a[ti], b1, T.X[1][ti]);
+    }
+    T.DA[0] = mfma4(a[W], b0, T.DA[0]);
+    T.DA[1] = mfma4(a[W + 4], b1, T.DA[1]);
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void fused_diag_wave(const TrailArgs &t, double *Adiag, int nb, double *uinv, int32_t *info,
+                                                int32_t k0n, double *smem, int lane) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  // panel rows k = 32 W .. 32 W + 31, columns of the next block: 1 KiB each
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {
+    const int k = W * 32 + i;
+    __builtin_amdgcn_global_load_lds((glb_void *)(t.P + (int64_t)k * t.lda + 2 * lane), (lds_void *)(smem + k * DLD), 16, 0, 0);
+  }
+  TileRegs T;
+  load_tiles<W>(T, Adiag, t.lda, nb, lane);
+  __syncthreads();
+  diag_update_from_panel<W>(T, smem, lane);
+  __syncthreads();   // the panel tile is dead: its LDS becomes the sweep's scratch
+  LeafShared &sh = *reinterpret_cast<LeafShared *>(smem);
+  long long *dbg = nullptr;
+  Slab16Loop<0, W>::run(T, sh, info, k0n, nb, lane, dbg);
+  store_tiles_v3<W>(T, Adiag, t.lda, nb, uinv, sh.stage[W], lane);
+}
+
+__global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *Adiag, int nb, double *uinv,
+                                                          int32_t *info, int32_t k0n) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ double mop[64];
-  __shared__ double slabA[8 * 64];
   const int tid = threadIdx.x, lane = tid & 63;
-  // workgroup 0: tile (0, 0) of the update -- the next diagonal block -- and then its factorisation,
-  // back to back in the same workgroup (no hand-over between workgroups, nothing to wait for);
-  // dispatched first, it works while the other CUs do the remaining tiles.  Its waves run at raised
-  // priority: the tile workgroup sharing the CU fills the stalls of the pivot chain instead of
-  // competing with it.
+  // workgroup 0: the next diagonal block (update + factorisation); dispatched first, it works while
+  // the other CUs do the remaining tiles of the update
   if (blockIdx.x > 0) {
     const int bid = (int)blockIdx.x;   // tile (0, 0) belongs to workgroup 0
     const int tm = bid / t.tiles_n, tn = bid % t.tiles_n;
@@ -376,16 +729,15 @@ __global__ __launch_bounds__(256, 2) void trail_potf2_kernel(TrailArgs t, double
     trail_tile(t, tm, tn, smem, tid);
     return;
   }
-  __builtin_amdgcn_s_setprio(3);
-  trail_tile(t, 0, 0, smem, tid);
-  __syncthreads();   // the tile is re-read below in a different thread layout
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave == 0) potf2_wave<0>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
-  else if (wave == 1) potf2_wave<1>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
-  else if (wave == 2) potf2_wave<2>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
-  else potf2_wave<3>(Adiag, t.lda, nb, uinv, info, k0n, mop, slabA, lane);
+  if (wave == 0) fused_diag_wave<0>(t, Adiag, nb, uinv, info, k0n, smem, lane);
+  else if (wave == 1) fused_diag_wave<1>(t, Adiag, nb, uinv, info, k0n, smem, lane);
+  else if (wave == 2) fused_diag_wave<2>(t, Adiag, nb, uinv, info, k0n, smem, lane);
+  else fused_diag_wave<3>(t, Adiag, nb, uinv, info, k0n, smem, lane);
 }
 
+static_assert(sizeof(LeafShared) <= DIAG_LDS_BYTES, "the sweep's scratch lives in the dead panel tile");
+constexpr size_t TRAIL_KERNEL_LDS = DIAG_LDS_BYTES > TRAIL_LDS_BYTES ? DIAG_LDS_BYTES : TRAIL_LDS_BYTES;
 static bool g_trail_attr = false;
 
 // trailing update of the step whose panel is P (128 x rest), fused with the diagonal block of the
@@ -394,7 +746,7 @@ hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_
                               int64_t rest, int nb_next, double *uinv_next, int32_t *info, int32_t k0_next) {
   if (!g_trail_attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trail_potf2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRAIL_LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRAIL_KERNEL_LDS);
     if (e != hipSuccess) return e;
     g_trail_attr = true;
   }
@@ -402,7 +754,7 @@ hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_
   t.P = P; t.C = C; t.lda = lda;
   t.tiles_m = (int32_t)(mrest / 128);
   t.tiles_n = (int32_t)(rest / 128);
-  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)(t.tiles_m * t.tiles_n)), dim3(256), TRAIL_LDS_BYTES,
+  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)(t.tiles_m * t.tiles_n)), dim3(256), TRAIL_KERNEL_LDS,
                      st, t, C, nb_next, uinv_next, info, k0_next);
   return hipGetLastError();
 }
@@ -410,8 +762,13 @@ hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_
 hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, double *uinv, int32_t *info,
                              int32_t k0, int32_t batch, int64_t strideA, int64_t strideW,
                              const int32_t *active) {
-  hipLaunchKernelGGL(potf2_mfma_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info,
-                     k0, strideA, strideW, active);
+  static const bool v2 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '2'; }();
+  if (v2)
+    hipLaunchKernelGGL(potf2_mfma_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info,
+                       k0, strideA, strideW, active);
+  else
+    hipLaunchKernelGGL(potf2_v3_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info,
+                       k0, strideA, strideW, active, g_potf2_dbg);
   return hipGetLastError();
 }
 

@@ -14,11 +14,8 @@ lib.lsqamd_op_potrf_work_bytes.argtypes = [C.c_int64]
 lib.lsqamd_op_potrf_upper.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                       C.c_size_t, C.c_void_p]
 lib.lsqamd_debug_set_potf2_stamps.argtypes = [C.c_void_p]
-stamps = torch.zeros(32, dtype=torch.int64, device='cuda')
+stamps = torch.zeros(64, dtype=torch.int64, device='cuda')
 lib.lsqamd_debug_set_potf2_stamps(stamps.data_ptr())
-NAMES = {0: 'load', 1: 'sync', 2: 'chol0', 3: 'solve0', 4: 'trail0', 5: 'chol1', 6: 'solve1', 7: 'trail1',
-         8: 'chol2', 9: 'solve2', 10: 'trail2', 11: 'chol3', 14: 'end1', 15: 'storeU', 16: 'diaginv',
-         17: 'inv_lvls', 18: 'store_inv'}
 for n in [128, 33, 96, 300]:
     rng = np.random.default_rng(n)
     G = rng.standard_normal((n + 20, n))
@@ -38,9 +35,10 @@ for n in [128, 33, 96, 300]:
         np.abs(U - Uref).max(), np.abs(w @ Uref[:nb0, :nb0] - np.eye(nb0)).max()))
     if n == 128:
         t = stamps.cpu().numpy()
-        idx = sorted(NAMES)
-        print('total ticks', t[18] - t[0])
-        prev = t[0]
-        for i in idx[1:]:
-            print('   %-10s %8d' % (NAMES[i], t[i] - prev))
-            prev = t[i]
+        t0 = t[60]
+        print('kernel: load %d | slabs %d | store %d | total %d cycles' % (t[61] - t[60], t[62] - t[61], t[63] - t[62], t[63] - t[60]))
+        for ti in range(8):
+            p0, p1 = t[3 * ti:3 * ti + 2]
+            a0, a1, a2 = t[32 + 3 * ti:35 + 3 * ti]
+            print('  slab %d  leaf start %6d  leaf %5d | wave 0: scaled @%6d  B2 @%6d  updated @%6d'
+                  % (ti, p0 - t0, p1 - p0, a0 - t0, a1 - t0, a2 - t0))
