@@ -138,6 +138,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->Wl = cv.take<double>(P * f->ldm);
   f->cov = cv.take<double>(P * f->ldm);
   f->scal = cv.take<double>(16);
+  f->lmd = cv.take<double>(LMS_COUNT);
   f->info_dev = cv.take<int32_t>(16);
   f->tape = cv.take<int32_t>(1024);
   f->consts = cv.take<double>(256);
@@ -195,8 +196,9 @@ int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
   return 0;
 }
 
-// whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return
-int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
+// whitened residual at device parameters p -> f->r; chi2 (summed over ranks) -> f->red_scalar[0].
+// Launches only: nothing is waited for.
+int eval_residual_launch(lsqamd_fit *f, const double *p) {
   {
     Scope sc(f, LSQAMD_T_RESIDUAL);
     ModelArgs m = model_args(f, p);
@@ -225,7 +227,12 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
       HIPCHK(f, launch_prior_chi2(f->st, f->P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, p,
                                   f->tvec, f->red_scalar));
   }
-  int rc = do_reduce(f, f->red_scalar, 1);
+  return do_reduce(f, f->red_scalar, 1);
+}
+
+// whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return
+int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
+  int rc = eval_residual_launch(f, p);
   if (rc) return rc;
   HIPCHK(f, hipMemcpyAsync(f->pin_s, f->red_scalar, sizeof(double), hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
@@ -313,7 +320,7 @@ int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks) {
 }
 
 // J, J^T J (packed), J^T f, chi2 at device parameters p; host g/chi2/colnorm refreshed
-int eval_normal_dev(lsqamd_fit *f, const double *p) {
+int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   const int64_t P = f->P;
   {
     Scope sc(f, LSQAMD_T_JACOBIAN);
@@ -357,6 +364,13 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
   rc = do_reduce(f, f->redbuf, f->npk + P + 1);
   if (rc) return rc;
   HIPCHK(f, launch_packed_diag(f->st, f->redbuf, P, f->diag_dev));
+  f->have_cov = false;
+  f->have_dense_A = false;
+  if (!mirror) {   // the caller keeps g, the column norms and chi2 on the device (iterate_device)
+    f->njev++;
+    f->mirrors_stale = true;
+    return 0;
+  }
   HIPCHK(f, hipMemcpyAsync(f->pin_g, gvec, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipMemcpyAsync(f->pin_c, f->diag_dev, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
@@ -377,7 +391,8 @@ int eval_normal_dev(lsqamd_fit *f, const double *p) {
 // diag_host == nullptr: D is the device-resident mirror (no host-to-device copy: on this platform
 // an SDMA upload followed by a dependent kernel costs ~100 us of cross-engine synchronisation)
 // frozen_host (with mu = 0, dogbox): flags of the parameters taken out of the system
-int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr) {
+int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr,
+                        bool fetch = true) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
   {
@@ -396,8 +411,10 @@ int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const
     Scope sc(f, LSQAMD_T_SOLVE);
     HIPCHK(f, launch_copy_strided(f->st, f->M + P, f->ldm, f->yv, 1, P, 1));
     HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
-    HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->pin_s + 4, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+    if (fetch) {
+      HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+      HIPCHK(f, hipMemcpyAsync(f->pin_s + 4, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+    }
   }
   return 0;
 }
@@ -774,8 +791,79 @@ int iterate_varpro(lsqamd_fit *f) {
   }
 }
 
+// host copies of x, g, D, the column norms and the last step after iterations that kept them on
+// the device
+int refresh_mirrors(lsqamd_fit *f) {
+  if (!f->mirrors_stale) return 0;
+  const int64_t P = f->P;
+  HIPCHK(f, hipMemcpyAsync(f->pin_x, f->p_dev, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_g, f->redbuf + f->npk, sizeof(double) * (P + 1), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_d, f->dscale, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_c, f->diag_dev, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  for (int64_t j = 0; j < P; ++j) {
+    f->hx[j] = f->pin_x[j];
+    f->hg[j] = f->pin_g[j];
+    f->hdiag[j] = f->pin_d[j];
+    f->hcoln[j] = std::sqrt(f->pin_c[j] > 0.0 ? f->pin_c[j] : 0.0);
+    f->hv[j] = f->pin_v[j];
+    f->hdx[j] = -f->pin_v[j];
+  }
+  f->mirrors_stale = false;
+  return 0;
+}
+
+// One trust_iterate of plain lm with the state on the device: per trial the host queues
+//   solve -> (trial point, v.g, |D v|^2) -> residual (+ all-reduce) -> decision (rho, mu, nu, delta)
+// and reads ONE 128-byte record; an accepted trial queues the Jacobian, the normal equations, the
+// update of D and the convergence test and reads the record once more.  No P-length vector
+// crosses PCIe, no P-length loop runs on the host.
+int iterate_device(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  double *gvec = f->redbuf + f->npk;
+  int bad_steps = 0;
+  while (true) {
+    int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false);
+    if (rc) return rc;
+    HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
+    rc = eval_residual_launch(f, f->p_trial);
+    if (rc) return rc;
+    HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
+    HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    const double *st = f->pin_lm;
+    f->ntrial++;
+    if (st[LMS_SOLVED] != 0.0) f->nfev++;   // (a residual evaluated at garbage is not a trial)
+    else f->chol_fail++;
+    f->mu = st[LMS_MU];
+    f->nu = (long)st[LMS_NU];
+    f->delta = st[LMS_DELTA];
+    if (st[LMS_ACCEPT] != 0.0) {
+      rc = eval_normal_dev(f, f->p_trial, false);
+      if (rc) return rc;
+      std::swap(f->p_dev, f->p_trial);
+      HIPCHK(f, launch_scale_update(f->st, P, f->opt.scaler, 0, f->diag_dev, f->dscale));
+      HIPCHK(f, launch_lm_converge(f->st, P, f->p_dev, f->yv + P, gvec, f->opt.xtol, f->opt.gtol, f->lmd));
+      HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+      HIPCHK(f, hipStreamSynchronize(f->st));
+      f->chi2 = f->pin_lm[LMS_CHI2];
+      f->conv_info_dev = (int32_t)f->pin_lm[LMS_INFO];
+      if (!std::isfinite(f->chi2)) FAIL(f, LSQAMD_ENONFINITE, "chi2 is not finite at this point");
+      return 0;
+    }
+    if (++bad_steps > 15) return LSQAMD_ENOPROG;
+  }
+}
+
 // one trust_iterate: GSL_SUCCESS (0) or LSQAMD_ENOPROG; negative on backend failure
 int iterate(lsqamd_fit *f) {
+  if (f->dev_lm && f->opt.trs == LSQAMD_TRS_LM && f->linear.empty()) return iterate_device(f);
+  if (f->mirrors_stale) {
+    const int rcm = refresh_mirrors(f);
+    if (rcm) return rcm;
+  }
+  f->dev_lm = false;
   if (!f->linear.empty()) return iterate_varpro(f);
   const int64_t P = f->P;
   const int trs = f->opt.trs;
@@ -900,6 +988,7 @@ int iterate(lsqamd_fit *f) {
 }
 
 int convergence_test(lsqamd_fit *f) {
+  if (f->dev_lm) return f->conv_info_dev;
   const int64_t P = f->P;
   const double xtol = f->opt.xtol, gtol = f->opt.gtol;
   bool ok = true;
@@ -958,6 +1047,16 @@ int do_init(lsqamd_fit *f, const double *p0) {
   double dxn = 0.0;
   for (int64_t j = 0; j < P; ++j) dxn += f->hdiag[j] * f->hx[j] * f->hdiag[j] * f->hx[j];
   f->delta = 0.3 * std::fmax(1.0, std::sqrt(dxn));
+  f->mirrors_stale = false;
+  f->conv_info_dev = 0;
+  f->dev_lm = f->opt.trs == LSQAMD_TRS_LM && f->linear.empty() && getenv("LSQAMD_HOST_LM") == nullptr;
+  if (f->dev_lm) {   // the record the device-side decisions start from (once per fit)
+    for (int i = 0; i < LMS_COUNT; ++i) f->pin_lm[i] = 0.0;
+    f->pin_lm[LMS_CHI2] = f->chi2; f->pin_lm[LMS_MU] = f->mu; f->pin_lm[LMS_NU] = (double)f->nu;
+    f->pin_lm[LMS_DELTA] = f->delta;
+    HIPCHK(f, hipMemcpyAsync(f->lmd, f->pin_lm, sizeof(double) * LMS_COUNT, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+  }
   f->initialised = true;
   return 0;
 }
@@ -1076,12 +1175,12 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.avmax = 0.75;
   {
     const size_t P1 = (size_t)f->P + 1;
-    if (hipHostMalloc((void **)&f->pin, sizeof(double) * (5 * P1 + 8), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&f->pin, sizeof(double) * (5 * P1 + 8 + LMS_COUNT), hipHostMallocDefault) != hipSuccess) {
       delete f;
       return LSQAMD_ENOMEM;
     }
     f->pin_g = f->pin; f->pin_c = f->pin_g + P1; f->pin_v = f->pin_c + P1; f->pin_d = f->pin_v + P1;
-    f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1;
+    f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1; f->pin_lm = f->pin_s + 8;
   }
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
@@ -1458,6 +1557,8 @@ int lsqamd_eval_normal(lsqamd_fit *f, const double *p, double *chi2) {
   f->hv.assign(P, 0.0);
   f->hdx.assign(P, 0.0);
   if ((int64_t)f->hdiag.size() != P) f->hdiag.assign(P, 1.0);
+  f->dev_lm = false;
+  f->mirrors_stale = false;
   HIPCHK(f, hipMemcpyAsync(f->p_dev, p, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
   rc = eval_normal_dev(f, f->p_dev);
   if (f->timing) resolve_timers(f);
@@ -1516,6 +1617,7 @@ int lsqamd_get_x(lsqamd_fit *f, double *out, size_t cap) {
   if (!f || !out) return LSQAMD_EINVAL;
   if (cap < (size_t)f->P) FAIL(f, LSQAMD_ECAPACITY, "get_x: need %lld", (long long)f->P);
   if ((int64_t)f->hx.size() != f->P) FAIL(f, LSQAMD_EINVAL, "get_x: no fit has run");
+  if (const int rcm = refresh_mirrors(f)) return rcm;
   std::memcpy(out, f->hx.data(), sizeof(double) * f->P);
   return 0;
 }
@@ -1524,6 +1626,7 @@ int lsqamd_get_grad(lsqamd_fit *f, double *out, size_t cap) {
   if (!f || !out) return LSQAMD_EINVAL;
   if (cap < (size_t)f->P) FAIL(f, LSQAMD_ECAPACITY, "get_grad: need %lld", (long long)f->P);
   if ((int64_t)f->hg.size() != f->P) FAIL(f, LSQAMD_EINVAL, "get_grad: no fit has run");
+  if (const int rcm = refresh_mirrors(f)) return rcm;
   std::memcpy(out, f->hg.data(), sizeof(double) * f->P);
   return 0;
 }

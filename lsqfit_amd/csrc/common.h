@@ -176,6 +176,15 @@ hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, 
                                double *dscale);
 // xt = x - v
 hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt);
+// LM state record on the device (plain lm; vecops.hip)
+enum { LMS_CHI2 = 0, LMS_MU, LMS_NU, LMS_DELTA, LMS_VG, LMS_DV2, LMS_VFINITE, LMS_RHO, LMS_CHI2_TRIAL, LMS_ACCEPT,
+       LMS_SOLVED, LMS_INFO, LMS_COUNT = 16 };
+hipError_t launch_lm_trial(hipStream_t st, int64_t P, const double *x, const double *v, const double *g,
+                           const double *d, double *xt, double *state);
+hipError_t launch_lm_decide(hipStream_t st, const double *chi2_trial, const int32_t *chol_info, double factor_up,
+                            double factor_down, double *state);
+hipError_t launch_lm_converge(hipStream_t st, int64_t P, const double *x, const double *v, const double *gvec,
+                              double xtol, double gtol, double *state);
 
 inline int64_t packed_doubles(int64_t P) {
   const int64_t T = (P + 127) / 128;

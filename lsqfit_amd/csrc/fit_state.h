@@ -50,6 +50,7 @@ struct lsqamd_fit {
   double *red_scalar = nullptr;
   double *M = nullptr, *chol_work = nullptr, *yv = nullptr, *diag_dev = nullptr, *tvec = nullptr;
   double *dscale = nullptr;  // the scaling matrix D, device-resident mirror of hdiag
+  double *lmd = nullptr;     // LM state record on the device (LMS_*: chi2, mu, nu, delta, rho, flags)
   double *partial = nullptr, *Wl = nullptr, *cov = nullptr, *scal = nullptr;
   int32_t *info_dev = nullptr;
   int32_t *tape = nullptr;
@@ -88,6 +89,10 @@ struct lsqamd_fit {
   std::vector<double> hx, hg, hdiag, hdx, hv, hcoln, htmp;
   double chi2 = 0.0, mu = 0.0, delta = 0.0;
   long nu = 2;
+  // plain lm keeps its vectors on the device (api.hip iterate_device): the host mirrors hx / hg /
+  // hdiag / hcoln / hv / hdx are refreshed on demand (refresh_mirrors)
+  bool dev_lm = false, mirrors_stale = false;
+  int32_t conv_info_dev = 0;
   bool initialised = false, have_cov = false, have_dense_A = false;
   int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
   double logdet = NAN;
@@ -96,6 +101,7 @@ struct lsqamd_fit {
   // kernel and cost ~40 us each): [g | chi2](P+1), coln(P), v(P), diag(P), x_trial(P), scalars(8)
   double *pin = nullptr;
   double *pin_g = nullptr, *pin_c = nullptr, *pin_v = nullptr, *pin_d = nullptr, *pin_x = nullptr, *pin_s = nullptr;
+  double *pin_lm = nullptr;   // the device's LM state record, as last read
   std::vector<hipEvent_t> event_pool;
 
   // timing
@@ -161,7 +167,9 @@ size_t qr_work_bytes(const lsqamd_fit *f);
 // whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return; counts one nfev
 int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out);
 // J, A = J^T J (+ prior), g, chi2, column norms at device parameters p (all-reduced); counts one njev
-int eval_normal_dev(lsqamd_fit *f, const double *p);
+int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror = true);
+// host copies of x, g, D, column norms, v after steps that kept them on the device
+int refresh_mirrors(lsqamd_fit *f);
 // (A + mu D^2) v = g -> f->hv ; LSQAMD_ENOTPD when a pivot fails.  diag_host nullptr: the
 // device-resident D.  frozen_host (with mu = 0): flags of parameters taken out of the system.
 int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr);

@@ -520,7 +520,10 @@ __device__ __forceinline__ void store_tiles_v3(const TileRegs &T, double *A, int
         const int gr = 16 * ti + i4 + t;
         w4[t] = (gr >= gcw && gr < nb && gcw < nb) ? w4[t] : 0.0;
       }
-      if (gcw < nb) *reinterpret_cast<v4d *>(uinv + gcw * NB + 16 * ti + i4) = w4;
+      // every lane stores (rows >= nb of the 128 x 128 inverse block receive zeros nobody reads): a
+      // store under `if (gcw < nb)` left lanes 16..63 of the NEXT tile's LDS staging writes masked off
+      // for partial blocks (nb = 16 k + 4 in the second tile column of waves 0..2)
+      *reinterpret_cast<v4d *>(uinv + gcw * NB + 16 * ti + i4) = w4;
     }
   }
 }

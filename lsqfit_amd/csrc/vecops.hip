@@ -633,4 +633,117 @@ hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const 
   return hipGetLastError();
 }
 
+// ---- LM state on the device (plain lm): what trust.c / nielsen.c / convergence.c do with O(P)
+// vectors and a handful of scalars, as three one-workgroup kernels.  The host reads ONE small
+// status record per trial and one per accepted step; x, g, D, v never leave the device.
+//   st[LMS_*]: the record (doubles; also copied to the host)
+__device__ __forceinline__ double block_sum(double a, double *sh) {
+  a = wsum64(a);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// trial point + the two dot products of the gain ratio:  xt = x - v,  st[VG] = v.g,  st[DV2] = |D v|^2,
+// st[VFINITE] = 1 when every component of v is finite
+__global__ __launch_bounds__(256) void lm_trial_kernel(int64_t P, const double *x, const double *v, const double *g,
+                                                       const double *d, double *xt, double *st) {
+  __shared__ double sh[4];
+  double vg = 0.0, dv2 = 0.0, bad = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double vj = v[j];
+    xt[j] = x[j] - vj;
+    vg += vj * g[j];
+    const double t = d[j] * vj;
+    dv2 += t * t;
+    bad += (vj - vj == 0.0) ? 0.0 : 1.0;   // NaN / inf
+  }
+  vg = block_sum(vg, sh);
+  dv2 = block_sum(dv2, sh);
+  bad = block_sum(bad, sh);
+  if (threadIdx.x == 0) {
+    st[LMS_VG] = vg;
+    st[LMS_DV2] = dv2;
+    st[LMS_VFINITE] = bad == 0.0 ? 1.0 : 0.0;
+  }
+}
+
+hipError_t launch_lm_trial(hipStream_t stream, int64_t P, const double *x, const double *v, const double *g,
+                           const double *d, double *xt, double *st) {
+  hipLaunchKernelGGL(lm_trial_kernel, dim3(1), dim3(256), 0, stream, P, x, v, g, d, xt, st);
+  return hipGetLastError();
+}
+
+// trust_iterate's decision (trust.c) and nielsen.c's update of mu:
+//   rho = (1 - |f_t|^2 / |f|^2) / ((v.g + mu |D v|^2) / |f|^2)   [|J v|^2 = v.g - mu |D v|^2]
+__global__ void lm_decide_kernel(const double *chi2_trial, const int32_t *chol_info, double factor_up,
+                                 double factor_down, double *st) {
+  const double chi2 = st[LMS_CHI2], mu = st[LMS_MU];
+  const double ct = chi2_trial[0];
+  const bool solved = chol_info[0] == 0 && st[LMS_VFINITE] != 0.0;
+  double rho = -1.0;
+  if (solved) {
+    const double normf = sqrt(chi2), normf_t = sqrt(ct);
+    if (normf_t < normf) {   // NaN-safe: anything else rejects
+      const double u = normf_t / normf;
+      const double pred = (st[LMS_VG] + mu * st[LMS_DV2]) / chi2;
+      rho = pred > 0.0 ? (1.0 - u * u) / pred : -1.0;
+    }
+  }
+  if (rho > 0.75) st[LMS_DELTA] *= factor_up;
+  else if (rho < 0.25) st[LMS_DELTA] /= factor_down;
+  if (rho > 0.0) {
+    const double b = 2.0 * rho - 1.0;
+    st[LMS_MU] = mu * fmax(0.333333333333333, 1.0 - b * b * b);
+    st[LMS_NU] = 2.0;
+  } else {
+    st[LMS_MU] = mu * st[LMS_NU];
+    st[LMS_NU] *= 2.0;
+  }
+  st[LMS_RHO] = rho;
+  st[LMS_CHI2_TRIAL] = ct;
+  st[LMS_ACCEPT] = rho > 0.0 ? 1.0 : 0.0;
+  st[LMS_SOLVED] = solved ? 1.0 : 0.0;
+}
+
+hipError_t launch_lm_decide(hipStream_t stream, const double *chi2_trial, const int32_t *chol_info, double factor_up,
+                            double factor_down, double *st) {
+  hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1), 0, stream, chi2_trial, chol_info, factor_up, factor_down, st);
+  return hipGetLastError();
+}
+
+// after the accepted point's normal equations: chi2 into the record and gsl_multifit_nlinear_test
+// (convergence.c): info 1 when every |dx_i| < xtol^2 + xtol |x_i|, else 2 when
+// max_i |g_i max(x_i, 1)| <= gtol max(chi2 / 2, 1), else 0.  dx = -v.
+__global__ __launch_bounds__(256) void lm_converge_kernel(int64_t P, const double *x, const double *v, const double *gvec,
+                                                          double xtol, double gtol, double *st) {
+  __shared__ double sh[4];
+  double notx = 0.0, gn = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const double xj = x[j];
+    notx += (fabs(v[j]) < xtol * xtol + xtol * fabs(xj)) ? 0.0 : 1.0;
+    gn = fmax(gn, fabs(fmax(xj, 1.0) * gvec[j]));
+  }
+  notx = block_sum(notx, sh);
+  // max over the block
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gn = fmax(gn, __shfl_down(gn, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gn = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    const double chi2 = gvec[P];
+    st[LMS_CHI2] = chi2;
+    st[LMS_INFO] = notx == 0.0 ? 1.0 : (gn <= gtol * fmax(0.5 * chi2, 1.0) ? 2.0 : 0.0);
+  }
+}
+
+hipError_t launch_lm_converge(hipStream_t stream, int64_t P, const double *x, const double *v, const double *gvec,
+                              double xtol, double gtol, double *st) {
+  hipLaunchKernelGGL(lm_converge_kernel, dim3(1), dim3(256), 0, stream, P, x, v, gvec, xtol, gtol, st);
+  return hipGetLastError();
+}
+
 }  // namespace lsqamd

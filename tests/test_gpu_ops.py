@@ -102,6 +102,30 @@ def test_potrf_upper_with_rhs_column(env, n):
     np.testing.assert_allclose(out[:, n], np.linalg.solve(Uref.T, b), rtol=1e-9, atol=1e-10)
 
 
+def test_diagonal_block_kernel_every_size(env):
+    """The diagonal-block kernel (16-row slabs, leaf in registers) at EVERY block size 1..128: the factor
+    and the block inverse the row panels and the back substitution multiply with.  (The inverse of
+    sizes 16 k + 4 was once lost to an exec-masked store; nothing but this sweep saw it.)"""
+    torch, lib = env
+    for n in range(1, 129):
+        rng = np.random.default_rng(n)
+        G = rng.standard_normal((n + 20, n))
+        A = G.T @ G + 0.1 * np.eye(n)
+        wbytes = lib.lsqamd_op_potrf_work_bytes(n)
+        work = torch.full((wbytes // 8 + 8,), 7.0, dtype=torch.float64, device='cuda')
+        info = torch.zeros(4, dtype=torch.int32, device='cuda')
+        dA = dev(torch, np.triu(A))
+        assert lib.lsqamd_op_potrf_upper(None, dA.data_ptr(), n, n, n, work.data_ptr(), wbytes, info.data_ptr()) == 0
+        torch.cuda.synchronize()
+        Uref = np.linalg.cholesky(A).T
+        U = np.triu(dA.cpu().numpy())
+        uinv = work.cpu().numpy()[:128 * 128].reshape(128, 128)[:n, :n]
+        assert int(info[0]) == 0, n
+        assert np.abs(U - Uref).max() < 1e-11, n
+        assert np.abs(uinv @ Uref - np.eye(n)).max() < 1e-11, n
+        assert np.all(np.tril(uinv, -1) == 0.0), n
+
+
 def test_potrf_flags_indefinite(env):
     torch, lib = env
     n = 200
