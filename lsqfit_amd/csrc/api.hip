@@ -852,7 +852,16 @@ int iterate_device(lsqamd_fit *f) {
       if (!std::isfinite(f->chi2)) FAIL(f, LSQAMD_ENONFINITE, "chi2 is not finite at this point");
       return 0;
     }
-    if (++bad_steps > 15) return LSQAMD_ENOPROG;
+    if (++bad_steps > 15) {
+      // gsl_multifit_nlinear_driver tests convergence after an iteration that made no progress as
+      // well, with the last (rejected) trial step as dx: at a minimum resolved to rounding that
+      // step is below xtol and the fit ends on criterion 1
+      HIPCHK(f, launch_lm_converge(f->st, P, f->p_dev, f->yv + P, gvec, f->opt.xtol, f->opt.gtol, f->lmd));
+      HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+      HIPCHK(f, hipStreamSynchronize(f->st));
+      f->conv_info_dev = (int32_t)f->pin_lm[LMS_INFO];
+      return LSQAMD_ENOPROG;
+    }
   }
 }
 

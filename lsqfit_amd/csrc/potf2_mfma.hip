@@ -32,13 +32,17 @@ __device__ __forceinline__ double rsqrt_refined(double d) {
   return __builtin_fma(y, e, y);
 }
 
-// The same to full precision with a shorter dependent chain (4 operations after v_rsq_f64 instead
-// of 6): with e = 1 - d y0^2,  1/sqrt(d) = y0 (1 - e)^-1/2 = y0 (1 + e/2 + 3 e^2/8 + O(e^3)); the
-// hardware estimate is good to ~2^-23, so the cubic term is below 2^-66.
+// The same to full precision with a shorter dependent chain (5 levels after v_rsq_f64 instead of
+// 6): with e = 1 - d y0^2,  1/sqrt(d) = y0 (1 - e)^-1/2 = y0 (1 + e/2 + 3 e^2/8 + 5 e^3/16 + 35 e^4/128 + ..),
+// the polynomial in Estrin form.  v_rsq_f64 is good to ~2^-16 only (a cubic truncation was measured
+// at 1e-14 relative -- visible in log det J^T J at cond 1e8), so the first neglected term is ~2^-77.
 __device__ __forceinline__ double rsqrt_cubic(double d) {
   const double y0 = __builtin_amdgcn_rsq(d);
   const double e = __builtin_fma(-(d * y0), y0, 1.0);
-  const double p = __builtin_fma(0.375, e, 0.5);
+  const double e2 = e * e;
+  const double pa = __builtin_fma(0.375, e, 0.5);
+  const double pb = __builtin_fma(0.2734375, e, 0.3125);
+  const double p = __builtin_fma(pb, e2, pa);
   return __builtin_fma(y0 * e, p, y0);
 }
 
