@@ -64,7 +64,8 @@ extern "C" {
 enum {
   LSQAMD_MODEL_COSMIX = 1,   /* sum_k a_k cos(w_k x); p=[a_0..a_{K-1}, w_0..w_{K-1}] */
   LSQAMD_MODEL_MULTIEXP = 2, /* sum_k a_k exp(-E_k x); p=[a.., E..] (examples/y-vs-x.py:58-61) */
-  LSQAMD_MODEL_TAPE = 3,     /* RPN expression tape over x[0..n_x) and p[0..P) (examples/nist.py models) */
+  LSQAMD_MODEL_TAPE = 3,     /* RPN expression tape over x[0..n_x) and p[0..P): ANY formula -- the stand-in for the
+                              * user's Python fit function (examples/nist.py models); Jacobian by reverse-mode AD */
   LSQAMD_MODEL_IDENTITY = 4  /* f_i = p_i (tests/test_lsqfit.py:1815) */
 };
 
@@ -106,8 +107,10 @@ enum {
   LSQAMD_OP_POWI = 15  /* a ** (int)arg */
 };
 #define LSQAMD_TAPE_MAX_PARAM 4096 /* parameters of a tape model */
-#define LSQAMD_TAPE_CHUNK 16       /* ... differentiated 16 at a time: ceil(P/16) passes over the tape per row */
+#define LSQAMD_TAPE_CHUNK 16       /* batched fits: differentiated 16 at a time, ceil(P/16) forward passes per row */
 #define LSQAMD_TAPE_MAX_STACK 16
+#define LSQAMD_TAPE_MAX_CODE 16384 /* instructions (single fits: ONE forward and ONE reverse sweep per row,
+                                    * whatever P is; batched fits: at most 1024) */
 
 /* Devices this process can use (one process per GPU; a host in another language picks its
  * device with the HIP runtime before lsqamd_create).  *count <- visible devices (0 without a GPU:
@@ -132,6 +135,9 @@ typedef struct {
   int64_t sum_block_sq;  /* sum over blocks of B_b * B_b (whitening storage) */
   int32_t want_jacobian_out; /* keep the whitened J retrievable (fit.J, __init__.py:668) */
   int32_t n_batch;       /* independent fits sharing shape (1 unless batched sweep) */
+  int32_t tape_len;      /* LSQAMD_MODEL_TAPE: instructions of the tape lsqamd_set_tape will bring (0 = up to
+                          * 1024); sizes the per-row partial-derivative store of the reverse sweep */
+  int32_t reserved1;
 } lsqamd_config;
 
 /* Driver options: gsl_multifit.__init__ keyword arguments (_gsl.pyx:563-575). */

@@ -22,7 +22,8 @@ class Config(C.Structure):
     _fields_ = [('abi_version', C.c_int32), ('model', C.c_int32), ('n_data', C.c_int64),
                 ('n_param', C.c_int64), ('n_x', C.c_int32), ('has_prior', C.c_int32),
                 ('prior_dense', C.c_int32), ('n_blocks', C.c_int32), ('max_block', C.c_int64),
-                ('sum_block_sq', C.c_int64), ('want_jacobian_out', C.c_int32), ('n_batch', C.c_int32)]
+                ('sum_block_sq', C.c_int64), ('want_jacobian_out', C.c_int32), ('n_batch', C.c_int32),
+                ('tape_len', C.c_int32), ('reserved1', C.c_int32)]
 
 
 class Options(C.Structure):

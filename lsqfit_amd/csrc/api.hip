@@ -140,8 +140,21 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->scal = cv.take<double>(16);
   f->lmd = cv.take<double>(LMS_COUNT);
   f->info_dev = cv.take<int32_t>(16);
-  f->tape = cv.take<int32_t>(1024);
-  f->consts = cv.take<double>(256);
+  f->tape_cap = c.tape_len > 1024 ? c.tape_len : 1024;
+  f->tape = cv.take<int32_t>(f->tape_cap);
+  f->tape_poff = cv.take<int32_t>(f->tape_cap);
+  f->consts = cv.take<double>(1024);
+  if (c.model == LSQAMD_MODEL_TAPE) {
+    // one forward + one reverse sweep per row: per resident wave 2 slots per instruction (upper
+    // bound) x 64 lanes of local partial derivatives; at most 1024 waves are resident
+    const int64_t groups = (N + 63) / 64;
+    f->tape_wgs = (groups + 3) / 4 < 256 ? (groups + 3) / 4 : 256;
+    if (f->tape_wgs < 1) f->tape_wgs = 1;
+    f->tape_slot_cap = 2 * f->tape_cap;
+    f->tape_part = cv.take<double>(f->tape_wgs * 4 * (int64_t)f->tape_slot_cap * 64);
+    f->tape_ldn = rup(N > 0 ? N : 1, 64);
+    f->tape_jt = cv.take<double>((P + 1) * f->tape_ldn);
+  }
   f->syrk_nwork = (int32_t)syrk_work_count(P, f->splits);
   f->syrk_map = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);
   return cv.off;
@@ -152,6 +165,7 @@ int check_cfg(const lsqamd_config *c) {
   if (c->n_data < 0 || c->n_param < 1 || c->n_blocks < 0) return LSQAMD_EINVAL;
   if (c->model < LSQAMD_MODEL_COSMIX || c->model > LSQAMD_MODEL_IDENTITY) return LSQAMD_EINVAL;
   if (c->model == LSQAMD_MODEL_TAPE && c->n_param > LSQAMD_TAPE_MAX_PARAM) return LSQAMD_EINVAL;
+  if (c->tape_len < 0 || c->tape_len > LSQAMD_TAPE_MAX_CODE) return LSQAMD_EINVAL;
   if ((c->model == LSQAMD_MODEL_COSMIX || c->model == LSQAMD_MODEL_MULTIEXP) && (c->n_param & 1))
     return LSQAMD_EINVAL;
   if (c->n_batch > 1) return LSQAMD_EUNSUPPORTED;
@@ -172,6 +186,14 @@ ModelArgs model_args(const lsqamd_fit *f, const double *p) {
   m.tape = f->tape;
   m.n_tape = f->n_tape;
   m.consts = f->consts;
+  if (f->tape_part) {
+    m.tape_poff = f->tape_poff;
+    m.tape_part = f->tape_part;
+    m.tape_jt = f->tape_jt;
+    m.tape_ldn = f->tape_ldn;
+    m.tape_wgs = f->tape_wgs;
+    m.tape_slots = f->tape_slots;
+  }
   return m;
 }
 
@@ -1235,8 +1257,8 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
 int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const double *consts,
                     int32_t n_consts) {
   if (!f) return LSQAMD_EINVAL;
-  if (!code || n_code < 1 || n_code > 1024 || n_consts < 0 || n_consts > 256)
-    FAIL(f, LSQAMD_EINVAL, "set_tape: 1..1024 instructions, <= 256 constants");
+  if (!code || n_code < 1 || n_code > f->tape_cap || n_consts < 0 || n_consts > 1024)
+    FAIL(f, LSQAMD_EINVAL, "set_tape: 1..%d instructions (lsqamd_config.tape_len), <= 1024 constants", f->tape_cap);
   // validate stack discipline and operand ranges on the host
   int sp = 0;
   for (int t = 0; t < n_code; ++t) {
@@ -1250,6 +1272,17 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
     if (sp > LSQAMD_TAPE_MAX_STACK) FAIL(f, LSQAMD_EINVAL, "tape: stack deeper than %d", LSQAMD_TAPE_MAX_STACK);
   }
   if (sp != 1) FAIL(f, LSQAMD_EINVAL, "tape: must leave exactly one value");
+  {
+    std::vector<int32_t> poff((size_t)n_code);
+    int32_t slots = 0;
+    for (int t = 0; t < n_code; ++t) {
+      poff[(size_t)t] = slots;
+      slots += tape_slots_of_op(code[t] & 0xff);
+    }
+    f->tape_slots = slots;
+    HIPCHK(f, hipMemcpyAsync(f->tape_poff, poff.data(), sizeof(int32_t) * n_code, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));   // (poff is a local)
+  }
   HIPCHK(f, hipMemcpyAsync(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice, f->st));
   if (n_consts > 0)
     HIPCHK(f, hipMemcpyAsync(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice, f->st));

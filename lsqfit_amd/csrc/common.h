@@ -101,7 +101,14 @@ struct ModelArgs {
   int64_t p_stride = 0, out_stride = 0;
   int64_t ymean_stride = 0;  // 0: the fits share ymean; n_data: fit b reads ymean + b*n_data
   const int32_t *batch_active = nullptr;
+  // tape model, single fit: buffers of the reverse-mode Jacobian (null: forward-mode kernel)
+  const int32_t *tape_poff = nullptr;   // first partial-derivative slot of every instruction
+  double *tape_part = nullptr;          // [tape_wgs * 4 waves][tape_slots][64]
+  double *tape_jt = nullptr;            // [(n_param + 1)][tape_ldn]
+  int64_t tape_ldn = 0, tape_wgs = 0;
+  int32_t tape_slots = 0;
 };
+int tape_slots_of_op(int op);
 // r_w[i] = w_i (f(x_i;p) - y_i) for 1x1 rows; r_raw[i] = f - y for rows inside blocks
 hipError_t launch_residual_ex(hipStream_t st, const ModelArgs &m, double *r_w, double *r_raw);
 // J[i][0..P) = w_i d f_i / d p ; J[i][P] = w_i delta_i (ld >= P+1); block rows -> J_raw unweighted

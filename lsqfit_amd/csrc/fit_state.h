@@ -56,6 +56,11 @@ struct lsqamd_fit {
   int32_t *tape = nullptr;
   double *consts = nullptr;
   int32_t n_tape = 0;
+  // reverse-mode tape Jacobian (model.hip): slot offsets, partial store, transposed Jacobian
+  int32_t *tape_poff = nullptr;
+  double *tape_part = nullptr, *tape_jt = nullptr;
+  int64_t tape_ldn = 0, tape_wgs = 0;
+  int32_t tape_cap = 0, tape_slots = 0, tape_slot_cap = 0;
   int32_t *syrk_map = nullptr;
   int32_t syrk_nwork = 0;
 

@@ -14,8 +14,16 @@
 // to a correlated block are written unweighted into the raw buffer and whitened
 // afterwards by the TN GEMM (X = W_b^T).
 //
-// Tape model: one lane per data row runs an RPN program over (x_i, p) with dual
-// numbers, 16 parameters per pass -- any model expressible as a formula in x and p.
+// Tape model -- the stand-in for the user's own fit function: an RPN program over (x_i, p).
+//   single fits: REVERSE-mode AD, one lane per data row: one forward sweep stores the local partial
+//     derivatives of every instruction (coalesced: [slot][lane]), one reverse sweep propagates the
+//     adjoint through an LDS stack and adds d f / d p_j into a TRANSPOSED Jacobian (row j, lanes =
+//     consecutive data rows: 512-byte segments); a tiled transpose then writes the weighted rows.
+//     Cost O(tape length) per row whatever P is -- the forward-mode kernel below needs ceil(P / 16)
+//     passes over the tape per row with a 16 x 16 dual stack in scratch;
+//   batched fits and residual-only evaluations: the forward kernel (16 parameters per pass).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace lsqamd {
@@ -267,6 +275,137 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
   else dst[row] = w * delta;
 }
 
+
+// ---- reverse-mode tape Jacobian ------------------------------------------------------------------
+// slots of local partial derivatives an instruction stores in the forward sweep
+__host__ __device__ inline int tape_slots_of(int op) {
+  if (op == LSQAMD_OP_MUL || op == LSQAMD_OP_DIV || op == LSQAMD_OP_POW) return 2;
+  if (op >= LSQAMD_OP_EXP && op <= LSQAMD_OP_POWI) return 1;
+  return 0;   // pushes, ADD, SUB, NEG: constants
+}
+
+struct TapeRev {
+  ModelDev m;
+  const int32_t *poff;   // first slot of instruction t
+  double *part;          // [wave slot][n_slots][64]
+  double *jt;            // [(P + 1)][ldn]: d f / d p_j per data row; row P = f - ymean
+  int64_t ldn;
+  int32_t n_slots;
+  int64_t n_groups;      // ceil(n_data / 64)
+};
+
+__global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
+  __shared__ double stk[4][LSQAMD_TAPE_MAX_STACK][64];   // value stack, then adjoint stack
+  extern __shared__ int32_t tcode[];                      // [n_tape] instructions, [n_tape] slot offsets
+  const ModelDev &m = a.m;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int32_t *toff = tcode + m.n_tape;
+  for (int t = threadIdx.x; t < m.n_tape; t += 256) {
+    tcode[t] = m.tape[t];
+    toff[t] = a.poff[t];
+  }
+  __syncthreads();
+  const int64_t slot = (int64_t)blockIdx.x * 4 + wave, nslots = (int64_t)gridDim.x * 4;
+  double *part = a.part + slot * a.n_slots * 64 + lane;
+  double (*S)[64] = stk[wave];
+  for (int64_t g = slot; g < a.n_groups; g += nslots) {
+    const int64_t row = g * 64 + lane;
+    const bool valid = row < m.n_data;
+    const int64_t rr = valid ? row : m.n_data - 1;
+    // ---- forward: values through the LDS stack, local partials to the store
+    int sp = 0;
+    int32_t ins_n = tcode[0], off_n = toff[0];
+    for (int t = 0; t < m.n_tape; ++t) {
+      const int32_t ins = ins_n;
+      double *pd = part + (int64_t)off_n * 64;
+      if (t + 1 < m.n_tape) { ins_n = tcode[t + 1]; off_n = toff[t + 1]; }   // decode one ahead
+      const int op = ins & 0xff, arg = ins >> 8;
+      if (op == LSQAMD_OP_CONST) S[sp++][lane] = m.consts[arg];
+      else if (op == LSQAMD_OP_X) S[sp++][lane] = m.x[rr * m.n_x + arg];
+      else if (op == LSQAMD_OP_P) S[sp++][lane] = m.p[arg];
+      else if (op <= LSQAMD_OP_POW) {
+        const double b = S[sp - 1][lane], x = S[sp - 2][lane];
+        double v;
+        if (op == LSQAMD_OP_ADD) v = x + b;
+        else if (op == LSQAMD_OP_SUB) v = x - b;
+        else if (op == LSQAMD_OP_MUL) { v = x * b; pd[0] = b; pd[64] = x; }
+        else if (op == LSQAMD_OP_DIV) { v = x / b; pd[0] = 1.0 / b; pd[64] = -v / b; }
+        else { v = pow(x, b); pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? v * log(x) : 0.0; }
+        S[sp - 2][lane] = v;
+        --sp;
+      } else {
+        const double x = S[sp - 1][lane];
+        double v, d = 1.0;
+        switch (op) {
+          case LSQAMD_OP_NEG: v = -x; break;
+          case LSQAMD_OP_EXP: v = exp(x); d = v; break;
+          case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
+          case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
+          case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
+          case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
+          case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
+          case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
+          default: v = x; break;
+        }
+        if (op != LSQAMD_OP_NEG) pd[0] = d;
+        S[sp - 1][lane] = v;
+      }
+    }
+    if (valid) a.jt[(int64_t)m.n_param * a.ldn + row] = S[0][lane] - m.ymean[row];
+    // ---- reverse: adjoints through the same stack; d f / d p_j accumulates in the transposed Jacobian
+    S[0][lane] = 1.0;
+    sp = 1;
+    ins_n = tcode[m.n_tape - 1];
+    off_n = toff[m.n_tape - 1];
+    for (int t = m.n_tape - 1; t >= 0; --t) {
+      const int32_t ins = ins_n;
+      const double *pd = part + (int64_t)off_n * 64;
+      if (t > 0) { ins_n = tcode[t - 1]; off_n = toff[t - 1]; }
+      const int op = ins & 0xff, arg = ins >> 8;
+      if (op <= LSQAMD_OP_P) {
+        --sp;
+        if (op == LSQAMD_OP_P && valid)   // fire and forget: a parameter may occur more than once on the tape
+          (void)__hip_atomic_fetch_add(a.jt + (int64_t)arg * a.ldn + row, S[sp][lane], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+      } else if (op <= LSQAMD_OP_POW) {
+        const double gbar = S[sp - 1][lane];
+        double da = 1.0, db = 1.0;
+        if (op == LSQAMD_OP_SUB) db = -1.0;
+        else if (op != LSQAMD_OP_ADD) { da = pd[0]; db = pd[64]; }
+        S[sp - 1][lane] = gbar * da;
+        S[sp][lane] = gbar * db;
+        ++sp;
+      } else {
+        S[sp - 1][lane] *= (op == LSQAMD_OP_NEG) ? -1.0 : pd[0];
+      }
+    }
+  }
+}
+
+// dst[row][c] = w_row * jt[c][row] for c <= P: 64 x 64 tiles through LDS, rows inside covariance
+// blocks go unweighted to the raw buffer
+__global__ __launch_bounds__(256) void tape_finish_kernel(const double *jt, int64_t ldn, int64_t N, int64_t ncols,
+                                                          const double *wdiag, const uint8_t *in_block,
+                                                          double *out_w, double *out_raw, int64_t ld) {
+  __shared__ double tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 64, c0 = (int64_t)blockIdx.y * 64;
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;
+    tile[i][tx] = (c < ncols && r < N) ? jt[c * ldn + r] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    if (r < N && c < ncols) {
+      const bool blk = in_block && in_block[r];
+      (blk ? out_raw : out_w)[r * ld + c] = (blk ? 1.0 : wdiag[r]) * tile[tx][i];
+    }
+  }
+}
+
 template <bool JAC>
 static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w, double *out_raw,
                                int64_t ld) {
@@ -304,6 +443,26 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
                          dim3(256), 0, st, m);
       break;
     case LSQAMD_MODEL_TAPE:
+      if (JAC && nb == 1 && a.tape_part && a.tape_jt && a.tape_poff) {
+        TapeRev r;
+        r.m = m; r.poff = a.tape_poff; r.part = a.tape_part; r.jt = a.tape_jt; r.ldn = a.tape_ldn;
+        r.n_slots = a.tape_slots > 0 ? a.tape_slots : 1;
+        r.n_groups = (a.n_data + 63) / 64;
+        hipError_t e = hipMemsetAsync(a.tape_jt, 0, sizeof(double) * (size_t)((a.n_param + 1) * a.tape_ldn), st);
+        if (e != hipSuccess) return e;
+        int64_t wgs = (r.n_groups + 3) / 4;
+        if (wgs > a.tape_wgs) wgs = a.tape_wgs;
+        static const bool fwd = [] { const char *e = getenv("LSQAMD_TAPE"); return e && e[0] == 'f'; }();
+        if (fwd) {   // developer knob: the forward-mode kernel, for comparison
+          hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64), nb), dim3(64), 0, st, m);
+          break;
+        }
+        hipLaunchKernelGGL(tape_reverse_kernel, dim3((unsigned)wgs), dim3(256), sizeof(int32_t) * 2 * (size_t)a.n_tape, st, r);
+        dim3 grid((unsigned)((a.n_data + 63) / 64), (unsigned)((a.n_param + 1 + 63) / 64));
+        hipLaunchKernelGGL(tape_finish_kernel, grid, dim3(256), 0, st, a.tape_jt, a.tape_ldn, a.n_data, a.n_param + 1,
+                           a.wdiag, a.in_block, out_w, out_raw, ld);
+        break;
+      }
       hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64), nb), dim3(64),
                          0, st, m);
       break;
@@ -312,6 +471,8 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
   }
   return hipGetLastError();
 }
+
+int tape_slots_of_op(int op) { return tape_slots_of(op); }
 
 hipError_t launch_residual_ex(hipStream_t st, const ModelArgs &m, double *r_w, double *r_raw) {
   return launch_model<false>(st, m, r_w, r_raw, 1);

@@ -95,7 +95,8 @@ class DeviceProblem:
                           n_x=model.n_x, has_prior=int(whitening.has_prior),
                           prior_dense=int(whitening.prior_dense), n_blocks=len(size),
                           max_block=int(size.max()) if len(size) else 0,
-                          sum_block_sq=int(np.sum(size * size)), want_jacobian_out=1, n_batch=1)
+                          sum_block_sq=int(np.sum(size * size)), want_jacobian_out=1, n_batch=1,
+                          tape_len=0 if model.tape is None else int(len(model.tape)))
         self.cfg = cfg
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         t0 = time.perf_counter()

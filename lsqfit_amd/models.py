@@ -137,3 +137,26 @@ def expr(text, params, xnames=('x',)):
     if c.maxdepth > TAPE_MAX_STACK:
         raise ValueError('expression needs a stack deeper than %d' % TAPE_MAX_STACK)
     return Model(MODEL_TAPE, len(params), len(xnames), tape=c.code, consts=c.consts, text=text)
+
+
+def tape_sum(term, K, params_per_term=('a', 'w'), xnames=('x',)):
+    """Sum of K copies of ``term`` (an expression in ``params_per_term`` and x), parameters laid
+    out family by family: p = [a_0..a_{K-1}, w_0..w_{K-1}].  Built instruction by instruction (a
+    K-term formula string would nest K levels deep in Python's parser):
+    ``tape_sum('a*cos(w*x)', 512)`` is cosmix(512) as a general tape with P = 1024."""
+    nfam = len(params_per_term)
+    code, consts = [], []
+    for k in range(K):
+        c = _Compiler(list(params_per_term), list(xnames))
+        c.consts = consts
+        c.visit(ast.parse(term.strip(), mode='eval').body)
+        if c.maxdepth + 1 > TAPE_MAX_STACK:
+            raise ValueError('term needs a stack deeper than %d' % (TAPE_MAX_STACK - 1))
+        for ins in c.code:
+            op, arg = ins & 0xff, ins >> 8
+            if op == OP['P']:
+                arg = arg * K + k
+            code.append((op & 0xff) | (int(arg) << 8))
+        if k:
+            code.append(OP['ADD'])
+    return Model(MODEL_TAPE, nfam * K, len(xnames), tape=code, consts=consts, text='sum_%d(%s)' % (K, term))

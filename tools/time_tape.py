@@ -1,0 +1,29 @@
+"""Developer tool (GPU): Jacobian assembly time of the expression-tape model (reverse-mode AD) at
+N = 65536 for a P = 64 and a P = 1024 tape, beside the analytic cosmix kernel on the same function.
+Run under rocprofv3 --kernel-trace --stats for the per-kernel numbers in profiles/."""
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+import lsqfit_amd as amd
+from lsqfit_amd import models, synth
+
+N = 65536
+for P in (64, 1024):
+    d = synth.make_cosmix(N=N, P=P, seed=5, block=0, prior_corr=False)
+    tape = models.tape_sum('a*cos(w*x)', P // 2)
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    for name, model in (('tape', tape), ('cosmix', d['model'])):
+        pr = amd.DeviceProblem(model, d['x'], wh)
+        pr.timing(True)
+        for rep in range(6):
+            pr.normal(d['p0'])
+        tm = pr.timings()
+        jac_ms = tm['jacobian'][0] / tm['jacobian'][1]
+        nbytes = 8.0 * N * (P + 1)
+        print('P = %4d  %-6s  Jacobian %.3f ms  (J = %.0f MB: %.2f TB/s of J written)  tape length %d'
+              % (P, name, jac_ms, nbytes / 1e6, nbytes / jac_ms / 1e9, 0 if model.tape is None else len(model.tape)))
+        pr.close()
