@@ -286,11 +286,12 @@ def main():
         # FETCH_SIZE x2 gfx950 correction): taken from the committed profile of this workload
         traffic, traffic_src, clk = None, None, None
         try:
-            prof = json.load(open(os.path.join(ROOT, 'profiles', 'r01_syrk_pmc.json')))
+            pmc = [f for f in ('r02_syrk_pmc.json', 'r01_syrk_pmc.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))][0]
+            prof = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
             clk = prof['summary'].get('effective_clock_GHz')
             if world == 1 and (N, P) == (65536, 4096):
                 traffic = prof['summary']['hbm_read_bytes_corrected'] + prof['summary'].get('hbm_write_bytes', 0)
-                traffic_src = 'profiles/r01_syrk_pmc.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch)'
+                traffic_src = 'profiles/%s (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, per launch)' % pmc
         except Exception:
             pass
         syrk_ms, syrk_n = tm['syrk']

@@ -1,0 +1,24 @@
+#!/bin/bash
+# GPU box: everything profiles/ carries for one round -- bench lines (c4, the 8-GPU shard shape, c2, c3),
+# the rocprofv3 kernel trace of the c4 bench, the three PMC passes of the J^T J launch, and the
+# tape-model Jacobian timings.  gpurun -- 'bash tools/collect_round_profiles.sh'
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+R=${LSQAMD_ROUND:-r02}
+OUT=$ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd $ROOT
+python3 bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_c4_1gpu.json 2> $OUT/bench_c4.err
+python3 bench.py --ndata 8192 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_shard8192_1gpu.json 2>/dev/null
+python3 bench.py --workload c2 --steps 200 --warmup 20 --cpu-seconds 5 > $OUT/${R}_bench_c2_1gpu.json 2>/dev/null
+python3 bench.py --workload c3 --steps 40 --warmup 5 --cpu-seconds 10 > $OUT/${R}_bench_c3_1gpu.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_c4_1gpu_under_rocprof.json 2> $OUT/trace_c4.err
+cp $(find $OUT/trace_c4 -name "*kernel_stats.csv" | head -1) $OUT/${R}_c4_1gpu_kernel_stats.csv
+PYTHONPATH=$ROOT rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tape -- python3 $ROOT/tools/time_tape.py > $OUT/${R}_tape_timing.txt 2> $OUT/trace_tape.err
+cp $(find $OUT/trace_tape -name "*kernel_stats.csv" | head -1) $OUT/${R}_tape_n65536_kernel_stats.csv
+rm -rf $OUT/trace_c4 $OUT/trace_tape
+cd $ROOT
+LSQAMD_ROUND=$R bash tools/collect_syrk_pmc.sh > $OUT/pmc.log 2>&1
+cp gpurun_out/pmc_$R/summary.json $OUT/${R}_syrk_pmc.json
+for p in sq fetch write; do cp gpurun_out/pmc_$R/syrk_${p}_pass.csv $OUT/${R}_syrk_pmc_${p}_pass.csv; done
+ls -la $OUT
