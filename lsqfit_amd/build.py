@@ -31,7 +31,7 @@ def _newer(target, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fit_state.h'),
+    headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fit_state.h'), os.path.join(CSRC, 'devmath.h'),
                os.path.join(HERE, '..', 'include', 'lsqfit_amd.h')]
     jobs = []
     objs = []

@@ -218,32 +218,40 @@ int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
   return 0;
 }
 
+// whitened residual VECTOR at device parameters p -> f->r (model kernel + block whitening); launches only
+int residual_vector_launch(lsqamd_fit *f, const double *p) {
+  ModelArgs m = model_args(f, p);
+  HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
+  if (f->have_param_rows)
+    HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, 1, p, f->ymean, f->wdiag,
+                                f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->r, f->r_raw, 0));
+  if (f->cfg.n_blocks > 0) {
+    // small blocks: one thread per output row; large ones (a single 8192-row block would keep
+    // 32 workgroups busy for milliseconds): r_b = Wt_b^T delta_b as a two-stage column sum at
+    // HBM speed, staged through the raw-Jacobian buffer (idle during a residual evaluation)
+    constexpr int64_t BIG = 1024;
+    HIPCHK(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff,
+                                      f->cfg.n_blocks, f->cfg.max_block, f->r_raw, f->r, 1, 0, nullptr, BIG));
+    for (size_t b = 0; b < f->h_size.size(); ++b) {
+      const int64_t B = f->h_size[b];
+      if (B < BIG) continue;
+      int64_t nch = (f->N * f->ld) / B;
+      if (nch > 256) nch = 256;
+      HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->Jraw, nch,
+                                  f->r + f->h_row0[b], f->r_raw + f->h_row0[b]));
+    }
+  }
+  return 0;
+}
+
 // whitened residual at device parameters p -> f->r; chi2 (summed over ranks) -> f->red_scalar[0].
 // Launches only: nothing is waited for.
 int eval_residual_launch(lsqamd_fit *f, const double *p) {
+  f->r_fresh = false;
   {
     Scope sc(f, LSQAMD_T_RESIDUAL);
-    ModelArgs m = model_args(f, p);
-    HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
-    if (f->have_param_rows)
-      HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, 1, p, f->ymean, f->wdiag,
-                                  f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->r, f->r_raw, 0));
-    if (f->cfg.n_blocks > 0) {
-      // small blocks: one thread per output row; large ones (a single 8192-row block would keep
-      // 32 workgroups busy for milliseconds): r_b = Wt_b^T delta_b as a two-stage column sum at
-      // HBM speed, staged through the raw-Jacobian buffer (idle during a residual evaluation)
-      constexpr int64_t BIG = 1024;
-      HIPCHK(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff,
-                                        f->cfg.n_blocks, f->cfg.max_block, f->r_raw, f->r, 1, 0, nullptr, BIG));
-      for (size_t b = 0; b < f->h_size.size(); ++b) {
-        const int64_t B = f->h_size[b];
-        if (B < BIG) continue;
-        int64_t nch = (f->N * f->ld) / B;
-        if (nch > 256) nch = 256;
-        HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->Jraw, nch,
-                                    f->r + f->h_row0[b], f->r_raw + f->h_row0[b]));
-      }
-    }
+    const int rc = residual_vector_launch(f, p);
+    if (rc) return rc;
     HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, f->red_scalar));
     if (f->cfg.has_prior && f->adds_prior)
       HIPCHK(f, launch_prior_chi2(f->st, f->P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, p,
@@ -344,17 +352,49 @@ int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks) {
 // J, J^T J (packed), J^T f, chi2 at device parameters p; host g/chi2/colnorm refreshed
 int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   const int64_t P = f->P;
-  {
-    Scope sc(f, LSQAMD_T_JACOBIAN);
-    ModelArgs m = model_args(f, p);
-    HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
-    if (f->have_param_rows)
-      HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, f->ld, p, f->ymean, f->wdiag,
-                                  f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->J, f->Jraw, 1));
-  }
   int64_t fused_chunks = 0;
-  int rc = whiten_jacobian(f, &fused_chunks);
-  if (rc) return rc;
+  int rc = 0;
+  const bool r_here = f->r_fresh && f->r_ptr == p;
+  f->r_fresh = false;
+  const int nbk = f->cfg.n_blocks;
+  const int64_t B0 = nbk > 0 ? f->h_size[0] : 0;
+  const int64_t slab_doubles = (int64_t)f->splits * P * f->ldm;
+  if (nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
+      f->h_row0[0] == 0 && (int64_t)nbk * B0 == f->N && whiten_synth_eligible(f->cfg.model, B0, P) &&
+      (int64_t)nbk * (B0 / 128) * P <= slab_doubles) {
+    // the raw Jacobian rows are synthesised inside the whitening product (never written, never re-read);
+    // the whitened residual -- column P, and the weights of the fused J^T f -- is the one the trial
+    // evaluation just left in f->r when this IS the trial point, else it is evaluated here
+    {
+      Scope sc(f, LSQAMD_T_JACOBIAN);
+      if (!r_here) {
+        rc = residual_vector_launch(f, p);
+        if (rc) return rc;
+      }
+      HIPCHK(f, launch_copy_strided(f->st, f->r, 1, f->J + P, f->ld, f->N, 1));
+    }
+    Scope sc(f, LSQAMD_T_WHITEN);
+    WhitenSynth w;
+    w.model = f->cfg.model; w.Wt = f->wt; w.x = f->x; w.p = p; w.J = f->J; w.ld = f->ld;
+    w.B = B0; w.K = P / 2; w.nb = nbk; w.colsum_out = f->slabs;
+    HIPCHK(f, launch_whiten_synth(f->st, w));
+    f->used_synth = true;
+    fused_chunks = (int64_t)nbk * (B0 / 128);
+    double *gv = f->redbuf + f->npk;
+    HIPCHK(f, launch_colsum_reduce(f->st, f->slabs, fused_chunks, P, gv));
+    HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, gv + P));
+  } else {
+    {
+      Scope sc(f, LSQAMD_T_JACOBIAN);
+      ModelArgs m = model_args(f, p);
+      HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
+      if (f->have_param_rows)
+        HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, f->ld, p, f->ymean, f->wdiag,
+                                    f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->J, f->Jraw, 1));
+    }
+    rc = whiten_jacobian(f, &fused_chunks);
+    if (rc) return rc;
+  }
   {
     Scope sc(f, LSQAMD_T_SYRK);
     GemmTN g;
@@ -851,6 +891,8 @@ int iterate_device(lsqamd_fit *f) {
     HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
     rc = eval_residual_launch(f, f->p_trial);
     if (rc) return rc;
+    f->r_fresh = true;      // f->r is the whitened residual AT p_trial (used if the trial is accepted)
+    f->r_ptr = f->p_trial;
     HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
     HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
     HIPCHK(f, hipStreamSynchronize(f->st));
@@ -1941,7 +1983,8 @@ void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long 
 // introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;
-  return (int64_t)(f->uniform_blocks ? 1 : 0) | ((int64_t)f->splits << 8) | ((int64_t)f->h_size.size() << 32);
+  return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | ((int64_t)f->splits << 8) |
+         ((int64_t)f->h_size.size() << 32);
 }
 
 int lsqamd_timing_enable(lsqamd_fit *f, int32_t on) {

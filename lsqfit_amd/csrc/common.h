@@ -40,6 +40,20 @@ struct GemmTN {
 // true when launch_gemm_tn would take the kernel that honours colsum_out for this call
 bool gemm_tn_fuses_colsum(const GemmTN &g);
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
+// Jacobian rows of a sum model synthesised INSIDE the whitening product (gemm_tn_f64.hip):
+//   J_b = W_b x [d f / d p] for nb uniform triangular blocks of B rows, raw rows never written.
+struct WhitenSynth {
+  int32_t model = 0;            // LSQAMD_MODEL_COSMIX | _MULTIEXP
+  const double *Wt = nullptr;   // [nb][B][B] transposed weights (upper triangular)
+  const double *x = nullptr;    // [nb * B] predictor of every row (n_x = 1)
+  const double *p = nullptr;    // [2 K] device parameters
+  double *J = nullptr;          // [nb * B][ld] output rows; column P = 2 K holds the whitened residual already
+  int64_t ld = 0, B = 0, K = 0;
+  int32_t nb = 0;
+  double *colsum_out = nullptr; // [(b * B / 128 + tm)][2 K]: per-tile-row pieces of J^T f
+};
+bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P);
+hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a);
 int64_t syrk_work_count(int64_t P, int32_t splits);
 void syrk_work_fill(int64_t P, int32_t splits, int32_t *out);
 

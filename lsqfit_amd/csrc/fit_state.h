@@ -97,6 +97,10 @@ struct lsqamd_fit {
   // plain lm keeps its vectors on the device (api.hip iterate_device): the host mirrors hx / hg /
   // hdiag / hcoln / hv / hdx are refreshed on demand (refresh_mirrors)
   bool dev_lm = false, mirrors_stale = false;
+  // f->r holds the whitened residual AT r_ptr's current contents (set by iterate_device right before
+  // the accepted point's normal equations, consumed there: the fused Jacobian path needs it)
+  bool r_fresh = false, used_synth = false;
+  const double *r_ptr = nullptr;
   int32_t conv_info_dev = 0;
   bool initialised = false, have_cov = false, have_dense_A = false;
   int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;

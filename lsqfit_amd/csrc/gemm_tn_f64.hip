@@ -29,6 +29,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "devmath.h"
 
 namespace lsqamd {
 
@@ -889,6 +890,160 @@ void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
             if (tn < tm) continue;
             out[o++] = tm; out[o++] = tn; out[o++] = s; out[o++] = 0;
           }
+}
+
+// ---- whitening product with the raw Jacobian rows synthesised in LDS ---------------------------------
+// J_b = W_b x Jraw_b for the sum models, the Y operand (16 raw rows x 128 columns per stage) computed
+// by the workgroup instead of being read: the raw Jacobian (2.15 GB at the named shape) is neither
+// written nor re-read.  Same tile, staging order and MFMA sequence as
+// gemm_tn_f64_interior_kernel<true, false> -- the whitened rows come out bit-identical to the
+// two-kernel route -- with the 128 tile columns = 64 terms k and their 64 partners K + k
+// (value columns and frequency / exponent columns of the same terms share the sincos / exp):
+//   thread t: term c = t & 63, stage rows t >> 6, + 4, + 8, + 12  ->  4 transcendental pairs per stage.
+// fp64 VALU and fp64 MFMA share the datapath, so this work adds to the MFMA time (about a quarter)
+// instead of hiding behind it; what is saved is the Jacobian kernel and 4.3 GB of traffic.
+template <int MODEL>
+__global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int64_t b = blockIdx.z;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t ke = m0 + BM;                     // X[k][m] = 0 for k > m
+  const double *Xb = a.Wt + b * a.B * a.B;
+  const double *xrow = a.x + b * a.B;
+  double *C = a.J + b * a.B * a.ld;
+  const int sc = tid & 63, srow = tid >> 6;       // synthesis: term within the tile, first stage row
+  const double amp = a.p[(int64_t)tn * 64 + sc], frq = a.p[a.K + (int64_t)tn * 64 + sc];
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const double *xp = Xb + (int64_t)wave * a.B + m0 + 2 * lane;
+  const int64_t xstep = 4 * a.B;
+  int64_t ksyn = 0;
+  auto stage = [&](int buf) {
+    double *Xs = smem + buf * STAGE + wave * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
+    xp += 4 * xstep;
+    double *Ys = smem + buf * STAGE + BK * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 4 * i;
+      const double xv = xrow[ksyn + row];
+      double t, dq;
+      if (MODEL == LSQAMD_MODEL_COSMIX) {
+        double sn, cs;
+        sincos_moderate(frq * xv, &sn, &cs);
+        t = cs;
+        dq = -amp * xv * sn;
+      } else {
+        const double e = exp(-frq * xv);
+        t = e;
+        dq = -amp * xv * e;
+      }
+      Ys[row * LDT + sc] = t;
+      Ys[row * LDT + 64 + sc] = dq;
+    }
+    ksyn += BK;
+  };
+  const double wreg = (tid < BM) ? C[(m0 + tid) * a.ld + 2 * a.K] : 0.0;   // whitened residual of this tile's rows
+  const int fr = lane & 15, fq = lane >> 4;
+  stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = 0; k0 < ke; k0 += BK) {
+    if (k0 + BK < ke) stage(cur ^ 1);
+    const double *Xs = smem + cur * STAGE;
+    const double *Ys = Xs + BK * LDT;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double av[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) av[i] = Xs[kr * LDT + (2 * i + wm) * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (k0 + kk * 4 > m0 + (2 * i + wm) * 16 + 15) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  double *wcol = smem, *red = smem + 128;
+  if (tid < BM) wcol[tid] = wreg;
+  __syncthreads();
+  // tile column (wn, j, fr)  ->  Jacobian column: the value half (wn = 0) or the partner half at K + ..
+  const int64_t cbase = (wn ? a.K : 0) + (int64_t)tn * 64;
+  double sj[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rloc = (2 * i + wm) * 16 + fq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double w = wcol[rloc + 4 * r];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = acc[i][j][r];
+        C[(m0 + rloc + 4 * r) * a.ld + cbase + j * 16 + fr] = v;
+        sj[j] += v * w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sj[j] += __shfl_xor(sj[j], 16, 64);
+    sj[j] += __shfl_xor(sj[j], 32, 64);
+  }
+  if (fq == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[wave * 64 + j * 16 + fr] = sj[j];
+  }
+  __syncthreads();
+  if (wm == 0 && fq == 0) {
+    double *out = a.colsum_out + (b * tiles_m + tm) * (2 * a.K) + cbase;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j * 16 + fr] = red[wave * 64 + j * 16 + fr] + red[(wave + 2) * 64 + j * 16 + fr];
+  }
+}
+
+bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P) {
+  static const bool off = [] { const char *e = getenv("LSQAMD_FUSED_JACOBIAN"); return e && e[0] == '0'; }();
+  return !off && (model == LSQAMD_MODEL_COSMIX || model == LSQAMD_MODEL_MULTIEXP) && B >= BM && B % BM == 0 &&
+         P % 128 == 0 && P >= 128;
+}
+
+hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  const int tiles_m = (int)(a.B / BM), tiles_n = (int)(a.K / 64);
+  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)a.nb);
+  if (a.model == LSQAMD_MODEL_COSMIX)
+    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX>), grid, dim3(256), GEMM_LDS_BYTES, st, a, tiles_m, tiles_n);
+  else
+    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>), grid, dim3(256), GEMM_LDS_BYTES, st, a, tiles_m, tiles_n);
+  return hipGetLastError();
 }
 
 }  // namespace lsqamd

@@ -25,6 +25,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "devmath.h"
 
 namespace lsqamd {
 
@@ -32,37 +33,6 @@ __device__ __forceinline__ double wave_sum_all(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
-}
-
-// sin and cos of a moderate argument (|t| < 1e5; here t = w_k x_i <= a few 10^4): two-constant
-// Cody-Waite reduction by pi/2 with FMAs (the product n * PIO2_HI is formed exactly inside the
-// FMA), then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error ~1e-16; about a third of
-// the instructions of the general-range library sincos, which remains the fallback for huge t.
-__device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs) {
-  if (!(fabs(t) < 1.0e5)) {
-    sincos(t, sn, cs);
-    return;
-  }
-  const double n = rint(t * 6.36619772367581382433e-01);      // 2/pi
-  double r = __builtin_fma(-n, 1.57079632679489655800e+00, t);   // pi/2 = HI + MID + ...
-  r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
-  const double z = r * r;
-  const double ps = -1.66666666666666324348e-01 +
-                    z * (8.33333333332248946124e-03 +
-                         z * (-1.98412698298579493134e-04 +
-                              z * (2.75573137070700676789e-06 +
-                                   z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
-  const double pc = 4.16666666666666019037e-02 +
-                    z * (-1.38888888888741095749e-03 +
-                         z * (2.48015872894767294178e-05 +
-                              z * (-2.75573143513906633035e-07 +
-                                   z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
-  const double s = __builtin_fma(r * z, ps, r);
-  const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-  const int q = (int)n & 3;
-  const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
-  *sn = (q & 2) ? -s1 : s1;
-  *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
 struct ModelDev {
