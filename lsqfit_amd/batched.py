@@ -40,6 +40,8 @@ class BatchedFits:
                 yerr = np.broadcast_to(yerr, ymean.shape)
             whitening = Whitening(ymean, yerr, svdcut=svdcut)
         self.wh = wh = whitening
+        if getattr(wh, 'perm', None) is not None:
+            raise NotImplementedError('BatchedFits: covariance components that interleave; reorder the data rows')
         row0, size, modes, tri, wt = wh.block_arrays()
         self.has_prior = prior_mean is not None
         self.prior_dense = prior_prec is not None

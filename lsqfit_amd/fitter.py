@@ -82,6 +82,14 @@ class DeviceProblem:
             xe[whitening.model_rows] = np.asarray(x, np.float64).reshape(whitening.n_model, model.n_x)[
                 whitening.row_src[whitening.model_rows]]
             x = xe
+        self.perm = None if joint else getattr(whitening, 'perm', None)
+        if self.perm is not None:
+            # interleaved covariance components: the whitening reordered the rows; x follows
+            if rows is not None:
+                raise ValueError('row sharding is not available for interleaved covariance components')
+            if model.kind == MODEL_IDENTITY:
+                raise ValueError('identity model with interleaved covariance components: reorder the data')
+            x = np.asarray(x, np.float64).reshape(whitening.n_data, model.n_x)[self.perm]
         self.rows = (a, b)
         N = b - a
         P = model.n_param
@@ -175,6 +183,8 @@ class DeviceProblem:
 
     def set_ymean(self, ymean):
         """New data means for this problem's rows (same covariance)."""
+        if self.perm is not None and np.size(ymean) == self.wh.n_data:
+            ymean = np.asarray(ymean, np.float64).reshape(-1)[self.perm]
         ymean = np.ascontiguousarray(np.asarray(ymean, np.float64).reshape(-1)[self.rows[0]:self.rows[1]]
                                      if np.size(ymean) == self.wh.n_data else ymean, np.float64)
         if ymean.size != self.N:
@@ -186,6 +196,10 @@ class DeviceProblem:
         p = np.ascontiguousarray(p, np.float64)
         out = np.empty(self.N)
         _check(self.lib, self.h, self.lib.lsqamd_eval_fcn(self.h, _lib.dptr(p), _lib.dptr(out), out.size), 'eval_fcn')
+        if self.perm is not None:
+            back = np.empty_like(out)
+            back[self.perm] = out
+            return back
         return out
 
     def set_reduce(self, hook):

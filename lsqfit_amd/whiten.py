@@ -26,8 +26,9 @@ consumes through ``lsqamd_set_data`` / ``lsqamd_set_prior``:
   * ``logdet`` (= log det of the regulated covariance), ``nmod`` (svdn),
     ``nblocks``, ``nchiv``.
 
-Blocks must be contiguous row ranges (true for every layout the benchmark and
-the reference's example fixtures use).  Data-prior cross-correlations
+Blocks are the connected components of the covariance pattern, as gvar's; components that
+interleave are made contiguous by a row permutation (``Whitening.perm``) that DeviceProblem applies
+to x and un-does in its row-ordered outputs.  Data-prior cross-correlations
 (examples/y-noerr.py) go through :func:`joint_whitening`: concat(y, prior) is
 whitened as ONE vector, exactly as the reference does, and the prior entries
 travel to the device as extra "parameter rows" (lsqamd_set_param_rows).
@@ -204,43 +205,34 @@ def _extreme_eigs(corr, L, iters=40):
 
 
 def _as_blocks(err, n):
-    """Normalise an error spec to (sdev[n], [(row0, cov_block), ...]).
+    """Normalise an error spec to (sdev[n], [(row0, cov_block), ...], perm): ``perm`` is None, or the
+    order (new position -> original index) in which sdev and the block offsets are given.
 
     err: sdev vector | dense cov (n x n, split at zero off-diagonal bands) |
          dict(sdev=..., blocks=[(row0, cov), ...])."""
     if isinstance(err, dict):
         sd = np.array(err['sdev'], float).reshape(-1)
         blocks = [(int(r0), np.asarray(c, float)) for r0, c in err.get('blocks', [])]
-        return sd, blocks
+        return sd, blocks, None
     err = np.asarray(err, float)
     if err.ndim <= 1:
-        return err.reshape(-1) * np.ones(n), []
+        return err.reshape(-1) * np.ones(n), [], None
     if err.shape != (n, n):
         raise ValueError('covariance must be %d x %d' % (n, n))
     sd = np.sqrt(np.diag(err))
-    # connected components of the off-diagonal pattern must be contiguous ranges
-    nz = err != 0.0
-    reach = np.arange(n)
-    for i in range(n):
-        js = np.nonzero(nz[i])[0]
-        if js.size:
-            reach[i] = max(reach[i], js[-1])
-    blocks = []
-    i = 0
-    while i < n:
-        end = reach[i]
-        j = i
-        while j <= end:
-            end = max(end, reach[j])
-            j += 1
-        B = end - i + 1
-        if B > 1:
-            blk = err[i:end + 1, i:end + 1]
-            # a contiguous range that is not fully connected would be split by gvar;
-            # keeping it whole changes nothing numerically when svdcut touches no mode
-            blocks.append((i, blk))
-        i = end + 1
-    return sd, blocks
+    # gvar.evalcov_blocks: one block per connected component of the off-diagonal pattern
+    # (tests/test_lsqfit.py:1011-1012,1047-1050).  Components that interleave (rows 0 and 5 correlated,
+    # rows 1-4 not) are made contiguous by a permutation the caller applies to its rows.
+    comps = _components(err)
+    if all(int(c[-1]) - int(c[0]) + 1 == c.size for c in comps):
+        return sd, [(int(c[0]), err[c[0]:c[-1] + 1, c[0]:c[-1] + 1]) for c in comps if c.size > 1], None
+    perm = np.concatenate(comps)
+    blocks, r0 = [], 0
+    for c in comps:
+        if c.size > 1:
+            blocks.append((r0, err[np.ix_(c, c)]))
+        r0 += c.size
+    return sd[perm], blocks, perm
 
 
 class Whitening:
@@ -255,9 +247,13 @@ class Whitening:
         self.eps = None
         self.ymean = np.array(ymean, float).reshape(-1)
         N = self.ymean.size
-        ysd, yblocks = _as_blocks(yerr, N)
+        ysd, yblocks, self.perm = _as_blocks(yerr, N)
         if udata:
             yblocks = []                      # __init__.py:1892-1893
+            if self.perm is not None:
+                ysd, self.perm = ysd[np.argsort(self.perm)], None
+        if self.perm is not None:             # interleaved components: rows reordered, device and all
+            self.ymean = self.ymean[self.perm]
         self.logdet = 0.0
         self.nmod = 0
         self.nblocks = {}
@@ -293,8 +289,15 @@ class Whitening:
         if self.has_prior:
             pm = np.array(prior_mean, float).reshape(-1)
             P = pm.size
-            psd, pblocks = _as_blocks(prior_err, P)
+            psd, pblocks, pperm = _as_blocks(prior_err, P)
+            pidx = np.arange(P) if pperm is None else pperm      # position in (psd, pblocks) -> parameter
+            if pperm is not None:
+                psd_full = np.empty(P)
+                psd_full[pperm] = psd
+            else:
+                psd_full = psd
             self.prior_mean = pm
+            psd = psd_full
             if not pblocks:
                 if np.any(psd <= 0):
                     raise ValueError('some priors have zero standard deviations')
@@ -310,9 +313,9 @@ class Whitening:
                 for (r0, cov), reg in zip(pblocks, regulate_blocks([c for _, c in pblocks], svdcut,
                                                                    want_prec=True, engine=engine)):
                     B = cov.shape[0]
-                    reg.update(row0=int(r0), size=int(B))
+                    reg.update(row0=int(r0), size=int(B), idx=pidx[r0:r0 + B])
                     self.prior_blocks.append(reg)
-                    pin[r0:r0 + B] = True
+                    pin[reg['idx']] = True
                     self.logdet += reg['logdet']
                     self.nmod += reg['nmod']
                     self.nblocks[B] = self.nblocks.get(B, 0) + 1
@@ -325,7 +328,7 @@ class Whitening:
                 n1 += dd.size
                 nprior += dd.size
                 k0 = self.prior_blocks[0]
-                if len(self.prior_blocks) == 1 and k0['size'] == P and 'prec_dev' in k0:
+                if len(self.prior_blocks) == 1 and k0['size'] == P and 'prec_dev' in k0 and pperm is None:
                     self.prior_prec_dev = k0['prec_dev']      # one block over all parameters: stays in HBM
             self.prior_sdev = psd
         if n1:
@@ -340,12 +343,12 @@ class Whitening:
             P = self.prior_mean.size
             prec = np.zeros((P, P))
             for k in self.prior_blocks:
-                r0, B = k['row0'], k['size']
+                ix = np.ix_(k['idx'], k['idx'])
                 if 'prec_dev' in k:
-                    prec[r0:r0 + B, r0:r0 + B] = k['prec']
+                    prec[ix] = k['prec']
                 else:
                     W = k['Wt'].T[:k['modes']]
-                    prec[r0:r0 + B, r0:r0 + B] = W.T @ W
+                    prec[ix] = W.T @ W
             dd, sd = self._prior_diag
             prec[dd, dd] = 1.0 / sd ** 2
             self._prior_prec = prec
@@ -371,14 +374,14 @@ class Whitening:
         for k in self.prior_blocks:
             W = k['Wt'].T[:k['modes']]
             full = np.zeros((W.shape[0], P))
-            full[:, k['row0']:k['row0'] + k['size']] = W
+            full[:, k['idx']] = W
             Wrows.append(full)
         return ('dense', diag_rows, Wrows)
 
     @property
     def prior_S(self):
         """[(indices, sampling factor)]: S S^T = regulated prior covariance."""
-        out = [(np.arange(k['row0'], k['row0'] + k['size']), k['S']) for k in self.prior_blocks]
+        out = [(k['idx'], k['S']) for k in self.prior_blocks]
         dd, sd = self._prior_diag
         if dd.size:
             out.append((dd, sd))
@@ -475,7 +478,10 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12):
         raise ValueError('cross must be the %d x %d covariance between data and prior' % (N, P))
 
     def dense(err, n):
-        sd, blocks = _as_blocks(err, n)
+        err_a = None if isinstance(err, dict) else np.asarray(err, float)
+        if err_a is not None and err_a.ndim == 2:
+            return err_a.copy()
+        sd, blocks, _ = _as_blocks(err, n)
         c = np.diag(sd ** 2)
         for r0, b in blocks:
             c[r0:r0 + b.shape[0], r0:r0 + b.shape[0]] = b

@@ -1,0 +1,68 @@
+"""-m gpu: data (and prior) whose covariance components interleave -- rows 1, 4, 9, 10 correlated with
+each other and with nothing between them.  gvar's block search returns index sets
+(tests/test_lsqfit.py:1011-1012); the whitening makes each set contiguous by a row permutation and
+the device problem follows it.  Checked against the oracle, which works on index sets directly."""
+import numpy as np
+import pytest
+
+from oracle import fit as ofit
+from tests import gpu_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+def _scatter_blocks(rng, n, sets, floor):
+    cov = np.diag(rng.uniform(0.05, 0.2, n) ** 2)
+    for idx in sets:
+        B = len(idx)
+        sd = np.sqrt(cov[idx, idx])
+        A = rng.standard_normal((B, B))
+        corr = A @ A.T + floor * B * np.eye(B)
+        d = np.sqrt(np.diag(corr))
+        cov[np.ix_(idx, idx)] = corr / np.outer(d, d) * np.outer(sd, sd)
+    return cov
+
+
+@pytest.mark.parametrize('svdcut', [1e-12, 1e-2])
+def test_fit_with_interleaved_components_matches_oracle(amd, svdcut):
+    rng = np.random.default_rng(23)
+    K, N = 3, 96
+    P = 2 * K
+    x = np.sort(rng.uniform(0.0, 3.0, N))
+    ptrue = np.concatenate([[1.0, 0.6, 0.3], [1.1, 2.3, 3.9]])
+    ysets = [list(range(1, N, 7)), [2, 3, 52, 53, 90], list(range(5, 40, 11))]
+    ycov = _scatter_blocks(rng, N, ysets, 0.02 if svdcut < 1e-6 else 1e-4)
+    psets = [[0, 3], [1, 5]]
+    pcov = _scatter_blocks(rng, P, psets, 0.5) * 25.0
+    f = gu.cosmix_fcn(x, ptrue)
+    ymean = f + np.linalg.cholesky(ycov) @ rng.standard_normal(N)
+    pmean = ptrue + 0.05 * rng.standard_normal(P)
+    model = amd.cosmix(K)
+    fit = amd.nonlinear_fit(data=(x, ymean, ycov), model=model, prior=(pmean, pcov), p0=pmean, svdcut=svdcut,
+                            tol=1e-10)
+    wh = fit.whitening
+    assert wh.perm is not None and sorted(b['size'] for b in wh.blocks) == sorted(len(s) for s in ysets)
+    ref = ofit.nonlinear_fit(x, ymean, ycov, gu.cosmix_fcn, prior_mean=pmean, prior_err=pcov, p0=pmean, tol=1e-10,
+                             svdcut=svdcut, jac=gu.cosmix_jac, solver='cholesky')
+    assert (fit.dof, wh.nmod, wh.nblocks) == (ref.dof, ref.pdf.nmod, ref.pdf.nblocks)
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-8)
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    # row-ordered outputs come back in the caller's order
+    np.testing.assert_allclose(fit.problem.fcn(fit.pmean), gu.cosmix_fcn(x, fit.pmean), rtol=1e-12, atol=1e-13)
+    D, Dref = fit.dp_dinputs(), ofit.dp_dinputs(ref)
+    assert D.shape == Dref.shape and gu.relmax(D, Dref) < 1e-6
+    pts = fit.pmean + 1e-3 * rng.standard_normal((4, P))
+    np.testing.assert_allclose(fit.dchi2(pts), [ofit.dchi2(ref, q) for q in pts], rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        fit.simulated_fits(2)
+    with pytest.raises(ValueError):
+        amd.DeviceProblem(model, x, wh, rows=(0, 48))

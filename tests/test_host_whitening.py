@@ -234,3 +234,49 @@ def test_joint_whitening_of_correlated_data_and_prior():
     assert chi2 == pytest.approx(float(delta @ np.linalg.solve(full, delta)), rel=1e-10)
     sign, ld = np.linalg.slogdet(full)
     assert wh.logdet == pytest.approx(ld, rel=1e-10)
+
+
+def _interleaved_cov(rng, N):
+    """Components {1,4,9,10}, {2,7}, {5,6,13} (the first nearly singular); everything else 1x1."""
+    cov = np.diag(rng.uniform(0.5, 2.0, N) ** 2)
+    for idx, small in (([1, 4, 9, 10], 1e-5), ([2, 7], 0.3), ([5, 6, 13], 0.2)):
+        B = len(idx)
+        Q, _ = np.linalg.qr(rng.standard_normal((B, B)))
+        ev = np.concatenate([np.linspace(2.0, 0.5, B - 1), [small]])
+        cov[np.ix_(idx, idx)] = (Q * ev) @ Q.T
+    return cov
+
+
+@pytest.mark.parametrize('svdcut', [1e-12, 1e-3, -1e-3])
+def test_interleaved_components_are_whitened_through_a_permutation(svdcut):
+    """gvar's block search returns index sets, not ranges (tests/test_lsqfit.py:1011-1012): the
+    whitening reorders the rows so each set is contiguous and must agree with the oracle PDF, for
+    the data and for the prior."""
+    rng = np.random.default_rng(17)
+    N, P = 16, 14
+    cov = _interleaved_cov(rng, N)
+    pcov = _interleaved_cov(rng, 16)[:P, :P]          # prior components {1,4,9,10}, {2,7}, {5,6,13}
+    ymean, pmean = rng.standard_normal(N), rng.standard_normal(P)
+    wh = Whitening(ymean, cov, pmean, pcov, svdcut=svdcut)
+    pdf = ofit.build_pdf(ymean, cov, pmean, pcov, svdcut=svdcut)
+    assert wh.perm is not None and sorted(wh.perm) == list(range(N))
+    assert [b['size'] for b in wh.blocks] == [4, 2, 3]
+    np.testing.assert_array_equal(wh.ymean, ymean[wh.perm])
+    assert (wh.nchiv, wh.nmod, wh.nblocks) == (pdf.nchiv, pdf.nmod, pdf.nblocks)
+    assert wh.logdet == pytest.approx(pdf.logdet, rel=1e-10, abs=1e-9)
+    full = pdf.icov()
+    ic = np.empty((N, N))
+    ic[np.ix_(wh.perm, wh.perm)] = icov_from_whitening(wh)        # back to the caller's row order
+    scale = np.abs(full).max()
+    np.testing.assert_allclose(ic, full[:N, :N], rtol=1e-7, atol=1e-9 * scale)
+    np.testing.assert_allclose(wh.prior_prec, full[N:, N:], rtol=1e-7, atol=1e-9 * scale)
+    kind, drows, brows = wh.prior_W
+    W = np.vstack([drows] + brows)
+    np.testing.assert_allclose(W.T @ W, full[N:, N:], rtol=1e-7, atol=1e-9 * scale)
+    Cs = np.zeros((P, P))
+    for idx, S in wh.prior_S:                          # S S^T = the regulated covariance, in place
+        Cs[np.ix_(idx, idx)] = S @ S.T if np.ndim(S) == 2 else np.diag(S ** 2)
+    if svdcut > 0:
+        np.testing.assert_allclose(Cs @ full[N:, N:], np.eye(P), atol=1e-6)
+    # contiguous layouts are untouched
+    assert Whitening(ymean, np.diag(np.diag(cov)), pmean, np.sqrt(np.diag(pcov))).perm is None
