@@ -29,6 +29,8 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <type_traits>
+#include <vector>
 #include "devmath.h"
 
 namespace lsqamd {
@@ -49,6 +51,7 @@ struct GemmDev {
   int64_t sx, sy, sc;
   int32_t tiles_n, upper_only, x_upper_tri, xy_lower_tri, splits;
   int32_t tiles_m, pair_rows;
+  int32_t syrk_diag;     // WORKMAP launch with X == Y: diagonal tiles take the triangular schedule (see kernel)
   int32_t vec_x, vec_y;  // operand rows are 16-byte aligned -> dwordx4 loads
   int64_t kchunk, split_stride;
   const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
@@ -238,6 +241,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
 // while the upper half idles; interleaved, the busier wave row does 62 %.
 // WORKMAP: the split-K J^T J launch (XCD-aware work list).  A separate instantiation so that it
 // shows up under its own name in kernel traces (the Cholesky's trailing updates use <false, false>).
+// Diagonal tiles of that launch (X == Y, tm == tn) are symmetric: the lower-left 64 x 64 quadrant is
+// the transpose of the upper-right one and the 16 x 16 sub-tiles below the diagonal of the two
+// diagonal quadrants repeat the ones above.  Schedule: waves 0 and 3 compute the 10 sub-tiles
+// i <= j of their quadrants, waves 1 and 2 each take two 16-row strips of the upper-right quadrant
+// (8 sub-tiles), i.e. at most 10 MFMAs per k-step and wave instead of 16, the Y tile is not staged
+// (it is the X tile), and the epilogue writes every value to (row, col) and (col, row): the tile in
+// the slab is bit-identical to the one the full schedule writes (same products, same k order).
 template <bool XTRI, bool WORKMAP>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -286,6 +296,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
+  const bool diag = WORKMAP && !XTRI && g.syrk_diag && tm == tn;
+  // tile rows / columns of this wave's 16-wide strips: strip i -> rows arow0 + 16 i, strip j -> columns bcol0 + 16 j
+  const int arow0 = diag ? (wave == 2 ? 32 : (wave == 3 ? 64 : 0)) : wm * 64;
+  const int bcol0 = diag ? (wave == 0 ? 0 : 64) : wn * 64;
+
   // wave w stages rows w, w+4, w+8, w+12 of both tiles; lane -> 2 columns
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
@@ -296,10 +311,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   auto stage = [&](int buf) {
     double *Xs = smem + buf * STAGE + wave * LDT;
     double *Ys = Xs + BK * LDT;
+    if (diag) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void *)(yp + i * ystep), (lds_void *)(Ys + 4 * i * LDT), 16, 0, 0);
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void *)(yp + i * ystep), (lds_void *)(Ys + 4 * i * LDT), 16, 0, 0);
+      }
     }
     xp += 4 * xstep;
     yp += 4 * ystep;
@@ -312,31 +333,61 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const int fr = lane & 15, fq = lane >> 4;
   if (kb < ke) stage(0);
   __syncthreads();
-  int cur = 0;
-  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
-    if (k0 + BK < ke) stage(cur ^ 1);
-    const double *Xs = smem + cur * STAGE;
-    const double *Ys = Xs + BK * LDT;
+  // ROLE 0: all 16 sub-tiles; 1: sub-tiles i <= j (diagonal quadrant of a diagonal tile); 2: strips i < 2
+  auto kloop = [&](auto role_tag) {
+    constexpr int ROLE = decltype(role_tag)::value;
+    int cur = 0;
+    for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+      if (k0 + BK < ke) stage(cur ^ 1);
+      const double *Xs = smem + cur * STAGE;
+      const double *Ys = ROLE == 0 ? Xs + BK * LDT : Xs;
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      const int kr = kk * 4 + fq;
-      double a[4], bb[4];
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        const int kr = kk * 4 + fq;
+        double a[4], bb[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = Xs[kr * LDT + (XTRI ? (2 * i + wm) * 16 : wm * 64 + i * 16) + fr];
+        for (int i = 0; i < (ROLE == 2 ? 2 : 4); ++i)
+          a[i] = Xs[kr * LDT + (XTRI ? (2 * i + wm) * 16 : arow0 + i * 16) + fr];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + wn * 64 + j * 16 + fr];
+        for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + bcol0 + j * 16 + fr];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        // X[k][m] = 0 for k > m: strip rows m0 + 16 s .. + 15 see nothing from k-steps beyond them
-        if (XTRI && k0 + kk * 4 > m0 + (2 * i + wm) * 16 + 15) continue;
+        for (int i = 0; i < (ROLE == 2 ? 2 : 4); ++i) {
+          // X[k][m] = 0 for k > m: strip rows m0 + 16 s .. + 15 see nothing from k-steps beyond them
+          if (XTRI && k0 + kk * 4 > m0 + (2 * i + wm) * 16 + 15) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+          for (int j = (ROLE == 1 ? i : 0); j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  };
+  if (WORKMAP && !XTRI && diag) {
+    if (wave == 0 || wave == 3) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 2>{});
+    // epilogue of a diagonal tile: each value to (row, col) and to its mirror image
+    const double alpha = g.alpha;
+    const bool tri = wave == 0 || wave == 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!tri && i >= 2) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (tri && j < i) continue;
+        const int64_t col = n0 + bcol0 + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + arow0 + i * 16 + fq + 4 * r;
+          const double v = alpha * acc[i][j][r];
+          C[row * g.ldc + col] = v;
+          if (!(tri && i == j)) C[col * g.ldc + row] = v;
+        }
       }
     }
-    __syncthreads();
-    cur ^= 1;
+    continue;
   }
+  kloop(std::integral_constant<int, 0>{});
 
   const double alpha = g.alpha;
   const double beta = g.splits > 1 ? 0.0 : g.beta;
@@ -795,6 +846,8 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
   g.work_map = a.work_map;
   g.n_work = a.n_work;
+  static const bool diag_off = [] { const char *e = getenv("LSQAMD_SYRK_DIAG"); return e && atoi(e) == 0; }();  // developer knob
+  g.syrk_diag = a.work_map && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy && a.M == a.N && g.splits > 1 && !diag_off;
   g.batch_active = a.batch_active;
   g.colsum_out = a.colsum_out;
   g.colsum_ld = a.colsum_ld;
@@ -872,7 +925,10 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
 
 // Work list for the upper-triangular tiles of a P x P SYRK with `splits` K-chunks:
 // split-major, then 8 x 8 patches of tiles, then tiles of the patch.  Consecutive
-// entries share row/column panels AND the K-chunk.
+// entries share row/column panels AND the K-chunk.  Within the run of entries each XCD walks (the
+// kernel's blockIdx -> entry map: eight contiguous runs) the diagonal tiles go LAST: they take 10/16
+// of the time of the others (triangular schedule), so the round of workgroups that drains each XCD
+// is the short one.
 int64_t syrk_work_count(int64_t P, int32_t splits) {
   const int64_t T = (P + BM - 1) / BM;
   return T * (T + 1) / 2 * (splits < 1 ? 1 : splits);
@@ -890,6 +946,19 @@ void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
             if (tn < tm) continue;
             out[o++] = tm; out[o++] = tn; out[o++] = s; out[o++] = 0;
           }
+  const int64_t nw = o / 4, q = nw / 8, r = nw % 8;
+  std::vector<int32_t> tmp;
+  for (int xcd = 0; xcd < 8; ++xcd) {
+    const int64_t b = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, n = q + (xcd < r ? 1 : 0);
+    tmp.assign(out + 4 * b, out + 4 * (b + n));
+    int64_t w = b;
+    for (int keep = 0; keep < 2; ++keep)          // stable: off-diagonal entries, then diagonal ones
+      for (int64_t e = 0; e < n; ++e)
+        if ((tmp[4 * e] == tmp[4 * e + 1]) == (keep == 1)) {
+          for (int c = 0; c < 4; ++c) out[4 * w + c] = tmp[4 * e + c];
+          ++w;
+        }
+  }
 }
 
 // ---- whitening product with the raw Jacobian rows synthesised in LDS ---------------------------------

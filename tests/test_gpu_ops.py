@@ -171,3 +171,41 @@ def test_gemm_tn_rejects_unsafe_in_place(env):
     rc = lib.lsqamd_op_gemm_tn(None, 256, 512, 256, 1.0, X.data_ptr(), 256, Y.data_ptr(), 512, 0.0,
                                Y.data_ptr(), 512, 0, 0)
     assert rc != 0
+
+
+_JTJ_HASH_SCRIPT = r'''
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import lsqfit_amd as amd
+from lsqfit_amd import synth
+out = []
+for N, P in ((4096, 384), (2048, 128), (8192, 1024)):
+    d = synth.make_cosmix(N=N, P=P, seed=7, block=0, prior_corr=False)
+    pr = amd.DeviceProblem(d['model'], d['x'], amd.Whitening(d['ymean'], d['yerr'], *d['prior']))
+    pr.normal(d['p0'])
+    A = pr.get_jtj()
+    assert np.array_equal(A, A.T)
+    out.append(hashlib.sha256(np.ascontiguousarray(A).tobytes()).hexdigest())
+    pr.close()
+print(' '.join(out))
+'''
+
+
+def test_syrk_diagonal_tile_schedule_is_bit_identical(tmp_path):
+    """Diagonal tiles of the split-K J^T J launch take a triangular schedule (10 MFMAs per k-step and
+    wave instead of 16, values mirrored in the epilogue).  The packed normal matrix must be the SAME
+    BITS as with the full schedule (LSQAMD_SYRK_DIAG=0): same products, same order over k."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'jtj_hash.py'
+    script.write_text(_JTJ_HASH_SCRIPT % dict(root=root))
+    got = []
+    for knob in ('1', '0'):
+        env = dict(os.environ, LSQAMD_SYRK_DIAG=knob)
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got.append(r.stdout.strip().splitlines()[-1])
+    assert got[0] == got[1] and len(got[0].split()) == 3
