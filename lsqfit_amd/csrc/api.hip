@@ -129,7 +129,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->red_scalar = cv.take<double>(8);
   f->M = cv.take<double>(P * f->ldm);
   f->chol_work = cv.take<double>((int64_t)(potrf_work_bytes(P) / sizeof(double)));
-  f->yv = cv.take<double>(2 * P);
+  f->yv = cv.take<double>(4 * P + 8);   // y, v, then the hand-off granules of the chained back substitution
   f->diag_dev = cv.take<double>(P);
   f->dscale = cv.take<double>(P);
   f->tvec = cv.take<double>(P + 1);
@@ -472,7 +472,7 @@ int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const
   {
     Scope sc(f, LSQAMD_T_SOLVE);
     HIPCHK(f, launch_copy_strided(f->st, f->M + P, f->ldm, f->yv, 1, P, 1));
-    HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
+    HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv, f->yv + 2 * P, f->info_dev));
     if (fetch) {
       HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
       HIPCHK(f, hipMemcpyAsync(f->pin_s + 4, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
@@ -488,6 +488,7 @@ int solve_damped_collect(lsqamd_fit *f) {
   std::memcpy(f->hv.data(), f->pin_v, sizeof(double) * P);
   std::memcpy(&info, f->pin_s + 4, sizeof(int32_t));
   f->ntrial++;
+  if (info == -77) FAIL(f, LSQAMD_EHIP, "back substitution: a workgroup of the chain gave up waiting");
   if (info != 0) {
     f->chol_fail++;
     return LSQAMD_ENOTPD;
@@ -568,7 +569,7 @@ int solve_with_factor(lsqamd_fit *f, const double *rhs, double *out) {
     b.alpha = -1.0; b.beta = 1.0;
     HIPCHK(f, launch_gemm_tn(f->st, b));
   }
-  HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv));
+  HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv, f->yv + 2 * P, f->info_dev));
   HIPCHK(f, hipMemcpyAsync(out, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;

@@ -604,13 +604,169 @@ __global__ __launch_bounds__(256) void backsolve_group_kernel(const double *A, i
   }
 }
 
+// ---- back substitution as ONE launch: a chain of workgroups --------------------------------------
+// Workgroup i owns block row i (128 rows of U, n / 128 workgroups, all resident).  It folds
+// U[i, k] v_k into its 128 partial sums as the v_k appear (k = T-1 .. i+1, each tile prefetched into
+// registers while it waits), then v_i = inv(U_ii) (y_i - sums) and publishes v_i for the rows above.
+// What is serial is T hand-offs of 1 KiB plus two 128 x 128 GEMVs out of registers each -- no kernel
+// boundary, no re-computation of the solved blocks in every workgroup (backsolve_group_kernel).
+// Hand-off (cdna_hip_programming.md guideline 16, form R2): the data is the flag.  Every double
+// travels as two 8-byte granules {tag, 32 bits}, each written by ONE agent-scope (write-through)
+// store; one wave of every consumer re-reads its granules until all tags carry this call's epoch.
+// The granule words are zeroed by a memset before every launch.  Spins are bounded: a workgroup that
+// gives up raises the abort word, everybody leaves, *info reports LSQAMD_CHAIN_TIMEOUT.
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+constexpr unsigned CHAIN_EPOCH = 0x5a17u;
+constexpr int32_t CHAIN_TIMEOUT_INFO = -77;
+
+__device__ __forceinline__ void granule_store(gu64 *g, double x) {
+  union { double d; unsigned u[2]; } c;
+  c.d = x;
+  __hip_atomic_store(g, ((unsigned long long)CHAIN_EPOCH << 32) | c.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(g + 1, ((unsigned long long)CHAIN_EPOCH << 32) | c.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// GEMV piece layout of the chain: wave w owns rows 32 w .. 32 w + 31 of a 128 x 128 tile; its four
+// 16-lane groups own 8 rows each and lane c of a group the 8 columns 8 c .. 8 c + 7 -- the 8 per-row
+// partial sums of a lane are reduced over 16 lanes only (halving butterfly: 4 + 2 + 1 + 1 exchanges
+// instead of 32 over the whole wave); row 8 g + (c >> 1)'s total lands in lanes c and c ^ 1.
+__device__ __forceinline__ double reduce8(double (&p)[8], int lane) {
+#pragma unroll
+  for (int cnt = 8, mask = 8; cnt >= 2; cnt >>= 1, mask >>= 1) {
+    const bool hi = (lane & mask) != 0;
+#pragma unroll
+    for (int i = 0; i < cnt / 2; ++i) {
+      const double send = hi ? p[i] : p[i + cnt / 2];
+      const double keep = hi ? p[i + cnt / 2] : p[i];
+      p[i] = keep + shfl_xor_d(send, mask);
+    }
+  }
+  return p[0] + shfl_xor_d(p[0], 1);
+}
+
+struct ChainTile {
+  v2d t[8][4];
+  __device__ __forceinline__ void fetch(const double *M, int64_t ld, int wave, int lane) {
+    const double *row = M + (int64_t)(wave * 32 + (lane >> 4) * 8) * ld + (lane & 15) * 8;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) t[r][q] = *reinterpret_cast<const v2d *>(row + r * ld + 2 * q);
+  }
+  __device__ __forceinline__ double times(const double *xs, int lane) const {
+    const v2d *xp = reinterpret_cast<const v2d *>(xs + (lane & 15) * 8);
+    const v2d x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+    double p[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double a = t[r][0][0] * x0[0];
+      a = fma(t[r][0][1], x0[1], a);
+      double b = t[r][1][0] * x1[0];
+      b = fma(t[r][1][1], x1[1], b);
+      a = fma(t[r][2][0], x2[0], a);
+      a = fma(t[r][2][1], x2[1], a);
+      b = fma(t[r][3][0], x3[0], b);
+      b = fma(t[r][3][1], x3[1], b);
+      p[r] = a + b;
+    }
+    return reduce8(p, lane);
+  }
+};
+
+__global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *A, int64_t lda, int T, const double *uinv,
+                                                              const double *y, double *v, unsigned long long *gran_,
+                                                              unsigned int *abort_, int32_t *info) {
+  __shared__ __attribute__((aligned(16))) double xs[NB];
+  __shared__ int give_up;
+  gu64 *gran = (gu64 *)gran_;
+  gu32 *abortw = (gu32 *)abort_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = T - 1 - (int)blockIdx.x;              // the first workgroups dispatched start the chain
+  if (tid == 0) give_up = 0;
+  const int myrow = wave * 32 + (lane >> 4) * 8 + ((lane & 15) >> 1);   // the row whose totals this lane keeps
+  const bool keeper = !(lane & 1);
+  double sum = 0.0;
+  ChainTile cur, inv;
+  const double *Arow = A + (int64_t)i * NB * lda;
+  if (i < T - 1) cur.fetch(Arow + (int64_t)(T - 1) * NB, lda, wave, lane);
+  // inv(U_ii) stays in registers from the start: its GEMV is the last link before the hand-off
+  inv.fetch(uinv + (int64_t)i * NB * NB, NB, wave, lane);
+  const double yi = y[(int64_t)i * NB + myrow];
+  __syncthreads();
+  for (int k = T - 1; k > i; --k) {
+    if (wave == 0) {                                    // one wave polls: doubles lane and lane + 64 of v_k
+      gu64 *g = gran + ((int64_t)k * NB + lane) * 2;
+      unsigned long long a0, a1, b0, b1;
+      unsigned spins = 0;
+      bool bad = false;
+      for (;;) {
+        a0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b0 = __hip_atomic_load(g + 128, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b1 = __hip_atomic_load(g + 129, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ok = (a0 >> 32) == CHAIN_EPOCH && (a1 >> 32) == CHAIN_EPOCH && (b0 >> 32) == CHAIN_EPOCH &&
+                        (b1 >> 32) == CHAIN_EPOCH;
+        if (__all(ok)) break;
+        if ((++spins & 63) == 0) {
+          const unsigned ab = __hip_atomic_load(abortw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ab != 0 || spins > (1u << 22)) { bad = true; break; }
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      if (bad) {
+        if (lane == 0) {
+          give_up = 1;
+          __hip_atomic_store(abortw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicCAS(info, 0, CHAIN_TIMEOUT_INFO);
+        }
+      } else {
+        union { double d; unsigned u[2]; } c;
+        c.u[0] = (unsigned)a0; c.u[1] = (unsigned)a1;
+        xs[lane] = c.d;
+        c.u[0] = (unsigned)b0; c.u[1] = (unsigned)b1;
+        xs[lane + 64] = c.d;
+      }
+    }
+    __syncthreads();
+    if (give_up) return;
+    const double part = cur.times(xs, lane);
+    // the next operand is requested right away: its latency hides behind the wait for the next piece
+    if (k - 1 > i) cur.fetch(Arow + (int64_t)(k - 1) * NB, lda, wave, lane);
+    sum += part;
+    __syncthreads();
+  }
+  if (keeper) xs[myrow] = yi - sum;
+  __syncthreads();
+  const double vi = inv.times(xs, lane);
+  if (keeper) {
+    if (i > 0) granule_store(gran + ((int64_t)i * NB + myrow) * 2, vi);
+    v[(int64_t)i * NB + myrow] = vi;
+  }
+}
+
+size_t backsolve_scratch_bytes(int64_t n) { return (size_t)n * 16 + 64; }
+
 hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                    const double *work, double *y_inout, int32_t batch, int64_t strideA,
-                                   int64_t strideW, int64_t strideY, const int32_t *active) {
+                                   int64_t strideW, int64_t strideY, const int32_t *active, void *scratch,
+                                   int32_t *info_dev) {
   // y_inout (per batch entry): [0,n) = y (destroyed), [n, 2n) = v on return
   double *y = y_inout, *v = y_inout + n;
   const int64_t nblk = (n + NB - 1) / NB;
   static const bool grouped = [] { const char *e = getenv("LSQAMD_BACKSOLVE"); return !(e && e[0] == 's'); }();
+  static const bool chained = [] { const char *e = getenv("LSQAMD_BACKSOLVE"); return !e || e[0] == 'c'; }();
+  if (chained && scratch && batch == 1 && !active && n % NB == 0 && nblk >= 2 && nblk <= 192 && info_dev &&
+      !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15) && !(reinterpret_cast<uintptr_t>(work) & 15)) {
+    // granules for n doubles, then the abort word
+    hipError_t e = hipMemsetAsync(scratch, 0, backsolve_scratch_bytes(n), st);
+    if (e != hipSuccess) return e;
+    unsigned long long *gran = static_cast<unsigned long long *>(scratch);
+    unsigned int *abortw = reinterpret_cast<unsigned int *>(gran + 2 * n);
+    hipLaunchKernelGGL(backsolve_chain_kernel, dim3((unsigned)nblk), dim3(256), 0, st, A, lda, (int)nblk, work, y, v,
+                       gran, abortw, info_dev);
+    return hipGetLastError();
+  }
   if (grouped && n % NB == 0 && nblk >= 2 * BSQ) {
     for (int64_t kb = nblk - 1; kb >= 0; kb -= BSQ) {
       const int64_t top = (kb - BSQ + 1 > 0 ? kb - BSQ + 1 : 0) * NB;
@@ -631,8 +787,8 @@ hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, i
 }
 
 hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
-                           const double *work, double *y_inout) {
-  return backsolve_upper_batched(st, A, n, lda, work, y_inout, 1, 0, 0, 0, nullptr);
+                           const double *work, double *y_inout, void *scratch, int32_t *info_dev) {
+  return backsolve_upper_batched(st, A, n, lda, work, y_inout, 1, 0, 0, 0, nullptr, scratch, info_dev);
 }
 
 // ---- W = U^-T (lower triangular, row-major) -------------------------------------------

@@ -83,13 +83,16 @@ hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda
                                int64_t strideW, const int32_t *active);
 hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                    const double *work, double *y_inout, int32_t batch, int64_t strideA,
-                                   int64_t strideW, int64_t strideY, const int32_t *active);
+                                   int64_t strideW, int64_t strideY, const int32_t *active,
+                                   void *scratch = nullptr, int32_t *info_dev = nullptr);
 hipError_t trtri_upper_to_lower_T_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                           const double *work, double *Wl, int64_t ldw, int32_t batch,
                                           int64_t strideA, int64_t strideW, int64_t strideWl);
 // v = U^-1 y (y = column `ycol` of A rows 0..n-1), using the diagonal-block inverses in work
+// scratch (backsolve_scratch_bytes(n), with info_dev): the one-launch chain of workgroups (n a multiple of 128)
+size_t backsolve_scratch_bytes(int64_t n);
 hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
-                           const double *work, double *y_inout);
+                           const double *work, double *y_inout, void *scratch = nullptr, int32_t *info_dev = nullptr);
 // Wl (n x n, ld) = U^-T (lower triangular), given factored A and the block inverses.
 hipError_t trtri_upper_to_lower_T(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                   const double *work, double *Wl, int64_t ldw);
