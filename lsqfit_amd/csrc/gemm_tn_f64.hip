@@ -972,12 +972,18 @@ void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
 // fp64 VALU and fp64 MFMA share the datapath, so this work adds to the MFMA time (about a quarter)
 // instead of hiding behind it; what is saved is the Jacobian kernel and 4.3 GB of traffic.
 template <int MODEL>
-__global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int tiles_m, int tiles_n, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  const int tm_first = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+  // pair_rows (blocks of many tile rows: the k-range of a tile row grows with it): this workgroup does tile
+  // rows tm and tiles_m - 1 - tm one after the other, so that every workgroup sees the same total K
+  const int npass = (pair_rows && tiles_m - 1 - tm_first != tm_first) ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  if (pass == 1) __syncthreads();
+  const int tm = pass == 0 ? tm_first : tiles_m - 1 - tm_first;
   const int64_t b = blockIdx.z;
   const int64_t m0 = (int64_t)tm * BM;
   const int64_t ke = m0 + BM;                     // X[k][m] = 0 for k > m
@@ -996,8 +1002,24 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
   typedef const __attribute__((address_space(1))) void glb_void;
   const double *xp = Xb + (int64_t)wave * a.B + m0 + 2 * lane;
   const int64_t xstep = 4 * a.B;
-  int64_t ksyn = 0;
+  // abscissae of the stage rows: a ring of three 32-double slots in LDS, slot s % 3 = x[16 s .. 16 s + 31],
+  // filled two stages ahead by one 256-byte DMA of wave 0 -- no register ever waits on a global load in
+  // the loop (vmcnt retires in order: a wait for x would be a wait for the operand rows behind it)
+  double *xring = smem + 2 * STAGE;
+  auto xdma = [&](int64_t sidx) {
+    if (wave == 0) {
+      int64_t e = sidx * BK + (lane >> 1);
+      if (e > a.B - 1) e = a.B - 1;
+      const char *src = reinterpret_cast<const char *>(xrow + e) + 4 * (lane & 1);
+      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(xring + (sidx % 3) * 32), 4, 0, 0);
+    }
+  };
+  int64_t ssyn = 0;     // index of the stage `stage` builds next
   auto stage = [&](int buf) {
+    double xs4[4];
+    const double *xq = xring + (ssyn % 3) * 32 + srow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs4[i] = xq[4 * i];
     double *Xs = smem + buf * STAGE + wave * LDT;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1007,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = srow + 4 * i;
-      const double xv = xrow[ksyn + row];
+      const double xv = xs4[i];
       double t, dq;
       if (MODEL == LSQAMD_MODEL_COSMIX) {
         double sn, cs;
@@ -1022,15 +1044,21 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
       Ys[row * LDT + sc] = t;
       Ys[row * LDT + 64 + sc] = dq;
     }
-    ksyn += BK;
+    ++ssyn;
   };
   const double wreg = (tid < BM) ? C[(m0 + tid) * a.ld + 2 * a.K] : 0.0;   // whitened residual of this tile's rows
   const int fr = lane & 15, fq = lane >> 4;
+  xdma(0);
+  xdma(1);
+  __syncthreads();
   stage(0);
   __syncthreads();
   int cur = 0;
   for (int64_t k0 = 0; k0 < ke; k0 += BK) {
-    if (k0 + BK < ke) stage(cur ^ 1);
+    if (k0 + BK < ke) {
+      if (k0 + 2 * BK < ke) xdma(k0 / BK + 2);
+      stage(cur ^ 1);
+    }
     const double *Xs = smem + cur * STAGE;
     const double *Ys = Xs + BK * LDT;
 #pragma unroll
@@ -1087,6 +1115,7 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j * 16 + fr] = red[wave * 64 + j * 16 + fr] + red[(wave + 2) * 64 + j * 16 + fr];
   }
+  }  // pass
 }
 
 bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P) {
@@ -1095,23 +1124,27 @@ bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P) {
          P % 128 == 0 && P >= 128;
 }
 
+constexpr size_t SYNTH_LDS_BYTES = GEMM_LDS_BYTES + 3 * 32 * sizeof(double);
+
 hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a) {
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
     if (e != hipSuccess) return e;
     attr = true;
   }
   const int tiles_m = (int)(a.B / BM), tiles_n = (int)(a.K / 64);
-  dim3 grid((unsigned)(tiles_m * tiles_n), 1, (unsigned)a.nb);
+  // few large blocks: unpaired, the workgroups of the last tile rows run 2 tiles_m / (tiles_m + 1) times the average
+  const int pair = tiles_m >= 4 ? 1 : 0;
+  dim3 grid((unsigned)((pair ? (tiles_m + 1) / 2 : tiles_m) * tiles_n), 1, (unsigned)a.nb);
   if (a.model == LSQAMD_MODEL_COSMIX)
-    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX>), grid, dim3(256), GEMM_LDS_BYTES, st, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
   else
-    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>), grid, dim3(256), GEMM_LDS_BYTES, st, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
   return hipGetLastError();
 }
 
