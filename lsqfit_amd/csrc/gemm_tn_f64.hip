@@ -847,7 +847,8 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.work_map = a.work_map;
   g.n_work = a.n_work;
   static const bool diag_off = [] { const char *e = getenv("LSQAMD_SYRK_DIAG"); return e && atoi(e) == 0; }();  // developer knob
-  g.syrk_diag = a.work_map && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy && a.M == a.N && g.splits > 1 && !diag_off;
+  g.syrk_diag = a.work_map && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy && a.M == a.N &&
+                (g.splits > 1 || a.beta == 0.0) && !diag_off;
   g.batch_active = a.batch_active;
   g.colsum_out = a.colsum_out;
   g.colsum_ld = a.colsum_ld;
