@@ -52,15 +52,21 @@ class nonlinear_fit(object):
     model = :class:`lsqfit_amd.Model`."""
 
     def __init__(self, data=None, model=None, prior=None, p0=None, svdcut=False, tol=None,
-                 maxit=None, udata=None, fitter=None, problem=None, linear=None, cross=None, **fitterargs):
+                 maxit=None, udata=None, fitter=None, problem=None, linear=None, cross=None, eps=False,
+                 noise=False, rng=None, **fitterargs):
         if data is None and udata is None:
             raise ValueError('neither data nor udata is specified')
         if model is None:
             raise ValueError('no fit function (model) specified')
         if p0 is None and prior is None:
             raise ValueError('neither p0 nor prior is specified')
-        if svdcut is False:
-            svdcut = DEFAULTS['svdcut']
+        # src/lsqfit/__init__.py:471-479: neither given -> the default svdcut; eps alone -> no svdcut
+        if svdcut is False and eps is False:
+            svdcut, eps = DEFAULTS['svdcut'], None
+        elif svdcut is False:
+            svdcut = None
+        elif eps is False:
+            eps = None
         tol = DEFAULTS['tol'] if tol is None else tol
         maxit = DEFAULTS['maxit'] if maxit is None else maxit
         self.fitter = DEFAULTS['fitter'] if fitter is None else fitter
@@ -79,9 +85,12 @@ class nonlinear_fit(object):
                 if prior is None or uncorrelated:
                     raise ValueError('cross needs data= and prior=')
                 from .whiten import joint_whitening
+                if eps is not None or np.any(noise):
+                    raise NotImplementedError('eps / noise with data-prior cross-correlations')
                 wh = joint_whitening(ymean, yerr, pm, perr, cross, svdcut=svdcut)
             else:
-                wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, udata=uncorrelated)
+                wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, eps=eps, udata=uncorrelated, noise=noise,
+                               rng=rng)
             problem = DeviceProblem(model, x, wh)
         else:
             wh = problem.wh
@@ -89,6 +98,8 @@ class nonlinear_fit(object):
         self.problem_x = x
         self.whitening = wh
         self.svdcut = svdcut
+        self.eps = getattr(wh, 'eps', None)
+        self.noise = getattr(wh, 'noise', (False, False))
         self.svdn = wh.nmod
         self.nblocks = wh.nblocks
         self.model = model

@@ -89,7 +89,13 @@ def _regulate_block(cov, svdcut, force_eig=False):
     var_reg = np.einsum('ik,k,ik->i', vec_k, lam_k, vec_k) * sd ** 2 if np.all(keep) else sd ** 2
     # S S^T = regulated block covariance (restricted to the kept modes): sampling factor
     S = sd[:, None] * (vec_k * np.sqrt(lam_k))
-    return dict(Wt=Wt, modes=m, tri=0, logdet=logdet, nmod=nmod, var_reg=var_reg, S=S)
+    out = dict(Wt=Wt, modes=m, tri=0, logdet=logdet, nmod=nmod, var_reg=var_reg, S=S)
+    if cut > 0 and nmod:
+        # what the floor ADDED to the covariance: sum over the raised modes of (floor - lam) D v v^T D;
+        # its square root drives ``noise=True`` (src/lsqfit/__init__.py:247-256)
+        low = lam < abs(cut) * lam[-1]
+        out['S_add'] = sd[:, None] * (vec[:, low] * np.sqrt(lam_reg[low] - np.minimum(lam[low], lam_reg[low])))
+    return out
 
 
 class _Block(dict):
@@ -235,16 +241,40 @@ def _as_blocks(err, n):
     return sd[perm], blocks, perm
 
 
+def _eps_shift(cov, eps):
+    """gvar.regulate's ``eps`` mode on one correlated block: (C + eps ||corr||_inf D^2, sqrt of what was
+    added as a diagonal factor)."""
+    cov = np.asarray(cov, float)
+    sd = np.sqrt(np.diag(cov))
+    if not np.all(np.isfinite(sd)) or np.any(sd <= 0):
+        raise ValueError('covariance block has a non-positive variance')
+    norm = float(np.max(np.sum(np.abs(cov / np.outer(sd, sd)), axis=1)))
+    out = cov.copy()
+    out[np.diag_indices_from(out)] += eps * norm * sd ** 2
+    return out, np.sqrt(eps * norm) * sd
+
+
 class Whitening:
     """Everything the device path needs to know about concat(y, prior)."""
 
     def __init__(self, ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12, eps=None,
-                 udata=False, engine=None):
-        if eps is not None:
-            raise NotImplementedError('eps regulation is not available on the device path')
+                 udata=False, engine=None, noise=False, rng=None):
+        """``eps`` (used only when ``svdcut is None``, src/lsqfit/__init__.py:240-245): gvar.regulate's
+        other mode -- every correlated block's correlation matrix gets ``eps * ||corr||_inf`` on its
+        diagonal, i.e. ``C -> C + eps ||corr||_inf D^2``; no eigen-decomposition is ever needed, so every
+        block takes the device's Cholesky route.  Restated from gvar's documentation; the reference holds
+        no expected value for it (parity unpinned).  ``noise`` (bool or (data, prior),
+        :247-256): means shifted by a draw from what the regulation added (data) / from the prior itself
+        (prior), drawn from ``rng`` (numpy Generator or seed) -- not gvar's random stream."""
+        if svdcut is not None:
+            eps = None
+        if eps is not None and eps < 0:
+            raise ValueError('eps must not be negative')
         self.engine = engine
         self.svdcut = svdcut
-        self.eps = None
+        self.eps = eps
+        self.noise = (bool(noise), bool(noise)) if np.ndim(noise) == 0 else (bool(noise[0]), bool(noise[1]))
+        added = []                            # (row0, factor): S S^T = what the regulation added to the block
         self.ymean = np.array(ymean, float).reshape(-1)
         N = self.ymean.size
         ysd, yblocks, self.perm = _as_blocks(yerr, N)
@@ -261,14 +291,29 @@ class Whitening:
         self.blocks = []                      # dicts: row0, size, modes, tri, Wt
         in_block = np.zeros(N, bool)
         yblocks = sorted(yblocks, key=lambda b: b[0])
-        for (r0, cov), reg in zip(yblocks, regulate_blocks([c for _, c in yblocks], svdcut, engine=engine)):
+        if eps:
+            shifted = []
+            for r0, cov in yblocks:
+                creg, extra = _eps_shift(cov, eps)
+                shifted.append((r0, creg))
+                added.append((int(r0), extra))
+            yblocks = shifted
+        for (r0, cov), reg in zip(yblocks, regulate_blocks([c for _, c in yblocks], 0.0 if eps else svdcut,
+                                                           engine=engine)):
             B = cov.shape[0]
             reg.update(row0=int(r0), size=int(B))
             self.blocks.append(reg)
             in_block[r0:r0 + B] = True
             self.logdet += reg['logdet']
-            self.nmod += reg['nmod']
+            self.nmod += B if eps else reg['nmod']
             self.nblocks[B] = self.nblocks.get(B, 0) + 1
+            if 'S_add' in reg:
+                added.append((int(r0), reg['S_add']))
+        if self.noise[0] and added:
+            gen = np.random.default_rng(rng)
+            for r0, S in added:               # S: [B] (diagonal addition) or [B, m]
+                z = gen.standard_normal(S.shape[-1])
+                self.ymean[r0:r0 + S.shape[0]] += S * z if S.ndim == 1 else S @ z
         d = ~in_block
         if np.any(ysd[d] <= 0) or not np.all(np.isfinite(ysd[d])):
             raise ValueError('some input data have zero or non-finite standard deviations')
@@ -309,15 +354,17 @@ class Whitening:
             else:
                 self.prior_dense = True
                 pblocks = sorted(pblocks, key=lambda b: b[0])
+                if eps:
+                    pblocks = [(r0, _eps_shift(cov, eps)[0]) for r0, cov in pblocks]
                 pin = np.zeros(P, bool)
-                for (r0, cov), reg in zip(pblocks, regulate_blocks([c for _, c in pblocks], svdcut,
+                for (r0, cov), reg in zip(pblocks, regulate_blocks([c for _, c in pblocks], 0.0 if eps else svdcut,
                                                                    want_prec=True, engine=engine)):
                     B = cov.shape[0]
                     reg.update(row0=int(r0), size=int(B), idx=pidx[r0:r0 + B])
                     self.prior_blocks.append(reg)
                     pin[reg['idx']] = True
                     self.logdet += reg['logdet']
-                    self.nmod += reg['nmod']
+                    self.nmod += B if eps else reg['nmod']
                     self.nblocks[B] = self.nblocks.get(B, 0) + 1
                     nprior += reg['modes']
                 dd = np.nonzero(~pin)[0]
@@ -334,6 +381,11 @@ class Whitening:
         if n1:
             self.nblocks[1] = n1
         self.nchiv = self.nchiv_data + nprior
+        if self.noise[1] and self.has_prior:  # prior means move by a draw from the (regulated) prior
+            gen = np.random.default_rng(None if rng is None else np.random.default_rng(rng).integers(1 << 62))
+            for idx, S in self.prior_S:
+                z = gen.standard_normal(S.shape[-1])
+                self.prior_mean[idx] += S * z if np.ndim(S) == 1 else S @ z
 
     # -- prior pieces the host needs only now and then (made on first use) ---------------------
     @property

@@ -35,7 +35,7 @@ def _spec(mean, err):
 
 
 def build_pdf(ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12,
-              udata=False, extra_cov=None):
+              udata=False, extra_cov=None, eps=None):
     """``extra_cov``: optional list of ((i, j), value) cross-covariances between
     entries of concat(y, prior) (data-prior correlations, test_lsqfit.py:1000-1017)."""
     from .pdf import find_blocks
@@ -58,7 +58,7 @@ def build_pdf(ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12,
                 full[off:off + c.shape[0], off:off + c.shape[0]] = c
         for (i, j), v in extra_cov:
             full[i, j] = full[j, i] = v
-        return PDF.from_dense(mean, full, svdcut=svdcut)
+        return PDF.from_dense(mean, full, svdcut=svdcut, eps=eps)
     blocks = []
     for off, c in covs:
         if c is None:
@@ -66,7 +66,7 @@ def build_pdf(ymean, yerr, prior_mean=None, prior_err=None, svdcut=1e-12,
         for comp in find_blocks(c):
             if comp.size > 1:
                 blocks.append((comp + off, c[np.ix_(comp, comp)]))
-    return PDF(mean, sd, blocks, svdcut=svdcut)
+    return PDF(mean, sd, blocks, svdcut=svdcut, eps=eps)
 
 
 def default_p0(prior_mean, prior_sdev):
@@ -81,12 +81,12 @@ class FitResult:
 
 def nonlinear_fit(x, ymean, yerr, fcn, prior_mean=None, prior_err=None, p0=None,
                   svdcut=1e-12, tol=1e-8, maxit=1000, udata=False, extra_cov=None,
-                  jac=None, fitter='gsl_multifit', linear=None, **fitterargs):
+                  jac=None, fitter='gsl_multifit', linear=None, eps=None, **fitterargs):
     """``fcn(x, p)`` must accept float arrays and ``oracle.dual.Dual`` arrays
     (or pass ``jac(x, p)`` returning d fcn / d p explicitly)."""
     from .dual import Dual
     pdf = build_pdf(ymean, yerr, prior_mean, prior_err, svdcut=svdcut,
-                    udata=udata, extra_cov=extra_cov)
+                    udata=udata, extra_cov=extra_cov, eps=eps)
     noprior = prior_mean is None
     if p0 is None:
         if noprior:

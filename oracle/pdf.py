@@ -17,8 +17,12 @@ and src/lsqfit/_utilities.pyx:58-61:
 
 gvar itself is third-party and absent from /root/reference; its block search
 and eigen-regulation are restated from its documentation.  The ``eps``
-regulation mode has no literal expected values anywhere in the reference and
-is NOT implemented (parity unpinned for it).
+regulation mode (``gvar.regulate(g, eps=...)``: every correlated block's CORRELATION
+matrix gets ``eps * ||corr||_inf`` added to its diagonal, then plain Cholesky-style
+weights; all of a block's modes count as modified) is restated from gvar's published
+documentation as well, but NO literal expected value for it exists anywhere in the
+reference (no test, no example output): PARITY UNPINNED for ``eps`` -- the tests
+only check the stated identity ``W^T W = inv(C + eps ||corr||_inf D^2)``.
 """
 import numpy as np
 
@@ -52,13 +56,16 @@ class PDF:
     overriding ``sdev`` on their indices (B >= 2)."""
 
     def __init__(self, mean, sdev, blocks=(), svdcut=1e-12, eps=None):
-        if eps is not None:
-            raise NotImplementedError('eps regulation is unpinned in the reference')
+        # src/lsqfit/__init__.py:240-245: eps is ignored when svdcut is given (and not None)
+        if svdcut is not None:
+            eps = None
+        if eps is not None and eps < 0:
+            raise ValueError('eps must not be negative')
         self.mean = np.array(mean, float)
         n = self.mean.size
         sdev = np.array(sdev, float)
         self.svdcut = svdcut
-        self.eps = None
+        self.eps = eps
         in_block = np.zeros(n, bool)
         for idx, _ in blocks:
             in_block[np.asarray(idx, int)] = True
@@ -79,6 +86,9 @@ class PDF:
             self.nblocks[B] = self.nblocks.get(B, 0) + 1
             sd = np.sqrt(np.diag(cov))
             corr = cov / np.outer(sd, sd)
+            if eps:                                # Tikhonov shift of the whole spectrum (UNPINNED, see header)
+                corr = corr + eps * np.linalg.norm(corr, np.inf) * np.eye(B)
+                self.nmod += B
             lam, vec = np.linalg.eigh(corr)
             keep = np.ones(B, bool)
             lam_reg = lam.copy()

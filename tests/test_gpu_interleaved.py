@@ -19,12 +19,13 @@ def amd():
     return lsqfit_amd
 
 
-def _scatter_blocks(rng, n, sets, floor):
+def _scatter_blocks(rng, n, sets, floor, deficit=0):
+    assert len(set(sum(map(list, sets), []))) == sum(len(k) for k in sets)       # disjoint index sets
     cov = np.diag(rng.uniform(0.05, 0.2, n) ** 2)
     for idx in sets:
         B = len(idx)
         sd = np.sqrt(cov[idx, idx])
-        A = rng.standard_normal((B, B))
+        A = rng.standard_normal((B, B - deficit))
         corr = A @ A.T + floor * B * np.eye(B)
         d = np.sqrt(np.diag(corr))
         cov[np.ix_(idx, idx)] = corr / np.outer(d, d) * np.outer(sd, sd)
@@ -66,3 +67,31 @@ def test_fit_with_interleaved_components_matches_oracle(amd, svdcut):
         fit.simulated_fits(2)
     with pytest.raises(ValueError):
         amd.DeviceProblem(model, x, wh, rows=(0, 48))
+
+
+def test_fit_with_eps_regulation_matches_oracle(amd):
+    """eps instead of svdcut (src/lsqfit/__init__.py:240-245): C -> C + eps ||corr||_inf D^2 on every
+    correlated block, data and prior; every block then takes the device's Cholesky route.  Unpinned in the
+    reference -- the device fit is held to the oracle's restatement of gvar's documented rule."""
+    rng = np.random.default_rng(29)
+    K, N = 2, 64
+    P = 2 * K
+    x = np.sort(rng.uniform(0.0, 3.0, N))
+    ptrue = np.array([1.0, 0.5, 1.3, 3.1])
+    ycov = _scatter_blocks(rng, N, [list(range(0, N, 5)), [1, 2, 3], [33, 36, 39, 42, 46, 49]], 0.0, deficit=1)
+    pcov = _scatter_blocks(rng, P, [[0, 2]], 0.5) * 25.0
+    ymean = gu.cosmix_fcn(x, ptrue) + 0.05 * rng.standard_normal(N)
+    pmean = ptrue + 0.05 * rng.standard_normal(P)
+    eps = 1e-2
+    fit = amd.nonlinear_fit(data=(x, ymean, ycov), model=amd.cosmix(K), prior=(pmean, pcov), p0=pmean, eps=eps, tol=1e-10)
+    assert fit.svdcut is None and fit.eps == eps
+    assert all(b['tri'] == 1 and 'Wt_dev' in b for b in fit.whitening.blocks)        # built on the device
+    ref = ofit.nonlinear_fit(x, ymean, ycov, gu.cosmix_fcn, prior_mean=pmean, prior_err=pcov, p0=pmean, tol=1e-10,
+                             svdcut=None, eps=eps, jac=gu.cosmix_jac, solver='cholesky')
+    assert (fit.dof, fit.svdn) == (ref.dof, ref.svdn) and fit.svdn > 0
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-8)
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    # the blocks are singular to rounding: without regulation they are refused
+    with pytest.raises(ValueError):
+        amd.nonlinear_fit(data=(x, ymean, ycov), model=amd.cosmix(K), prior=(pmean, pcov), p0=pmean, svdcut=0.0)

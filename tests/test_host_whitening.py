@@ -280,3 +280,68 @@ def test_interleaved_components_are_whitened_through_a_permutation(svdcut):
         np.testing.assert_allclose(Cs @ full[N:, N:], np.eye(P), atol=1e-6)
     # contiguous layouts are untouched
     assert Whitening(ymean, np.diag(np.diag(cov)), pmean, np.sqrt(np.diag(pcov))).perm is None
+
+
+def test_eps_regulation_is_a_diagonal_shift_of_the_correlation_matrix():
+    """``eps`` (src/lsqfit/__init__.py:240-245, gvar.regulate's second mode): every correlated block's
+    correlation matrix gets eps * ||corr||_inf on its diagonal.  The reference holds no expected value
+    for it (unpinned); what is checked is the stated identity, against an inverse computed here."""
+    rng = np.random.default_rng(41)
+    N, P, eps = 16, 14, 1e-3
+    cov = _interleaved_cov(rng, N)
+    pcov = _interleaved_cov(rng, 16)[:P, :P]
+    ymean, pmean = rng.standard_normal(N), rng.standard_normal(P)
+
+    def shifted(c):
+        out = c.copy()
+        for comp in (np.array(k) for k in ([1, 4, 9, 10], [2, 7], [5, 6, 13])):
+            sd = np.sqrt(np.diag(c)[comp])
+            corr = c[np.ix_(comp, comp)] / np.outer(sd, sd)
+            out[comp, comp] += eps * np.abs(corr).sum(axis=1).max() * sd ** 2
+        return out
+    wh = Whitening(ymean, cov, pmean, pcov, svdcut=None, eps=eps)
+    assert wh.eps == eps and wh.svdcut is None
+    ic = np.empty((N, N))
+    ic[np.ix_(wh.perm, wh.perm)] = icov_from_whitening(wh)
+    np.testing.assert_allclose(ic, np.linalg.inv(shifted(cov)), rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(wh.prior_prec, np.linalg.inv(shifted(pcov)), rtol=1e-9, atol=1e-12)
+    assert wh.logdet == pytest.approx(np.linalg.slogdet(shifted(cov))[1] + np.linalg.slogdet(shifted(pcov))[1], rel=1e-11)
+    assert wh.nmod == 2 * (4 + 2 + 3)                  # every mode of every correlated block moved
+    pdf = ofit.build_pdf(ymean, cov, pmean, pcov, svdcut=None, eps=eps)
+    assert (wh.nchiv, wh.nmod, wh.nblocks) == (pdf.nchiv, pdf.nmod, pdf.nblocks)
+    assert wh.logdet == pytest.approx(pdf.logdet, rel=1e-10)
+    # eps is ignored when an svdcut is given (and not None)
+    w2 = Whitening(ymean, cov, pmean, pcov, svdcut=1e-12, eps=eps)
+    assert w2.eps is None and w2.nmod == 0
+    with pytest.raises(ValueError):
+        Whitening(ymean, cov, svdcut=None, eps=-1.0)
+
+
+@pytest.mark.parametrize('mode', ['eps', 'svdcut'])
+def test_noise_is_a_draw_from_what_the_regulation_added(mode):
+    """noise=(True, False) (src/lsqfit/__init__.py:247-256): the data means move by a Gaussian draw whose
+    covariance is C_regulated - C; repeated with the same seed it repeats, and over many draws its
+    sample covariance is that difference."""
+    rng = np.random.default_rng(43)
+    N = 16
+    cov = _interleaved_cov(rng, N)
+    ymean = rng.standard_normal(N)
+    kw = dict(svdcut=None, eps=0.05) if mode == 'eps' else dict(svdcut=0.05)
+    quiet = Whitening(ymean, cov, engine='host', **kw)
+    ic = np.empty((N, N))
+    ic[np.ix_(quiet.perm, quiet.perm)] = icov_from_whitening(quiet)
+    added = np.linalg.inv(ic) - cov
+    assert np.abs(added).max() > 1e-3                # the regulation does something here
+    a = Whitening(ymean, cov, engine='host', noise=(True, False), rng=7, **kw)
+    b = Whitening(ymean, cov, engine='host', noise=(True, False), rng=7, **kw)
+    np.testing.assert_array_equal(a.ymean, b.ymean)
+    assert not np.array_equal(a.ymean, quiet.ymean)
+    inv_perm = np.argsort(quiet.perm)
+    shifts = np.array([(Whitening(ymean, cov, engine='host', noise=True, rng=1000 + k, **kw).ymean - quiet.ymean)[inv_perm]
+                       for k in range(4000)])
+    np.testing.assert_allclose(shifts.T @ shifts / len(shifts), added, atol=0.08 * np.abs(added).max())
+    # prior noise: a draw from the prior itself
+    pm, psd = np.zeros(5), np.full(5, 2.0)
+    d = np.array([Whitening(ymean, cov, pm, psd, engine='host', noise=(False, True), rng=k, **kw).prior_mean
+                  for k in range(2000)])
+    assert abs(d.std() - 2.0) < 0.1 and abs(d.mean()) < 0.1
