@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void backsolve_group_kernel(const double *A, i
     for (int e = tid; e < nq * NB; e += 256) v[(int64_t)(kb - e / NB) * NB + e % NB] = vg[e / NB][e % NB];
     return;
   }
-  // rows above the group: 32 per workgroup, 8 per wave, lane -> two columns of each of the nq blocks
+  // rows above the group: BS_ROWS per workgroup, BS_ROWS / 4 per wave, lane -> two columns of each of the nq blocks
   const int64_t top = (int64_t)(kb - nq + 1) * NB;
   const int64_t r0 = (int64_t)(blockIdx.x - 1) * BS_ROWS + wave * (BS_ROWS / 4);
   double acc[BS_ROWS / 4];
