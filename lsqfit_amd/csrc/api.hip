@@ -120,6 +120,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->prior_prec = cv.take<double>(c.prior_dense ? P * P : P);
   f->p_dev = cv.take<double>(P);
   f->p_trial = cv.take<double>(P);
+  f->p_buf0 = f->p_dev;
   f->r = cv.take<double>(N);
   f->r_raw = cv.take<double>(c.n_blocks > 0 ? N : 1);
   f->J = cv.take<double>(N * f->ld);
@@ -454,7 +455,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
 // an SDMA upload followed by a dependent kernel costs ~100 us of cross-engine synchronisation)
 // frozen_host (with mu = 0, dogbox): flags of the parameters taken out of the system
 int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr,
-                        bool fetch = true) {
+                        bool fetch = true, const double *mu_dev = nullptr) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
   {
@@ -466,7 +467,7 @@ int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const
       if (diag_host) dd = f->diag_dev;
       else frozen = f->diag_dev;
     }
-    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M, frozen));
+    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M, frozen, mu_dev));
     HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev));
   }
   {
@@ -882,20 +883,87 @@ int refresh_mirrors(lsqamd_fit *f) {
 // and reads ONE 128-byte record; an accepted trial queues the Jacobian, the normal equations, the
 // update of D and the convergence test and reads the record once more.  No P-length vector
 // crosses PCIe, no P-length loop runs on the host.
+// The two halves of a device-resident LM step as launch sequences (no host reads in between), so that
+// each can be captured once per p-buffer parity and replayed: small problems spend more host time
+// launching their ~35 kernels than the GPU spends running them.
+static int enqueue_trial(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  double *gvec = f->redbuf + f->npk;
+  int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false, f->lmd + LMS_MU);
+  if (rc) return rc;
+  HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
+  rc = eval_residual_launch(f, f->p_trial);
+  if (rc) return rc;
+  HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
+  HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+  return 0;
+}
+
+static int enqueue_accept(lsqamd_fit *f) {   // p_trial becomes the point; the caller swaps the buffers afterwards
+  const int64_t P = f->P;
+  double *gvec = f->redbuf + f->npk;
+  f->r_fresh = true;      // f->r is the whitened residual AT p_trial: the trial evaluation left it there
+  f->r_ptr = f->p_trial;
+  int rc = eval_normal_dev(f, f->p_trial, false);
+  if (rc) return rc;
+  HIPCHK(f, launch_scale_update(f->st, P, f->opt.scaler, 0, f->diag_dev, f->dscale));
+  HIPCHK(f, launch_lm_converge(f->st, P, f->p_trial, f->yv + P, gvec, f->opt.xtol, f->opt.gtol, f->lmd));
+  HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+  return 0;
+}
+
+// run one half eagerly, or capture it (second time this parity sees it) and replay it
+static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
+  static const bool env_off = [] { const char *e = getenv("LSQAMD_STEP_GRAPH"); return e && e[0] == '0'; }();
+  static const int64_t maxp = [] { const char *e = getenv("LSQAMD_STEP_GRAPH_MAXP"); return e ? atoll(e) : (int64_t)1024; }();
+  const bool eligible = !env_off && !f->step_graph_off && !f->timing && !f->comm && !f->reduce && f->P <= maxp;
+  const int par = f->p_dev == f->p_buf0 ? 0 : 1;
+  if (!eligible) return enqueue(f);
+  hipGraphExec_t &exec = f->step_exec[par][which];
+  if (!exec) {
+    if (f->step_seen[par][which]++ == 0) return enqueue(f);      // warm-up: one-time attribute calls happen here
+    const int64_t njev0 = f->njev;
+    hipError_t e = hipStreamBeginCapture(f->st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      f->step_graph_off = true;
+      return enqueue(f);
+    }
+    const int rc = enqueue(f);
+    hipGraph_t gr = nullptr;
+    e = hipStreamEndCapture(f->st, &gr);
+    f->njev = njev0;                                             // counted when the graph runs, below
+    if (rc || e != hipSuccess || !gr || hipGraphInstantiate(&exec, gr, nullptr, nullptr, 0) != hipSuccess) {
+      if (gr) (void)hipGraphDestroy(gr);
+      (void)hipGetLastError();
+      exec = nullptr;
+      f->step_graph_off = true;
+      if (rc) return rc;
+      return enqueue(f);
+    }
+    (void)hipGraphDestroy(gr);
+  }
+  HIPCHK(f, hipGraphLaunch(exec, f->st));
+  f->graph_launches++;
+  if (which == 1) {            // what enqueue_accept's host side does besides launching
+    f->r_fresh = false;
+    f->have_cov = false;
+    f->have_dense_A = false;
+    f->njev++;
+    f->mirrors_stale = true;
+  } else {
+    f->r_fresh = false;
+  }
+  return 0;
+}
+
 int iterate_device(lsqamd_fit *f) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
   int bad_steps = 0;
   while (true) {
-    int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false);
+    int rc = run_half(f, 0, enqueue_trial);
     if (rc) return rc;
-    HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
-    rc = eval_residual_launch(f, f->p_trial);
-    if (rc) return rc;
-    f->r_fresh = true;      // f->r is the whitened residual AT p_trial (used if the trial is accepted)
-    f->r_ptr = f->p_trial;
-    HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
-    HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
     HIPCHK(f, hipStreamSynchronize(f->st));
     const double *st = f->pin_lm;
     f->ntrial++;
@@ -905,12 +973,9 @@ int iterate_device(lsqamd_fit *f) {
     f->nu = (long)st[LMS_NU];
     f->delta = st[LMS_DELTA];
     if (st[LMS_ACCEPT] != 0.0) {
-      rc = eval_normal_dev(f, f->p_trial, false);
+      rc = run_half(f, 1, enqueue_accept);
       if (rc) return rc;
       std::swap(f->p_dev, f->p_trial);
-      HIPCHK(f, launch_scale_update(f->st, P, f->opt.scaler, 0, f->diag_dev, f->dscale));
-      HIPCHK(f, launch_lm_converge(f->st, P, f->p_dev, f->yv + P, gvec, f->opt.xtol, f->opt.gtol, f->lmd));
-      HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
       HIPCHK(f, hipStreamSynchronize(f->st));
       f->chi2 = f->pin_lm[LMS_CHI2];
       f->conv_info_dev = (int32_t)f->pin_lm[LMS_INFO];
@@ -1300,6 +1365,7 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
 int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const double *consts,
                     int32_t n_consts) {
   if (!f) return LSQAMD_EINVAL;
+  f->drop_step_graphs();
   if (!code || n_code < 1 || n_code > f->tape_cap || n_consts < 0 || n_consts > 1024)
     FAIL(f, LSQAMD_EINVAL, "set_tape: 1..%d instructions (lsqamd_config.tape_len), <= 1024 constants", f->tape_cap);
   // validate stack discipline and operand ranges on the host
@@ -1339,6 +1405,7 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
                     const int64_t *block_row0, const int64_t *block_size, const int64_t *block_modes,
                     const int32_t *block_tri, const double *wt) {
   if (!f) return LSQAMD_EINVAL;
+  f->drop_step_graphs();
   if (n_blocks != f->cfg.n_blocks) FAIL(f, LSQAMD_EINVAL, "set_data: n_blocks differs from the config");
   if (f->N > 0 && (!ymean || !wdiag)) FAIL(f, LSQAMD_EINVAL, "set_data: null ymean/wdiag");
   if (n_blocks > 0 && (!block_row0 || !block_size || !block_modes || !wt))
@@ -1416,6 +1483,7 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   if (!(opt->factor_up > 1.0) || !(opt->factor_down > 1.0)) FAIL(f, LSQAMD_EINVAL, "set_options: factors must exceed 1");
   if (opt->trs < LSQAMD_TRS_LM || opt->trs > LSQAMD_TRS_MINPACK_LM) FAIL(f, LSQAMD_EINVAL, "set_options: unknown trust-region method");
   f->opt = *opt;
+  f->drop_step_graphs();   // tolerances, factors and the scaler are baked into the captured nodes
   return 0;
 }
 
@@ -1459,6 +1527,7 @@ int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
 
 int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) {
   if (!f) return LSQAMD_EINVAL;
+  f->drop_step_graphs();
   if (!row_param) {
     f->have_param_rows = false;
     return 0;
@@ -1503,6 +1572,7 @@ int lsqamd_set_reduce(lsqamd_fit *f, lsqamd_reduce_fn fn, void *user) {
 int lsqamd_set_adds_prior(lsqamd_fit *f, int32_t on) {
   if (!f) return LSQAMD_EINVAL;
   f->adds_prior = on != 0;
+  f->drop_step_graphs();
   return 0;
 }
 
@@ -1984,7 +2054,8 @@ void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long 
 // introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;
-  return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | ((int64_t)f->splits << 8) |
+  return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | (int64_t)(f->graph_launches > 0 ? 4 : 0) |
+         ((int64_t)f->splits << 8) |
          ((int64_t)f->h_size.size() << 32);
 }
 

@@ -170,7 +170,7 @@ hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int3
 // M (P x ld, upper tiles) = A + mu diag(d^2); M[:, P] = g
 hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
                                const double *diag, const double *g, double *Mout,
-                               const double *frozen = nullptr);
+                               const double *frozen = nullptr, const double *mu_dev = nullptr);
 hipError_t launch_packed_diag(hipStream_t st, const double *apk, int64_t P, double *out);
 hipError_t launch_unpack_sym(hipStream_t st, const double *apk, int64_t P, double *out, int64_t ld);
 hipError_t launch_symmetrize_from_upper(hipStream_t st, double *A, int64_t P, int64_t ld);

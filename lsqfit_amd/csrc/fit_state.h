@@ -117,7 +117,21 @@ struct lsqamd_fit {
   bool timing = false;
   lsqamd_host::TimerSlot timers[LSQAMD_T_COUNT];
 
+  // captured LM step (iterate_device): [p-buffer parity][0 = trial, 1 = accepted branch]
+  hipGraphExec_t step_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  int step_seen[2][2] = {{0, 0}, {0, 0}};   // eager executions so far (the first one is the warm-up)
+  bool step_graph_off = false;               // capture failed once on this handle: stay eager
+  double *p_buf0 = nullptr;                  // the buffer p_dev started as (parity 0)
+  int64_t graph_launches = 0;
+  void drop_step_graphs() {
+    for (auto &row : step_exec)
+      for (auto &e : row)
+        if (e) { (void)hipGraphExecDestroy(e); e = nullptr; }
+    for (auto &row : step_seen) row[0] = row[1] = 0;
+  }
+
   ~lsqamd_fit() {  // every exit path (including the failure returns of lsqamd_create) ends here
+    drop_step_graphs();
     for (auto &t : timers)
       for (auto &pr : t.pending) {
         (void)hipEventDestroy(pr.first);

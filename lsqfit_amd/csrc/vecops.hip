@@ -330,8 +330,10 @@ hipError_t launch_param_rows(hipStream_t st, const int32_t *row_param, int64_t N
 // M[i][j] = A[i][j] + mu d_i^2 [i==j] for the upper tiles; M[i][P] = g[i].  frozen (nullable):
 // parameters with frozen[i] != 0 are taken out of the system (unit row/column, zero right-hand side)
 __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, int64_t P, int64_t T,
-                                                           int64_t ld, double mu, const double *diag,
-                                                           const double *g, double *M, const double *frozen) {
+                                                           int64_t ld, double mu_arg, const double *diag,
+                                                           const double *g, double *M, const double *frozen,
+                                                           const double *mu_dev) {
+  const double mu = mu_dev ? *mu_dev : mu_arg;   // the device-resident LM state (a captured step must not bake mu in)
   int64_t t = blockIdx.x, tm = 0;
   while (t >= T - tm) { t -= T - tm; ++tm; }
   const int64_t tn = tm + t;
@@ -354,10 +356,11 @@ __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, in
 }
 
 hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
-                               const double *diag, const double *g, double *Mout, const double *frozen) {
+                               const double *diag, const double *g, double *Mout, const double *frozen,
+                               const double *mu_dev) {
   const int64_t T = (P + TB - 1) / TB;
   dim3 grid((unsigned)(T * (T + 1) / 2), 16);
-  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout, frozen);
+  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout, frozen, mu_dev);
   return hipGetLastError();
 }
 

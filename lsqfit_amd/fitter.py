@@ -114,7 +114,10 @@ class DeviceProblem:
         self.workspace = torch.empty(nbytes + 512, dtype=torch.uint8, device=self.device)
         base = self.workspace.data_ptr()
         self._ws_off = (-base) % 256
-        self.stream = torch.cuda.current_stream(self.device)
+        # a stream of its own: the caller's current stream may be the legacy default stream, which cannot be
+        # captured (the LM step of small problems is replayed from graphs); every entry point of the
+        # library synchronises its stream before handing results back, so callers see no difference
+        self.stream = torch.cuda.Stream(device=self.device)
         h = C.c_void_p()
         rc = self.lib.lsqamd_create(C.byref(cfg), C.c_void_p(base + self._ws_off), nbytes,
                                     C.c_void_p(self.stream.cuda_stream), C.byref(h))
