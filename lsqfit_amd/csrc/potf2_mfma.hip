@@ -679,11 +679,20 @@ __device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, d
 // factorisation without the block ever returning to memory.  (Before: a full 128 x 128 x 128 tile
 // product through eight dependent DMA stages, a store and a reload: 15.6 us of MFMA alone.)
 constexpr int DLD = 128 + 16;                                  // LDS row of the one-shot panel tile
-constexpr size_t DIAG_LDS_BYTES = (size_t)128 * DLD * sizeof(double);
+
+// Wave W holds tile columns W and W + 4, i.e. 2 W + 6 of the 36 upper tiles: 6 / 8 / 10 / 12.  To give
+// every wave 9 MFMAs per k-chunk, wave 0 computes the contributions to wave 3's tiles (0..2, 7) and
+// wave 1 the one to wave 2's tile (0, 6) into fresh accumulators; they travel through 8 KiB of LDS
+// behind the panel tile and are added by their owners after the barrier that follows anyway.
+constexpr int DIAG_HELP_OFF = 128 * DLD;                       // doubles: 4 tiles x 4 registers x 64 lanes behind the panel
+constexpr size_t DIAG_LDS_BYTES = (size_t)(128 * DLD + 4 * 4 * 64) * sizeof(double);
 
 template <int W>
-__device__ __forceinline__ void diag_update_from_panel(TileRegs &T, const double *Ps, int lane) {
+__device__ __forceinline__ void diag_update_from_panel(TileRegs &T, double *Ps, int lane) {
   const int col = lane & 15, q = lane >> 4;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  v4d h0 = zero, h1 = zero, h2 = zero;                          // helper accumulators (waves 0 and 1)
+  constexpr int SKIP1 = W == 3 ? 3 : (W == 2 ? 1 : 0);          // leading tiles of column W + 4 done by a helper
   for (int kc = 0; kc < 32; ++kc) {
     const double *row = Ps + (4 * kc + q) * DLD + col;
     double a[8];
@@ -694,10 +703,46 @@ __device__ __forceinline__ void diag_update_from_panel(TileRegs &T, const double
 #pragma unroll
     for (int ti = 0; ti < 8; ++ti) {
       if (ti < W) T.X[0][ti] = mfma4(a[ti], b0, T.X[0][ti]);
-      if (ti < W + 4) T.X[1][ti] = mfma4(a[ti], b1, T.X[1][ti]);
+      if (ti < W + 4 && ti >= SKIP1) T.X[1][ti] = mfma4(a[ti], b1, T.X[1][ti]);
     }
     T.DA[0] = mfma4(a[W], b0, T.DA[0]);
     T.DA[1] = mfma4(a[W + 4], b1, T.DA[1]);
+    if constexpr (W == 0) {
+      const double b7 = row[16 * 7];
+      h0 = mfma4(a[0], b7, h0);
+      h1 = mfma4(a[1], b7, h1);
+      h2 = mfma4(a[2], b7, h2);
+    }
+    if constexpr (W == 1) h0 = mfma4(a[0], row[16 * 6], h0);
+  }
+  double *help = Ps + DIAG_HELP_OFF;
+  if constexpr (W == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      help[(0 * 4 + r) * 64 + lane] = h0[r];
+      help[(1 * 4 + r) * 64 + lane] = h1[r];
+      help[(2 * 4 + r) * 64 + lane] = h2[r];
+    }
+  }
+  if constexpr (W == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) help[(3 * 4 + r) * 64 + lane] = h0[r];
+  }
+}
+
+// after the barrier: the owners add what the helpers computed for them
+template <int W>
+__device__ __forceinline__ void diag_update_collect(TileRegs &T, const double *Ps, int lane) {
+  const double *help = Ps + DIAG_HELP_OFF;
+  if constexpr (W == 3) {
+#pragma unroll
+    for (int ti = 0; ti < 3; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T.X[1][ti][r] += help[(ti * 4 + r) * 64 + lane];
+  }
+  if constexpr (W == 2) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T.X[1][0][r] += help[(3 * 4 + r) * 64 + lane];
   }
 }
 
@@ -717,6 +762,7 @@ __device__ __forceinline__ void fused_diag_wave(const TrailArgs &t, double *Adia
   __syncthreads();
   diag_update_from_panel<W>(T, smem, lane);
   __syncthreads();   // the panel tile is dead: its LDS becomes the sweep's scratch
+  diag_update_collect<W>(T, smem, lane);
   LeafShared &sh = *reinterpret_cast<LeafShared *>(smem);
   long long *dbg = nullptr;
   Slab16Loop<0, W>::run(T, sh, info, k0n, nb, lane, dbg);
