@@ -693,6 +693,7 @@ __device__ __forceinline__ void diag_update_from_panel(TileRegs &T, double *Ps, 
   const v4d zero = {0.0, 0.0, 0.0, 0.0};
   v4d h0 = zero, h1 = zero, h2 = zero;                          // helper accumulators (waves 0 and 1)
   constexpr int SKIP1 = W == 3 ? 3 : (W == 2 ? 1 : 0);          // leading tiles of column W + 4 done by a helper
+#pragma unroll 4
   for (int kc = 0; kc < 32; ++kc) {
     const double *row = Ps + (4 * kc + q) * DLD + col;
     double a[8];
