@@ -1017,17 +1017,19 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
       __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(xring + (sidx % 3) * 32), 4, 0, 0);
     }
   };
-  int64_t ssyn = 0;     // index of the stage `stage` builds next
-  auto stage = [&](int buf) {
-    double xs4[4];
-    const double *xq = xring + (ssyn % 3) * 32 + srow;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xs4[i] = xq[4 * i];
+  int64_t ssyn = 0;     // index of the stage `stage_synth` builds next
+  auto stage_dma = [&](int buf) {
     double *Xs = smem + buf * STAGE + wave * LDT;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
     xp += 4 * xstep;
+  };
+  auto stage_synth = [&](int buf) {
+    double xs4[4];
+    const double *xq = xring + (ssyn % 3) * 32 + srow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xs4[i] = xq[4 * i];
     double *Ys = smem + buf * STAGE + BK * LDT;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1053,14 +1055,16 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
   const int fr = lane & 15, fq = lane >> 4;
   xdma(0);
   xdma(1);
+  stage_dma(0);          // the first operand rows travel together with the abscissae: one exposed latency, not two
   __syncthreads();
-  stage(0);
+  stage_synth(0);
   __syncthreads();
   int cur = 0;
   for (int64_t k0 = 0; k0 < ke; k0 += BK) {
     if (k0 + BK < ke) {
       if (k0 + 2 * BK < ke) xdma(k0 / BK + 2);
-      stage(cur ^ 1);
+      stage_dma(cur ^ 1);
+      stage_synth(cur ^ 1);
     }
     const double *Xs = smem + cur * STAGE;
     const double *Ys = Xs + BK * LDT;
