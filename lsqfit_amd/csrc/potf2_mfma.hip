@@ -383,7 +383,8 @@ __device__ __forceinline__ void leaf_slab(v4d &DA, v4d &DE, int &bad, int lane) 
 
 // 16 x 16 leaf [D | I] -> [U | U^-T] in place in the owner's registers (accumulator layout), then
 // published row-major for the other waves
-__device__ __forceinline__ void leaf16(v4d &DA, v4d &DE, LeafShared &sh, int32_t *info, int32_t row0, int lane) {
+template <class SH>
+__device__ __forceinline__ void leaf16(v4d &DA, v4d &DE, SH &sh, int32_t *info, int32_t row0, int lane) {
   const int col = lane & 15, q = lane >> 4;
   int bad = -1;
   leaf_slab<0>(DA, DE, bad, lane);
@@ -587,6 +588,324 @@ __global__ __launch_bounds__(256) void potf2_mfma_kernel(double *A, int64_t lda,
   else if (wave == 1) potf2_wave<1>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
   else if (wave == 2) potf2_wave<2>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
   else potf2_wave<3>(A, lda, nb, uinv, info, k0, mop, slabA, lane);
+}
+
+// ================================================================================================
+// Third formulation: ONE pivot wave + THREE tile waves (16-row slabs as above).
+//
+// In the formulation above the wave that factors leaf TI + 1 also carries a quarter of the scaling and
+// of the rank-16 update of slab TI: that share sits between two leaves of the pivot chain (stamps:
+// leaf 5.1 k cycles, everything between two leaves 2.6 k, per slab).  Here wave 0 holds no tiles and
+// does nothing but leaves; the eight tile columns are dealt to waves 1..3 (V4_COLS below).  The owner of column TI + 1 scales its tile (TI, TI + 1) first, applies it to the
+// next diagonal tile at once (its own registers are the A operand) and hands that tile to the pivot
+// wave through LDS with a flag -- 8 MFMAs and one LDS hop between two leaves; the other scaling and
+// the whole update run on the other three SIMDs while the next leaf is being factored.  One
+// workgroup barrier pair per slab as before (the pivot wave takes part: B1 = "U, W of leaf TI are
+// published", B2 = "the scaled slab row is published").
+// column tj takes part in tj (tj + 1) / 2 + (7 - tj)(8 - tj) / 2 tile updates over the sweep: 28 22 18 16 16 18 22 28;
+// dealt so that the three waves carry 56 / 60 / 52 of the 168
+constexpr int V4_COLS[3][3] = {{0, 7, -1}, {1, 3, 6}, {2, 4, 5}};
+constexpr int v4_col(int U, int c) { return V4_COLS[U][c]; }
+constexpr bool v4_has(int U, int c) { return V4_COLS[U][c] >= 0; }
+constexpr int v4_owner(int tj) {
+  for (int u = 0; u < 3; ++u)
+    for (int c = 0; c < 3; ++c)
+      if (V4_COLS[u][c] == tj) return u;
+  return -1;
+}
+constexpr int v4_slot(int tj) {
+  for (int u = 0; u < 3; ++u)
+    for (int c = 0; c < 3; ++c)
+      if (V4_COLS[u][c] == tj) return c;
+  return -1;
+}
+
+struct TileRegs4 {
+  v4d X[3][8];  // slot c <-> tile column V4_COLS[U][c] (as TileRegs)
+  v4d DA[3];
+  v4d DE[3];
+};
+
+struct Leaf4Shared {
+  double Ul[2][16 * LW];      // by leaf parity: the pivot wave may be a leaf ahead of the slowest tile wave
+  double Wl[2][16 * LW];
+  double slabA[2][8 * 4 * 64];
+  double stage[3][16 * LW];
+  double Dbuf[4 * 64];        // the next diagonal tile in accumulator layout (register r, lane)
+  volatile int flagD[8];      // != 0: diagonal tile t is in Dbuf            (tile wave -> pivot wave)
+  volatile int flagW[8];      // != 0: U, W of leaf t are in Ul / Wl[t & 1]  (pivot wave -> tile waves)
+  int cnt[8];                 // tile waves that have published their part of scaled slab row t
+#ifdef LSQAMD_POTF2_TIMING
+  long long stamps[64];
+#endif
+};
+struct LeafOut { double *Ul, *Wl; };   // what leaf16 writes to
+
+#ifdef LSQAMD_POTF2_TIMING
+#define V4STAMP(i) do { if (lane == 0) sh.stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define V4STAMP(i) do { } while (0)
+#endif
+
+template <int U>
+__device__ __forceinline__ void load_tiles4(TileRegs4 &T, const double *A, int64_t lda, int nb, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (v4_has(U, c)) {
+      const int tj = v4_col(U, c);
+      const int gc = 16 * tj + col;
+      const int gcc = gc < nb ? gc : nb - 1;
+#pragma unroll
+      for (int ti = 0; ti < 8; ++ti) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gr = 16 * ti + 4 * r + q;
+          const int grc = gr < nb ? gr : nb - 1;
+          double a = 0.0;
+          if (ti <= tj) a = A[(int64_t)grc * lda + gcc];
+          a = (gr < nb && gc < nb) ? a : (gr == gc ? 1.0 : 0.0);
+          if (ti < tj) T.X[c][ti][r] = a;
+          else if (ti == tj) T.DA[c][r] = a;
+          // E-part tiles (ti > tj) come to life at slab tj (upd4_tile); DE with the leaf: with all 27
+          // tiles of a wave live here the compiler serialises the loads behind register spills
+        }
+      }
+    }
+  }
+}
+
+// The inverse: E(gr, gc) = W[gr][gc], lower triangular -> uinv[gc][gr], through a per-wave LDS tile as in
+// store_tiles_v3.  (U itself has left already: every row slab is stored the moment it is scaled, the
+// diagonal tiles by the pivot wave -- which also keeps at most ~16 tiles of a wave alive at any time.)
+template <int U>
+__device__ __forceinline__ void store_tiles4(const TileRegs4 &T, int nb, double *uinv, double *stage, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+  const int jj = lane >> 2, i4 = 4 * (lane & 3);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (v4_has(U, c)) {
+      const int tj = v4_col(U, c);
+#pragma unroll
+      for (int ti = 0; ti < 8; ++ti) {
+        v4d w4 = {0.0, 0.0, 0.0, 0.0};
+        if (ti >= tj && 16 * tj < nb) {      // (columns beyond nb never saw their slab: their E tiles do not exist)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) stage[(4 * r + q) * LW + col] = (ti > tj) ? T.X[c][ti][r] : T.DE[c][r];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) w4[t] = stage[(i4 + t) * LW + jj];
+        }
+        const int gcw = 16 * tj + jj;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int gr = 16 * ti + i4 + t;
+          w4[t] = (gr >= gcw && gr < nb && gcw < nb) ? w4[t] : 0.0;
+        }
+        *reinterpret_cast<v4d *>(uinv + gcw * NB + 16 * ti + i4) = w4;   // unconditional: see store_tiles_v3
+      }
+    }
+  }
+}
+
+// rank-16 update of ONE tile (TR, tj = U + 3 C) with slab TI (cases as upd16_tile)
+template <int TI, int U, int TR, int C>
+__device__ __forceinline__ void upd4_tile(TileRegs4 &T, const Leaf4Shared &sh, int lane) {
+  if constexpr (v4_has(U, C)) {
+    constexpr int tj = v4_col(U, C);
+    constexpr bool live = (TR < tj) || (TR == tj) || (tj <= TI);
+    if constexpr (live) {
+      double a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = sh.slabA[TI & 1][(TR * 4 + j) * 64 + lane];
+      if constexpr (TR < tj) T.X[C][TR] = mfma4x4(a, T.X[C][TI], T.X[C][TR]);
+      else if constexpr (TR == tj) T.DA[C] = mfma4x4(a, T.X[C][TI], T.DA[C]);
+      else if constexpr (tj < TI) T.X[C][TR] = mfma4x4(a, T.X[C][TI], T.X[C][TR]);
+      else {                                                       // tj == TI: the E tile's first contribution
+        const v4d zero = {0.0, 0.0, 0.0, 0.0};
+        T.X[C][TR] = mfma4x4(a, T.DE[C], zero);
+      }
+    }
+  }
+}
+
+template <int TI, int U, int TR, int C, int SKIP_TR, int SKIP_C>
+__device__ __forceinline__ void upd4_rest(TileRegs4 &T, const Leaf4Shared &sh, int lane) {
+  if constexpr (TR <= 7) {
+    if constexpr (!(TR == SKIP_TR && C == SKIP_C)) upd4_tile<TI, U, TR, C>(T, sh, lane);
+    if constexpr (C < 2) upd4_rest<TI, U, TR, C + 1, SKIP_TR, SKIP_C>(T, sh, lane);
+    else upd4_rest<TI, U, TR + 1, 0, SKIP_TR, SKIP_C>(T, sh, lane);
+  }
+}
+
+// hand a diagonal tile to the pivot wave
+__device__ __forceinline__ void publish_diag(const v4d &D, Leaf4Shared &sh, int t, int lane) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) sh.Dbuf[r * 64 + lane] = D[r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) sh.flagD[t] = 1;
+}
+
+template <int TI, int U>
+__device__ __forceinline__ void slab4_step(TileRegs4 &T, Leaf4Shared &sh, double *A, int64_t lda, int nb, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+  auto store_row_tile = [&](const v4d &t, int tj) {   // rows 16 TI.. of U, tile column tj > TI: final
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gr = 16 * TI + 4 * r + q, gc = 16 * tj + col;
+      if (gr < nb && gc < nb) A[(int64_t)gr * lda + gc] = t[r];
+    }
+  };
+  while (sh.flagW[TI] == 0) __builtin_amdgcn_s_sleep(0);     // U, W of leaf TI are in LDS
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  const double *Ul = sh.Ul[TI & 1], *Wl = sh.Wl[TI & 1];
+  double *slab = sh.slabA[TI & 1];
+  (void)Ul;
+  if constexpr (v4_owner(TI) == U) {   // my column TI: the leaf's W is the diagonal tile of its E part
+    constexpr int c = v4_slot(TI);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) T.DE[c][r] = Wl[(4 * r + q) * LW + col];
+  }
+  double wop[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wop[j] = Wl[col * LW + 4 * j + q];
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  constexpr int NT = TI + 1;
+  constexpr bool next_owner = NT < 8 && v4_owner(NT < 8 ? NT : 0) == U;
+  constexpr int NC = v4_slot(NT < 8 ? NT : 0);
+  if constexpr (next_owner) {
+    // tile (TI, NT) first, then the next diagonal tile with it: the pivot wave is waiting for that one
+    const v4d t = mfma4x4(wop, T.X[NC][TI], zero);
+    T.X[NC][TI] = t;
+    double a[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = -t[j];
+      slab[(NT * 4 + j) * 64 + lane] = a[j];
+    }
+    T.DA[NC] = mfma4x4(a, t, T.DA[NC]);
+    publish_diag(T.DA[NC], sh, NT, lane);
+    store_row_tile(t, NT);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (v4_has(U, c)) {
+      const int tj = v4_col(U, c);
+      if (tj != TI && !(next_owner && c == NC)) {
+        const v4d t = mfma4x4(wop, T.X[c][TI], zero);
+        T.X[c][TI] = t;
+        if (tj > TI) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) slab[(tj * 4 + j) * 64 + lane] = -t[j];
+          store_row_tile(t, tj);
+        }
+      }
+    }
+  }
+  // the scaled slab row is complete when all three tile waves have published their part (the pivot
+  // wave is not in this: it is already factoring the next leaf)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  if (lane == 0) __hip_atomic_fetch_add(&sh.cnt[TI], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(&sh.cnt[TI], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 3) __builtin_amdgcn_s_sleep(0);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if constexpr (TI < 7) {
+    if constexpr (next_owner) upd4_rest<TI, U, TI + 1, 0, NT, NC>(T, sh, lane);
+    else upd4_rest<TI, U, TI + 1, 0, -1, -1>(T, sh, lane);
+  }
+  if constexpr (U == 1) V4STAMP(32 + TI);     // tile wave 2: done with slab TI
+}
+
+template <int TI, int U>
+struct Slab4Loop {
+  static __device__ __forceinline__ void run(TileRegs4 &T, Leaf4Shared &sh, double *A, int64_t lda, int nb, int lane) {
+    if (16 * TI >= nb) return;  // identity padding: nothing left to eliminate (uniform; the pivot wave stops too)
+    slab4_step<TI, U>(T, sh, A, lda, nb, lane);
+    Slab4Loop<TI + 1, U>::run(T, sh, A, lda, nb, lane);
+  }
+};
+template <int U>
+struct Slab4Loop<8, U> {
+  static __device__ __forceinline__ void run(TileRegs4 &, Leaf4Shared &, double *, int64_t, int, int) {}
+};
+
+// the pivot wave: leaves only
+__device__ __forceinline__ void pivot_wave4(Leaf4Shared &sh, double *A, int64_t lda, int32_t *info, int32_t k0, int nb,
+                                            int lane) {
+  const int col = lane & 15, q = lane >> 4;
+  for (int ti = 0; ti < 8; ++ti) {
+    if (16 * ti >= nb) return;
+    V4STAMP(4 * ti);
+    v4d DA, DE;
+    if (ti == 0) {          // the first diagonal tile comes straight from memory (identity outside nb x nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gr = 4 * r + q;
+        const double a = A[(int64_t)(gr < nb ? gr : nb - 1) * lda + (col < nb ? col : nb - 1)];
+        DA[r] = (gr < nb && col < nb) ? a : (gr == col ? 1.0 : 0.0);
+      }
+    } else {
+      while (sh.flagD[ti] == 0) __builtin_amdgcn_s_sleep(0);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+      for (int r = 0; r < 4; ++r) DA[r] = sh.Dbuf[r * 64 + lane];
+    }
+    V4STAMP(4 * ti + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) DE[r] = (4 * r + q == col) ? 1.0 : 0.0;
+    LeafOut out = {sh.Ul[ti & 1], sh.Wl[ti & 1]};
+    leaf16(DA, DE, out, info, k0 + 16 * ti, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) sh.flagW[ti] = 1;
+    V4STAMP(4 * ti + 2);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {            // the diagonal tile of U (leaf16 left it masked to its upper triangle)
+      const int gr = 16 * ti + 4 * r + q, gc = 16 * ti + col;
+      if (gr < nb && gc < nb && gc >= gr) A[(int64_t)gr * lda + gc] = DA[r];
+    }
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void tile_wave4(double *A, int64_t lda, int nb, double *uinv, Leaf4Shared &sh, int lane) {
+  TileRegs4 T;
+  load_tiles4<U>(T, A, lda, nb, lane);
+  Slab4Loop<0, U>::run(T, sh, A, lda, nb, lane);
+  store_tiles4<U>(T, nb, uinv, sh.stage[U], lane);
+}
+
+__device__ __forceinline__ void potf2v4_run(double *A, int64_t lda, int nb, double *uinv, int32_t *info, int32_t k0,
+                                            Leaf4Shared &sh, int tid) {
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (tid < 8) {
+    sh.flagD[tid] = 0;
+    sh.flagW[tid] = 0;
+    sh.cnt[tid] = 0;
+  }
+  __syncthreads();
+  if (wave == 0) pivot_wave4(sh, A, lda, info, k0, nb, lane);
+  else if (wave == 1) tile_wave4<0>(A, lda, nb, uinv, sh, lane);
+  else if (wave == 2) tile_wave4<1>(A, lda, nb, uinv, sh, lane);
+  else tile_wave4<2>(A, lda, nb, uinv, sh, lane);
+}
+
+__global__ __launch_bounds__(256) void potf2_v4_kernel(double *A, int64_t lda, int nb, double *uinv, int32_t *info,
+                                                       int32_t k0, int64_t strideA, int64_t strideW,
+                                                       const int32_t *active, long long *dbg) {
+  __shared__ Leaf4Shared sh;
+  if (active && !active[blockIdx.x]) return;
+  A += (int64_t)blockIdx.x * strideA;
+  uinv += (int64_t)blockIdx.x * strideW;
+  info += blockIdx.x;
+#ifdef LSQAMD_POTF2_TIMING
+  if (threadIdx.x == 0) sh.stamps[60] = (long long)__builtin_readcyclecounter();
+#endif
+  potf2v4_run(A, lda, nb, uinv, info, k0, sh, threadIdx.x);
+#ifdef LSQAMD_POTF2_TIMING
+  __syncthreads();
+  if (threadIdx.x == 0) sh.stamps[63] = (long long)__builtin_readcyclecounter();
+  __syncthreads();
+  if (dbg && threadIdx.x < 64) dbg[threadIdx.x] = sh.stamps[threadIdx.x];
+#endif
 }
 
 // ---- trailing update of step k with the diagonal block of step k + 1 riding along -------------
@@ -817,7 +1136,11 @@ hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, dou
                              int32_t k0, int32_t batch, int64_t strideA, int64_t strideW,
                              const int32_t *active) {
   static const bool v2 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '2'; }();
-  if (v2)
+  static const bool v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '4'; }();
+  if (v4)
+    hipLaunchKernelGGL(potf2_v4_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info, k0, strideA,
+                       strideW, active, g_potf2_dbg);
+  else if (v2)
     hipLaunchKernelGGL(potf2_mfma_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info,
                        k0, strideA, strideW, active);
   else
