@@ -630,7 +630,7 @@ struct Leaf4Shared {
   double Ul[2][16 * LW];      // by leaf parity: the pivot wave may be a leaf ahead of the slowest tile wave
   double Wl[2][16 * LW];
   double slabA[2][8 * 4 * 64];
-  double stage[3][16 * LW];
+  double stage[4][16 * LW];   // per wave: transposition buffer of the inverse's stores (0..2 tile waves, 3 pivot wave)
   double Dbuf[4 * 64];        // the next diagonal tile in accumulator layout (register r, lane)
   volatile int flagD[8];      // != 0: diagonal tile t is in Dbuf            (tile wave -> pivot wave)
   volatile int flagW[8];      // != 0: U, W of leaf t are in Ul / Wl[t & 1]  (pivot wave -> tile waves)
@@ -675,34 +675,41 @@ __device__ __forceinline__ void load_tiles4(TileRegs4 &T, const double *A, int64
   }
 }
 
-// The inverse: E(gr, gc) = W[gr][gc], lower triangular -> uinv[gc][gr], through a per-wave LDS tile as in
-// store_tiles_v3.  (U itself has left already: every row slab is stored the moment it is scaled, the
-// diagonal tiles by the pivot wave -- which also keeps at most ~16 tiles of a wave alive at any time.)
-template <int U>
-__device__ __forceinline__ void store_tiles4(const TileRegs4 &T, int nb, double *uinv, double *stage, int lane) {
+// The inverse: E(gr, gc) = W[gr][gc], lower triangular -> uinv[gc][gr].  A 16 x 16 tile (ti, tj) of E is
+// final the moment row slab ti is scaled and leaves right then, through the wave's LDS tile so that
+// every store writes whole 128-byte row segments (as store_tiles_v3); the diagonal tiles are the pivot
+// wave's.  The tiles above the diagonal of the inverse (ti < tj) are zeros, written once up front.
+// U itself: every row slab is stored as it is scaled, the diagonal tiles by the pivot wave.  At most
+// ~16 tiles of a wave are alive at any time, and nothing is left to store when the last leaf is done.
+__device__ __forceinline__ void store_inv_tile(const v4d &t, int ti, int tj, int nb, double *uinv, double *stage,
+                                               int lane) {
   const int col = lane & 15, q = lane >> 4;
   const int jj = lane >> 2, i4 = 4 * (lane & 3);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) stage[(4 * r + q) * LW + col] = t[r];
+  v4d w4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w4[k] = stage[(i4 + k) * LW + jj];
+  const int gcw = 16 * tj + jj;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int gr = 16 * ti + i4 + k;
+    w4[k] = (gr >= gcw && gr < nb && gcw < nb) ? w4[k] : 0.0;
+  }
+  *reinterpret_cast<v4d *>(uinv + gcw * NB + 16 * ti + i4) = w4;   // unconditional: see store_tiles_v3
+}
+
+template <int U>
+__device__ __forceinline__ void zero_upper_inv(double *uinv, int lane) {
+  const int jj = lane >> 2, i4 = 4 * (lane & 3);
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     if (v4_has(U, c)) {
       const int tj = v4_col(U, c);
 #pragma unroll
-      for (int ti = 0; ti < 8; ++ti) {
-        v4d w4 = {0.0, 0.0, 0.0, 0.0};
-        if (ti >= tj && 16 * tj < nb) {      // (columns beyond nb never saw their slab: their E tiles do not exist)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) stage[(4 * r + q) * LW + col] = (ti > tj) ? T.X[c][ti][r] : T.DE[c][r];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) w4[t] = stage[(i4 + t) * LW + jj];
-        }
-        const int gcw = 16 * tj + jj;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int gr = 16 * ti + i4 + t;
-          w4[t] = (gr >= gcw && gr < nb && gcw < nb) ? w4[t] : 0.0;
-        }
-        *reinterpret_cast<v4d *>(uinv + gcw * NB + 16 * ti + i4) = w4;   // unconditional: see store_tiles_v3
-      }
+      for (int ti = 0; ti < 8; ++ti)
+        if (ti < tj) *reinterpret_cast<v4d *>(uinv + (16 * tj + jj) * NB + 16 * ti + i4) = zero;
     }
   }
 }
@@ -746,7 +753,8 @@ __device__ __forceinline__ void publish_diag(const v4d &D, Leaf4Shared &sh, int 
 }
 
 template <int TI, int U>
-__device__ __forceinline__ void slab4_step(TileRegs4 &T, Leaf4Shared &sh, double *A, int64_t lda, int nb, int lane) {
+__device__ __forceinline__ void slab4_step(TileRegs4 &T, Leaf4Shared &sh, double *A, int64_t lda, int nb, double *uinv,
+                                           int lane) {
   const int col = lane & 15, q = lane >> 4;
   auto store_row_tile = [&](const v4d &t, int tj) {   // rows 16 TI.. of U, tile column tj > TI: final
 #pragma unroll
@@ -797,6 +805,8 @@ __device__ __forceinline__ void slab4_step(TileRegs4 &T, Leaf4Shared &sh, double
 #pragma unroll
           for (int j = 0; j < 4; ++j) slab[(tj * 4 + j) * 64 + lane] = -t[j];
           store_row_tile(t, tj);
+        } else {
+          store_inv_tile(t, TI, tj, nb, uinv, sh.stage[U], lane);   // E(TI, tj): final
         }
       }
     }
@@ -816,26 +826,28 @@ __device__ __forceinline__ void slab4_step(TileRegs4 &T, Leaf4Shared &sh, double
 
 template <int TI, int U>
 struct Slab4Loop {
-  static __device__ __forceinline__ void run(TileRegs4 &T, Leaf4Shared &sh, double *A, int64_t lda, int nb, int lane) {
+  static __device__ __forceinline__ void run(TileRegs4 &T, Leaf4Shared &sh, double *A, int64_t lda, int nb, double *uinv,
+                                             int lane) {
     if (16 * TI >= nb) return;  // identity padding: nothing left to eliminate (uniform; the pivot wave stops too)
-    slab4_step<TI, U>(T, sh, A, lda, nb, lane);
-    Slab4Loop<TI + 1, U>::run(T, sh, A, lda, nb, lane);
+    slab4_step<TI, U>(T, sh, A, lda, nb, uinv, lane);
+    Slab4Loop<TI + 1, U>::run(T, sh, A, lda, nb, uinv, lane);
   }
 };
 template <int U>
 struct Slab4Loop<8, U> {
-  static __device__ __forceinline__ void run(TileRegs4 &, Leaf4Shared &, double *, int64_t, int, int) {}
+  static __device__ __forceinline__ void run(TileRegs4 &, Leaf4Shared &, double *, int64_t, int, double *, int) {}
 };
 
 // the pivot wave: leaves only
-__device__ __forceinline__ void pivot_wave4(Leaf4Shared &sh, double *A, int64_t lda, int32_t *info, int32_t k0, int nb,
-                                            int lane) {
+template <bool FIRST_FROM_MEMORY>
+__device__ __forceinline__ void pivot_wave4(Leaf4Shared &sh, double *A, int64_t lda, double *uinv, int32_t *info,
+                                            int32_t k0, int nb, int lane) {
   const int col = lane & 15, q = lane >> 4;
   for (int ti = 0; ti < 8; ++ti) {
     if (16 * ti >= nb) return;
     V4STAMP(4 * ti);
     v4d DA, DE;
-    if (ti == 0) {          // the first diagonal tile comes straight from memory (identity outside nb x nb)
+    if (FIRST_FROM_MEMORY && ti == 0) {   // the first diagonal tile comes straight from memory (identity outside nb x nb)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gr = 4 * r + q;
@@ -861,6 +873,7 @@ __device__ __forceinline__ void pivot_wave4(Leaf4Shared &sh, double *A, int64_t 
       const int gr = 16 * ti + 4 * r + q, gc = 16 * ti + col;
       if (gr < nb && gc < nb && gc >= gr) A[(int64_t)gr * lda + gc] = DA[r];
     }
+    store_inv_tile(DE, ti, ti, nb, uinv, sh.stage[3], lane);   // ... and of the inverse
   }
 }
 
@@ -868,8 +881,8 @@ template <int U>
 __device__ __forceinline__ void tile_wave4(double *A, int64_t lda, int nb, double *uinv, Leaf4Shared &sh, int lane) {
   TileRegs4 T;
   load_tiles4<U>(T, A, lda, nb, lane);
-  Slab4Loop<0, U>::run(T, sh, A, lda, nb, lane);
-  store_tiles4<U>(T, nb, uinv, sh.stage[U], lane);
+  zero_upper_inv<U>(uinv, lane);
+  Slab4Loop<0, U>::run(T, sh, A, lda, nb, uinv, lane);
 }
 
 __device__ __forceinline__ void potf2v4_run(double *A, int64_t lda, int nb, double *uinv, int32_t *info, int32_t k0,
@@ -882,7 +895,7 @@ __device__ __forceinline__ void potf2v4_run(double *A, int64_t lda, int nb, doub
     sh.cnt[tid] = 0;
   }
   __syncthreads();
-  if (wave == 0) pivot_wave4(sh, A, lda, info, k0, nb, lane);
+  if (wave == 0) pivot_wave4<true>(sh, A, lda, uinv, info, k0, nb, lane);
   else if (wave == 1) tile_wave4<0>(A, lda, nb, uinv, sh, lane);
   else if (wave == 2) tile_wave4<1>(A, lda, nb, uinv, sh, lane);
   else tile_wave4<2>(A, lda, nb, uinv, sh, lane);
@@ -1089,8 +1102,118 @@ __device__ __forceinline__ void fused_diag_wave(const TrailArgs &t, double *Adia
   store_tiles_v3<W>(T, Adiag, t.lda, nb, uinv, sh.stage[W], lane);
 }
 
+// ---- the same with the pivot-wave formulation ---------------------------------------------------
+// Upper tiles per tile wave with V4_COLS: 9 / 13 / 14.  The pivot wave (idle until the first leaf) computes
+// the contributions to four of wave 2's tiles ((0..3, 6)) and five of wave 3's ((0..4, 5)): 9 MFMAs per
+// k-chunk on every wave; 18 KiB of LDS behind the panel tile (136-double rows here: 139 + 18 KiB).
+constexpr int DLD4 = 128 + 8;
+constexpr int DIAG4_HELP_OFF = 128 * DLD4;
+constexpr size_t DIAG4_LDS_BYTES = (size_t)(128 * DLD4 + 9 * 4 * 64) * sizeof(double);
+constexpr int v4_help_skip(int U) { return U == 1 ? 4 : (U == 2 ? 5 : 0); }   // leading tiles of slot 2 done by the pivot wave
+
+template <int U>
+__device__ __forceinline__ void diag_update_from_panel4(TileRegs4 &T, const double *Ps, int lane) {
+  const int col = lane & 15, q = lane >> 4;
+#pragma unroll 4
+  for (int kc = 0; kc < 32; ++kc) {
+    const double *row = Ps + (4 * kc + q) * DLD4 + col;
+    double a[8];
+#pragma unroll
+    for (int ti = 0; ti < 8; ++ti) a[ti] = -row[16 * ti];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (v4_has(U, c)) {
+        const int tj = v4_col(U, c);
+        const double b = row[16 * tj];
+#pragma unroll
+        for (int ti = 0; ti < 8; ++ti) {
+          if (ti < tj && !(c == 2 && ti < v4_help_skip(U))) T.X[c][ti] = mfma4(a[ti], b, T.X[c][ti]);
+          if (ti == tj) T.DA[c] = mfma4(a[ti], b, T.DA[c]);
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void diag_update_help4(double *Ps, int lane) {   // the pivot wave's share
+  const int col = lane & 15, q = lane >> 4;
+  const v4d zero = {0.0, 0.0, 0.0, 0.0};
+  v4d h[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) h[i] = zero;
+#pragma unroll 4
+  for (int kc = 0; kc < 32; ++kc) {
+    const double *row = Ps + (4 * kc + q) * DLD4 + col;
+    double a[5];
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti) a[ti] = -row[16 * ti];
+    const double b6 = row[16 * 6], b5 = row[16 * 5];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti) h[ti] = mfma4(a[ti], b6, h[ti]);
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti) h[4 + ti] = mfma4(a[ti], b5, h[4 + ti]);
+  }
+  double *help = Ps + DIAG4_HELP_OFF;
+#pragma unroll
+  for (int i = 0; i < 9; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) help[(i * 4 + r) * 64 + lane] = h[i][r];
+}
+
+template <int U>
+__device__ __forceinline__ void diag_update_collect4(TileRegs4 &T, const double *Ps, int lane) {
+  const double *help = Ps + DIAG4_HELP_OFF;
+  static_assert(V4_COLS[1][2] == 6 && V4_COLS[2][2] == 5, "the pivot wave's helper tiles are columns 6 and 5");
+  if constexpr (U == 1) {
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T.X[2][ti][r] += help[(ti * 4 + r) * 64 + lane];
+  }
+  if constexpr (U == 2) {
+#pragma unroll
+    for (int ti = 0; ti < 5; ++ti)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T.X[2][ti][r] += help[((4 + ti) * 4 + r) * 64 + lane];
+  }
+}
+
+template <int WV>   // 0: pivot wave, 1..3: tile waves U = WV - 1
+__device__ __forceinline__ void fused_diag_wave4(const TrailArgs &t, double *Adiag, int nb, double *uinv, int32_t *info,
+                                                 int32_t k0n, double *smem, int tid) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int lane = tid & 63;
+#pragma unroll 8
+  for (int i = 0; i < 32; ++i) {
+    const int k = WV * 32 + i;
+    __builtin_amdgcn_global_load_lds((glb_void *)(t.P + (int64_t)k * t.lda + 2 * lane), (lds_void *)(smem + k * DLD4), 16, 0, 0);
+  }
+  TileRegs4 T;
+  if constexpr (WV > 0) load_tiles4<WV - 1>(T, Adiag, t.lda, nb, lane);
+  __syncthreads();
+  if constexpr (WV > 0) diag_update_from_panel4<WV - 1>(T, smem, lane);
+  else diag_update_help4(smem, lane);
+  __syncthreads();   // the panel tile is dead: its LDS becomes the sweep's scratch
+  Leaf4Shared &sh = *reinterpret_cast<Leaf4Shared *>(smem);
+  if (tid < 8) {
+    sh.flagD[tid] = 0;
+    sh.flagW[tid] = 0;
+    sh.cnt[tid] = 0;
+  }
+  if constexpr (WV > 0) diag_update_collect4<WV - 1>(T, smem, lane);
+  __syncthreads();
+  if constexpr (WV == 0) {
+    pivot_wave4<false>(sh, Adiag, t.lda, uinv, info, k0n, nb, lane);
+  } else {
+    if constexpr (WV == 1) publish_diag(T.DA[0], sh, 0, lane);
+    zero_upper_inv<WV - 1>(uinv, lane);
+    Slab4Loop<0, WV - 1>::run(T, sh, Adiag, t.lda, nb, uinv, lane);
+  }
+}
+
 __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *Adiag, int nb, double *uinv,
-                                                          int32_t *info, int32_t k0n) {
+                                                          int32_t *info, int32_t k0n, int pivot_wave) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   // workgroup 0: the next diagonal block (update + factorisation); dispatched first, it works while
@@ -1103,14 +1226,23 @@ __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *A
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (pivot_wave) {
+    if (wave == 0) fused_diag_wave4<0>(t, Adiag, nb, uinv, info, k0n, smem, tid);
+    else if (wave == 1) fused_diag_wave4<1>(t, Adiag, nb, uinv, info, k0n, smem, tid);
+    else if (wave == 2) fused_diag_wave4<2>(t, Adiag, nb, uinv, info, k0n, smem, tid);
+    else fused_diag_wave4<3>(t, Adiag, nb, uinv, info, k0n, smem, tid);
+    return;
+  }
   if (wave == 0) fused_diag_wave<0>(t, Adiag, nb, uinv, info, k0n, smem, lane);
   else if (wave == 1) fused_diag_wave<1>(t, Adiag, nb, uinv, info, k0n, smem, lane);
   else if (wave == 2) fused_diag_wave<2>(t, Adiag, nb, uinv, info, k0n, smem, lane);
   else fused_diag_wave<3>(t, Adiag, nb, uinv, info, k0n, smem, lane);
 }
 
+static_assert(sizeof(Leaf4Shared) <= (size_t)128 * DLD4 * sizeof(double), "the sweep's scratch lives in the dead panel tile");
 static_assert(sizeof(LeafShared) <= DIAG_LDS_BYTES, "the sweep's scratch lives in the dead panel tile");
-constexpr size_t TRAIL_KERNEL_LDS = DIAG_LDS_BYTES > TRAIL_LDS_BYTES ? DIAG_LDS_BYTES : TRAIL_LDS_BYTES;
+constexpr size_t TRAIL_KERNEL_LDS0 = DIAG_LDS_BYTES > TRAIL_LDS_BYTES ? DIAG_LDS_BYTES : TRAIL_LDS_BYTES;
+constexpr size_t TRAIL_KERNEL_LDS = TRAIL_KERNEL_LDS0 > DIAG4_LDS_BYTES ? TRAIL_KERNEL_LDS0 : DIAG4_LDS_BYTES;
 static bool g_trail_attr = false;
 
 // trailing update of the step whose panel is P (128 x rest), fused with the diagonal block of the
@@ -1127,8 +1259,9 @@ hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_
   t.P = P; t.C = C; t.lda = lda;
   t.tiles_m = (int32_t)(mrest / 128);
   t.tiles_n = (int32_t)(rest / 128);
+  static const int v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return (!e || (e[0] == 'v' && e[1] == '4')) ? 1 : 0; }();
   hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)(t.tiles_m * t.tiles_n)), dim3(256), TRAIL_KERNEL_LDS,
-                     st, t, C, nb_next, uinv_next, info, k0_next);
+                     st, t, C, nb_next, uinv_next, info, k0_next, v4);
   return hipGetLastError();
 }
 
@@ -1136,7 +1269,7 @@ hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, dou
                              int32_t k0, int32_t batch, int64_t strideA, int64_t strideW,
                              const int32_t *active) {
   static const bool v2 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '2'; }();
-  static const bool v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '4'; }();
+  static const bool v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return !e || (e[0] == 'v' && e[1] == '4'); }();   // the default
   if (v4)
     hipLaunchKernelGGL(potf2_v4_kernel, dim3((unsigned)batch), dim3(256), 0, st, A, lda, nb, uinv, info, k0, strideA,
                        strideW, active, g_potf2_dbg);
