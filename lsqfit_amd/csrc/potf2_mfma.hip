@@ -1219,10 +1219,16 @@ __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *A
   // workgroup 0: the next diagonal block (update + factorisation); dispatched first, it works while
   // the other CUs do the remaining tiles of the update
   if (blockIdx.x > 0) {
-    const int bid = (int)blockIdx.x;   // tile (0, 0) belongs to workgroup 0
-    const int tm = bid / t.tiles_n, tn = bid % t.tiles_n;
-    if (tn < tm) return;  // upper tiles only
-    trail_tile(t, tm, tn, smem, tid);
+    // upper tiles only, numbered row by row (tile (0, 0) belongs to workgroup 0).  A tiles_m x tiles_n
+    // grid whose lower half exits at once looks the same but is not: workgroup b runs on XCD b % 8, so
+    // with tiles_n a multiple of 8 a tile COLUMN stays on one XCD and the XCD of the longest columns
+    // got 80 of the 496 tiles of the first step -- three rounds on its 32 CUs instead of two
+    int rem = (int)blockIdx.x, tm = 0;
+    while (rem >= t.tiles_n - tm) {
+      rem -= t.tiles_n - tm;
+      ++tm;
+    }
+    trail_tile(t, tm, tm + rem, smem, tid);
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1260,7 +1266,8 @@ hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_
   t.tiles_m = (int32_t)(mrest / 128);
   t.tiles_n = (int32_t)(rest / 128);
   static const int v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return (!e || (e[0] == 'v' && e[1] == '4')) ? 1 : 0; }();
-  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)(t.tiles_m * t.tiles_n)), dim3(256), TRAIL_KERNEL_LDS,
+  const int64_t n_upper = (int64_t)t.tiles_m * t.tiles_n - (int64_t)t.tiles_m * (t.tiles_m - 1) / 2;
+  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)n_upper), dim3(256), TRAIL_KERNEL_LDS,
                      st, t, C, nb_next, uinv_next, info, k0_next, v4);
   return hipGetLastError();
 }
