@@ -934,20 +934,26 @@ struct TrailArgs {
   double *C;         // A[(k0 + nb).., (k0 + nb)..]
   int64_t lda;
   int32_t tiles_m, tiles_n;   // mrest / 128, rest / 128
+  int32_t halves;             // tiles are done as two 64-column halves by two workgroups
 };
 
 constexpr int TBK = 16, TLD = 128 + 16, TSTAGE = 2 * TBK * TLD;
 constexpr size_t TRAIL_LDS_BYTES = 2 * TSTAGE * sizeof(double);
 
-__device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, double *smem, int tid) {
+// NJ = 4: the whole 128 x 128 tile; NJ = 2: its 64-column half `half` (same staging -- the panel rows come
+// from L2 -- half the products: used while the update needs more than one round of workgroups, where
+// the finer grain cuts the quantisation of the last round).
+template <int NJ>
+__device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, int half, double *smem, int tid) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)tm * 128, n0 = (int64_t)tn * 128;
-  v4d acc[4][4];
+  const int cw = (NJ == 4 ? 0 : 64 * half) + wn * 16 * NJ;      // this wave's first column inside the tile
+  v4d acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   const double *xp = t.P + (int64_t)wave * t.lda + m0 + 2 * lane;
@@ -975,32 +981,32 @@ __device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, d
 #pragma unroll
     for (int kk = 0; kk < TBK / 4; ++kk) {
       const int kr = kk * 4 + fq;
-      double a[4], bb[4];
+      double a[4], bb[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = Xs[kr * TLD + wm * 64 + i * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * TLD + wn * 64 + j * 16 + fr];
+      for (int j = 0; j < NJ; ++j) bb[j] = Ys[kr * TLD + cw + j * 16 + fr];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma4(a[i], bb[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma4(a[i], bb[j], acc[i][j]);
     }
     __syncthreads();
     cur ^= 1;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    double cv[4][4];
+    double cv[NJ][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        cv[j][r] = t.C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * t.lda + n0 + wn * 64 + j * 16 + fr];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        t.C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * t.lda + n0 + wn * 64 + j * 16 + fr] = cv[j][r] - acc[i][j][r];
+        cv[j][r] = t.C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * t.lda + n0 + cw + j * 16 + fr];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        t.C[(m0 + wm * 64 + i * 16 + fq + 4 * r) * t.lda + n0 + cw + j * 16 + fr] = cv[j][r] - acc[i][j][r];
   }
 }
 
@@ -1223,12 +1229,17 @@ __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *A
     // grid whose lower half exits at once looks the same but is not: workgroup b runs on XCD b % 8, so
     // with tiles_n a multiple of 8 a tile COLUMN stays on one XCD and the XCD of the longest columns
     // got 80 of the 496 tiles of the first step -- three rounds on its 32 CUs instead of two
-    int rem = (int)blockIdx.x, tm = 0;
+    int rem = (int)blockIdx.x, half = 0, tm = 0;
+    if (t.halves) {                     // two workgroups per tile: (tile, column half); workgroup 0 keeps tile (0, 0)
+      half = (rem + 1) & 1;
+      rem = (rem + 1) >> 1;
+    }
     while (rem >= t.tiles_n - tm) {
       rem -= t.tiles_n - tm;
       ++tm;
     }
-    trail_tile(t, tm, tm + rem, smem, tid);
+    if (t.halves) trail_tile<2>(t, tm, tm + rem, half, smem, tid);
+    else trail_tile<4>(t, tm, tm + rem, 0, smem, tid);
     return;
   }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1267,7 +1278,12 @@ hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_
   t.tiles_n = (int32_t)(rest / 128);
   static const int v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return (!e || (e[0] == 'v' && e[1] == '4')) ? 1 : 0; }();
   const int64_t n_upper = (int64_t)t.tiles_m * t.tiles_n - (int64_t)t.tiles_m * (t.tiles_m - 1) / 2;
-  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)n_upper), dim3(256), TRAIL_KERNEL_LDS,
+  // one workgroup per CU (workgroup 0's LDS): more tiles than CUs means a second round of workgroups,
+  // mostly empty -- 64-column halves (twice the workgroups, half the work each) fill the rounds better
+  static const int64_t half_from = [] { const char *e = getenv("LSQAMD_TRAIL_HALVES"); return e ? atoll(e) : (int64_t)256; }();
+  t.halves = (n_upper > half_from) ? 1 : 0;
+  const int64_t n_wg = t.halves ? 2 * (n_upper - 1) + 1 : n_upper;
+  hipLaunchKernelGGL(trail_potf2_kernel, dim3((unsigned)n_wg), dim3(256), TRAIL_KERNEL_LDS,
                      st, t, C, nb_next, uinv_next, info, k0_next, v4);
   return hipGetLastError();
 }
