@@ -417,12 +417,15 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   {
     Scope sc(f, LSQAMD_T_GRAD);
     // when splits == 1 the kernel ignored split_stride and wrote slab 0 directly
-    HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf));
+    const bool with_prior = f->cfg.has_prior && f->adds_prior;
+    // the slab sum and the prior precision in ONE pass over the packed tiles
+    HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
+                                   with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
     if (fused_chunks == 0)
       HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
-    if (f->cfg.has_prior && f->adds_prior)
+    if (with_prior)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)
       HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
-                                 f->prior_mean, p, f->tvec, gvec, 1));
+                                 f->prior_mean, p, f->tvec, gvec, 0, r_here ? 1 : 0));
   }
   rc = do_reduce(f, f->redbuf, f->npk + P + 1);
   if (rc) return rc;

@@ -160,11 +160,12 @@ hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64
                                    int64_t skip_from = INT64_MAX);  // blocks of >= skip_from rows are left out
 // packed upper tiles <- sum over split-K slabs (matrix layout, P x ld each)
 hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
-                                int64_t split_stride, int64_t P, int64_t ld, double *apk);
+                                int64_t split_stride, int64_t P, int64_t ld, double *apk,
+                                const double *prior = nullptr, int32_t prior_dense = 0);
 // prior precision into the packed tiles (with_matrix) and into gvec = [J^T f ; chi2]
 hipError_t launch_add_prior(hipStream_t st, double *apk, int64_t P, const double *prec, int32_t dense,
                             const double *pmean, const double *p, double *tvec, double *gvec,
-                            int32_t with_matrix);
+                            int32_t with_matrix, int32_t tvec_ready = 0);
 hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int32_t dense,
                              const double *pmean, const double *p, double *tvec, double *scalar);
 // M (P x ld, upper tiles) = A + mu diag(d^2); M[:, P] = g

@@ -178,31 +178,60 @@ hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64
 }
 
 // ---- split-K slabs -> packed upper tiles ---------------------------------------------------
+// prior (nullable): the prior precision is added on the way (dense: P x P, else its diagonal) -- one pass
+// over the packed tiles instead of two
 __global__ __launch_bounds__(256) void finalize_pack_kernel(const double *slabs, int32_t splits,
                                                             int64_t split_stride, int64_t P,
-                                                            int64_t ld, int64_t T, double *apk) {
-  // blockIdx.x = packed tile index, blockIdx.y = 16-row strip inside the tile
+                                                            int64_t ld, int64_t T, double *apk,
+                                                            const double *prior, int prior_dense) {
+  // blockIdx.x = packed tile index, blockIdx.y = 8-row strip inside the tile; thread -> two columns, two rows
   int64_t t = blockIdx.x, tm = 0;
   while (t >= T - tm) { t -= T - tm; ++tm; }
   const int64_t tn = tm + t;
   double *dst = apk + (int64_t)blockIdx.x * TB * TB;
-  const int c = threadIdx.x & 127;
-  for (int rr = (threadIdx.x >> 7); rr < 8; rr += 2) {
-    const int r = blockIdx.y * 8 + rr;
-    const int64_t i = tm * TB + r, j = tn * TB + c;
-    double a = 0.0;
-    if (i < P && j < P)
-      for (int s = 0; s < splits; ++s) a += slabs[s * split_stride + i * ld + j];
-    dst[r * TB + c] = a;
+  const int c = 2 * (threadIdx.x & 63);
+  const int64_t j = tn * TB + c;
+  const bool vec = !(ld & 1) && !(split_stride & 1) && !(reinterpret_cast<uintptr_t>(slabs) & 15) && j + 1 < P;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = blockIdx.y * 8 + (threadIdx.x >> 6) + 4 * h;
+    const int64_t i = tm * TB + r;
+    double a0 = 0.0, a1 = 0.0;
+    if (i < P && vec) {
+      const double *src = slabs + i * ld + j;
+#pragma unroll 8
+      for (int s = 0; s < splits; ++s) {
+        const double2 v = *reinterpret_cast<const double2 *>(src + s * split_stride);
+        a0 += v.x;
+        a1 += v.y;
+      }
+    } else if (i < P) {
+      for (int s = 0; s < splits; ++s) {
+        if (j < P) a0 += slabs[s * split_stride + i * ld + j];
+        if (j + 1 < P) a1 += slabs[s * split_stride + i * ld + j + 1];
+      }
+    }
+    if (prior && i < P) {
+      if (prior_dense) {
+        if (j < P) a0 += prior[i * P + j];
+        if (j + 1 < P) a1 += prior[i * P + j + 1];
+      } else {
+        if (i == j) a0 += prior[i];
+        if (i == j + 1) a1 += prior[i];
+      }
+    }
+    dst[r * TB + c] = a0;
+    dst[r * TB + c + 1] = a1;
   }
 }
 
 hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
-                                int64_t split_stride, int64_t P, int64_t ld, double *apk) {
+                                int64_t split_stride, int64_t P, int64_t ld, double *apk,
+                                const double *prior, int32_t prior_dense) {
   const int64_t T = (P + TB - 1) / TB;
   dim3 grid((unsigned)(T * (T + 1) / 2), 16);
   hipLaunchKernelGGL(finalize_pack_kernel, grid, dim3(256), 0, st, slabs, splits, split_stride, P, ld,
-                     T, apk);
+                     T, apk, prior, (int)prior_dense);
   return hipGetLastError();
 }
 
@@ -261,14 +290,15 @@ __global__ __launch_bounds__(256) void prior_apply_kernel(int64_t P, const doubl
 
 hipError_t launch_add_prior(hipStream_t st, double *apk, int64_t P, const double *prec, int32_t dense,
                             const double *pmean, const double *p, double *tvec, double *gvec,
-                            int32_t with_matrix) {
+                            int32_t with_matrix, int32_t tvec_ready) {
   const int64_t T = (P + TB - 1) / TB;
   if (with_matrix) {
     dim3 grid((unsigned)(T * (T + 1) / 2), 16);
     hipLaunchKernelGGL(prior_matrix_kernel, grid, dim3(256), 0, st, apk, P, T, prec, dense);
   }
-  hipLaunchKernelGGL(prior_vec_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, P, prec, dense,
-                     pmean, p, tvec);
+  if (!tvec_ready)    // (the caller's trial evaluation at this very point left Lambda (p - pbar) in tvec)
+    hipLaunchKernelGGL(prior_vec_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, P, prec, dense,
+                       pmean, p, tvec);
   hipLaunchKernelGGL(prior_apply_kernel, dim3(1), dim3(256), 0, st, P, pmean, p, tvec, gvec);
   return hipGetLastError();
 }
