@@ -230,3 +230,40 @@ def test_chained_back_substitution_matches_lapack_and_repeats_bit_for_bit(P):
     for _ in range(40):
         assert np.array_equal(pr.solve_damped(mu, diag), first)
     pr.close()
+
+
+@pytest.mark.parametrize('n', [1536, 4096])
+def test_potrf_upper_tile_aligned_fused_path(env, n):
+    """Tile-aligned sizes take the fused launches (trailing update + next diagonal block by the pivot-wave
+    kernel): n = 1536 stays within one round of tile workgroups, n = 4096 goes through every regime --
+    64-column half tiles while an update needs more than one round, whole tiles, the unfused tail.  Factor,
+    forward-substituted right-hand side, and the 128 x 128 inverse blocks against LAPACK."""
+    torch, lib = env
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n + 64, n))
+    A = G.T @ G + 0.1 * np.eye(n)
+    b = rng.standard_normal(n)
+    lda = n + 128                       # the product's padding: every Cholesky GEMM stays tile-aligned
+    Ab = np.zeros((n, lda))
+    Ab[:, :n] = np.triu(A)
+    Ab[:, n] = b
+    dA = dev(torch, Ab)
+    wbytes = lib.lsqamd_op_potrf_work_bytes(n)
+    work = torch.full((wbytes // 8 + 8,), float('nan'), dtype=torch.float64, device='cuda')
+    info = torch.zeros(4, dtype=torch.int32, device='cuda')
+    rc = lib.lsqamd_op_potrf_upper(None, dA.data_ptr(), n, lda, n + 128, work.data_ptr(), wbytes, info.data_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(info[0]) == 0
+    out = dA.cpu().numpy()
+    U = np.triu(out[:, :n])
+    Uref = np.linalg.cholesky(A).T
+    scale = np.abs(Uref).max()
+    assert np.abs(U - Uref).max() < 1e-11 * scale
+    assert np.abs(out[:, n] - np.linalg.solve(Uref.T, b)).max() < 1e-10 * np.abs(b).max()
+    w = work.cpu().numpy()[:(n // 128) * 128 * 128].reshape(n // 128, 128, 128)
+    assert np.all(np.isfinite(w))                                    # zeros above the diagonal included
+    for k in (0, 1, n // 256, n // 128 - 1):
+        Ukk = Uref[128 * k:128 * (k + 1), 128 * k:128 * (k + 1)]
+        assert np.abs(w[k] @ Ukk - np.eye(128)).max() < 1e-9
+        assert np.all(np.tril(w[k], -1) == 0.0)
