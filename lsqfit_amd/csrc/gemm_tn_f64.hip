@@ -974,7 +974,10 @@ void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
 //   thread t: term c = t & 63, stage rows t >> 6, + 4, + 8, + 12  ->  4 transcendental pairs per stage.
 // fp64 VALU and fp64 MFMA share the datapath, so this work adds to the MFMA time (about a quarter)
 // instead of hiding behind it; what is saved is the Jacobian kernel and 4.3 GB of traffic.
-template <int MODEL>
+// NT = terms per tile: 64 (128 output columns) or 32 (64 output columns: twice the workgroups for the shapes
+// that would otherwise leave one workgroup per CU -- config 3's single 8192-row block -- where nothing but
+// a second workgroup covers the barrier and LDS latencies of the first); same products in the same order.
+template <int MODEL, int NT>
 __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int tiles_m, int tiles_n, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
@@ -993,14 +996,16 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
   const double *Xb = a.Wt + b * a.B * a.B;
   const double *xrow = a.x + b * a.B;
   double *C = a.J + b * a.B * a.ld;
-  const int sc = tid & 63, srow = tid >> 6;       // synthesis: term within the tile, first stage row
-  const double amp = a.p[(int64_t)tn * 64 + sc], frq = a.p[a.K + (int64_t)tn * 64 + sc];
+  constexpr int NJ = NT / 16;                      // 16-column MFMA tiles per wave
+  constexpr int SR = 256 / NT, NS = BK / SR;       // stage rows synthesised per pass of the workgroup, passes
+  const int sc = tid % NT, srow = tid / NT;        // synthesis: term within the tile, first stage row
+  const double amp = a.p[(int64_t)tn * NT + sc], frq = a.p[a.K + (int64_t)tn * NT + sc];
 
-  v4d acc[4][4];
+  v4d acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
   const double *xp = Xb + (int64_t)wave * a.B + m0 + 2 * lane;
@@ -1026,14 +1031,14 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
     xp += 4 * xstep;
   };
   auto stage_synth = [&](int buf) {
-    double xs4[4];
+    double xs4[NS];
     const double *xq = xring + (ssyn % 3) * 32 + srow;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) xs4[i] = xq[4 * i];
+    for (int i = 0; i < NS; ++i) xs4[i] = xq[SR * i];
     double *Ys = smem + buf * STAGE + BK * LDT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = srow + 4 * i;
+    for (int i = 0; i < NS; ++i) {
+      const int row = srow + SR * i;
       const double xv = xs4[i];
       double t, dq;
       if (MODEL == LSQAMD_MODEL_COSMIX) {
@@ -1047,7 +1052,7 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
         dq = -amp * xv * e;
       }
       Ys[row * LDT + sc] = t;
-      Ys[row * LDT + 64 + sc] = dq;
+      Ys[row * LDT + NT + sc] = dq;
     }
     ++ssyn;
   };
@@ -1071,16 +1076,16 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       const int kr = kk * 4 + fq;
-      double av[4], bb[4];
+      double av[4], bb[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) av[i] = Xs[kr * LDT + (2 * i + wm) * 16 + fr];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + wn * 64 + j * 16 + fr];
+      for (int j = 0; j < NJ; ++j) bb[j] = Ys[kr * LDT + wn * NT + j * 16 + fr];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (k0 + kk * 4 > m0 + (2 * i + wm) * 16 + 15) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bb[j], acc[i][j], 0, 0, 0);
       }
     }
@@ -1091,8 +1096,10 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
   if (tid < BM) wcol[tid] = wreg;
   __syncthreads();
   // tile column (wn, j, fr)  ->  Jacobian column: the value half (wn = 0) or the partner half at K + ..
-  const int64_t cbase = (wn ? a.K : 0) + (int64_t)tn * 64;
-  double sj[4] = {0.0, 0.0, 0.0, 0.0};
+  const int64_t cbase = (wn ? a.K : 0) + (int64_t)tn * NT;
+  double sj[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sj[j] = 0.0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rloc = (2 * i + wm) * 16 + fq;
@@ -1100,7 +1107,7 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
     for (int r = 0; r < 4; ++r) {
       const double w = wcol[rloc + 4 * r];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const double v = acc[i][j][r];
         C[(m0 + rloc + 4 * r) * a.ld + cbase + j * 16 + fr] = v;
         sj[j] += v * w;
@@ -1108,19 +1115,19 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
     }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     sj[j] += __shfl_xor(sj[j], 16, 64);
     sj[j] += __shfl_xor(sj[j], 32, 64);
   }
   if (fq == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[wave * 64 + j * 16 + fr] = sj[j];
+    for (int j = 0; j < NJ; ++j) red[wave * 64 + j * 16 + fr] = sj[j];
   }
   __syncthreads();
   if (wm == 0 && fq == 0) {
     double *out = a.colsum_out + (b * tiles_m + tm) * (2 * a.K) + cbase;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j * 16 + fr] = red[wave * 64 + j * 16 + fr] + red[(wave + 2) * 64 + j * 16 + fr];
+    for (int j = 0; j < NJ; ++j) out[j * 16 + fr] = red[wave * 64 + j * 16 + fr] + red[(wave + 2) * 64 + j * 16 + fr];
   }
   }  // pass
 }
@@ -1136,22 +1143,32 @@ constexpr size_t SYNTH_LDS_BYTES = GEMM_LDS_BYTES + 3 * 32 * sizeof(double);
 hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
-    if (e != hipSuccess) return e;
+    const void *fns[] = {reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 64>),
+                         reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 64>),
+                         reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 32>),
+                         reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 32>)};
+    for (const void *fn : fns) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
+      if (e != hipSuccess) return e;
+    }
     attr = true;
   }
-  const int tiles_m = (int)(a.B / BM), tiles_n = (int)(a.K / 64);
+  const int tiles_m = (int)(a.B / BM);
   // few large blocks: unpaired, the workgroups of the last tile rows run 2 tiles_m / (tiles_m + 1) times the average
   const int pair = tiles_m >= 4 ? 1 : 0;
-  dim3 grid((unsigned)((pair ? (tiles_m + 1) / 2 : tiles_m) * tiles_n), 1, (unsigned)a.nb);
-  if (a.model == LSQAMD_MODEL_COSMIX)
-    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
-  else
-    hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
+  const int64_t rows = pair ? (tiles_m + 1) / 2 : tiles_m;
+  // 64 terms per tile unless that leaves the chip with (about) one workgroup per CU
+  static const int64_t narrow_below = [] { const char *e = getenv("LSQAMD_SYNTH_NARROW"); return e ? atoll(e) : (int64_t)400; }();
+  const bool narrow = rows * (a.K / 64) * a.nb < narrow_below && a.K % 32 == 0;
+  const int tiles_n = (int)(a.K / (narrow ? 32 : 64));
+  dim3 grid((unsigned)(rows * tiles_n), 1, (unsigned)a.nb);
+  if (a.model == LSQAMD_MODEL_COSMIX) {
+    if (narrow) hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 32>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
+    else hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 64>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
+  } else {
+    if (narrow) hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 32>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
+    else hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 64>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
+  }
   return hipGetLastError();
 }
 
