@@ -396,7 +396,8 @@ hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda
   // (sweep at P = 4096 with the pivot-wave diagonal kernel: >= 1 tile 1.553 ms, >= 6 1.541, >= 15 1.543, >= 28 1.546,
   // >= 45 1.550, >= 66 1.565; round 1: never 2.73 ms, >= 3 tiles 2.60, >= 30 2.55, >= 136 2.53)
   static const int64_t fuse_min_tiles = [] { const char *v = getenv("LSQAMD_FUSE_MIN_TILES"); return v ? atoll(v) : (int64_t)10; }();
-  const bool can_fuse = batch == 1 && !active && fuse_min_tiles >= 0 && (n % NB) == 0 && (n_cols % NB) == 0 &&
+  const bool can_fuse = batch == 1 && !active && fuse_min_tiles >= 0 && trail_potf2_available() && (n % NB) == 0 &&
+                        (n_cols % NB) == 0 &&
                         !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15);
   bool diag_done = false;  // the diagonal block of this step was factored by the previous launch
   for (int64_t k0 = 0; k0 < n; k0 += NB) {

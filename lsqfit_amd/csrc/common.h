@@ -69,6 +69,7 @@ hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_
 // batched: matrix b at A + b*strideA, block inverses at work + b*strideW, info[b];
 // trailing update C -= P^T P (upper tiles; P = 128 x rest panel, C = mrest x rest, both multiples of
 // 128, 16-byte aligned rows) fused with the diagonal block of the next step (= tile (0, 0) of C)
+bool trail_potf2_available();
 hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_t lda, int64_t mrest,
                               int64_t rest, int nb_next, double *uinv_next, int32_t *info, int32_t k0_next);
 // diagonal block (nb <= 128) of the blocked Cholesky: A_kk -> U_kk in place, inv(U_kk) -> uinv

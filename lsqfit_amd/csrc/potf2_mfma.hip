@@ -1250,10 +1250,12 @@ __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *A
     else fused_diag_wave4<3>(t, Adiag, nb, uinv, info, k0n, smem, tid);
     return;
   }
+#ifdef LSQAMD_TRAIL_V3
   if (wave == 0) fused_diag_wave<0>(t, Adiag, nb, uinv, info, k0n, smem, lane);
   else if (wave == 1) fused_diag_wave<1>(t, Adiag, nb, uinv, info, k0n, smem, lane);
   else if (wave == 2) fused_diag_wave<2>(t, Adiag, nb, uinv, info, k0n, smem, lane);
   else fused_diag_wave<3>(t, Adiag, nb, uinv, info, k0n, smem, lane);
+#endif
 }
 
 static_assert(sizeof(Leaf4Shared) <= (size_t)128 * DLD4 * sizeof(double), "the sweep's scratch lives in the dead panel tile");
@@ -1264,6 +1266,18 @@ static bool g_trail_attr = false;
 
 // trailing update of the step whose panel is P (128 x rest), fused with the diagonal block of the
 // next step.  Requires mrest and rest multiples of 128 and 16-byte aligned rows.
+// the fused launch exists for the pivot-wave formulation (the four-wave one: build with -DLSQAMD_TRAIL_V3;
+// kept out of the default build, where its SGPR pressure spilled ~200 scalars of the whole kernel)
+bool trail_potf2_available() {
+  static const bool v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return !e || (e[0] == 'v' && e[1] == '4'); }();
+#ifdef LSQAMD_TRAIL_V3
+  static const bool v3 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '3'; }();
+  return v4 || v3;
+#else
+  return v4;
+#endif
+}
+
 hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_t lda, int64_t mrest,
                               int64_t rest, int nb_next, double *uinv_next, int32_t *info, int32_t k0_next) {
   if (!g_trail_attr) {
