@@ -7,6 +7,7 @@ import sys
 import numpy as np
 import torch
 
+os.environ['LSQAMD_POTF2'] = 'v3'   # these stamps are the four-wave formulation's (potf2_timing_v4.py: the default kernel)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lib = C.CDLL(os.path.join(ROOT, 'lsqfit_amd/build/libdbg.so'))
 lib.lsqamd_op_potrf_work_bytes.restype = C.c_size_t
