@@ -267,3 +267,51 @@ def test_potrf_upper_tile_aligned_fused_path(env, n):
         Ukk = Uref[128 * k:128 * (k + 1), 128 * k:128 * (k + 1)]
         assert np.abs(w[k] @ Ukk - np.eye(128)).max() < 1e-9
         assert np.all(np.tril(w[k], -1) == 0.0)
+
+
+_POTRF_VARIANT_SCRIPT = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+from lsqfit_amd import _lib
+lib = _lib.load()
+for n in (96, 300, 1536):
+    rng = np.random.default_rng(n)
+    G = rng.standard_normal((n + 20, n))
+    A = G.T @ G + 0.1 * np.eye(n)
+    b = rng.standard_normal(n)
+    lda = n + 128 if n %% 128 == 0 else n + 1 + ((n + 1) & 1)
+    ncols = n + 128 if n %% 128 == 0 else n + 1
+    Ab = np.zeros((n, lda)); Ab[:, :n] = np.triu(A); Ab[:, n] = b
+    dA = torch.from_numpy(Ab).cuda()
+    wb = lib.lsqamd_op_potrf_work_bytes(n)
+    work = torch.zeros(wb // 8 + 8, dtype=torch.float64, device='cuda')
+    info = torch.zeros(4, dtype=torch.int32, device='cuda')
+    assert lib.lsqamd_op_potrf_upper(None, dA.data_ptr(), n, lda, ncols, work.data_ptr(), wb, info.data_ptr()) == 0
+    torch.cuda.synchronize()
+    out = dA.cpu().numpy()
+    Uref = np.linalg.cholesky(A).T
+    assert int(info[0]) == 0
+    assert np.abs(np.triu(out[:, :n]) - Uref).max() < 1e-10 * np.abs(Uref).max(), n
+    assert np.abs(out[:, n] - np.linalg.solve(Uref.T, b)).max() < 1e-9 * np.abs(b).max(), n
+    nb0 = min(n, 128)
+    w = work.cpu().numpy()[:128 * 128].reshape(128, 128)[:nb0, :nb0]
+    assert np.abs(w @ Uref[:nb0, :nb0] - np.eye(nb0)).max() < 1e-9, n
+print('ok')
+'''
+
+
+@pytest.mark.parametrize('variant', ['v3', 'v2', 'lds'])
+def test_selectable_diagonal_kernels_still_factor(tmp_path, variant):
+    """LSQAMD_POTF2 = v3 (four-wave 16-row slabs), v2 (4-row sweep), lds (LDS-resident): the earlier
+    formulations of the diagonal-block kernel stay selectable and correct (ragged, padded and tile-aligned n)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'potrf_variant.py'
+    script.write_text(_POTRF_VARIANT_SCRIPT % dict(root=root))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, LSQAMD_POTF2=variant), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('ok'), (r.stdout[-500:], r.stderr[-2000:])
