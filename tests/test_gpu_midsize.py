@@ -54,3 +54,50 @@ def test_midsize_fit_matches_oracle(amd, shape):
     vref = np.linalg.solve(A + 1e-3 * np.diag(dd ** 2), g)
     assert np.max(np.abs(np.abs(v) - np.abs(vref))) < 1e-8 * np.max(np.abs(vref))
     pr.close()
+
+
+_KNOB_SCRIPT = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import lsqfit_amd as amd
+from lsqfit_amd import synth
+out = {}
+for name, shape in (('a', dict(N=1536, P=384, block=256, prior_corr=True)), ('b', dict(N=3328, P=3200, block=128, prior_corr=False))):
+    d = synth.make_cosmix(seed=77, **shape)
+    p0 = d['p0'] * (1 + 3e-4 * np.random.default_rng(5).standard_normal(shape['P']))
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=p0,
+                            tol=1e-10, maxit=6 if name == 'b' else 1000)
+    out[name + '_p'] = fit.pmean
+    out[name + '_cov'] = fit.cov[::97, ::89].copy()
+    out[name + '_chi2'] = np.array([fit.chi2, fit.logGBF])
+np.savez(sys.argv[1], **out)
+'''
+
+
+@pytest.mark.parametrize('knob', ['LSQAMD_BACKSOLVE=g', 'LSQAMD_BACKSOLVE=s', 'LSQAMD_HOST_LM=1', 'LSQAMD_FUSE_MIN_TILES=-1',
+                                  'LSQAMD_TRAIL_HALVES=1', 'LSQAMD_SYNTH_NARROW=100000000', 'LSQAMD_POTF2=v3'])
+def test_developer_knobs_select_equivalent_paths(tmp_path, knob):
+    """Every alternative path a developer knob selects (grouped / per-block back substitution, host-side LM
+    bookkeeping, unfused factorisation, half tiles everywhere, 32-term whitening tiles everywhere, the four-wave
+    diagonal kernel) gives the default path's fit to rounding: a P = 384 fit to convergence and six LM steps of a
+    P = 3200 fit (25 tile rows: fused launches, half tiles, the chained back substitution)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'knob.py'
+    script.write_text(_KNOB_SCRIPT % dict(root=root))
+    res = []
+    for extra in ({}, dict([knob.split('=')])):
+        path = str(tmp_path / ('res%d.npz' % len(res)))
+        r = subprocess.run([sys.executable, str(script), path], env=dict(os.environ, **extra), capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(np.load(path))
+    for k in res[0].files:
+        # different summation orders: the iterates agree to rounding amplified by the conditioning of the step;
+        # the covariance (P = 3200 on 3328 data rows leans on the prior) to cond * eps
+        tol = 1e-4 if k.endswith('_cov') else 1e-7
+        scale = np.max(np.abs(res[0][k]))
+        assert np.max(np.abs(res[0][k] - res[1][k])) <= tol * scale, (knob, k, np.max(np.abs(res[0][k] - res[1][k])) / scale)
