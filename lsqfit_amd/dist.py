@@ -82,9 +82,16 @@ def attach_rccl(problem, rank, world, group=None):
     """Library-side communicator for this handle: rank 0 makes the id, torch.distributed
     carries it (setup only), every rank joins."""
     import torch.distributed as dist
-    box = [problem.comm_unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = problem.comm_unique_id()
+        except Exception as e:          # the other ranks are waiting in the broadcast: tell them, then raise here too
+            box[0] = RuntimeError('rank 0 could not create the communicator id: %r' % (e,))
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast_object_list(box, src=src, group=group)
+    if isinstance(box[0], Exception):
+        raise RuntimeError(str(box[0]))
     problem.comm_init(box[0], rank, world)
 
 
