@@ -36,4 +36,27 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
   *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
+// cos alone (the residual kernels): ONE polynomial with its coefficients chosen per lane by the quadrant
+// instead of both -- the same operations in the same order as the cosine of sincos_moderate, so the same bits.
+__device__ __forceinline__ double cos_moderate(double t) {
+  if (!(fabs(t) < 1.0e5)) return cos(t);
+  const double n = rint(t * 6.36619772367581382433e-01);
+  double r = __builtin_fma(-n, 1.57079632679489655800e+00, t);
+  r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const int q = (int)n & 3;
+  const bool odd = q & 1;             // cos(t) = -+ sin(r) in the odd quadrants, +- cos(r) in the even ones
+  const double c5 = odd ? 1.58969099521155010221e-10 : -1.13596475577881948265e-11;
+  const double c4 = odd ? -2.50507602534068634195e-08 : 2.08757232129817482790e-09;
+  const double c3 = odd ? 2.75573137070700676789e-06 : -2.75573143513906633035e-07;
+  const double c2 = odd ? -1.98412698298579493134e-04 : 2.48015872894767294178e-05;
+  const double c1 = odd ? 8.33333333332248946124e-03 : -1.38888888888741095749e-03;
+  const double c0 = odd ? -1.66666666666666324348e-01 : 4.16666666666666019037e-02;
+  const double p = c0 + z * (c1 + z * (c2 + z * (c3 + z * (c4 + z * c5))));
+  const double a = odd ? r * z : z * z;
+  const double b = odd ? r : __builtin_fma(-0.5, z, 1.0);
+  const double v = __builtin_fma(a, p, b);
+  return ((q + 1) & 2) ? -v : v;
+}
+
 }  // namespace lsqamd

@@ -99,10 +99,15 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
       const double a = pp[k], q = pp[K + k];
       double term, dq;
       if (MODEL == LSQAMD_MODEL_COSMIX) {
-        double s, c;
-        sincos_moderate(q * x, &s, &c);
-        term = c;
-        dq = -a * x * s;
+        if (JAC) {
+          double s, c;
+          sincos_moderate(q * x, &s, &c);
+          term = c;
+          dq = -a * x * s;
+        } else {
+          term = cos_moderate(q * x);
+          dq = 0.0;
+        }
       } else {
         const double e = exp(-q * x);
         term = e;
