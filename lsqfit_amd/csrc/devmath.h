@@ -9,9 +9,25 @@ namespace lsqamd {
 // Cody-Waite reduction by pi/2 with FMAs (the product n * PIO2_HI is formed exactly inside the
 // FMA), then the fdlibm minimax kernels on [-pi/4, pi/4].  Absolute error ~1e-16; about a third of
 // the instructions of the general-range library sincos, which remains the fallback for huge t.
+// Beyond the fast range (and for NaN / Inf): the library routine, kept out of line -- inlined, its
+// Payne-Hanek branch costs the fused whitening kernel 34 VGPRs and a scratch frame (1.83 vs 1.66 ms).
+struct SinCos { double s, c; };
+__device__ __attribute__((noinline)) inline SinCos sincos_far(double t) {
+  SinCos r;
+  sincos(t, &r.s, &r.c);
+  return r;
+}
+__device__ __attribute__((noinline)) inline double cos_far(double t) { return cos(t); }
+
+// Two-term Cody-Waite reduction carried by FMAs (the products n * HI, n * LO are exact inside the FMA; HI + LO
+// is pi/2 to 2e-32): 1.1e-16 absolute up to |t| = 1e13 (checked against libm), where a double's own spacing is
+// already 2e-3.
+constexpr double TRIG_FAST_LIMIT = 1.0e13;
 __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs) {
-  if (!(fabs(t) < 1.0e5)) {
-    sincos(t, sn, cs);
+  if (!(fabs(t) < TRIG_FAST_LIMIT)) {
+    const SinCos f = sincos_far(t);
+    *sn = f.s;
+    *cs = f.c;
     return;
   }
   const double n = rint(t * 6.36619772367581382433e-01);      // 2/pi
@@ -30,7 +46,7 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
                                    z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
   const double s = __builtin_fma(r * z, ps, r);
   const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-  const int q = (int)n & 3;
+  const int q = (int)((long long)n & 3);
   const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
   *sn = (q & 2) ? -s1 : s1;
   *cs = ((q + 1) & 2) ? -c1 : c1;
@@ -39,12 +55,12 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
 // cos alone (the residual kernels): ONE polynomial with its coefficients chosen per lane by the quadrant
 // instead of both -- the same operations in the same order as the cosine of sincos_moderate, so the same bits.
 __device__ __forceinline__ double cos_moderate(double t) {
-  if (!(fabs(t) < 1.0e5)) return cos(t);
+  if (!(fabs(t) < TRIG_FAST_LIMIT)) return cos_far(t);
   const double n = rint(t * 6.36619772367581382433e-01);
   double r = __builtin_fma(-n, 1.57079632679489655800e+00, t);
   r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
   const double z = r * r;
-  const int q = (int)n & 3;
+  const int q = (int)((long long)n & 3);
   const bool odd = q & 1;             // cos(t) = -+ sin(r) in the odd quadrants, +- cos(r) in the even ones
   const double c5 = odd ? 1.58969099521155010221e-10 : -1.13596475577881948265e-11;
   const double c4 = odd ? -2.50507602534068634195e-08 : 2.08757232129817482790e-09;

@@ -198,3 +198,34 @@ def test_query_devices_reports_the_mi355x():
     buf = ctypes.create_string_buffer(64)
     assert lib.lsqamd_query_devices(ctypes.byref(n), 0, buf, 64, ctypes.byref(mem)) == 0
     assert n.value >= 1 and buf.value.startswith(b'gfx950') and mem.value > 200 * (1 << 30)
+
+
+@pytest.mark.parametrize('scale', [1.0, 1e4, 1e9, 1e14, 1e17])
+def test_cosine_model_at_large_arguments(amd, scale):
+    """cos / sin of w x in the model kernels: a two-term Cody-Waite reduction carried by FMAs up to |w x| = 1e13
+    (1.1e-16 absolute), the library routine beyond -- model values and Jacobian (analytic kernel, the kernel fused
+    into the whitening product, and the residual kernel's cosine-only path) against numpy at every magnitude."""
+    from lsqfit_amd import synth
+    for block in (0, 128):
+        d = synth.make_cosmix(N=512, P=128, seed=8, block=block, prior_corr=False)
+        wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+        pr = amd.DeviceProblem(d['model'], d['x'], wh)
+        p = d['p_true'].copy()
+        p[64:] *= scale
+        f = pr.fcn(p)
+        ref = gu.cosmix_fcn(d['x'], p)
+        assert np.abs(f - ref).max() < 1e-13 * 64
+        pr.normal(p)
+        if block == 0:
+            J = pr.get_J_data()
+            Jref = gu.cosmix_jac(d['x'], p) * wh.wdiag[:, None]
+            assert np.abs(J - Jref).max() <= 1e-14 * np.abs(Jref).max()
+        else:       # whitened rows differ from numpy's by the rotation inside a block: compare J^T J
+            A = pr.get_jtj()
+            Jr = gu.cosmix_jac(d['x'], p)
+            Aref = np.diag(1.0 / np.asarray(d['prior'][1]) ** 2)
+            for r0, c in d['yerr']['blocks']:
+                B = c.shape[0]
+                Aref = Aref + Jr[r0:r0 + B].T @ np.linalg.solve(c, Jr[r0:r0 + B])
+            assert np.abs(A - Aref).max() <= 1e-9 * np.abs(Aref).max()
+        pr.close()
