@@ -141,6 +141,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->scal = cv.take<double>(16);
   f->lmd = cv.take<double>(LMS_COUNT);
   f->info_dev = cv.take<int32_t>(16);
+  f->trig_far = cv.take<int32_t>(16);
   f->tape_cap = c.tape_len > 1024 ? c.tape_len : 1024;
   f->tape = cv.take<int32_t>(f->tape_cap);
   f->tape_poff = cv.take<int32_t>(f->tape_cap);
@@ -219,9 +220,19 @@ int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
   return 0;
 }
 
+// two extra launches per evaluation (the range kernel and the variant that finds nothing to do, ~5 us together)
+// buy a trig kernel without far-range code: worth it from a few million cosines per evaluation on
+static bool trig_split_pays(const lsqamd_fit *f) { return f->N * (f->P / 2) >= ((int64_t)1 << 22); }
+
 // whitened residual VECTOR at device parameters p -> f->r (model kernel + block whitening); launches only
 int residual_vector_launch(lsqamd_fit *f, const double *p) {
   ModelArgs m = model_args(f, p);
+  if (f->cfg.model == LSQAMD_MODEL_COSMIX && f->have_x && trig_split_pays(f)) {
+    // cosine model: the range flag of THIS point (the frequencies are parameters P/2 .. P - 1); the fused
+    // whitening kernel, which only ever runs at the point whose residual is current, reads the same flag
+    HIPCHK(f, launch_trig_range(f->st, p + f->P / 2, f->P / 2, f->xmax, f->trig_far));
+    m.trig_far = f->trig_far;
+  }
   HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
   if (f->have_param_rows)
     HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, 1, p, f->ymean, f->wdiag,
@@ -378,6 +389,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     WhitenSynth w;
     w.model = f->cfg.model; w.Wt = f->wt; w.x = f->x; w.p = p; w.J = f->J; w.ld = f->ld;
     w.B = B0; w.K = P / 2; w.nb = nbk; w.colsum_out = f->slabs;
+    w.trig_far = (f->cfg.model == LSQAMD_MODEL_COSMIX && f->have_x && trig_split_pays(f)) ? f->trig_far : nullptr;   // current: set with the residual at p
     HIPCHK(f, launch_whiten_synth(f->st, w));
     f->used_synth = true;
     fused_chunks = (int64_t)nbk * (B0 / 128);
@@ -1361,6 +1373,11 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
     FAIL(f, LSQAMD_EINVAL, "set_x: expected %lld x %d", (long long)f->N, f->cfg.n_x);
   HIPCHK(f, hipMemcpyAsync(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
+  f->xmax = 0.0;
+  for (int64_t i = 0; i < n_rows * n_x; ++i) {
+    const double ax = std::fabs(x[i]);
+    if (!(ax <= f->xmax)) f->xmax = ax;      // (NaN sticks: the flag then always says "far")
+  }
   f->have_x = true;
   return 0;
 }

@@ -51,6 +51,7 @@ struct WhitenSynth {
   int64_t ld = 0, B = 0, K = 0;
   int32_t nb = 0;
   double *colsum_out = nullptr; // [(b * B / 128 + tm)][2 K]: per-tile-row pieces of J^T f
+  const int32_t *trig_far = nullptr;   // device flag (launch_trig_range); null: the safe kernel only
 };
 bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P);
 hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a);
@@ -119,6 +120,9 @@ struct ModelArgs {
   int64_t p_stride = 0, out_stride = 0;
   int64_t ymean_stride = 0;  // 0: the fits share ymean; n_data: fit b reads ymean + b*n_data
   const int32_t *batch_active = nullptr;
+  // cosine model: device flag "some |w x| may reach the far range of the trig reduction" (launch_trig_range);
+  // set: the kernel without far-range code runs unless the flag says otherwise.  null: the safe kernel only
+  const int32_t *trig_far = nullptr;
   // tape model, single fit: buffers of the reverse-mode Jacobian (null: forward-mode kernel)
   const int32_t *tape_poff = nullptr;   // first partial-derivative slot of every instruction
   double *tape_part = nullptr;          // [tape_wgs * 4 waves][tape_slots][64]
@@ -127,6 +131,8 @@ struct ModelArgs {
   int32_t tape_slots = 0;
 };
 int tape_slots_of_op(int op);
+// flag[0] = 1 unless max_k |q_k| * xmax is (finite and) below the fast range of the model kernels' trig reduction
+hipError_t launch_trig_range(hipStream_t st, const double *q, int64_t n, double xmax, int32_t *flag);
 // r_w[i] = w_i (f(x_i;p) - y_i) for 1x1 rows; r_raw[i] = f - y for rows inside blocks
 hipError_t launch_residual_ex(hipStream_t st, const ModelArgs &m, double *r_w, double *r_raw);
 // J[i][0..P) = w_i d f_i / d p ; J[i][P] = w_i delta_i (ld >= P+1); block rows -> J_raw unweighted

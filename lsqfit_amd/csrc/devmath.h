@@ -23,8 +23,11 @@ __device__ __attribute__((noinline)) inline double cos_far(double t) { return co
 // is pi/2 to 2e-32): 1.1e-16 absolute up to |t| = 1e13 (checked against libm), where a double's own spacing is
 // already 2e-3.
 constexpr double TRIG_FAST_LIMIT = 1.0e13;
+// FAR = false: the caller guarantees |t| < TRIG_FAST_LIMIT (a device flag computed from the parameters, see
+// trig_range_kernel) -- no far-range code in the kernel at all
+template <bool FAR = true>
 __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs) {
-  if (!(fabs(t) < TRIG_FAST_LIMIT)) {
+  if (FAR && !(fabs(t) < TRIG_FAST_LIMIT)) {
     const SinCos f = sincos_far(t);
     *sn = f.s;
     *cs = f.c;
@@ -54,8 +57,9 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
 
 // cos alone (the residual kernels): ONE polynomial with its coefficients chosen per lane by the quadrant
 // instead of both -- the same operations in the same order as the cosine of sincos_moderate, so the same bits.
+template <bool FAR = true>
 __device__ __forceinline__ double cos_moderate(double t) {
-  if (!(fabs(t) < TRIG_FAST_LIMIT)) return cos_far(t);
+  if (FAR && !(fabs(t) < TRIG_FAST_LIMIT)) return cos_far(t);
   const double n = rint(t * 6.36619772367581382433e-01);
   double r = __builtin_fma(-n, 1.57079632679489655800e+00, t);
   r = __builtin_fma(-n, 6.12323399573676603587e-17, r);

@@ -117,6 +117,9 @@ struct lsqamd_fit {
   bool timing = false;
   lsqamd_host::TimerSlot timers[LSQAMD_T_COUNT];
 
+  // cosine model: max |x| (set_x) and the device flag "some |w x| may leave the fast range of the trig reduction"
+  double xmax = 0.0;
+  int32_t *trig_far = nullptr;
   // captured LM step (iterate_device): [p-buffer parity][0 = trial, 1 = accepted branch]
   hipGraphExec_t step_exec[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
   int step_seen[2][2] = {{0, 0}, {0, 0}};   // eager executions so far (the first one is the warm-up)

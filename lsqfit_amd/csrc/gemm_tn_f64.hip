@@ -977,9 +977,10 @@ void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
 // NT = terms per tile: 64 (128 output columns) or 32 (64 output columns: twice the workgroups for the shapes
 // that would otherwise leave one workgroup per CU -- config 3's single 8192-row block -- where nothing but
 // a second workgroup covers the barrier and LDS latencies of the first); same products in the same order.
-template <int MODEL, int NT>
+template <int MODEL, int NT, bool FAR>
 __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int tiles_m, int tiles_n, int pair_rows) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (a.trig_far && (a.trig_far[0] != 0) != FAR) return;    // (FAR = false: no far-range trig code, see model.hip)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -1043,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
       double t, dq;
       if (MODEL == LSQAMD_MODEL_COSMIX) {
         double sn, cs;
-        sincos_moderate(frq * xv, &sn, &cs);
+        sincos_moderate<FAR>(frq * xv, &sn, &cs);
         t = cs;
         dq = -amp * xv * sn;
       } else {
@@ -1140,19 +1141,33 @@ bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P) {
 
 constexpr size_t SYNTH_LDS_BYTES = GEMM_LDS_BYTES + 3 * 32 * sizeof(double);
 
-hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a) {
+template <int MODEL, int NT, bool FAR>
+static hipError_t launch_whiten_synth_one(hipStream_t st, const WhitenSynth &a, dim3 grid, int tiles_m, int tiles_n, int pair) {
   static bool attr = false;
   if (!attr) {
-    const void *fns[] = {reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 64>),
-                         reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 64>),
-                         reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 32>),
-                         reinterpret_cast<const void *>(whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 32>)};
-    for (const void *fn : fns) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
-      if (e != hipSuccess) return e;
-    }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<MODEL, NT, FAR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
+    if (e != hipSuccess) return e;
     attr = true;
   }
+  hipLaunchKernelGGL((whiten_synth_kernel<MODEL, NT, FAR>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
+  return hipGetLastError();
+}
+
+template <int MODEL, int NT>
+static hipError_t launch_whiten_synth_nt(hipStream_t st, const WhitenSynth &a, dim3 grid, int tiles_m, int tiles_n, int pair) {
+  // cosine model with a range flag: the kernel without far-range trig code first, then the safe one -- the
+  // device flag leaves exactly one of them with work
+  if (MODEL == LSQAMD_MODEL_COSMIX && a.trig_far) {
+    hipError_t e = launch_whiten_synth_one<MODEL, NT, false>(st, a, grid, tiles_m, tiles_n, pair);
+    if (e != hipSuccess) return e;
+  }
+  return launch_whiten_synth_one<MODEL, NT, true>(st, a, grid, tiles_m, tiles_n, pair);
+}
+
+hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a0) {
+  WhitenSynth a = a0;
+  if (a.model != LSQAMD_MODEL_COSMIX) a.trig_far = nullptr;
   const int tiles_m = (int)(a.B / BM);
   // few large blocks: unpaired, the workgroups of the last tile rows run 2 tiles_m / (tiles_m + 1) times the average
   const int pair = tiles_m >= 4 ? 1 : 0;
@@ -1162,14 +1177,11 @@ hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a) {
   const bool narrow = rows * (a.K / 64) * a.nb < narrow_below && a.K % 32 == 0;
   const int tiles_n = (int)(a.K / (narrow ? 32 : 64));
   dim3 grid((unsigned)(rows * tiles_n), 1, (unsigned)a.nb);
-  if (a.model == LSQAMD_MODEL_COSMIX) {
-    if (narrow) hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 32>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
-    else hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_COSMIX, 64>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
-  } else {
-    if (narrow) hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 32>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
-    else hipLaunchKernelGGL((whiten_synth_kernel<LSQAMD_MODEL_MULTIEXP, 64>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
-  }
-  return hipGetLastError();
+  if (a.model == LSQAMD_MODEL_COSMIX)
+    return narrow ? launch_whiten_synth_nt<LSQAMD_MODEL_COSMIX, 32>(st, a, grid, tiles_m, tiles_n, pair)
+                  : launch_whiten_synth_nt<LSQAMD_MODEL_COSMIX, 64>(st, a, grid, tiles_m, tiles_n, pair);
+  return narrow ? launch_whiten_synth_nt<LSQAMD_MODEL_MULTIEXP, 32>(st, a, grid, tiles_m, tiles_n, pair)
+                : launch_whiten_synth_nt<LSQAMD_MODEL_MULTIEXP, 64>(st, a, grid, tiles_m, tiles_n, pair);
 }
 
 }  // namespace lsqamd

@@ -47,13 +47,17 @@ struct ModelDev {
   int32_t p_in_lds;
   int64_t p_stride, out_stride, ymean_stride;
   const int32_t *batch_active;
+  const int32_t *trig_far;
 };
 
-template <int MODEL, bool JAC>
+// FAR (cosine model): false = no far-range trig code; both variants are launched and the device flag decides
+// which one works (an empty launch costs ~2 us, the far-range code 10 % of the fused whitening kernel)
+template <int MODEL, bool JAC, bool FAR = true>
 __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
   extern __shared__ __attribute__((aligned(16))) double sp[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t P = m.n_param, K = P / 2;
+  if (m.trig_far && (m.trig_far[0] != 0) != FAR) return;
   if (m.batch_active && !m.batch_active[blockIdx.y]) return;
   m.p += (int64_t)blockIdx.y * m.p_stride;
   m.ymean += (int64_t)blockIdx.y * m.ymean_stride;
@@ -81,7 +85,7 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
           const double a = pp[k + u], q = pp[K + k + u];
           if (MODEL == LSQAMD_MODEL_COSMIX) {
             double s, c;
-            sincos_moderate(q * x, &s, &c);
+            sincos_moderate<FAR>(q * x, &s, &c);
             t[u] = c;
             dq[u] = -a * x * s;
           } else {
@@ -101,11 +105,11 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
       if (MODEL == LSQAMD_MODEL_COSMIX) {
         if (JAC) {
           double s, c;
-          sincos_moderate(q * x, &s, &c);
+          sincos_moderate<FAR>(q * x, &s, &c);
           term = c;
           dq = -a * x * s;
         } else {
-          term = cos_moderate(q * x);
+          term = cos_moderate<FAR>(q * x);
           dq = 0.0;
         }
       } else {
@@ -381,6 +385,22 @@ __global__ __launch_bounds__(256) void tape_finish_kernel(const double *jt, int6
   }
 }
 
+__global__ __launch_bounds__(256) void trig_range_kernel(const double *q, int64_t n, double xmax, int32_t *flag) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  bool far = false;
+  for (int64_t k = threadIdx.x; k < n; k += 256) far |= !(fabs(q[k]) * xmax < 0.5 * TRIG_FAST_LIMIT);
+  if (far) any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) flag[0] = any;
+}
+
+hipError_t launch_trig_range(hipStream_t st, const double *q, int64_t n, double xmax, int32_t *flag) {
+  hipLaunchKernelGGL(trig_range_kernel, dim3(1), dim3(256), 0, st, q, n, xmax, flag);
+  return hipGetLastError();
+}
+
 template <bool JAC>
 static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w, double *out_raw,
                                int64_t ld) {
@@ -394,6 +414,7 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
   m.p_in_lds = 0;
   m.p_stride = a.p_stride; m.out_stride = a.out_stride; m.batch_active = a.batch_active;
   m.ymean_stride = a.ymean_stride;
+  m.trig_far = a.model == LSQAMD_MODEL_COSMIX ? a.trig_far : nullptr;
   const unsigned nb = (unsigned)(a.n_batch < 1 ? 1 : a.n_batch);
   switch (a.model) {
     case LSQAMD_MODEL_COSMIX:
@@ -405,10 +426,13 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
       }
       int64_t blocks = (a.n_data + 3) / 4;
       if (blocks > 4096) blocks = 4096;
-      if (a.model == LSQAMD_MODEL_COSMIX)
-        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_COSMIX, JAC>), dim3((unsigned)blocks, nb),
+      if (a.model == LSQAMD_MODEL_COSMIX) {
+        if (m.trig_far)
+          hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_COSMIX, JAC, false>), dim3((unsigned)blocks, nb),
+                             dim3(256), lds, st, m);
+        hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_COSMIX, JAC, true>), dim3((unsigned)blocks, nb),
                            dim3(256), lds, st, m);
-      else
+      } else
         hipLaunchKernelGGL((sum_model_kernel<LSQAMD_MODEL_MULTIEXP, JAC>), dim3((unsigned)blocks, nb),
                            dim3(256), lds, st, m);
       break;

@@ -200,6 +200,34 @@ def test_query_devices_reports_the_mi355x():
     assert n.value >= 1 and buf.value.startswith(b'gfx950') and mem.value > 200 * (1 << 30)
 
 
+@pytest.mark.parametrize('scale', [1.0, 1e14])
+def test_cosine_model_range_flag_at_size(amd, scale):
+    """From a few million cosines per evaluation on, the model kernels run as a pair -- one without far-range trig
+    code, one with -- and a device flag computed from the frequencies leaves exactly one of them with work
+    (api.hip residual_vector_launch, model.hip trig_range_kernel).  Both sides of the flag against numpy."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=8192, P=1024, seed=12, block=256, prior_corr=False)
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    p = d['p_true'].copy()
+    p[512:] *= scale
+    chi2 = pr.normal(p)
+    assert pr.lib.lsqamd_debug_flags(pr.h) & 2                      # the fused whitening kernel ran
+    A = pr.get_jtj()
+    Jr = gu.cosmix_jac(d['x'], p)
+    r = gu.cosmix_fcn(d['x'], p) - d['ymean']
+    Aref = np.diag(1.0 / np.asarray(d['prior'][1]) ** 2)
+    c2 = float(np.sum(((p - d['prior'][0]) / np.asarray(d['prior'][1])) ** 2))
+    for r0, c in d['yerr']['blocks']:
+        B = c.shape[0]
+        sol = np.linalg.solve(c, np.column_stack([Jr[r0:r0 + B], r[r0:r0 + B]]))
+        Aref = Aref + Jr[r0:r0 + B].T @ sol[:, :-1]
+        c2 += float(r[r0:r0 + B] @ sol[:, -1])
+    assert np.abs(A - Aref).max() <= 1e-9 * np.abs(Aref).max()
+    assert chi2 == pytest.approx(c2, rel=1e-9)
+    pr.close()
+
+
 @pytest.mark.parametrize('scale', [1.0, 1e4, 1e9, 1e14, 1e17])
 def test_cosine_model_at_large_arguments(amd, scale):
     """cos / sin of w x in the model kernels: a two-term Cody-Waite reduction carried by FMAs up to |w x| = 1e13
