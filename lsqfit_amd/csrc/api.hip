@@ -144,7 +144,8 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->trig_far = cv.take<int32_t>(16);
   f->tape_cap = c.tape_len > 1024 ? c.tape_len : 1024;
   f->tape = cv.take<int32_t>(f->tape_cap);
-  f->tape_poff = cv.take<int32_t>(f->tape_cap);
+  f->tape_poff = cv.take<int32_t>(f->tape_cap + 1);
+  f->tape_seg = cv.take<int32_t>(3 * (int64_t)f->tape_cap + 3);
   f->consts = cv.take<double>(1024);
   if (c.model == LSQAMD_MODEL_TAPE) {
     // one forward + one reverse sweep per row: per resident wave 2 slots per instruction (upper
@@ -195,6 +196,12 @@ ModelArgs model_args(const lsqamd_fit *f, const double *p) {
     m.tape_ldn = f->tape_ldn;
     m.tape_wgs = f->tape_wgs;
     m.tape_slots = f->tape_slots;
+    m.tape_seg = f->tape_seg;
+    m.tape_n_seg = f->tape_n_seg;
+    m.tape_seg_depth = f->tape_seg_depth;
+    m.tape_seg_slots = f->tape_seg_slots;
+    m.tape_single = f->tape_single;
+    m.tape_slot_cap = f->tape_slot_cap;
   }
   return m;
 }
@@ -1402,15 +1409,79 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
   }
   if (sp != 1) FAIL(f, LSQAMD_EINVAL, "tape: must leave exactly one value");
   {
-    std::vector<int32_t> poff((size_t)n_code);
+    std::vector<int32_t> poff((size_t)n_code + 1);
     int32_t slots = 0;
     for (int t = 0; t < n_code; ++t) {
       poff[(size_t)t] = slots;
       slots += tape_slots_of_op(code[t] & 0xff);
     }
+    poff[(size_t)n_code] = slots;
     f->tape_slots = slots;
-    HIPCHK(f, hipMemcpyAsync(f->tape_poff, poff.data(), sizeof(int32_t) * n_code, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipStreamSynchronize(f->st));   // (poff is a local)
+    // Is the root a sum S_1 + S_2 + ... ?  The joining ADDs are the ones that take the stack from depth 2 to 1;
+    // S_1 ends where the depth is 1 for the last time before the first of them.  Every segment must fit the
+    // kernel's LDS store of local partials; otherwise (or if anything follows the last join) the whole-tape
+    // kernel runs.
+    std::vector<int32_t> seg;      // (first, last, sign) per segment
+    {
+      std::vector<int> depth_after((size_t)n_code);
+      int d = 0;
+      std::vector<int> joins;
+      for (int t = 0; t < n_code; ++t) {
+        const int op = code[t] & 0xff;
+        if (op <= LSQAMD_OP_P) ++d;
+        else if (op <= LSQAMD_OP_POW) {
+          if ((op == LSQAMD_OP_ADD || op == LSQAMD_OP_SUB) && d == 2) joins.push_back(t);
+          --d;
+        }
+        depth_after[(size_t)t] = d;
+      }
+      bool ok = !joins.empty() && joins.back() == n_code - 1;
+      if (ok) {
+        int split = -1;
+        for (int t = joins[0] - 1; t >= 0; --t)
+          if (depth_after[(size_t)t] == 1) { split = t; break; }
+        ok = split >= 0 && split + 1 <= joins[0] - 1;
+        if (ok) {
+          seg.insert(seg.end(), {0, split, 1});
+          for (size_t k = 0; k < joins.size(); ++k) {
+            const int lo = k == 0 ? split + 1 : joins[k - 1] + 1, hi = joins[k] - 1;
+            if (lo > hi) { ok = false; break; }
+            seg.insert(seg.end(), {lo, hi, (code[joins[k]] & 0xff) == LSQAMD_OP_SUB ? -1 : 1});
+          }
+        }
+      }
+      int max_depth = 1, max_slots = 1;
+      for (size_t k = 0; ok && k + 2 < seg.size(); k += 3) {
+        const int nsl = poff[(size_t)seg[k + 1] + 1] - poff[(size_t)seg[k]];
+        if (nsl > 32) ok = false;     // TAPE_SEG_SLOTS
+        if (nsl > max_slots) max_slots = nsl;
+        int sd = 0;                              // every segment is a complete expression of its own
+        for (int t = seg[k]; ok && t <= seg[k + 1]; ++t) {
+          const int op = code[t] & 0xff;
+          if (op <= LSQAMD_OP_P) ++sd;
+          else if (op <= LSQAMD_OP_POW) { if (sd < 2) ok = false; --sd; }
+          else if (sd < 1) ok = false;
+          if (sd > max_depth) max_depth = sd;
+        }
+        if (sd != 1) ok = false;
+      }
+      if (!ok) seg.clear();
+      f->tape_seg_depth = max_depth + 1;         // (the reverse sweep pushes one adjoint before it pops)
+      f->tape_seg_slots = max_slots;
+      // a parameter read once has one contribution to its column: a plain store, no atomic; if that is true of
+      // all of them and none is missing, the transposed Jacobian needs no zero fill either
+      std::vector<int> uses((size_t)f->P, 0);
+      for (int t = 0; t < n_code; ++t)
+        if ((code[t] & 0xff) == LSQAMD_OP_P) ++uses[(size_t)(code[t] >> 8)];
+      int most = 0, least = 1 << 30;
+      for (int u : uses) { if (u > most) most = u; if (u < least) least = u; }
+      f->tape_single = most <= 1 ? (least == 1 ? 2 : 1) : 0;
+    }
+    f->tape_n_seg = (int32_t)(seg.size() / 3);
+    HIPCHK(f, hipMemcpyAsync(f->tape_poff, poff.data(), sizeof(int32_t) * (n_code + 1), hipMemcpyHostToDevice, f->st));
+    if (!seg.empty())
+      HIPCHK(f, hipMemcpyAsync(f->tape_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));   // (poff, seg are locals)
   }
   HIPCHK(f, hipMemcpyAsync(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice, f->st));
   if (n_consts > 0)

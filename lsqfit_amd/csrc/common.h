@@ -129,6 +129,8 @@ struct ModelArgs {
   double *tape_jt = nullptr;            // [(n_param + 1)][tape_ldn]
   int64_t tape_ldn = 0, tape_wgs = 0;
   int32_t tape_slots = 0;
+  const int32_t *tape_seg = nullptr;    // root-sum segments [n][3] (first, last instruction, sign), or null
+  int32_t tape_n_seg = 0, tape_seg_depth = 0, tape_seg_slots = 0, tape_slot_cap = 0, tape_single = 0;
 };
 int tape_slots_of_op(int op);
 // flag[0] = 1 unless max_k |q_k| * xmax is (finite and) below the fast range of the model kernels' trig reduction

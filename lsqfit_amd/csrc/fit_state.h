@@ -58,6 +58,9 @@ struct lsqamd_fit {
   int32_t n_tape = 0;
   // reverse-mode tape Jacobian (model.hip): slot offsets, partial store, transposed Jacobian
   int32_t *tape_poff = nullptr;
+  int32_t *tape_seg = nullptr;     // root-sum segments of the tape (set_tape), tape_n_seg of them (0: not a sum)
+  int32_t tape_single = 0;   // 1: no parameter is read twice by the tape; 2: and every one is read
+  int32_t tape_n_seg = 0, tape_seg_depth = 0, tape_seg_slots = 0;   // deepest stack / most partials of a segment
   double *tape_part = nullptr, *tape_jt = nullptr;
   int64_t tape_ldn = 0, tape_wgs = 0;
   int32_t tape_cap = 0, tape_slots = 0, tape_slot_cap = 0;

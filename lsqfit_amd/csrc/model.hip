@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
   __shared__ double stk[4][LSQAMD_TAPE_MAX_STACK][64];   // value stack, then adjoint stack
   extern __shared__ int32_t tcode[];                      // [n_tape] instructions, [n_tape] slot offsets
   const ModelDev &m = a.m;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the interpreter must branch on scalars)
   int32_t *toff = tcode + m.n_tape;
   for (int t = threadIdx.x; t < m.n_tape; t += 256) {
     tcode[t] = m.tape[t];
@@ -359,6 +359,145 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
       }
     }
   }
+}
+
+// ---- the same for tapes whose root is a SUM of independent sub-expressions ----------------------------
+// f = +-S_1 +- S_2 ... +- S_m (lsqamd_set_tape finds the root-level ADDs / SUBs): the adjoint of every S_k is
+// +-1, so each segment is differentiated right after it is evaluated -- forward through the LDS stack with the
+// local partials in LDS as well, reverse at once -- and the segments are independent of each other: the
+// launch spreads (row group, chunk of segments) pairs over the chip.  What the whole-tape kernel above
+// suffers from at N = 65536 is occupancy, not arithmetic: 1024 row groups are 1024 waves, ONE per SIMD, each
+// walking 2 x 3583 dependent LDS / memory round trips alone (2.3 ms).  With eight chunks there are eight
+// waves per SIMD to cover each other; the per-wave LDS footprint is sized by the deepest / widest segment
+// (a cosine term: 3 stack levels + 5 partials = 4 KB), the parameters sit in LDS, the tape is read through
+// scalar loads one instruction ahead, x of the row through registers.  Per-chunk values of f go to a
+// scratch array and are summed in chunk order (tape_total_kernel): reproducible bit for bit.
+constexpr int TAPE_SEG_SLOTS = 32;     // partial-derivative slots a segment may use at most
+
+struct TapeSeg {
+  TapeRev r;
+  const int32_t *seg;    // [n_seg][3]: first and last instruction of every segment and its sign (the joining ADD / SUB is implied)
+  int32_t n_seg, n_chunks, seg_per_chunk;
+  int32_t depth, slots;  // LDS rows per wave: value / adjoint stack, local partials
+  int32_t single;        // no parameter occurs twice on the tape: its column is stored, not accumulated
+  double *ftot;          // [n_chunks][ldn] partial values of f
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tape_segment_kernel(TapeSeg a) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [n_param] parameters, then per wave [depth + slots][64]
+  const ModelDev &m = a.r.m;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the interpreter must branch on scalars)
+  double *plds = lds;
+  for (int64_t i = threadIdx.x; i < m.n_param; i += 256) plds[i] = m.p[i];
+  __syncthreads();
+  double *mine = lds + ((m.n_param + 1) & ~(int64_t)1) + (int64_t)wave * (a.depth + a.slots) * 64 + lane;
+  auto S = [&](int i) -> double & { return mine[i * 64]; };
+  double *PL = mine + a.depth * 64;
+  // The tape, its slot offsets, the segment table and the constants are read at wave-uniform addresses and are
+  // never written on the device: through the constant address space they become scalar loads (s_load, scalar
+  // cache) that the decode-ahead below can really hide -- as ordinary global pointers the compiler must
+  // assume the stores to jt may alias them and issues a vector load per instruction (540 cycles each, measured).
+  typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+  typedef const __attribute__((address_space(4))) double *ConstF64;
+  const ConstI32 tape = (ConstI32)m.tape, poff = (ConstI32)a.r.poff, segs = (ConstI32)a.seg;
+  const ConstF64 consts = (ConstF64)m.consts;
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;          // (row group, chunk), chunk fastest
+  const int64_t g = unit / a.n_chunks;
+  const int chunk = (int)(unit % a.n_chunks);
+  if (g >= a.r.n_groups) return;
+  const int64_t row = g * 64 + lane;
+  const bool valid = row < m.n_data;
+  const int64_t rr = valid ? row : m.n_data - 1;
+  const double x0 = m.x[rr * m.n_x], x1 = m.n_x > 1 ? m.x[rr * m.n_x + 1] : 0.0;
+  double total = 0.0;
+  const int s_lo = chunk * a.seg_per_chunk, s_hi = s_lo + a.seg_per_chunk < a.n_seg ? s_lo + a.seg_per_chunk : a.n_seg;
+  for (int sgi = s_lo; sgi < s_hi; ++sgi) {
+    const int lo = segs[3 * sgi], hi = segs[3 * sgi + 1];
+    const double sign = (double)segs[3 * sgi + 2];
+    const int base = poff[lo];
+    // ---- forward over the segment.  The top of the stack lives in a register (tos); the entry k below it
+    // (k < sp - 1) at S(k + 1), so a push is one LDS store, a binary operation one LDS load, a function none.
+    int sp = 0;
+    double tos = 0.0;
+    int32_t ins_n = tape[lo], off_n = base;
+    for (int t = lo; t <= hi; ++t) {
+      const int32_t ins = ins_n;
+      double *pd = PL + (off_n - base) * 64;
+      if (t < hi) { ins_n = tape[t + 1]; off_n = poff[t + 1]; }      // decode one ahead (scalar loads)
+      const int op = ins & 0xff, arg = ins >> 8;
+      if (op <= LSQAMD_OP_P) {
+        S(sp++) = tos;
+        if (op == LSQAMD_OP_P) tos = plds[arg];
+        else if (op == LSQAMD_OP_X) tos = arg == 0 ? x0 : (arg == 1 ? x1 : m.x[rr * m.n_x + arg]);
+        else tos = consts[arg];
+      } else if (op <= LSQAMD_OP_POW) {
+        const double b = tos, x = S(--sp);
+        if (op == LSQAMD_OP_MUL) { tos = x * b; pd[0] = b; pd[64] = x; }
+        else if (op == LSQAMD_OP_ADD) tos = x + b;
+        else if (op == LSQAMD_OP_SUB) tos = x - b;
+        else if (op == LSQAMD_OP_DIV) { tos = x / b; pd[0] = 1.0 / b; pd[64] = -tos / b; }
+        else { tos = pow(x, b); pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; }
+      } else {
+        const double x = tos;
+        double v, d = 1.0;
+        switch (op) {
+          case LSQAMD_OP_NEG: v = -x; break;
+          case LSQAMD_OP_EXP: v = exp(x); d = v; break;
+          case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
+          case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
+          case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
+          case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
+          case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
+          case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
+          default: v = x; break;
+        }
+        if (op != LSQAMD_OP_NEG) pd[0] = d;
+        tos = v;
+      }
+    }
+    total += sign * tos;
+    // ---- reverse over the segment: its root carries the adjoint of the sum, +-1 (same stack convention)
+    tos = sign;
+    sp = 1;
+    ins_n = tape[hi];
+    off_n = poff[hi];
+    for (int t = hi; t >= lo; --t) {
+      const int32_t ins = ins_n;
+      const double *pd = PL + (off_n - base) * 64;
+      if (t > lo) { ins_n = tape[t - 1]; off_n = poff[t - 1]; }
+      const int op = ins & 0xff, arg = ins >> 8;
+      if (op <= LSQAMD_OP_P) {
+        const double gbar = tos;
+        tos = S(--sp);
+        if (op == LSQAMD_OP_P && valid) {
+          double *dst = a.r.jt + (int64_t)arg * a.r.ldn + row;
+          if (a.single) __builtin_nontemporal_store(gbar, dst);
+          else   // fire and forget: the parameter occurs more than once on the tape
+            (void)__hip_atomic_fetch_add(dst, gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else if (op <= LSQAMD_OP_POW) {
+        const double gbar = tos;
+        double da = 1.0, db = 1.0;
+        if (op == LSQAMD_OP_SUB) db = -1.0;
+        else if (op != LSQAMD_OP_ADD) { da = pd[0]; db = pd[64]; }
+        S(sp++) = gbar * da;
+        tos = gbar * db;
+      } else {
+        tos *= (op == LSQAMD_OP_NEG) ? -1.0 : pd[0];
+      }
+    }
+  }
+  if (valid) a.ftot[(int64_t)chunk * a.r.ldn + row] = total;
+}
+
+// row P of the transposed Jacobian: f - ymean, the chunks' pieces of f summed in chunk order
+__global__ __launch_bounds__(256) void tape_total_kernel(const double *ftot, int n_chunks, int64_t ldn, int64_t N,
+                                                         const double *ymean, double *out) {
+  const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= N) return;
+  double f = 0.0;
+  for (int c = 0; c < n_chunks; ++c) f += ftot[(int64_t)c * ldn + row];
+  out[row] = f - ymean[row];
 }
 
 // dst[row][c] = w_row * jt[c][row] for c <= P: 64 x 64 tiles through LDS, rows inside covariance
@@ -447,8 +586,6 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
         r.m = m; r.poff = a.tape_poff; r.part = a.tape_part; r.jt = a.tape_jt; r.ldn = a.tape_ldn;
         r.n_slots = a.tape_slots > 0 ? a.tape_slots : 1;
         r.n_groups = (a.n_data + 63) / 64;
-        hipError_t e = hipMemsetAsync(a.tape_jt, 0, sizeof(double) * (size_t)((a.n_param + 1) * a.tape_ldn), st);
-        if (e != hipSuccess) return e;
         int64_t wgs = (r.n_groups + 3) / 4;
         if (wgs > a.tape_wgs) wgs = a.tape_wgs;
         static const bool fwd = [] { const char *e = getenv("LSQAMD_TAPE"); return e && e[0] == 'f'; }();
@@ -456,7 +593,42 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64), nb), dim3(64), 0, st, m);
           break;
         }
-        hipLaunchKernelGGL(tape_reverse_kernel, dim3((unsigned)wgs), dim3(256), sizeof(int32_t) * 2 * (size_t)a.n_tape, st, r);
+        static const bool whole = [] { const char *e = getenv("LSQAMD_TAPE"); return e && e[0] == 'w'; }();   // developer knob
+        const bool by_segment = a.tape_seg && a.tape_n_seg > 0 && !whole;
+        if (!(by_segment && a.tape_single == 2)) {   // (every column is stored in full otherwise)
+          hipError_t e = hipMemsetAsync(a.tape_jt, 0, sizeof(double) * (size_t)((a.n_param + 1) * a.tape_ldn), st);
+          if (e != hipSuccess) return e;
+        }
+        if (by_segment) {   // the root is a sum: segment by segment, partials never leave LDS
+          TapeSeg sg;
+          sg.r = r; sg.seg = a.tape_seg; sg.n_seg = a.tape_n_seg;
+          sg.single = a.tape_single;
+          sg.depth = a.tape_seg_depth; sg.slots = a.tape_seg_slots > 0 ? a.tape_seg_slots : 1;
+          // chunks of segments: enough (row group, chunk) units for ~24 waves per CU, at least 8 segments per unit
+          int64_t chunks = (24 * 256 + r.n_groups - 1) / r.n_groups;
+          if (chunks > (sg.n_seg + 7) / 8) chunks = (sg.n_seg + 7) / 8;
+          if (chunks < 1) chunks = 1;
+          const int64_t cap = (a.tape_wgs * 4 * (int64_t)(a.tape_slot_cap > 0 ? a.tape_slot_cap : 1) * 64) / a.tape_ldn;   // room in the scratch
+          if (chunks > cap) chunks = cap;
+          if (chunks < 1) chunks = 1;
+          sg.n_chunks = (int32_t)chunks;
+          sg.seg_per_chunk = (int32_t)((sg.n_seg + chunks - 1) / chunks);
+          sg.ftot = a.tape_part;
+          const size_t lds = sizeof(double) * (size_t)(((a.n_param + 1) & ~(int64_t)1) + 4 * (sg.depth + sg.slots) * 64);
+          static size_t lds_set = 0;
+          if (lds > lds_set) {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(tape_segment_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e2 != hipSuccess) return e2;
+            lds_set = lds;
+          }
+          const int64_t units = r.n_groups * chunks;
+          hipLaunchKernelGGL(tape_segment_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);
+          hipLaunchKernelGGL(tape_total_kernel, dim3((unsigned)((a.n_data + 255) / 256)), dim3(256), 0, st, sg.ftot,
+                             sg.n_chunks, a.tape_ldn, a.n_data, a.ymean, a.tape_jt + (int64_t)a.n_param * a.tape_ldn);
+        } else {
+          hipLaunchKernelGGL(tape_reverse_kernel, dim3((unsigned)wgs), dim3(256), sizeof(int32_t) * 2 * (size_t)a.n_tape, st, r);
+        }
         dim3 grid((unsigned)((a.n_data + 63) / 64), (unsigned)((a.n_param + 1 + 63) / 64));
         hipLaunchKernelGGL(tape_finish_kernel, grid, dim3(256), 0, st, a.tape_jt, a.tape_ldn, a.n_data, a.n_param + 1,
                            a.wdiag, a.in_block, out_w, out_raw, ld);

@@ -65,3 +65,69 @@ def test_tape_repeated_parameters_and_every_opcode(amd):
         assert np.max(np.abs(J[:, j] - fd)) < 1e-7 * max(1.0, np.max(np.abs(fd))), j
     assert np.all(np.isfinite(f0))
     pr.close()
+
+
+_SEG_SCRIPT = r'''
+import sys, json
+sys.path.insert(0, %(root)r)
+import numpy as np
+import lsqfit_amd as amd
+rng = np.random.default_rng(11)
+N = 700
+x = np.stack([rng.uniform(0.5, 2.0, N), rng.uniform(0.1, 1.0, N)], axis=1)
+cases = {
+    # every parameter exactly once (columns stored, no zero fill)
+    'once': ('a1*cos(w1*x) + a2*cos(w2*z) - a3*exp(-w3*x) + a4*sin(w4*x*z)', ['a1', 'w1', 'a2', 'w2', 'a3', 'w3', 'a4', 'w4']),
+    # one parameter never read (its column must be zero), none read twice
+    'unused': ('a1*cos(w1*x) - a2*z + w2*w2_0', ['a1', 'w1', 'a2', 'w2', 'dead', 'w2_0']),
+    # parameters shared between the terms of the sum (adjoints accumulate across segments and chunks)
+    'shared': ('a1*exp(-w1*x) + a1*a1*sin(w1*z) - a2/(1 + w1*w1) + a2*cos(a1*x) + (w1*x)**a2 - a1', ['a1', 'w1', 'a2']),
+    # the root is not a sum: whole-tape kernel whatever the knob says
+    'product': ('(a1 + w1*x)*(a2 - cos(w1*z))', ['a1', 'w1', 'a2']),
+}
+out = {}
+for name, (text, names) in cases.items():
+    model = amd.expr(text, names, xnames=('x', 'z'))
+    p = rng.uniform(0.6, 1.7, len(names))
+    wh = amd.Whitening(np.zeros(N), np.linspace(0.5, 2.0, N))
+    pr = amd.DeviceProblem(model, x, wh)
+    pr.normal(p)
+    out[name] = dict(J=pr.get_J_data().tolist(), f=pr.fcn(p).tolist(), p=p.tolist())
+    pr.close()
+print('RESULT' + json.dumps(out))
+'''
+
+
+def test_segmented_tape_kernel_matches_the_whole_tape_and_forward_mode_kernels(tmp_path):
+    """The kernel that differentiates a root-level sum term by term (parameters stored when each is read once,
+    accumulated atomically otherwise; chunks of terms on different waves) against the whole-tape reverse kernel
+    (LSQAMD_TAPE=w) and the forward-mode kernel (LSQAMD_TAPE=f) on the same tapes.  A process each: the knob
+    is read once."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'seg.py'
+    script.write_text(_SEG_SCRIPT % dict(root=root))
+    res = {}
+    for knob in ('', 'w', 'f'):
+        env = dict(os.environ)
+        env.pop('LSQAMD_TAPE', None)
+        if knob:
+            env['LSQAMD_TAPE'] = knob
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith('RESULT')][-1]
+        res[knob] = json.loads(line[len('RESULT'):])
+    for name in res['']:
+        J = np.array(res[''][name]['J'])
+        assert np.all(np.isfinite(J))
+        if name == 'unused':
+            assert np.all(J[:, 4] == 0.0)
+        for other in ('w', 'f'):
+            Jo = np.array(res[other][name]['J'])
+            scale = np.max(np.abs(Jo), axis=0) + 1e-300
+            assert np.max(np.abs(J - Jo) / scale) < 1e-13, (name, other)
+            fo = np.array(res[other][name]['f'])
+            assert np.max(np.abs(np.array(res[''][name]['f']) - fo)) <= 1e-14 * np.max(np.abs(fo)), (name, other)
