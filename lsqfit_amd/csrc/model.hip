@@ -271,49 +271,51 @@ struct TapeRev {
   int64_t ldn;
   int32_t n_slots;
   int64_t n_groups;      // ceil(n_data / 64)
+  int32_t single;        // no parameter occurs twice on the tape: its column is stored, not accumulated
 };
 
 __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
   __shared__ double stk[4][LSQAMD_TAPE_MAX_STACK][64];   // value stack, then adjoint stack
-  extern __shared__ int32_t tcode[];                      // [n_tape] instructions, [n_tape] slot offsets
   const ModelDev &m = a.m;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the interpreter must branch on scalars)
-  int32_t *toff = tcode + m.n_tape;
-  for (int t = threadIdx.x; t < m.n_tape; t += 256) {
-    tcode[t] = m.tape[t];
-    toff[t] = a.poff[t];
-  }
-  __syncthreads();
+  // tape, slot offsets, constants and parameters: wave-uniform addresses, never written while this kernel
+  // runs -- the constant address space makes them scalar loads (see tape_segment_kernel below)
+  typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+  typedef const __attribute__((address_space(4))) double *ConstF64;
+  const ConstI32 tcode = (ConstI32)m.tape, toff = (ConstI32)a.poff;
+  const ConstF64 consts = (ConstF64)m.consts, par = (ConstF64)m.p;
   const int64_t slot = (int64_t)blockIdx.x * 4 + wave, nslots = (int64_t)gridDim.x * 4;
   double *part = a.part + slot * a.n_slots * 64 + lane;
   double (*S)[64] = stk[wave];
+  // The top of the stack lives in a register (tos); the entry k below it (k < sp - 1) at S[k + 1]: a push is
+  // one LDS store, a binary operation one LDS load, a function none.
   for (int64_t g = slot; g < a.n_groups; g += nslots) {
     const int64_t row = g * 64 + lane;
     const bool valid = row < m.n_data;
     const int64_t rr = valid ? row : m.n_data - 1;
-    // ---- forward: values through the LDS stack, local partials to the store
+    // ---- forward: values through the stack, local partials to the store
     int sp = 0;
+    double tos = 0.0;
     int32_t ins_n = tcode[0], off_n = toff[0];
     for (int t = 0; t < m.n_tape; ++t) {
       const int32_t ins = ins_n;
       double *pd = part + (int64_t)off_n * 64;
       if (t + 1 < m.n_tape) { ins_n = tcode[t + 1]; off_n = toff[t + 1]; }   // decode one ahead
       const int op = ins & 0xff, arg = ins >> 8;
-      if (op == LSQAMD_OP_CONST) S[sp++][lane] = m.consts[arg];
-      else if (op == LSQAMD_OP_X) S[sp++][lane] = m.x[rr * m.n_x + arg];
-      else if (op == LSQAMD_OP_P) S[sp++][lane] = m.p[arg];
-      else if (op <= LSQAMD_OP_POW) {
-        const double b = S[sp - 1][lane], x = S[sp - 2][lane];
-        double v;
-        if (op == LSQAMD_OP_ADD) v = x + b;
-        else if (op == LSQAMD_OP_SUB) v = x - b;
-        else if (op == LSQAMD_OP_MUL) { v = x * b; pd[0] = b; pd[64] = x; }
-        else if (op == LSQAMD_OP_DIV) { v = x / b; pd[0] = 1.0 / b; pd[64] = -v / b; }
-        else { v = pow(x, b); pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? v * log(x) : 0.0; }
-        S[sp - 2][lane] = v;
-        --sp;
+      if (op <= LSQAMD_OP_P) {
+        S[sp++][lane] = tos;
+        if (op == LSQAMD_OP_P) tos = par[arg];
+        else if (op == LSQAMD_OP_X) tos = m.x[rr * m.n_x + arg];
+        else tos = consts[arg];
+      } else if (op <= LSQAMD_OP_POW) {
+        const double b = tos, x = S[--sp][lane];
+        if (op == LSQAMD_OP_MUL) { tos = x * b; pd[0] = b; pd[64] = x; }
+        else if (op == LSQAMD_OP_ADD) tos = x + b;
+        else if (op == LSQAMD_OP_SUB) tos = x - b;
+        else if (op == LSQAMD_OP_DIV) { tos = x / b; pd[0] = 1.0 / b; pd[64] = -tos / b; }
+        else { tos = pow(x, b); pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; }
       } else {
-        const double x = S[sp - 1][lane];
+        const double x = tos;
         double v, d = 1.0;
         switch (op) {
           case LSQAMD_OP_NEG: v = -x; break;
@@ -327,12 +329,12 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
           default: v = x; break;
         }
         if (op != LSQAMD_OP_NEG) pd[0] = d;
-        S[sp - 1][lane] = v;
+        tos = v;
       }
     }
-    if (valid) a.jt[(int64_t)m.n_param * a.ldn + row] = S[0][lane] - m.ymean[row];
+    if (valid) a.jt[(int64_t)m.n_param * a.ldn + row] = tos - m.ymean[row];
     // ---- reverse: adjoints through the same stack; d f / d p_j accumulates in the transposed Jacobian
-    S[0][lane] = 1.0;
+    tos = 1.0;
     sp = 1;
     ins_n = tcode[m.n_tape - 1];
     off_n = toff[m.n_tape - 1];
@@ -342,20 +344,23 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
       if (t > 0) { ins_n = tcode[t - 1]; off_n = toff[t - 1]; }
       const int op = ins & 0xff, arg = ins >> 8;
       if (op <= LSQAMD_OP_P) {
-        --sp;
-        if (op == LSQAMD_OP_P && valid)   // fire and forget: a parameter may occur more than once on the tape
-          (void)__hip_atomic_fetch_add(a.jt + (int64_t)arg * a.ldn + row, S[sp][lane], __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+        const double gbar = tos;
+        tos = S[--sp][lane];
+        if (op == LSQAMD_OP_P && valid) {
+          double *dst = a.jt + (int64_t)arg * a.ldn + row;
+          if (a.single) *dst = gbar;   // the only read of this parameter
+          else   // fire and forget: the parameter occurs more than once on the tape
+            (void)__hip_atomic_fetch_add(dst, gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       } else if (op <= LSQAMD_OP_POW) {
-        const double gbar = S[sp - 1][lane];
+        const double gbar = tos;
         double da = 1.0, db = 1.0;
         if (op == LSQAMD_OP_SUB) db = -1.0;
         else if (op != LSQAMD_OP_ADD) { da = pd[0]; db = pd[64]; }
-        S[sp - 1][lane] = gbar * da;
-        S[sp][lane] = gbar * db;
-        ++sp;
+        S[sp++][lane] = gbar * da;
+        tos = gbar * db;
       } else {
-        S[sp - 1][lane] *= (op == LSQAMD_OP_NEG) ? -1.0 : pd[0];
+        tos *= (op == LSQAMD_OP_NEG) ? -1.0 : pd[0];
       }
     }
   }
@@ -379,7 +384,6 @@ struct TapeSeg {
   const int32_t *seg;    // [n_seg][3]: first and last instruction of every segment and its sign (the joining ADD / SUB is implied)
   int32_t n_seg, n_chunks, seg_per_chunk;
   int32_t depth, slots;  // LDS rows per wave: value / adjoint stack, local partials
-  int32_t single;        // no parameter occurs twice on the tape: its column is stored, not accumulated
   double *ftot;          // [n_chunks][ldn] partial values of f
 };
 
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
         tos = S(--sp);
         if (op == LSQAMD_OP_P && valid) {
           double *dst = a.r.jt + (int64_t)arg * a.r.ldn + row;
-          if (a.single) __builtin_nontemporal_store(gbar, dst);
+          if (a.r.single) __builtin_nontemporal_store(gbar, dst);
           else   // fire and forget: the parameter occurs more than once on the tape
             (void)__hip_atomic_fetch_add(dst, gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -586,6 +590,7 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
         r.m = m; r.poff = a.tape_poff; r.part = a.tape_part; r.jt = a.tape_jt; r.ldn = a.tape_ldn;
         r.n_slots = a.tape_slots > 0 ? a.tape_slots : 1;
         r.n_groups = (a.n_data + 63) / 64;
+        r.single = a.tape_single;
         int64_t wgs = (r.n_groups + 3) / 4;
         if (wgs > a.tape_wgs) wgs = a.tape_wgs;
         static const bool fwd = [] { const char *e = getenv("LSQAMD_TAPE"); return e && e[0] == 'f'; }();
@@ -602,7 +607,6 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
         if (by_segment) {   // the root is a sum: segment by segment, partials never leave LDS
           TapeSeg sg;
           sg.r = r; sg.seg = a.tape_seg; sg.n_seg = a.tape_n_seg;
-          sg.single = a.tape_single;
           sg.depth = a.tape_seg_depth; sg.slots = a.tape_seg_slots > 0 ? a.tape_seg_slots : 1;
           // chunks of segments: enough (row group, chunk) units for ~24 waves per CU, at least 8 segments per unit
           int64_t chunks = (24 * 256 + r.n_groups - 1) / r.n_groups;
@@ -627,7 +631,7 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           hipLaunchKernelGGL(tape_total_kernel, dim3((unsigned)((a.n_data + 255) / 256)), dim3(256), 0, st, sg.ftot,
                              sg.n_chunks, a.tape_ldn, a.n_data, a.ymean, a.tape_jt + (int64_t)a.n_param * a.tape_ldn);
         } else {
-          hipLaunchKernelGGL(tape_reverse_kernel, dim3((unsigned)wgs), dim3(256), sizeof(int32_t) * 2 * (size_t)a.n_tape, st, r);
+          hipLaunchKernelGGL(tape_reverse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, r);
         }
         dim3 grid((unsigned)((a.n_data + 63) / 64), (unsigned)((a.n_param + 1 + 63) / 64));
         hipLaunchKernelGGL(tape_finish_kernel, grid, dim3(256), 0, st, a.tape_jt, a.tape_ldn, a.n_data, a.n_param + 1,
