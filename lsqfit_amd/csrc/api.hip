@@ -80,11 +80,12 @@ int32_t choose_splits(int64_t N, int64_t P) {
   }
   const int64_t T = (P + 127) / 128;
   const int64_t tiles = T * (T + 1) / 2;
-  // enough workgroups to fill the chip a few times over (>= 4096), K-chunks of ~4096 rows when
-  // there are that many rows (tail balance: 16 chunks beat 8 at N = 65536), never below 256 rows,
-  // never more than 16 slabs (their read-back in finalize_pack grows with the count: at the
-  // 8-GPU shard shape N = 8192, P = 4096 eight chunks beat sixteen by 0.12 ms)
-  int64_t s = (4096 + tiles - 1) / tiles;
+  // enough workgroups to fill the chip a few times over (>= 2048: four rounds of two per CU), K-chunks of
+  // ~4096 rows when there are that many rows (tail balance: 16 chunks beat 8 at N = 65536), never below 256
+  // rows, never more than 16 slabs.  Their read-back in finalize_pack grows with the count: at the 8-GPU
+  // shard shape N = 8192, P = 4096 (528 tiles) the product itself takes 3.07 / 2.53 / 2.24 / 2.10 / 2.10 ms
+  // with 1 / 2 / 3 / 4 / 8 chunks and the read-back 0.06 / 0.07 / 0.09 / 0.10 / 0.16 ms: four.
+  int64_t s = (2048 + tiles - 1) / tiles;
   if (s < N / 4096) s = N / 4096;
   const int64_t maxs = N / 256 > 1 ? N / 256 : 1;
   if (s > maxs) s = maxs;
