@@ -274,6 +274,9 @@ struct TapeRev {
   int32_t single;        // no parameter occurs twice on the tape: its column is stored, not accumulated
 };
 
+// JAC = false: the forward sweep alone (trial residuals): no partials stored, the weighted residual written
+// straight to the vector the block whitening / sum of squares read.
+template <bool JAC>
 __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
   __shared__ double stk[4][LSQAMD_TAPE_MAX_STACK][64];   // value stack, then adjoint stack
   const ModelDev &m = a.m;
@@ -309,28 +312,50 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
         else tos = consts[arg];
       } else if (op <= LSQAMD_OP_POW) {
         const double b = tos, x = S[--sp][lane];
-        if (op == LSQAMD_OP_MUL) { tos = x * b; pd[0] = b; pd[64] = x; }
+        if (op == LSQAMD_OP_MUL) { tos = x * b; if (JAC) { pd[0] = b; pd[64] = x; } }
         else if (op == LSQAMD_OP_ADD) tos = x + b;
         else if (op == LSQAMD_OP_SUB) tos = x - b;
-        else if (op == LSQAMD_OP_DIV) { tos = x / b; pd[0] = 1.0 / b; pd[64] = -tos / b; }
-        else { tos = pow(x, b); pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; }
+        else if (op == LSQAMD_OP_DIV) { tos = x / b; if (JAC) { pd[0] = 1.0 / b; pd[64] = -tos / b; } }
+        else { tos = pow(x, b); if (JAC) { pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; } }
       } else {
         const double x = tos;
         double v, d = 1.0;
-        switch (op) {
-          case LSQAMD_OP_NEG: v = -x; break;
-          case LSQAMD_OP_EXP: v = exp(x); d = v; break;
-          case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
-          case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
-          case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
-          case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
-          case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
-          case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
-          default: v = x; break;
+        if constexpr (JAC) {
+          switch (op) {
+            case LSQAMD_OP_NEG: v = -x; break;
+            case LSQAMD_OP_EXP: v = exp(x); d = v; break;
+            case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
+            case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
+            case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
+            case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
+            case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
+            case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
+            default: v = x; break;
+          }
+          if (op != LSQAMD_OP_NEG) pd[0] = d;
+        } else {   // the values the Jacobian sweep computes, from the same library calls (sincos(x).s == sin(x) bit for bit is not promised: keep sincos)
+          switch (op) {
+            case LSQAMD_OP_NEG: v = -x; break;
+            case LSQAMD_OP_EXP: v = exp(x); break;
+            case LSQAMD_OP_LOG: v = log(x); break;
+            case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; break; }
+            case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; break; }
+            case LSQAMD_OP_ATAN: v = atan(x); break;
+            case LSQAMD_OP_SQRT: v = sqrt(x); break;
+            case LSQAMD_OP_POWI: v = pow(x, (double)arg); break;
+            default: v = x; break;
+          }
+          (void)d;
         }
-        if (op != LSQAMD_OP_NEG) pd[0] = d;
         tos = v;
       }
+    }
+    if constexpr (!JAC) {
+      if (valid) {
+        const bool blk = m.in_block && m.in_block[row];
+        (blk ? m.out_raw : m.out_w)[row] = (blk ? 1.0 : m.wdiag[row]) * (tos - m.ymean[row]);
+      }
+      continue;
     }
     if (valid) a.jt[(int64_t)m.n_param * a.ldn + row] = tos - m.ymean[row];
     // ---- reverse: adjoints through the same stack; d f / d p_j accumulates in the transposed Jacobian
@@ -387,6 +412,7 @@ struct TapeSeg {
   double *ftot;          // [n_chunks][ldn] partial values of f
 };
 
+template <bool JAC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tape_segment_kernel(TapeSeg a) {
   extern __shared__ __attribute__((aligned(16))) double lds[];   // [n_param] parameters, then per wave [depth + slots][64]
   const ModelDev &m = a.r.m;
@@ -436,30 +462,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
         else tos = consts[arg];
       } else if (op <= LSQAMD_OP_POW) {
         const double b = tos, x = S(--sp);
-        if (op == LSQAMD_OP_MUL) { tos = x * b; pd[0] = b; pd[64] = x; }
+        if (op == LSQAMD_OP_MUL) { tos = x * b; if (JAC) { pd[0] = b; pd[64] = x; } }
         else if (op == LSQAMD_OP_ADD) tos = x + b;
         else if (op == LSQAMD_OP_SUB) tos = x - b;
-        else if (op == LSQAMD_OP_DIV) { tos = x / b; pd[0] = 1.0 / b; pd[64] = -tos / b; }
-        else { tos = pow(x, b); pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; }
+        else if (op == LSQAMD_OP_DIV) { tos = x / b; if (JAC) { pd[0] = 1.0 / b; pd[64] = -tos / b; } }
+        else { tos = pow(x, b); if (JAC) { pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; } }
       } else {
         const double x = tos;
         double v, d = 1.0;
-        switch (op) {
-          case LSQAMD_OP_NEG: v = -x; break;
-          case LSQAMD_OP_EXP: v = exp(x); d = v; break;
-          case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
-          case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
-          case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
-          case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
-          case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
-          case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
-          default: v = x; break;
+        if constexpr (JAC) {
+          switch (op) {
+            case LSQAMD_OP_NEG: v = -x; break;
+            case LSQAMD_OP_EXP: v = exp(x); d = v; break;
+            case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
+            case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
+            case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
+            case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
+            case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
+            case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
+            default: v = x; break;
+          }
+          if (op != LSQAMD_OP_NEG) pd[0] = d;
+        } else {   // the values the Jacobian sweep computes, from the same library calls (sincos(x).s == sin(x) bit for bit is not promised: keep sincos)
+          switch (op) {
+            case LSQAMD_OP_NEG: v = -x; break;
+            case LSQAMD_OP_EXP: v = exp(x); break;
+            case LSQAMD_OP_LOG: v = log(x); break;
+            case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; break; }
+            case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; break; }
+            case LSQAMD_OP_ATAN: v = atan(x); break;
+            case LSQAMD_OP_SQRT: v = sqrt(x); break;
+            case LSQAMD_OP_POWI: v = pow(x, (double)arg); break;
+            default: v = x; break;
+          }
+          (void)d;
         }
-        if (op != LSQAMD_OP_NEG) pd[0] = d;
         tos = v;
       }
     }
     total += sign * tos;
+    if constexpr (!JAC) continue;
     // ---- reverse over the segment: its root carries the adjoint of the sum, +-1 (same stack convention)
     tos = sign;
     sp = 1;
@@ -494,14 +536,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
   if (valid) a.ftot[(int64_t)chunk * a.r.ldn + row] = total;
 }
 
-// row P of the transposed Jacobian: f - ymean, the chunks' pieces of f summed in chunk order
+// row P of the transposed Jacobian: f - ymean, the chunks' pieces of f summed in chunk order; for a residual
+// evaluation (out_w given) the weighted residual itself, rows inside covariance blocks unweighted to out_raw
 __global__ __launch_bounds__(256) void tape_total_kernel(const double *ftot, int n_chunks, int64_t ldn, int64_t N,
-                                                         const double *ymean, double *out) {
+                                                         const double *ymean, double *out, const double *wdiag,
+                                                         const uint8_t *in_block, double *out_w, double *out_raw) {
   const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (row >= N) return;
   double f = 0.0;
   for (int c = 0; c < n_chunks; ++c) f += ftot[(int64_t)c * ldn + row];
-  out[row] = f - ymean[row];
+  if (out_w) {
+    const bool blk = in_block && in_block[row];
+    (blk ? out_raw : out_w)[row] = (blk ? 1.0 : wdiag[row]) * (f - ymean[row]);
+  } else {
+    out[row] = f - ymean[row];
+  }
 }
 
 // dst[row][c] = w_row * jt[c][row] for c <= P: 64 x 64 tiles through LDS, rows inside covariance
@@ -585,7 +634,7 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
                          dim3(256), 0, st, m);
       break;
     case LSQAMD_MODEL_TAPE:
-      if (JAC && nb == 1 && a.tape_part && a.tape_jt && a.tape_poff) {
+      if (nb == 1 && a.tape_part && a.tape_jt && a.tape_poff) {
         TapeRev r;
         r.m = m; r.poff = a.tape_poff; r.part = a.tape_part; r.jt = a.tape_jt; r.ldn = a.tape_ldn;
         r.n_slots = a.tape_slots > 0 ? a.tape_slots : 1;
@@ -600,7 +649,7 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
         }
         static const bool whole = [] { const char *e = getenv("LSQAMD_TAPE"); return e && e[0] == 'w'; }();   // developer knob
         const bool by_segment = a.tape_seg && a.tape_n_seg > 0 && !whole;
-        if (!(by_segment && a.tape_single == 2)) {   // (every column is stored in full otherwise)
+        if (JAC && !(by_segment && a.tape_single == 2)) {   // (every column is stored in full otherwise)
           hipError_t e = hipMemsetAsync(a.tape_jt, 0, sizeof(double) * (size_t)((a.n_param + 1) * a.tape_ldn), st);
           if (e != hipSuccess) return e;
         }
@@ -621,21 +670,24 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           const size_t lds = sizeof(double) * (size_t)(((a.n_param + 1) & ~(int64_t)1) + 4 * (sg.depth + sg.slots) * 64);
           static size_t lds_set = 0;
           if (lds > lds_set) {
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(tape_segment_kernel),
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(tape_segment_kernel<JAC>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e2 != hipSuccess) return e2;
             lds_set = lds;
           }
           const int64_t units = r.n_groups * chunks;
-          hipLaunchKernelGGL(tape_segment_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);
+          hipLaunchKernelGGL(tape_segment_kernel<JAC>, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);
           hipLaunchKernelGGL(tape_total_kernel, dim3((unsigned)((a.n_data + 255) / 256)), dim3(256), 0, st, sg.ftot,
-                             sg.n_chunks, a.tape_ldn, a.n_data, a.ymean, a.tape_jt + (int64_t)a.n_param * a.tape_ldn);
+                             sg.n_chunks, a.tape_ldn, a.n_data, a.ymean, a.tape_jt + (int64_t)a.n_param * a.tape_ldn,
+                             a.wdiag, a.in_block, JAC ? nullptr : out_w, JAC ? nullptr : out_raw);
         } else {
-          hipLaunchKernelGGL(tape_reverse_kernel, dim3((unsigned)wgs), dim3(256), 0, st, r);
+          hipLaunchKernelGGL(tape_reverse_kernel<JAC>, dim3((unsigned)wgs), dim3(256), 0, st, r);
         }
-        dim3 grid((unsigned)((a.n_data + 63) / 64), (unsigned)((a.n_param + 1 + 63) / 64));
-        hipLaunchKernelGGL(tape_finish_kernel, grid, dim3(256), 0, st, a.tape_jt, a.tape_ldn, a.n_data, a.n_param + 1,
-                           a.wdiag, a.in_block, out_w, out_raw, ld);
+        if (JAC) {
+          dim3 grid((unsigned)((a.n_data + 63) / 64), (unsigned)((a.n_param + 1 + 63) / 64));
+          hipLaunchKernelGGL(tape_finish_kernel, grid, dim3(256), 0, st, a.tape_jt, a.tape_ldn, a.n_data, a.n_param + 1,
+                             a.wdiag, a.in_block, out_w, out_raw, ld);
+        }
         break;
       }
       hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((a.n_data + 63) / 64), nb), dim3(64),

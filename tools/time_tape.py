@@ -26,4 +26,9 @@ for P in (64, 1024):
         nbytes = 8.0 * N * (P + 1)
         print('P = %4d  %-6s  Jacobian %.3f ms  (J = %.0f MB: %.2f TB/s of J written)  tape length %d'
               % (P, name, jac_ms, nbytes / 1e6, nbytes / jac_ms / 1e9, 0 if model.tape is None else len(model.tape)))
+        pr.timing_reset()
+        for rep in range(6):
+            pr.chi2(d['p0'])
+        tm = pr.timings()
+        print('          %-6s  residual %.3f ms' % (name, tm['residual'][0] / tm['residual'][1]))
         pr.close()
