@@ -170,6 +170,11 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
   m.out_w += (int64_t)blockIdx.y * m.out_stride;
   if (m.out_raw) m.out_raw += (int64_t)blockIdx.y * m.out_stride;
   const int P = (int)m.n_param;
+  // wave-uniform addresses, never written while the kernel runs: scalar loads (see tape_segment_kernel)
+  typedef const __attribute__((address_space(4))) int32_t *ConstI32;
+  typedef const __attribute__((address_space(4))) double *ConstF64;
+  const ConstI32 tape = (ConstI32)m.tape;
+  const ConstF64 consts = (ConstF64)m.consts, par = (ConstF64)m.p;
   const bool blk = m.in_block && m.in_block[row];
   const double w = blk ? 1.0 : m.wdiag[row];
   double *dst = blk ? m.out_raw : m.out_w;
@@ -181,11 +186,11 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
     const int nc = JAC ? (P - c0 < MP ? P - c0 : MP) : 0;
     int sp = 0;
     for (int t = 0; t < m.n_tape; ++t) {
-      const int32_t ins = m.tape[t];
+      const int32_t ins = tape[t];
       const int op = ins & 0xff, arg = ins >> 8;
       switch (op) {
         case LSQAMD_OP_CONST:
-          sv[sp] = m.consts[arg];
+          sv[sp] = consts[arg];
           if (JAC) for (int j = 0; j < MP; ++j) sd[sp][j] = 0.0;
           ++sp;
           break;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
           ++sp;
           break;
         case LSQAMD_OP_P:
-          sv[sp] = m.p[arg];
+          sv[sp] = par[arg];
           if (JAC) for (int j = 0; j < MP; ++j) sd[sp][j] = (c0 + j == arg) ? 1.0 : 0.0;
           ++sp;
           break;
