@@ -14,8 +14,13 @@ python3 bench.py --workload c3 --steps 40 --warmup 5 --cpu-seconds 10 > $OUT/${R
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4 -- python3 $ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > $OUT/${R}_bench_c4_1gpu_under_rocprof.json 2> $OUT/trace_c4.err
 cp $(find $OUT/trace_c4 -name "*kernel_stats.csv" | head -1) $OUT/${R}_c4_1gpu_kernel_stats.csv
-PYTHONPATH=$ROOT rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tape -- python3 $ROOT/tools/time_tape.py > $OUT/${R}_tape_timing.txt 2> $OUT/trace_tape.err
+PYTHONPATH=$ROOT rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_tape -- python3 $ROOT/tools/time_tape.py > $OUT/tape_default.txt 2> $OUT/trace_tape.err
 cp $(find $OUT/trace_tape -name "*kernel_stats.csv" | head -1) $OUT/${R}_tape_n65536_kernel_stats.csv
+cd $ROOT
+{ echo "# by terms (tape_segment_kernel: the default when the root of the tape is a sum; this run under rocprofv3)"; grep -E "P =|residual" $OUT/tape_default.txt
+  echo "# whole-tape reverse kernel (LSQAMD_TAPE=w)"; LSQAMD_TAPE=w PYTHONPATH=$ROOT python3 tools/time_tape.py 2>/dev/null | grep -E "P =|residual"
+  echo "# forward-mode kernel, 16 parameters per pass (LSQAMD_TAPE=f; round 1)"; LSQAMD_TAPE=f PYTHONPATH=$ROOT timeout 300 python3 tools/time_tape.py 2>/dev/null | grep -E "P =|residual"
+} > $OUT/${R}_tape_timing.txt
 rm -rf $OUT/trace_c4 $OUT/trace_tape
 cd $ROOT
 LSQAMD_ROUND=$R bash tools/collect_syrk_pmc.sh > $OUT/pmc.log 2>&1
