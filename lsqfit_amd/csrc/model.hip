@@ -417,17 +417,21 @@ struct TapeSeg {
   double *ftot;          // [n_chunks][ldn] partial values of f
 };
 
-template <bool JAC>
+// R = data rows per lane (1 or 2): the interpreter's own work per instruction -- thirty scalar instructions
+// of decode, dispatch and address arithmetic -- is paid once per wave whatever the lanes carry, so with two
+// rows per lane (rows g*128 + lane and + 64) it is spread over twice the arithmetic.
+template <bool JAC, int R>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void tape_segment_kernel(TapeSeg a) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];   // [n_param] parameters, then per wave [depth + slots][64]
+  extern __shared__ __attribute__((aligned(16))) double lds[];   // [n_param] parameters, then per wave [depth + slots][R][64]
+  constexpr int RS = R * 64;
   const ModelDev &m = a.r.m;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: the interpreter must branch on scalars)
   double *plds = lds;
   for (int64_t i = threadIdx.x; i < m.n_param; i += 256) plds[i] = m.p[i];
   __syncthreads();
-  double *mine = lds + ((m.n_param + 1) & ~(int64_t)1) + (int64_t)wave * (a.depth + a.slots) * 64 + lane;
-  auto S = [&](int i) -> double & { return mine[i * 64]; };
-  double *PL = mine + a.depth * 64;
+  double *mine = lds + ((m.n_param + 1) & ~(int64_t)1) + (int64_t)wave * (a.depth + a.slots) * RS + lane;
+  auto S = [&](int i, int r) -> double & { return mine[i * RS + r * 64]; };
+  double *PL = mine + a.depth * RS;
   // The tape, its slot offsets, the segment table and the constants are read at wave-uniform addresses and are
   // never written on the device: through the constant address space they become scalar loads (s_load, scalar
   // cache) that the decode-ahead below can really hide -- as ordinary global pointers the compiler must
@@ -440,11 +444,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
   const int64_t g = unit / a.n_chunks;
   const int chunk = (int)(unit % a.n_chunks);
   if (g >= a.r.n_groups) return;
-  const int64_t row = g * 64 + lane;
-  const bool valid = row < m.n_data;
-  const int64_t rr = valid ? row : m.n_data - 1;
-  const double x0 = m.x[rr * m.n_x], x1 = m.n_x > 1 ? m.x[rr * m.n_x + 1] : 0.0;
-  double total = 0.0;
+  int64_t row[R], rr[R];
+  bool valid[R];
+  double x0[R], x1[R], total[R], tos[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    row[r] = (g * R + r) * 64 + lane;
+    valid[r] = row[r] < m.n_data;
+    rr[r] = valid[r] ? row[r] : m.n_data - 1;
+    x0[r] = m.x[rr[r] * m.n_x];
+    x1[r] = m.n_x > 1 ? m.x[rr[r] * m.n_x + 1] : 0.0;
+    total[r] = 0.0;
+  }
   const int s_lo = chunk * a.seg_per_chunk, s_hi = s_lo + a.seg_per_chunk < a.n_seg ? s_lo + a.seg_per_chunk : a.n_seg;
   for (int sgi = s_lo; sgi < s_hi; ++sgi) {
     const int lo = segs[3 * sgi], hi = segs[3 * sgi + 1];
@@ -453,92 +464,125 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
     // ---- forward over the segment.  The top of the stack lives in a register (tos); the entry k below it
     // (k < sp - 1) at S(k + 1), so a push is one LDS store, a binary operation one LDS load, a function none.
     int sp = 0;
-    double tos = 0.0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) tos[r] = 0.0;
     int32_t ins_n = tape[lo], off_n = base;
     for (int t = lo; t <= hi; ++t) {
       const int32_t ins = ins_n;
-      double *pd = PL + (off_n - base) * 64;
+      double *pd = PL + (off_n - base) * RS;
       if (t < hi) { ins_n = tape[t + 1]; off_n = poff[t + 1]; }      // decode one ahead (scalar loads)
       const int op = ins & 0xff, arg = ins >> 8;
       if (op <= LSQAMD_OP_P) {
-        S(sp++) = tos;
-        if (op == LSQAMD_OP_P) tos = plds[arg];
-        else if (op == LSQAMD_OP_X) tos = arg == 0 ? x0 : (arg == 1 ? x1 : m.x[rr * m.n_x + arg]);
-        else tos = consts[arg];
-      } else if (op <= LSQAMD_OP_POW) {
-        const double b = tos, x = S(--sp);
-        if (op == LSQAMD_OP_MUL) { tos = x * b; if (JAC) { pd[0] = b; pd[64] = x; } }
-        else if (op == LSQAMD_OP_ADD) tos = x + b;
-        else if (op == LSQAMD_OP_SUB) tos = x - b;
-        else if (op == LSQAMD_OP_DIV) { tos = x / b; if (JAC) { pd[0] = 1.0 / b; pd[64] = -tos / b; } }
-        else { tos = pow(x, b); if (JAC) { pd[0] = b * pow(x, b - 1.0); pd[64] = (x > 0.0) ? tos * log(x) : 0.0; } }
-      } else {
-        const double x = tos;
-        double v, d = 1.0;
-        if constexpr (JAC) {
-          switch (op) {
-            case LSQAMD_OP_NEG: v = -x; break;
-            case LSQAMD_OP_EXP: v = exp(x); d = v; break;
-            case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
-            case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
-            case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
-            case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
-            case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
-            case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
-            default: v = x; break;
-          }
-          if (op != LSQAMD_OP_NEG) pd[0] = d;
-        } else {   // the values the Jacobian sweep computes, from the same library calls (sincos(x).s == sin(x) bit for bit is not promised: keep sincos)
-          switch (op) {
-            case LSQAMD_OP_NEG: v = -x; break;
-            case LSQAMD_OP_EXP: v = exp(x); break;
-            case LSQAMD_OP_LOG: v = log(x); break;
-            case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; break; }
-            case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; break; }
-            case LSQAMD_OP_ATAN: v = atan(x); break;
-            case LSQAMD_OP_SQRT: v = sqrt(x); break;
-            case LSQAMD_OP_POWI: v = pow(x, (double)arg); break;
-            default: v = x; break;
-          }
-          (void)d;
+#pragma unroll
+        for (int r = 0; r < R; ++r) S(sp, r) = tos[r];
+        ++sp;
+        if (op == LSQAMD_OP_P) {
+          const double v = plds[arg];
+#pragma unroll
+          for (int r = 0; r < R; ++r) tos[r] = v;
+        } else if (op == LSQAMD_OP_X) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) tos[r] = arg == 0 ? x0[r] : (arg == 1 ? x1[r] : m.x[rr[r] * m.n_x + arg]);
+        } else {
+          const double v = consts[arg];
+#pragma unroll
+          for (int r = 0; r < R; ++r) tos[r] = v;
         }
-        tos = v;
+      } else if (op <= LSQAMD_OP_POW) {
+        --sp;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double b = tos[r], x = S(sp, r);
+          double *q = pd + r * 64;
+          if (op == LSQAMD_OP_MUL) { tos[r] = x * b; if (JAC) { q[0] = b; q[RS] = x; } }
+          else if (op == LSQAMD_OP_ADD) tos[r] = x + b;
+          else if (op == LSQAMD_OP_SUB) tos[r] = x - b;
+          else if (op == LSQAMD_OP_DIV) { tos[r] = x / b; if (JAC) { q[0] = 1.0 / b; q[RS] = -tos[r] / b; } }
+          else { tos[r] = pow(x, b); if (JAC) { q[0] = b * pow(x, b - 1.0); q[RS] = (x > 0.0) ? tos[r] * log(x) : 0.0; } }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double x = tos[r];
+          double v, d = 1.0;
+          if constexpr (JAC) {
+            switch (op) {
+              case LSQAMD_OP_NEG: v = -x; break;
+              case LSQAMD_OP_EXP: v = exp(x); d = v; break;
+              case LSQAMD_OP_LOG: v = log(x); d = 1.0 / x; break;
+              case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; d = cs; break; }
+              case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; d = -sn; break; }
+              case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
+              case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
+              case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
+              default: v = x; break;
+            }
+            if (op != LSQAMD_OP_NEG) pd[r * 64] = d;
+          } else {   // the values the Jacobian sweep computes, from the same library calls (sincos(x).s == sin(x) bit for bit is not promised: keep sincos)
+            switch (op) {
+              case LSQAMD_OP_NEG: v = -x; break;
+              case LSQAMD_OP_EXP: v = exp(x); break;
+              case LSQAMD_OP_LOG: v = log(x); break;
+              case LSQAMD_OP_SIN: { double sn, cs; sincos(x, &sn, &cs); v = sn; break; }
+              case LSQAMD_OP_COS: { double sn, cs; sincos(x, &sn, &cs); v = cs; break; }
+              case LSQAMD_OP_ATAN: v = atan(x); break;
+              case LSQAMD_OP_SQRT: v = sqrt(x); break;
+              case LSQAMD_OP_POWI: v = pow(x, (double)arg); break;
+              default: v = x; break;
+            }
+            (void)d;
+          }
+          tos[r] = v;
+        }
       }
     }
-    total += sign * tos;
+#pragma unroll
+    for (int r = 0; r < R; ++r) total[r] += sign * tos[r];
     if constexpr (!JAC) continue;
     // ---- reverse over the segment: its root carries the adjoint of the sum, +-1 (same stack convention)
-    tos = sign;
+#pragma unroll
+    for (int r = 0; r < R; ++r) tos[r] = sign;
     sp = 1;
     ins_n = tape[hi];
     off_n = poff[hi];
     for (int t = hi; t >= lo; --t) {
       const int32_t ins = ins_n;
-      const double *pd = PL + (off_n - base) * 64;
+      const double *pd = PL + (off_n - base) * RS;
       if (t > lo) { ins_n = tape[t - 1]; off_n = poff[t - 1]; }
       const int op = ins & 0xff, arg = ins >> 8;
       if (op <= LSQAMD_OP_P) {
-        const double gbar = tos;
-        tos = S(--sp);
-        if (op == LSQAMD_OP_P && valid) {
-          double *dst = a.r.jt + (int64_t)arg * a.r.ldn + row;
-          if (a.r.single) __builtin_nontemporal_store(gbar, dst);
-          else   // fire and forget: the parameter occurs more than once on the tape
-            (void)__hip_atomic_fetch_add(dst, gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        --sp;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double gbar = tos[r];
+          tos[r] = S(sp, r);
+          if (op == LSQAMD_OP_P && valid[r]) {
+            double *dst = a.r.jt + (int64_t)arg * a.r.ldn + row[r];
+            if (a.r.single) __builtin_nontemporal_store(gbar, dst);
+            else   // fire and forget: the parameter occurs more than once on the tape
+              (void)__hip_atomic_fetch_add(dst, gbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
       } else if (op <= LSQAMD_OP_POW) {
-        const double gbar = tos;
-        double da = 1.0, db = 1.0;
-        if (op == LSQAMD_OP_SUB) db = -1.0;
-        else if (op != LSQAMD_OP_ADD) { da = pd[0]; db = pd[64]; }
-        S(sp++) = gbar * da;
-        tos = gbar * db;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const double gbar = tos[r];
+          double da = 1.0, db = 1.0;
+          if (op == LSQAMD_OP_SUB) db = -1.0;
+          else if (op != LSQAMD_OP_ADD) { da = pd[r * 64]; db = pd[RS + r * 64]; }
+          S(sp, r) = gbar * da;
+          tos[r] = gbar * db;
+        }
+        ++sp;
       } else {
-        tos *= (op == LSQAMD_OP_NEG) ? -1.0 : pd[0];
+#pragma unroll
+        for (int r = 0; r < R; ++r) tos[r] *= (op == LSQAMD_OP_NEG) ? -1.0 : pd[r * 64];
       }
     }
   }
-  if (valid) a.ftot[(int64_t)chunk * a.r.ldn + row] = total;
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (valid[r]) a.ftot[(int64_t)chunk * a.r.ldn + row[r]] = total[r];
 }
 
 // row P of the transposed Jacobian: f - ymean, the chunks' pieces of f summed in chunk order; for a residual
@@ -662,8 +706,15 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           TapeSeg sg;
           sg.r = r; sg.seg = a.tape_seg; sg.n_seg = a.tape_n_seg;
           sg.depth = a.tape_seg_depth; sg.slots = a.tape_seg_slots > 0 ? a.tape_seg_slots : 1;
-          // chunks of segments: enough (row group, chunk) units for ~24 waves per CU, at least 8 segments per unit
-          int64_t chunks = (24 * 256 + r.n_groups - 1) / r.n_groups;
+          // two rows per lane once there are row groups enough to fill the chip either way (developer knob: LSQAMD_TAPE_ROWS)
+          static const int rows_knob = [] { const char *e = getenv("LSQAMD_TAPE_ROWS"); return e ? atoi(e) : 0; }();
+          const int R = rows_knob == 1 || rows_knob == 2 ? rows_knob : (a.n_data >= 16384 ? 2 : 1);   // (four: 0.76-0.80 against 0.74 ms, fewer waves and spills)
+          const int64_t groups = (a.n_data + 64 * R - 1) / (64 * R);
+          sg.r.n_groups = groups;
+          // chunks of segments: enough (row group, chunk) units for ~24 waves per CU (two rounds of the three per
+          // SIMD the registers allow), at least 8 segments per unit
+          static const int64_t per_cu = [] { const char *e = getenv("LSQAMD_TAPE_WAVES_PER_CU"); return e && atoi(e) > 0 ? (int64_t)atoi(e) : (int64_t)24; }();
+          int64_t chunks = (per_cu * 256 + groups - 1) / groups;
           if (chunks > (sg.n_seg + 7) / 8) chunks = (sg.n_seg + 7) / 8;
           if (chunks < 1) chunks = 1;
           const int64_t cap = (a.tape_wgs * 4 * (int64_t)(a.tape_slot_cap > 0 ? a.tape_slot_cap : 1) * 64) / a.tape_ldn;   // room in the scratch
@@ -672,16 +723,18 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           sg.n_chunks = (int32_t)chunks;
           sg.seg_per_chunk = (int32_t)((sg.n_seg + chunks - 1) / chunks);
           sg.ftot = a.tape_part;
-          const size_t lds = sizeof(double) * (size_t)(((a.n_param + 1) & ~(int64_t)1) + 4 * (sg.depth + sg.slots) * 64);
-          static size_t lds_set = 0;
-          if (lds > lds_set) {
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(tape_segment_kernel<JAC>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          const size_t lds = sizeof(double) * (size_t)(((a.n_param + 1) & ~(int64_t)1) + 4 * (sg.depth + sg.slots) * 64 * R);
+          static size_t lds_set[3] = {0, 0, 0};
+          const void *kfn = R == 2 ? reinterpret_cast<const void *>(tape_segment_kernel<JAC, 2>)
+                                   : reinterpret_cast<const void *>(tape_segment_kernel<JAC, 1>);
+          if (lds > lds_set[R]) {
+            hipError_t e2 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e2 != hipSuccess) return e2;
-            lds_set = lds;
+            lds_set[R] = lds;
           }
-          const int64_t units = r.n_groups * chunks;
-          hipLaunchKernelGGL(tape_segment_kernel<JAC>, dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);
+          const int64_t units = groups * chunks;
+          if (R == 2) hipLaunchKernelGGL((tape_segment_kernel<JAC, 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);
+          else hipLaunchKernelGGL((tape_segment_kernel<JAC, 1>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);
           hipLaunchKernelGGL(tape_total_kernel, dim3((unsigned)((a.n_data + 255) / 256)), dim3(256), 0, st, sg.ftot,
                              sg.n_chunks, a.tape_ldn, a.n_data, a.ymean, a.tape_jt + (int64_t)a.n_param * a.tape_ldn,
                              a.wdiag, a.in_block, JAC ? nullptr : out_w, JAC ? nullptr : out_raw);

@@ -18,7 +18,7 @@ def amd():
     return lsqfit_amd
 
 
-@pytest.mark.parametrize('N,P,block', [(1000, 64, 0), (4096, 1024, 256), (777, 38, 111)])
+@pytest.mark.parametrize('N,P,block', [(1000, 64, 0), (4096, 1024, 256), (777, 38, 111), (16500, 64, 0)])   # (the last: two rows per lane)
 def test_tape_jacobian_equals_analytic_kernel(amd, N, P, block):
     from lsqfit_amd import models, synth
     d = synth.make_cosmix(N=N, P=P, seed=5, block=block, prior_corr=False)
@@ -36,7 +36,8 @@ def test_tape_jacobian_equals_analytic_kernel(amd, N, P, block):
     assert pt.chi2(p) == pytest.approx(pa.chi2(p), rel=1e-12)
     fa = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], problem=pa)
     ft = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=tape, prior=d['prior'], problem=pt)
-    assert ft.nit == fa.nit and gu.relmax(ft.pmean, fa.pmean) < 1e-9 and gu.relmax(ft.cov, fa.cov) < 1e-8
+    # (39 iterations at 16500 rows: rounding differences of 1e-11 in J reach 1.4e-8 in the covariance)
+    assert ft.nit == fa.nit and gu.relmax(ft.pmean, fa.pmean) < 1e-9 and gu.relmax(ft.cov, fa.cov) < (1e-8 if N < 16384 else 1e-7)
     pa.close()
     pt.close()
 
@@ -101,8 +102,8 @@ print('RESULT' + json.dumps(out))
 def test_segmented_tape_kernel_matches_the_whole_tape_and_forward_mode_kernels(tmp_path):
     """The kernel that differentiates a root-level sum term by term (parameters stored when each is read once,
     accumulated atomically otherwise; chunks of terms on different waves) against the whole-tape reverse kernel
-    (LSQAMD_TAPE=w) and the forward-mode kernel (LSQAMD_TAPE=f) on the same tapes.  A process each: the knob
-    is read once."""
+    (LSQAMD_TAPE=w), the forward-mode kernel (LSQAMD_TAPE=f) and the two-rows-per-lane variant of itself
+    (LSQAMD_TAPE_ROWS=2; 700 rows: a ragged last group) on the same tapes.  A process each: the knobs are read once."""
     import json
     import os
     import subprocess
@@ -111,10 +112,13 @@ def test_segmented_tape_kernel_matches_the_whole_tape_and_forward_mode_kernels(t
     script = tmp_path / 'seg.py'
     script.write_text(_SEG_SCRIPT % dict(root=root))
     res = {}
-    for knob in ('', 'w', 'f'):
+    for knob in ('', 'w', 'f', 'rows2'):
         env = dict(os.environ)
         env.pop('LSQAMD_TAPE', None)
-        if knob:
+        env.pop('LSQAMD_TAPE_ROWS', None)
+        if knob == 'rows2':
+            env['LSQAMD_TAPE_ROWS'] = '2'        # two data rows per lane (the default from 16384 rows on)
+        elif knob:
             env['LSQAMD_TAPE'] = knob
         out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
@@ -125,7 +129,7 @@ def test_segmented_tape_kernel_matches_the_whole_tape_and_forward_mode_kernels(t
         assert np.all(np.isfinite(J))
         if name == 'unused':
             assert np.all(J[:, 4] == 0.0)
-        for other in ('w', 'f'):
+        for other in ('w', 'f', 'rows2'):
             Jo = np.array(res[other][name]['J'])
             scale = np.max(np.abs(Jo), axis=0) + 1e-300
             assert np.max(np.abs(J - Jo) / scale) < 1e-13, (name, other)
