@@ -706,9 +706,12 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           TapeSeg sg;
           sg.r = r; sg.seg = a.tape_seg; sg.n_seg = a.tape_n_seg;
           sg.depth = a.tape_seg_depth; sg.slots = a.tape_seg_slots > 0 ? a.tape_seg_slots : 1;
-          // two rows per lane once there are row groups enough to fill the chip either way (developer knob: LSQAMD_TAPE_ROWS)
+          // two rows per lane once there are row groups enough to fill the chip either way (developer knob: LSQAMD_TAPE_ROWS);
           static const int rows_knob = [] { const char *e = getenv("LSQAMD_TAPE_ROWS"); return e ? atoi(e) : 0; }();
-          const int R = rows_knob == 1 || rows_knob == 2 ? rows_knob : (a.n_data >= 16384 ? 2 : 1);   // (four: 0.76-0.80 against 0.74 ms, fewer waves and spills)
+          // two only if the halved row groups times the chunks the tape admits still give every SIMD its three waves
+          // (four rows: 0.76-0.80 against 0.74 ms, fewer waves and spills)
+          const int64_t units2 = ((a.n_data + 127) / 128) * ((sg.n_seg + 7) / 8);
+          const int R = rows_knob == 1 || rows_knob == 2 ? rows_knob : (a.n_data >= 16384 && units2 >= 12 * 256 ? 2 : 1);
           const int64_t groups = (a.n_data + 64 * R - 1) / (64 * R);
           sg.r.n_groups = groups;
           // chunks of segments: enough (row group, chunk) units for ~24 waves per CU (two rounds of the three per

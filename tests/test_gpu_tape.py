@@ -18,7 +18,7 @@ def amd():
     return lsqfit_amd
 
 
-@pytest.mark.parametrize('N,P,block', [(1000, 64, 0), (4096, 1024, 256), (777, 38, 111), (16500, 64, 0)])   # (the last: two rows per lane)
+@pytest.mark.parametrize('N,P,block', [(1000, 64, 0), (4096, 1024, 256), (777, 38, 111), (16500, 512, 0)])   # (the last: two rows per lane)
 def test_tape_jacobian_equals_analytic_kernel(amd, N, P, block):
     from lsqfit_amd import models, synth
     d = synth.make_cosmix(N=N, P=P, seed=5, block=block, prior_corr=False)
