@@ -55,6 +55,54 @@ __global__ __launch_bounds__(256) void colsum_dot_stage1(const double *J, int64_
   if (two) partial[(int64_t)blockIdx.y * ncols + j + 1] = a1;
 }
 
+// The same for a NARROW matrix (ncols <= 256: few parameters, many rows): with one thread per column pair a
+// workgroup would have 33 of its 256 threads at work on 65 columns, each walking its rows alone (123 us for
+// 65536 x 65).  Here CW column pairs x 256 / CW rows per sweep; the row lanes meet in LDS in a fixed order.
+template <int CW>
+__global__ __launch_bounds__(256) void colsum_dot_narrow(const double *J, int64_t nrows, int64_t ld,
+                                                         int64_t ncols, const double *rv, int64_t rs,
+                                                         int64_t rows_per_chunk, double *partial) {
+  constexpr int CG = 256 / CW;
+  __shared__ double sh[CG][2 * CW + 2];
+  const int tx = threadIdx.x % CW, ty = threadIdx.x / CW;
+  const int64_t j = 2 * tx;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > nrows) r1 = nrows;
+  const bool one = j < ncols, two = j + 1 < ncols;
+  double a0 = 0.0, a1 = 0.0;
+  if (one) {
+    if ((ld & 1) == 0 && two) {
+#pragma unroll 4
+      for (int64_t i = r0 + ty; i < r1; i += CG) {
+        const double ri = rv[i * rs];
+        const double2 v = *reinterpret_cast<const double2 *>(J + i * ld + j);
+        a0 += v.x * ri;
+        a1 += v.y * ri;
+      }
+    } else {
+      for (int64_t i = r0 + ty; i < r1; i += CG) {
+        const double ri = rv[i * rs];
+        a0 += J[i * ld + j] * ri;
+        if (two) a1 += J[i * ld + j + 1] * ri;
+      }
+    }
+  }
+  sh[ty][2 * tx] = a0;
+  sh[ty][2 * tx + 1] = a1;
+  __syncthreads();
+  if (ty == 0 && one) {
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int q = 0; q < CG; ++q) {   // fixed order: deterministic
+      t0 += sh[q][2 * tx];
+      t1 += sh[q][2 * tx + 1];
+    }
+    partial[(int64_t)blockIdx.x * ncols + j] = t0;
+    if (two) partial[(int64_t)blockIdx.x * ncols + j + 1] = t1;
+  }
+}
+
 hipError_t launch_colsum_reduce(hipStream_t st, const double *partial, int64_t nchunks, int64_t ncols,
                                 double *out);
 
@@ -67,7 +115,14 @@ hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int
   if (nchunks > nrows) nchunks = nrows > 0 ? nrows : 1;
   const int64_t rpc = nrows > 0 ? (nrows + nchunks - 1) / nchunks : 1;
   nchunks = nrows > 0 ? (nrows + rpc - 1) / rpc : 0;
-  if (nchunks > 0) {
+  if (nchunks > 0 && ncols <= 256 && nrows >= 4096) {
+    const int64_t cp = (ncols + 1) / 2;
+    const dim3 grid((unsigned)nchunks);
+    if (cp <= 16) hipLaunchKernelGGL(colsum_dot_narrow<16>, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc, partial);
+    else if (cp <= 32) hipLaunchKernelGGL(colsum_dot_narrow<32>, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc, partial);
+    else if (cp <= 64) hipLaunchKernelGGL(colsum_dot_narrow<64>, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc, partial);
+    else hipLaunchKernelGGL(colsum_dot_narrow<128>, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc, partial);
+  } else if (nchunks > 0) {
     dim3 grid((unsigned)((ncols + 511) / 512), (unsigned)nchunks);
     hipLaunchKernelGGL(colsum_dot_stage1, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc,
                        partial);

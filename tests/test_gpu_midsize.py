@@ -23,7 +23,9 @@ CASES = [dict(N=1024, P=256, block=0, prior_corr=False),
          dict(N=1536, P=384, block=256, prior_corr=True),
          dict(N=768, P=640, block=128, prior_corr=True),
          dict(N=1500, P=300, block=100, prior_corr=False),       # nothing tile-aligned
-         dict(N=1024, P=256, block=512, prior_corr=False)]       # two large blocks: paired tile rows, 32-term tiles
+         dict(N=1024, P=256, block=512, prior_corr=False),       # two large blocks: paired tile rows, 32-term tiles
+         dict(N=40000, P=24, block=0, prior_corr=False),         # many rows, few parameters: 156 K-chunks, narrow J^T f
+         dict(N=33000, P=128, block=100, prior_corr=True)]       # the same with one aligned tile and small blocks
 
 
 @pytest.mark.parametrize('shape', CASES, ids=lambda s: 'N%d_P%d_B%d' % (s['N'], s['P'], s['block']))
