@@ -113,7 +113,11 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->ncols_aug = (P % 128 == 0) ? P + 128 : P + 1;
   f->npk = packed_doubles(P);
   f->splits = choose_splits(N, P);
+  // row chunks of the two-stage J^T f: 256, more for many rows and few parameters (a chunk of 2048 rows is a
+  // serial walk per thread: (524288, 64) took 0.25 ms for 268 MB) while the partial sums stay within 8 MB
   f->npartial = 256;
+  while (f->npartial < 4096 && 2 * f->npartial <= N / 64 && 2 * f->npartial * (P + 1) * 8 <= (int64_t)(8 << 20))
+    f->npartial *= 2;
   Carver cv(ws, cap, dry);
   f->x = cv.take<double>(N * (c.n_x > 0 ? c.n_x : 1));
   f->ymean = cv.take<double>(N);
@@ -432,8 +436,10 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     g.upper_only = 1;
     g.splits = f->splits;
     g.split_stride = P * f->ldm;
-    g.work_map = f->syrk_map;
-    g.n_work = f->syrk_nwork;
+    if (P > 64) {   // (one tile: nothing to order, and the 64 x 64 kernel takes no work list)
+      g.work_map = f->syrk_map;
+      g.n_work = f->syrk_nwork;
+    }
     if (f->N > 0) {
       HIPCHK(f, launch_gemm_tn(f->st, g));
     } else {

@@ -898,7 +898,10 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
 #undef LSQAMD_PANEL
     return hipGetLastError();
   }
-  if (!a.work_map && a.K <= 512 && nblk128 <= small_max && !a.force_generic && small_ok) {
+  // (... or ONE 64 x 64 tile whatever K is: J^T J for up to 64 parameters, where a 128 x 128 tile is three
+  // quarters padding -- 0.33 -> 0.1 ms at N = 524288)
+  const bool one_small_tile = a.M <= TS && a.N <= TS;
+  if (!a.work_map && (a.K <= 512 || one_small_tile) && nblk128 <= small_max && !a.force_generic && small_ok) {
     const int64_t tm64 = (a.M + TS - 1) / TS, tn64 = (a.N + TS - 1) / TS;
     g.tiles_n = (int32_t)tn64;
     dim3 grid64((unsigned)(tm64 * tn64), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));

@@ -38,13 +38,15 @@ __global__ __launch_bounds__(256) void colsum_dot_stage1(const double *J, int64_
   const bool two = j + 1 < ncols;
   double a0 = 0.0, a1 = 0.0;
   if ((ld & 1) == 0 && two) {
-    for (int64_t i = r0; i < r1; ++i) {
+#pragma unroll 8   // eight rows requested before the first is used (the sums stay in row order): 2048 rows per
+    for (int64_t i = r0; i < r1; ++i) {   // thread at N = 524288 were 2048 round trips to memory, one at a time
       const double ri = rv[i * rs];
       const double2 v = *reinterpret_cast<const double2 *>(J + i * ld + j);
       a0 += v.x * ri;
       a1 += v.y * ri;
     }
   } else {
+#pragma unroll 4
     for (int64_t i = r0; i < r1; ++i) {
       const double ri = rv[i * rs];
       a0 += J[i * ld + j] * ri;
@@ -140,8 +142,10 @@ __global__ __launch_bounds__(256) void colsum_reduce_kernel(const double *partia
   const int c = threadIdx.x & 15, g = threadIdx.x >> 4;
   const int64_t j = (int64_t)blockIdx.x * 16 + c;
   double a = 0.0;
-  if (j < ncols)
+  if (j < ncols) {
+#pragma unroll 8   // (4096 chunks of a 524288-row fit: 256 values per thread, requested eight at a time, added in order)
     for (int64_t k = g; k < nchunks; k += 16) a += partial[k * ncols + j];
+  }
   sh[g][c] = a;
   __syncthreads();
   if (g == 0 && j < ncols) {

@@ -21,11 +21,10 @@ def _free_port():
 
 def _worker(rank, world, port, outdir):
     sys.path.insert(0, ROOT)
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
     import torch
     import torch.distributed as dist
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no port to lose a race for
+    dist.init_process_group('gloo', init_method='file://' + os.path.join(outdir, 'rendezvous'), rank=rank, world_size=world)
     from lsqfit_amd import synth
     from lsqfit_amd.dist import WorkspaceView, make_reduce_hook, shard_rows
     from lsqfit_amd.whiten import Whitening

@@ -43,7 +43,7 @@ def test_single_process_line():
 def test_two_rank_launch_line():
     env = dict(os.environ, LSQAMD_DIST_BACKEND='gloo')
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                        '--master-addr', '127.0.0.1', '--master-port', '29533', 'bench.py', '--gpus', '2', '--steps',
+                        '--standalone', '--local-addr', '127.0.0.1', 'bench.py', '--gpus', '2', '--steps',
                         '3', '--warmup', '1', '--ndata', '4096', '--nparam', '256'],
                        cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]

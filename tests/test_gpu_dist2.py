@@ -46,12 +46,11 @@ def _fit_kw(case, P):
 
 def _worker(rank, world, port, outdir, case):
     sys.path.insert(0, ROOT)
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(0)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    # rendezvous through a file in the test's own directory: no port to lose a race for
+    dist.init_process_group('gloo', init_method='file://' + os.path.join(outdir, 'rendezvous'), rank=rank, world_size=world)
     import lsqfit_amd as amd
     from lsqfit_amd.dist import sharded_problem
     d = _problem(case)

@@ -260,21 +260,16 @@ def test_reduce_hook_on_device_single_rank(amd):
     """The all-reduce hook path (RCCL through torch.distributed on a float64 view of the
     handle's workspace) with a one-rank group: identical results to the hook-free fit."""
     import os
-    import socket
     import torch.distributed as dist
     from lsqfit_amd import synth
     from lsqfit_amd.dist import cuda_sync, make_reduce_hook
     d = synth.make_cosmix(N=512, P=32, seed=41, block=64, prior_corr=True)
     ref = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
-    os.environ['MASTER_ADDR'] = '127.0.0.1'
-    os.environ['MASTER_PORT'] = str(port)
     created = not dist.is_initialized()
-    if created:
-        dist.init_process_group('nccl', rank=0, world_size=1)
+    if created:   # rendezvous through a file: no port to lose a race for (EADDRINUSE has been seen here)
+        import tempfile
+        rdv = os.path.join(tempfile.mkdtemp(prefix='lsqamd_rdv_'), 'store')
+        dist.init_process_group('nccl', init_method='file://' + rdv, rank=0, world_size=1)
     try:
         wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
         pr = amd.DeviceProblem(d['model'], d['x'], wh)
