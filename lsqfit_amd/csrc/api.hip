@@ -97,6 +97,13 @@ int32_t choose_splits(int64_t N, int64_t P) {
   if (cap > 256) cap = 256;
   if (cap < 16) cap = 16;
   if (s > cap) s = cap;
+  // ... and for MANY rows at a few dozen tiles 16 chunks are one round of workgroups and a bit ((131072, 1024):
+  // 576 workgroups, 2.81 ms; 32 chunks 2.26 ms): chunks of 4096 rows up to 32 of them, while the slabs stay
+  // below a quarter of the Jacobian's own size
+  int64_t more = N / 4096 < 32 ? N / 4096 : 32;
+  const int64_t room = (N * P / 4) / (P * ldm);
+  if (more > room) more = room;
+  if (tiles >= 36 && s < more) s = more;
   if (s < 1) s = 1;
   return (int32_t)s;
 }
