@@ -42,8 +42,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c4', choices=sorted(WORKLOADS))
     ap.add_argument('--ndata', type=int, default=0, help='override N_data (debug)')
     ap.add_argument('--nparam', type=int, default=0, help='override N_param (debug)')
