@@ -510,13 +510,15 @@ int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const
       if (diag_host) dd = f->diag_dev;
       else frozen = f->diag_dev;
     }
-    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M, frozen, mu_dev));
-    HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev));
+    // (the pivot-failure word is cleared by the kernel that builds the matrix, the hand-off granules of the
+    // back substitution by the one that copies its right-hand side: two memsets fewer per trial)
+    HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M, frozen, mu_dev, f->info_dev));
+    HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev, true));
   }
   {
     Scope sc(f, LSQAMD_T_SOLVE);
-    HIPCHK(f, launch_copy_strided(f->st, f->M + P, f->ldm, f->yv, 1, P, 1));
-    HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv, f->yv + 2 * P, f->info_dev));
+    HIPCHK(f, launch_copy_column_zero(f->st, f->M + P, f->ldm, f->yv, P, f->yv + 2 * P, backsolve_scratch_bytes(P)));
+    HIPCHK(f, backsolve_upper(f->st, f->M, P, f->ldm, f->chol_work, f->yv, f->yv + 2 * P, f->info_dev, true));
     if (fetch) {
       HIPCHK(f, hipMemcpyAsync(f->pin_v, f->yv + P, sizeof(double) * P, hipMemcpyDeviceToHost, f->st));
       HIPCHK(f, hipMemcpyAsync(f->pin_s + 4, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));

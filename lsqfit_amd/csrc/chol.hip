@@ -388,8 +388,8 @@ static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, d
 
 hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
                                double *work, int32_t *dev_info, int32_t batch, int64_t strideA,
-                               int64_t strideW, const int32_t *active) {
-  hipError_t e = hipMemsetAsync(dev_info, 0, sizeof(int32_t) * (size_t)batch, st);
+                               int64_t strideW, const int32_t *active, bool info_zeroed) {
+  hipError_t e = info_zeroed ? hipSuccess : hipMemsetAsync(dev_info, 0, sizeof(int32_t) * (size_t)batch, st);
   if (e != hipSuccess) return e;
   // single matrix, everything tile-aligned: the trailing update of step k carries the diagonal
   // block of step k + 1 along (launch_trail_potf2) while there are enough tiles to hide it behind
@@ -445,8 +445,8 @@ hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda
 }
 
 hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
-                       double *work, int32_t *dev_info) {
-  return potrf_upper_batched(st, A, n, lda, n_cols, work, dev_info, 1, 0, 0, nullptr);
+                       double *work, int32_t *dev_info, bool info_zeroed) {
+  return potrf_upper_batched(st, A, n, lda, n_cols, work, dev_info, 1, 0, 0, nullptr, info_zeroed);
 }
 
 // ---- back substitution U v = y ------------------------------------------------------
@@ -752,7 +752,7 @@ size_t backsolve_scratch_bytes(int64_t n) { return (size_t)n * 16 + 64; }
 hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                    const double *work, double *y_inout, int32_t batch, int64_t strideA,
                                    int64_t strideW, int64_t strideY, const int32_t *active, void *scratch,
-                                   int32_t *info_dev) {
+                                   int32_t *info_dev, bool scratch_zeroed) {
   // y_inout (per batch entry): [0,n) = y (destroyed), [n, 2n) = v on return
   double *y = y_inout, *v = y_inout + n;
   const int64_t nblk = (n + NB - 1) / NB;
@@ -761,7 +761,7 @@ hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, i
   if (chained && scratch && batch == 1 && !active && n % NB == 0 && nblk >= 2 && nblk <= 192 && info_dev &&
       !(lda & 1) && !(reinterpret_cast<uintptr_t>(A) & 15) && !(reinterpret_cast<uintptr_t>(work) & 15)) {
     // granules for n doubles, then the abort word
-    hipError_t e = hipMemsetAsync(scratch, 0, backsolve_scratch_bytes(n), st);
+    hipError_t e = scratch_zeroed ? hipSuccess : hipMemsetAsync(scratch, 0, backsolve_scratch_bytes(n), st);
     if (e != hipSuccess) return e;
     unsigned long long *gran = static_cast<unsigned long long *>(scratch);
     unsigned int *abortw = reinterpret_cast<unsigned int *>(gran + 2 * n);
@@ -789,8 +789,8 @@ hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, i
 }
 
 hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
-                           const double *work, double *y_inout, void *scratch, int32_t *info_dev) {
-  return backsolve_upper_batched(st, A, n, lda, work, y_inout, 1, 0, 0, 0, nullptr, scratch, info_dev);
+                           const double *work, double *y_inout, void *scratch, int32_t *info_dev, bool scratch_zeroed) {
+  return backsolve_upper_batched(st, A, n, lda, work, y_inout, 1, 0, 0, 0, nullptr, scratch, info_dev, scratch_zeroed);
 }
 
 // ---- W = U^-T (lower triangular, row-major) -------------------------------------------

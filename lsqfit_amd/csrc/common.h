@@ -65,8 +65,9 @@ size_t potrf_work_bytes(int64_t n);
 // In-place upper Cholesky A = U^T U of the leading n x n block of A[n x n_cols]
 // (row-major, lda); columns n..n_cols-1 are carried along (they become U^-T * A[:, n:]).
 // *dev_info (device int32) is set to (first failing pivot + 1) if not positive definite.
+// info_zeroed: *dev_info is 0 already (the caller's previous kernel did it): no 4-byte memset
 hipError_t potrf_upper(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
-                       double *work, int32_t *dev_info);
+                       double *work, int32_t *dev_info, bool info_zeroed = false);
 // batched: matrix b at A + b*strideA, block inverses at work + b*strideW, info[b];
 // trailing update C -= P^T P (upper tiles; P = 128 x rest panel, C = mrest x rest, both multiples of
 // 128, 16-byte aligned rows) fused with the diagonal block of the next step (= tile (0, 0) of C)
@@ -82,19 +83,21 @@ hipError_t launch_potf2_mfma(hipStream_t st, double *A, int64_t lda, int nb, dou
 // entries with active[b] == 0 (if given) are skipped
 hipError_t potrf_upper_batched(hipStream_t st, double *A, int64_t n, int64_t lda, int64_t n_cols,
                                double *work, int32_t *dev_info, int32_t batch, int64_t strideA,
-                               int64_t strideW, const int32_t *active);
+                               int64_t strideW, const int32_t *active, bool info_zeroed = false);
 hipError_t backsolve_upper_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                    const double *work, double *y_inout, int32_t batch, int64_t strideA,
                                    int64_t strideW, int64_t strideY, const int32_t *active,
-                                   void *scratch = nullptr, int32_t *info_dev = nullptr);
+                                   void *scratch = nullptr, int32_t *info_dev = nullptr, bool scratch_zeroed = false);
 hipError_t trtri_upper_to_lower_T_batched(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                           const double *work, double *Wl, int64_t ldw, int32_t batch,
                                           int64_t strideA, int64_t strideW, int64_t strideWl);
 // v = U^-1 y (y = column `ycol` of A rows 0..n-1), using the diagonal-block inverses in work
 // scratch (backsolve_scratch_bytes(n), with info_dev): the one-launch chain of workgroups (n a multiple of 128)
 size_t backsolve_scratch_bytes(int64_t n);
+// scratch_zeroed: the scratch is all zero already (launch_copy_column_zero): no memset before the chain
 hipError_t backsolve_upper(hipStream_t st, const double *A, int64_t n, int64_t lda,
-                           const double *work, double *y_inout, void *scratch = nullptr, int32_t *info_dev = nullptr);
+                           const double *work, double *y_inout, void *scratch = nullptr, int32_t *info_dev = nullptr,
+                           bool scratch_zeroed = false);
 // Wl (n x n, ld) = U^-T (lower triangular), given factored A and the block inverses.
 hipError_t trtri_upper_to_lower_T(hipStream_t st, const double *A, int64_t n, int64_t lda,
                                   const double *work, double *Wl, int64_t ldw);
@@ -180,7 +183,9 @@ hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int3
 // M (P x ld, upper tiles) = A + mu diag(d^2); M[:, P] = g
 hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
                                const double *diag, const double *g, double *Mout,
-                               const double *frozen = nullptr, const double *mu_dev = nullptr);
+                               const double *frozen = nullptr, const double *mu_dev = nullptr, int32_t *info_zero = nullptr);
+hipError_t launch_copy_column_zero(hipStream_t st, const double *src, int64_t ld, double *dst, int64_t n,
+                                   void *zbuf, size_t zbytes);
 hipError_t launch_packed_diag(hipStream_t st, const double *apk, int64_t P, double *out);
 hipError_t launch_unpack_sym(hipStream_t st, const double *apk, int64_t P, double *out, int64_t ld);
 hipError_t launch_symmetrize_from_upper(hipStream_t st, double *A, int64_t P, int64_t ld);

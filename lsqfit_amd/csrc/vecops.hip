@@ -421,8 +421,9 @@ hipError_t launch_param_rows(hipStream_t st, const int32_t *row_param, int64_t N
 __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, int64_t P, int64_t T,
                                                            int64_t ld, double mu_arg, const double *diag,
                                                            const double *g, double *M, const double *frozen,
-                                                           const double *mu_dev) {
+                                                           const double *mu_dev, int32_t *info_zero) {
   const double mu = mu_dev ? *mu_dev : mu_arg;   // the device-resident LM state (a captured step must not bake mu in)
+  if (info_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *info_zero = 0;   // (saves the factorisation its 4-byte memset)
   int64_t t = blockIdx.x, tm = 0;
   while (t >= T - tm) { t -= T - tm; ++tm; }
   const int64_t tn = tm + t;
@@ -446,10 +447,10 @@ __global__ __launch_bounds__(256) void build_damped_kernel(const double *apk, in
 
 hipError_t launch_build_damped(hipStream_t st, const double *apk, int64_t P, int64_t ld, double mu,
                                const double *diag, const double *g, double *Mout, const double *frozen,
-                               const double *mu_dev) {
+                               const double *mu_dev, int32_t *info_zero) {
   const int64_t T = (P + TB - 1) / TB;
   dim3 grid((unsigned)(T * (T + 1) / 2), 16);
-  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout, frozen, mu_dev);
+  hipLaunchKernelGGL(build_damped_kernel, grid, dim3(256), 0, st, apk, P, T, ld, mu, diag, g, Mout, frozen, mu_dev, info_zero);
   return hipGetLastError();
 }
 
@@ -506,6 +507,22 @@ __global__ __launch_bounds__(256) void copy_strided_kernel(const double *src, in
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= cols) return;
   for (int64_t i = blockIdx.y; i < rows; i += gridDim.y) dst[i * ldd + j] = src[i * lds_ + j];
+}
+
+// dst[i] = src[i * ld] (a column) and zbuf[0 .. zwords) = 0 in one launch: the right-hand side of the back
+// substitution and the zeroed hand-off granules its chain needs, instead of a copy and a memset
+__global__ __launch_bounds__(256) void copy_column_zero_kernel(const double *src, int64_t ld, double *dst, int64_t n,
+                                                               unsigned long long *zbuf, int64_t zwords) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = src[i * ld];
+  for (int64_t k = i; k < zwords; k += (int64_t)gridDim.x * 256) zbuf[k] = 0ull;
+}
+
+hipError_t launch_copy_column_zero(hipStream_t st, const double *src, int64_t ld, double *dst, int64_t n,
+                                   void *zbuf, size_t zbytes) {
+  hipLaunchKernelGGL(copy_column_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, ld, dst, n,
+                     static_cast<unsigned long long *>(zbuf), (int64_t)(zbytes / 8));
+  return hipGetLastError();
 }
 
 hipError_t launch_copy_strided(hipStream_t st, const double *src, int64_t lds_, double *dst,
