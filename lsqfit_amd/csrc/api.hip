@@ -284,8 +284,19 @@ int residual_vector_launch(lsqamd_fit *f, const double *p) {
 
 // whitened residual at device parameters p -> f->r; chi2 (summed over ranks) -> f->red_scalar[0].
 // Launches only: nothing is waited for.
-int eval_residual_launch(lsqamd_fit *f, const double *p) {
+// decide: a single rank's trial -- the sum of squares' second stage, the prior's share and the LM decision in
+// one launch (lm_trial_tail_kernel); with ranks to sum over the scalar is exchanged first and the caller decides
+int eval_residual_launch(lsqamd_fit *f, const double *p, bool decide = false) {
   f->r_fresh = false;
+  if (decide) {
+    Scope sc(f, LSQAMD_T_RESIDUAL);
+    const int rc = residual_vector_launch(f, p);
+    if (rc) return rc;
+    HIPCHK(f, launch_lm_trial_tail(f->st, f->r, f->N, f->partial, f->P, f->prior_prec, f->cfg.prior_dense,
+                                   f->prior_mean, p, f->tvec, f->cfg.has_prior && f->adds_prior, f->red_scalar,
+                                   f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
+    return 0;
+  }
   {
     Scope sc(f, LSQAMD_T_RESIDUAL);
     const int rc = residual_vector_launch(f, p);
@@ -469,7 +480,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   }
   rc = do_reduce(f, f->redbuf, f->npk + P + 1);
   if (rc) return rc;
-  HIPCHK(f, launch_packed_diag(f->st, f->redbuf, P, f->diag_dev));
+  if (mirror) HIPCHK(f, launch_packed_diag(f->st, f->redbuf, P, f->diag_dev));   // (else: lm_accept_tail_kernel, the caller's next launch)
   f->have_cov = false;
   f->have_dense_A = false;
   if (!mirror) {   // the caller keeps g, the column norms and chi2 on the device (iterate_device)
@@ -937,9 +948,11 @@ static int enqueue_trial(lsqamd_fit *f) {
   int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false, f->lmd + LMS_MU);
   if (rc) return rc;
   HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
-  rc = eval_residual_launch(f, f->p_trial);
+  const bool alone = !f->comm && !f->reduce;
+  rc = eval_residual_launch(f, f->p_trial, alone);
   if (rc) return rc;
-  HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
+  if (!alone)
+    HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
   HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
   return 0;
 }
@@ -951,8 +964,8 @@ static int enqueue_accept(lsqamd_fit *f) {   // p_trial becomes the point; the c
   f->r_ptr = f->p_trial;
   int rc = eval_normal_dev(f, f->p_trial, false);
   if (rc) return rc;
-  HIPCHK(f, launch_scale_update(f->st, P, f->opt.scaler, 0, f->diag_dev, f->dscale));
-  HIPCHK(f, launch_lm_converge(f->st, P, f->p_trial, f->yv + P, gvec, f->opt.xtol, f->opt.gtol, f->lmd));
+  HIPCHK(f, launch_lm_accept_tail(f->st, f->redbuf, P, f->opt.scaler, f->diag_dev, f->dscale, f->p_trial, f->yv + P, gvec,
+                                  f->opt.xtol, f->opt.gtol, f->lmd));
   HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
   return 0;
 }

@@ -220,6 +220,13 @@ enum { LMS_CHI2 = 0, LMS_MU, LMS_NU, LMS_DELTA, LMS_VG, LMS_DV2, LMS_VFINITE, LM
        LMS_SOLVED, LMS_INFO, LMS_COUNT = 16 };
 hipError_t launch_lm_trial(hipStream_t st, int64_t P, const double *x, const double *v, const double *g,
                            const double *d, double *xt, double *state);
+hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, double *partial, int64_t P,
+                                const double *prec, int32_t dense, const double *pmean, const double *p, double *tvec,
+                                bool with_prior, double *chi2_out, const int32_t *chol_info, double factor_up,
+                                double factor_down, double *lmd);
+hipError_t launch_lm_accept_tail(hipStream_t st, const double *apk, int64_t P, int scaler, double *coln2,
+                                 double *dscale, const double *x, const double *v, const double *gvec, double xtol,
+                                 double gtol, double *lmd);
 hipError_t launch_lm_decide(hipStream_t st, const double *chi2_trial, const int32_t *chol_info, double factor_up,
                             double factor_down, double *state);
 hipError_t launch_lm_converge(hipStream_t st, int64_t P, const double *x, const double *v, const double *gvec,

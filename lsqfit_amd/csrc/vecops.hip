@@ -816,6 +816,119 @@ __global__ void lm_decide_kernel(const double *chi2_trial, const int32_t *chol_i
   st[LMS_SOLVED] = solved ? 1.0 : 0.0;
 }
 
+// The tail of a trial in ONE launch (single rank: no exchange in between): the second stage of |f_trial|^2,
+// the prior's share of chi2 and the decision -- the same sums in the same order as sum_stage2,
+// prior_chi2_kernel and lm_decide_kernel, which the multi-rank path keeps (it all-reduces the scalar first).
+__global__ __launch_bounds__(256) void lm_trial_tail_kernel(const double *partial, int n_partial, int64_t P,
+                                                            const double *pmean, const double *p, const double *tvec,
+                                                            double *chi2_out, const int32_t *chol_info,
+                                                            double factor_up, double factor_down, double *st) {
+  __shared__ double part[4];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n_partial; i += 256) a += partial[i];
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  double ct = part[0] + part[1] + part[2] + part[3];
+  __syncthreads();
+  if (tvec) {
+    double b = 0.0;
+    for (int64_t j = threadIdx.x; j < P; j += 256) b += (p[j] - pmean[j]) * tvec[j];
+    b = wsum(b);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = b;
+    __syncthreads();
+    ct += part[0] + part[1] + part[2] + part[3];
+  }
+  if (threadIdx.x != 0) return;
+  chi2_out[0] = ct;
+  const double chi2 = st[LMS_CHI2], mu = st[LMS_MU];
+  const bool solved = chol_info[0] == 0 && st[LMS_VFINITE] != 0.0;
+  double rho = -1.0;
+  if (solved) {
+    const double normf = sqrt(chi2), normf_t = sqrt(ct);
+    if (normf_t < normf) {   // NaN-safe: anything else rejects
+      const double u = normf_t / normf;
+      const double pred = (st[LMS_VG] + mu * st[LMS_DV2]) / chi2;
+      rho = pred > 0.0 ? (1.0 - u * u) / pred : -1.0;
+    }
+  }
+  if (rho > 0.75) st[LMS_DELTA] *= factor_up;
+  else if (rho < 0.25) st[LMS_DELTA] /= factor_down;
+  if (rho > 0.0) {
+    const double b = 2.0 * rho - 1.0;
+    st[LMS_MU] = mu * fmax(0.333333333333333, 1.0 - b * b * b);
+    st[LMS_NU] = 2.0;
+  } else {
+    st[LMS_MU] = mu * st[LMS_NU];
+    st[LMS_NU] *= 2.0;
+  }
+  st[LMS_RHO] = rho;
+  st[LMS_CHI2_TRIAL] = ct;
+  st[LMS_ACCEPT] = rho > 0.0 ? 1.0 : 0.0;
+  st[LMS_SOLVED] = solved ? 1.0 : 0.0;
+}
+
+// |r|^2 first stage + (prior: t = Lambda (p - pbar)) + the tail above
+hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, double *partial, int64_t P,
+                                const double *prec, int32_t dense, const double *pmean, const double *p, double *tvec,
+                                bool with_prior, double *chi2_out, const int32_t *chol_info, double factor_up,
+                                double factor_down, double *lmd) {
+  int blocks = (int)((n + 1023) / 1024);
+  if (blocks > 1024) blocks = 1024;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, st, r, n, partial);
+  if (with_prior)
+    hipLaunchKernelGGL(prior_vec_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, P, prec, dense, pmean, p, tvec);
+  hipLaunchKernelGGL(lm_trial_tail_kernel, dim3(1), dim3(256), 0, st, partial, blocks, P, pmean, p,
+                     with_prior ? tvec : nullptr, chi2_out, chol_info, factor_up, factor_down, lmd);
+  return hipGetLastError();
+}
+
+// The tail of an accepted step in ONE launch: diag(J^T J) out of the packed tiles, the update of the scaling D
+// and the convergence test (packed_diag_kernel + scale_update_kernel + lm_converge_kernel, element for element).
+__global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, int64_t P, int64_t T, int scaler,
+                                                             double *coln2, double *dscale, const double *x,
+                                                             const double *v, const double *gvec, double xtol,
+                                                             double gtol, double *st) {
+  __shared__ double sh[4];
+  double notx = 0.0, gn = 0.0;
+  for (int64_t j = threadIdx.x; j < P; j += 256) {
+    const int64_t tm = j / TB, r = j % TB;
+    const double c2 = apk[packed_tile_index(tm, tm, T) * TB * TB + r * TB + r];
+    coln2[j] = c2;
+    const double cn = sqrt(c2 > 0.0 ? c2 : 0.0);
+    double d;
+    if (scaler == LSQAMD_SCALE_LEVENBERG) d = dscale[j];
+    else if (scaler == LSQAMD_SCALE_MORE) d = fmax(dscale[j], cn);
+    else d = cn == 0.0 ? 1.0 : cn;
+    dscale[j] = d;
+    const double xj = x[j];
+    notx += (fabs(v[j]) < xtol * xtol + xtol * fabs(xj)) ? 0.0 : 1.0;
+    gn = fmax(gn, fabs(fmax(xj, 1.0) * gvec[j]));
+  }
+  notx = block_sum(notx, sh);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) gn = fmax(gn, __shfl_down(gn, o, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gn = fmax(fmax(sh[0], sh[1]), fmax(sh[2], sh[3]));
+    const double chi2 = gvec[P];
+    st[LMS_CHI2] = chi2;
+    st[LMS_INFO] = notx == 0.0 ? 1.0 : (gn <= gtol * fmax(0.5 * chi2, 1.0) ? 2.0 : 0.0);
+  }
+}
+
+hipError_t launch_lm_accept_tail(hipStream_t stream, const double *apk, int64_t P, int scaler, double *coln2,
+                                 double *dscale, const double *x, const double *v, const double *gvec, double xtol,
+                                 double gtol, double *st) {
+  const int64_t T = (P + TB - 1) / TB;
+  hipLaunchKernelGGL(lm_accept_tail_kernel, dim3(1), dim3(256), 0, stream, apk, P, T, scaler, coln2, dscale, x, v, gvec,
+                     xtol, gtol, st);
+  return hipGetLastError();
+}
+
 hipError_t launch_lm_decide(hipStream_t stream, const double *chi2_trial, const int32_t *chol_info, double factor_up,
                             double factor_down, double *st) {
   hipLaunchKernelGGL(lm_decide_kernel, dim3(1), dim3(1), 0, stream, chi2_trial, chol_info, factor_up, factor_down, st);
