@@ -156,7 +156,30 @@ def launch_ranks(args):
         port = sk.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd))
+    # a wall-clock limit on the children: a collective that never completes (a rank that died, a
+    # fabric problem) must end as a non-zero exit, never as a bench that waits forever.  The ranks run
+    # in a process group of their own so that the whole tree can be ended; this process never
+    # re-execs (it has not touched the GPU, but the children have).
+    import signal
+    limit = float(os.environ.get('LSQAMD_BENCH_TIMEOUT_S', '1500'))
+    child = subprocess.Popen(cmd, start_new_session=True)
+    try:
+        rc = child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write('bench.py: the %d ranks did not finish within %.0f s (LSQAMD_BENCH_TIMEOUT_S): ending them\n'
+                         % (args.gpus, limit))
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise SystemExit(124)
+    raise SystemExit(rc)
 
 
 def main():
@@ -172,6 +195,19 @@ def main():
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     import torch
     import torch.distributed as dist
+    if world > 1:
+        # launched by a launcher we do not control: every rank carries its own wall-clock limit, so a
+        # collective that never completes ends the run with a non-zero exit instead of hanging it
+        import threading
+        limit = float(os.environ.get('LSQAMD_BENCH_TIMEOUT_S', '1500'))
+
+        def give_up():
+            sys.stderr.write('bench.py: rank %d still running after %.0f s (LSQAMD_BENCH_TIMEOUT_S): exiting\n' % (rank, limit))
+            sys.stderr.flush()
+            os._exit(124)
+        wd = threading.Timer(limit, give_up)
+        wd.daemon = True
+        wd.start()
     ndev = max(1, torch.cuda.device_count())
     dev_index = local_rank % ndev            # one process per GPU on a real node; wraps on smaller boxes
     torch.cuda.set_device(dev_index)
@@ -217,14 +253,14 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
+            # the measured configuration is the collective INSIDE the library; a run that cannot set it
+            # up fails loudly (LSQAMD_COLLECTIVE=hook asks for the torch.distributed hook explicitly)
             if ok:
                 pr.close()
-            pr = sharded_problem(d['model'], d['x'], wh, rank, world, collective='hook')
-            note = note or 'another rank could not join the library communicator'
+            raise SystemExit('bench.py: rank %d: the library communicator (RCCL) could not be set up on every rank: %s'
+                             % (rank, note or 'another rank failed'))
     collective = {None: 'none (one rank)', 'rccl': 'RCCL reduce-scatter + all-gather inside the library, on the step\'s stream',
                   'hook': 'torch.distributed all_reduce through the C-ABI hook'}[pr.collective]
-    if note:
-        collective += ' (fallback: %s)' % note
     pr.set_options((1e-8, 1e-10, 1e-10), 1000)
     t_setup = time.perf_counter() - t0
     lib, h = pr.lib, pr.h
@@ -275,9 +311,18 @@ def main():
     pr.timing(False)
     s = _lib.Summary()
     lib.lsqamd_finish(h, C.byref(s))
+    reduce_ms = [tm['reduce'][0] / max(1, tm['reduce'][1])]
+    step_ms = [1e3 * elapsed / args.steps]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        # per-rank view of the exchange: average duration of the `reduce` phase (HIP events around the
+        # collective on the step's stream: includes waiting for the slowest rank) and the rank's own step time
+        mine = torch.tensor([reduce_ms[0], step_ms[0]], dtype=torch.float64, device='cuda')
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        reduce_ms = [float(t[0].item()) for t in every]
+        step_ms = [float(t[1].item()) for t in every]
         elapsed = float(tt.item())
 
     if rank == 0:
@@ -312,6 +357,7 @@ def main():
                        'setup_s': round(t_setup, 3), 'generate_s': round(t_generate, 3), 'chi2_dof_last': s.chi2 / max(1, wh.nchiv - P)},
             'phases_ms_per_call': {k: (v[0] / v[1] if v[1] else None) for k, v in tm.items()},
             'phases_calls': {k: v[1] for k, v in tm.items()},
+            'per_rank': {'reduce_ms_per_call': reduce_ms, 'ms_per_step': step_ms},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm_tn_f64_interior_kernel<false, true> (J^T J; the name in profiles/*kernel_stats*.csv)', 'achieved': ach,
                          'peak': PEAK_FP64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_FP64_MFMA_TFLOPS, 'traffic': traffic,

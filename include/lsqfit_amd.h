@@ -56,6 +56,9 @@ extern "C" {
 #define LSQAMD_EUNSUPPORTED (-6)
 #define LSQAMD_EREDUCE (-7)   /* the all-reduce hook reported failure    */
 #define LSQAMD_ECAPACITY (-8) /* caller's output buffer too small        */
+#define LSQAMD_EINACCURATE (-9) /* summary.cov_status only: the covariance was delivered, but the factorisation
+                                 * behind it missed its own accuracy test (solver = qr: Q not orthogonal to 1e-6
+                                 * after six passes) */
 
 /* Row models f(x_i; p) the kernels evaluate with forward-mode AD.  They take
  * the place of the user's Python fit function + gvar.valder derivative
@@ -163,7 +166,7 @@ typedef struct {
   int32_t njev;               /* Jacobian evaluations */
   int32_t ntrial;             /* damped solves attempted */
   int32_t chol_fail;          /* factorizations that hit a non-positive pivot */
-  int32_t cov_status;         /* 0, or LSQAMD_ENOTPD: J^T J is not positive definite at the end point --
+  int32_t cov_status;         /* 0, LSQAMD_EINACCURATE, or LSQAMD_ENOTPD: J^T J is not positive definite at the end point --
                                * cov and logdet_jtj (NaN) are undefined (gsl_multifit_nlinear_covar has no
                                * such report: its QR-based inverse returns garbage silently) */
   int32_t reserved0;

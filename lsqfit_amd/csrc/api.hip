@@ -1281,6 +1281,7 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
 
 // covariance + logdet at the current point: factor A (mu = 0), invert
 int do_covariance(lsqamd_fit *f) {
+  f->cov_inaccurate = false;
   if (f->opt.solver == LSQAMD_SOLVER_QR) return do_covariance_qr(f);
   const int64_t P = f->P;
   Scope sc(f, LSQAMD_T_COVAR);
@@ -1416,6 +1417,7 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
     FAIL(f, LSQAMD_EINVAL, "set_x: expected %lld x %d", (long long)f->N, f->cfg.n_x);
   HIPCHK(f, hipMemcpyAsync(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
+  f->drop_step_graphs();   // captured steps bake xmax (and the path choices behind have_x) in by value
   f->xmax = 0.0;
   for (int64_t i = 0; i < n_rows * n_x; ++i) {
     const double ax = std::fabs(x[i]);
@@ -1730,7 +1732,7 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
   const int rc = do_covariance(f);
   if (f->timing) resolve_timers(f);
   fill_summary(f, out, 0, 0);
-  if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : 0;
+  if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : (rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : 0);
   return rc == LSQAMD_ENOTPD ? 0 : rc;
 }
 
@@ -1786,7 +1788,8 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   fill_summary(f, out, status, info);
   if (out) {
     out->t_run_ms = ms;
-    out->cov_status = rc;   // LSQAMD_ENOTPD: J^T J singular at the end point, cov / logdet undefined
+    // LSQAMD_ENOTPD: J^T J singular at the end point, cov / logdet undefined; LSQAMD_EINACCURATE: delivered, degraded
+    out->cov_status = rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : rc;
   }
   return 0;
 }

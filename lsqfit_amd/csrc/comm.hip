@@ -49,16 +49,30 @@ Api &api() {
   static Api a = [] {
     Api t;
     const char *names[] = {"librccl.so", "librccl.so.1"};
+    // LSQAMD_RCCL_PATH is an explicit choice and beats the copy already in the process (a host with
+    // its own RCCL build; the multi-rank tests' stand-in, tests/fake_rccl.cpp)
+    const char *path = getenv("LSQAMD_RCCL_PATH");
+    std::string tried;
+    if (path && *path) {
+      t.lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+      if (!t.lib) {   // a named library that does not load is an error, not a reason to pick another one
+        const char *e = dlerror();
+        t.why = std::string("LSQAMD_RCCL_PATH=") + path + " could not be loaded: " + (e ? e : "unknown error");
+        return t;
+      }
+    }
     for (const char *n : names)   // the copy already in the process (PyTorch's), if any
       if (!t.lib) t.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    for (const char *n : names)
+      if (!t.lib) {
+        t.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!t.lib) {
+          const char *e = dlerror();   // ONE call: dlerror() clears the message it returns
+          tried += std::string(tried.empty() ? "" : "; ") + (e ? e : "not found");
+        }
+      }
     if (!t.lib) {
-      const char *path = getenv("LSQAMD_RCCL_PATH");
-      if (path && *path) t.lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
-      for (const char *n : names)
-        if (!t.lib) t.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    }
-    if (!t.lib) {
-      t.why = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+      t.why = "librccl.so could not be loaded: " + tried;
       return t;
     }
     struct { const char *name; void **slot; } syms[] = {

@@ -87,6 +87,7 @@ struct lsqamd_fit {
   size_t qr_work_bytes = 0;
   int32_t qr_passes = 0;
   double qr_delta = NAN;
+  bool cov_inaccurate = false;   // the last covariance was delivered from a factorisation that did not meet its accuracy test
 
   // box bounds of the reflective trust-region method (empty: none)
   std::vector<double> lb, ub;

@@ -309,6 +309,9 @@ int do_covariance_qr(lsqamd_fit *f) {
   }
   f->qr_passes = pass;
   f->qr_delta = delta;
+  // six passes without reaching |Q^T Q - I| < 1e-6 (shift escalations on a nearly rank-deficient J):
+  // the factor is not the R of an orthogonal Q -- say so instead of passing for a cond(J) eps result
+  f->cov_inaccurate = !(delta < 1e-6);
   // cov = D_c (Wtot^T Wtot) D_c
   GemmTN g;
   g.X = q.Wtot; g.Y = q.Wtot; g.ldx = g.ldy = ldm;

@@ -51,7 +51,10 @@ def normalize_tol(tol):
 
 def _cov_failed(fit, summary):
     """A rank-deficient J^T J at the end point must not look like a clean fit."""
-    if summary.cov_status != 0:
+    if summary.cov_status == -9:      # LSQAMD_EINACCURATE: delivered, but not to the accuracy the route promises
+        warnings.warn('lsqfit_amd: the orthogonalisation behind the covariance did not converge '
+                      '(nearly rank-deficient Jacobian); covariance and logGBF may be inaccurate')
+    elif summary.cov_status != 0:
         msg = 'J^T J is not positive definite at the solution: covariance and logGBF are undefined'
         warnings.warn('lsqfit_amd: ' + msg)
         if fit.error is None:
@@ -118,6 +121,9 @@ class DeviceProblem:
         # captured (the LM step of small problems is replayed from graphs); every entry point of the
         # library synchronises its stream before handing results back, so callers see no difference
         self.stream = torch.cuda.Stream(device=self.device)
+        # device-made whitening weights (block_arrays above: torch.cat on the caller's current stream)
+        # are read by lsqamd_set_data on OUR stream: order the two
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         h = C.c_void_p()
         rc = self.lib.lsqamd_create(C.byref(cfg), C.c_void_p(base + self._ws_off), nbytes,
                                     C.c_void_p(self.stream.cuda_stream), C.byref(h))
@@ -173,7 +179,8 @@ class DeviceProblem:
         if mean.size != P:
             raise ValueError('prior mean has %d entries, the model has %d parameters' % (mean.size, P))
         if hasattr(prec, 'data_ptr'):
-            pass
+            import torch                             # produced on the caller's stream, copied on ours
+            self.stream.wait_stream(torch.cuda.current_stream(self.device))
         elif self.cfg.prior_dense:
             if prec.size == P:
                 prec = np.ascontiguousarray(np.diag(prec.reshape(-1)))

@@ -99,3 +99,26 @@ def test_no_cpu_fallback():
         mod = importlib.import_module('lsqfit_amd.' + name)
         src = open(mod.__file__).read()
         assert 'import oracle' not in src and 'from oracle' not in src, name
+
+
+def test_unloadable_rccl_is_reported_not_crashed(libpath, tmp_path):
+    """The header promises LSQAMD_EUNSUPPORTED when no usable librccl.so can be bound.  A named
+    library that does not load must come back as that code (round 2 called dlerror() twice on this
+    path and built a std::string from NULL)."""
+    import subprocess
+    import sys
+    bogus = str(tmp_path / 'no_such_librccl.so')
+    notlib = tmp_path / 'not_a_library.so'
+    notlib.write_bytes(b'this is not an ELF file')
+    prog = ('import ctypes, sys\n'
+            'sys.path.insert(0, %r)\n'
+            'from lsqfit_amd import _lib\n'
+            'lib = _lib.load()\n'
+            'buf = ctypes.create_string_buffer(128)\n'
+            'print("rc", lib.lsqamd_comm_unique_id(buf, 128))\n' % ROOT)
+    for path in (bogus, str(notlib)):
+        env = dict(os.environ, LSQAMD_RCCL_PATH=path)
+        r = subprocess.run([sys.executable, '-c', prog], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stdout
+        assert 'rc -6' in r.stdout, r.stdout

@@ -1,0 +1,142 @@
+"""-m gpu: the collective INSIDE the library (comm.hip comm_all_reduce: reduce-scatter + all-gather
+over 256-byte slices with in-place offsets, tail all-reduce, the count-1 trial scalar) driven by 2
+and 3 ranks.  RCCL refuses two ranks on one device and the pool's boxes have one GPU, so the seven
+RCCL symbols comm.hip binds are provided by a TEST-ONLY stand-in (tests/fake_rccl.cpp, built here,
+selected through LSQAMD_RCCL_PATH, host-staged through POSIX shared memory, every wait bounded):
+everything on the library's side of those seven calls is the product's code, the same code an
+8-GPU run executes.  Checks, as tests/test_gpu_dist2.py does for the hook: all ranks bit-identical,
+equal to the unsharded device fit; both LSQAMD_COMM_ALGO forms; element counts that are not
+multiples of 32 * nranks; a missing rank is an error, not a hang."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def fake_rccl(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp('fake_rccl') / 'libfake_rccl.so')
+    cmd = [os.environ.get('HIPCC', 'hipcc'), '-O2', '-std=c++17', '-fPIC', '-shared',     # host code only: no kernels
+           os.path.join(HERE, 'fake_rccl.cpp'), '-o', out, '-lrt']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return out
+
+
+def _problem(case):
+    from lsqfit_amd import synth
+    if case == 'blocks':      # P = 384: npk + P + 1 = 6 tiles * 128^2 + 385 = 98689 doubles (odd; slices of 49344 / 32896 + tails)
+        return synth.make_cosmix(N=1536, P=384, seed=191, block=256, prior_corr=True)
+    if case == 'small':       # P = 30: the packed buffer is below the 64 KiB-per-rank switch -> single all-reduce
+        return synth.make_cosmix(N=1000, P=30, seed=192, block=0, prior_corr=False)
+    raise ValueError(case)
+
+
+def _worker(rank, world, outdir, case, fake, algo, missing):
+    os.environ['LSQAMD_RCCL_PATH'] = fake
+    os.environ['LSQAMD_COMM_ALGO'] = algo
+    if missing:
+        os.environ['LSQAMD_FAKE_RCCL_TIMEOUT_S'] = '3'
+    sys.path.insert(0, ROOT)
+    import torch
+    torch.cuda.set_device(0)
+    import lsqfit_amd as amd
+    from lsqfit_amd.dist import shard_rows
+    d = _problem(case)
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    ranges = shard_rows(wh.n_data, [(b['row0'], b['size']) for b in wh.blocks], world)
+    pr = amd.DeviceProblem(d['model'], d['x'], wh, rows=ranges[rank], adds_prior=(rank == 0))
+    # the id travels through a file (any host channel will do: lsqamd_comm_unique_id's contract)
+    idf = os.path.join(outdir, 'comm_id')
+    if rank == 0:
+        uid = pr.comm_unique_id()
+        with open(idf + '.tmp', 'wb') as fh:
+            fh.write(uid)
+        os.replace(idf + '.tmp', idf)
+    else:
+        import time
+        t0 = time.time()
+        while not os.path.exists(idf):
+            time.sleep(0.01)
+            assert time.time() - t0 < 120
+        uid = open(idf, 'rb').read()
+    if missing:
+        # rank 1 of 2 never joins: rank 0's init must come back with an error inside the bounded wait
+        try:
+            pr.comm_init(uid, rank, world)
+            np.savez(os.path.join(outdir, 'r%d.npz' % rank), error='')
+        except RuntimeError as e:
+            np.savez(os.path.join(outdir, 'r%d.npz' % rank), error=str(e))
+        pr.close()
+        return
+    pr.comm_init(uid, rank, world)
+    assert pr.comm_info() == (rank, world)
+    pr.timing(True)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], problem=pr)
+    tm = pr.timings()
+    s = fit.fitter_results.summary
+    pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
+    c2 = pr.chi2_points(pts)                         # m = 5 sums through the communicator (count 5: all-reduce form)
+    np.savez(os.path.join(outdir, 'r%d.npz' % rank), pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit,
+             logGBF=fit.logGBF, c2=c2, reduces=tm['reduce'][1], expect=s.njev + s.nfev - 1, error='')
+    pr.comm_destroy()
+    pr.close()
+
+
+def _run(world, tmp_path, case, fake, algo, missing=False, nstart=None):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker, args=(r, world, str(tmp_path), case, fake, algo, missing))
+             for r in range(world if nstart is None else nstart)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(len(procs))]
+
+
+@pytest.mark.parametrize('case,world,algo', [('blocks', 2, 'rsag'), ('blocks', 3, 'rsag'), ('blocks', 2, 'allreduce'),
+                                             ('small', 3, 'rsag')])
+def test_library_collective_with_several_ranks(case, world, algo, tmp_path, fake_rccl):
+    import lsqfit_amd as amd
+    res = _run(world, tmp_path, case, fake_rccl, algo)
+    for r in res:
+        assert int(r['reduces']) == int(r['expect'])       # one packed exchange per Jacobian, one scalar per trial
+    for r in res[1:]:                                      # every rank received the same bytes: identical decisions
+        for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
+            assert np.array_equal(res[0][k], r[k]), k
+    d = _problem(case)
+    ref = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(res[0]['pmean'], ref.pmean) < 1e-9
+    assert rel(res[0]['cov'], ref.cov) < 1e-8
+    assert abs(res[0]['chi2'] / ref.chi2 - 1) < 1e-10
+    assert int(res[0]['nit']) == ref.nit
+    pts = ref.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
+    assert rel(res[0]['c2'], ref.problem.chi2_points(pts)) < 1e-8
+
+
+def test_rsag_and_allreduce_forms_agree_bit_for_bit(tmp_path, fake_rccl):
+    """Both forms sum in rank order in the stand-in, so the fits must be the same bits: what differs
+    is only comm.hip's slicing (offsets, tail), which this pins."""
+    (tmp_path / 'a').mkdir()
+    (tmp_path / 'b').mkdir()
+    a = _run(2, tmp_path / 'a', 'blocks', fake_rccl, 'rsag')
+    b = _run(2, tmp_path / 'b', 'blocks', fake_rccl, 'allreduce')
+    for k in ('pmean', 'cov', 'chi2', 'nit'):
+        assert np.array_equal(a[0][k], b[0][k]), k
+
+
+def test_missing_rank_is_an_error_not_a_hang(tmp_path, fake_rccl):
+    res = _run(2, tmp_path, 'small', fake_rccl, 'rsag', missing=True, nstart=1)
+    assert 'EREDUCE' in str(res[0]['error']) or 'missing' in str(res[0]['error'])
