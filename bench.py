@@ -237,10 +237,10 @@ def main():
     wh = lsqfit_amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
     # N > 1: the sums run inside the library (RCCL reduce-scatter + all-gather on the handle's
     # stream).  LSQAMD_COLLECTIVE=hook selects the torch.distributed hook instead; without the
-    # variable a failed communicator set-up falls back to the hook on ALL ranks and says so.
+    # variable a failed communicator set-up ends the run (never a silent change of transport).
     want = os.environ.get('LSQAMD_COLLECTIVE') or None
-    if world > 1 and os.environ.get('LSQAMD_DIST_BACKEND', 'nccl') != 'nccl':
-        want = 'hook'
+    if world > 1 and want is None and os.environ.get('LSQAMD_DIST_BACKEND', 'nccl') != 'nccl':
+        want = 'hook'      # (LSQAMD_COLLECTIVE=rccl + LSQAMD_RCCL_PATH: the library's collective over a named RCCL build)
     note = None
     try:
         pr = sharded_problem(d['model'], d['x'], wh, rank, world, collective=want)

@@ -51,3 +51,32 @@ def test_two_rank_launch_line():
     assert KEYS <= set(d) and d['n_gpus'] == 2 and d['scaling'] == 'strong'
     assert d['phases_calls']['reduce'] >= 2 * d['phases_calls']['jacobian']     # packed normal eqs + trial chi2
     assert d['cpu_baseline'] is None and d['value'] > 0
+
+
+def test_two_rank_self_launch_through_the_library_collective(tmp_path):
+    """`python bench.py --gpus 2` (the self-launch path) with the sums running through comm.hip: the
+    RCCL stand-in of tests/fake_rccl.cpp lets both ranks share the one GPU; config.collective must
+    name the library's collective and every rank reports its reduce phase."""
+    fake = str(tmp_path / 'libfake_rccl.so')
+    b = subprocess.run([os.environ.get('HIPCC', 'hipcc'), '-O2', '-std=c++17', '-fPIC', '-shared',
+                        os.path.join(ROOT, 'tests', 'fake_rccl.cpp'), '-o', fake, '-lrt'], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    env = dict(os.environ, LSQAMD_DIST_BACKEND='gloo', LSQAMD_COLLECTIVE='rccl', LSQAMD_RCCL_PATH=fake)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--ndata', '8192',
+                        '--nparam', '512'], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d['n_gpus'] == 2 and d['config']['collective'].startswith('RCCL reduce-scatter + all-gather inside the library')
+    assert len(d['per_rank']['reduce_ms_per_call']) == 2 and all(t > 0 for t in d['per_rank']['reduce_ms_per_call'])
+    assert d['phases_calls']['reduce'] >= 2 * d['phases_calls']['jacobian']
+
+
+def test_self_launch_has_a_wall_clock_limit():
+    """A multi-rank run that does not finish is ended (exit 124), never waited for indefinitely."""
+    import time
+    env = dict(os.environ, LSQAMD_DIST_BACKEND='gloo', LSQAMD_BENCH_TIMEOUT_S='2')
+    t0 = time.time()
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '2', '--steps', '3', '--warmup', '1', '--ndata', '4096',
+                        '--nparam', '256'], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
+    assert 'LSQAMD_BENCH_TIMEOUT_S' in r.stderr and time.time() - t0 < 120
