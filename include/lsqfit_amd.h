@@ -411,10 +411,21 @@ int lsqamd_timing_enable(lsqamd_fit *fit, int32_t on);
 int lsqamd_timing_get(lsqamd_fit *fit, int32_t which, double *total_ms, int64_t *count);
 int lsqamd_timing_reset(lsqamd_fit *fit);
 /* introspection for tests: bit 0 = batched (uniform-block) whitening in use, bit 1 = Jacobian rows
- * synthesised inside the whitening product, bit 2 = LM steps replayed from captured graphs (small
+ * synthesised inside the whitening product, bit 3 = the tape model's formula runs as compiled code (hiprtc) rather than through the
+ * interpreter kernels, bit 2 = LM steps replayed from captured graphs (small
  * single-rank problems without phase timing; LSQAMD_STEP_GRAPH=0 disables),
  * bits 8..31 = split-K factor of the J^T J kernel, bits 32.. = block count */
 int64_t lsqamd_debug_flags(const lsqamd_fit *fit);
+/* The formula of a tape model as the straight-line gfx950 code lsqamd_set_tape builds with hiprtc in
+ * place of interpreting the tape (bit 3 of lsqamd_debug_flags: the compiled route is in use; it stands
+ * in for the Python fit function the reference differentiates with gvar.valder, src/lsqfit/_gsl.pyx:
+ * 742-760).  Needs no GPU: src_out[cap] <- the generated source (or the reason it was declined),
+ * *variant <- 0 one lane per data row, 1 one wave per data row with the lanes striding look-alike
+ * terms of its sums; compile != 0 also runs hiprtc on it.  Returns 0, LSQAMD_EUNSUPPORTED (formula
+ * outside what the generator handles / no hiprtc: the interpreter kernels run instead), LSQAMD_EHIP
+ * (hiprtc rejected the source: a bug). */
+int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts, int32_t n_param,
+                        int32_t n_x, char *src_out, size_t cap, int32_t *variant, int32_t compile);
 /* developer builds (-DLSQAMD_POTF2_TIMING): device buffer of 32 int64 cycle stamps written by the
  * diagonal-block Cholesky kernel; NULL (default) disables */
 void lsqamd_debug_set_potf2_stamps(void *dev_ptr);

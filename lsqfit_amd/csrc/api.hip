@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "fit_state.h"
+#include "jit.h"
 
 using namespace lsqamd;
 
@@ -222,6 +223,7 @@ ModelArgs model_args(const lsqamd_fit *f, const double *p) {
     m.tape_single = f->tape_single;
     m.tape_slot_cap = f->tape_slot_cap;
   }
+  m.jit = f->jit;
   return m;
 }
 
@@ -1527,6 +1529,10 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
   HIPCHK(f, hipStreamSynchronize(f->st));
   f->n_tape = n_code;
   f->have_tape = true;
+  // the formula as straight-line code for gfx950 (hiprtc, cached by content); without it the interpreter
+  // kernels above run -- lsqamd_debug_flags bit 3 says which
+  f->jit_why.clear();
+  f->jit = lsqamd_jit::compile_tape(code, n_code, consts, n_consts, (int)f->P, f->cfg.n_x > 0 ? f->cfg.n_x : 1, f->jit_why);
   return 0;
 }
 
@@ -2185,6 +2191,7 @@ void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long 
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;
   return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | (int64_t)(f->graph_launches > 0 ? 4 : 0) |
+         (int64_t)(f->jit ? 8 : 0) |
          ((int64_t)f->splits << 8) |
          ((int64_t)f->h_size.size() << 32);
 }

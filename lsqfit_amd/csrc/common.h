@@ -134,6 +134,7 @@ struct ModelArgs {
   int32_t tape_slots = 0;
   const int32_t *tape_seg = nullptr;    // root-sum segments [n][3] (first, last instruction, sign), or null
   int32_t tape_n_seg = 0, tape_seg_depth = 0, tape_seg_slots = 0, tape_slot_cap = 0, tape_single = 0;
+  const void *jit = nullptr;            // the tape compiled (jit.hip, lsqamd_jit::Kernel); null: the interpreter kernels
 };
 int tape_slots_of_op(int op);
 // flag[0] = 1 unless max_k |q_k| * xmax is (finite and) below the fast range of the model kernels' trig reduction

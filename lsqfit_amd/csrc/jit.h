@@ -1,0 +1,25 @@
+// Compiled expression tapes (jit.hip): internal to the library, not part of the C ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace lsqamd_jit {
+
+struct Kernel;   // a loaded code object with the residual and the Jacobian kernel of ONE tape; owned by a process-wide cache
+
+struct LaunchArgs {
+  const double *x = nullptr, *p = nullptr, *ymean = nullptr, *wdiag = nullptr;
+  const unsigned char *in_block = nullptr;
+  double *out_w = nullptr, *out_raw = nullptr;
+  int64_t ld = 1, n_data = 0;
+};
+
+// nullptr (and why) when hiprtc is not available or the formula is outside what the generator handles
+const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x, std::string &why);
+// residual: out[row] (ld ignored); Jacobian: out[row * ld + 0..P] with the residual in column P
+hipError_t launch(const Kernel *k, hipStream_t st, bool jac, const LaunchArgs &a);
+bool available(std::string *why);
+
+}  // namespace lsqamd_jit

@@ -1,0 +1,852 @@
+// The user's formula COMPILED instead of interpreted (gfx950, hiprtc).
+//
+// The reference differentiates an arbitrary Python fit function by pushing gvar.valder vectors
+// through it (src/lsqfit/_gsl.pyx:742-760, `_c_df`); the device's stand-in is the RPN tape of
+// lsqamd_set_tape.  Interpreting that tape (model.hip) costs ~40 scalar + vector + LDS instructions
+// per tape instruction; here the tape is turned into straight-line HIP at lsqamd_set_tape time,
+// built with hiprtc for gfx950 and launched in place of the interpreter (which stays as the route
+// when hiprtc is not in the process / on the box, or when the formula is outside what the
+// generator handles: lsqamd_debug_flags bit 3 says which one runs).
+//
+// Shape of the generated code.  The tape is parsed into its expression tree; every additive chain
+// (+, -, unary minus) is flattened and its leaves are grouped by STRUCTURE (same operations,
+// constants and x's; only the parameter indices differ).  A group of >= 4 look-alike terms -- the
+// sum over states / exponentials / harmonics of a real fit function -- becomes ONE loop in which
+// the 64 lanes of a wave stride over the terms of ONE data row: parameter loads and Jacobian
+// stores are then contiguous 512-byte segments (families laid out p = [a_0.., w_0..]), exactly the
+// access pattern of the hand-written sum kernels.  What is left (the "outer" expression: a few
+// dozen nodes, its own parameters, the sums as inputs) is evaluated forward and differentiated in
+// REVERSE by every lane; the adjoint of each sum then scales the term derivatives in a second loop
+// -- or, when the sum is reached from the root through +/- only (adjoint +-1 known beforehand: the
+// usual case), values and derivatives come out of a single loop.  Formulas without wide sums (the
+// 27 NIST models) get one lane per data row and the whole expression in registers.
+//
+// Values in the generated code are computed with the same device functions as the hand-written
+// kernels (devmath.h is embedded: sincos_moderate / cos_moderate) and libm otherwise.
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cinttypes>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "fit_state.h"
+#include "jit.h"
+
+namespace {
+
+const char *kDevmath =
+#include "devmath_src.inc"
+    ;
+
+// ---- hiprtc, bound at run time ---------------------------------------------------------------------
+typedef void *Prog;
+struct Rtc {
+  void *lib = nullptr;
+  int (*Create)(Prog *, const char *, const char *, int, const char **, const char **) = nullptr;
+  int (*Compile)(Prog, int, const char **) = nullptr;
+  int (*LogSize)(Prog, size_t *) = nullptr;
+  int (*Log)(Prog, char *) = nullptr;
+  int (*CodeSize)(Prog, size_t *) = nullptr;
+  int (*Code)(Prog, char *) = nullptr;
+  int (*Destroy)(Prog *) = nullptr;
+  int (*Version)(int *, int *) = nullptr;
+  std::string why, where;
+  bool ok = false;
+  int vmajor = 0, vminor = 0;
+};
+
+Rtc &rtc() {
+  static Rtc r = [] {
+    Rtc t;
+    const char *off = getenv("LSQAMD_TAPE");
+    if (off && (off[0] == 'i' || off[0] == 'w' || off[0] == 'f')) {   // interp / whole / forward: developer knobs
+      t.why = "disabled by LSQAMD_TAPE";
+      return t;
+    }
+    const char *path = getenv("LSQAMD_HIPRTC_PATH");
+    std::vector<std::string> tries;
+    if (path && *path) tries.push_back(path);
+    // the copy that belongs to the HIP runtime THIS process runs on (inside PyTorch: torch/lib): a code
+    // object built by another ROCm's compiler may not load
+    Dl_info di;
+    if (dladdr((void *)&hipModuleLoadData, &di) && di.dli_fname) {
+      std::string dir = di.dli_fname;
+      const size_t s = dir.rfind('/');
+      if (s != std::string::npos) {
+        dir.resize(s + 1);
+        tries.push_back(dir + "libhiprtc.so");
+        tries.push_back(dir + "libhiprtc.so.7");
+      }
+    }
+    tries.push_back("libhiprtc.so");
+    tries.push_back("libhiprtc.so.7");
+    std::string errs;
+    for (const std::string &n : tries) {
+      t.lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+      if (t.lib) { t.where = n; break; }
+      const char *e = dlerror();
+      errs += (errs.empty() ? "" : "; ") + std::string(e ? e : "not found");
+    }
+    if (!t.lib) {
+      t.why = "libhiprtc.so could not be loaded: " + errs;
+      return t;
+    }
+    struct { const char *name; void **slot; } syms[] = {
+        {"hiprtcCreateProgram", (void **)&t.Create}, {"hiprtcCompileProgram", (void **)&t.Compile},
+        {"hiprtcGetProgramLogSize", (void **)&t.LogSize}, {"hiprtcGetProgramLog", (void **)&t.Log},
+        {"hiprtcGetCodeSize", (void **)&t.CodeSize}, {"hiprtcGetCode", (void **)&t.Code},
+        {"hiprtcDestroyProgram", (void **)&t.Destroy}, {"hiprtcVersion", (void **)&t.Version}};
+    for (auto &s : syms) {
+      *s.slot = dlsym(t.lib, s.name);
+      if (!*s.slot) {
+        t.why = std::string("libhiprtc.so lacks ") + s.name;
+        return t;
+      }
+    }
+    (void)t.Version(&t.vmajor, &t.vminor);
+    t.ok = true;
+    return t;
+  }();
+  return r;
+}
+
+// ---- the tape as a tree ----------------------------------------------------------------------------
+enum { OP_WSUM = 100 };   // pseudo-node of the outer expression: the value of a wide sum
+struct Node {
+  int op = 0, arg = 0, a = -1, b = -1;
+};
+
+struct Group {            // look-alike terms of one additive chain, one sign
+  int sign = 1;
+  int tmpl = -1;          // root (in the ORIGINAL node array) of the first term: the template the loop body is made from
+  int n_terms = 0, n_slots = 0;
+  std::vector<std::vector<int>> idx;   // [slot][term] parameter index
+  std::vector<int> shared;             // [slot] 1: the same parameter in every term (accumulated), 0: private (stored)
+  std::vector<int> base, stride;       // [slot] affine index base + k * stride, or stride = INT_MIN: table
+};
+struct WSum {
+  std::vector<Group> groups;
+  int fused = 0;          // adjoint known beforehand: +1 / -1 (one loop), 0: from the outer reverse sweep (two loops)
+};
+struct Plan {
+  std::vector<Node> nodes;      // original tree
+  int root = -1;
+  std::vector<Node> outer;      // outer expression (WSUM pseudo-nodes; P / X / CONST leaves as in the original)
+  int oroot = -1;
+  std::vector<WSum> wsums;
+  std::vector<int> out_params;  // parameters whose derivative is formed by the outer sweep (incl. shared slots)
+  std::vector<double> consts;
+  int P = 0, n_x = 1;
+  bool wave_per_row = false;
+};
+
+bool is_push(int op) { return op <= LSQAMD_OP_P; }
+bool is_bin(int op) { return op >= LSQAMD_OP_ADD && op <= LSQAMD_OP_POW; }
+
+bool parse_tape(const int32_t *code, int n, std::vector<Node> &nodes, int &root) {
+  std::vector<int> st;
+  nodes.clear();
+  nodes.reserve((size_t)n);
+  for (int t = 0; t < n; ++t) {
+    Node nd;
+    nd.op = code[t] & 0xff;
+    nd.arg = code[t] >> 8;
+    if (is_push(nd.op)) {
+    } else if (is_bin(nd.op)) {
+      if (st.size() < 2) return false;
+      nd.b = st.back(); st.pop_back();
+      nd.a = st.back(); st.pop_back();
+    } else {
+      if (st.empty()) return false;
+      nd.a = st.back(); st.pop_back();
+    }
+    nodes.push_back(nd);
+    st.push_back((int)nodes.size() - 1);
+  }
+  if (st.size() != 1) return false;
+  root = st[0];
+  return true;
+}
+
+bool additive(int op) { return op == LSQAMD_OP_ADD || op == LSQAMD_OP_SUB; }
+
+// leaves (node, sign) of the additive chain rooted at n, left to right
+void flatten(const std::vector<Node> &nodes, int n, std::vector<std::pair<int, int>> &leaves) {
+  std::vector<std::pair<int, int>> st{{n, 1}};
+  while (!st.empty()) {
+    auto [k, s] = st.back();
+    st.pop_back();
+    const Node &nd = nodes[(size_t)k];
+    if (nd.op == LSQAMD_OP_ADD) { st.push_back({nd.b, s}); st.push_back({nd.a, s}); }
+    else if (nd.op == LSQAMD_OP_SUB) { st.push_back({nd.b, -s}); st.push_back({nd.a, s}); }
+    else if (nd.op == LSQAMD_OP_NEG && (additive(nodes[(size_t)nd.a].op) || nodes[(size_t)nd.a].op == LSQAMD_OP_NEG)) st.push_back({nd.a, -s});
+    else leaves.push_back({k, s});
+  }
+}
+
+// structure of a subtree with the parameter indices abstracted into slots (first-use order)
+struct Sig {
+  std::string text;
+  std::vector<int> params;   // slot -> parameter index
+  int n_nodes = 0;
+};
+void signature(const std::vector<Node> &nodes, const std::vector<double> &consts, int n, Sig &s) {
+  const Node &nd = nodes[(size_t)n];
+  ++s.n_nodes;
+  char b[64];
+  if (nd.op == LSQAMD_OP_P) {
+    int slot = -1;
+    for (size_t i = 0; i < s.params.size(); ++i)
+      if (s.params[i] == nd.arg) slot = (int)i;
+    if (slot < 0) { slot = (int)s.params.size(); s.params.push_back(nd.arg); }
+    snprintf(b, sizeof(b), "P%d;", slot);
+  } else if (nd.op == LSQAMD_OP_CONST) {
+    uint64_t u;
+    std::memcpy(&u, &consts[(size_t)nd.arg], 8);
+    snprintf(b, sizeof(b), "C%016" PRIx64 ";", u);
+  } else if (nd.op == LSQAMD_OP_X) {
+    snprintf(b, sizeof(b), "X%d;", nd.arg);
+  } else {
+    if (nd.a >= 0) signature(nodes, consts, nd.a, s);
+    if (nd.b >= 0) signature(nodes, consts, nd.b, s);
+    snprintf(b, sizeof(b), "o%d,%d;", nd.op, nd.op == LSQAMD_OP_POWI ? nd.arg : 0);
+  }
+  s.text += b;
+}
+
+int subtree_nodes(const std::vector<Node> &nodes, int n) {
+  int c = 0;
+  std::vector<int> st{n};
+  while (!st.empty()) {
+    const int k = st.back();
+    st.pop_back();
+    ++c;
+    if (nodes[(size_t)k].a >= 0) st.push_back(nodes[(size_t)k].a);
+    if (nodes[(size_t)k].b >= 0) st.push_back(nodes[(size_t)k].b);
+  }
+  return c;
+}
+
+constexpr int MIN_GROUP = 4, MAX_TERM_NODES = 160, MAX_TERM_SLOTS = 16, MAX_OUTER_NODES = 768, MAX_OUT_PARAMS = 64;
+
+struct Builder {
+  Plan &pl;
+  std::vector<int> reads;      // reads of every parameter on the whole tape
+  bool too_deep = false;
+  explicit Builder(Plan &p) : pl(p) {}
+
+  int add_outer(const Node &nd) {
+    pl.outer.push_back(nd);
+    return (int)pl.outer.size() - 1;
+  }
+
+  // original node n -> outer node (wide sums become pseudo-nodes)
+  int xf(int n, int depth) {
+    if (depth > 200) { too_deep = true; return add_outer(Node()); }
+    const Node &nd = pl.nodes[(size_t)n];
+    if (!additive(nd.op)) {
+      Node o = nd;
+      if (nd.a >= 0) o.a = xf(nd.a, depth + 1);
+      if (nd.b >= 0) o.b = xf(nd.b, depth + 1);
+      return add_outer(o);
+    }
+    std::vector<std::pair<int, int>> leaves;
+    flatten(pl.nodes, n, leaves);
+    // group look-alike leaves
+    std::map<std::string, std::vector<size_t>> by_sig;
+    std::vector<Sig> sigs(leaves.size());
+    for (size_t i = 0; i < leaves.size(); ++i) {
+      if (subtree_nodes(pl.nodes, leaves[i].first) > MAX_TERM_NODES) continue;
+      signature(pl.nodes, pl.consts, leaves[i].first, sigs[i]);
+      if (sigs[i].params.empty() || (int)sigs[i].params.size() > MAX_TERM_SLOTS) continue;
+      by_sig[(leaves[i].second > 0 ? "+" : "-") + sigs[i].text].push_back(i);
+    }
+    std::vector<char> grouped(leaves.size(), 0);
+    WSum ws;
+    for (auto &kv : by_sig) {
+      const std::vector<size_t> &mem = kv.second;
+      if ((int)mem.size() < MIN_GROUP) continue;
+      Group g;
+      g.sign = leaves[mem[0]].second;
+      g.tmpl = leaves[mem[0]].first;
+      g.n_terms = (int)mem.size();
+      g.n_slots = (int)sigs[mem[0]].params.size();
+      g.idx.assign((size_t)g.n_slots, std::vector<int>((size_t)g.n_terms));
+      for (int k = 0; k < g.n_terms; ++k)
+        for (int s = 0; s < g.n_slots; ++s) g.idx[(size_t)s][(size_t)k] = sigs[mem[(size_t)k]].params[(size_t)s];
+      // reads of each parameter inside ONE term (same for every term: same structure)
+      std::vector<int> in_term((size_t)g.n_slots, 0);
+      {
+        std::vector<int> st{g.tmpl};
+        while (!st.empty()) {
+          const Node &t = pl.nodes[(size_t)st.back()];
+          st.pop_back();
+          if (t.op == LSQAMD_OP_P)
+            for (int s = 0; s < g.n_slots; ++s)
+              if (g.idx[(size_t)s][0] == t.arg) ++in_term[(size_t)s];
+          if (t.a >= 0) st.push_back(t.a);
+          if (t.b >= 0) st.push_back(t.b);
+        }
+      }
+      bool ok = true;
+      g.shared.assign((size_t)g.n_slots, 0);
+      g.base.assign((size_t)g.n_slots, 0);
+      g.stride.assign((size_t)g.n_slots, 0);
+      for (int s = 0; s < g.n_slots && ok; ++s) {
+        const std::vector<int> &ix = g.idx[(size_t)s];
+        bool all_same = true, priv = true;
+        for (int k = 1; k < g.n_terms; ++k) all_same = all_same && ix[(size_t)k] == ix[0];
+        if (all_same) { g.shared[(size_t)s] = 1; g.base[(size_t)s] = ix[0]; g.stride[(size_t)s] = 0; continue; }
+        for (int k = 0; k < g.n_terms && priv; ++k) priv = reads[(size_t)ix[(size_t)k]] == in_term[(size_t)s];
+        if (!priv) { ok = false; break; }   // read elsewhere as well (or by several terms): not a plain store
+        bool affine = true;
+        const int st0 = ix[1] - ix[0];
+        for (int k = 2; k < g.n_terms; ++k) affine = affine && ix[(size_t)k] - ix[(size_t)k - 1] == st0;
+        g.base[(size_t)s] = ix[0];
+        g.stride[(size_t)s] = affine ? st0 : INT32_MIN;
+      }
+      if (!ok) continue;
+      for (size_t m : mem) grouped[m] = 1;
+      ws.groups.push_back(std::move(g));
+    }
+    int cur = -1;
+    if (!ws.groups.empty()) {
+      Node o;
+      o.op = OP_WSUM;
+      o.arg = (int)pl.wsums.size();
+      pl.wsums.push_back(std::move(ws));
+      cur = add_outer(o);
+    }
+    for (size_t i = 0; i < leaves.size(); ++i) {
+      if (grouped[i]) continue;
+      const int leaf = xf(leaves[i].first, depth + 1);
+      if (cur < 0) {
+        if (leaves[i].second > 0) cur = leaf;
+        else { Node o; o.op = LSQAMD_OP_NEG; o.a = leaf; cur = add_outer(o); }
+      } else {
+        Node o;
+        o.op = leaves[i].second > 0 ? LSQAMD_OP_ADD : LSQAMD_OP_SUB;
+        o.a = cur;
+        o.b = leaf;
+        cur = add_outer(o);
+      }
+    }
+    return cur;
+  }
+};
+
+bool make_plan(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x, Plan &pl, std::string &why) {
+  pl.P = P;
+  pl.n_x = n_x < 1 ? 1 : n_x;
+  pl.consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
+  if (!parse_tape(code, n_code, pl.nodes, pl.root)) { why = "malformed tape"; return false; }
+  Builder b(pl);
+  b.reads.assign((size_t)P, 0);
+  for (const Node &nd : pl.nodes)
+    if (nd.op == LSQAMD_OP_P) ++b.reads[(size_t)nd.arg];
+  pl.oroot = b.xf(pl.root, 0);
+  if (b.too_deep) { why = "expression nested too deeply"; return false; }
+  if ((int)pl.outer.size() > MAX_OUTER_NODES) { why = "the part of the formula outside its wide sums is too large"; return false; }
+  // adjoints known beforehand: sums reached from the root through + / - / unary minus only
+  {
+    std::vector<std::pair<int, int>> st{{pl.oroot, 1}};
+    while (!st.empty()) {
+      auto [k, s] = st.back();
+      st.pop_back();
+      const Node &nd = pl.outer[(size_t)k];
+      if (nd.op == OP_WSUM) pl.wsums[(size_t)nd.arg].fused = s;
+      else if (nd.op == LSQAMD_OP_ADD) { st.push_back({nd.a, s}); st.push_back({nd.b, s}); }
+      else if (nd.op == LSQAMD_OP_SUB) { st.push_back({nd.a, s}); st.push_back({nd.b, -s}); }
+      else if (nd.op == LSQAMD_OP_NEG) st.push_back({nd.a, -s});
+    }
+  }
+  // parameters differentiated by the outer sweep: its own leaves + the shared slots of the groups
+  std::vector<char> isout((size_t)P, 0);
+  for (const Node &nd : pl.outer)
+    if (nd.op == LSQAMD_OP_P) isout[(size_t)nd.arg] = 1;
+  for (const WSum &w : pl.wsums)
+    for (const Group &g : w.groups)
+      for (int s = 0; s < g.n_slots; ++s)
+        if (g.shared[(size_t)s]) isout[(size_t)g.base[(size_t)s]] = 1;
+  for (int j = 0; j < P; ++j)
+    if (isout[(size_t)j]) pl.out_params.push_back(j);
+  if ((int)pl.out_params.size() > MAX_OUT_PARAMS) { why = "too many parameters outside the wide sums"; return false; }
+  pl.wave_per_row = !pl.wsums.empty();
+  return true;
+}
+
+// ---- code generation -------------------------------------------------------------------------------
+struct Src {
+  std::string s;
+  void f(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char b[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(b, sizeof(b), fmt, ap);
+    va_end(ap);
+    s += b;
+  }
+};
+
+std::string dlit(double v) {   // exact literal
+  char b[64];
+  if (std::isnan(v)) return "__builtin_nan(\"\")";
+  if (std::isinf(v)) return v > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+  snprintf(b, sizeof(b), "%a", v);
+  return b;
+}
+
+// Emits forward values (and, jac, local partials) of a tree, then its reverse sweep.  Variables are named
+// <pfx>v<node> / <pfx>d<node>a|b / <pfx>g<node>.
+struct TreeGen {
+  const std::vector<Node> &nodes;
+  const Plan &pl;
+  Src &o;
+  std::string pfx, ind;
+  bool jac;
+  std::function<std::string(const Node &)> leaf_value;                          // P / WSUM leaves
+  std::function<void(const Node &, const std::string &)> leaf_adjoint;          // adjoint arriving at a P / WSUM leaf
+  TreeGen(const std::vector<Node> &n, const Plan &p, Src &out, const std::string &prefix, const std::string &indent, bool j)
+      : nodes(n), pl(p), o(out), pfx(prefix), ind(indent), jac(j) {}
+
+  std::string v(int n) const { return pfx + "v" + std::to_string(n); }
+  std::string d(int n, char w) const { return pfx + "d" + std::to_string(n) + w; }
+
+  void forward(int n) {
+    const Node &nd = nodes[(size_t)n];
+    if (nd.a >= 0) forward(nd.a);
+    if (nd.b >= 0) forward(nd.b);
+    const std::string V = v(n), I = ind;
+    const char *i = I.c_str();
+    const std::string A = nd.a >= 0 ? v(nd.a) : "", B = nd.b >= 0 ? v(nd.b) : "";
+    const char *a = A.c_str(), *b = B.c_str(), *vv = V.c_str();
+    switch (nd.op) {
+      case LSQAMD_OP_CONST: o.f("%sconst double %s = %s;\n", i, vv, dlit(pl.consts[(size_t)nd.arg]).c_str()); break;
+      case LSQAMD_OP_X: o.f("%sconst double %s = x%d;\n", i, vv, nd.arg); break;
+      case LSQAMD_OP_P:
+      case OP_WSUM: o.f("%sconst double %s = %s;\n", i, vv, leaf_value(nd).c_str()); break;
+      case LSQAMD_OP_ADD: o.f("%sconst double %s = %s + %s;\n", i, vv, a, b); break;
+      case LSQAMD_OP_SUB: o.f("%sconst double %s = %s - %s;\n", i, vv, a, b); break;
+      case LSQAMD_OP_MUL: o.f("%sconst double %s = %s * %s;\n", i, vv, a, b); break;
+      case LSQAMD_OP_DIV:
+        o.f("%sconst double %s = %s / %s;\n", i, vv, a, b);
+        if (jac) o.f("%sconst double %s = 1.0 / %s, %s = -%s / %s;\n", i, d(n, 'a').c_str(), b, d(n, 'b').c_str(), vv, b);
+        break;
+      case LSQAMD_OP_POW:
+        o.f("%sconst double %s = pow(%s, %s);\n", i, vv, a, b);
+        if (jac)
+          o.f("%sconst double %s = %s * pow(%s, %s - 1.0), %s = (%s > 0.0) ? %s * log(%s) : 0.0;\n", i, d(n, 'a').c_str(), b, a, b,
+              d(n, 'b').c_str(), a, vv, a);
+        break;
+      case LSQAMD_OP_NEG: o.f("%sconst double %s = -%s;\n", i, vv, a); break;
+      case LSQAMD_OP_EXP: o.f("%sconst double %s = exp(%s);\n", i, vv, a); break;
+      case LSQAMD_OP_LOG:
+        o.f("%sconst double %s = log(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = 1.0 / %s;\n", i, d(n, 'a').c_str(), a);
+        break;
+      case LSQAMD_OP_SIN:
+        if (jac) o.f("%sdouble %s, %s; sincos_moderate<true>(%s, &%s, &%s);\n", i, vv, d(n, 'a').c_str(), a, vv, d(n, 'a').c_str());
+        else o.f("%sdouble %s, %sc; sincos_moderate<true>(%s, &%s, &%sc);\n", i, vv, vv, a, vv, vv);
+        break;
+      case LSQAMD_OP_COS:
+        if (jac) o.f("%sdouble %s, %ss; sincos_moderate<true>(%s, &%ss, &%s); const double %s = -%ss;\n", i, vv, vv, a, vv, vv, d(n, 'a').c_str(), vv);
+        else o.f("%sconst double %s = cos_moderate<true>(%s);\n", i, vv, a);
+        break;
+      case LSQAMD_OP_ATAN:
+        o.f("%sconst double %s = atan(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = 1.0 / (1.0 + %s * %s);\n", i, d(n, 'a').c_str(), a, a);
+        break;
+      case LSQAMD_OP_SQRT:
+        o.f("%sconst double %s = sqrt(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = 0.5 / %s;\n", i, d(n, 'a').c_str(), vv);
+        break;
+      case LSQAMD_OP_POWI:
+        if (nd.arg == 0) { o.f("%sconst double %s = 1.0;\n", i, vv); if (jac) o.f("%sconst double %s = 0.0;\n", i, d(n, 'a').c_str()); }
+        else if (nd.arg == 1) { o.f("%sconst double %s = %s;\n", i, vv, a); if (jac) o.f("%sconst double %s = 1.0;\n", i, d(n, 'a').c_str()); }
+        else if (nd.arg == 2) { o.f("%sconst double %s = %s * %s;\n", i, vv, a, a); if (jac) o.f("%sconst double %s = 2.0 * %s;\n", i, d(n, 'a').c_str(), a); }
+        else {
+          o.f("%sconst double %s = pow(%s, %d.0);\n", i, vv, a, nd.arg);
+          if (jac) o.f("%sconst double %s = %d.0 * pow(%s, %d.0);\n", i, d(n, 'a').c_str(), nd.arg, a, nd.arg - 1);
+        }
+        break;
+      default: o.f("%sconst double %s = %s;\n", i, vv, a); break;
+    }
+  }
+
+  // adjoint `g` (an identifier or literal) arrives at node n
+  void reverse(int n, const std::string &g) {
+    const Node &nd = nodes[(size_t)n];
+    const char *i = ind.c_str();
+    auto child = [&](int c, const std::string &expr) {   // name the child's adjoint, then descend
+      const Node &cn = nodes[(size_t)c];
+      if (cn.op == LSQAMD_OP_CONST || cn.op == LSQAMD_OP_X) return;
+      const std::string G = pfx + "g" + std::to_string(c);
+      o.f("%sconst double %s = %s;\n", i, G.c_str(), expr.c_str());
+      reverse(c, G);
+    };
+    switch (nd.op) {
+      case LSQAMD_OP_CONST:
+      case LSQAMD_OP_X: break;
+      case LSQAMD_OP_P:
+      case OP_WSUM: leaf_adjoint(nd, g); break;
+      case LSQAMD_OP_ADD: child(nd.a, g); child(nd.b, g); break;
+      case LSQAMD_OP_SUB: child(nd.a, g); child(nd.b, "-" + g); break;
+      case LSQAMD_OP_MUL: child(nd.a, g + " * " + v(nd.b)); child(nd.b, g + " * " + v(nd.a)); break;
+      case LSQAMD_OP_DIV:
+      case LSQAMD_OP_POW: child(nd.a, g + " * " + d(n, 'a')); child(nd.b, g + " * " + d(n, 'b')); break;
+      case LSQAMD_OP_NEG: child(nd.a, "-" + g); break;
+      case LSQAMD_OP_EXP: child(nd.a, g + " * " + v(n)); break;
+      default: child(nd.a, g + " * " + d(n, 'a')); break;
+    }
+  }
+};
+
+std::string slot_index(const Group &g, int gi_global, int s, const char *k) {
+  char b[96];
+  if (g.shared[(size_t)s]) snprintf(b, sizeof(b), "%d", g.base[(size_t)s]);
+  else if (g.stride[(size_t)s] == INT32_MIN) snprintf(b, sizeof(b), "T%d_%d[%s]", gi_global, s, k);
+  else if (g.stride[(size_t)s] == 1) snprintf(b, sizeof(b), "(%d + %s)", g.base[(size_t)s], k);
+  else snprintf(b, sizeof(b), "(%d + %s * %d)", g.base[(size_t)s], k, g.stride[(size_t)s]);
+  return b;
+}
+
+// one loop over the terms of a group.  mode 0: values only; 1: values + derivatives (adjoint `adj`, a literal or a
+// variable); 2: derivatives only (second loop of a sum whose adjoint came out of the outer sweep)
+void gen_group(const Plan &pl, Src &o, const Group &g, int gid, int mode, const std::string &adj, const std::string &acc) {
+  const bool der = mode >= 1;
+  o.f("      for (int k = lane; k < %d; k += 64) {\n", g.n_terms);
+  for (int s = 0; s < g.n_slots; ++s) o.f("        const double q%d = sp[%s];\n", s, slot_index(g, gid, s, "k").c_str());
+  TreeGen tg(pl.nodes, pl, o, "t", "        ", der);
+  tg.leaf_value = [&](const Node &nd) {
+    for (int s = 0; s < g.n_slots; ++s)
+      if (g.idx[(size_t)s][0] == nd.arg) return "q" + std::to_string(s);
+    return std::string("0.0");
+  };
+  if (der)
+    for (int s = 0; s < g.n_slots; ++s) o.f("        double e%d = 0.0;\n", s);
+  tg.leaf_adjoint = [&](const Node &nd, const std::string &gg) {
+    for (int s = 0; s < g.n_slots; ++s)
+      if (g.idx[(size_t)s][0] == nd.arg) o.f("        e%d += %s;\n", s, gg.c_str());
+  };
+  tg.forward(g.tmpl);
+  if (mode <= 1) o.f("        %s += %s;\n", acc.c_str(), tg.v(g.tmpl).c_str());
+  if (der) {
+    o.f("        const double tadj = %s%s;\n", g.sign > 0 ? "" : "-", adj.c_str());
+    tg.reverse(g.tmpl, "tadj");
+    for (int s = 0; s < g.n_slots; ++s) {
+      if (g.shared[(size_t)s]) {
+        int j = 0;
+        while (pl.out_params[(size_t)j] != g.base[(size_t)s]) ++j;
+        o.f("        sh%d += e%d;\n", j, s);
+      } else {
+        o.f("        dst[%s] = w * e%d;\n", slot_index(g, gid, s, "k").c_str(), s);
+      }
+    }
+  }
+  o.f("      }\n");
+}
+
+std::string generate(const Plan &pl) {
+  Src o;
+  o.s += "// generated by lsqfit_amd (jit.hip) from an expression tape\n";
+  o.s += kDevmath;
+  o.s += "\nusing namespace lsqamd;\n";
+  o.s += "struct Args { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data; };\n";
+  o.s += "static __device__ __forceinline__ double wsum(double v) {\n"
+         "#pragma unroll\n  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);\n  return v;\n}\n";
+  // index tables of the non-affine private slots
+  int gid = 0;
+  for (const WSum &w : pl.wsums)
+    for (const Group &g : w.groups) {
+      for (int s = 0; s < g.n_slots; ++s)
+        if (!g.shared[(size_t)s] && g.stride[(size_t)s] == INT32_MIN) {
+          o.f("static __device__ const int T%d_%d[%d] = {", gid, s, g.n_terms);
+          for (int k = 0; k < g.n_terms; ++k) o.f("%d,", g.idx[(size_t)s][(size_t)k]);
+          o.s += "};\n";
+        }
+      ++gid;
+    }
+  std::vector<char> xused((size_t)pl.n_x, 0);
+  for (const Node &nd : pl.nodes)
+    if (nd.op == LSQAMD_OP_X) xused[(size_t)nd.arg] = 1;
+  const int nout = (int)pl.out_params.size();
+  for (int jac = 0; jac < 2; ++jac) {
+    o.f("extern \"C\" __global__ __launch_bounds__(256) void %s(Args a) {\n", jac ? "lsqamd_jit_jac" : "lsqamd_jit_res");
+    o.f("  __shared__ double sp[%d];\n", pl.P < 1 ? 1 : pl.P);
+    o.f("  for (int i = threadIdx.x; i < %d; i += 256) sp[i] = a.p[i];\n  __syncthreads();\n", pl.P);
+    if (pl.wave_per_row) {
+      o.s += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
+      o.s += "  for (long long row = (long long)blockIdx.x * 4 + wave; row < a.n_data; row += (long long)gridDim.x * 4) {\n";
+    } else {
+      o.s += "  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < a.n_data; row += (long long)gridDim.x * 256) {\n";
+    }
+    for (int i = 0; i < pl.n_x; ++i)
+      if (xused[(size_t)i]) o.f("    const double x%d = a.x[row * %d + %d];\n", i, pl.n_x, i);
+    o.s += "    const bool blk = a.in_block && a.in_block[row];\n    const double w = blk ? 1.0 : a.wdiag[row];\n";
+    if (jac) o.s += "    double *dst = (blk ? a.out_raw : a.out_w) + row * a.ld;\n";
+    if (jac)
+      for (int j = 0; j < nout; ++j) o.f("    double oacc%d = 0.0, sh%d = 0.0;\n", j, j);
+    // phase 1: the wide sums
+    gid = 0;
+    for (size_t wi = 0; wi < pl.wsums.size(); ++wi) {
+      const WSum &w = pl.wsums[wi];
+      o.f("    double S%zu = 0.0;\n", wi);
+      for (const Group &g : w.groups) {
+        o.s += "    {\n      double acc = 0.0;\n";
+        const int mode = jac && w.fused ? 1 : 0;
+        gen_group(pl, o, g, gid, mode, w.fused > 0 ? "1.0" : "-1.0", "acc");
+        o.f("      S%zu %s wsum(acc);\n    }\n", wi, g.sign > 0 ? "+=" : "-=");
+        ++gid;
+      }
+    }
+    // phase 2: the outer expression, forward and (jac) reverse
+    {
+      TreeGen tg(pl.outer, pl, o, "o", "    ", jac != 0);
+      tg.leaf_value = [&](const Node &nd) {
+        if (nd.op == OP_WSUM) return "S" + std::to_string(nd.arg);
+        return "sp[" + std::to_string(nd.arg) + "]";
+      };
+      if (jac)
+        for (size_t wi = 0; wi < pl.wsums.size(); ++wi)
+          if (!pl.wsums[wi].fused) o.f("    double aS%zu = 0.0;\n", wi);
+      tg.leaf_adjoint = [&](const Node &nd, const std::string &gg) {
+        if (nd.op == OP_WSUM) {
+          if (!pl.wsums[(size_t)nd.arg].fused) o.f("    aS%d += %s;\n", nd.arg, gg.c_str());
+          return;
+        }
+        int j = 0;
+        while (pl.out_params[(size_t)j] != nd.arg) ++j;
+        o.f("    oacc%d += %s;\n", j, gg.c_str());
+      };
+      tg.forward(pl.oroot);
+      o.f("    const double fval = %s;\n", tg.v(pl.oroot).c_str());
+      if (jac) {
+        o.s += "    const double one = 1.0;\n";
+        tg.reverse(pl.oroot, "one");
+      }
+    }
+    if (jac) {
+      // phase 3: sums whose adjoint came out of the outer sweep
+      gid = 0;
+      for (size_t wi = 0; wi < pl.wsums.size(); ++wi) {
+        const WSum &w = pl.wsums[wi];
+        for (const Group &g : w.groups) {
+          if (!w.fused) {
+            o.s += "    {\n";
+            gen_group(pl, o, g, gid, 2, "aS" + std::to_string(wi), "");
+            o.s += "    }\n";
+          }
+          ++gid;
+        }
+      }
+      if (pl.wave_per_row) {
+        if (nout > 0) {
+          bool any_shared = false;
+          for (const WSum &w : pl.wsums)
+            for (const Group &g : w.groups)
+              for (int s = 0; s < g.n_slots; ++s) any_shared = any_shared || g.shared[(size_t)s];
+          o.s += "    double mine = 0.0; int mycol = 0;\n";
+          for (int j = 0; j < nout; ++j) {
+            bool sh = false;
+            for (const WSum &w : pl.wsums)
+              for (const Group &g : w.groups)
+                for (int s = 0; s < g.n_slots; ++s) sh = sh || (g.shared[(size_t)s] && g.base[(size_t)s] == pl.out_params[(size_t)j]);
+            if (sh) o.f("    oacc%d += wsum(sh%d);\n", j, j);
+            o.f("    if (lane == %d) { mine = oacc%d; mycol = %d; }\n", j, j, pl.out_params[(size_t)j]);
+          }
+          (void)any_shared;
+          o.f("    if (lane < %d) dst[mycol] = w * mine;\n", nout);
+        }
+        o.f("    if (lane == 63) dst[%d] = w * (fval - a.ymean[row]);\n", pl.P);
+      } else {
+        for (int j = 0; j < nout; ++j) o.f("    dst[%d] = w * oacc%d;\n", pl.out_params[(size_t)j], j);
+        o.f("    dst[%d] = w * (fval - a.ymean[row]);\n", pl.P);
+      }
+    } else {
+      if (pl.wave_per_row) o.s += "    if (lane == 0) (blk ? a.out_raw : a.out_w)[row] = w * (fval - a.ymean[row]);\n";
+      else o.s += "    (blk ? a.out_raw : a.out_w)[row] = w * (fval - a.ymean[row]);\n";
+    }
+    o.s += "  }\n}\n";
+  }
+  return o.s;
+}
+
+// ---- build, cache, load ----------------------------------------------------------------------------
+uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string cache_dir() {
+  const char *e = getenv("LSQAMD_JIT_CACHE");
+  std::string d;
+  if (e && *e) d = e;
+  else if ((e = getenv("XDG_CACHE_HOME")) && *e) d = std::string(e) + "/lsqfit_amd";
+  else if ((e = getenv("HOME")) && *e) d = std::string(e) + "/.cache/lsqfit_amd";
+  else d = "/tmp/lsqfit_amd_jit_" + std::to_string((long)getuid());
+  if (d == "off" || d == "0") return "";
+  std::string acc;
+  for (size_t i = 0; i <= d.size(); ++i) {   // mkdir -p
+    if (i == d.size() || (d[i] == '/' && i > 0)) {
+      acc = d.substr(0, i);
+      (void)mkdir(acc.c_str(), 0700);
+    }
+  }
+  return d;
+}
+
+bool compile_source(const std::string &src, std::vector<char> &code, std::string &log) {
+  Rtc &r = rtc();
+  if (!r.ok) { log = r.why; return false; }
+  char name[64];
+  snprintf(name, sizeof(name), "%016" PRIx64 "%016" PRIx64, fnv1a(src), fnv1a(src + std::to_string(r.vmajor * 1000 + r.vminor), 88172645463325252ull));
+  const std::string dir = cache_dir();
+  const std::string file = dir.empty() ? "" : dir + "/" + name + ".hsaco";
+  if (!file.empty()) {
+    if (FILE *fh = fopen(file.c_str(), "rb")) {
+      fseek(fh, 0, SEEK_END);
+      const long n = ftell(fh);
+      fseek(fh, 0, SEEK_SET);
+      code.resize(n > 0 ? (size_t)n : 0);
+      const bool ok = n > 0 && fread(code.data(), 1, (size_t)n, fh) == (size_t)n;
+      fclose(fh);
+      if (ok) return true;
+    }
+  }
+  Prog p = nullptr;
+  if (r.Create(&p, src.c_str(), "lsqamd_tape.hip", 0, nullptr, nullptr) != 0) { log = "hiprtcCreateProgram failed"; return false; }
+  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17"};
+  const int rc = r.Compile(p, 3, opts);
+  size_t n = 0;
+  if (r.LogSize(p, &n) == 0 && n > 1) {
+    log.resize(n);
+    (void)r.Log(p, &log[0]);
+  }
+  if (rc != 0) {
+    (void)r.Destroy(&p);
+    if (log.empty()) log = "hiprtcCompileProgram failed";
+    return false;
+  }
+  n = 0;
+  if (r.CodeSize(p, &n) != 0 || n == 0) { (void)r.Destroy(&p); log = "hiprtc produced no code"; return false; }
+  code.resize(n);
+  const int rg = r.Code(p, code.data());
+  (void)r.Destroy(&p);
+  if (rg != 0) { log = "hiprtcGetCode failed"; return false; }
+  if (!file.empty()) {
+    const std::string tmp = file + ".tmp" + std::to_string((long)getpid());
+    if (FILE *fh = fopen(tmp.c_str(), "wb")) {
+      const bool ok = fwrite(code.data(), 1, code.size(), fh) == code.size();
+      fclose(fh);
+      if (ok) (void)rename(tmp.c_str(), file.c_str());
+      else (void)unlink(tmp.c_str());
+    }
+  }
+  return true;
+}
+
+struct Loaded {
+  hipModule_t mod = nullptr;
+  hipFunction_t res = nullptr, jac = nullptr;
+  bool wave_per_row = false;
+};
+std::mutex g_mu;
+
+}  // namespace
+
+namespace lsqamd_jit {
+
+struct Kernel {
+  Loaded l;
+};
+
+int plan_and_generate(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x,
+                      std::string &src, int *variant, std::string &why) {
+  Plan pl;
+  if (!make_plan(code, n_code, consts, n_consts, P, n_x, pl, why)) return 1;
+  src = generate(pl);
+  if (variant) *variant = pl.wave_per_row ? 1 : 0;
+  return 0;
+}
+
+const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x, std::string &why) {
+  if (!rtc().ok) { why = rtc().why; return nullptr; }
+  std::string src;
+  int variant = 0;
+  if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why)) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { why = "no device"; (void)hipGetLastError(); return nullptr; }
+  const std::pair<int, uint64_t> key{dev, fnv1a(src)};
+  std::lock_guard<std::mutex> lk(g_mu);
+  static std::map<std::pair<int, uint64_t>, Kernel> kernels;
+  auto it = kernels.find(key);
+  if (it != kernels.end()) return &it->second;
+  std::vector<char> obj;
+  std::string log;
+  if (!compile_source(src, obj, log)) { why = "hiprtc: " + log.substr(0, 400); return nullptr; }
+  Kernel k;
+  if (hipModuleLoadData(&k.l.mod, obj.data()) != hipSuccess ||
+      hipModuleGetFunction(&k.l.res, k.l.mod, "lsqamd_jit_res") != hipSuccess ||
+      hipModuleGetFunction(&k.l.jac, k.l.mod, "lsqamd_jit_jac") != hipSuccess) {
+    (void)hipGetLastError();
+    why = "the compiled tape could not be loaded";
+    return nullptr;
+  }
+  k.l.wave_per_row = variant == 1;
+  return &kernels.emplace(key, k).first->second;
+}
+
+hipError_t launch(const Kernel *k, hipStream_t st, bool jac, const LaunchArgs &a) {
+  if (a.n_data <= 0) return hipSuccess;
+  struct { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data; } args =
+      {a.x, a.p, a.ymean, a.wdiag, a.in_block, a.out_w, a.out_raw, (long long)a.ld, (long long)a.n_data};
+  size_t sz = sizeof(args);
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  int64_t blocks = k->l.wave_per_row ? (a.n_data + 3) / 4 : (a.n_data + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  return hipModuleLaunchKernel(jac ? k->l.jac : k->l.res, (unsigned)blocks, 1, 1, 256, 1, 1, 0, st, nullptr, cfg);
+}
+
+bool available(std::string *why) {
+  if (why) *why = rtc().ok ? rtc().where : rtc().why;
+  return rtc().ok;
+}
+
+}  // namespace lsqamd_jit
+
+extern "C" int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts, int32_t n_param,
+                                   int32_t n_x, char *src_out, size_t cap, int32_t *variant, int32_t compile) {
+  if (!code || n_code < 1 || n_param < 0) return LSQAMD_EINVAL;
+  for (int t = 0; t < n_code; ++t) {
+    const int op = code[t] & 0xff, arg = code[t] >> 8;
+    if ((op == LSQAMD_OP_P && (arg < 0 || arg >= n_param)) || (op == LSQAMD_OP_CONST && (arg < 0 || arg >= n_consts)) ||
+        (op == LSQAMD_OP_X && (arg < 0 || arg >= (n_x < 1 ? 1 : n_x))) || op > LSQAMD_OP_POWI)
+      return LSQAMD_EINVAL;
+  }
+  std::string src, why;
+  int v = 0;
+  if (lsqamd_jit::plan_and_generate(code, n_code, consts, n_consts, n_param, n_x, src, &v, why)) {
+    if (src_out && cap) snprintf(src_out, cap, "%s", why.c_str());
+    return LSQAMD_EUNSUPPORTED;
+  }
+  if (variant) *variant = v;
+  if (src_out && cap) snprintf(src_out, cap, "%s", src.c_str());
+  if (compile) {
+    std::vector<char> obj;
+    std::string log;
+    if (!compile_source(src, obj, log)) {
+      if (src_out && cap) snprintf(src_out, cap, "%s", log.c_str());
+      return rtc().ok ? LSQAMD_EHIP : LSQAMD_EUNSUPPORTED;
+    }
+  }
+  return 0;
+}

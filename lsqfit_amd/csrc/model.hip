@@ -26,6 +26,7 @@
 
 #include "common.h"
 #include "devmath.h"
+#include "jit.h"
 
 namespace lsqamd {
 
@@ -683,6 +684,12 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
                          dim3(256), 0, st, m);
       break;
     case LSQAMD_MODEL_TAPE:
+      if (nb == 1 && a.jit) {   // the formula compiled at lsqamd_set_tape time (jit.hip)
+        lsqamd_jit::LaunchArgs la;
+        la.x = a.x; la.p = a.p; la.ymean = a.ymean; la.wdiag = a.wdiag; la.in_block = a.in_block;
+        la.out_w = out_w; la.out_raw = out_raw; la.ld = ld; la.n_data = a.n_data;
+        return lsqamd_jit::launch(static_cast<const lsqamd_jit::Kernel *>(a.jit), st, JAC, la);
+      }
       if (nb == 1 && a.tape_part && a.tape_jt && a.tape_poff) {
         TapeRev r;
         r.m = m; r.poff = a.tape_poff; r.part = a.tape_part; r.jt = a.tape_jt; r.ldn = a.tape_ldn;

@@ -1,0 +1,97 @@
+"""-m "not gpu": the tape compiler (lsqfit_amd/csrc/jit.hip) -- plans, generated source and the
+hiprtc build for gfx950 (hiprtc needs no GPU).  What the generated kernels COMPUTE is checked on the
+device (tests/test_gpu_tape.py, test_gpu_parity.py: every tape fit runs through them)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.helpers import load
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from lsqfit_amd import _lib
+    return _lib.load()
+
+
+def codegen(lib, model, compile=1):
+    from lsqfit_amd import _lib
+    code = np.ascontiguousarray(model.tape, np.int32)
+    consts = np.ascontiguousarray(model.consts, np.float64)
+    buf = C.create_string_buffer(1 << 22)
+    var = C.c_int32(-1)
+    rc = lib.lsqamd_tape_codegen(code.ctypes.data_as(C.POINTER(C.c_int32)), code.size, _lib.dptr(consts), consts.size,
+                                 model.n_param, model.n_x, buf, len(buf), C.byref(var), compile)
+    return rc, var.value, buf.value.decode()
+
+
+def body(src, kernel):
+    return src[src.index('void %s(' % kernel):].split('extern "C"')[0]
+
+
+@pytest.mark.parametrize('name', sorted(load('nist.json')))
+def test_nist_models_compile_for_gfx950(lib, name):
+    """The 27 formulas of examples/nist.py: one lane per data row, the whole expression in registers."""
+    import lsqfit_amd as amd
+    d = load('nist.json')[name]
+    model = amd.expr(d['expr'], ['b%d' % (i + 1) for i in range(d['nparam'])], d['columns'][1:])
+    rc, variant, src = codegen(lib, model)
+    assert rc == 0, src[:2000]
+    assert variant == 0
+    for j in range(d['nparam']):          # every parameter gets its column, the residual the last one
+        assert 'dst[%d] = w * oacc' % j in body(src, 'lsqamd_jit_jac')
+    assert 'dst[%d] = w * (fval - a.ymean[row])' % d['nparam'] in src
+
+
+def test_wide_sum_becomes_one_loop_with_contiguous_columns(lib):
+    import lsqfit_amd as amd
+    rc, variant, src = codegen(lib, amd.models.tape_sum('a*cos(w*x)', 512))
+    assert rc == 0 and variant == 1
+    jac = body(src, 'lsqamd_jit_jac')
+    assert jac.count('for (int k = lane; k < 512; k += 64)') == 1          # adjoint +1 known beforehand: ONE loop
+    assert 'dst[(0 + k)] = w * e0;' in jac and 'dst[(512 + k)] = w * e1;' in jac
+    assert 'sincos_moderate<true>' in jac and 'cos_moderate<true>' in body(src, 'lsqamd_jit_res')
+    assert 'T0_' not in src                                                # affine parameter indices: no table
+
+
+def test_sum_inside_a_product_takes_its_adjoint_from_the_outer_sweep(lib):
+    import lsqfit_amd as amd
+    K = 8
+    names = ['a%d' % k for k in range(K)] + ['w%d' % k for k in range(K)] + ['g', 'c', 'phi']
+    text = 'c + exp(-g*x)*(' + '+'.join('a%d*cos(w%d*x+phi)' % (k, k) for k in range(K)) + ')'
+    rc, variant, src = codegen(lib, amd.expr(text, names))
+    assert rc == 0 and variant == 1
+    jac = body(src, 'lsqamd_jit_jac')
+    assert jac.count('for (int k = lane; k < 8; k += 64)') == 2           # values, then derivatives scaled by the adjoint
+    assert 'const double tadj = aS0;' in jac
+    assert 'sh2 += e2;' in jac and 'oacc2 += wsum(sh2);' in jac           # phi: shared by all terms, summed over the wave
+    assert 'mycol = 16' in jac and 'mycol = 17' in jac and 'mycol = 18' in jac
+
+
+def test_scattered_parameter_indices_use_a_table(lib):
+    import lsqfit_amd as amd
+    names = ['p%d' % i for i in range(16)]
+    order = [3, 0, 7, 5, 1, 6, 2, 4]
+    text = '+'.join('p%d*exp(-p%d*x)' % (order[k], 8 + k) for k in range(8))
+    rc, variant, src = codegen(lib, amd.expr(text, names))
+    assert rc == 0 and variant == 1
+    assert 'static __device__ const int T0_0[8] = {3,0,7,5,1,6,2,4,};' in src
+    assert 'dst[T0_0[k]] = w * e0;' in body(src, 'lsqamd_jit_jac')
+
+
+def test_parameter_shared_between_two_sums_falls_back_to_the_outer_expression(lib):
+    """A parameter that is private in one group but read elsewhere too cannot be a plain store."""
+    import lsqfit_amd as amd
+    names = ['a%d' % k for k in range(4)] + ['w%d' % k for k in range(4)]
+    text = '+'.join('a%d*cos(w%d*x)' % (k, k) for k in range(4)) + ' + a0*x'
+    rc, variant, src = codegen(lib, amd.expr(text, names))
+    assert rc == 0 and variant == 0         # the group is not formed: everything is outer, one lane per row
+
+
+def test_formula_outside_the_generator_is_declined_not_miscompiled(lib):
+    import lsqfit_amd as amd
+    names = ['p%d' % i for i in range(130)]
+    text = '*'.join('(p%d + x)' % i for i in range(130))          # 130 parameters, no sums to stride over
+    rc, variant, src = codegen(lib, amd.expr(text, names), compile=0)
+    assert rc == -6 and 'too many parameters' in src

@@ -12,12 +12,29 @@ import lsqfit_amd as amd
 from lsqfit_amd import models, synth
 
 N = 65536
-for P in (64, 1024):
-    d = synth.make_cosmix(N=N, P=P, seed=5, block=0, prior_corr=False)
-    tape = models.tape_sum('a*cos(w*x)', P // 2)
+
+
+def damped(K):
+    """exp(-g*x) * sum_k a_k cos(w_k x): a root that is NOT a sum (P = 2 K + 1), built instruction by instruction"""
+    t = models.tape_sum('a*cos(w*x)', K)
+    OP = models.OP
+    code = [OP['P'] | ((2 * K) << 8), OP['NEG'], OP['X'], OP['MUL'], OP['EXP']] + [int(c) for c in t.tape] + [OP['MUL']]
+    return models.Model(models.MODEL_TAPE, 2 * K + 1, 1, tape=code, consts=t.consts, text='exp(-g*x)*sum_%d(a*cos(w*x))' % K)
+
+
+for P in (64, 1024, 1025):
+    d = synth.make_cosmix(N=N, P=P - P % 2, seed=5, block=0, prior_corr=False)
+    tape = models.tape_sum('a*cos(w*x)', P // 2) if P % 2 == 0 else damped(P // 2)
+    if P % 2:     # one parameter more than the synthetic problem: g, prior 0.01 +- 0.01, start 0.01
+        d['prior'] = (np.append(d['prior'][0], 0.01), np.append(d['prior'][1], 0.01))
+        d['p0'] = np.append(d['p0'], 0.01)
     wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
     for name, model in (('tape', tape), ('cosmix', d['model'])):
+        if P % 2 and name == 'cosmix':
+            continue
         pr = amd.DeviceProblem(model, d['x'], wh)
+        if name == 'tape':
+            print('          (tape runs %s)' % ('COMPILED (hiprtc)' if pr.lib.lsqamd_debug_flags(pr.h) & 8 else 'through the interpreter kernels'))
         pr.timing(True)
         for rep in range(6):
             pr.normal(d['p0'])
