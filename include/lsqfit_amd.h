@@ -228,6 +228,16 @@ int lsqamd_set_x(lsqamd_fit *fit, const double *x, int64_t n_rows, int32_t n_x);
 /* tape for LSQAMD_MODEL_TAPE: code[n_code] = opcode | arg << 8 */
 int lsqamd_set_tape(lsqamd_fit *fit, const int32_t *code, int32_t n_code,
                     const double *consts, int32_t n_consts);
+/* Several formulas, each for its own contiguous range of data rows: the reference's fit function may
+ * return a dictionary (or an array assembled from different expressions), which nonlinear_fit flattens
+ * into ONE residual vector (_unpack_fcn / flatfcn, src/lsqfit/__init__.py:1997-2042; examples/simple.py:
+ * `dict(data1=exp(a + x*b), data2=..., "b/a"=b/a)`): output i is computed by whatever expression the
+ * user wrote for it.  Program k = code[code_off[k] .. code_off[k + 1]) (encoding as in lsqamd_set_tape)
+ * covers rows row0[k] .. row0[k + 1] - 1; row0[0] = 0, row0[n_prog] = n_data, code_off[0] = 0; all
+ * programs share the parameter vector, the predictors' layout and consts[].  Replaces a previous
+ * lsqamd_set_tape (and vice versa).  lsqamd_config.tape_len must cover code_off[n_prog].  Single fits. */
+int lsqamd_set_tape_programs(lsqamd_fit *fit, int32_t n_prog, const int64_t *row0, const int32_t *code,
+                             const int32_t *code_off, const double *consts, int32_t n_consts);
 /* Whitening of the data rows = PDF.mean / PDF.i_invwgts (_utilities.pyx:58-61):
  *   ymean[n_data];  wdiag[n_data]: 1/sdev for 1x1 rows (ignored inside blocks);
  *   block b covers rows [block_row0[b], block_row0[b]+block_size[b]) and has

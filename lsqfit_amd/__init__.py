@@ -17,7 +17,7 @@ raises.
   dist       row sharding across GPUs + the all-reduce hook (torch.distributed/RCCL)
   synth      fake_fitargs-style synthetic problems (benchmark generator)
 """
-from .models import Model, cosmix, multiexp, identity, expr  # noqa: F401
+from .models import Model, cosmix, multiexp, identity, expr, piecewise  # noqa: F401
 from .whiten import Whitening  # noqa: F401
 from .fitter import mi355x_lm, mi355x_trf, DeviceProblem, register  # noqa: F401
 from .fit import nonlinear_fit, gammaQ  # noqa: F401

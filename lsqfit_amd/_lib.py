@@ -76,6 +76,8 @@ PROTOTYPES = {
     'lsqamd_comm_init': (C.c_int, [_vp, _vp, C.c_size_t, C.c_int32, C.c_int32]),
     'lsqamd_comm_destroy': (C.c_int, [_vp]),
     'lsqamd_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'lsqamd_set_tape_programs': (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp,
+                                           C.c_int32]),
     'lsqamd_tape_codegen': (C.c_int, [C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_char_p,
                                       C.c_size_t, C.POINTER(C.c_int32), C.c_int32]),
     'lsqamd_run': (C.c_int, [_vp, _dp, C.POINTER(Summary)]),

@@ -224,6 +224,10 @@ ModelArgs model_args(const lsqamd_fit *f, const double *p) {
     m.tape_slot_cap = f->tape_slot_cap;
   }
   m.jit = f->jit;
+  if (!f->progs.empty()) {
+    m.progs = f->progs.data();
+    m.n_prog = (int32_t)f->progs.size();
+  }
   return m;
 }
 
@@ -1429,13 +1433,8 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
   return 0;
 }
 
-int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const double *consts,
-                    int32_t n_consts) {
-  if (!f) return LSQAMD_EINVAL;
-  f->drop_step_graphs();
-  if (!code || n_code < 1 || n_code > f->tape_cap || n_consts < 0 || n_consts > 1024)
-    FAIL(f, LSQAMD_EINVAL, "set_tape: 1..%d instructions (lsqamd_config.tape_len), <= 1024 constants", f->tape_cap);
-  // validate stack discipline and operand ranges on the host
+// stack discipline and operand ranges of one RPN program (host side)
+static int validate_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, int32_t n_consts) {
   int sp = 0;
   for (int t = 0; t < n_code; ++t) {
     const int op = code[t] & 0xff, arg = code[t] >> 8;
@@ -1448,6 +1447,20 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
     if (sp > LSQAMD_TAPE_MAX_STACK) FAIL(f, LSQAMD_EINVAL, "tape: stack deeper than %d", LSQAMD_TAPE_MAX_STACK);
   }
   if (sp != 1) FAIL(f, LSQAMD_EINVAL, "tape: must leave exactly one value");
+  return 0;
+}
+
+int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const double *consts,
+                    int32_t n_consts) {
+  if (!f) return LSQAMD_EINVAL;
+  f->drop_step_graphs();
+  f->progs.clear();
+  if (!code || n_code < 1 || n_code > f->tape_cap || n_consts < 0 || n_consts > 1024)
+    FAIL(f, LSQAMD_EINVAL, "set_tape: 1..%d instructions (lsqamd_config.tape_len), <= 1024 constants", f->tape_cap);
+  {
+    const int rcv = validate_tape(f, code, n_code, n_consts);
+    if (rcv) return rcv;
+  }
   {
     std::vector<int32_t> poff((size_t)n_code + 1);
     int32_t slots = 0;
@@ -1533,6 +1546,51 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
   // kernels above run -- lsqamd_debug_flags bit 3 says which
   f->jit_why.clear();
   f->jit = lsqamd_jit::compile_tape(code, n_code, consts, n_consts, (int)f->P, f->cfg.n_x > 0 ? f->cfg.n_x : 1, f->jit_why);
+  return 0;
+}
+
+int lsqamd_set_tape_programs(lsqamd_fit *f, int32_t n_prog, const int64_t *row0, const int32_t *code,
+                             const int32_t *code_off, const double *consts, int32_t n_consts) {
+  if (!f) return LSQAMD_EINVAL;
+  f->drop_step_graphs();
+  if (f->cfg.model != LSQAMD_MODEL_TAPE) FAIL(f, LSQAMD_EINVAL, "set_tape_programs: the handle's model is not LSQAMD_MODEL_TAPE");
+  if (n_prog < 1 || !row0 || !code || !code_off || n_consts < 0 || n_consts > 1024 || (n_consts > 0 && !consts))
+    FAIL(f, LSQAMD_EINVAL, "set_tape_programs: n_prog >= 1, row0[n_prog + 1], code, code_off[n_prog + 1], <= 1024 constants");
+  if (row0[0] != 0 || row0[n_prog] != f->N || code_off[0] != 0 || code_off[n_prog] < 1 || code_off[n_prog] > f->tape_cap)
+    FAIL(f, LSQAMD_EINVAL, "set_tape_programs: the row ranges must tile 0..%lld and the programs hold 1..%d instructions in all "
+                           "(lsqamd_config.tape_len)", (long long)f->N, f->tape_cap);
+  std::vector<lsqamd::TapeProgram> progs((size_t)n_prog);
+  for (int i = 0; i < n_prog; ++i) {
+    if (row0[i + 1] < row0[i] || code_off[i + 1] <= code_off[i])
+      FAIL(f, LSQAMD_EINVAL, "set_tape_programs: row0 must not decrease and every program needs at least one instruction");
+    const int rcv = validate_tape(f, code + code_off[i], code_off[i + 1] - code_off[i], n_consts);
+    if (rcv) return rcv;
+    progs[(size_t)i].row0 = row0[i];
+    progs[(size_t)i].n_rows = row0[i + 1] - row0[i];
+    progs[(size_t)i].tape_off = code_off[i];
+    progs[(size_t)i].n_tape = code_off[i + 1] - code_off[i];
+  }
+  HIPCHK(f, hipMemcpyAsync(f->tape, code, sizeof(int32_t) * code_off[n_prog], hipMemcpyHostToDevice, f->st));
+  if (n_consts > 0)
+    HIPCHK(f, hipMemcpyAsync(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  // every formula compiled on its own (hiprtc, cached by content); one that cannot be runs through the
+  // forward-mode interpreter kernel over its rows
+  f->jit = nullptr;
+  f->jit_why.clear();
+  int compiled = 0;
+  for (int i = 0; i < n_prog; ++i) {
+    std::string why;
+    progs[(size_t)i].jit = lsqamd_jit::compile_tape(code + code_off[i], progs[(size_t)i].n_tape, consts, n_consts, (int)f->P,
+                                                    f->cfg.n_x > 0 ? f->cfg.n_x : 1, why);
+    if (progs[(size_t)i].jit) ++compiled;
+    else f->jit_why = why;
+  }
+  f->progs = std::move(progs);
+  f->progs_compiled = compiled;
+  f->n_tape = code_off[n_prog];
+  f->tape_n_seg = 0;
+  f->have_tape = true;
   return 0;
 }
 
@@ -2191,7 +2249,7 @@ void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long 
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;
   return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | (int64_t)(f->graph_launches > 0 ? 4 : 0) |
-         (int64_t)(f->jit ? 8 : 0) |
+         (int64_t)(f->jit || (!f->progs.empty() && f->progs_compiled == (int)f->progs.size()) ? 8 : 0) |
          ((int64_t)f->splits << 8) |
          ((int64_t)f->h_size.size() << 32);
 }

@@ -106,6 +106,13 @@ hipError_t logdiag_sum(hipStream_t st, const double *A, int64_t n, int64_t lda, 
 extern long long *g_potf2_dbg;  // cycle stamps of the diagonal kernel (LSQAMD_POTF2_TIMING builds only)
 
 // ---- model kernels (model.hip) ----------------------------------------------------
+// one formula of a tape model with several (lsqamd_set_tape_programs): rows [row0, row0 + n_rows) run
+// instructions [tape_off, tape_off + n_tape) of the handle's tape
+struct TapeProgram {
+  int64_t row0 = 0, n_rows = 0;
+  int32_t tape_off = 0, n_tape = 0;
+  const void *jit = nullptr;   // this formula compiled (jit.hip), or null: the forward-mode interpreter kernel
+};
 struct ModelArgs {
   int32_t model = 0;
   int64_t n_data = 0, n_param = 0;
@@ -135,6 +142,8 @@ struct ModelArgs {
   const int32_t *tape_seg = nullptr;    // root-sum segments [n][3] (first, last instruction, sign), or null
   int32_t tape_n_seg = 0, tape_seg_depth = 0, tape_seg_slots = 0, tape_slot_cap = 0, tape_single = 0;
   const void *jit = nullptr;            // the tape compiled (jit.hip, lsqamd_jit::Kernel); null: the interpreter kernels
+  const TapeProgram *progs = nullptr;   // host array: one formula per row range (n_prog > 0), instead of one tape for all rows
+  int32_t n_prog = 0;
 };
 int tape_slots_of_op(int op);
 // flag[0] = 1 unless max_k |q_k| * xmax is (finite and) below the fast range of the model kernels' trig reduction

@@ -64,6 +64,8 @@ struct lsqamd_fit {
   double *tape_part = nullptr, *tape_jt = nullptr;
   int64_t tape_ldn = 0, tape_wgs = 0;
   int32_t tape_cap = 0, tape_slots = 0, tape_slot_cap = 0;
+  std::vector<lsqamd::TapeProgram> progs;   // one formula per row range (lsqamd_set_tape_programs); empty: one tape for all rows
+  int progs_compiled = 0;
   const void *jit = nullptr;   // the tape compiled (jit.hip); null: interpreted (jit_why says why)
   std::string jit_why;
   int32_t *syrk_map = nullptr;

@@ -144,6 +144,7 @@ struct Plan {
   int oroot = -1;
   std::vector<WSum> wsums;
   std::vector<int> out_params;  // parameters whose derivative is formed by the outer sweep (incl. shared slots)
+  std::vector<int> unread;      // parameters the formula never reads: their Jacobian column is zero
   std::vector<double> consts;
   int P = 0, n_x = 1;
   bool wave_per_row = false;
@@ -353,6 +354,8 @@ bool make_plan(const int32_t *code, int n_code, const double *consts, int n_cons
   b.reads.assign((size_t)P, 0);
   for (const Node &nd : pl.nodes)
     if (nd.op == LSQAMD_OP_P) ++b.reads[(size_t)nd.arg];
+  for (int j = 0; j < P; ++j)
+    if (b.reads[(size_t)j] == 0) pl.unread.push_back(j);
   pl.oroot = b.xf(pl.root, 0);
   if (b.too_deep) { why = "expression nested too deeply"; return false; }
   if ((int)pl.outer.size() > MAX_OUTER_NODES) { why = "the part of the formula outside its wide sums is too large"; return false; }
@@ -575,6 +578,11 @@ std::string generate(const Plan &pl) {
         }
       ++gid;
     }
+  if (!pl.unread.empty()) {
+    o.f("static __device__ const int ZC[%zu] = {", pl.unread.size());
+    for (int j : pl.unread) o.f("%d,", j);
+    o.s += "};\n";
+  }
   std::vector<char> xused((size_t)pl.n_x, 0);
   for (const Node &nd : pl.nodes)
     if (nd.op == LSQAMD_OP_X) xused[(size_t)nd.arg] = 1;
@@ -647,6 +655,10 @@ std::string generate(const Plan &pl) {
           }
           ++gid;
         }
+      }
+      if (!pl.unread.empty()) {   // columns of parameters the formula does not read
+        if (pl.wave_per_row) o.f("    for (int k = lane; k < %zu; k += 64) dst[ZC[k]] = 0.0;\n", pl.unread.size());
+        else o.f("    for (int k = 0; k < %zu; ++k) dst[ZC[k]] = 0.0;\n", pl.unread.size());
       }
       if (pl.wave_per_row) {
         if (nout > 0) {

@@ -684,6 +684,34 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
                          dim3(256), 0, st, m);
       break;
     case LSQAMD_MODEL_TAPE:
+      if (a.n_prog > 0) {
+        // one formula per row range (the flattened dict-valued fit function of the reference,
+        // src/lsqfit/__init__.py:1997-2042): each range is a launch of its own over offset views of the rows
+        for (int i = 0; i < a.n_prog; ++i) {
+          const TapeProgram &pg = a.progs[i];
+          if (pg.n_rows <= 0) continue;
+          if (nb == 1 && pg.jit) {
+            lsqamd_jit::LaunchArgs la;
+            la.x = a.x + pg.row0 * a.n_x; la.p = a.p; la.ymean = a.ymean + pg.row0; la.wdiag = a.wdiag + pg.row0;
+            la.in_block = a.in_block ? a.in_block + pg.row0 : nullptr;
+            la.out_w = out_w + pg.row0 * ld; la.out_raw = out_raw ? out_raw + pg.row0 * ld : nullptr;
+            la.ld = ld; la.n_data = pg.n_rows;
+            hipError_t e = lsqamd_jit::launch(static_cast<const lsqamd_jit::Kernel *>(pg.jit), st, JAC, la);
+            if (e != hipSuccess) return e;
+            continue;
+          }
+          ModelDev q = m;
+          q.x += pg.row0 * a.n_x; q.ymean += pg.row0; q.wdiag += pg.row0;
+          if (q.in_block) q.in_block += pg.row0;
+          q.out_w += pg.row0 * ld;
+          if (q.out_raw) q.out_raw += pg.row0 * ld;
+          q.n_data = pg.n_rows;
+          q.tape += pg.tape_off;
+          q.n_tape = pg.n_tape;
+          hipLaunchKernelGGL((tape_model_kernel<JAC>), dim3((unsigned)((pg.n_rows + 63) / 64), nb), dim3(64), 0, st, q);
+        }
+        break;
+      }
       if (nb == 1 && a.jit) {   // the formula compiled at lsqamd_set_tape time (jit.hip)
         lsqamd_jit::LaunchArgs la;
         la.x = a.x; la.p = a.p; la.ymean = a.ymean; la.wdiag = a.wdiag; la.in_block = a.in_block;

@@ -135,7 +135,31 @@ class DeviceProblem:
         if model.kind != MODEL_IDENTITY:
             xa = np.ascontiguousarray(np.asarray(x, np.float64).reshape(whitening.n_data, model.n_x)[a:b])
             _check(lib, h, lib.lsqamd_set_x(h, _lib.dptr(xa), N, model.n_x), 'set_x')
-        if model.kind == MODEL_TAPE:
+        if model.kind == MODEL_TAPE and getattr(model, 'programs', None):
+            # one formula per row range (models.piecewise): the ranges clipped to this handle's rows
+            if joint or self.perm is not None:
+                raise ValueError('piecewise models: data whose covariance ties rows of different ranges into '
+                                 'interleaved components (or to the prior) is not supported')
+            if sum(n for n, _ in model.programs) != whitening.n_data:
+                raise ValueError('piecewise model covers %d rows, the data has %d'
+                                 % (sum(n for n, _ in model.programs), whitening.n_data))
+            row0, codes, r = [0], [], 0
+            for n, code in model.programs:
+                lo, hi = max(r, a), min(r + n, b)
+                r += n
+                if hi > lo:
+                    codes.append(np.asarray(code, np.int32))
+                    row0.append(hi - a)
+            if not codes:                                   # a shard without rows: any formula, no rows
+                codes, row0 = [np.asarray(model.programs[0][1], np.int32)], [0, 0]
+            code = np.ascontiguousarray(np.concatenate(codes), np.int32)
+            off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c.size for c in codes])]), np.int32)
+            row0 = np.ascontiguousarray(row0, np.int64)
+            consts = np.ascontiguousarray(model.consts, np.float64)
+            _check(lib, h, lib.lsqamd_set_tape_programs(
+                h, len(codes), row0.ctypes.data_as(C.POINTER(C.c_int64)), code.ctypes.data_as(C.POINTER(C.c_int32)),
+                off.ctypes.data_as(C.POINTER(C.c_int32)), _lib.dptr(consts), consts.size), 'set_tape_programs')
+        elif model.kind == MODEL_TAPE:
             code = np.ascontiguousarray(model.tape, np.int32)
             consts = np.ascontiguousarray(model.consts, np.float64)
             _check(lib, h, lib.lsqamd_set_tape(h, code.ctypes.data_as(C.POINTER(C.c_int32)), code.size,

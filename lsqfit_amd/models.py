@@ -23,13 +23,16 @@ _BIN = {ast.Add: 'ADD', ast.Sub: 'SUB', ast.Mult: 'MUL', ast.Div: 'DIV', ast.Pow
 class Model:
     """kind + shapes (+ tape).  ``n_param`` = P, ``n_x`` = predictors per row."""
 
-    def __init__(self, kind, n_param, n_x=1, tape=None, consts=None, text=None):
+    def __init__(self, kind, n_param, n_x=1, tape=None, consts=None, text=None, programs=None):
         self.kind = int(kind)
         self.n_param = int(n_param)
         self.n_x = int(n_x)
         self.tape = None if tape is None else np.asarray(tape, np.int32)
         self.consts = np.asarray(consts if consts is not None else [], np.float64)
         self.text = text
+        # [(n_rows, int32 code)]: one formula per contiguous range of data rows (``piecewise``); ``tape`` is
+        # then their concatenation
+        self.programs = programs
 
     def __repr__(self):
         return 'Model(%s, P=%d)' % (self.text or self.kind, self.n_param)
@@ -160,3 +163,32 @@ def tape_sum(term, K, params_per_term=('a', 'w'), xnames=('x',)):
         if k:
             code.append(OP['ADD'])
     return Model(MODEL_TAPE, nfam * K, len(xnames), tape=code, consts=consts, text='sum_%d(%s)' % (K, term))
+
+
+def piecewise(parts, params, xnames=('x',)):
+    """One formula per contiguous range of data rows -- the flattened form of a fit function that
+    returns a dictionary or an array built from different expressions (the reference flattens such
+    outputs itself: src/lsqfit/__init__.py:1997-2042; examples/simple.py).  ``parts`` is a list of
+    ``(n_rows, 'formula')`` in row order; all formulas share ``params`` and ``xnames``:
+
+        piecewise([(4, 'exp(a + x*b)'), (1, 'b/a')], ['a', 'b'])
+    """
+    params = list(params)
+    if len(params) > TAPE_MAX_PARAM:
+        raise ValueError('tape models support at most %d parameters' % TAPE_MAX_PARAM)
+    consts, programs, texts = [], [], []
+    for n_rows, text in parts:
+        if int(n_rows) < 0:
+            raise ValueError('piecewise: negative row count')
+        c = _Compiler(params, list(xnames))
+        c.consts = consts
+        c.visit(ast.parse(text.strip(), mode='eval').body)
+        if c.maxdepth > TAPE_MAX_STACK:
+            raise ValueError('expression needs a stack deeper than %d' % TAPE_MAX_STACK)
+        programs.append((int(n_rows), np.asarray(c.code, np.int32)))
+        texts.append('%d: %s' % (n_rows, text))
+    if not programs:
+        raise ValueError('piecewise: no parts')
+    tape = np.concatenate([code for _, code in programs])
+    return Model(MODEL_TAPE, len(params), len(xnames), tape=tape, consts=consts, text='{' + '; '.join(texts) + '}',
+                 programs=programs)

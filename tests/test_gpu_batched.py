@@ -86,7 +86,7 @@ def test_batched_maxit_and_rejections(amd):
 
 def test_config5_sweep_128x4096x512(amd):
     """BASELINE.json configs[4]: 128 batched fits of 4096 x 512 with a hipGraph-captured LM
-    round.  Spot-check three fits against the single-fit device path; the rest through the
+    round.  Three of the fits against the single-fit device path AND the oracle; the rest through the
     smoothness of logGBF(z) and chi2/dof."""
     d, pmb, psb = make(4096, 512, 128, 20264)
     bf = amd.BatchedFits(d['model'], d['x'], d['ymean'], d['yerr'], pmb, psb)
@@ -104,5 +104,12 @@ def test_config5_sweep_128x4096x512(amd):
         assert gu.relmax(out['pmean'][b], single.pmean) < 1e-9
         assert out['logGBF'][b] == pytest.approx(single.logGBF, rel=1e-9)
         assert out['nit'][b] == single.nit
+        # ... and against the ORACLE (the CPU restatement of the reference's algorithm) at full size, to the
+        # north_star tolerance: parameters, chi2/dof, covariance, logGBF
+        ref = gu.oracle_fit(dict(d, prior=(pmb[b], psb[b])), solver='cholesky')
+        assert gu.relmax(out['pmean'][b], ref.pmean) < 1e-6
+        assert out['chi2'][b] / out['dof'] == pytest.approx(ref.chi2 / ref.dof, rel=1e-6)
+        assert gu.relmax(bf.cov(b), ref.cov) < 1e-6
+        assert out['logGBF'][b] == pytest.approx(ref.logGBF, rel=1e-6, abs=1e-6)
     print('config5: %d rounds, %.1f ms on device, %d fits' % (out['rounds'], out['device_ms'], 128))
     bf.close()

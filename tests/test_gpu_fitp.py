@@ -31,9 +31,10 @@ def test_simple_example_error_budget_on_device(amd):
     ycov[:2, :2] = [[0.0047, 0.01], [0.01, 0.056]]
     ycov[2:4, 2:4] = [[0.0047, 0.0067], [0.0067, 0.0136]]
     ycov[4, 4] = 0.25
-    # rows 0-3: exp(a + x b); row 4: b/a  (selector column s)
-    x = np.array([[0.1, 1.0], [1.0, 1.0], [0.1, 1.0], [0.5, 1.0], [0.0, 0.0]])
-    model = amd.expr('s*exp(a + x*b) + (1 - s)*b/a', ['a', 'b'], xnames=('x', 's'))
+    # the dict-valued fit function of examples/simple.py, flattened: rows 0-3 exp(a + x b), row 4 b/a --
+    # each range runs its own formula (lsqamd_set_tape_programs)
+    x = np.array([0.1, 1.0, 0.1, 0.5, 0.0])
+    model = amd.piecewise([(4, 'exp(a + x*b)'), (1, 'b/a')], ['a', 'b'])
     fit = amd.nonlinear_fit(data=(x, ymean, ycov), model=model, prior=([0.5, 0.5], [0.5, 0.5]))
     ref, cov_in = _simple_fit()
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-6

@@ -95,3 +95,10 @@ def test_formula_outside_the_generator_is_declined_not_miscompiled(lib):
     text = '*'.join('(p%d + x)' % i for i in range(130))          # 130 parameters, no sums to stride over
     rc, variant, src = codegen(lib, amd.expr(text, names), compile=0)
     assert rc == -6 and 'too many parameters' in src
+
+
+def test_unread_parameter_gets_a_zero_column(lib):
+    import lsqfit_amd as amd
+    rc, variant, src = codegen(lib, amd.expr('py + 0*x', ['py', 'pn']))
+    assert rc == 0 and 'static __device__ const int ZC[1] = {1,};' in src
+    assert 'dst[ZC[k]] = 0.0;' in body(src, 'lsqamd_jit_jac')
