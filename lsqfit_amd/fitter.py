@@ -143,21 +143,21 @@ class DeviceProblem:
             if sum(n for n, _ in model.programs) != whitening.n_data:
                 raise ValueError('piecewise model covers %d rows, the data has %d'
                                  % (sum(n for n, _ in model.programs), whitening.n_data))
-            row0, codes, r = [0], [], 0
+            prow0, codes, r = [0], [], 0
             for n, code in model.programs:
                 lo, hi = max(r, a), min(r + n, b)
                 r += n
                 if hi > lo:
                     codes.append(np.asarray(code, np.int32))
-                    row0.append(hi - a)
+                    prow0.append(hi - a)
             if not codes:                                   # a shard without rows: any formula, no rows
-                codes, row0 = [np.asarray(model.programs[0][1], np.int32)], [0, 0]
+                codes, prow0 = [np.asarray(model.programs[0][1], np.int32)], [0, 0]
             code = np.ascontiguousarray(np.concatenate(codes), np.int32)
             off = np.ascontiguousarray(np.concatenate([[0], np.cumsum([c.size for c in codes])]), np.int32)
-            row0 = np.ascontiguousarray(row0, np.int64)
+            prow0 = np.ascontiguousarray(prow0, np.int64)
             consts = np.ascontiguousarray(model.consts, np.float64)
             _check(lib, h, lib.lsqamd_set_tape_programs(
-                h, len(codes), row0.ctypes.data_as(C.POINTER(C.c_int64)), code.ctypes.data_as(C.POINTER(C.c_int32)),
+                h, len(codes), prow0.ctypes.data_as(C.POINTER(C.c_int64)), code.ctypes.data_as(C.POINTER(C.c_int32)),
                 off.ctypes.data_as(C.POINTER(C.c_int32)), _lib.dptr(consts), consts.size), 'set_tape_programs')
         elif model.kind == MODEL_TAPE:
             code = np.ascontiguousarray(model.tape, np.int32)
