@@ -371,6 +371,44 @@ def main():
                          'frac_of_peak_at_sustained_clock':
                              (ach / (128 * 256 * clk * 1e9 / 1e12)) if clk else None},
         }
+        # both fractions per kernel and the blended per-step fraction.  Algorithmic counts per launch
+        #  over the HIP-event average of the phase that contains the kernel; MFMA phases against the
+        # fp64-MFMA peak, streaming phases against HBM (8 TB/s, MI355X_MICROARCH.md)
+        HBM_PEAK = 8.0e12
+        B = block if block > 1 else 0
+        spl = (lib.lsqamd_debug_flags(h) >> 8) & 0xffffff
+
+        def per(ms_cnt):
+            return (ms_cnt[0] / ms_cnt[1] * 1e-3) if ms_cnt[1] else None
+        pk = {}
+        t = per(tm['whiten'])
+        if t and B:
+            fl = float(B) * n_local * (P + 1)
+            pk['whitening (J_b = W_b [df/dp] per block)'] = {'bound': 'mfma', 'flops': fl, 'ms': t * 1e3, 'frac': fl / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+        t = per(tm['cholesky'])
+        if t:
+            fl = P ** 3 / 3.0
+            pk['potrf_upper (damped normal equations)'] = {'bound': 'mfma', 'flops': fl, 'ms': t * 1e3, 'frac': fl / t / 1e12 / PEAK_FP64_MFMA_TFLOPS}
+        t = per(tm['residual'])
+        if t:
+            by = 8.0 * n_local * (3 + (1 if B else 0))      # x, ymean, weight in; r out (+ the raw vector of block rows)
+            pk['trial residual (model + whitening + |f|^2)'] = {'bound': 'hbm', 'bytes': by, 'ms': t * 1e3, 'frac': by / t / HBM_PEAK,
+                                                                'note': 'transcendental-bound at this shape (N K sincos), not a streaming kernel'}
+        t = per(tm['grad'])
+        if t:
+            by = 8.0 * (spl * P * (P + 128.0) / 2 + P * P / 2)   # upper tiles of the split-K slabs in, packed tiles out
+            pk['finalize_pack + prior (slab sum, J^T f)'] = {'bound': 'hbm', 'bytes': by, 'ms': t * 1e3, 'frac': by / t / HBM_PEAK}
+        t = per(tm['jacobian'])
+        if t and not B:
+            by = 8.0 * n_local * (P + 1)
+            pk['Jacobian rows'] = {'bound': 'hbm', 'bytes': by, 'ms': t * 1e3, 'frac': by / t / HBM_PEAK}
+        out['roofline']['per_kernel'] = pk
+        step_flops = flops + (float(B) * n_local * (P + 1) if B else 0.0) + P ** 3 / 3.0 + 2.0 * n_local * P + 2.0 * P * P
+        out['roofline']['blended_step'] = {'flops_per_step': step_flops, 'ms_per_step': 1e3 * elapsed / args.steps,
+                                           'achieved_TFLOPs': step_flops / (elapsed / args.steps) / 1e12,
+                                           'frac': step_flops / (elapsed / args.steps) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
+                                           'note': 'algorithmic flops of one accepted step on this rank (SYRK + whitening + Cholesky + '
+                                                   'J^T f + solve; rejected trials and model evaluation not counted) over the wall-clock step'}
         if not args.no_cpu_baseline and world == 1:
             try:
                 cb, res = cpu_baseline(d, wh, args.cpu_seconds)

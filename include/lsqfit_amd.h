@@ -166,7 +166,10 @@ typedef struct {
   int32_t njev;               /* Jacobian evaluations */
   int32_t ntrial;             /* damped solves attempted */
   int32_t chol_fail;          /* factorizations that hit a non-positive pivot */
-  int32_t cov_status;         /* 0, LSQAMD_EINACCURATE, or LSQAMD_ENOTPD: J^T J is not positive definite at the end point --
+  int32_t cov_status;         /* 0; k > 0: the final Jacobian is rank deficient and cov is what the reference's plugin returns there
+                               * with k directions dropped (gsl_multifit_nlinear_covar's pivoted-QR form, _gsl.pyx:704-706; the
+                               * thresholded-SVD pseudo-inverse of _scipy.py:170-175 for the TRF / dogbox / MINPACK methods),
+                               * logdet_jtj = -inf; LSQAMD_EINACCURATE; or LSQAMD_ENOTPD: J^T J is not positive definite at the end point --
                                * cov and logdet_jtj (NaN) are undefined (gsl_multifit_nlinear_covar has no
                                * such report: its QR-based inverse returns garbage silently) */
   int32_t reserved0;
@@ -334,6 +337,11 @@ int lsqamd_op_gemm_tn(void *stream, int64_t M, int64_t N, int64_t K, double alph
 int lsqamd_op_potrf_upper(void *stream, double *A, int64_t n, int64_t lda, int64_t n_cols,
                           double *work, size_t work_bytes, int32_t *dev_info);
 size_t lsqamd_op_potrf_work_bytes(int64_t n);
+/* host arithmetic of the rank-deficient covariance (rankdef.hip; what lsqamd_run / lsqamd_finish fall back to when
+ * J^T J has no Cholesky factor at the end point): G[n*n] = J^T J, n_rows = rows of J; scipy_form 0: gsl_multifit_nlinear_covar's
+ * pivoted recipe (_gsl.pyx:704-706), 1: the thresholded pseudo-inverse of _scipy.py:170-175.  Host pointers, no GPU. */
+int lsqamd_op_truncated_inverse(const double *G, int64_t n, int64_t n_rows, int32_t scipy_form, double *cov_out,
+                                int32_t *dropped);
 
 /* ---- results (replace vector2array / matrix2array, _gsl.pyx:77-86,:104-120) ---- */
 int lsqamd_get_x(lsqamd_fit *fit, double *out, size_t cap);       /* P        : fit.x  */

@@ -92,6 +92,7 @@ PROTOTYPES = {
                                     _vp, C.c_int64, C.c_double, _vp, C.c_int64, C.c_int32, C.c_int32]),
     'lsqamd_op_potrf_upper': (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, _vp, C.c_size_t, _vp]),
     'lsqamd_op_potrf_work_bytes': (C.c_size_t, [C.c_int64]),
+    'lsqamd_op_truncated_inverse': (C.c_int, [_dp, C.c_int64, C.c_int64, C.c_int32, _dp, C.POINTER(C.c_int32)]),
     'lsqamd_get_x': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_get_f': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamd_get_J': (C.c_int, [_vp, _dp, C.c_size_t]),

@@ -1286,9 +1286,25 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
 }
 
 // covariance + logdet at the current point: factor A (mu = 0), invert
+static int do_covariance_chol(lsqamd_fit *f);
 int do_covariance(lsqamd_fit *f) {
   f->cov_inaccurate = false;
-  if (f->opt.solver == LSQAMD_SOLVER_QR) return do_covariance_qr(f);
+  f->cov_dropped = 0;
+  const int rc = f->opt.solver == LSQAMD_SOLVER_QR ? do_covariance_qr(f) : do_covariance_chol(f);
+  if (rc == LSQAMD_ENOTPD) {
+    // a rank-deficient final Jacobian: the reference's plugins return a truncated inverse there (rankdef.hip)
+    const std::string keep = f->err;
+    const int k = covariance_rank_deficient(f);
+    if (k > 0) {
+      f->cov_dropped = k;
+      return 0;
+    }
+    f->err = keep;
+  }
+  return rc;
+}
+
+static int do_covariance_chol(lsqamd_fit *f) {
   const int64_t P = f->P;
   Scope sc(f, LSQAMD_T_COVAR);
   int32_t info = 0;
@@ -1796,7 +1812,7 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
   const int rc = do_covariance(f);
   if (f->timing) resolve_timers(f);
   fill_summary(f, out, 0, 0);
-  if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : (rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : 0);
+  if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : (rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : (rc == 0 ? f->cov_dropped : 0));
   return rc == LSQAMD_ENOTPD ? 0 : rc;
 }
 
@@ -1853,7 +1869,7 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   if (out) {
     out->t_run_ms = ms;
     // LSQAMD_ENOTPD: J^T J singular at the end point, cov / logdet undefined; LSQAMD_EINACCURATE: delivered, degraded
-    out->cov_status = rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : rc;
+    out->cov_status = rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : (rc == 0 ? f->cov_dropped : rc);
   }
   return 0;
 }

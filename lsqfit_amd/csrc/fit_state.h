@@ -91,6 +91,7 @@ struct lsqamd_fit {
   size_t qr_work_bytes = 0;
   int32_t qr_passes = 0;
   double qr_delta = NAN;
+  int32_t cov_dropped = 0;       // > 0: the last covariance is the reference's truncated inverse with that many directions dropped
   bool cov_inaccurate = false;   // the last covariance was delivered from a factorisation that did not meet its accuracy test
 
   // box bounds of the reflective trust-region method (empty: none)
@@ -197,6 +198,7 @@ int do_reduce(lsqamd_fit *f, double *buf, int64_t count);
 // (J^T J)^-1 and log det J^T J at the current point: normal equations (api.hip) / CholeskyQR (qr.hip)
 int do_covariance(lsqamd_fit *f);
 int do_covariance_qr(lsqamd_fit *f);
+int covariance_rank_deficient(lsqamd_fit *f);   // rankdef.hip
 size_t qr_work_bytes(const lsqamd_fit *f);
 // whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return; counts one nfev
 int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out);

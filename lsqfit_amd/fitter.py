@@ -51,10 +51,11 @@ def normalize_tol(tol):
 
 def _cov_failed(fit, summary):
     """A rank-deficient J^T J at the end point must not look like a clean fit."""
+    fit.cov_dropped = max(0, int(summary.cov_status))   # > 0: rank-deficient Jacobian, the reference's truncated inverse
     if summary.cov_status == -9:      # LSQAMD_EINACCURATE: delivered, but not to the accuracy the route promises
         warnings.warn('lsqfit_amd: the orthogonalisation behind the covariance did not converge '
                       '(nearly rank-deficient Jacobian); covariance and logGBF may be inaccurate')
-    elif summary.cov_status != 0:
+    elif summary.cov_status < 0:
         msg = 'J^T J is not positive definite at the solution: covariance and logGBF are undefined'
         warnings.warn('lsqfit_amd: ' + msg)
         if fit.error is None:

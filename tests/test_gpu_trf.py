@@ -125,11 +125,21 @@ def test_reference_scipy_least_squares_case_on_device(amd):
                        for i, a in enumerate(xans))
     model = amd.expr(terms, ['p0', 'p1', 'p2'], xnames=('s0', 's1', 's2'))
     pr = amd.DeviceProblem(model, np.eye(3), amd.Whitening(np.zeros(3), np.ones(3)))
-    ans = amd.mi355x_trf(np.ones(3), 3, None, tol=(1e-15, 1e-8, 1e-15), method='trf', problem=pr)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                   # no "covariance undefined": the reference returns one
+        ans = amd.mi355x_trf(np.ones(3), 3, None, tol=(1e-15, 1e-8, 1e-15), method='trf', problem=pr)
     np.testing.assert_allclose(ans.x, xans, rtol=1e-3)
     assert ans.stopping_criterion == 2
     f = lambda x: (x - xans) ** 2 + (x - xans) ** 4
     df = lambda x: np.diag(2 * (x - xans) + 4 * (x - xans) ** 3)
+    # covariance: the thresholded-SVD pseudo-inverse of src/lsqfit/_scipy.py:170-175 at the end point; x0[0] sits
+    # on its optimum, so the first column of the Jacobian is zero and that direction is dropped
+    _, sv, VT = np.linalg.svd(df(ans.x), full_matrices=False)
+    keep = sv > np.finfo(float).eps * 3 * sv[0]
+    want = (VT[keep].T / sv[keep] ** 2) @ VT[keep]
+    assert ans.error is None and ans.cov_dropped == 1 and int(np.sum(~keep)) == 1
+    assert gu.relmax(ans.cov, want) < 1e-6
     ref = trf.scipy_least_squares(np.ones(3), 3, f, df, tol=(1e-15, 1e-8, 1e-15))
     # x0[0] sits exactly on its optimum: a zero Jacobian column, where scipy's SVD iteration takes
     # negative shifts; the device keeps B + alpha positive definite, so only the end point is compared

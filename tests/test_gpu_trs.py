@@ -2,8 +2,12 @@
 (alg = lmaccel / dogleg / ddogleg / subspace2D, src/lsqfit/_gsl.pyx:622-635) on the device,
 against the oracle's restatement and the reference's own assertions
 (tests/test_lsqfit.py:1700-1725).  Converged values to 1e-6; trajectories are unpinned."""
+import warnings
+
 import numpy as np
 import pytest
+
+from oracle import lm as olm
 
 from oracle import fit as ofit
 from tests import gpu_util as gu
@@ -34,9 +38,23 @@ def test_gsl_multifit_cases_on_device(amd):
     pr = amd.DeviceProblem(model, np.eye(3), wh)
     for c in k['cases'] + [dict(x0=[0., 0., 0.], alg=a, tol=[1e-10, 0.0, 0.0], stopping_criterion=1,
                                 rtol=1e-3) for a in ('dogleg', 'ddogleg')]:
-        ans = amd.mi355x_lm(np.array(c['x0']), 3, None, tol=tuple(c['tol']), alg=c['alg'], problem=pr)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')               # in particular: no "covariance undefined"
+            ans = amd.mi355x_lm(np.array(c['x0']), 3, None, tol=tuple(c['tol']), alg=c['alg'], problem=pr)
         np.testing.assert_allclose(ans.x, xans, rtol=c['rtol'])
         assert ans.stopping_criterion == c['stopping_criterion'], c
+        # the covariance the reference's plugin returns: gsl_multifit_nlinear_covar(J, 0.0) at the end point
+        # (src/lsqfit/_gsl.pyx:704-706), in the oracle's restatement -- also when x0[0] sits on its optimum
+        # and the first column of J is zero for the whole fit (the dropped direction: zero row and column)
+        J = np.diag(2 * (ans.x - xans) + 4 * (ans.x - xans) ** 3)
+        lin = olm._DenseLin('qr')
+        lin.set(J, np.zeros(3))
+        want = lin.covar()
+        assert ans.error is None
+        assert gu.relmax(ans.cov, want) < 1e-6
+        assert ans.cov_dropped == int(np.sum(np.diag(J) == 0.0))
+        if c['x0'][0] == 1.0:
+            assert ans.cov_dropped == 1 and np.all(ans.cov[0] == 0.0) and np.all(ans.cov[:, 0] == 0.0)
     assert amd.mi355x_lm(np.zeros(3), 3, None, alg='lmaccel', problem=pr).description == \
         'methods = lmaccel/more/cholesky    avmax = 0.75'
     with pytest.raises(ValueError):
