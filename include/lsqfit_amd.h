@@ -172,7 +172,8 @@ typedef struct {
                                * logdet_jtj = -inf; LSQAMD_EINACCURATE; or LSQAMD_ENOTPD: J^T J is not positive definite at the end point --
                                * cov and logdet_jtj (NaN) are undefined (gsl_multifit_nlinear_covar has no
                                * such report: its QR-based inverse returns garbage silently) */
-  int32_t reserved0;
+  int32_t qr_trials;          /* solver = qr: trial steps whose damped system had no Cholesky factor and was solved from the
+                               * orthogonal factorisation of [J ; sqrt(mu) D] instead (what gsl's qr solver does every time) */
   double chi2;                /* sum f**2, __init__.py:667 */
   double mu;                  /* final LM parameter */
   double logdet_jtj;          /* log det(J^T J) at the end (for logGBF, __init__.py:719) */

@@ -35,7 +35,7 @@ class Options(C.Structure):
 class Summary(C.Structure):
     _fields_ = [('status', C.c_int32), ('info', C.c_int32), ('stopping_criterion', C.c_int32),
                 ('nit', C.c_int32), ('nfev', C.c_int32), ('njev', C.c_int32), ('ntrial', C.c_int32),
-                ('chol_fail', C.c_int32), ('cov_status', C.c_int32), ('reserved0', C.c_int32),
+                ('chol_fail', C.c_int32), ('cov_status', C.c_int32), ('qr_trials', C.c_int32),
                 ('chi2', C.c_double), ('mu', C.c_double),
                 ('logdet_jtj', C.c_double), ('t_setup_ms', C.c_double), ('t_run_ms', C.c_double)]
 

@@ -953,7 +953,9 @@ static int enqueue_trial(lsqamd_fit *f) {
   double *gvec = f->redbuf + f->npk;
   int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false, f->lmd + LMS_MU);
   if (rc) return rc;
-  HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
+  const bool watch = f->opt.solver == LSQAMD_SOLVER_QR;    // solver = qr: how much of each column its pivot retained
+  HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd, watch ? f->M : nullptr, f->ldm,
+                            watch ? f->diag_dev : nullptr));
   const bool alone = !f->comm && !f->reduce;
   rc = eval_residual_launch(f, f->p_trial, alone);
   if (rc) return rc;
@@ -1026,13 +1028,52 @@ int iterate_device(lsqamd_fit *f) {
   double *gvec = f->redbuf + f->npk;
   int bad_steps = 0;
   while (true) {
-    int rc = run_half(f, 0, enqueue_trial);
-    if (rc) return rc;
-    HIPCHK(f, hipStreamSynchronize(f->st));
+    const double mu0 = f->mu, delta0 = f->delta;
+    const long nu0 = f->nu;
     const double *st = f->pin_lm;
+    const bool can_qr = f->opt.solver == LSQAMD_SOLVER_QR && f->qr_work && !f->comm && !f->reduce;
+    int rc = 0;
+    bool need_qr = can_qr && f->qr_steps_on;
+    if (!need_qr) {
+      rc = run_half(f, 0, enqueue_trial);
+      if (rc) return rc;
+      HIPCHK(f, hipStreamSynchronize(f->st));
+      // solver = qr (the reference's default, src/lsqfit/_gsl.pyx:571,646-647): gsl factors [J ; sqrt(mu) D] itself, error
+      // ~ cond eps; the damped normal equations have just gone through cond^2 ~ 1 / PIVMIN.  Once a trial's factor
+      // retains less than 1e-8 of some column (or has no positive pivot at all), this fit's steps come from the
+      // orthogonal factorisation (solve_damped_qr) -- the trial just taken included: the device's decision on it is
+      // taken back (mu, nu, delta as before) and the trial is repeated with the accurate step
+      if (can_qr && (st[LMS_SOLVED] == 0.0 || st[LMS_PIVMIN] < 1e-8)) {
+        if (st[LMS_SOLVED] == 0.0) f->chol_fail++;
+        f->qr_steps_on = true;
+        need_qr = true;
+      }
+    }
     f->ntrial++;
+    if (need_qr) {
+      double *rec = f->pin_lm;
+      rec[LMS_MU] = mu0; rec[LMS_NU] = (double)nu0; rec[LMS_DELTA] = delta0;
+      rec[LMS_ACCEPT] = 0.0; rec[LMS_SOLVED] = 0.0;
+      HIPCHK(f, hipMemcpyAsync(f->lmd, rec, sizeof(double) * LMS_COUNT, hipMemcpyHostToDevice, f->st));
+      rc = solve_damped_qr(f, mu0);
+      if (rc < 0 && rc != LSQAMD_ENOTPD && rc != LSQAMD_EUNSUPPORTED) return rc;
+      if (rc == 0) {
+        HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
+        rc = eval_residual_launch(f, f->p_trial, true);
+        if (rc) return rc;
+        HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+        HIPCHK(f, hipStreamSynchronize(f->st));
+        if (st[LMS_SOLVED] != 0.0) f->qr_trials++;
+      } else {   // no orthogonal factor either: the trial is rejected (mu grows)
+        f->chol_fail++;
+        rec[LMS_MU] = mu0 * (double)nu0; rec[LMS_NU] = 2.0 * (double)nu0;
+        HIPCHK(f, hipMemcpyAsync(f->lmd, rec, sizeof(double) * LMS_COUNT, hipMemcpyHostToDevice, f->st));
+        HIPCHK(f, hipStreamSynchronize(f->st));
+      }
+    } else if (st[LMS_SOLVED] == 0.0) {
+      f->chol_fail++;
+    }
     if (st[LMS_SOLVED] != 0.0) f->nfev++;   // (a residual evaluated at garbage is not a trial)
-    else f->chol_fail++;
     f->mu = st[LMS_MU];
     f->nu = (long)st[LMS_NU];
     f->delta = st[LMS_DELTA];
@@ -1219,7 +1260,8 @@ int do_init(lsqamd_fit *f, const double *p0) {
   f->hdx.assign(P, 0.0);
   f->hv.assign(P, 0.0);
   f->hcoln.assign(P, 0.0);
-  f->nit = f->nfev = f->njev = f->ntrial = f->chol_fail = 0;
+  f->nit = f->nfev = f->njev = f->ntrial = f->chol_fail = f->qr_trials = 0;
+  f->qr_steps_on = false;
   f->logdet = NAN;
   HIPCHK(f, hipMemcpyAsync(f->p_dev, p0, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
   rc = eval_normal_dev(f, f->p_dev);
@@ -1280,6 +1322,7 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
   } else s->stopping_criterion = 0;
   s->nit = f->nit; s->nfev = f->nfev; s->njev = f->njev; s->ntrial = f->ntrial;
   s->chol_fail = f->chol_fail;
+  s->qr_trials = f->qr_trials;
   s->chi2 = f->chi2;
   s->mu = f->mu;
   s->logdet_jtj = f->logdet;

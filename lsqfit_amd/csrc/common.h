@@ -227,9 +227,12 @@ hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, 
 hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt);
 // LM state record on the device (plain lm; vecops.hip)
 enum { LMS_CHI2 = 0, LMS_MU, LMS_NU, LMS_DELTA, LMS_VG, LMS_DV2, LMS_VFINITE, LMS_RHO, LMS_CHI2_TRIAL, LMS_ACCEPT,
-       LMS_SOLVED, LMS_INFO, LMS_COUNT = 16 };
+       LMS_SOLVED, LMS_INFO, LMS_PIVMIN, LMS_COUNT = 16 };
+// U / ldu / a_diag given: state[LMS_PIVMIN] = min_i U_ii^2 / (a_diag_i + mu d_i^2), the smallest share of a column of the
+// damped matrix that its Cholesky pivot retained (1 / it ~ the condition number the solve has just gone through)
 hipError_t launch_lm_trial(hipStream_t st, int64_t P, const double *x, const double *v, const double *g,
-                           const double *d, double *xt, double *state);
+                           const double *d, double *xt, double *state, const double *U = nullptr, int64_t ldu = 0,
+                           const double *a_diag = nullptr);
 hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, double *partial, int64_t P,
                                 const double *prec, int32_t dense, const double *pmean, const double *p, double *tvec,
                                 bool with_prior, double *chi2_out, const int32_t *chol_info, double factor_up,

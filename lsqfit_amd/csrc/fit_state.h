@@ -113,6 +113,8 @@ struct lsqamd_fit {
   int32_t conv_info_dev = 0;
   bool initialised = false, have_cov = false, have_dense_A = false;
   int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
+  bool qr_steps_on = false;    // solver = qr: this fit's trial steps come from the orthogonal factorisation from now on
+  int32_t qr_trials = 0;       // trial steps solved from the orthogonal factorisation after a failed pivot (solver = qr)
   double logdet = NAN;
 
   // pinned host staging for the per-step transfers (pageable copies go through a blit
@@ -199,6 +201,8 @@ int do_reduce(lsqamd_fit *f, double *buf, int64_t count);
 int do_covariance(lsqamd_fit *f);
 int do_covariance_qr(lsqamd_fit *f);
 int covariance_rank_deficient(lsqamd_fit *f);   // rankdef.hip
+// (A + mu D^2) v = g through the CholeskyQR factor of [J ; W_prior ; sqrt(mu) D] (qr.hip): v -> f->yv[P..2P)
+int solve_damped_qr(lsqamd_fit *f, double mu);
 size_t qr_work_bytes(const lsqamd_fit *f);
 // whitened residual at device parameters p -> f->r ; chi2 (all ranks) on return; counts one nfev
 int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out);

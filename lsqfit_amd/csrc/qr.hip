@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void col_equil_kernel(const double *diag, int6
 
 // M (upper tiles) = cs_i cs_j A_ij + shift [i == j]   from packed tiles; cs may be null
 __global__ __launch_bounds__(256) void build_scaled_kernel(const double *apk, int64_t P, int64_t T, int64_t ld,
-                                                           const double *cs, double shift, double *M) {
+                                                           const double *cs, double shift, double *M,
+                                                           const double *extra = nullptr) {
   int64_t t = blockIdx.x, tm = 0;
   while (t >= T - tm) { t -= T - tm; ++tm; }
   const int64_t tn = tm + t;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void build_scaled_kernel(const double *apk, in
     const int64_t i = tm * TB + r, j = tn * TB + c;
     if (i < P && j < P) {
       double v = src[r * TB + c];
+      if (extra && i == j) v += extra[i];      // (the damping term mu D^2 of a trial solve)
       if (cs) v *= cs[i] * cs[j];
       if (i == j) v += shift;
       M[i * ld + j] = v;
@@ -153,9 +155,31 @@ __global__ __launch_bounds__(256) void sum_kernel(const double *v, int64_t n, do
   if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// e[j] = mu d[j]^2 ; diag[j] += e[j]
+__global__ __launch_bounds__(256) void damp_vec_kernel(int64_t P, double mu, const double *d, double *e, double *diag) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= P) return;
+  const double v = mu * d[j] * d[j];
+  e[j] = v;
+  diag[j] += v;
+}
+
+// T[i][:] += e[i] * B[i][:]
+__global__ __launch_bounds__(256) void rows_axpy_kernel(double *T, const double *B, int64_t ld, int64_t P, const double *e) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i = blockIdx.y;
+  if (j < P) T[i * ld + j] += e[i] * B[i * ld + j];
+}
+
+// out[j] = a[j] * b[j]
+__global__ __launch_bounds__(256) void vec_mul_kernel(int64_t P, const double *a, const double *b, double *out) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < P) out[j] = a[j] * b[j];
+}
+
 struct QrPlan {
   int64_t ldn;
-  double *T, *Q, *Ri, *Wtot, *Ritot, *T1, *Bm, *Gpk, *dc, *logdc, *part, *scal;
+  double *T, *Q, *Ri, *Wtot, *Ritot, *T1, *Bm, *Gpk, *dc, *logdc, *part, *scal, *damp, *dwork, *vwork;
   size_t bytes;
 };
 
@@ -182,6 +206,9 @@ QrPlan qr_plan(const lsqamd_fit *f, void *base) {
   const int64_t T = (P + TB - 1) / TB;
   p.part = take(T * (T + 1) / 2 * 16);
   p.scal = take(8);
+  p.damp = take(P);
+  p.dwork = take(P);
+  p.vwork = take(2 * P);
   p.bytes = off;
   return p;
 }
@@ -196,24 +223,20 @@ namespace lsqamd_host {
 
 size_t qr_work_bytes(const lsqamd_fit *f) { return qr_plan(f, nullptr).bytes + 256; }
 
-int do_covariance_qr(lsqamd_fit *f) {
+// [J ; W_prior ; sqrt(mu) D] D_c = Q R by shifted, re-orthogonalised CholeskyQR (mu = 0: no damping rows).
+// Leaves q.Wtot = R^-T (lower triangular), q.dc = D_c, *logdet_r = log det R; f->qr_passes / qr_delta say how it went.
+static int qr_factor(lsqamd_fit *f, QrPlan &q, double mu, double *logdet_out) {
   const int64_t P = f->P, N = f->N, ldm = f->ldm;
-  if (!f->qr_work) FAIL(f, LSQAMD_EINVAL, "solver = qr: call lsqamd_set_qr_work first (lsqamd_qr_work_bytes gives the size)");
-  char *base = (char *)f->qr_work;
-  const size_t pad = (size_t)((-(intptr_t)base) & 255);
-  QrPlan q = qr_plan(f, base + pad);
-  if (f->qr_work_bytes < q.bytes + pad) FAIL(f, LSQAMD_ENOMEM, "solver = qr: the work buffer needs %zu bytes", q.bytes + 256);
-  Scope sc(f, LSQAMD_T_COVAR);
   hipStream_t st = f->st;
   const int64_t T = (P + TB - 1) / TB;
   const dim3 tgrid((unsigned)(T * (T + 1) / 2), 16);
   const unsigned pb = (unsigned)((P + 255) / 256);
-  f->have_dense_A = false;   // Wl is reused below
-  f->have_cov = true;
-  f->logdet = NAN;
-  // D_c from the Gram matrix of the current point (all-reduced, prior included)
-  HIPCHK(f, launch_packed_diag(st, f->redbuf, P, f->diag_dev));
-  hipLaunchKernelGGL(col_equil_kernel, dim3(pb), dim3(256), 0, st, f->diag_dev, P, q.dc, q.logdc);
+  const bool damped = mu > 0.0;
+  const bool mine = f->adds_prior;            // the replicated terms (prior, damping) enter the sums on one rank
+  // D_c from the Gram matrix of the current point (all-reduced, prior included; + mu D^2 for a damped solve)
+  HIPCHK(f, launch_packed_diag(st, f->redbuf, P, q.dwork));
+  if (damped) hipLaunchKernelGGL(damp_vec_kernel, dim3(pb), dim3(256), 0, st, P, mu, f->dscale, q.damp, q.dwork);
+  hipLaunchKernelGGL(col_equil_kernel, dim3(pb), dim3(256), 0, st, q.dwork, P, q.dc, q.logdc);
   double logdet_r = 0.0, shift = 0.0, delta = INFINITY;
   const double *Gsrc = f->redbuf;
   const double *cs = q.dc;
@@ -222,7 +245,8 @@ int do_covariance_qr(lsqamd_fit *f) {
     // ---- R_k = chol(G_k) (pass 1: the equilibrated Gram matrix of the fit, shifted if it must be)
     int32_t info = 0;
     for (int attempt = 0; attempt < 6; ++attempt) {
-      hipLaunchKernelGGL(build_scaled_kernel, tgrid, dim3(256), 0, st, Gsrc, P, T, ldm, cs, shift, f->M);
+      hipLaunchKernelGGL(build_scaled_kernel, tgrid, dim3(256), 0, st, Gsrc, P, T, ldm, cs, shift, f->M,
+                         (damped && pass == 1) ? q.damp : nullptr);
       HIPCHK(f, potrf_upper(st, f->M, P, ldm, P, f->chol_work, f->info_dev));
       HIPCHK(f, hipMemcpyAsync(&info, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIPCHK(f, hipStreamSynchronize(st));
@@ -278,18 +302,24 @@ int do_covariance_qr(lsqamd_fit *f) {
       HIPCHK(f, hipMemsetAsync(f->slabs, 0, sizeof(double) * f->splits * P * ldm, st));
     }
     HIPCHK(f, launch_finalize_pack(st, f->slabs, f->splits, P * ldm, P, ldm, q.Gpk));
-    if (f->cfg.has_prior && f->adds_prior) {
-      // prior rows W_p D_c R^-1: their Gram matrix B^T Lambda B with B = D_c R^-1 (R^-1 = Wtot^T)
+    const bool with_prior = f->cfg.has_prior && mine;
+    if (with_prior || (damped && mine)) {
+      // prior rows W_p D_c R^-1 and damping rows sqrt(mu) D D_c R^-1: their Gram matrix B^T (Lambda + mu D^2) B
+      // with B = D_c R^-1 (R^-1 = Wtot^T)
       HIPCHK(f, launch_transpose_sq(st, q.Wtot, ldm, q.Ritot, ldm, P));
       HIPCHK(f, launch_rows_scale_copy(st, q.Ritot, ldm, q.Bm, ldm, P, P, q.dc, nullptr));
-      if (f->cfg.prior_dense) {
+      if (with_prior && f->cfg.prior_dense) {
         GemmTN a;   // T1 = Lambda B
         a.X = f->prior_prec; a.ldx = P; a.Y = q.Bm; a.ldy = ldm; a.C = q.T1; a.ldc = ldm;
         a.M = P; a.N = P; a.K = P;
         HIPCHK(f, launch_gemm_tn(st, a));
-      } else {
+      } else if (with_prior) {
         HIPCHK(f, launch_rows_scale_copy(st, q.Bm, ldm, q.T1, ldm, P, P, f->prior_prec, nullptr));
+      } else {
+        HIPCHK(f, launch_rows_scale_copy(st, q.Bm, ldm, q.T1, ldm, P, P, q.damp, nullptr));
       }
+      if (with_prior && damped)
+        hipLaunchKernelGGL(rows_axpy_kernel, dim3(pb, (unsigned)P), dim3(256), 0, st, q.T1, q.Bm, ldm, P, q.damp);
       GemmTN b;     // Ritot (reused as output) = B^T T1
       b.X = q.Bm; b.ldx = ldm; b.Y = q.T1; b.ldy = ldm; b.C = q.Ritot; b.ldc = ldm;
       b.M = P; b.N = P; b.K = P;
@@ -309,9 +339,31 @@ int do_covariance_qr(lsqamd_fit *f) {
   }
   f->qr_passes = pass;
   f->qr_delta = delta;
+  *logdet_out = logdet_r;
+  return 0;
+}
+
+int do_covariance_qr(lsqamd_fit *f) {
+  const int64_t P = f->P, ldm = f->ldm;
+  if (!f->qr_work) FAIL(f, LSQAMD_EINVAL, "solver = qr: call lsqamd_set_qr_work first (lsqamd_qr_work_bytes gives the size)");
+  char *base = (char *)f->qr_work;
+  const size_t pad = (size_t)((-(intptr_t)base) & 255);
+  QrPlan q = qr_plan(f, base + pad);
+  if (f->qr_work_bytes < q.bytes + pad) FAIL(f, LSQAMD_ENOMEM, "solver = qr: the work buffer needs %zu bytes", q.bytes + 256);
+  Scope sc(f, LSQAMD_T_COVAR);
+  hipStream_t st = f->st;
+  const unsigned pb = (unsigned)((P + 255) / 256);
+  f->have_dense_A = false;   // Wl is reused below
+  f->have_cov = true;
+  f->logdet = NAN;
+  double logdet_r = 0.0;
+  {
+    const int rc = qr_factor(f, q, 0.0, &logdet_r);
+    if (rc) return rc;
+  }
   // six passes without reaching |Q^T Q - I| < 1e-6 (shift escalations on a nearly rank-deficient J):
   // the factor is not the R of an orthogonal Q -- say so instead of passing for a cond(J) eps result
-  f->cov_inaccurate = !(delta < 1e-6);
+  f->cov_inaccurate = !(f->qr_delta < 1e-6);
   // cov = D_c (Wtot^T Wtot) D_c
   GemmTN g;
   g.X = q.Wtot; g.Y = q.Wtot; g.ldx = g.ldy = ldm;
@@ -327,6 +379,41 @@ int do_covariance_qr(lsqamd_fit *f) {
   HIPCHK(f, hipMemcpyAsync(&sumlogdc, q.scal, sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(f, hipStreamSynchronize(st));
   f->logdet = 2.0 * logdet_r - 2.0 * sumlogdc;
+  return 0;
+}
+
+// The damped step of an LM trial from an orthogonal factorisation, as gsl's qr solver computes it
+// (src/lsqfit/_gsl.pyx:646-647; the reference's default): min |J v - f|^2 + mu |D v|^2 through the factor R of
+// [J ; W_prior ; sqrt(mu) D], v = R^-1 R^-T g with g = J^T f formed from J itself.  Called when the Cholesky
+// factorisation of the damped normal equations has met a non-positive pivot (cond(J D^-1)^2 beyond 1/eps at a
+// small mu): GSL proceeds there, and so does this -- instead of rejecting the trial and inflating mu.
+// v -> f->yv[P .. 2P) (where the trial-point kernel reads it), *f->info_dev <- 0.
+int solve_damped_qr(lsqamd_fit *f, double mu) {
+  const int64_t P = f->P, ldm = f->ldm;
+  if (!f->qr_work) return LSQAMD_EUNSUPPORTED;
+  char *base = (char *)f->qr_work;
+  const size_t pad = (size_t)((-(intptr_t)base) & 255);
+  QrPlan q = qr_plan(f, base + pad);
+  if (f->qr_work_bytes < q.bytes + pad) return LSQAMD_EUNSUPPORTED;
+  Scope sc(f, LSQAMD_T_CHOLESKY);
+  hipStream_t st = f->st;
+  const unsigned pb = (unsigned)((P + 255) / 256);
+  f->have_dense_A = false;
+  f->have_cov = false;
+  double logdet_r = 0.0;
+  const std::string keep = f->err;
+  const int rc = qr_factor(f, q, mu, &logdet_r);
+  if (rc == LSQAMD_ENOTPD) { f->err = keep; return LSQAMD_ENOTPD; }
+  if (rc) return rc;
+  if (!(f->qr_delta < 1e-6)) return LSQAMD_ENOTPD;          // not an orthogonal factor: let the caller reject the trial
+  const double *g = f->redbuf + f->npk;
+  double *y = q.vwork, *t = q.vwork + P;
+  hipLaunchKernelGGL(vec_mul_kernel, dim3(pb), dim3(256), 0, st, P, q.dc, g, y);              // y = D_c g
+  HIPCHK(f, launch_gemv_rows(st, q.Wtot, ldm, P, P, y, t));                                    // t = R^-T y
+  HIPCHK(f, launch_transpose_sq(st, q.Wtot, ldm, q.Ritot, ldm, P));                            // R^-1
+  HIPCHK(f, launch_gemv_rows(st, q.Ritot, ldm, P, P, t, y));                                   // y = R^-1 t
+  hipLaunchKernelGGL(vec_mul_kernel, dim3(pb), dim3(256), 0, st, P, q.dc, y, f->yv + P);       // v = D_c y
+  HIPCHK(f, hipMemsetAsync(f->info_dev, 0, sizeof(int32_t), st));
   return 0;
 }
 

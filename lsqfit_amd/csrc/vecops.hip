@@ -757,9 +757,11 @@ __device__ __forceinline__ double block_sum(double a, double *sh) {
 // trial point + the two dot products of the gain ratio:  xt = x - v,  st[VG] = v.g,  st[DV2] = |D v|^2,
 // st[VFINITE] = 1 when every component of v is finite
 __global__ __launch_bounds__(256) void lm_trial_kernel(int64_t P, const double *x, const double *v, const double *g,
-                                                       const double *d, double *xt, double *st) {
+                                                       const double *d, double *xt, double *st, const double *U, int64_t ldu,
+                                                       const double *a_diag) {
   __shared__ double sh[4];
-  double vg = 0.0, dv2 = 0.0, bad = 0.0;
+  double vg = 0.0, dv2 = 0.0, bad = 0.0, pmin = INFINITY;
+  const double mu = st[LMS_MU];
   for (int64_t j = threadIdx.x; j < P; j += 256) {
     const double vj = v[j];
     xt[j] = x[j] - vj;
@@ -767,20 +769,34 @@ __global__ __launch_bounds__(256) void lm_trial_kernel(int64_t P, const double *
     const double t = d[j] * vj;
     dv2 += t * t;
     bad += (vj - vj == 0.0) ? 0.0 : 1.0;   // NaN / inf
+    if (U) {
+      const double u = U[j * ldu + j], m = a_diag[j] + mu * d[j] * d[j];
+      const double r = m > 0.0 ? u * u / m : 1.0;
+      pmin = r < pmin ? r : pmin;          // (a NaN pivot never wins: the factorisation's own status reports it)
+    }
   }
   vg = block_sum(vg, sh);
   dv2 = block_sum(dv2, sh);
   bad = block_sum(bad, sh);
+  if (U) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pmin;
+    __syncthreads();
+    pmin = fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3]));
+  }
   if (threadIdx.x == 0) {
     st[LMS_VG] = vg;
     st[LMS_DV2] = dv2;
     st[LMS_VFINITE] = bad == 0.0 ? 1.0 : 0.0;
+    st[LMS_PIVMIN] = U ? pmin : 1.0;
   }
 }
 
 hipError_t launch_lm_trial(hipStream_t stream, int64_t P, const double *x, const double *v, const double *g,
-                           const double *d, double *xt, double *st) {
-  hipLaunchKernelGGL(lm_trial_kernel, dim3(1), dim3(256), 0, stream, P, x, v, g, d, xt, st);
+                           const double *d, double *xt, double *st, const double *U, int64_t ldu, const double *a_diag) {
+  hipLaunchKernelGGL(lm_trial_kernel, dim3(1), dim3(256), 0, stream, P, x, v, g, d, xt, st, U, ldu, a_diag);
   return hipGetLastError();
 }
 

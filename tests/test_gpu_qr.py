@@ -71,3 +71,27 @@ def test_ill_conditioned_covariance(amd, P, prior):
     assert np.max(np.abs(fit.pmean - ref.pmean) / ref.psdev) < 1e-5
     if prior:
         assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-9, abs=1e-6)
+
+
+@pytest.mark.parametrize('P', [8, 10, 11, 12])
+def test_qr_grade_trial_steps_follow_the_reference_solver(amd, P):
+    """solver='qr' is the reference's default (src/lsqfit/_gsl.pyx:571,646-647): gsl factors [J ; sqrt(mu) D] itself.
+    Monomial-basis fits with cond(J D^-1) from 1e9 (P = 8) upwards: once the damping has shrunk to where the damped
+    normal equations retain less than 1e-8 of a column, the device's trial steps come from the orthogonal
+    factorisation too (summary.qr_trials) and the fit follows the oracle's Householder-QR trajectory: same number of
+    iterations (+-1; the normal equations alone wander off by several rejected trials), same end point."""
+    x, text, V = hilbert_like(P)
+    rng = np.random.default_rng(P)
+    ysd = np.full(x.size, 1e-3)
+    y = V @ rng.standard_normal(P) + ysd * rng.standard_normal(x.size)
+    model = amd.expr(text, ['c%d' % n for n in range(P)])
+    fit = amd.nonlinear_fit(data=(x, y, ysd), model=model, solver='qr', tol=1e-12, p0=np.zeros(P))
+    ref = ofit.nonlinear_fit(x, y, ysd, lambda xx, p: V @ p, jac=lambda xx, p: V, solver='qr', tol=1e-12, p0=np.zeros(P))
+    s = fit.fitter_results.summary
+    print('P = %d: nit %d (oracle qr %d), %d of %d trials from the orthogonal factorisation' % (P, fit.nit, ref.nit, s.qr_trials, s.ntrial))
+    assert abs(fit.nit - ref.nit) <= 1
+    assert fit.stopping_criterion == ref.stopping_criterion
+    assert (s.qr_trials > 0) == (P > 8)
+    assert abs(fit.chi2 - ref.chi2) < 1e-8 * ref.chi2
+    assert np.max(np.abs(fit.pmean - ref.pmean) / ref.psdev) < 1e-5
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
