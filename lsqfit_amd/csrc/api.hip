@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <new>
 #include <string>
 #include <vector>
@@ -88,7 +90,10 @@ int32_t choose_splits(int64_t N, int64_t P) {
   // with 1 / 2 / 3 / 4 / 8 chunks and the read-back 0.06 / 0.07 / 0.09 / 0.10 / 0.16 ms: four.
   int64_t s = (2048 + tiles - 1) / tiles;
   if (s < N / 4096) s = N / 4096;
-  const int64_t maxs = N / 256 > 1 ? N / 256 : 1;
+  // (few tiles: chunks down to 64 rows -- at (4096, 256) three tiles times 16 chunks are 48 workgroups on 256 CUs and the
+  // product takes 40 us; 64 chunks: 21 us, the longer read-back of the slabs included in the balance below)
+  const int64_t minrows = tiles <= 10 ? 64 : 256;
+  const int64_t maxs = N / minrows > 1 ? N / minrows : 1;
   if (s > maxs) s = maxs;
   // ... except for FEW parameters and many rows (the usual shape of a fit): one or three tiles times 16 chunks
   // leaves 240 of the 256 CUs idle (N = 65536, P = 64: 0.62 ms for a product that reads 34 MB).  Slabs are
@@ -292,12 +297,19 @@ int residual_vector_launch(lsqamd_fit *f, const double *p) {
 // Launches only: nothing is waited for.
 // decide: a single rank's trial -- the sum of squares' second stage, the prior's share and the LM decision in
 // one launch (lm_trial_tail_kernel); with ranks to sum over the scalar is exchanged first and the caller decides
+static bool small_fuse(const lsqamd_fit *f);
 int eval_residual_launch(lsqamd_fit *f, const double *p, bool decide = false) {
   f->r_fresh = false;
   if (decide) {
     Scope sc(f, LSQAMD_T_RESIDUAL);
     const int rc = residual_vector_launch(f, p);
     if (rc) return rc;
+    const bool wp = f->cfg.has_prior && f->adds_prior;
+    if (small_fuse(f) && f->N <= 65536 && !(wp && f->cfg.prior_dense)) {
+      HIPCHK(f, launch_lm_trial_tail_small(f->st, f->r, f->N, f->P, wp ? f->prior_prec : nullptr, f->prior_mean, p, f->tvec,
+                                           f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
+      return 0;
+    }
     HIPCHK(f, launch_lm_trial_tail(f->st, f->r, f->N, f->partial, f->P, f->prior_prec, f->cfg.prior_dense,
                                    f->prior_mean, p, f->tvec, f->cfg.has_prior && f->adds_prior, f->red_scalar,
                                    f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
@@ -480,7 +492,8 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
                                    with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
     if (fused_chunks == 0)
       HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
-    if (with_prior)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)
+    f->prior_deferred = with_prior && r_here && !mirror && small_fuse(f);
+    if (with_prior && !f->prior_deferred)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)
       HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
                                  f->prior_mean, p, f->tvec, gvec, 0, r_here ? 1 : 0));
   }
@@ -515,7 +528,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
 // an SDMA upload followed by a dependent kernel costs ~100 us of cross-engine synchronisation)
 // frozen_host (with mu = 0, dogbox): flags of the parameters taken out of the system
 int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr,
-                        bool fetch = true, const double *mu_dev = nullptr) {
+                        bool fetch = true, const double *mu_dev = nullptr, bool factor_only = false) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
   {
@@ -532,6 +545,7 @@ int solve_damped_launch(lsqamd_fit *f, double mu, const double *diag_host, const
     HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, mu, dd, gvec, f->M, frozen, mu_dev, f->info_dev));
     HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->info_dev, true));
   }
+  if (factor_only) return 0;    // (small systems: the caller's single-workgroup kernel does the rest)
   {
     Scope sc(f, LSQAMD_T_SOLVE);
     HIPCHK(f, launch_copy_column_zero(f->st, f->M + P, f->ldm, f->yv, P, f->yv + 2 * P, backsolve_scratch_bytes(P)));
@@ -948,20 +962,33 @@ int refresh_mirrors(lsqamd_fit *f) {
 // The two halves of a device-resident LM step as launch sequences (no host reads in between), so that
 // each can be captured once per p-buffer parity and replayed: small problems spend more host time
 // launching their ~35 kernels than the GPU spends running them.
+// small single-rank fits: fused single-workgroup tails (LSQAMD_SMALL_FUSE=0: the general kernels)
+static bool small_fuse(const lsqamd_fit *f) {
+  static const bool off = [] { const char *e = getenv("LSQAMD_SMALL_FUSE"); return e && e[0] == '0'; }();
+  return !off && !f->comm && !f->reduce;
+}
+
 static int enqueue_trial(lsqamd_fit *f) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
-  int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false, f->lmd + LMS_MU);
+  const bool small = small_fuse(f) && (P == 128 || P == 256);   // (whole 128-blocks: the kernel's GEMVs read full tiles)
+  int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false, f->lmd + LMS_MU, small);
   if (rc) return rc;
   const bool watch = f->opt.solver == LSQAMD_SOLVER_QR;    // solver = qr: how much of each column its pivot retained
-  HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd, watch ? f->M : nullptr, f->ldm,
-                            watch ? f->diag_dev : nullptr));
+  if (small) {
+    Scope sc(f, LSQAMD_T_SOLVE);
+    HIPCHK(f, launch_lm_solve_tail_small(f->st, f->M, f->ldm, P, f->chol_work, f->p_dev, gvec, f->dscale, f->p_trial, f->yv + P,
+                                         f->lmd, watch ? f->diag_dev : nullptr, f->info_dev));
+  } else {
+    HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd, watch ? f->M : nullptr, f->ldm,
+                              watch ? f->diag_dev : nullptr));
+  }
   const bool alone = !f->comm && !f->reduce;
   rc = eval_residual_launch(f, f->p_trial, alone);
   if (rc) return rc;
   if (!alone)
     HIPCHK(f, launch_lm_decide(f->st, f->red_scalar, f->info_dev, f->opt.factor_up, f->opt.factor_down, f->lmd));
-  HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+  if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
   return 0;
 }
 
@@ -972,9 +999,10 @@ static int enqueue_accept(lsqamd_fit *f) {   // p_trial becomes the point; the c
   f->r_ptr = f->p_trial;
   int rc = eval_normal_dev(f, f->p_trial, false);
   if (rc) return rc;
+  // (prior_deferred: g += Lambda (p - pbar), chi2 += ... inside the tail kernel -- one launch fewer)
   HIPCHK(f, launch_lm_accept_tail(f->st, f->redbuf, P, f->opt.scaler, f->diag_dev, f->dscale, f->p_trial, f->yv + P, gvec,
-                                  f->opt.xtol, f->opt.gtol, f->lmd));
-  HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+                                  f->opt.xtol, f->opt.gtol, f->lmd, f->prior_deferred ? f->tvec : nullptr, f->prior_mean));
+  if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
   return 0;
 }
 
@@ -1023,6 +1051,27 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
   return 0;
 }
 
+// The record of the half step just queued has arrived in pin_lm.  With the kernels mirroring it themselves (zero copy)
+// the host POLLS the mirror's sequence number for a while before it falls back to a stream synchronisation: waking
+// from the latter costs ~15 us of the ~27 us between two half steps of a small fit (LSQAMD_POLL=0: always synchronise).
+static int wait_record(lsqamd_fit *f) {
+  static const bool poll = [] { const char *e = getenv("LSQAMD_POLL"); return !(e && e[0] == '0'); }();
+  f->lm_seq_expect += 1.0;
+  if (f->lm_zero_copy && poll) {
+    volatile double *h = f->pin_lm;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1;; ++spins) {
+      if (h[LMS_SEQ] >= f->lm_seq_expect) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return 0;
+      }
+      if ((spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(3000)) break;
+    }
+  }
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  return 0;
+}
+
 int iterate_device(lsqamd_fit *f) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
@@ -1031,13 +1080,15 @@ int iterate_device(lsqamd_fit *f) {
     const double mu0 = f->mu, delta0 = f->delta;
     const long nu0 = f->nu;
     const double *st = f->pin_lm;
-    const bool can_qr = f->opt.solver == LSQAMD_SOLVER_QR && f->qr_work && !f->comm && !f->reduce;
+    static const bool qr_steps_off = [] { const char *e = getenv("LSQAMD_QR_STEPS"); return e && e[0] == '0'; }();   // developer knob
+    const bool can_qr = f->opt.solver == LSQAMD_SOLVER_QR && f->qr_work && !f->comm && !f->reduce && !qr_steps_off;
     int rc = 0;
     bool need_qr = can_qr && f->qr_steps_on;
     if (!need_qr) {
       rc = run_half(f, 0, enqueue_trial);
       if (rc) return rc;
-      HIPCHK(f, hipStreamSynchronize(f->st));
+      rc = wait_record(f);
+      if (rc) return rc;
       // solver = qr (the reference's default, src/lsqfit/_gsl.pyx:571,646-647): gsl factors [J ; sqrt(mu) D] itself, error
       // ~ cond eps; the damped normal equations have just gone through cond^2 ~ 1 / PIVMIN.  Once a trial's factor
       // retains less than 1e-8 of some column (or has no positive pivot at all), this fit's steps come from the
@@ -1061,8 +1112,9 @@ int iterate_device(lsqamd_fit *f) {
         HIPCHK(f, launch_lm_trial(f->st, P, f->p_dev, f->yv + P, gvec, f->dscale, f->p_trial, f->lmd));
         rc = eval_residual_launch(f, f->p_trial, true);
         if (rc) return rc;
-        HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
-        HIPCHK(f, hipStreamSynchronize(f->st));
+        if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+        rc = wait_record(f);
+        if (rc) return rc;
         if (st[LMS_SOLVED] != 0.0) f->qr_trials++;
       } else {   // no orthogonal factor either: the trial is rejected (mu grows)
         f->chol_fail++;
@@ -1081,7 +1133,8 @@ int iterate_device(lsqamd_fit *f) {
       rc = run_half(f, 1, enqueue_accept);
       if (rc) return rc;
       std::swap(f->p_dev, f->p_trial);
-      HIPCHK(f, hipStreamSynchronize(f->st));
+      rc = wait_record(f);
+      if (rc) return rc;
       f->chi2 = f->pin_lm[LMS_CHI2];
       f->conv_info_dev = (int32_t)f->pin_lm[LMS_INFO];
       if (!std::isfinite(f->chi2)) FAIL(f, LSQAMD_ENONFINITE, "chi2 is not finite at this point");
@@ -1092,8 +1145,9 @@ int iterate_device(lsqamd_fit *f) {
       // well, with the last (rejected) trial step as dx: at a minimum resolved to rounding that
       // step is below xtol and the fit ends on criterion 1
       HIPCHK(f, launch_lm_converge(f->st, P, f->p_dev, f->yv + P, gvec, f->opt.xtol, f->opt.gtol, f->lmd));
-      HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
-      HIPCHK(f, hipStreamSynchronize(f->st));
+      if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+      rc = wait_record(f);
+      if (rc) return rc;
       f->conv_info_dev = (int32_t)f->pin_lm[LMS_INFO];
       return LSQAMD_ENOPROG;
     }
@@ -1299,6 +1353,15 @@ int do_init(lsqamd_fit *f, const double *p0) {
     for (int i = 0; i < LMS_COUNT; ++i) f->pin_lm[i] = 0.0;
     f->pin_lm[LMS_CHI2] = f->chi2; f->pin_lm[LMS_MU] = f->mu; f->pin_lm[LMS_NU] = (double)f->nu;
     f->pin_lm[LMS_DELTA] = f->delta;
+    {   // the kernels that finish a half step mirror the record into this pinned block themselves (LSQAMD_ZERO_COPY=0: a copy per read)
+      static const bool off = [] { const char *e = getenv("LSQAMD_ZERO_COPY"); return e && e[0] == '0'; }();
+      void *dp = nullptr;
+      f->lm_zero_copy = !off && hipHostGetDevicePointer(&dp, f->pin_lm, 0) == hipSuccess && dp != nullptr;
+      if (!f->lm_zero_copy) (void)hipGetLastError();
+      long long bits = f->lm_zero_copy ? (long long)(intptr_t)dp : 0;
+      std::memcpy(&f->pin_lm[LMS_HOSTPTR], &bits, sizeof(double));
+      f->lm_seq_expect = 0.0;
+    }
     HIPCHK(f, hipMemcpyAsync(f->lmd, f->pin_lm, sizeof(double) * LMS_COUNT, hipMemcpyHostToDevice, f->st));
     HIPCHK(f, hipStreamSynchronize(f->st));
   }

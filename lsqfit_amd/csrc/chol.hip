@@ -554,6 +554,79 @@ __device__ __forceinline__ void gemv32(const double *M, int64_t ld, const double
   }
 }
 
+
+// ---- small systems (n = 128 or 256): the rest of a trial solve in ONE single-workgroup launch -------------------
+// After potrf_upper the factor U sits in M, column n of M holds y = U^-T g (the forward substitution rode along with
+// the row panels) and uinv the inverses of the diagonal blocks.  This kernel is the back substitution v = U^-1 y (at
+// most three 128 x 128 GEMVs, every wave's 32 rows requested at once: gemv32), the trial point x - v and the dot
+// products / finiteness / pivot watch of lm_trial_kernel (vecops.hip) -- instead of copy_column_zero +
+// backsolve_chain + lm_trial, three dependent launches of 4-7 us each.
+__global__ __launch_bounds__(256) void lm_solve_tail_small_kernel(const double *M, int64_t ld, int n, const double *uinv,
+                                                                  const double *x, const double *g, const double *d,
+                                                                  double *xt, double *v_out, double *st,
+                                                                  const double *a_diag, const int32_t *chol_info) {
+  __shared__ double ys[2 * NB], vs[2 * NB];
+  __shared__ double sh[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nblk = n / NB;
+  if (tid < n) ys[tid] = M[(int64_t)tid * ld + n];
+  __syncthreads();
+  for (int k = nblk - 1; k >= 0; --k) {
+    gemv32(uinv + (int64_t)k * NB * NB, NB, ys + k * NB, vs + k * NB, false, wave, lane);      // v_k = inv(U_kk) y_k
+    __syncthreads();
+    for (int b = 0; b < k; ++b)                                                                 // y_b -= U[b, k] v_k
+      gemv32(M + (int64_t)b * NB * ld + (int64_t)k * NB, ld, vs + k * NB, ys + b * NB, true, wave, lane);
+    __syncthreads();
+  }
+  double vg = 0.0, dv2 = 0.0, bad = 0.0, pmin = INFINITY;
+  const double mu = st[LMS_MU];
+  if (tid < n) {
+    const double vj = vs[tid];
+    v_out[tid] = vj;
+    xt[tid] = x[tid] - vj;
+    vg = vj * g[tid];
+    const double t = d[tid] * vj;
+    dv2 = t * t;
+    bad = (vj - vj == 0.0) ? 0.0 : 1.0;
+    if (a_diag) {
+      const double u = M[(int64_t)tid * ld + tid], m = a_diag[tid] + mu * d[tid] * d[tid];
+      pmin = m > 0.0 ? u * u / m : 1.0;
+      pmin = (pmin == pmin) ? pmin : INFINITY;   // (a NaN pivot: the factorisation's own status reports it)
+    }
+  }
+  auto bsum = [&](double a) {
+    a = wave_sum(a);
+    __syncthreads();
+    if (lane == 0) sh[wave] = a;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+  };
+  vg = bsum(vg);
+  dv2 = bsum(dv2);
+  bad = bsum(bad);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
+  __syncthreads();
+  if (lane == 0) sh[wave] = pmin;
+  __syncthreads();
+  if (tid == 0) {
+    st[LMS_VG] = vg;
+    st[LMS_DV2] = dv2;
+    st[LMS_VFINITE] = bad == 0.0 ? 1.0 : 0.0;
+    st[LMS_PIVMIN] = a_diag ? fmin(fmin(sh[0], sh[1]), fmin(sh[2], sh[3])) : 1.0;
+  }
+  (void)chol_info;
+}
+
+hipError_t launch_lm_solve_tail_small(hipStream_t stream, const double *M, int64_t ld, int64_t n, const double *uinv,
+                                      const double *x, const double *g, const double *d, double *xt, double *v_out,
+                                      double *st, const double *a_diag, const int32_t *chol_info) {
+  if (n != NB && n != 2 * NB) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lm_solve_tail_small_kernel, dim3(1), dim3(256), 0, stream, M, ld, (int)n, uinv, x, g, d, xt, v_out, st,
+                     a_diag, chol_info);
+  return hipGetLastError();
+}
+
 constexpr int BSQ = 4;  // measured at n = 4096: 2 -> 0.52 ms, 4 -> 0.37 ms, 8 -> 0.56 ms (step kernel: 0.48 ms)
 
 __global__ __launch_bounds__(256) void backsolve_group_kernel(const double *A, int64_t lda, int kb,

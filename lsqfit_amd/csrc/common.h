@@ -227,7 +227,10 @@ hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, 
 hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt);
 // LM state record on the device (plain lm; vecops.hip)
 enum { LMS_CHI2 = 0, LMS_MU, LMS_NU, LMS_DELTA, LMS_VG, LMS_DV2, LMS_VFINITE, LMS_RHO, LMS_CHI2_TRIAL, LMS_ACCEPT,
-       LMS_SOLVED, LMS_INFO, LMS_PIVMIN, LMS_COUNT = 16 };
+       LMS_SOLVED, LMS_INFO, LMS_PIVMIN,
+       LMS_SEQ /* counts the half steps published: the host may poll the mirror for it instead of sleeping in a stream synchronisation */,
+       LMS_HOSTPTR /* bits of a device-visible HOST address the record is mirrored to by the kernels that finish a half step (0: none) */,
+       LMS_COUNT = 16 };
 // U / ldu / a_diag given: state[LMS_PIVMIN] = min_i U_ii^2 / (a_diag_i + mu d_i^2), the smallest share of a column of the
 // damped matrix that its Cholesky pivot retained (1 / it ~ the condition number the solve has just gone through)
 hipError_t launch_lm_trial(hipStream_t st, int64_t P, const double *x, const double *v, const double *g,
@@ -237,9 +240,18 @@ hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, doub
                                 const double *prec, int32_t dense, const double *pmean, const double *p, double *tvec,
                                 bool with_prior, double *chi2_out, const int32_t *chol_info, double factor_up,
                                 double factor_down, double *lmd);
+// tvec / pmean given: g += tvec, chi2 += (x - pmean) . tvec first (the prior's share, prior_apply_kernel folded in)
 hipError_t launch_lm_accept_tail(hipStream_t st, const double *apk, int64_t P, int scaler, double *coln2,
-                                 double *dscale, const double *x, const double *v, const double *gvec, double xtol,
-                                 double gtol, double *lmd);
+                                 double *dscale, const double *x, const double *v, double *gvec, double xtol,
+                                 double gtol, double *lmd, const double *tvec = nullptr, const double *pmean = nullptr);
+// small systems (n <= 256): back substitution + trial point + the record's dot products in one single-workgroup launch
+hipError_t launch_lm_solve_tail_small(hipStream_t st, const double *M, int64_t ld, int64_t n, const double *uinv,
+                                      const double *x, const double *g, const double *d, double *xt, double *v_out,
+                                      double *lmd, const double *a_diag, const int32_t *chol_info);
+// small fits (n <= 65536 residuals, diagonal or no prior): |f_trial|^2 + the prior's share + the decision in one launch
+hipError_t launch_lm_trial_tail_small(hipStream_t st, const double *r, int64_t n, int64_t P, const double *prec,
+                                      const double *pmean, const double *p, double *tvec, double *chi2_out,
+                                      const int32_t *chol_info, double factor_up, double factor_down, double *lmd);
 hipError_t launch_lm_decide(hipStream_t st, const double *chi2_trial, const int32_t *chol_info, double factor_up,
                             double factor_down, double *state);
 hipError_t launch_lm_converge(hipStream_t st, int64_t P, const double *x, const double *v, const double *gvec,

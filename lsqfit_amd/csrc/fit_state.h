@@ -106,6 +106,9 @@ struct lsqamd_fit {
   // plain lm keeps its vectors on the device (api.hip iterate_device): the host mirrors hx / hg /
   // hdiag / hcoln / hv / hdx are refreshed on demand (refresh_mirrors)
   bool dev_lm = false, mirrors_stale = false;
+  bool prior_deferred = false;  // eval_normal_dev left the prior's share of g / chi2 to the accept-tail kernel
+  double lm_seq_expect = 0.0;   // half steps published so far (the record's LMS_SEQ the host waits for)
+  bool lm_zero_copy = false;   // the device kernels mirror the LM record into pin_lm themselves (no copy per read)
   // f->r holds the whitened residual AT r_ptr's current contents (set by iterate_device right before
   // the accepted point's normal equations, consumed there: the fused Jacobian path needs it)
   bool r_fresh = false, used_synth = false;

@@ -754,6 +754,26 @@ __device__ __forceinline__ double block_sum(double a, double *sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// the record, mirrored into pinned host memory by the kernel that completes a half step: the host reads it after
+// the stream synchronisation it needs anyway -- no copy kernel (4 us + a dependent-launch gap each, 2.6 per step)
+__device__ __forceinline__ void lm_publish(double *st) {
+  // called by ONE thread after it has written the record.  The sequence number goes last, behind a system-scope
+  // fence: a host that polls the mirror for it finds the rest of the record complete.
+  const long long hp = __double_as_longlong(st[LMS_HOSTPTR]);
+  const double seq = st[LMS_SEQ] + 1.0;
+  st[LMS_SEQ] = seq;
+  if (hp == 0) return;
+  double *h = reinterpret_cast<double *>(hp);
+  typedef double v2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int i = 0; i < LMS_COUNT; i += 2)      // 16-byte stores: eight posted writes instead of sixteen
+    if (i != (LMS_SEQ & ~1)) __builtin_nontemporal_store((v2){st[i], st[i + 1]}, reinterpret_cast<v2 *>(h + i));
+  __threadfence_system();
+  __builtin_nontemporal_store((v2){(LMS_SEQ & 1) ? st[LMS_SEQ - 1] : seq, (LMS_SEQ & 1) ? seq : st[LMS_SEQ + 1]},
+                              reinterpret_cast<v2 *>(h + (LMS_SEQ & ~1)));
+  __threadfence_system();
+}
+
 // trial point + the two dot products of the gain ratio:  xt = x - v,  st[VG] = v.g,  st[DV2] = |D v|^2,
 // st[VFINITE] = 1 when every component of v is finite
 __global__ __launch_bounds__(256) void lm_trial_kernel(int64_t P, const double *x, const double *v, const double *g,
@@ -830,6 +850,7 @@ __global__ void lm_decide_kernel(const double *chi2_trial, const int32_t *chol_i
   st[LMS_CHI2_TRIAL] = ct;
   st[LMS_ACCEPT] = rho > 0.0 ? 1.0 : 0.0;
   st[LMS_SOLVED] = solved ? 1.0 : 0.0;
+  lm_publish(st);
 }
 
 // The tail of a trial in ONE launch (single rank: no exchange in between): the second stage of |f_trial|^2,
@@ -882,6 +903,7 @@ __global__ __launch_bounds__(256) void lm_trial_tail_kernel(const double *partia
   st[LMS_CHI2_TRIAL] = ct;
   st[LMS_ACCEPT] = rho > 0.0 ? 1.0 : 0.0;
   st[LMS_SOLVED] = solved ? 1.0 : 0.0;
+  lm_publish(st);
 }
 
 // |r|^2 first stage + (prior: t = Lambda (p - pbar)) + the tail above
@@ -900,14 +922,99 @@ hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, doub
   return hipGetLastError();
 }
 
+
+// ---- small fits: the tail of a trial in ONE single-workgroup launch ------------------------------------------
+// |f_trial|^2 over n <= 65536 residuals, the prior's share for a diagonal (or absent) prior -- t = Lambda (p - pbar)
+// is left in tvec for the accepted branch, as prior_vec_kernel does -- and the decision of lm_trial_tail_kernel:
+// instead of sumsq_stage1 + prior_vec + lm_trial_tail (three dependent launches).
+__global__ __launch_bounds__(256) void lm_trial_tail_small_kernel(const double *r, int64_t n, int64_t P, const double *prec,
+                                                                  const double *pmean, const double *p, double *tvec,
+                                                                  double *chi2_out, const int32_t *chol_info,
+                                                                  double factor_up, double factor_down, double *st) {
+  __shared__ double part[4];
+  double a = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const double v = r[i];
+    a += v * v;
+  }
+  a = wsum(a);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+  __syncthreads();
+  double ct = part[0] + part[1] + part[2] + part[3];
+  __syncthreads();
+  if (prec) {
+    double b = 0.0;
+    for (int64_t j = threadIdx.x; j < P; j += 256) {
+      const double dlt = p[j] - pmean[j], t = prec[j] * dlt;
+      tvec[j] = t;
+      b += dlt * t;
+    }
+    b = wsum(b);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = b;
+    __syncthreads();
+    ct += part[0] + part[1] + part[2] + part[3];
+  }
+  if (threadIdx.x != 0) return;
+  chi2_out[0] = ct;
+  const double chi2 = st[LMS_CHI2], mu = st[LMS_MU];
+  const bool solved = chol_info[0] == 0 && st[LMS_VFINITE] != 0.0;
+  double rho = -1.0;
+  if (solved) {
+    const double normf = sqrt(chi2), normf_t = sqrt(ct);
+    if (normf_t < normf) {   // NaN-safe: anything else rejects
+      const double u = normf_t / normf;
+      const double pred = (st[LMS_VG] + mu * st[LMS_DV2]) / chi2;
+      rho = pred > 0.0 ? (1.0 - u * u) / pred : -1.0;
+    }
+  }
+  if (rho > 0.75) st[LMS_DELTA] *= factor_up;
+  else if (rho < 0.25) st[LMS_DELTA] /= factor_down;
+  if (rho > 0.0) {
+    const double b = 2.0 * rho - 1.0;
+    st[LMS_MU] = mu * fmax(0.333333333333333, 1.0 - b * b * b);
+    st[LMS_NU] = 2.0;
+  } else {
+    st[LMS_MU] = mu * st[LMS_NU];
+    st[LMS_NU] *= 2.0;
+  }
+  st[LMS_RHO] = rho;
+  st[LMS_CHI2_TRIAL] = ct;
+  st[LMS_ACCEPT] = rho > 0.0 ? 1.0 : 0.0;
+  st[LMS_SOLVED] = solved ? 1.0 : 0.0;
+  lm_publish(st);
+}
+
+hipError_t launch_lm_trial_tail_small(hipStream_t stream, const double *r, int64_t n, int64_t P, const double *prec,
+                                      const double *pmean, const double *p, double *tvec, double *chi2_out,
+                                      const int32_t *chol_info, double factor_up, double factor_down, double *lmd) {
+  hipLaunchKernelGGL(lm_trial_tail_small_kernel, dim3(1), dim3(256), 0, stream, r, n, P, prec, pmean, p, tvec, chi2_out,
+                     chol_info, factor_up, factor_down, lmd);
+  return hipGetLastError();
+}
+
 // The tail of an accepted step in ONE launch: diag(J^T J) out of the packed tiles, the update of the scaling D
 // and the convergence test (packed_diag_kernel + scale_update_kernel + lm_converge_kernel, element for element).
 __global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, int64_t P, int64_t T, int scaler,
                                                              double *coln2, double *dscale, const double *x,
-                                                             const double *v, const double *gvec, double xtol,
-                                                             double gtol, double *st) {
+                                                             const double *v, double *gvec, double xtol,
+                                                             double gtol, double *st, const double *tvec,
+                                                             const double *pmean) {
   __shared__ double sh[4];
   double notx = 0.0, gn = 0.0;
+  if (tvec) {   // the prior's share of g and chi2 (prior_apply_kernel, same sums in the same order) rides along
+    double a = 0.0;
+    for (int64_t j = threadIdx.x; j < P; j += 256) {
+      const double t = tvec[j];
+      gvec[j] += t;
+      a += (x[j] - pmean[j]) * t;
+    }
+    a = wsum(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) gvec[P] += sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+  }
   for (int64_t j = threadIdx.x; j < P; j += 256) {
     const int64_t tm = j / TB, r = j % TB;
     const double c2 = apk[packed_tile_index(tm, tm, T) * TB * TB + r * TB + r];
@@ -933,15 +1040,16 @@ __global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, 
     const double chi2 = gvec[P];
     st[LMS_CHI2] = chi2;
     st[LMS_INFO] = notx == 0.0 ? 1.0 : (gn <= gtol * fmax(0.5 * chi2, 1.0) ? 2.0 : 0.0);
+    lm_publish(st);
   }
 }
 
 hipError_t launch_lm_accept_tail(hipStream_t stream, const double *apk, int64_t P, int scaler, double *coln2,
-                                 double *dscale, const double *x, const double *v, const double *gvec, double xtol,
-                                 double gtol, double *st) {
+                                 double *dscale, const double *x, const double *v, double *gvec, double xtol,
+                                 double gtol, double *st, const double *tvec, const double *pmean) {
   const int64_t T = (P + TB - 1) / TB;
   hipLaunchKernelGGL(lm_accept_tail_kernel, dim3(1), dim3(256), 0, stream, apk, P, T, scaler, coln2, dscale, x, v, gvec,
-                     xtol, gtol, st);
+                     xtol, gtol, st, tvec, pmean);
   return hipGetLastError();
 }
 
@@ -975,6 +1083,7 @@ __global__ __launch_bounds__(256) void lm_converge_kernel(int64_t P, const doubl
     const double chi2 = gvec[P];
     st[LMS_CHI2] = chi2;
     st[LMS_INFO] = notx == 0.0 ? 1.0 : (gn <= gtol * fmax(0.5 * chi2, 1.0) ? 2.0 : 0.0);
+    lm_publish(st);
   }
 }
 
