@@ -298,8 +298,15 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    pr.timing(True)
-    pr.timing_reset()
+    # Phase timers (HIP events around every phase, on the handle's stream) ride along in the timed region at the
+    # named shape (0.1 % of a 20 ms step).  A SMALL problem's step is a captured graph (P <= 1024, one rank) that the
+    # timers would force back to eager launches with ~18 event records per step -- 0.30 instead of 0.19 ms at
+    # (4096, 256): there the timed region runs uninstrumented and the phases are timed in a second pass of the same
+    # number of steps right after it (said so in roofline.timing_pass).
+    two_pass = P <= 1024 and world == 1
+    if not two_pass:
+        pr.timing(True)
+        pr.timing_reset()
     state['reinits'] = 0
     barrier()
     t0 = time.perf_counter()
@@ -307,6 +314,14 @@ def main():
         one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    reinits_timed = state['reinits']
+    if two_pass:
+        pr.timing(True)
+        pr.timing_reset()
+        for _ in range(args.steps):
+            one_step()
+        torch.cuda.synchronize()
+    state['reinits'] = reinits_timed
     tm = pr.timings()
     pr.timing(False)
     s = _lib.Summary()
@@ -365,6 +380,9 @@ def main():
                          'algorithmic_bytes': 8.0 * n_local * P,
                          'flops_per_launch': flops,
                          'avg_launch_ms': (syrk_ms / syrk_n) if syrk_n else None,
+                         'timing_pass': ('a second, instrumented pass of %d steps right after the timed region (the timed region '
+                                         'itself replays captured graphs without event records)' % args.steps) if two_pass
+                                        else 'HIP events inside the timed region',
                          # informational: the chip sustains ~2.18 GHz (not the nominal 2.4) under this
                          # kernel (GRBM_GUI_ACTIVE in the committed PMC profile); frac stays vs nominal
                          'sustained_clock_GHz': clk,
