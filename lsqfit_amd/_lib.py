@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'liblsqfit_amd.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 COMM_ID_BYTES = 128
 

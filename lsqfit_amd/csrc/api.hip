@@ -964,8 +964,8 @@ int refresh_mirrors(lsqamd_fit *f) {
 // launching their ~35 kernels than the GPU spends running them.
 // small single-rank fits: fused single-workgroup tails (LSQAMD_SMALL_FUSE=0: the general kernels)
 static bool small_fuse(const lsqamd_fit *f) {
-  static const bool off = [] { const char *e = getenv("LSQAMD_SMALL_FUSE"); return e && e[0] == '0'; }();
-  return !off && !f->comm && !f->reduce;
+  const char *e = getenv("LSQAMD_SMALL_FUSE");     // read per call (tests flip it between fits; a getenv is ~50 ns)
+  return !(e && e[0] == '0') && !f->comm && !f->reduce;
 }
 
 static int enqueue_trial(lsqamd_fit *f) {

@@ -932,12 +932,27 @@ __global__ __launch_bounds__(256) void lm_trial_tail_small_kernel(const double *
                                                                   double *chi2_out, const int32_t *chol_info,
                                                                   double factor_up, double factor_down, double *st) {
   __shared__ double part[4];
-  double a = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const double v = r[i];
-    a += v * v;
+  __shared__ double blk[64];
+  // the SAME sums in the same order as sumsq_stage1 (one workgroup per 1024 residuals, grid-strided) followed by the
+  // second stage of lm_trial_tail_kernel: a fit takes bit-identical decisions with or without this fused tail
+  const int blocks = (int)((n + 1023) / 1024) < 1 ? 1 : (int)((n + 1023) / 1024);
+  for (int b = 0; b < blocks; ++b) {
+    double a = 0.0;
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n; i += (int64_t)blocks * 256) {
+      const double v = r[i];
+      a += v * v;
+    }
+    a = wsum(a);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) blk[b] = part[0] + part[1] + part[2] + part[3];
   }
+  __syncthreads();
+  double a = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 256) a += blk[i];
   a = wsum(a);
+  __syncthreads();
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
   __syncthreads();
   double ct = part[0] + part[1] + part[2] + part[3];
@@ -945,9 +960,9 @@ __global__ __launch_bounds__(256) void lm_trial_tail_small_kernel(const double *
   if (prec) {
     double b = 0.0;
     for (int64_t j = threadIdx.x; j < P; j += 256) {
-      const double dlt = p[j] - pmean[j], t = prec[j] * dlt;
+      const double t = prec[j] * (p[j] - pmean[j]);     // (prior_vec_kernel, then the tail's (p - pbar) . t)
       tvec[j] = t;
-      b += dlt * t;
+      b += (p[j] - pmean[j]) * t;
     }
     b = wsum(b);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = b;

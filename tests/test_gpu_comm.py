@@ -23,6 +23,10 @@ def amd():
 def test_one_rank_communicator_is_transparent(amd, algo, monkeypatch):
     from lsqfit_amd import synth
     monkeypatch.setenv('LSQAMD_COMM_ALGO', algo)
+    # (single-rank fits of this size take fused single-workgroup tails that a handle with a communicator does not:
+    # same arithmetic up to the order of a few sums.  Bit-for-bit transparency is a statement about the general
+    # kernels, so both fits run on those.)
+    monkeypatch.setenv('LSQAMD_SMALL_FUSE', '0')
     d = synth.make_cosmix(N=1024, P=256, seed=77, block=64, prior_corr=True)
     kw = dict(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
     ref = amd.nonlinear_fit(**kw)

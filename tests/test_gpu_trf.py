@@ -248,7 +248,10 @@ def test_half_sigma_walls_cosmix_1024x128(amd, method):
     # evaluation of each other, and which one is met first is a rounding-level tie
     assert fit.stopping_criterion != 0 and ref.stopping_criterion != 0
     assert fit.stopping_criterion == ref.stopping_criterion or {fit.stopping_criterion, ref.stopping_criterion} == {1, 3}
-    assert abs(fit.nit - ref.nit) <= max(1, ref.nit // 4), (fit.nit, ref.nit)   # ~150 evaluations, dozens of reflections
+    # 150-300 evaluations with dozens of wall reflections: the sequence is chaotic in the last bits of the inputs (the
+    # walls are placed from the device's own free fit: a different summation order there moves the ORACLE's count
+    # from ~150 to 268), so the counts are only required to be of the same size; the end point is the parity check
+    assert 0.5 < fit.nit / ref.nit < 2.0, (fit.nit, ref.nit)
     assert np.max(np.abs(fit.pmean - ref.pmean) / free.psdev) < 1e-5
     assert abs(fit.chi2 / ref.chi2 - 1) < 1e-9
     assert gu.relmax(fit.cov, ref.cov) < 1e-6
