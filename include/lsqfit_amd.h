@@ -110,10 +110,10 @@ enum {
   LSQAMD_OP_POWI = 15  /* a ** (int)arg */
 };
 #define LSQAMD_TAPE_MAX_PARAM 4096 /* parameters of a tape model */
-#define LSQAMD_TAPE_CHUNK 16       /* batched fits: differentiated 16 at a time, ceil(P/16) forward passes per row */
+#define LSQAMD_TAPE_CHUNK 16       /* interpreter fallback of batched fits: differentiated 16 at a time, ceil(P/16) forward passes per row */
 #define LSQAMD_TAPE_MAX_STACK 16
-#define LSQAMD_TAPE_MAX_CODE 16384 /* instructions (single fits: ONE forward and ONE reverse sweep per row,
-                                    * whatever P is; batched fits: at most 1024) */
+#define LSQAMD_TAPE_MAX_CODE 16384 /* instructions.  Tapes are compiled (hiprtc) at set_tape time, single and batched fits alike;
+                                    * the interpreter fallback of batched fits takes at most 1024 instructions */
 
 /* Devices this process can use (one process per GPU; a host in another language picks its
  * device with the HIP runtime before lsqamd_create).  *count <- visible devices (0 without a GPU:

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "common.h"
+#include "jit.h"
 
 namespace lsqamd {
 
@@ -509,6 +510,7 @@ struct lsqamdb_fits {
   int32_t *tape = nullptr;
   double *consts = nullptr;
   int32_t n_tape = 0;
+  const void *jit = nullptr;   // the tape compiled (jit.hip); null: the forward-mode interpreter kernel
   // per fit
   double *ptvec = nullptr;  // dense prior: Lambda (x - pbar) per fit
   double *pmean = nullptr, *pprec = nullptr, *px = nullptr, *pxt = nullptr, *dx = nullptr, *diag = nullptr;
@@ -629,6 +631,7 @@ ModelArgs model_args_b(const lsqamdb_fits *f, const double *p) {
   m.in_block = f->cfg.n_blocks > 0 ? f->in_block : nullptr;
   m.p = p; m.tape = f->tape; m.n_tape = f->n_tape; m.consts = f->consts;
   m.n_batch = f->B; m.p_stride = f->P; m.batch_active = f->s.active;
+  m.jit = f->jit;
   return m;
 }
 
@@ -800,9 +803,34 @@ int lsqamdb_set_x(lsqamdb_fits *f, const double *x, int64_t n_rows, int32_t n_x)
 
 int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts) {
   if (!f) return LSQAMD_EINVAL;
-  if (!code || n_code < 1 || n_code > 1024 || n_consts < 0 || n_consts > 256) BFAIL(f, LSQAMD_EINVAL, "set_tape: sizes");
-  BHIP(f, hipMemcpy(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice));
-  if (n_consts > 0) BHIP(f, hipMemcpy(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice));
+  if (!code || n_code < 1 || n_code > LSQAMD_TAPE_MAX_CODE || n_consts < 0 || n_consts > 1024 || (n_consts > 0 && !consts))
+    BFAIL(f, LSQAMD_EINVAL, "set_tape: sizes");
+  {   // stack discipline and operand ranges (the compiled route indexes by them)
+    int sp = 0;
+    for (int t = 0; t < n_code; ++t) {
+      const int op = code[t] & 0xff, arg = code[t] >> 8;
+      bool ok = true;
+      if (op == LSQAMD_OP_CONST) { ok = arg >= 0 && arg < n_consts; ++sp; }
+      else if (op == LSQAMD_OP_X) { ok = arg >= 0 && arg < (f->cfg.n_x > 0 ? f->cfg.n_x : 1); ++sp; }
+      else if (op == LSQAMD_OP_P) { ok = arg >= 0 && arg < f->P; ++sp; }
+      else if (op >= LSQAMD_OP_ADD && op <= LSQAMD_OP_POW) { ok = sp >= 2; --sp; }
+      else if (op >= LSQAMD_OP_NEG && op <= LSQAMD_OP_POWI) ok = sp >= 1;
+      else ok = false;
+      if (!ok || sp > LSQAMD_TAPE_MAX_STACK) BFAIL(f, LSQAMD_EINVAL, "set_tape: malformed tape at instruction %d", t);
+    }
+    if (sp != 1) BFAIL(f, LSQAMD_EINVAL, "set_tape: the tape must leave exactly one value");
+  }
+  // the formula compiled (jit.hip): one launch per evaluation with the fits as blockIdx.y, whatever P is -- the
+  // interpreter route (forward mode, ceil(P / 16) passes per row) remains for tapes of <= 1024 instructions when
+  // hiprtc is absent or the generator declines
+  std::string why;
+  f->jit = lsqamd_jit::compile_tape(code, n_code, consts, n_consts, (int)f->P, f->cfg.n_x > 0 ? f->cfg.n_x : 1, why);
+  if (!f->jit && (n_code > 1024 || n_consts > 256))
+    BFAIL(f, LSQAMD_EUNSUPPORTED, "set_tape: %d instructions need the compiled route, which is unavailable (%s)", n_code, why.c_str());
+  if (n_code <= 1024 && n_consts <= 256) {
+    BHIP(f, hipMemcpy(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice));
+    if (n_consts > 0) BHIP(f, hipMemcpy(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice));
+  }
   f->n_tape = n_code;
   f->have_tape = true;
   return 0;

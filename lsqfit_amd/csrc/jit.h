@@ -14,6 +14,10 @@ struct LaunchArgs {
   const unsigned char *in_block = nullptr;
   double *out_w = nullptr, *out_raw = nullptr;
   int64_t ld = 1, n_data = 0;
+  // batch (blockIdx.y): fit b reads p + b * p_stride, ymean + b * ymean_stride, writes at out + b * out_stride
+  int32_t n_batch = 1;
+  int64_t p_stride = 0, out_stride = 0, ymean_stride = 0;
+  const int *batch_active = nullptr;
 };
 
 // nullptr (and why) when hiprtc is not available or the formula is outside what the generator handles

@@ -563,7 +563,8 @@ std::string generate(const Plan &pl) {
   o.s += "// generated by lsqfit_amd (jit.hip) from an expression tape\n";
   o.s += kDevmath;
   o.s += "\nusing namespace lsqamd;\n";
-  o.s += "struct Args { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data; };\n";
+  o.s += "struct Args { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data;\n"
+         "              long long p_stride, out_stride, ymean_stride; const int *batch_active; };\n";
   o.s += "static __device__ __forceinline__ double wsum(double v) {\n"
          "#pragma unroll\n  for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);\n  return v;\n}\n";
   // index tables of the non-affine private slots
@@ -589,6 +590,10 @@ std::string generate(const Plan &pl) {
   const int nout = (int)pl.out_params.size();
   for (int jac = 0; jac < 2; ++jac) {
     o.f("extern \"C\" __global__ __launch_bounds__(256) void %s(Args a) {\n", jac ? "lsqamd_jit_jac" : "lsqamd_jit_res");
+    // blockIdx.y = fit of a batch (lockstep fits, chi2 at many points): its parameters, data means and output rows
+    o.s += "  if (a.batch_active && !a.batch_active[blockIdx.y]) return;\n";
+    o.s += "  a.p += (long long)blockIdx.y * a.p_stride;\n  a.ymean += (long long)blockIdx.y * a.ymean_stride;\n";
+    o.s += "  a.out_w += (long long)blockIdx.y * a.out_stride;\n  if (a.out_raw) a.out_raw += (long long)blockIdx.y * a.out_stride;\n";
     o.f("  __shared__ double sp[%d];\n", pl.P < 1 ? 1 : pl.P);
     o.f("  for (int i = threadIdx.x; i < %d; i += 256) sp[i] = a.p[i];\n  __syncthreads();\n", pl.P);
     if (pl.wave_per_row) {
@@ -819,13 +824,16 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
 
 hipError_t launch(const Kernel *k, hipStream_t st, bool jac, const LaunchArgs &a) {
   if (a.n_data <= 0) return hipSuccess;
-  struct { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data; } args =
-      {a.x, a.p, a.ymean, a.wdiag, a.in_block, a.out_w, a.out_raw, (long long)a.ld, (long long)a.n_data};
+  struct { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data;
+           long long p_stride, out_stride, ymean_stride; const int *batch_active; } args =
+      {a.x, a.p, a.ymean, a.wdiag, a.in_block, a.out_w, a.out_raw, (long long)a.ld, (long long)a.n_data,
+       (long long)a.p_stride, (long long)a.out_stride, (long long)a.ymean_stride, a.batch_active};
   size_t sz = sizeof(args);
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   int64_t blocks = k->l.wave_per_row ? (a.n_data + 3) / 4 : (a.n_data + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  return hipModuleLaunchKernel(jac ? k->l.jac : k->l.res, (unsigned)blocks, 1, 1, 256, 1, 1, 0, st, nullptr, cfg);
+  return hipModuleLaunchKernel(jac ? k->l.jac : k->l.res, (unsigned)blocks, (unsigned)(a.n_batch < 1 ? 1 : a.n_batch), 1, 256, 1, 1, 0,
+                               st, nullptr, cfg);
 }
 
 bool available(std::string *why) {

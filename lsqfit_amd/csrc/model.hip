@@ -690,8 +690,10 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
         for (int i = 0; i < a.n_prog; ++i) {
           const TapeProgram &pg = a.progs[i];
           if (pg.n_rows <= 0) continue;
-          if (nb == 1 && pg.jit) {
+          if (pg.jit) {
             lsqamd_jit::LaunchArgs la;
+            la.n_batch = (int32_t)nb; la.p_stride = a.p_stride; la.out_stride = a.out_stride; la.ymean_stride = a.ymean_stride;
+            la.batch_active = a.batch_active;
             la.x = a.x + pg.row0 * a.n_x; la.p = a.p; la.ymean = a.ymean + pg.row0; la.wdiag = a.wdiag + pg.row0;
             la.in_block = a.in_block ? a.in_block + pg.row0 : nullptr;
             la.out_w = out_w + pg.row0 * ld; la.out_raw = out_raw ? out_raw + pg.row0 * ld : nullptr;
@@ -712,8 +714,10 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
         }
         break;
       }
-      if (nb == 1 && a.jit) {   // the formula compiled at lsqamd_set_tape time (jit.hip)
+      if (a.jit) {   // the formula compiled at lsqamd_set_tape time (jit.hip); batched fits / many points: blockIdx.y
         lsqamd_jit::LaunchArgs la;
+        la.n_batch = (int32_t)nb; la.p_stride = a.p_stride; la.out_stride = a.out_stride; la.ymean_stride = a.ymean_stride;
+        la.batch_active = a.batch_active;
         la.x = a.x; la.p = a.p; la.ymean = a.ymean; la.wdiag = a.wdiag; la.in_block = a.in_block;
         la.out_w = out_w; la.out_raw = out_raw; la.ld = ld; la.n_data = a.n_data;
         return lsqamd_jit::launch(static_cast<const lsqamd_jit::Kernel *>(a.jit), st, JAC, la);

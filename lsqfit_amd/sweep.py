@@ -48,8 +48,9 @@ class EvidenceSurface:
     or a pair (dict, log prior plausibility of z).  The best point seen so far (``zbest``) and
     its parameters (the warm start of every later fit, _extras.py:160-161) are remembered."""
 
-    def __init__(self, fitargs, p0=None, scalar=True):
+    def __init__(self, fitargs, p0=None, scalar=True, fitter=nonlinear_fit):
         self.fitargs, self.scalar = fitargs, scalar
+        self.fitter = fitter          # anything but lsqfit_amd.nonlinear_fit is called fit by fit (never batched)
         self.warm = None if p0 is None else np.array(p0, float).reshape(-1)
         self.zbest, self.fbest = None, np.inf
         self.nfits = self.nbatches = 0
@@ -104,13 +105,13 @@ class EvidenceSurface:
     def __call__(self, zs):
         zs = np.atleast_2d(np.asarray(zs, float))
         items = [self.unpack(z) for z in zs]
-        got = self._batch(items) if len(items) > 1 else None
+        got = self._batch(items) if len(items) > 1 and self.fitter is nonlinear_fit else None
         if got is None:
             vals, pmeans = np.empty(len(items)), []
             for i, (a, pl) in enumerate(items):
                 if self.warm is not None and 'p0' not in a:
                     a['p0'] = self.warm
-                fit = nonlinear_fit(**a)
+                fit = self.fitter(**a)
                 g = np.nan if fit.logGBF is None else fit.logGBF
                 vals[i] = -g - pl
                 pmeans.append(fit.pmean)
@@ -169,10 +170,11 @@ def simplex_search(fmany, z0, tol=1e-4, maxit=1000):
 def empbayes_fit(z0, fitargs, p0=None, tol=1e-4, maxit=1000, fitter=nonlinear_fit):
     """-> (fit, z): the fit at the z that maximises ``logGBF`` (+ plausibility), and that z,
     laid out like ``z0`` (number or array).  ``tol`` / ``maxit`` steer the simplex search as the
-    reference's ``minargs`` steer its minimiser (src/lsqfit/_scipy.py:224-227)."""
-    if fitter is not nonlinear_fit:
-        raise NotImplementedError('empbayes_fit drives lsqfit_amd.nonlinear_fit only')
-    surface = EvidenceSurface(fitargs, p0=p0, scalar=np.shape(z0) == ())
+    reference's ``minargs`` steer its minimiser (src/lsqfit/_scipy.py:224-227).  ``fitter`` is any callable
+    with ``nonlinear_fit``'s keyword interface whose result has ``logGBF`` and ``pmean`` (the reference accepts one,
+    _extras.py:30-41,:163); only ``lsqfit_amd.nonlinear_fit`` itself is evaluated in lockstep batches, another
+    fitter fit by fit."""
+    surface = EvidenceSurface(fitargs, p0=p0, scalar=np.shape(z0) == (), fitter=fitter)
     try:
         simplex_search(surface, np.atleast_1d(np.asarray(z0, float)), tol=tol, maxit=maxit)
         if surface.zbest is None:
@@ -182,15 +184,26 @@ def empbayes_fit(z0, fitargs, p0=None, tol=1e-4, maxit=1000, fitter=nonlinear_fi
         args, _ = surface.unpack(surface.zbest)
         args.setdefault('p0', surface.warm)
         z = float(surface.zbest[0]) if surface.scalar else surface.zbest
-        return nonlinear_fit(**args), z
+        return fitter(**args), z
     finally:
         surface.close()
 
 
-def prior_width_sweep(data, model, prior_mean, widths, p0=None, **runkw):
-    """Fit the same data under the priors ``prior_mean +- widths[j]`` (each width a scalar or a
-    P-vector): one lockstep batch on the device.  -> [SweepFit] in the order of ``widths``."""
+def prior_width_sweep(*args, p0=None, **runkw):
+    """``prior_width_sweep(data, model, prior_mean, widths)``: fit the same data under the priors
+    ``prior_mean +- widths[j]`` (each width a scalar or a P-vector) as ONE lockstep batch on the device.
+    -> [SweepFit] in the order of ``widths`` (a namedtuple: width pmean psdev chi2 dof Q logGBF nit
+    stopping_criterion).  Round 1's form ``prior_width_sweep(problem, data, model, prior_mean, widths)`` -- a
+    resident ``DeviceProblem`` first, a list of fit objects back -- is still accepted: the problem is not
+    needed any more and is ignored; the return value is the list of SweepFit records either way."""
     from .batched import BatchedFits
+    if len(args) == 5:
+        warnings.warn('prior_width_sweep(problem, data, ...): the leading DeviceProblem is ignored since round 2 '
+                      '(the sweep runs as one batch); it returns SweepFit records', DeprecationWarning, stacklevel=2)
+        args = args[1:]
+    if len(args) != 4:
+        raise TypeError('prior_width_sweep(data, model, prior_mean, widths, p0=None, **run_options)')
+    data, model, prior_mean, widths = args
     x, ymean, yerr = data
     pm = np.asarray(prior_mean, float).reshape(-1)
     sd = np.array([np.broadcast_to(np.asarray(w, float), pm.shape) for w in widths])

@@ -113,3 +113,24 @@ def test_config5_sweep_128x4096x512(amd):
         assert out['logGBF'][b] == pytest.approx(ref.logGBF, rel=1e-6, abs=1e-6)
     print('config5: %d rounds, %.1f ms on device, %d fits' % (out['rounds'], out['device_ms'], 128))
     bf.close()
+
+
+def test_batched_fits_of_a_compiled_tape_model(amd):
+    """A sweep over a user formula: the same lockstep engine with the tape COMPILED (jit.hip) -- one launch per
+    evaluation with the fits as blockIdx.y, whatever P is.  sum_256 a*cos(w*x) as a tape (P = 512, 1791 instructions:
+    beyond the 1024 the interpreter fallback of batched fits takes) against the hand-written cosmix kernels."""
+    from lsqfit_amd import models
+    d, pmb, psb = make(2048, 512, 8, 53)
+    tape = models.tape_sum('a*cos(w*x)', 256)
+    assert len(tape.tape) > 1024
+    a = amd.BatchedFits(d['model'], d['x'], d['ymean'], d['yerr'], pmb, psb)
+    b = amd.BatchedFits(tape, d['x'], d['ymean'], d['yerr'], pmb, psb)
+    oa, ob = a.run(use_graph=True), b.run(use_graph=True)
+    assert np.all(ob['status'] == 0) and ob['graph_rounds'] > 0
+    assert gu.relmax(ob['pmean'], oa['pmean']) < 1e-9
+    assert np.allclose(ob['chi2'], oa['chi2'], rtol=1e-10) and np.allclose(ob['logGBF'], oa['logGBF'], rtol=1e-10, atol=1e-8)
+    assert np.array_equal(ob['nit'], oa['nit'])
+    assert gu.relmax(b.cov(3), a.cov(3)) < 1e-8
+    print('batched tape model: %.1f ms on device, cosmix kernels %.1f ms' % (ob['device_ms'], oa['device_ms']))
+    a.close()
+    b.close()

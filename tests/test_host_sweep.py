@@ -55,3 +55,51 @@ def test_bench_self_launch_needs_the_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, 'bench.py', '--gpus', '4'], cwd=ROOT, env=env, capture_output=True, text=True)
     assert r.returncode != 0 and 'visible' in (r.stderr + r.stdout)
+
+
+def test_empbayes_fit_accepts_any_fitter_callable():
+    """The reference takes an arbitrary `fitter` (src/lsqfit/_extras.py:30-41,:163); round 2 refused all but its own.
+    A stand-in with nonlinear_fit's keyword interface: logGBF peaks at prior width 0.7."""
+    from lsqfit_amd.sweep import empbayes_fit
+
+    class FakeFit:
+        def __init__(self, prior, p0=None, **kw):
+            w = float(prior[1][0])
+            self.logGBF = -(np.log(w) - np.log(0.7)) ** 2
+            self.pmean = np.array([w, 2 * w])
+            self.p0 = p0
+
+    calls = []
+
+    def fitter(**kw):
+        calls.append(kw)
+        return FakeFit(**kw)
+
+    fit, z = empbayes_fit(0.0, lambda z: dict(prior=(np.zeros(2), np.full(2, np.exp(z)))), fitter=fitter, tol=1e-6)
+    assert isinstance(fit, FakeFit) and abs(np.exp(z) - 0.7) < 1e-3
+    assert len(calls) > 5 and calls[-1]['p0'] is not None          # warm starts reach the custom fitter too
+
+
+def test_prior_width_sweep_old_positional_form_is_still_accepted(monkeypatch):
+    import lsqfit_amd.sweep as sw
+    seen = {}
+
+    class Eng:
+        def __init__(self, model, x, ym, yerr, pm, sd):
+            seen['shape'] = sd.shape
+        def run(self, p0=None, **kw):
+            n = seen['shape'][0]
+            return dict(pmean=np.zeros((n, 2)), psdev=np.ones((n, 2)), chi2=np.ones(n), dof=3, Q=np.ones(n),
+                        logGBF=np.arange(n, dtype=float), nit=np.ones(n, int), stopping_criterion=np.ones(n, int))
+        def close(self):
+            pass
+
+    import lsqfit_amd.batched as b
+    monkeypatch.setattr(b, 'BatchedFits', Eng)
+    data = (np.zeros(3), np.zeros(3), np.ones(3))
+    new = sw.prior_width_sweep(data, 'model', np.zeros(2), [0.1, 1.0, 10.0])
+    with pytest.warns(DeprecationWarning):
+        old = sw.prior_width_sweep('a DeviceProblem', data, 'model', np.zeros(2), [0.1, 1.0, 10.0])
+    assert [f.width for f in new] == [f.width for f in old] == [0.1, 1.0, 10.0] and new[2].logGBF == 2.0
+    with pytest.raises(TypeError):
+        sw.prior_width_sweep(data, 'model')
