@@ -118,25 +118,30 @@ def cpu_baseline(d, wh_blocks_from, budget_s):
 
 
 def faithful_qr_estimate(n, P):
-    """SURVEY.md 8d "faithful" mode: what the reference's default solver costs per LM step -- one
-    thread, pivoted Householder QR of the n x P Jacobian (lm/more/qr, src/lsqfit/__init__.py:1336;
-    GSL's is unblocked, LAPACK's dgeqp3 here is kinder).  Far too slow to run at full size inside a
-    bench, so the rate is measured on a small sample and scaled by the flop count 2 n P^2 - 2/3 P^3;
-    Jacobian assembly (Python-object AD in the reference) is not included."""
+    """SURVEY.md 8d "faithful" mode: what the reference's default solver costs per LM step -- one thread, an
+    UNBLOCKED column-pivoted Householder QR of the n x P Jacobian (lm/more/qr, src/lsqfit/__init__.py:1336;
+    gsl_linalg_QRPT_decomp: level-2 operations on a row-major matrix).  Timed with the oracle's C restatement of
+    that algorithm (oracle/csrc/qrpt_unblocked.c, gcc -O2, no BLAS) on a bounded sample and scaled by the flop count
+    2 n P^2 - 2/3 P^3 -- far too slow to run at full size inside a bench (hours); Jacobian assembly (Python-object
+    AD in the reference) is not included.  (Rounds 1-2 scaled LAPACK's blocked dgeqp3, 7x kinder to the reference.)"""
     try:
-        import scipy.linalg as sla
-        import threadpoolctl
-        m, q = 3072, 2048
-        A = np.random.default_rng(0).standard_normal((m, q))
-        with threadpoolctl.threadpool_limits(1):
-            t0 = time.perf_counter()
-            sla.qr(A, mode='r', pivoting=True)
-            dt = time.perf_counter() - t0
+        import ctypes as C
+        from oracle import build_c
+        lib = build_c.load()
+        m, q = 3072, 1024
+        A = np.ascontiguousarray(np.random.default_rng(0).standard_normal((m, q)))
+        tau, work, perm = np.empty(q), np.empty(2 * q), np.empty(q, dtype=np.int64)
+        dp = C.POINTER(C.c_double)
+        t0 = time.perf_counter()
+        lib.oracle_qrpt_unblocked(A.ctypes.data_as(dp), m, q, tau.ctypes.data_as(dp), perm.ctypes.data_as(C.POINTER(C.c_long)),
+                                  work.ctypes.data_as(dp))
+        dt = time.perf_counter() - t0
         rate = (2.0 * m * q * q - 2.0 / 3.0 * q ** 3) / dt
         flops = 2.0 * n * P * P - 2.0 / 3.0 * P ** 3
-        return dict(value=rate / flops, unit='LM steps/s', cores=1, extrapolated=True,
-                    sample='dgeqp3 of a %d x %d sample on one thread: %.1f GFLOP/s, scaled to the %d x %d '
-                           'Jacobian (%.2e flop per step); QR only' % (m, q, rate / 1e9, n, P, flops))
+        return dict(value=rate / flops, unit='LM steps/s', cores=1, extrapolated=True, kind='port',
+                    sample='unblocked pivoted Householder QR (C restatement of gsl_linalg_QRPT_decomp) of a %d x %d sample on '
+                           'one thread: %.2f GFLOP/s in %.1f s, scaled to the %d x %d Jacobian (%.2e flop per step); QR only'
+                           % (m, q, rate / 1e9, dt, n, P, flops))
     except Exception as e:
         return dict(value=None, unit='LM steps/s', cores=1, extrapolated=True, sample='failed: %r' % (e,))
 

@@ -26,4 +26,8 @@ Modules
   lm         -- gsl_multifit_nlinear trust/LM driver      (_gsl.pyx:563-723)
   fit        -- nonlinear_fit problem setup + reductions  (__init__.py:455-737)
   synth      -- fake_fitargs-style generators             (_extras.py:2508-2589)
+  trf, minpack -- scipy's least_squares methods restated (the scipy plugin, _scipy.py:115-181; pinned on scipy itself)
+  csrc/qrpt_unblocked.c + build_c -- the ONE C file: an unblocked column-pivoted Householder QR (the algorithm class
+               of gsl's default `qr` solver, _gsl.pyx:646-647), gcc -O2 -> oracle/_build/liboracle_c.so; checked against
+               LAPACK (tests/test_oracle_qr_c.py) and timed by bench.py's cpu_baseline "faithful" mode
 """
