@@ -2321,7 +2321,6 @@ size_t lsqamd_chi2_points_work_bytes(const lsqamd_fit *f, int64_t m) {
 
 int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scratch, size_t scratch_bytes,
                        double *chi2_out) {
-  if (f && f->have_param_rows) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_chi2_points: not available with parameter rows (lsqamd_set_param_rows)");
   if (!f || !p || !chi2_out || !dev_scratch || m < 0) return LSQAMD_EINVAL;
   int rc = ready(f);
   if (rc) return rc;
@@ -2345,6 +2344,9 @@ int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scra
       ModelArgs ma = model_args(f, d.p);
       ma.n_batch = (int32_t)mm; ma.p_stride = P; ma.out_stride = N;
       HIPCHK(f, launch_residual_ex(f->st, ma, d.r, d.r_raw));
+      if (f->have_param_rows)   // prior entries whitened together with the data: rows whose "model" is a parameter
+        HIPCHK(f, launch_param_rows(f->st, f->row_param, N, P, 1, d.p, f->ymean, f->wdiag,
+                                    f->cfg.n_blocks > 0 ? f->in_block : nullptr, d.r, d.r_raw, 0, (int32_t)mm, P, N));
       if (f->cfg.n_blocks > 0)
         HIPCHK(f, launch_block_whiten_vec(f->st, f->wt, f->blk_row0, f->blk_size, f->blk_woff,
                                           f->cfg.n_blocks, f->cfg.max_block, d.r_raw, d.r, (int32_t)mm, N,

@@ -157,7 +157,8 @@ hipError_t launch_jacobian_ex(hipStream_t st, const ModelArgs &m, double *J_w, d
 // rows with row_param[i] = j >= 0 are parameter rows f_i = p_j: overwrite what the model kernel left
 hipError_t launch_param_rows(hipStream_t st, const int32_t *row_param, int64_t N, int64_t P, int64_t ld,
                              const double *p, const double *ymean, const double *wdiag, const uint8_t *in_block,
-                             double *out_w, double *out_raw, int jac);
+                             double *out_w, double *out_raw, int jac, int32_t n_batch = 1, int64_t p_stride = 0,
+                             int64_t out_stride = 0);
 
 // ---- vector / reduction kernels (vecops.hip) --------------------------------------
 // out[j] = sum_i J[i][j] * J[i][rcol] for j in [0, ncols)   (ncols = P+1 gives grad and chi2)

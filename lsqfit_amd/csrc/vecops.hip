@@ -391,10 +391,13 @@ hipError_t launch_prior_chi2(hipStream_t st, int64_t P, const double *prec, int3
 __global__ __launch_bounds__(256) void param_rows_kernel(const int32_t *row_param, int64_t N, int64_t P, int64_t ld,
                                                          const double *p, const double *ymean, const double *wdiag,
                                                          const uint8_t *in_block, double *out_w, double *out_raw,
-                                                         int jac) {
+                                                         int jac, int64_t p_stride, int64_t out_stride) {
   const int64_t i = blockIdx.x;
   const int32_t j = row_param[i];
   if (j < 0) return;
+  p += (int64_t)blockIdx.y * p_stride;          // blockIdx.y: one of many parameter points (lsqamd_chi2_points)
+  out_w += (int64_t)blockIdx.y * out_stride;
+  if (out_raw) out_raw += (int64_t)blockIdx.y * out_stride;
   const bool blk = in_block && in_block[i];
   const double w = blk ? 1.0 : wdiag[i];
   double *dst = blk ? out_raw : out_w;
@@ -408,10 +411,10 @@ __global__ __launch_bounds__(256) void param_rows_kernel(const int32_t *row_para
 
 hipError_t launch_param_rows(hipStream_t st, const int32_t *row_param, int64_t N, int64_t P, int64_t ld,
                              const double *p, const double *ymean, const double *wdiag, const uint8_t *in_block,
-                             double *out_w, double *out_raw, int jac) {
+                             double *out_w, double *out_raw, int jac, int32_t n_batch, int64_t p_stride, int64_t out_stride) {
   if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(param_rows_kernel, dim3((unsigned)N), dim3(jac ? 256 : 64), 0, st, row_param, N, P, ld, p, ymean,
-                     wdiag, in_block, out_w, out_raw, jac);
+  hipLaunchKernelGGL(param_rows_kernel, dim3((unsigned)N, (unsigned)(n_batch < 1 ? 1 : n_batch)), dim3(jac ? 256 : 64), 0, st,
+                     row_param, N, P, ld, p, ymean, wdiag, in_block, out_w, out_raw, jac, p_stride, out_stride);
   return hipGetLastError();
 }
 

@@ -248,7 +248,6 @@ class nonlinear_fit(object):
         """``chi**2(p) - fit.chi2`` (``_fit_dchi2``, src/lsqfit/__init__.py:1648-1670); ``p`` of
         shape (P,) -> float, (m, P) -> array of m values evaluated in one device pass (the
         lbatch layout of ``vegas_fit._chiv``, src/lsqfit/_extras.py:2467-2486)."""
-        self._no_joint()
         p = np.asarray(p, float)
         c = self.problem.chi2_points(p.reshape(-1, self.pmean.size)) - self.chi2
         return float(c[0]) if p.ndim == 1 else c

@@ -91,3 +91,25 @@ def test_many_points_throughput(amd):
     k = int(np.argmax(dc))
     ref = gu.oracle_fit(d)
     assert abs(dc[k] - ofit.dchi2(ref, pts[k])) < 1e-6 * (abs(dc[k]) + fit.chi2)
+
+
+def test_dchi2_with_data_prior_cross_correlations(amd):
+    """examples/y-noerr.py's shape: prior entries whitened together with the data (parameter rows).  chi2 at many points
+    in one pass -- parameter rows take the batch dimension too -- against one evaluation per point, and 0 at the minimum."""
+    from tests.helpers import load, y_noerr_joint
+    k = load('kat.json')['y_noerr']
+    nexp = 2
+    x, mean, cov = y_noerr_joint(k, nexp)
+    P, n = 2 * nexp, len(k['x'])
+    fit = amd.nonlinear_fit(data=(x, mean[:n], cov[:n, :n]), model=amd.multiexp(nexp), prior=(mean[n:], cov[n:, n:]),
+                            cross=cov[:n, n:], tol=k['tol'], svdcut=k['svdcut'], solver='qr')
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal((9, P))
+    pts = fit.pmean + 0.1 * z @ np.linalg.cholesky(fit.cov).T          # 0.1-sigma steps with the fit's own correlations
+    got = fit.dchi2(pts)
+    one = np.array([fit.problem.chi2(p) for p in pts]) - fit.chi2
+    assert np.allclose(got, one, rtol=1e-10, atol=1e-10)
+    assert abs(fit.dchi2(fit.pmean)) < 1e-6 * max(1.0, fit.chi2)
+    # (no quadratic-form check here: the data of this example carry no errors, so a tenth of a prior-dominated sigma
+    # leaves the manifold the data pin down and chi2 is dominated by second-order terms)
+    assert np.all(got > 0)
