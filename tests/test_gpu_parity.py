@@ -556,8 +556,8 @@ def test_y_noerr_out_on_device(amd):
         p0 = fit.pmean
     with pytest.raises(NotImplementedError):
         fit.simulated_fits(2)
-    with pytest.raises(RuntimeError, match='parameter rows'):
-        fit.problem.chi2_points(np.atleast_2d(fit.pmean))
+    # chi2 at many points works for such fits since round 3 (tests/test_gpu_points.py); at the minimum it is the fit's chi2
+    assert abs(fit.problem.chi2_points(np.atleast_2d(fit.pmean))[0] - fit.chi2) < 1e-6 * max(1.0, fit.chi2)
 
 
 def test_cross_correlated_fit_sensitivities(amd):
