@@ -146,7 +146,8 @@ def test_nist_on_device(amd, name):
     assert abs(fit.Q - float(pr['out']['Q'])) < 0.006
     # lanczos1: residuals ~1e-14 are pure roundoff, chi2 itself is only defined to ~1e-3
     assert fit.chi2 == pytest.approx(ref.chi2, rel=2e-3 if name == 'lanczos1' else 1e-6)
-    assert np.all(np.abs(fit.pmean - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-3 * ref.psdev)
+    # the north_star tolerance, relative, parameter by parameter (round 3 measured 1.2e-7 at worst: mgh10)
+    assert np.all(np.abs(fit.pmean - ref.pmean) <= 1e-6 * np.abs(ref.pmean))
     # covariance against the reference's default route (lm/more/qr) at the north_star tolerance
     assert gu.relmax(fit.cov, ref.cov) < 1e-6
     assert fit.description == ref.description == 'methods = lm/more/qr'
