@@ -430,7 +430,8 @@ int lsqamd_timing_enable(lsqamd_fit *fit, int32_t on);
 int lsqamd_timing_get(lsqamd_fit *fit, int32_t which, double *total_ms, int64_t *count);
 int lsqamd_timing_reset(lsqamd_fit *fit);
 /* introspection for tests: bit 0 = batched (uniform-block) whitening in use, bit 1 = Jacobian rows
- * synthesised inside the whitening product, bit 3 = the tape model's formula runs as compiled code (hiprtc) rather than through the
+ * synthesised inside the whitening product, bit 4 = the normal equations of the last accepted step were formed without writing the Jacobian (few
+ * parameters, compiled formula, uncorrelated rows), bit 3 = the tape model's formula runs as compiled code (hiprtc) rather than through the
  * interpreter kernels, bit 2 = LM steps replayed from captured graphs (small
  * single-rank problems without phase timing; LSQAMD_STEP_GRAPH=0 disables),
  * bits 8..31 = split-K factor of the J^T J kernel, bits 32.. = block count */

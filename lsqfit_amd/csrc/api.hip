@@ -29,6 +29,7 @@ using namespace lsqamd;
 namespace {
 
 constexpr int64_t ALIGN = 256;
+constexpr int NRM_BLOCKS = 1024;   // workgroups of the fused normal-equation kernel (few parameters, jit.hip)
 inline int64_t rup(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 struct Carver {
@@ -161,6 +162,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->tvec = cv.take<double>(P + 1);
   const int64_t part = f->npartial * (P + 1);
   f->partial = cv.take<double>(part > 2048 ? part : 2048);
+  if (c.model == LSQAMD_MODEL_TAPE && P <= lsqamd_jit::NRM_MAX_P) f->nrm_part = cv.take<double>(NRM_BLOCKS * 96 + 128);
   f->Wl = cv.take<double>(P * f->ldm);
   f->cov = cv.take<double>(P * f->ldm);
   f->scal = cv.take<double>(16);
@@ -426,6 +428,44 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   const int nbk = f->cfg.n_blocks;
   const int64_t B0 = nbk > 0 ? f->h_size[0] : 0;
   const int64_t slab_doubles = (int64_t)f->splits * P * f->ldm;
+  // few parameters, uncorrelated rows, a compiled formula: J^T J, J^T f and chi2 straight from the model kernel's registers
+  // (jit.hip lsqamd_jit_nrm) -- the Jacobian is never written, the evaluation reads x, y, w once.  Device-resident LM only
+  // (the host-side drivers and the getters call ensure_J() when they need the rows).  LSQAMD_FUSED_NORMAL=0 disables.
+  static const bool nrm_off = [] { const char *e = getenv("LSQAMD_FUSED_NORMAL"); return e && e[0] == '0'; }();
+  const int nq = (!mirror && !nrm_off && f->nrm_part && f->progs.empty() && nbk == 0 && !f->have_param_rows && f->N > 0)
+                     ? lsqamd_jit::normal_nq(static_cast<const lsqamd_jit::Kernel *>(f->jit)) : 0;
+  if (nq > 0) {
+    double *gv = f->redbuf + f->npk;
+    const bool with_prior = f->cfg.has_prior && f->adds_prior;
+    {
+      Scope sc(f, LSQAMD_T_JACOBIAN);
+      int64_t blocks = (f->N + 255) / 256;
+      if (blocks > NRM_BLOCKS) blocks = NRM_BLOCKS;
+      lsqamd_jit::LaunchArgs la;
+      la.x = f->x; la.p = p; la.ymean = f->ymean; la.wdiag = f->wdiag; la.n_data = f->N;
+      HIPCHK(f, lsqamd_jit::launch_normal(static_cast<const lsqamd_jit::Kernel *>(f->jit), f->st, la, f->nrm_part, (int)blocks));
+      double *tot = f->nrm_part + (int64_t)NRM_BLOCKS * 96;
+      HIPCHK(f, launch_colsum_reduce(f->st, f->nrm_part, blocks, nq, tot));
+      HIPCHK(f, launch_nrm_unpack(f->st, tot, P, f->redbuf, gv, with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
+    }
+    f->J_stale = true;
+    f->used_nrm = true;
+    {
+      Scope sc(f, LSQAMD_T_GRAD);
+      f->prior_deferred = with_prior && r_here && small_fuse(f);
+      if (with_prior && !f->prior_deferred)
+        HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, p, f->tvec, gv, 0,
+                                   r_here ? 1 : 0));
+    }
+    rc = do_reduce(f, f->redbuf, f->npk + P + 1);
+    if (rc) return rc;
+    f->have_cov = false;
+    f->have_dense_A = false;
+    f->njev++;
+    f->mirrors_stale = true;
+    return 0;
+  }
+  f->J_stale = false;
   if (nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
       f->h_row0[0] == 0 && (int64_t)nbk * B0 == f->N && whiten_synth_eligible(f->cfg.model, B0, P) &&
       (int64_t)nbk * (B0 / 128) * P <= slab_doubles) {
@@ -660,6 +700,7 @@ int grad_like_at(lsqamd_fit *f, const double *xh, double *out) {
   double c2 = 0.0;
   int rc = eval_residual_dev(f, f->p_trial, &c2);  // f->r = whitened residual at x_h
   if (rc) return rc;
+  if ((rc = ensure_J(f))) return rc;
   HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P, P, f->partial, f->npartial, f->yv, f->r));
   if (f->cfg.has_prior && f->adds_prior)
     HIPCHK(f, launch_add_prior(f->st, nullptr, P, f->prior_prec, f->cfg.prior_dense, f->prior_mean,
@@ -933,6 +974,14 @@ int iterate_varpro(lsqamd_fit *f) {
 
 // host copies of x, g, D, the column norms and the last step after iterations that kept them on
 // the device
+int ensure_J(lsqamd_fit *f) {
+  if (!f->J_stale) return 0;
+  ModelArgs m = model_args(f, f->p_dev);     // (the fused path runs for uncorrelated rows only: no whitening product to redo)
+  HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
+  f->J_stale = false;
+  return 0;
+}
+
 int refresh_mirrors(lsqamd_fit *f) {
   if (!f->mirrors_stale) return 0;
   const int64_t P = f->P;
@@ -2112,6 +2161,7 @@ int lsqamd_get_f(lsqamd_fit *f, double *out, size_t cap) {
   for (size_t b = 0; b < f->h_size.size(); ++b) nfd -= f->h_size[b] - f->h_modes[b];
   if (cap < (size_t)nfd) FAIL(f, LSQAMD_ECAPACITY, "get_f: need %lld", (long long)nfd);
   std::vector<double> r((size_t)(f->N > 0 ? f->N : 1));
+  if (const int rcj = ensure_J(f)) return rcj;
   // the residual at the CURRENT point is column P of J
   HIPCHK(f, launch_copy_strided(f->st, f->J + f->P, f->ld, f->r, 1, f->N, 1));
   HIPCHK(f, hipMemcpyAsync(r.data(), f->r, sizeof(double) * f->N, hipMemcpyDeviceToHost, f->st));
@@ -2131,6 +2181,7 @@ int lsqamd_get_J(lsqamd_fit *f, double *out, size_t cap) {
   if (!f || !out) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_J: no fit has run");
   const int64_t P = f->P;
+  if (const int rcj = ensure_J(f)) return rcj;
   int64_t nfd = f->N;
   for (size_t b = 0; b < f->h_size.size(); ++b) nfd -= f->h_size[b] - f->h_modes[b];
   if (cap < (size_t)(nfd * P)) FAIL(f, LSQAMD_ECAPACITY, "get_J: need %lld", (long long)(nfd * P));
@@ -2221,6 +2272,7 @@ int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, s
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "dpdy: no fit has run");
   const int64_t P = f->P, N = f->N;
   if (m < 1 || (!gt && m != P)) FAIL(f, LSQAMD_EINVAL, "dpdy: gt == NULL needs m == P");
+  if (const int rcj = ensure_J(f)) return rcj;
   const int64_t nrows = N + (f->cfg.has_prior ? P : 0);
   if (cap < (size_t)(nrows * m)) FAIL(f, LSQAMD_ECAPACITY, "dpdy: need %lld", (long long)(nrows * m));
   char *base = (char *)dev_scratch;
@@ -2373,6 +2425,7 @@ void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long 
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;
   return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | (int64_t)(f->graph_launches > 0 ? 4 : 0) |
+         (int64_t)(f->used_nrm ? 16 : 0) |
          (int64_t)(f->jit || (!f->progs.empty() && f->progs_compiled == (int)f->progs.size()) ? 8 : 0) |
          ((int64_t)f->splits << 8) |
          ((int64_t)f->h_size.size() << 32);

@@ -67,6 +67,8 @@ struct lsqamd_fit {
   std::vector<lsqamd::TapeProgram> progs;   // one formula per row range (lsqamd_set_tape_programs); empty: one tape for all rows
   int progs_compiled = 0;
   const void *jit = nullptr;   // the tape compiled (jit.hip); null: interpreted (jit_why says why)
+  double *nrm_part = nullptr;  // few parameters: per-workgroup sums of the fused normal-equation kernel, then their total
+  bool J_stale = false;        // the last normal equations were formed WITHOUT writing J (jit.hip lsqamd_jit_nrm): ensure_J() first
   std::string jit_why;
   int32_t *syrk_map = nullptr;
   int32_t syrk_nwork = 0;
@@ -111,7 +113,7 @@ struct lsqamd_fit {
   bool lm_zero_copy = false;   // the device kernels mirror the LM record into pin_lm themselves (no copy per read)
   // f->r holds the whitened residual AT r_ptr's current contents (set by iterate_device right before
   // the accepted point's normal equations, consumed there: the fused Jacobian path needs it)
-  bool r_fresh = false, used_synth = false;
+  bool r_fresh = false, used_synth = false, used_nrm = false;
   const double *r_ptr = nullptr;
   int32_t conv_info_dev = 0;
   bool initialised = false, have_cov = false, have_dense_A = false;
@@ -213,6 +215,8 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out);
 int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror = true);
 // host copies of x, g, D, column norms, v after steps that kept them on the device
 int refresh_mirrors(lsqamd_fit *f);
+// the whitened Jacobian at the current point in f->J (a no-op unless the fused normal-equation kernel skipped it)
+int ensure_J(lsqamd_fit *f);
 // (A + mu D^2) v = g -> f->hv ; LSQAMD_ENOTPD when a pivot fails.  diag_host nullptr: the
 // device-resident D.  frozen_host (with mu = 0): flags of parameters taken out of the system.
 int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const double *frozen_host = nullptr);

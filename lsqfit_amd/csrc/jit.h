@@ -26,4 +26,10 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
 hipError_t launch(const Kernel *k, hipStream_t st, bool jac, const LaunchArgs &a);
 bool available(std::string *why);
 
+// Few parameters (<= NRM_MAX_P), one lane per data row, uncorrelated rows: a third kernel accumulates J^T J (upper, row-major),
+// J^T f and |f|^2 -- normal_nq() numbers per workgroup into partial[blocks][nq] -- without ever writing the Jacobian.
+constexpr int NRM_MAX_P = 12;
+int normal_nq(const Kernel *k);     // 0: this formula has no such kernel
+hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, double *partial, int blocks);
+
 }  // namespace lsqamd_jit

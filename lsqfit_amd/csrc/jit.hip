@@ -148,6 +148,7 @@ struct Plan {
   std::vector<double> consts;
   int P = 0, n_x = 1;
   bool wave_per_row = false;
+  bool nrm_ok = false;          // few parameters, no wide sums: a third kernel forms J^T J, J^T f and chi2 without writing J
 };
 
 bool is_push(int op) { return op <= LSQAMD_OP_P; }
@@ -384,6 +385,7 @@ bool make_plan(const int32_t *code, int n_code, const double *consts, int n_cons
     if (isout[(size_t)j]) pl.out_params.push_back(j);
   if ((int)pl.out_params.size() > MAX_OUT_PARAMS) { why = "too many parameters outside the wide sums"; return false; }
   pl.wave_per_row = !pl.wsums.empty();
+  pl.nrm_ok = !pl.wave_per_row && P >= 1 && P <= lsqamd_jit::NRM_MAX_P;
   return true;
 }
 
@@ -694,6 +696,53 @@ std::string generate(const Plan &pl) {
     }
     o.s += "  }\n}\n";
   }
+  if (pl.nrm_ok) {
+    // ---- normal equations without the Jacobian: per lane P (P + 1) / 2 + P + 1 running sums over its rows
+    const int P = pl.P, NA = P * (P + 1) / 2, NQ = NA + P + 1;
+    o.f("extern \"C\" __global__ __launch_bounds__(256) void lsqamd_jit_nrm(Args a) {\n");
+    o.f("  __shared__ double sp[%d];\n  __shared__ double red[4][%d];\n", P, NQ);
+    o.f("  for (int i = threadIdx.x; i < %d; i += 256) sp[i] = a.p[i];\n  __syncthreads();\n", P);
+    o.s += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
+    for (int i = 0; i < P; ++i)
+      for (int j = i; j < P; ++j) o.f("  double nA%d_%d = 0.0;\n", i, j);
+    for (int i = 0; i < P; ++i) o.f("  double nG%d = 0.0;\n", i);
+    o.s += "  double nC = 0.0;\n";
+    o.s += "  for (long long row = (long long)blockIdx.x * 256 + threadIdx.x; row < a.n_data; row += (long long)gridDim.x * 256) {\n";
+    for (int i = 0; i < pl.n_x; ++i)
+      if (xused[(size_t)i]) o.f("    const double x%d = a.x[row * %d + %d];\n", i, pl.n_x, i);
+    o.s += "    const double w = a.wdiag[row];\n";
+    for (int j = 0; j < nout; ++j) o.f("    double oacc%d = 0.0;\n", j);
+    {
+      TreeGen tg(pl.outer, pl, o, "o", "    ", true);
+      tg.leaf_value = [&](const Node &nd) { return "sp[" + std::to_string(nd.arg) + "]"; };
+      tg.leaf_adjoint = [&](const Node &nd, const std::string &gg) {
+        int j = 0;
+        while (pl.out_params[(size_t)j] != nd.arg) ++j;
+        o.f("    oacc%d += %s;\n", j, gg.c_str());
+      };
+      tg.forward(pl.oroot);
+      o.f("    const double fval = %s;\n    const double one = 1.0;\n", tg.v(pl.oroot).c_str());
+      tg.reverse(pl.oroot, "one");
+    }
+    o.s += "    const double rr = w * (fval - a.ymean[row]);\n";
+    std::vector<int> slot((size_t)P, -1);
+    for (int j = 0; j < nout; ++j) slot[(size_t)pl.out_params[(size_t)j]] = j;
+    for (int i = 0; i < P; ++i) {
+      if (slot[(size_t)i] >= 0) o.f("    const double dd%d = w * oacc%d;\n", i, slot[(size_t)i]);
+      else o.f("    const double dd%d = 0.0;\n", i);
+    }
+    for (int i = 0; i < P; ++i)
+      for (int j = i; j < P; ++j) o.f("    nA%d_%d += dd%d * dd%d;\n", i, j, i, j);
+    for (int i = 0; i < P; ++i) o.f("    nG%d += dd%d * rr;\n", i, i);
+    o.s += "    nC += rr * rr;\n  }\n";
+    int q = 0;
+    for (int i = 0; i < P; ++i)
+      for (int j = i; j < P; ++j) { o.f("  { const double t = wsum(nA%d_%d); if (lane == 0) red[wave][%d] = t; }\n", i, j, q); ++q; }
+    for (int i = 0; i < P; ++i) { o.f("  { const double t = wsum(nG%d); if (lane == 0) red[wave][%d] = t; }\n", i, q); ++q; }
+    o.f("  { const double t = wsum(nC); if (lane == 0) red[wave][%d] = t; }\n", q);
+    o.f("  __syncthreads();\n  if (threadIdx.x < %d) a.out_w[(long long)blockIdx.x * %d + threadIdx.x] = "
+        "red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];\n}\n", NQ, NQ);
+  }
   return o.s;
 }
 
@@ -773,8 +822,10 @@ bool compile_source(const std::string &src, std::vector<char> &code, std::string
 
 struct Loaded {
   hipModule_t mod = nullptr;
-  hipFunction_t res = nullptr, jac = nullptr;
+  hipFunction_t res = nullptr, jac = nullptr, nrm = nullptr;
   bool wave_per_row = false;
+  int n_param = 0;
+  bool nrm_ok = false;          // few parameters, no wide sums: a third kernel forms J^T J, J^T f and chi2 without writing J
 };
 std::mutex g_mu;
 
@@ -787,11 +838,12 @@ struct Kernel {
 };
 
 int plan_and_generate(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x,
-                      std::string &src, int *variant, std::string &why) {
+                      std::string &src, int *variant, std::string &why, bool *has_nrm = nullptr) {
   Plan pl;
   if (!make_plan(code, n_code, consts, n_consts, P, n_x, pl, why)) return 1;
   src = generate(pl);
   if (variant) *variant = pl.wave_per_row ? 1 : 0;
+  if (has_nrm) *has_nrm = pl.nrm_ok;
   return 0;
 }
 
@@ -799,7 +851,8 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
   if (!rtc().ok) { why = rtc().why; return nullptr; }
   std::string src;
   int variant = 0;
-  if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why)) return nullptr;
+  bool has_nrm = false;
+  if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why, &has_nrm)) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { why = "no device"; (void)hipGetLastError(); return nullptr; }
   const std::pair<int, uint64_t> key{dev, fnv1a(src)};
@@ -819,6 +872,11 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
     return nullptr;
   }
   k.l.wave_per_row = variant == 1;
+  k.l.n_param = P;
+  if (has_nrm && hipModuleGetFunction(&k.l.nrm, k.l.mod, "lsqamd_jit_nrm") != hipSuccess) {
+    (void)hipGetLastError();
+    k.l.nrm = nullptr;
+  }
   return &kernels.emplace(key, k).first->second;
 }
 
@@ -834,6 +892,22 @@ hipError_t launch(const Kernel *k, hipStream_t st, bool jac, const LaunchArgs &a
   if (blocks > 8192) blocks = 8192;
   return hipModuleLaunchKernel(jac ? k->l.jac : k->l.res, (unsigned)blocks, (unsigned)(a.n_batch < 1 ? 1 : a.n_batch), 1, 256, 1, 1, 0,
                                st, nullptr, cfg);
+}
+
+int normal_nq(const Kernel *k) {
+  if (!k || !k->l.nrm) return 0;
+  const int P = k->l.n_param;
+  return P * (P + 1) / 2 + P + 1;
+}
+
+hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, double *partial, int blocks) {
+  if (!k || !k->l.nrm || blocks < 1) return hipErrorInvalidValue;
+  struct { const double *x, *p, *ymean, *wdiag; const unsigned char *in_block; double *out_w, *out_raw; long long ld, n_data;
+           long long p_stride, out_stride, ymean_stride; const int *batch_active; } args =
+      {a.x, a.p, a.ymean, a.wdiag, nullptr, partial, nullptr, 1, (long long)a.n_data, 0, 0, 0, nullptr};
+  size_t sz = sizeof(args);
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(k->l.nrm, (unsigned)blocks, 1, 1, 256, 1, 1, 0, st, nullptr, cfg);
 }
 
 bool available(std::string *why) {

@@ -232,7 +232,8 @@ static int qr_factor(lsqamd_fit *f, QrPlan &q, double mu, double *logdet_out) {
   const dim3 tgrid((unsigned)(T * (T + 1) / 2), 16);
   const unsigned pb = (unsigned)((P + 255) / 256);
   const bool damped = mu > 0.0;
-  const bool mine = f->adds_prior;            // the replicated terms (prior, damping) enter the sums on one rank
+  const bool mine = f->adds_prior;
+  if (const int rcj = ensure_J(f)) return rcj;   // (few-parameter fits form their normal equations without writing J)            // the replicated terms (prior, damping) enter the sums on one rank
   // D_c from the Gram matrix of the current point (all-reduced, prior included; + mu D^2 for a damped solve)
   HIPCHK(f, launch_packed_diag(st, f->redbuf, P, q.dwork));
   if (damped) hipLaunchKernelGGL(damp_vec_kernel, dim3(pb), dim3(256), 0, st, P, mu, f->dscale, q.damp, q.dwork);

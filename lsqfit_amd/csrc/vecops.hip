@@ -926,6 +926,29 @@ hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, doub
 }
 
 
+
+// ---- few parameters: the sums of the fused normal-equation kernel (jit.hip lsqamd_jit_nrm) into their places -----
+// q = [J^T J upper row-major | J^T f | |f|^2] -> the packed 128 x 128 tile (both triangles, prior precision added on the
+// way like finalize_pack does), gvec = [J^T f ; chi2]
+__global__ __launch_bounds__(256) void nrm_unpack_kernel(const double *q, int P, double *apk, double *gvec, const double *prior,
+                                                         int prior_dense) {
+  const int NA = P * (P + 1) / 2;
+  for (int e = threadIdx.x; e < P * P; e += 256) {
+    const int i = e / P, j = e % P;
+    const int a = i < j ? i : j, b = i < j ? j : i;
+    double v = q[a * P - a * (a - 1) / 2 + (b - a)];
+    if (prior) v += prior_dense ? prior[i * P + j] : (i == j ? prior[i] : 0.0);
+    apk[i * TB + j] = v;
+  }
+  for (int j = threadIdx.x; j <= P; j += 256) gvec[j] = q[NA + j];
+}
+
+hipError_t launch_nrm_unpack(hipStream_t st, const double *q, int64_t P, double *apk, double *gvec, const double *prior,
+                             int32_t prior_dense) {
+  hipLaunchKernelGGL(nrm_unpack_kernel, dim3(1), dim3(256), 0, st, q, (int)P, apk, gvec, prior, (int)prior_dense);
+  return hipGetLastError();
+}
+
 // ---- small fits: the tail of a trial in ONE single-workgroup launch ------------------------------------------
 // |f_trial|^2 over n <= 65536 residuals, the prior's share for a diagonal (or absent) prior -- t = Lambda (p - pbar)
 // is left in tvec for the accepted branch, as prior_vec_kernel does -- and the decision of lm_trial_tail_kernel:
