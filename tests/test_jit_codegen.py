@@ -42,6 +42,11 @@ def test_nist_models_compile_for_gfx950(lib, name):
     for j in range(d['nparam']):          # every parameter gets its column, the residual the last one
         assert 'dst[%d] = w * oacc' % j in body(src, 'lsqamd_jit_jac')
     assert 'dst[%d] = w * (fval - a.ymean[row])' % d['nparam'] in src
+    # few parameters: the third kernel that forms J^T J, J^T f and chi2 without writing the Jacobian
+    nq = d['nparam'] * (d['nparam'] + 1) // 2 + d['nparam'] + 1
+    nrm = body(src, 'lsqamd_jit_nrm')
+    assert '__shared__ double red[4][%d];' % nq in nrm and 'nC += rr * rr;' in nrm
+    assert nrm.count(' += dd') == nq - 1
 
 
 def test_wide_sum_becomes_one_loop_with_contiguous_columns(lib):
@@ -53,6 +58,7 @@ def test_wide_sum_becomes_one_loop_with_contiguous_columns(lib):
     assert 'dst[(0 + k)] = w * e0;' in jac and 'dst[(512 + k)] = w * e1;' in jac
     assert 'sincos_moderate<true>' in jac and 'cos_moderate<true>' in body(src, 'lsqamd_jit_res')
     assert 'T0_' not in src                                                # affine parameter indices: no table
+    assert 'lsqamd_jit_nrm' not in src                                     # wide sums: no register-resident normal equations
 
 
 def test_sum_inside_a_product_takes_its_adjoint_from_the_outer_sweep(lib):
