@@ -1020,10 +1020,23 @@ static bool small_fuse(const lsqamd_fit *f) {
 static int enqueue_trial(lsqamd_fit *f) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
+  const bool watch = f->opt.solver == LSQAMD_SOLVER_QR;    // solver = qr: how much of each column its pivot retained
+  if (small_fuse(f) && P <= 12) {
+    // a dozen parameters at most: the whole trial solve (build, factor, substitute, trial point, record) by one wave
+    // out of the packed tile -- one launch instead of six
+    {
+      Scope sc(f, LSQAMD_T_CHOLESKY);
+      HIPCHK(f, launch_lm_tiny12_solve(f->st, f->redbuf, P, gvec, f->dscale, f->p_dev, f->p_trial, f->yv + P, f->lmd, f->info_dev,
+                                       watch ? 1 : 0));
+    }
+    const int rct = eval_residual_launch(f, f->p_trial, true);
+    if (rct) return rct;
+    if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+    return 0;
+  }
   const bool small = small_fuse(f) && (P == 128 || P == 256);   // (whole 128-blocks: the kernel's GEMVs read full tiles)
   int rc = solve_damped_launch(f, f->mu, nullptr, nullptr, false, f->lmd + LMS_MU, small);
   if (rc) return rc;
-  const bool watch = f->opt.solver == LSQAMD_SOLVER_QR;    // solver = qr: how much of each column its pivot retained
   if (small) {
     Scope sc(f, LSQAMD_T_SOLVE);
     HIPCHK(f, launch_lm_solve_tail_small(f->st, f->M, f->ldm, P, f->chol_work, f->p_dev, gvec, f->dscale, f->p_trial, f->yv + P,

@@ -249,6 +249,9 @@ hipError_t launch_lm_accept_tail(hipStream_t st, const double *apk, int64_t P, i
 hipError_t launch_lm_solve_tail_small(hipStream_t st, const double *M, int64_t ld, int64_t n, const double *uinv,
                                       const double *x, const double *g, const double *d, double *xt, double *v_out,
                                       double *lmd, const double *a_diag, const int32_t *chol_info);
+// P <= 12: build (A + mu D^2 | g) from the packed tile, factor, solve, trial point, record -- one wave, one launch
+hipError_t launch_lm_tiny12_solve(hipStream_t st, const double *apk, int64_t P, const double *g, const double *d,
+                                  const double *x, double *xt, double *v_out, double *lmd, int32_t *chol_info, int watch);
 // q = [J^T J upper | J^T f | chi2] of the fused normal-equation kernel -> packed tile (+ prior precision), gvec
 hipError_t launch_nrm_unpack(hipStream_t st, const double *q, int64_t P, double *apk, double *gvec, const double *prior,
                              int32_t prior_dense);

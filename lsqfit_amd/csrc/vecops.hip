@@ -949,6 +949,94 @@ hipError_t launch_nrm_unpack(hipStream_t st, const double *q, int64_t P, double 
   return hipGetLastError();
 }
 
+
+// ---- a dozen parameters at most: a whole trial solve by ONE WAVE, the matrix in registers ------------------------
+// (A + mu D^2) v = g for P <= 12: lane j holds column j of the upper triangle (12 registers), lane 12 the right-hand
+// side; the factorisation is 12 unrolled steps of shuffles and FMAs (the forward substitution rides along in lane
+// 12), the back substitution 12 wave sums -- no LDS, no barrier, ~200 shuffles in all -- followed by the trial point
+// and the record's dot products.  Replaces build_damped + diagonal-block kernel + row panel + column copy + back
+// substitution + lm_trial (six dependent launches, 50 us) for the fits lsqfit is used for every day.
+constexpr int T12 = 12;
+__global__ __launch_bounds__(64) void lm_tiny12_solve_kernel(const double *apk, int P, const double *g, const double *d,
+                                                             const double *x, double *xt, double *v_out, double *st,
+                                                             int32_t *chol_info, int watch) {
+  const int lane = threadIdx.x;
+  const double mu = st[LMS_MU];
+  double m[T12];
+  double diag0 = 1.0;                     // the damped diagonal entry of this lane's column, before the factorisation
+#pragma unroll
+  for (int i = 0; i < T12; ++i) {
+    double v = 0.0;
+    if (lane < T12) {
+      if (lane < P && i <= lane && i < P) {
+        v = apk[i * TB + lane];           // (P <= 128: the packed form is ONE 128 x 128 tile)
+        if (i == lane) { v += mu * d[i] * d[i]; diag0 = v; }
+      } else if (i == lane) v = 1.0;      // padding: unit diagonal
+    } else if (lane == T12 && i < P) v = g[i];
+    m[i] = v;
+  }
+  int fail = 0;
+  double pmin = INFINITY;
+#pragma unroll
+  for (int k = 0; k < T12; ++k) {
+    const double pk = __shfl(m[k], k, 64);
+    if (!(pk > 0.0) && fail == 0) fail = k + 1;               // uniform
+    const double uk = sqrt(pk > 0.0 ? pk : 1.0), inv = 1.0 / uk;
+    if (lane == k) { pmin = pk / diag0 < pmin ? pk / diag0 : pmin; m[k] = uk; }
+    else if (lane > k) m[k] *= inv;
+#pragma unroll
+    for (int i = k + 1; i < T12; ++i) {
+      const double ui = __shfl(m[k], i, 64);
+      if (lane >= i) m[i] -= ui * m[k];
+    }
+  }
+  // back substitution: y lives in lane 12, v_k ends up in lane k
+  double vl = 0.0;
+#pragma unroll
+  for (int k = T12 - 1; k >= 0; --k) {
+    double t = (lane > k && lane < T12) ? m[k] * vl : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);   // lanes 0..15 hold everything that matters
+    const double yk = __shfl(m[k], T12, 64), ukk = __shfl(m[k], k, 64);
+    const double vk = (yk - __shfl(t, 0, 64)) / ukk;
+    if (lane == k) vl = vk;
+  }
+  const bool bad = fail != 0;
+  double vg = 0.0, dv2 = 0.0, nf = 0.0;
+  if (lane < P) {
+    const double vj = bad ? NAN : vl;
+    v_out[lane] = vj;
+    xt[lane] = x[lane] - vj;
+    vg = vj * g[lane];
+    const double t = d[lane] * vj;
+    dv2 = t * t;
+    nf = (vj - vj == 0.0) ? 0.0 : 1.0;
+  } else {
+    pmin = INFINITY;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vg += __shfl_xor(vg, o, 64);
+    dv2 += __shfl_xor(dv2, o, 64);
+    nf += __shfl_xor(nf, o, 64);
+    pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
+  }
+  if (lane == 0) {
+    chol_info[0] = fail;
+    st[LMS_VG] = vg;
+    st[LMS_DV2] = dv2;
+    st[LMS_VFINITE] = nf == 0.0 ? 1.0 : 0.0;
+    st[LMS_PIVMIN] = (watch && !bad) ? pmin : 1.0;
+  }
+}
+
+hipError_t launch_lm_tiny12_solve(hipStream_t stream, const double *apk, int64_t P, const double *g, const double *d,
+                                  const double *x, double *xt, double *v_out, double *st, int32_t *chol_info, int watch) {
+  if (P < 1 || P > T12) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(lm_tiny12_solve_kernel, dim3(1), dim3(64), 0, stream, apk, (int)P, g, d, x, xt, v_out, st, chol_info, watch);
+  return hipGetLastError();
+}
+
 // ---- small fits: the tail of a trial in ONE single-workgroup launch ------------------------------------------
 // |f_trial|^2 over n <= 65536 residuals, the prior's share for a diagonal (or absent) prior -- t = Lambda (p - pbar)
 // is left in tvec for the accepted branch, as prior_vec_kernel does -- and the decision of lm_trial_tail_kernel:
