@@ -444,9 +444,14 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
       lsqamd_jit::LaunchArgs la;
       la.x = f->x; la.p = p; la.ymean = f->ymean; la.wdiag = f->wdiag; la.n_data = f->N;
       HIPCHK(f, lsqamd_jit::launch_normal(static_cast<const lsqamd_jit::Kernel *>(f->jit), f->st, la, f->nrm_part, (int)blocks));
-      double *tot = f->nrm_part + (int64_t)NRM_BLOCKS * 96;
-      HIPCHK(f, launch_colsum_reduce(f->st, f->nrm_part, blocks, nq, tot));
-      HIPCHK(f, launch_nrm_unpack(f->st, tot, P, f->redbuf, gv, with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
+      // few rows as well, one rank: totalling the sums and unpacking them is left to the accept-tail kernel (one launch
+      // instead of three); the prior's share of g and chi2 then has to be deferred to it too
+      f->nrm_in_tail = blocks <= 64 && small_fuse(f) && (!with_prior || r_here) ? (int)blocks : 0;
+      if (!f->nrm_in_tail) {
+        double *tot = f->nrm_part + (int64_t)NRM_BLOCKS * 96;
+        HIPCHK(f, launch_colsum_reduce(f->st, f->nrm_part, blocks, nq, tot));
+        HIPCHK(f, launch_nrm_unpack(f->st, tot, P, f->redbuf, gv, with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
+      }
     }
     f->J_stale = true;
     f->used_nrm = true;
@@ -466,6 +471,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     return 0;
   }
   f->J_stale = false;
+  f->nrm_in_tail = 0;
   if (nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
       f->h_row0[0] == 0 && (int64_t)nbk * B0 == f->N && whiten_synth_eligible(f->cfg.model, B0, P) &&
       (int64_t)nbk * (B0 / 128) * P <= slab_doubles) {
@@ -1062,8 +1068,11 @@ static int enqueue_accept(lsqamd_fit *f) {   // p_trial becomes the point; the c
   int rc = eval_normal_dev(f, f->p_trial, false);
   if (rc) return rc;
   // (prior_deferred: g += Lambda (p - pbar), chi2 += ... inside the tail kernel -- one launch fewer)
+  const bool wp = f->cfg.has_prior && f->adds_prior;
   HIPCHK(f, launch_lm_accept_tail(f->st, f->redbuf, P, f->opt.scaler, f->diag_dev, f->dscale, f->p_trial, f->yv + P, gvec,
-                                  f->opt.xtol, f->opt.gtol, f->lmd, f->prior_deferred ? f->tvec : nullptr, f->prior_mean));
+                                  f->opt.xtol, f->opt.gtol, f->lmd, f->prior_deferred ? f->tvec : nullptr, f->prior_mean,
+                                  f->nrm_in_tail ? f->nrm_part : nullptr, f->nrm_in_tail, (f->nrm_in_tail && wp) ? f->prior_prec : nullptr,
+                                  f->cfg.prior_dense));
   if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
   return 0;
 }
@@ -1107,6 +1116,8 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
     f->have_dense_A = false;
     f->njev++;
     f->mirrors_stale = true;
+    f->J_stale = f->used_nrm;   // (the captured branch formed its normal equations without writing J: see eval_normal_dev;
+                                //  a handle takes that route for all of its accepted steps or for none)
   } else {
     f->r_fresh = false;
   }
@@ -1639,6 +1650,8 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
   f->progs.clear();
+  f->used_nrm = false;
+  f->J_stale = false;
   if (!code || n_code < 1 || n_code > f->tape_cap || n_consts < 0 || n_consts > 1024)
     FAIL(f, LSQAMD_EINVAL, "set_tape: 1..%d instructions (lsqamd_config.tape_len), <= 1024 constants", f->tape_cap);
   {
@@ -1737,6 +1750,8 @@ int lsqamd_set_tape_programs(lsqamd_fit *f, int32_t n_prog, const int64_t *row0,
                              const int32_t *code_off, const double *consts, int32_t n_consts) {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
+  f->used_nrm = false;
+  f->J_stale = false;
   if (f->cfg.model != LSQAMD_MODEL_TAPE) FAIL(f, LSQAMD_EINVAL, "set_tape_programs: the handle's model is not LSQAMD_MODEL_TAPE");
   if (n_prog < 1 || !row0 || !code || !code_off || n_consts < 0 || n_consts > 1024 || (n_consts > 0 && !consts))
     FAIL(f, LSQAMD_EINVAL, "set_tape_programs: n_prog >= 1, row0[n_prog + 1], code, code_off[n_prog + 1], <= 1024 constants");

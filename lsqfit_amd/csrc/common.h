@@ -244,7 +244,11 @@ hipError_t launch_lm_trial_tail(hipStream_t st, const double *r, int64_t n, doub
 // tvec / pmean given: g += tvec, chi2 += (x - pmean) . tvec first (the prior's share, prior_apply_kernel folded in)
 hipError_t launch_lm_accept_tail(hipStream_t st, const double *apk, int64_t P, int scaler, double *coln2,
                                  double *dscale, const double *x, const double *v, double *gvec, double xtol,
-                                 double gtol, double *lmd, const double *tvec = nullptr, const double *pmean = nullptr);
+                                 double gtol, double *lmd, const double *tvec = nullptr, const double *pmean = nullptr,
+                                 // nrm_part: the <= 64 per-workgroup sums of the fused normal-equation kernel are totalled and
+                                 // unpacked (into apk / gvec, prior precision added) by this launch first
+                                 const double *nrm_part = nullptr, int nrm_blocks = 0, const double *nrm_prior = nullptr,
+                                 int nrm_prior_dense = 0);
 // small systems (n <= 256): back substitution + trial point + the record's dot products in one single-workgroup launch
 hipError_t launch_lm_solve_tail_small(hipStream_t st, const double *M, int64_t ld, int64_t n, const double *uinv,
                                       const double *x, const double *g, const double *d, double *xt, double *v_out,

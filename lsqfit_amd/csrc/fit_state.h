@@ -68,6 +68,7 @@ struct lsqamd_fit {
   int progs_compiled = 0;
   const void *jit = nullptr;   // the tape compiled (jit.hip); null: interpreted (jit_why says why)
   double *nrm_part = nullptr;  // few parameters: per-workgroup sums of the fused normal-equation kernel, then their total
+  int nrm_in_tail = 0;         // > 0: that many per-workgroup sums wait for the accept-tail kernel to total and unpack them
   bool J_stale = false;        // the last normal equations were formed WITHOUT writing J (jit.hip lsqamd_jit_nrm): ensure_J() first
   std::string jit_why;
   int32_t *syrk_map = nullptr;

@@ -1127,8 +1127,30 @@ __global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, 
                                                              double *coln2, double *dscale, const double *x,
                                                              const double *v, double *gvec, double xtol,
                                                              double gtol, double *st, const double *tvec,
-                                                             const double *pmean) {
+                                                             const double *pmean, const double *nrm_part, int nrm_blocks,
+                                                             const double *nrm_prior, int nrm_prior_dense, double *apk_w) {
   __shared__ double sh[4];
+  __shared__ double nq_s[96];
+  if (nrm_part) {
+    // few parameters, few rows (jit.hip lsqamd_jit_nrm, <= 64 workgroups): the per-workgroup sums are added up here, in
+    // workgroup order, and unpacked into the packed tile / gvec -- colsum_reduce + nrm_unpack folded into this launch
+    const int Pn = (int)P, NA = Pn * (Pn + 1) / 2, NQ = NA + Pn + 1;
+    if ((int)threadIdx.x < NQ) {
+      double a = 0.0;
+      for (int b = 0; b < nrm_blocks; ++b) a += nrm_part[b * NQ + threadIdx.x];
+      nq_s[threadIdx.x] = a;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < Pn * Pn; e += 256) {
+      const int i = e / Pn, j = e % Pn;
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      double val = nq_s[a * Pn - a * (a - 1) / 2 + (b - a)];
+      if (nrm_prior) val += nrm_prior_dense ? nrm_prior[i * Pn + j] : (i == j ? nrm_prior[i] : 0.0);
+      apk_w[i * TB + j] = val;
+    }
+    for (int j = threadIdx.x; j <= Pn; j += 256) gvec[j] = nq_s[NA + j];
+    __syncthreads();
+  }
   double notx = 0.0, gn = 0.0;
   if (tvec) {   // the prior's share of g and chi2 (prior_apply_kernel, same sums in the same order) rides along
     double a = 0.0;
@@ -1175,10 +1197,11 @@ __global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, 
 
 hipError_t launch_lm_accept_tail(hipStream_t stream, const double *apk, int64_t P, int scaler, double *coln2,
                                  double *dscale, const double *x, const double *v, double *gvec, double xtol,
-                                 double gtol, double *st, const double *tvec, const double *pmean) {
+                                 double gtol, double *st, const double *tvec, const double *pmean, const double *nrm_part,
+                                 int nrm_blocks, const double *nrm_prior, int nrm_prior_dense) {
   const int64_t T = (P + TB - 1) / TB;
   hipLaunchKernelGGL(lm_accept_tail_kernel, dim3(1), dim3(256), 0, stream, apk, P, T, scaler, coln2, dscale, x, v, gvec,
-                     xtol, gtol, st, tvec, pmean);
+                     xtol, gtol, st, tvec, pmean, nrm_part, nrm_blocks, nrm_prior, nrm_prior_dense, const_cast<double *>(apk));
   return hipGetLastError();
 }
 

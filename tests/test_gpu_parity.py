@@ -151,7 +151,18 @@ def test_nist_on_device(amd, name):
     # ends somewhere within 1e-4 sigma of where the oracle's trajectory ends (round 2 allowed 1e-3 sigma)
     assert np.all(np.abs(fit.pmean - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-4 * ref.psdev)
     # covariance against the reference's default route (lm/more/qr) at the north_star tolerance
-    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    if name == 'bennett5':
+        # ... at one and the same point: along bennett5's valley the covariance moves by 1e-3 over the 1e-4 sigma the two
+        # trajectories' end points differ by (303 iterations each), so the oracle's covariance recipe (its whitened
+        # Jacobian from dual numbers, gsl_multifit_nlinear_covar's pivoted QR) is evaluated at the device's end point
+        from oracle import lm as olm
+        Jat = ref.chiv.jacobian(fit.pmean)
+        lin = olm._DenseLin('qr')
+        lin.set(Jat, np.zeros(Jat.shape[0]))
+        assert gu.relmax(fit.cov, lin.covar()) < 1e-6
+        assert gu.relmax(fit.cov, ref.cov) < 5e-3
+    else:
+        assert gu.relmax(fit.cov, ref.cov) < 1e-6
     assert fit.description == ref.description == 'methods = lm/more/qr'
     assert fit.stopping_criterion == 1
 
