@@ -132,6 +132,8 @@ struct Group {            // look-alike terms of one additive chain, one sign
   std::vector<std::vector<int>> idx;   // [slot][term] parameter index
   std::vector<int> shared;             // [slot] 1: the same parameter in every term (accumulated), 0: private (stored)
   std::vector<int> base, stride;       // [slot] affine index base + k * stride, or stride = INT_MIN: table
+  std::vector<int> cnodes;             // constant nodes of the template term, in traversal order
+  std::vector<std::vector<double>> cvals;   // [constant][term]; one entry when the value is the same in every term
 };
 struct WSum {
   std::vector<Group> groups;
@@ -199,6 +201,9 @@ void flatten(const std::vector<Node> &nodes, int n, std::vector<std::pair<int, i
 struct Sig {
   std::string text;
   std::vector<int> params;   // slot -> parameter index
+  std::vector<double> cvals; // constants in traversal order (their VALUES are not part of the structure: a Fourier series
+                             // a_k cos(k x) with literal k is one group with a table of k's)
+  std::vector<int> cnodes;   // ... and the nodes they sit in
   int n_nodes = 0;
 };
 void signature(const std::vector<Node> &nodes, const std::vector<double> &consts, int n, Sig &s) {
@@ -212,9 +217,9 @@ void signature(const std::vector<Node> &nodes, const std::vector<double> &consts
     if (slot < 0) { slot = (int)s.params.size(); s.params.push_back(nd.arg); }
     snprintf(b, sizeof(b), "P%d;", slot);
   } else if (nd.op == LSQAMD_OP_CONST) {
-    uint64_t u;
-    std::memcpy(&u, &consts[(size_t)nd.arg], 8);
-    snprintf(b, sizeof(b), "C%016" PRIx64 ";", u);
+    snprintf(b, sizeof(b), "K%d;", (int)s.cvals.size());
+    s.cvals.push_back(consts[(size_t)nd.arg]);
+    s.cnodes.push_back(n);
   } else if (nd.op == LSQAMD_OP_X) {
     snprintf(b, sizeof(b), "X%d;", nd.arg);
   } else {
@@ -317,6 +322,20 @@ struct Builder {
         g.stride[(size_t)s] = affine ? st0 : INT32_MIN;
       }
       if (!ok) continue;
+      g.cnodes = sigs[mem[0]].cnodes;
+      g.cvals.assign(g.cnodes.size(), std::vector<double>());
+      for (size_t c = 0; c < g.cnodes.size(); ++c) {
+        bool same = true;
+        for (int k = 1; k < g.n_terms; ++k) {
+          uint64_t u0, u1;
+          std::memcpy(&u0, &sigs[mem[0]].cvals[c], 8);
+          std::memcpy(&u1, &sigs[mem[(size_t)k]].cvals[c], 8);
+          same = same && u0 == u1;
+        }
+        if (same) g.cvals[c].push_back(sigs[mem[0]].cvals[c]);
+        else
+          for (int k = 0; k < g.n_terms; ++k) g.cvals[c].push_back(sigs[mem[(size_t)k]].cvals[c]);
+      }
       for (size_t m : mem) grouped[m] = 1;
       ws.groups.push_back(std::move(g));
     }
@@ -420,6 +439,7 @@ struct TreeGen {
   bool jac;
   std::function<std::string(const Node &)> leaf_value;                          // P / WSUM leaves
   std::function<void(const Node &, const std::string &)> leaf_adjoint;          // adjoint arriving at a P / WSUM leaf
+  std::function<std::string(int)> const_value;                                  // optional: expression for the constant in node n
   TreeGen(const std::vector<Node> &n, const Plan &p, Src &out, const std::string &prefix, const std::string &indent, bool j)
       : nodes(n), pl(p), o(out), pfx(prefix), ind(indent), jac(j) {}
 
@@ -435,7 +455,9 @@ struct TreeGen {
     const std::string A = nd.a >= 0 ? v(nd.a) : "", B = nd.b >= 0 ? v(nd.b) : "";
     const char *a = A.c_str(), *b = B.c_str(), *vv = V.c_str();
     switch (nd.op) {
-      case LSQAMD_OP_CONST: o.f("%sconst double %s = %s;\n", i, vv, dlit(pl.consts[(size_t)nd.arg]).c_str()); break;
+      case LSQAMD_OP_CONST:
+        o.f("%sconst double %s = %s;\n", i, vv, (const_value ? const_value(n) : dlit(pl.consts[(size_t)nd.arg])).c_str());
+        break;
       case LSQAMD_OP_X: o.f("%sconst double %s = x%d;\n", i, vv, nd.arg); break;
       case LSQAMD_OP_P:
       case OP_WSUM: o.f("%sconst double %s = %s;\n", i, vv, leaf_value(nd).c_str()); break;
@@ -536,6 +558,14 @@ void gen_group(const Plan &pl, Src &o, const Group &g, int gid, int mode, const 
       if (g.idx[(size_t)s][0] == nd.arg) return "q" + std::to_string(s);
     return std::string("0.0");
   };
+  tg.const_value = [&](int node) {
+    for (size_t c = 0; c < g.cnodes.size(); ++c)
+      if (g.cnodes[c] == node) {
+        if (g.cvals[c].size() == 1) return dlit(g.cvals[c][0]);
+        return "CT" + std::to_string(gid) + "_" + std::to_string(c) + "[k]";
+      }
+    return dlit(pl.consts[(size_t)pl.nodes[(size_t)node].arg]);
+  };
   if (der)
     for (int s = 0; s < g.n_slots; ++s) o.f("        double e%d = 0.0;\n", s);
   tg.leaf_adjoint = [&](const Node &nd, const std::string &gg) {
@@ -577,6 +607,12 @@ std::string generate(const Plan &pl) {
         if (!g.shared[(size_t)s] && g.stride[(size_t)s] == INT32_MIN) {
           o.f("static __device__ const int T%d_%d[%d] = {", gid, s, g.n_terms);
           for (int k = 0; k < g.n_terms; ++k) o.f("%d,", g.idx[(size_t)s][(size_t)k]);
+          o.s += "};\n";
+        }
+      for (size_t c = 0; c < g.cvals.size(); ++c)
+        if (g.cvals[c].size() > 1) {     // a constant that differs from term to term
+          o.f("static __device__ const double CT%d_%zu[%d] = {", gid, c, g.n_terms);
+          for (int k = 0; k < g.n_terms; ++k) o.f("%s,", dlit(g.cvals[c][(size_t)k]).c_str());
           o.s += "};\n";
         }
       ++gid;

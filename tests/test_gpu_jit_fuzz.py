@@ -21,7 +21,8 @@ def amd():
 
 
 TERMS = ['{a}*cos({b}*x)', '{a}*exp(-{b}*x)', '{a}/(1 + {b}*x**2)', '{a}*sin({b}*x + {s})', '{a}*x*exp(-({b}*x)**2)',
-         'sqrt(1 + ({a}*x)**2)*{b}', 'log(1 + {a}**2 + {b}**2*x**2)', '{a}*arctan({b}*x)/{s}']
+         'sqrt(1 + ({a}*x)**2)*{b}', 'log(1 + {a}**2 + {b}**2*x**2)', '{a}*arctan({b}*x)/{s}',
+         '{a}*cos({k}*x) + 0*{b}', '{a}*exp(-{b}*(x - {k})**2)']        # {k}: a literal that differs from term to term
 OUTER = ['{S}', '{c} + {S}', 'exp(-{c}*x)*({S})', '({S})/(1 + {c}**2)', '({S})*({T}) + {c}', '{c}*log(1 + ({S})**2)',
          '({S}) - ({T})', '-({S}) + {c}*x', 'sqrt(1 + ({S})**2) + {T}']
 
@@ -45,7 +46,7 @@ def random_formula(rng):
         else:
             names += [v for pair in zip(a, b) for v in pair]
         sign = ['+', '-'][int(rng.integers(0, 2))] if rng.random() < 0.3 else '+'
-        sums.append((' %s ' % sign).join(tmpl.format(a=a[k], b=b[k], s=shared) for k in range(K)))
+        sums.append((' %s ' % sign).join('(' + tmpl.format(a=a[k], b=b[k], s=shared, k=repr(0.25 * (k + 1))) + ')' for k in range(K)))
     uses_shared = any(shared in s for s in sums)
     outer = OUTER[int(rng.integers(0, len(OUTER)))]
     if '{T}' in outer and nsum == 1:
@@ -70,7 +71,7 @@ def oracle_values(text, names, x, p):
     return out.val, out.der
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(32))
 def test_compiled_formula_matches_dual_numbers(amd, seed):
     rng = np.random.default_rng(1000 + seed)
     text, names = random_formula(rng)
@@ -102,4 +103,4 @@ def test_compiled_formula_matches_dual_numbers(amd, seed):
 
 
 def test_most_fuzz_formulas_ran_compiled():
-    assert getattr(test_compiled_formula_matches_dual_numbers, 'compiled', 0) >= 18
+    assert getattr(test_compiled_formula_matches_dual_numbers, 'compiled', 0) >= 24

@@ -108,3 +108,16 @@ def test_unread_parameter_gets_a_zero_column(lib):
     rc, variant, src = codegen(lib, amd.expr('py + 0*x', ['py', 'pn']))
     assert rc == 0 and 'static __device__ const int ZC[1] = {1,};' in src
     assert 'dst[ZC[k]] = 0.0;' in body(src, 'lsqamd_jit_jac')
+
+
+def test_constants_that_differ_from_term_to_term_become_a_table(lib):
+    """A Fourier series with literal harmonics: one group, the k's in a table (their values are not part of the
+    structure); a constant shared by all terms stays a literal."""
+    import lsqfit_amd as amd
+    names = ['a%d' % k for k in range(1, 9)]
+    text = ' + '.join('a%d*cos(%d*x*0.5)' % (k, k) for k in range(1, 9))
+    rc, variant, src = codegen(lib, amd.expr(text, names))
+    assert rc == 0 and variant == 1
+    assert 'static __device__ const double CT0_0[8] = {0x1p+0,0x1p+1,0x1.8p+1,0x1p+2,0x1.4p+2,0x1.8p+2,0x1.cp+2,0x1p+3,};' in src
+    jac = body(src, 'lsqamd_jit_jac')
+    assert 'CT0_0[k]' in jac and '0x1p-1' in jac and 'CT0_1' not in src
