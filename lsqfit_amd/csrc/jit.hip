@@ -10,7 +10,7 @@
 //
 // Shape of the generated code.  The tape is parsed into its expression tree; every additive chain
 // (+, -, unary minus) is flattened and its leaves are grouped by STRUCTURE (same operations,
-// constants and x's; only the parameter indices differ).  A group of >= 4 look-alike terms -- the
+// x's; only the parameter indices and literal constants differ).  A group of >= 16 look-alike terms -- the
 // sum over states / exponentials / harmonics of a real fit function -- becomes ONE loop in which
 // the 64 lanes of a wave stride over the terms of ONE data row: parameter loads and Jacobian
 // stores are then contiguous 512-byte segments (families laid out p = [a_0.., w_0..]), exactly the
@@ -243,7 +243,10 @@ int subtree_nodes(const std::vector<Node> &nodes, int n) {
   return c;
 }
 
-constexpr int MIN_GROUP = 4, MAX_TERM_NODES = 160, MAX_TERM_SLOTS = 16, MAX_OUTER_NODES = 768, MAX_OUT_PARAMS = 64;
+// (a group keeps n_terms of a wave's 64 lanes busy: below a quarter of them the terms are better off unrolled in the
+// one-lane-per-row form -- a sum of 2-6 exponentials, lsqfit's canonical fit, then also gets the register-resident
+// normal equations)
+constexpr int MIN_GROUP = 16, MAX_TERM_NODES = 160, MAX_TERM_SLOTS = 16, MAX_OUTER_NODES = 768, MAX_OUT_PARAMS = 64;
 
 struct Builder {
   Plan &pl;

@@ -28,12 +28,12 @@ OUTER = ['{S}', '{c} + {S}', 'exp(-{c}*x)*({S})', '({S})/(1 + {c}**2)', '({S})*(
 
 
 def random_formula(rng):
-    """-> (text, names): 1-2 sums of 4..70 look-alike terms + an outer expression + possibly unread parameters"""
+    """-> (text, names): 1-2 sums of 3..70 look-alike terms (16 and more: one loop over a wave's lanes; fewer: unrolled per lane) + an outer expression + possibly unread parameters"""
     names, sums = [], []
     nsum = int(rng.integers(1, 3))
     shared = 'sh%d' % int(rng.integers(0, 100))
     for si in range(nsum):
-        K = int(rng.choice([4, 5, 8, 17, 64, 70]))
+        K = int(rng.choice([3, 5, 16, 17, 64, 70]))
         tmpl = TERMS[int(rng.integers(0, len(TERMS)))]
         a = ['a%d_%d' % (si, k) for k in range(K)]
         b = ['b%d_%d' % (si, k) for k in range(K)]

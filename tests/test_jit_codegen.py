@@ -63,36 +63,40 @@ def test_wide_sum_becomes_one_loop_with_contiguous_columns(lib):
 
 def test_sum_inside_a_product_takes_its_adjoint_from_the_outer_sweep(lib):
     import lsqfit_amd as amd
-    K = 8
+    K = 20
     names = ['a%d' % k for k in range(K)] + ['w%d' % k for k in range(K)] + ['g', 'c', 'phi']
     text = 'c + exp(-g*x)*(' + '+'.join('a%d*cos(w%d*x+phi)' % (k, k) for k in range(K)) + ')'
     rc, variant, src = codegen(lib, amd.expr(text, names))
     assert rc == 0 and variant == 1
     jac = body(src, 'lsqamd_jit_jac')
-    assert jac.count('for (int k = lane; k < 8; k += 64)') == 2           # values, then derivatives scaled by the adjoint
+    assert jac.count('for (int k = lane; k < 20; k += 64)') == 2          # values, then derivatives scaled by the adjoint
     assert 'const double tadj = aS0;' in jac
     assert 'sh2 += e2;' in jac and 'oacc2 += wsum(sh2);' in jac           # phi: shared by all terms, summed over the wave
-    assert 'mycol = 16' in jac and 'mycol = 17' in jac and 'mycol = 18' in jac
+    assert 'mycol = 40' in jac and 'mycol = 41' in jac and 'mycol = 42' in jac
 
 
 def test_scattered_parameter_indices_use_a_table(lib):
     import lsqfit_amd as amd
-    names = ['p%d' % i for i in range(16)]
-    order = [3, 0, 7, 5, 1, 6, 2, 4]
-    text = '+'.join('p%d*exp(-p%d*x)' % (order[k], 8 + k) for k in range(8))
+    names = ['p%d' % i for i in range(32)]
+    order = [3, 0, 7, 5, 1, 6, 2, 4, 11, 8, 15, 13, 9, 14, 10, 12]
+    text = '+'.join('p%d*exp(-p%d*x)' % (order[k], 16 + k) for k in range(16))
     rc, variant, src = codegen(lib, amd.expr(text, names))
     assert rc == 0 and variant == 1
-    assert 'static __device__ const int T0_0[8] = {3,0,7,5,1,6,2,4,};' in src
+    assert 'static __device__ const int T0_0[16] = {3,0,7,5,1,6,2,4,11,8,15,13,9,14,10,12,};' in src
     assert 'dst[T0_0[k]] = w * e0;' in body(src, 'lsqamd_jit_jac')
 
 
 def test_parameter_shared_between_two_sums_falls_back_to_the_outer_expression(lib):
     """A parameter that is private in one group but read elsewhere too cannot be a plain store."""
     import lsqfit_amd as amd
-    names = ['a%d' % k for k in range(4)] + ['w%d' % k for k in range(4)]
-    text = '+'.join('a%d*cos(w%d*x)' % (k, k) for k in range(4)) + ' + a0*x'
+    names = ['a%d' % k for k in range(16)] + ['w%d' % k for k in range(16)]
+    text = '+'.join('a%d*cos(w%d*x)' % (k, k) for k in range(16)) + ' + a0*x'
     rc, variant, src = codegen(lib, amd.expr(text, names))
     assert rc == 0 and variant == 0         # the group is not formed: everything is outer, one lane per row
+    # ... and a short sum (lsqfit's canonical 2-6 exponentials) is unrolled in the one-lane-per-row form on purpose,
+    # with the register-resident normal equations
+    rc, variant, src = codegen(lib, amd.expr('+'.join('a%d*exp(-w%d*x)' % (k, k) for k in range(4)), names[:4] + names[16:20]))
+    assert rc == 0 and variant == 0 and 'lsqamd_jit_nrm' in src
 
 
 def test_formula_outside_the_generator_is_declined_not_miscompiled(lib):
@@ -114,10 +118,10 @@ def test_constants_that_differ_from_term_to_term_become_a_table(lib):
     """A Fourier series with literal harmonics: one group, the k's in a table (their values are not part of the
     structure); a constant shared by all terms stays a literal."""
     import lsqfit_amd as amd
-    names = ['a%d' % k for k in range(1, 9)]
-    text = ' + '.join('a%d*cos(%d*x*0.5)' % (k, k) for k in range(1, 9))
+    names = ['a%d' % k for k in range(1, 17)]
+    text = ' + '.join('a%d*cos(%d*x*0.5)' % (k, k) for k in range(1, 17))
     rc, variant, src = codegen(lib, amd.expr(text, names))
     assert rc == 0 and variant == 1
-    assert 'static __device__ const double CT0_0[8] = {0x1p+0,0x1p+1,0x1.8p+1,0x1p+2,0x1.4p+2,0x1.8p+2,0x1.cp+2,0x1p+3,};' in src
+    assert 'static __device__ const double CT0_0[16] = {0x1p+0,0x1p+1,0x1.8p+1,0x1p+2,0x1.4p+2,0x1.8p+2,0x1.cp+2,0x1p+3,' in src
     jac = body(src, 'lsqamd_jit_jac')
     assert 'CT0_0[k]' in jac and '0x1p-1' in jac and 'CT0_1' not in src
