@@ -509,6 +509,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     rc = whiten_jacobian(f, &fused_chunks);
     if (rc) return rc;
   }
+  bool syrk_colsum = false;
   {
     Scope sc(f, LSQAMD_T_SYRK);
     GemmTN g;
@@ -521,6 +522,13 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     if (P > 64) {   // (one tile: nothing to order, and the 64 x 64 kernel takes no work list)
       g.work_map = f->syrk_map;
       g.n_work = f->syrk_nwork;
+    }
+    if (fused_chunks == 0 && f->N > 0) {   // J^T f and chi2 out of the diagonal tiles of this launch, when it is that kernel
+      g.colsum_out = f->partial;            // [splits][P + 1] (splits <= 256 <= npartial)
+      g.colsum_ld = P + 1;
+      g.colsum_rcol = P;
+      if (gemm_tn_fuses_colsum(g)) syrk_colsum = true;
+      else g.colsum_out = nullptr;
     }
     if (f->N > 0) {
       HIPCHK(f, launch_gemm_tn(f->st, g));
@@ -536,7 +544,9 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     // the slab sum and the prior precision in ONE pass over the packed tiles
     HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
                                    with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
-    if (fused_chunks == 0)
+    if (syrk_colsum)
+      HIPCHK(f, launch_colsum_reduce(f->st, f->partial, f->splits, P + 1, gvec));
+    else if (fused_chunks == 0)
       HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
     f->prior_deferred = with_prior && r_here && !mirror && small_fuse(f);
     if (with_prior && !f->prior_deferred)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)

@@ -665,21 +665,32 @@ int normal_all(lsqamdb_fits *f, const int32_t *mask) {
   g.split_stride = P * f->ldm;
   g.work_map = f->syrk_map; g.n_work = f->syrk_nwork;
   g.batch = (int32_t)B; g.batch_active = mask;
+  // J^T f and chi2 from the diagonal tiles of the same launch when it is the kernel that can (P a multiple of 128):
+  // partial[(b * splits + split)][P + 1]   (splits <= 16 <= nparts)
+  g.colsum_out = f->partial; g.colsum_ld = P + 1; g.colsum_rcol = P;
+  const bool syrk_colsum = gemm_tn_fuses_colsum(g);
+  if (!syrk_colsum) g.colsum_out = nullptr;
   BHIP(f, launch_gemm_tn(f->st, g));
   const int64_t red_stride = f->npk + P + 1;
   hipLaunchKernelGGL(b_finalize_pack_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
                      dim3(256), 0, f->st, f->slabs, f->splits, P * f->ldm, (int64_t)f->splits * P * f->ldm, P,
                      f->ldm, f->T, f->red, red_stride, mask);
-  int64_t nchunks = f->nparts;
-  if (nchunks > N) nchunks = N;
-  const int64_t rpc = (N + nchunks - 1) / nchunks;
-  nchunks = (N + rpc - 1) / rpc;
-  hipLaunchKernelGGL(b_colsum_stage1, dim3((unsigned)((P + 1 + 511) / 512), (unsigned)nchunks, (unsigned)B),
-                     dim3(256), 0, f->st, f->J, N, f->ld, P + 1, P, rpc, N * f->ld, f->partial,
-                     (int64_t)f->nparts * (P + 1), mask);
-  hipLaunchKernelGGL(b_colsum_stage2, dim3((unsigned)((P + 1 + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
-                     f->partial, nchunks, P + 1, (int64_t)f->nparts * (P + 1), f->red + f->npk, red_stride,
-                     mask);
+  if (syrk_colsum) {
+    hipLaunchKernelGGL(b_colsum_stage2, dim3((unsigned)((P + 1 + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
+                       f->partial, (int64_t)f->splits, P + 1, (int64_t)f->splits * (P + 1), f->red + f->npk, red_stride,
+                       mask);
+  } else {
+    int64_t nchunks = f->nparts;
+    if (nchunks > N) nchunks = N;
+    const int64_t rpc = (N + nchunks - 1) / nchunks;
+    nchunks = (N + rpc - 1) / rpc;
+    hipLaunchKernelGGL(b_colsum_stage1, dim3((unsigned)((P + 1 + 511) / 512), (unsigned)nchunks, (unsigned)B),
+                       dim3(256), 0, f->st, f->J, N, f->ld, P + 1, P, rpc, N * f->ld, f->partial,
+                       (int64_t)f->nparts * (P + 1), mask);
+    hipLaunchKernelGGL(b_colsum_stage2, dim3((unsigned)((P + 1 + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
+                       f->partial, nchunks, P + 1, (int64_t)f->nparts * (P + 1), f->red + f->npk, red_stride,
+                       mask);
+  }
   if (f->cfg.has_prior && f->cfg.prior_dense) {
     hipLaunchKernelGGL(b_prior_matrix_dense_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
                        dim3(256), 0, f->st, f->red, red_stride, P, f->T, f->pprec, mask);

@@ -34,6 +34,9 @@ struct GemmTN {
   // gemm_tn_fuses_colsum()): colsum_out[(b * tiles_m + tm) * colsum_ld + n] = sum over the 128
   // rows of tile row tm of C[row][n] * C_b[row][colsum_rcol]   (the weights are a column of the
   // output matrix itself, written by an earlier launch: J^T f from the whitened Jacobian)
+  // With a work list (the split-K J^T J launch, X == Y): colsum_out[(b * splits + split) * colsum_ld + m] =
+  // sum over the split's rows k of X[k][m] * X[k][colsum_rcol] for m < M, and at m = colsum_rcol the sum of
+  // X[k][colsum_rcol]^2 -- formed by the diagonal tiles' workgroups from the rows they stage anyway.
   double *colsum_out = nullptr;
   int64_t colsum_ld = 0, colsum_rcol = 0;
 };

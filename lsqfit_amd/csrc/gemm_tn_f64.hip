@@ -248,7 +248,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
 // (8 sub-tiles), i.e. at most 10 MFMAs per k-step and wave instead of 16, the Y tile is not staged
 // (it is the X tile), and the epilogue writes every value to (row, col) and (col, row): the tile in
 // the slab is bit-identical to the one the full schedule writes (same products, same k order).
-template <bool XTRI, bool WORKMAP>
+// CS (with WORKMAP, diagonal tiles on the triangular schedule): the workgroup of diagonal tile (tm, tm, split)
+// also forms sum_k X[k][m] * X[k][rcol] over its K-range for its 128 columns m -- J^T f out of the tile rows
+// that are in LDS anyway, so the gradient costs no second pass over J.  The residual column's 16 values of a
+// stage land in the (unused) Y half of the stage buffer; column rcol itself gets sum_k X[k][rcol]^2 from tile 0.
+// colsum_out[(b * splits + split) * colsum_ld + m]: per-split partials, summed in split order by the caller.
+template <bool XTRI, bool WORKMAP, bool CS = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
@@ -307,6 +312,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const double *xp = g.X + b * g.sx + (kb + wave) * g.ldx + m0 + 2 * lane;
   const double *yp = g.Y + b * g.sy + (kb + wave) * g.ldy + n0 + 2 * lane;
   const int64_t xstep = 4 * g.ldx, ystep = 4 * g.ldy;
+  // CS: lanes 0..31 of wave 1 fetch the 16 residuals of a stage as 32 dwords (lane -> row lane / 2, half lane & 1)
+  const char *fp = reinterpret_cast<const char *>(g.X + b * g.sx + (kb + (lane >> 1)) * g.ldx + g.colsum_rcol) + 4 * (lane & 1);
+  const int64_t fstep = (int64_t)BK * g.ldx * (int64_t)sizeof(double);
+  double cs = 0.0, cs2 = 0.0;
 
   auto stage = [&](int buf) {
     double *Xs = smem + buf * STAGE + wave * LDT;
@@ -315,6 +324,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
+      if (CS && wave == 1) {
+        if (lane < 32)
+          __builtin_amdgcn_global_load_lds((glb_void *)fp, (lds_void *)(smem + buf * STAGE + BK * LDT), 4, 0, 0);
+        fp += fstep;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -359,6 +373,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
         }
       }
+      if (CS && ROLE != 0) {   // thread -> column tid & 127, rows 8 (tid >> 7) .. + 7 of the stage
+        const double *Fs = Xs + BK * LDT + 8 * (tid >> 7);
+        const double *Xc = Xs + 8 * (tid >> 7) * LDT + (tid & 127);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const double fv = Fs[r];
+          cs = fma(Xc[r * LDT], fv, cs);
+          cs2 = fma(fv, fv, cs2);
+        }
+      }
       __syncthreads();
       cur ^= 1;
     }
@@ -384,6 +408,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
           if (!(tri && i == j)) C[col * g.ldc + row] = v;
         }
       }
+    }
+    if (CS) {   // (the k loop ended on a barrier: the stage buffers are free)
+      smem[tid] = cs;
+      if ((tid & 127) == 0) smem[256 + (tid >> 7)] = cs2;
+      __syncthreads();
+      double *out = g.colsum_out + (b * g.splits + split) * g.colsum_ld;
+      if (tid < BM) out[m0 + tid] = smem[tid] + smem[tid + 128];
+      if (tm == 0 && tid == 0) out[g.colsum_rcol] = smem[256] + smem[257];
     }
     continue;
   }
@@ -794,7 +826,20 @@ static bool interior_eligible(const GemmTN &a) {
   return vx && vy && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) && !a.force_generic;
 }
 
+static bool syrk_diag_off() {
+  static const bool v = [] { const char *e = getenv("LSQAMD_SYRK_DIAG"); return e && atoi(e) == 0; }();  // developer knob
+  return v;
+}
+
 bool gemm_tn_fuses_colsum(const GemmTN &a) {
+  if (a.work_map) {
+    // the split-K J^T J launch: diagonal tiles on the triangular schedule carry the column sums (<false, true, true>)
+    const char *e = getenv("LSQAMD_SYRK_COLSUM");   // developer knob, read per call (A/B tests): 0 = separate J^T f pass
+    const bool off = e && atoi(e) == 0;
+    const int splits = a.splits < 1 ? 1 : a.splits;
+    return interior_eligible(a) && !a.x_upper_tri && a.upper_only && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy &&
+           a.M == a.N && (splits > 1 || a.beta == 0.0) && !syrk_diag_off() && !off && a.C != a.X;
+  }
   // the conditions under which launch_gemm_tn reaches gemm_tn_f64_interior_kernel<true>
   const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
   const int64_t nblk128 = tiles_m * tiles_n * (a.splits < 1 ? 1 : a.splits) * (a.batch < 1 ? 1 : a.batch);
@@ -820,6 +865,9 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
     if (e != hipSuccess) return e;
     g_attr_set = true;
@@ -848,7 +896,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
   g.work_map = a.work_map;
   g.n_work = a.n_work;
-  static const bool diag_off = [] { const char *e = getenv("LSQAMD_SYRK_DIAG"); return e && atoi(e) == 0; }();  // developer knob
+  const bool diag_off = syrk_diag_off();
   g.syrk_diag = a.work_map && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy && a.M == a.N &&
                 (g.splits > 1 || a.beta == 0.0) && !diag_off;
   g.batch_active = a.batch_active;
@@ -917,6 +965,10 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
       grid.x = (unsigned)(((tiles_m + 1) / 2) * tiles_n);
     }
     hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<true, false>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
+  }
+  else if (interior && a.work_map && a.colsum_out) {
+    if (!g.syrk_diag || !a.upper_only) return hipErrorInvalidValue;   // (callers ask gemm_tn_fuses_colsum first)
+    hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   }
   else if (interior && a.work_map)
     hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
