@@ -289,7 +289,7 @@ int residual_vector_launch(lsqamd_fit *f, const double *p) {
       int64_t nch = (f->N * f->ld) / B;
       if (nch > 256) nch = 256;
       HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->Jraw, nch,
-                                  f->r + f->h_row0[b], f->r_raw + f->h_row0[b]));
+                                  f->r + f->h_row0[b], f->r_raw + f->h_row0[b], 1, f->h_tri[b] ? 1 : 0));
     }
   }
   return 0;
@@ -343,7 +343,7 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
 // Whitening of the block rows of the Jacobian (and of its residual column).  *fused_chunks > 0 on
 // return: the bulk GEMM also left per-tile-row partial sums of J^T f in f->slabs
 // (fused_chunks x P, to be reduced before the SYRK reuses the slabs).
-int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks) {
+int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks, bool r_here) {
   *fused_chunks = 0;
   const int nb = f->cfg.n_blocks;
   if (nb <= 0) return 0;
@@ -371,8 +371,9 @@ int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks) {
         if (nch >= 1) {
           for (int b = 0; b < nb; ++b) {
             const int64_t r0 = f->h_row0[b];
-            HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->slabs, nch, f->r + r0,
-                                        f->Jraw + r0 * f->ld + f->P, f->ld));
+            if (!r_here)   // (else f->r already holds the whitened residual of this point: the trial evaluation left it)
+              HIPCHK(f, launch_colsum_dot(f->st, f->wt + f->h_woff[b], B, B, B, 0, f->slabs, nch, f->r + r0,
+                                          f->Jraw + r0 * f->ld + f->P, f->ld, f->uniform_tri ? 1 : 0));
             HIPCHK(f, launch_copy_strided(f->st, f->r + r0, 1, f->J + r0 * f->ld + f->P, f->ld, B, 1));
           }
           col_done = true;
@@ -392,7 +393,23 @@ int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks) {
         if (gemm_tn_fuses_colsum(g)) *fused_chunks = chunks;
         else g.colsum_out = nullptr;
       }
+      // one (or a few) large blocks: too few workgroups for the chip -- both halves of every tile row's K-range at once, the
+      // upper halves into the slabs (free until the J^T J launch), added below; J^T f then comes from that launch's
+      // diagonal tiles instead of this one's epilogue
+      bool halves = false;
+      if ((int64_t)nb * B * f->ld <= slab_doubles && f->h_row0[0] == 0 && (int64_t)nb * B == f->N) {
+        GemmTN h = g;
+        h.colsum_out = nullptr;
+        h.tri_halves = 1;
+        h.split_stride = f->slabs - g.C;
+        if (gemm_tn_wants_tri_halves(h)) {
+          g = h;
+          *fused_chunks = 0;
+          halves = true;
+        }
+      }
       HIPCHK(f, launch_gemm_tn(f->st, g));
+      if (halves) HIPCHK(f, launch_add_rows(f->st, f->J, f->slabs, f->N, f->P, f->ld));
       if (*fused_chunks > 0) {
         // J^T f = sum of the per-tile-row pieces; |f|^2 from the residual column
         double *gvec = f->redbuf + f->npk;
@@ -506,7 +523,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
         HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, f->ld, p, f->ymean, f->wdiag,
                                     f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->J, f->Jraw, 1));
     }
-    rc = whiten_jacobian(f, &fused_chunks);
+    rc = whiten_jacobian(f, &fused_chunks, r_here);
     if (rc) return rc;
   }
   bool syrk_colsum = false;

@@ -30,6 +30,9 @@ struct GemmTN {
   int32_t n_work = 0;
   int32_t force_generic = 0;       // A/B switch: never take the direct-to-LDS interior kernel
   const int32_t *batch_active = nullptr;  // device flags[batch]: 0 = skip that batch entry
+  // triangular X, few long tile rows: the caller offers a scratch slab at C + split_stride (same layout as C) and adds
+  // it to C afterwards when gemm_tn_wants_tri_halves() says the launch will use it (see gemm_tn_f64.hip)
+  int32_t tri_halves = 0;
   // fused column sums (triangular-X interior path only; ignored elsewhere -- check
   // gemm_tn_fuses_colsum()): colsum_out[(b * tiles_m + tm) * colsum_ld + n] = sum over the 128
   // rows of tile row tm of C[row][n] * C_b[row][colsum_rcol]   (the weights are a column of the
@@ -42,6 +45,7 @@ struct GemmTN {
 };
 // true when launch_gemm_tn would take the kernel that honours colsum_out for this call
 bool gemm_tn_fuses_colsum(const GemmTN &g);
+bool gemm_tn_wants_tri_halves(const GemmTN &g);
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &g);
 // Jacobian rows of a sum model synthesised INSIDE the whitening product (gemm_tn_f64.hip):
 //   J_b = W_b x [d f / d p] for nb uniform triangular blocks of B rows, raw rows never written.
@@ -168,7 +172,7 @@ hipError_t launch_param_rows(hipStream_t st, const int32_t *row_param, int64_t N
 hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
                              double *out, const double *rvec = nullptr,   // rvec: weights instead of J[:, rcol]
-                             int64_t rvec_stride = 1);
+                             int64_t rvec_stride = 1, int tri = 0);      // tri: J[i][j] == 0 for i > j, those rows are skipped
 // out[j] = sum over nchunks rows of partial[chunk][j] (partial row stride = ncols)
 hipError_t launch_colsum_reduce(hipStream_t st, const double *partial, int64_t nchunks, int64_t ncols,
                                 double *out);
@@ -204,6 +208,8 @@ hipError_t launch_packed_diag(hipStream_t st, const double *apk, int64_t P, doub
 hipError_t launch_unpack_sym(hipStream_t st, const double *apk, int64_t P, double *out, int64_t ld);
 hipError_t launch_symmetrize_from_upper(hipStream_t st, double *A, int64_t P, int64_t ld);
 hipError_t launch_set_identity(hipStream_t st, double *A, int64_t P, int64_t ld);
+// dst[i][j] += src[i][j]  (rows x cols, both with leading dimension ld; cols even, 16-byte aligned rows)
+hipError_t launch_add_rows(hipStream_t st, double *dst, const double *src, int64_t rows, int64_t cols, int64_t ld);
 hipError_t launch_copy_strided(hipStream_t st, const double *src, int64_t lds_, double *dst,
                                int64_t ldd, int64_t rows, int64_t cols);
 

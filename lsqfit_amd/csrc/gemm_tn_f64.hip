@@ -51,6 +51,7 @@ struct GemmDev {
   int64_t sx, sy, sc;
   int32_t tiles_n, upper_only, x_upper_tri, xy_lower_tri, splits;
   int32_t tiles_m, pair_rows;
+  int32_t tri_halves;    // XTRI interior launch with two K-halves per tile row (grid.y = 2), see GemmTN::tri_halves
   int32_t syrk_diag;     // WORKMAP launch with X == Y: diagonal tiles take the triangular schedule (see kernel)
   int32_t vec_x, vec_y;  // operand rows are 16-byte aligned -> dwordx4 loads
   int64_t kchunk, split_stride;
@@ -293,6 +294,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
     int64_t lo = m0 > n0 ? m0 : n0;
     lo -= lo % BK;
     if (kb < lo) kb = lo;
+  }
+  if (XTRI && g.tri_halves) {   // the tile row's own K-range [0, m0 + 128) cut in two: split 0 the lower half, split 1 the upper
+    const int64_t lim = m0 + BM, h = (lim >> 1) & ~(int64_t)(BK - 1);
+    kb = split ? h : 0;
+    ke = split ? lim : h;
   }
 
   v4d acc[4][4];
@@ -826,6 +832,18 @@ static bool interior_eligible(const GemmTN &a) {
   return vx && vy && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) && !a.force_generic;
 }
 
+// few long tile rows (one large dense block: config 3's 8192 x 8192 W against 1024 columns is 32 row pairs x 8 tile
+// columns = 256 workgroups, one per CU, four waves each with nothing to cover their barrier and LDS latencies):
+// every tile row's K-range in two halves, 2x the workgroups, the second half into a scratch slab the caller adds.
+bool gemm_tn_wants_tri_halves(const GemmTN &a) {
+  const char *e = getenv("LSQAMD_TRI_HALVES");   // developer knob, read per call (A/B tests): 0 = one workgroup per tile-row pair
+  const bool off = e && atoi(e) == 0;
+  const int64_t tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+  const int64_t nwg = ((tiles_m + 1) / 2) * tiles_n * (a.batch < 1 ? 1 : a.batch);
+  return !off && a.tri_halves && interior_eligible(a) && a.x_upper_tri && a.splits <= 1 && !a.work_map && tiles_m >= 8 &&
+         nwg < 400 && a.split_stride != 0 && a.C != a.X && a.C != a.Y && !a.colsum_out;
+}
+
 static bool syrk_diag_off() {
   static const bool v = [] { const char *e = getenv("LSQAMD_SYRK_DIAG"); return e && atoi(e) == 0; }();  // developer knob
   return v;
@@ -885,6 +903,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.tiles_n = (int32_t)tiles_n;
   g.tiles_m = (int32_t)tiles_m;
   g.pair_rows = 0;
+  g.tri_halves = 0;
   g.upper_only = a.upper_only;
   g.x_upper_tri = a.x_upper_tri;
   g.xy_lower_tri = a.xy_lower_tri;
@@ -963,6 +982,12 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
     if (tiles_m >= 4 && g.splits == 1 && !a.work_map) {  // balance the growing k-ranges (see kernel)
       g.pair_rows = 1;
       grid.x = (unsigned)(((tiles_m + 1) / 2) * tiles_n);
+      if (gemm_tn_wants_tri_halves(a)) {
+        g.tri_halves = 1;
+        g.splits = 2;                       // (epilogue: beta ignored, split s -> C + s * split_stride)
+        g.split_stride = a.split_stride;
+        grid.y = 2;
+      }
     }
     hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<true, false>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   }
@@ -1189,9 +1214,13 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
 }
 
 bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P) {
-  static const bool off = [] { const char *e = getenv("LSQAMD_FUSED_JACOBIAN"); return e && e[0] == '0'; }();
+  const char *e = getenv("LSQAMD_FUSED_JACOBIAN");   // developer knob, read per call: 0 = never, 2 = also for large blocks
+  const bool off = e && e[0] == '0', always = e && e[0] == '2';
+  // Large blocks: every tile row of the block synthesises the raw rows below it again -- B / 256 times each on average.
+  // From eight tile rows on, writing the raw Jacobian once (it stays in the last-level cache) and reading it back is the
+  // faster route (config 3, one 8192-row block: 1.52 ms synthesised, 1.45 ms read, 1.1 ms read with split tile rows).
   return !off && (model == LSQAMD_MODEL_COSMIX || model == LSQAMD_MODEL_MULTIEXP) && B >= BM && B % BM == 0 &&
-         P % 128 == 0 && P >= 128;
+         (B < 8 * BM || always) && P % 128 == 0 && P >= 128;
 }
 
 constexpr size_t SYNTH_LDS_BYTES = GEMM_LDS_BYTES + 3 * 32 * sizeof(double);

@@ -26,15 +26,17 @@ __host__ __device__ inline int64_t packed_tile_index(int64_t tm, int64_t tn, int
 
 // ---- J^T f and |f|^2 in one pass over J ------------------------------------------------
 // stage 1: partial[rc][j] = sum_{i in row chunk rc} J[i][j] * J[i][rcol]
+// tri: J[i][j] == 0 for i > j (a whitening factor W_b^T): rows below a column pair are not read
 __global__ __launch_bounds__(256) void colsum_dot_stage1(const double *J, int64_t nrows, int64_t ld,
                                                          int64_t ncols, const double *rv,
                                                          int64_t rs, int64_t rows_per_chunk,
-                                                         double *partial) {
+                                                         double *partial, int tri) {
   const int64_t j = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
   int64_t r1 = r0 + rows_per_chunk;
   if (r1 > nrows) r1 = nrows;
   if (j >= ncols) return;
+  if (tri && r1 > j + 2) r1 = j + 2;     // (an empty range leaves zeros)
   const bool two = j + 1 < ncols;
   double a0 = 0.0, a1 = 0.0;
   if ((ld & 1) == 0 && two) {
@@ -110,14 +112,14 @@ hipError_t launch_colsum_reduce(hipStream_t st, const double *partial, int64_t n
 
 hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int64_t ld,
                              int64_t ncols, int64_t rcol, double *partial, int64_t npartial,
-                             double *out, const double *rvec, int64_t rvec_stride) {
+                             double *out, const double *rvec, int64_t rvec_stride, int tri) {
   const double *rv = rvec ? rvec : J + rcol;
   const int64_t rs = rvec ? rvec_stride : ld;
   int64_t nchunks = npartial;
   if (nchunks > nrows) nchunks = nrows > 0 ? nrows : 1;
   const int64_t rpc = nrows > 0 ? (nrows + nchunks - 1) / nchunks : 1;
   nchunks = nrows > 0 ? (nrows + rpc - 1) / rpc : 0;
-  if (nchunks > 0 && ncols <= 256 && nrows >= 4096) {
+  if (nchunks > 0 && ncols <= 256 && nrows >= 4096 && !tri) {
     const int64_t cp = (ncols + 1) / 2;
     const dim3 grid((unsigned)nchunks);
     if (cp <= 16) hipLaunchKernelGGL(colsum_dot_narrow<16>, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc, partial);
@@ -127,7 +129,7 @@ hipError_t launch_colsum_dot(hipStream_t st, const double *J, int64_t nrows, int
   } else if (nchunks > 0) {
     dim3 grid((unsigned)((ncols + 511) / 512), (unsigned)nchunks);
     hipLaunchKernelGGL(colsum_dot_stage1, grid, dim3(256), 0, st, J, nrows, ld, ncols, rv, rs, rpc,
-                       partial);
+                       partial, tri);
   }
   return launch_colsum_reduce(st, partial, nchunks, ncols, out);
 }
@@ -510,6 +512,25 @@ __global__ __launch_bounds__(256) void copy_strided_kernel(const double *src, in
   const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (j >= cols) return;
   for (int64_t i = blockIdx.y; i < rows; i += gridDim.y) dst[i * ldd + j] = src[i * lds_ + j];
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(double *dst, const double *src, int64_t rows, int64_t cols2, int64_t ld) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= cols2) return;
+  for (int64_t i = blockIdx.y; i < rows; i += gridDim.y) {
+    v2d *d = reinterpret_cast<v2d *>(dst + i * ld) + j;
+    const v2d a = *d, b = reinterpret_cast<const v2d *>(src + i * ld)[j];
+    *d = a + b;
+  }
+}
+
+hipError_t launch_add_rows(hipStream_t st, double *dst, const double *src, int64_t rows, int64_t cols, int64_t ld) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  if ((cols & 1) || (ld & 1)) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((cols / 2 + 255) / 256), (unsigned)(rows < 16384 ? rows : 16384));
+  hipLaunchKernelGGL(add_rows_kernel, grid, dim3(256), 0, st, dst, src, rows, cols / 2, ld);
+  return hipGetLastError();
 }
 
 // dst[i] = src[i * ld] (a column) and zbuf[0 .. zwords) = 0 in one launch: the right-hand side of the back
