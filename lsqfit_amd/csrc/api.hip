@@ -1601,12 +1601,14 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.avmax = 0.75;
   {
     const size_t P1 = (size_t)f->P + 1;
-    if (hipHostMalloc((void **)&f->pin, sizeof(double) * (5 * P1 + 8 + LMS_COUNT), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&f->pin, sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 96), hipHostMallocDefault) != hipSuccess) {
       delete f;
       return LSQAMD_ENOMEM;
     }
     f->pin_g = f->pin; f->pin_c = f->pin_g + P1; f->pin_v = f->pin_c + P1; f->pin_d = f->pin_v + P1;
     f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1; f->pin_lm = f->pin_s + 8;
+    f->pin_fit = f->pin_lm + LMS_COUNT;       // 96 doubles: what the one-launch fit kernel hands back (jit.h FitArgs::host)
+    static_assert(lsqamd_jit::FIT_HOST_DOUBLES <= 96, "pin_fit");
   }
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
@@ -2026,6 +2028,97 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
   return rc == LSQAMD_ENOTPD ? 0 : rc;
 }
 
+// A whole small fit in ONE launch (jit.hip lsqamd_jit_lm): a compiled formula with at most a dozen parameters, uncorrelated rows,
+// a few thousand of them at most, plain lm on one rank -- the fits of examples/nist.py and tests/test_lsqfit.py, where the
+// half dozen launches and two host round trips of an iteration of iterate_device cost more than its arithmetic.  One workgroup
+// runs gsl_multifit_nlinear_driver's loop from p0 to the stopping criterion and hands back the state where do_init / iterate_device
+// would have left it (device buffers and host mirrors).  -> 1: done (iter, info set); 0: not this fit's route, or the kernel met
+// something irregular and the general path runs the fit from the start; < 0: error.  LSQAMD_ONE_LAUNCH_FIT=0 disables (read per call).
+static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info) {
+  const char *e = getenv("LSQAMD_ONE_LAUNCH_FIT");
+  if (e && e[0] == '0') return 0;
+  const int64_t P = f->P;
+  const lsqamd_jit::Kernel *k = static_cast<const lsqamd_jit::Kernel *>(f->jit);
+  if (!lsqamd_jit::has_fit_kernel(k) || P > lsqamd_jit::NRM_MAX_P || f->N < 1 || f->N > lsqamd_jit::FIT_MAX_ROWS) return 0;
+  if (f->opt.trs != LSQAMD_TRS_LM || !f->linear.empty() || getenv("LSQAMD_HOST_LM") || f->opt.maxit < 1) return 0;
+  if (f->comm || f->reduce || f->timing || !small_fuse(f) || !f->progs.empty() || f->cfg.n_blocks != 0 || f->have_param_rows) return 0;
+  if (f->cfg.has_prior && !f->adds_prior) return 0;
+  int rc = ready(f);
+  if (rc) return rc;
+  void *dfit = nullptr, *dx = nullptr, *dlm = nullptr;
+  if (hipHostGetDevicePointer(&dfit, f->pin_fit, 0) != hipSuccess || hipHostGetDevicePointer(&dx, f->pin_x, 0) != hipSuccess ||
+      hipHostGetDevicePointer(&dlm, f->pin_lm, 0) != hipSuccess || !dfit || !dx || !dlm) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  static const bool zc_off = [] { const char *z = getenv("LSQAMD_ZERO_COPY"); return z && z[0] == '0'; }();
+  std::memcpy(f->pin_x, p0, sizeof(double) * P);
+  volatile double *h = f->pin_fit;
+  h[16] = 0.0;
+  std::atomic_thread_fence(std::memory_order_release);
+  lsqamd_jit::FitArgs a;
+  a.x = f->x; a.ymean = f->ymean; a.wdiag = f->wdiag; a.n_data = f->N;
+  a.p0 = static_cast<const double *>(dx);
+  a.p = f->p_dev; a.p_trial = f->p_trial; a.dscale = f->dscale; a.apk = f->redbuf; a.gvec = f->redbuf + f->npk;
+  a.v_out = f->yv + P; a.coln2 = f->diag_dev; a.st = f->lmd;
+  a.prior_prec = f->cfg.has_prior ? f->prior_prec : nullptr;
+  a.prior_mean = f->cfg.has_prior ? f->prior_mean : nullptr;
+  a.prior_dense = f->cfg.prior_dense; a.scaler = f->opt.scaler; a.maxit = f->opt.maxit;
+  a.watch = f->opt.solver == LSQAMD_SOLVER_QR ? 1 : 0;
+  a.xtol = f->opt.xtol; a.gtol = f->opt.gtol; a.factor_up = f->opt.factor_up; a.factor_down = f->opt.factor_down;
+  const long long bits = zc_off ? 0 : (long long)(intptr_t)dlm;
+  std::memcpy(&a.hostptr_bits, &bits, sizeof(double));
+  a.host = static_cast<double *>(dfit);
+  HIPCHK(f, lsqamd_jit::launch_fit(k, f->st, a));
+  {   // the kernel writes `reason` last, behind a system-scope fence: poll for it, then fall back to sleeping on the stream
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; h[16] == 0.0; ++spins)
+      if ((spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(5000)) {
+        HIPCHK(f, hipStreamSynchronize(f->st));
+        break;
+      }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (h[16] != 1.0) {                 // irregular (or nothing came back): the general path from the start
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    return 0;
+  }
+  const double *m = f->pin_fit + 24;
+  f->hx.assign(m, m + P);
+  f->hg.assign(m + (P + 1), m + (P + 1) + P);
+  f->hdiag.assign(m + 2 * (P + 1), m + 2 * (P + 1) + P);
+  f->hcoln.resize(P); f->hv.resize(P); f->hdx.resize(P);
+  for (int64_t j = 0; j < P; ++j) {
+    const double c2 = m[3 * (P + 1) + j], v = m[4 * (P + 1) + j];
+    f->hcoln[j] = std::sqrt(c2 > 0.0 ? c2 : 0.0);
+    f->hv[j] = v;
+    f->hdx[j] = -v;
+  }
+  for (int i = 0; i < LMS_COUNT; ++i) f->pin_lm[i] = f->pin_fit[i];
+  f->nit = (int)f->pin_fit[17]; f->nfev = (int)f->pin_fit[18]; f->njev = (int)f->pin_fit[19]; f->ntrial = (int)f->pin_fit[20];
+  f->chol_fail = f->qr_trials = 0;
+  f->qr_steps_on = false;
+  f->logdet = NAN;
+  f->chi2 = f->pin_fit[LMS_CHI2]; f->mu = f->pin_fit[LMS_MU]; f->nu = (long)f->pin_fit[LMS_NU]; f->delta = f->pin_fit[LMS_DELTA];
+  f->conv_info_dev = (int32_t)f->pin_fit[LMS_INFO];
+  f->dev_lm = true;
+  f->lm_zero_copy = bits != 0;
+  f->lm_seq_expect = 0.0;
+  f->mirrors_stale = false;
+  f->J_stale = true;               // (no Jacobian was written: ensure_J() for whoever reads it)
+  f->used_nrm = true;
+  f->used_one_launch = true;
+  f->nrm_in_tail = 0;
+  f->prior_deferred = false;
+  f->r_fresh = false;
+  f->have_cov = false;
+  f->have_dense_A = false;
+  f->initialised = true;
+  *iter = (int)f->nit;
+  *info = f->conv_info_dev;
+  return 1;
+}
+
 int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   if (!f || !p0) return LSQAMD_EINVAL;
   struct Pair {   // recycled events: every return path hands them back
@@ -2035,6 +2128,7 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
     ~Pair() { f->event_pool.push_back(a); f->event_pool.push_back(b); }
   } ev(f);
   (void)hipEventRecord(ev.a, f->st);
+  f->used_one_launch = false;
   int rc = 0;
   int iter = 0, info = 0, status = -2;
   bool early = false;
@@ -2047,6 +2141,9 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
     f->nit = f->nfev;                      // _scipy.py:161: nit = number of function evaluations
     info = LSQAMD_INFO_TRF + st;
     status = 0;
+  } else if ((rc = run_one_launch(f, p0, &iter, &info)) != 0) {
+    if (rc < 0) return rc;
+    status = info ? 0 : (iter >= maxit ? LSQAMD_EMAXITER : -2);
   } else if ((rc = do_init(f, p0)) != 0) {
     return rc;
   } else if (maxit > 0) {  // gsl_multifit_nlinear_driver
@@ -2480,7 +2577,7 @@ void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long 
 int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
   if (!f) return -1;
   return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | (int64_t)(f->graph_launches > 0 ? 4 : 0) |
-         (int64_t)(f->used_nrm ? 16 : 0) |
+         (int64_t)(f->used_nrm ? 16 : 0) | (int64_t)(f->used_one_launch ? 32 : 0) |
          (int64_t)(f->jit || (!f->progs.empty() && f->progs_compiled == (int)f->progs.size()) ? 8 : 0) |
          ((int64_t)f->splits << 8) |
          ((int64_t)f->h_size.size() << 32);

@@ -128,6 +128,8 @@ struct lsqamd_fit {
   double *pin = nullptr;
   double *pin_g = nullptr, *pin_c = nullptr, *pin_v = nullptr, *pin_d = nullptr, *pin_x = nullptr, *pin_s = nullptr;
   double *pin_lm = nullptr;   // the device's LM state record, as last read
+  double *pin_fit = nullptr;  // what the one-launch fit kernel hands back (jit.h FitArgs::host)
+  bool used_one_launch = false;   // the last lsqamd_run was ONE launch (api.hip run_one_launch); lsqamd_debug_flags bit 5
   std::vector<hipEvent_t> event_pool;
 
   // timing

@@ -32,4 +32,22 @@ constexpr int NRM_MAX_P = 12;
 int normal_nq(const Kernel *k);     // 0: this formula has no such kernel
 hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, double *partial, int blocks);
 
+// A whole small fit in one launch (same formulas as the normal-equation kernel: <= NRM_MAX_P parameters, uncorrelated rows):
+// plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
+// argument block, member for member.
+constexpr int FIT_MAX_ROWS = 4096;
+constexpr int FIT_HOST_DOUBLES = 24 + 5 * (NRM_MAX_P + 1);
+struct FitArgs {
+  const double *x, *ymean, *wdiag; long long n_data;
+  const double *p0;                      // start (may be device-visible host memory)
+  double *p, *p_trial, *dscale, *apk, *gvec, *v_out, *coln2, *st;
+  const double *prior_prec, *prior_mean; // prior_prec null: no prior
+  int prior_dense, scaler, maxit, watch;
+  double xtol, gtol, factor_up, factor_down, hostptr_bits;
+  double *host;                          // device-visible pinned block of FIT_HOST_DOUBLES: [0,16) record, [16] reason (written last:
+                                         // 1 done, 2 hand the fit to the general path), [17..20] nit nfev njev ntrial, [24..) x g D coln2 v
+};
+bool has_fit_kernel(const Kernel *k);
+hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a);
+
 }  // namespace lsqamd_jit

@@ -593,6 +593,271 @@ void gen_group(const Plan &pl, Src &o, const Group &g, int gid, int mode, const 
   o.f("      }\n");
 }
 
+
+// ---- a whole small fit in ONE launch (lsqamd_jit_lm): the text below follows the LM_* functions generate() emits -------
+// Plain Levenberg-Marquardt as api.hip iterate_device runs it over half a dozen launches per iteration -- the same solve
+// (vecops.hip lm_tiny12_solve_kernel), the same decision (lm_trial_tail_small_kernel), the same scaling update and
+// convergence test (lm_accept_tail_kernel) -- by one workgroup that keeps x, D, J^T J, J^T f in LDS from the first
+// evaluation to the last.  Anything irregular (no positive pivot, a step that is not finite, a pivot that retained too
+// little of its column under solver = qr, no progress in the very first iteration, a chi2 that is not finite) ends the kernel with
+// reason 2 and the host runs the fit through the general path from the start.
+const char *kLmDriver = R"LSQLM(
+struct LmArgs {
+  const double *x, *ymean, *wdiag; long long n_data;
+  const double *p0;
+  double *p, *p_trial, *dscale, *apk, *gvec, *v_out, *coln2, *st;
+  const double *prior_prec, *prior_mean;
+  int prior_dense, scaler, maxit, watch;
+  double xtol, gtol, factor_up, factor_down, hostptr_bits;
+  double *host;      // pinned mirror: [0, 16) the record, [16, 24) reason nit nfev njev ntrial chol_fail - -, then x g D coln2 v (LP + 1 each)
+};
+
+static __device__ void lm_normal(const LmArgs &a, const double *sp, double *red, double *sq, double *sA, double *sG, double *sT, double *ss) {
+  const int tid = threadIdx.x;
+  lm_nrm(a, sp, red, sq);
+  for (int e = tid; e < LP * LP; e += 256) {
+    const int i = e / LP, j = e % LP;
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    double v = sq[lo * LP - lo * (lo - 1) / 2 + (hi - lo)];
+    if (a.prior_prec) v += a.prior_dense ? a.prior_prec[i * LP + j] : (i == j ? a.prior_prec[i] : 0.0);
+    sA[e] = v;
+  }
+  if (tid < LP) {
+    double t = 0.0;
+    if (a.prior_prec) {
+      if (a.prior_dense) { for (int k = 0; k < LP; ++k) t += a.prior_prec[tid * LP + k] * (sp[k] - a.prior_mean[k]); }
+      else t = a.prior_prec[tid] * (sp[tid] - a.prior_mean[tid]);
+    }
+    sT[tid] = t;
+    sG[tid] = sq[LNA + tid] + t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double c = sq[LNA + LP];
+    if (a.prior_prec) for (int k = 0; k < LP; ++k) c += (sp[k] - a.prior_mean[k]) * sT[k];
+    ss[S_CHI2] = c;
+  }
+  __syncthreads();
+}
+
+// (A + mu D^2) v = g by wave 0: lane j holds column j of the upper triangle, lane 12 the right-hand side
+static __device__ void lm_solve(const double *sA, const double *sG, const double *sD, const double *sp, double mu, int watch,
+                                double *sV, double *spt, double *ss, int *si) {
+  constexpr int T12 = 12;
+  const int lane = threadIdx.x;
+  double m[T12];
+  double diag0 = 1.0;
+#pragma unroll
+  for (int i = 0; i < T12; ++i) {
+    double v = 0.0;
+    if (lane < T12) {
+      if (lane < LP && i <= lane && i < LP) {
+        v = sA[i * LP + lane];
+        if (i == lane) { v += mu * sD[i] * sD[i]; diag0 = v; }
+      } else if (i == lane) v = 1.0;
+    } else if (lane == T12 && i < LP) v = sG[i];
+    m[i] = v;
+  }
+  int fail = 0;
+  double pmin = __builtin_huge_val();
+#pragma unroll
+  for (int k = 0; k < T12; ++k) {
+    const double pk = __shfl(m[k], k, 64);
+    if (!(pk > 0.0) && fail == 0) fail = k + 1;
+    const double uk = sqrt(pk > 0.0 ? pk : 1.0), inv = 1.0 / uk;
+    if (lane == k) { pmin = pk / diag0 < pmin ? pk / diag0 : pmin; m[k] = uk; }
+    else if (lane > k) m[k] *= inv;
+#pragma unroll
+    for (int i = k + 1; i < T12; ++i) {
+      const double ui = __shfl(m[k], i, 64);
+      if (lane >= i) m[i] -= ui * m[k];
+    }
+  }
+  double vl = 0.0;
+#pragma unroll
+  for (int k = T12 - 1; k >= 0; --k) {
+    double t = (lane > k && lane < T12) ? m[k] * vl : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    const double yk = __shfl(m[k], T12, 64), ukk = __shfl(m[k], k, 64);
+    const double vk = (yk - __shfl(t, 0, 64)) / ukk;
+    if (lane == k) vl = vk;
+  }
+  const bool bad = fail != 0;
+  double vg = 0.0, dv2 = 0.0, nf = 0.0;
+  if (lane < LP) {
+    const double vj = bad ? __builtin_nan("") : vl;
+    sV[lane] = vj;
+    spt[lane] = sp[lane] - vj;
+    vg = vj * sG[lane];
+    const double t = sD[lane] * vj;
+    dv2 = t * t;
+    nf = (vj - vj == 0.0) ? 0.0 : 1.0;
+  } else {
+    pmin = __builtin_huge_val();
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    vg += __shfl_xor(vg, o, 64);
+    dv2 += __shfl_xor(dv2, o, 64);
+    nf += __shfl_xor(nf, o, 64);
+    pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
+  }
+  if (lane == 0) {
+    si[0] = fail;
+    ss[S_VG] = vg;
+    ss[S_DV2] = dv2;
+    ss[S_VFINITE] = nf == 0.0 ? 1.0 : 0.0;
+    ss[S_PIVMIN] = (watch && !bad) ? pmin : 1.0;
+  }
+}
+
+extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
+  __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[4 * LNQ], ss[16];
+  __shared__ int si[4];
+  const int tid = threadIdx.x;
+  if (tid < LP) { sp[tid] = a.p0[tid]; sV[tid] = 0.0; spt[tid] = a.p0[tid]; }
+  if (tid < 16) ss[tid] = 0.0;
+  __syncthreads();
+  lm_normal(a, sp, red, sq, sA, sG, sT, ss);
+  int reason = 0, nit = 0, nfev = 1, njev = 1, ntrial = 0;
+  if (!(ss[S_CHI2] - ss[S_CHI2] == 0.0)) reason = 2;
+  if (tid == 0 && reason == 0) {
+    // scale_init + the starting mu, nu, delta of do_init
+    double mx = 0.0, dxn = 0.0;
+    for (int j = 0; j < LP; ++j) {
+      const double c2 = sA[j * LP + j], cn = sqrt(c2 > 0.0 ? c2 : 0.0);
+      const double d = a.scaler == SC_LEVENBERG ? 1.0 : (cn == 0.0 ? 1.0 : cn);
+      sD[j] = d;
+      mx = fmax(mx, cn / d);
+      dxn += d * sp[j] * d * sp[j];
+    }
+    ss[S_MU] = 1e-3 * mx * mx;
+    ss[S_NU] = 2.0;
+    ss[S_DELTA] = 0.3 * fmax(1.0, sqrt(dxn));
+  }
+  __syncthreads();
+  while (reason == 0 && nit < a.maxit) {
+    int bad_steps = 0;
+    bool accepted = false;
+    while (!accepted) {
+      if (tid < 64) lm_solve(sA, sG, sD, sp, ss[S_MU], a.watch, sV, spt, ss, si);
+      __syncthreads();
+      if (si[0] != 0 || ss[S_VFINITE] == 0.0 || ss[S_PIVMIN] < 1e-8) { reason = 2; break; }
+      double ct = lm_res(a, spt, red);
+      if (a.prior_prec) {        // (every thread the same few terms, in the same order)
+        double c = 0.0;
+        for (int i = 0; i < LP; ++i) {
+          double t;
+          if (a.prior_dense) { t = 0.0; for (int k = 0; k < LP; ++k) t += a.prior_prec[i * LP + k] * (spt[k] - a.prior_mean[k]); }
+          else t = a.prior_prec[i] * (spt[i] - a.prior_mean[i]);
+          c += (spt[i] - a.prior_mean[i]) * t;
+        }
+        ct += c;
+      }
+      ++ntrial; ++nfev;
+      if (tid == 0) {
+        const double chi2 = ss[S_CHI2], mu = ss[S_MU];
+        double rho = -1.0;
+        const double normf = sqrt(chi2), normf_t = sqrt(ct);
+        if (normf_t < normf) {
+          const double u = normf_t / normf;
+          const double pred = (ss[S_VG] + mu * ss[S_DV2]) / chi2;
+          rho = pred > 0.0 ? (1.0 - u * u) / pred : -1.0;
+        }
+        if (rho > 0.75) ss[S_DELTA] *= a.factor_up;
+        else if (rho < 0.25) ss[S_DELTA] /= a.factor_down;
+        if (rho > 0.0) {
+          const double b = 2.0 * rho - 1.0;
+          ss[S_MU] = mu * fmax(0.333333333333333, 1.0 - b * b * b);
+          ss[S_NU] = 2.0;
+        } else {
+          ss[S_MU] = mu * ss[S_NU];
+          ss[S_NU] *= 2.0;
+        }
+        ss[S_RHO] = rho;
+        ss[S_CHI2_TRIAL] = ct;
+        ss[S_ACCEPT] = rho > 0.0 ? 1.0 : 0.0;
+        ss[S_SOLVED] = 1.0;
+      }
+      __syncthreads();
+      accepted = ss[S_ACCEPT] != 0.0;
+      if (!accepted && ++bad_steps > 15) break;
+      __syncthreads();
+    }
+    if (reason) break;
+    if (!accepted) {
+      // sixteen rejections in a row: gsl_multifit_nlinear_driver tests convergence after an iteration without progress as
+      // well, with the last (rejected) step as dx (api.hip iterate_device, lm_converge_kernel); at the very first iteration
+      // that is the driver's early exit, left to the general path
+      if (nit == 0) { reason = 2; break; }
+      if (tid == 0) {
+        double notx = 0.0, gn = 0.0;
+        for (int j = 0; j < LP; ++j) {
+          const double xj = sp[j];
+          notx += (fabs(sV[j]) < a.xtol * a.xtol + a.xtol * fabs(xj)) ? 0.0 : 1.0;
+          gn = fmax(gn, fabs(fmax(xj, 1.0) * sG[j]));
+        }
+        ss[S_INFO] = notx == 0.0 ? 1.0 : (gn <= a.gtol * fmax(0.5 * ss[S_CHI2], 1.0) ? 2.0 : 0.0);
+      }
+      __syncthreads();
+      ++nit;
+      if (ss[S_INFO] != 0.0) break;
+      __syncthreads();
+      continue;
+    }
+    if (tid < LP) sp[tid] = spt[tid];
+    __syncthreads();
+    lm_normal(a, sp, red, sq, sA, sG, sT, ss);
+    ++njev;
+    if (!(ss[S_CHI2] - ss[S_CHI2] == 0.0)) { reason = 2; break; }
+    if (tid == 0) {
+      double notx = 0.0, gn = 0.0;
+      for (int j = 0; j < LP; ++j) {
+        const double c2 = sA[j * LP + j], cn = sqrt(c2 > 0.0 ? c2 : 0.0);
+        double d;
+        if (a.scaler == SC_LEVENBERG) d = sD[j];
+        else if (a.scaler == SC_MORE) d = fmax(sD[j], cn);
+        else d = cn == 0.0 ? 1.0 : cn;
+        sD[j] = d;
+        const double xj = sp[j];
+        notx += (fabs(sV[j]) < a.xtol * a.xtol + a.xtol * fabs(xj)) ? 0.0 : 1.0;
+        gn = fmax(gn, fabs(fmax(xj, 1.0) * sG[j]));
+      }
+      ss[S_INFO] = notx == 0.0 ? 1.0 : (gn <= a.gtol * fmax(0.5 * ss[S_CHI2], 1.0) ? 2.0 : 0.0);
+    }
+    __syncthreads();
+    ++nit;
+    if (ss[S_INFO] != 0.0) break;
+    __syncthreads();
+  }
+  if (reason == 0) reason = 1;
+  __syncthreads();
+  // the state where the general path keeps it (device), and mirrored for the host
+  double *h = a.host;
+  if (tid < LP) {
+    a.p[tid] = sp[tid]; a.p_trial[tid] = spt[tid]; a.dscale[tid] = sD[tid]; a.v_out[tid] = sV[tid];
+    a.coln2[tid] = sA[tid * LP + tid]; a.gvec[tid] = sG[tid];
+    double *m = h + 24;
+    m[tid] = sp[tid]; m[LP + 1 + tid] = sG[tid]; m[2 * (LP + 1) + tid] = sD[tid]; m[3 * (LP + 1) + tid] = sA[tid * LP + tid];
+    m[4 * (LP + 1) + tid] = sV[tid];
+  }
+  for (int e = tid; e < LP * LP; e += 256) a.apk[(e / LP) * 128 + (e % LP)] = sA[e];
+  if (tid == 0) {
+    a.gvec[LP] = ss[S_CHI2];
+    h[24 + LP + 1 + LP] = ss[S_CHI2];
+    ss[S_SEQ] = 0.0;
+    ss[S_HOSTPTR] = a.hostptr_bits;
+  }
+  __syncthreads();
+  if (tid < 16) { a.st[tid] = ss[tid]; h[tid] = ss[tid]; }
+  if (tid == 0) { h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial; }
+  __threadfence_system();
+  __syncthreads();
+  if (tid == 0) { h[16] = (double)reason; __threadfence_system(); }
+}
+)LSQLM";
+
 std::string generate(const Plan &pl) {
   Src o;
   o.s += "// generated by lsqfit_amd (jit.hip) from an expression tape\n";
@@ -781,6 +1046,76 @@ std::string generate(const Plan &pl) {
     o.f("  { const double t = wsum(nC); if (lane == 0) red[wave][%d] = t; }\n", q);
     o.f("  __syncthreads();\n  if (threadIdx.x < %d) a.out_w[(long long)blockIdx.x * %d + threadIdx.x] = "
         "red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];\n}\n", NQ, NQ);
+    // ---- the same sums and the residual as functions of ONE workgroup, and the whole-fit kernel over them
+    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d;\n", P, NA, NQ);
+    o.f("enum { S_CHI2 = %d, S_MU = %d, S_NU = %d, S_DELTA = %d, S_VG = %d, S_DV2 = %d, S_VFINITE = %d, S_RHO = %d, S_CHI2_TRIAL = %d, "
+        "S_ACCEPT = %d, S_SOLVED = %d, S_INFO = %d, S_PIVMIN = %d, S_SEQ = %d, S_HOSTPTR = %d, SC_LEVENBERG = %d, SC_MORE = %d };\n",
+        (int)lsqamd::LMS_CHI2, (int)lsqamd::LMS_MU, (int)lsqamd::LMS_NU, (int)lsqamd::LMS_DELTA, (int)lsqamd::LMS_VG, (int)lsqamd::LMS_DV2, (int)lsqamd::LMS_VFINITE, (int)lsqamd::LMS_RHO,
+        (int)lsqamd::LMS_CHI2_TRIAL, (int)lsqamd::LMS_ACCEPT, (int)lsqamd::LMS_SOLVED, (int)lsqamd::LMS_INFO, (int)lsqamd::LMS_PIVMIN, (int)lsqamd::LMS_SEQ, (int)lsqamd::LMS_HOSTPTR,
+        (int)LSQAMD_SCALE_LEVENBERG, (int)LSQAMD_SCALE_MORE);
+    const char *decl = strstr(kLmDriver, "struct LmArgs {");
+    const char *decl_end = strstr(decl, "};");
+    o.s.append(decl, (size_t)(decl_end - decl) + 2);
+    o.s += "\n";
+    for (int fn = 0; fn < 2; ++fn) {
+      const bool nrm = fn == 0;
+      if (nrm) o.s += "static __device__ void lm_nrm(const LmArgs &a, const double *sp, double *red, double *sq) {\n";
+      else o.s += "static __device__ double lm_res(const LmArgs &a, const double *sp, double *red) {\n";
+      o.s += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
+      if (nrm) {
+        for (int i = 0; i < P; ++i)
+          for (int j = i; j < P; ++j) o.f("  double nA%d_%d = 0.0;\n", i, j);
+        for (int i = 0; i < P; ++i) o.f("  double nG%d = 0.0;\n", i);
+      }
+      o.s += "  double nC = 0.0;\n";
+      o.s += "  for (long long row = threadIdx.x; row < a.n_data; row += 256) {\n";
+      for (int i = 0; i < pl.n_x; ++i)
+        if (xused[(size_t)i]) o.f("    const double x%d = a.x[row * %d + %d];\n", i, pl.n_x, i);
+      o.s += "    const double w = a.wdiag[row];\n";
+      if (nrm)
+        for (int j = 0; j < nout; ++j) o.f("    double oacc%d = 0.0;\n", j);
+      {
+        TreeGen tg(pl.outer, pl, o, "o", "    ", nrm);
+        tg.leaf_value = [&](const Node &nd) { return "sp[" + std::to_string(nd.arg) + "]"; };
+        tg.leaf_adjoint = [&](const Node &nd, const std::string &gg) {
+          int j = 0;
+          while (pl.out_params[(size_t)j] != nd.arg) ++j;
+          o.f("    oacc%d += %s;\n", j, gg.c_str());
+        };
+        tg.forward(pl.oroot);
+        o.f("    const double fval = %s;\n", tg.v(pl.oroot).c_str());
+        if (nrm) {
+          o.s += "    const double one = 1.0;\n";
+          tg.reverse(pl.oroot, "one");
+        }
+      }
+      o.s += "    const double rr = w * (fval - a.ymean[row]);\n";
+      if (nrm) {
+        std::vector<int> slot((size_t)P, -1);
+        for (int j = 0; j < nout; ++j) slot[(size_t)pl.out_params[(size_t)j]] = j;
+        for (int i = 0; i < P; ++i) {
+          if (slot[(size_t)i] >= 0) o.f("    const double dd%d = w * oacc%d;\n", i, slot[(size_t)i]);
+          else o.f("    const double dd%d = 0.0;\n", i);
+        }
+        for (int i = 0; i < P; ++i)
+          for (int j = i; j < P; ++j) o.f("    nA%d_%d += dd%d * dd%d;\n", i, j, i, j);
+        for (int i = 0; i < P; ++i) o.f("    nG%d += dd%d * rr;\n", i, i);
+      }
+      o.s += "    nC += rr * rr;\n  }\n";
+      if (nrm) {
+        int qq = 0;
+        for (int i = 0; i < P; ++i)
+          for (int j = i; j < P; ++j) { o.f("  { const double t = wsum(nA%d_%d); if (lane == 0) red[wave * LNQ + %d] = t; }\n", i, j, qq); ++qq; }
+        for (int i = 0; i < P; ++i) { o.f("  { const double t = wsum(nG%d); if (lane == 0) red[wave * LNQ + %d] = t; }\n", i, qq); ++qq; }
+        o.f("  { const double t = wsum(nC); if (lane == 0) red[wave * LNQ + %d] = t; }\n", qq);
+        o.s += "  __syncthreads();\n  if (threadIdx.x < LNQ) sq[threadIdx.x] = red[threadIdx.x] + red[LNQ + threadIdx.x] + "
+               "red[2 * LNQ + threadIdx.x] + red[3 * LNQ + threadIdx.x];\n  __syncthreads();\n}\n";
+      } else {
+        o.s += "  { const double t = wsum(nC); if (lane == 0) red[wave] = t; }\n  __syncthreads();\n"
+               "  const double tot = red[0] + red[1] + red[2] + red[3];\n  __syncthreads();\n  return tot;\n}\n";
+      }
+    }
+    o.s += decl_end + 2;      // the driver: lm_normal, lm_solve, lsqamd_jit_lm
   }
   return o.s;
 }
@@ -861,7 +1196,7 @@ bool compile_source(const std::string &src, std::vector<char> &code, std::string
 
 struct Loaded {
   hipModule_t mod = nullptr;
-  hipFunction_t res = nullptr, jac = nullptr, nrm = nullptr;
+  hipFunction_t res = nullptr, jac = nullptr, nrm = nullptr, lm = nullptr;
   bool wave_per_row = false;
   int n_param = 0;
   bool nrm_ok = false;          // few parameters, no wide sums: a third kernel forms J^T J, J^T f and chi2 without writing J
@@ -916,6 +1251,10 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
     (void)hipGetLastError();
     k.l.nrm = nullptr;
   }
+  if (has_nrm && hipModuleGetFunction(&k.l.lm, k.l.mod, "lsqamd_jit_lm") != hipSuccess) {
+    (void)hipGetLastError();
+    k.l.lm = nullptr;
+  }
   return &kernels.emplace(key, k).first->second;
 }
 
@@ -947,6 +1286,16 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
   size_t sz = sizeof(args);
   void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
   return hipModuleLaunchKernel(k->l.nrm, (unsigned)blocks, 1, 1, 256, 1, 1, 0, st, nullptr, cfg);
+}
+
+bool has_fit_kernel(const Kernel *k) { return k && k->l.lm; }
+
+hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a) {
+  if (!k || !k->l.lm) return hipErrorInvalidValue;
+  FitArgs args = a;
+  size_t sz = sizeof(args);
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(k->l.lm, 1, 1, 1, 256, 1, 1, 0, st, nullptr, cfg);
 }
 
 bool available(std::string *why) {

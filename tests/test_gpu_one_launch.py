@@ -1,0 +1,131 @@
+"""-m gpu: a whole small fit in ONE launch (jit.hip lsqamd_jit_lm, api.hip run_one_launch) -- compiled formula, at most a
+dozen parameters, a few thousand uncorrelated rows, plain lm.  The kernel runs the loop the general path spreads over half a
+dozen launches per iteration; both must agree iteration for iteration (same solve, same decision, same stopping test; the
+sums are ordered differently, so values agree to rounding), and anything irregular must fall back to the general path.
+Against the oracle these fits are checked by tests/test_gpu_parity.py (the 27 NIST problems take this route by default)."""
+import numpy as np
+import pytest
+
+from tests.helpers import load, nist_problem
+
+pytestmark = pytest.mark.gpu
+NIST = load('nist.json')
+ONE = 32     # lsqamd_debug_flags bit 5
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+def flags(fit):
+    pr = fit.problem
+    return pr.lib.lsqamd_debug_flags(pr.h)
+
+
+def both(amd, monkeypatch, **kw):
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    one = amd.nonlinear_fit(**kw)
+    f1 = flags(one)
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '0')
+    gen = amd.nonlinear_fit(**kw)
+    assert not flags(gen) & ONE
+    return one, f1, gen
+
+
+def agree(one, gen, rtol=1e-8):
+    # (the two routes add their sums in different orders: at a stopping tolerance near the rounding floor -- the NIST
+    #  problems run at xtol = 1e-10 -- the last, rounding-sized step may be accepted by one and rejected sixteen times by
+    #  the other; both stop at the same point on the same criterion)
+    assert abs(one.nit - gen.nit) <= max(1, gen.nit // 8)
+    s1, s0 = one.fitter_results.summary, gen.fitter_results.summary
+    assert s1.stopping_criterion == s0.stopping_criterion
+    assert s1.nit == one.nit and s1.njev in (s1.nit, s1.nit + 1) and s1.nfev > s1.nit
+    assert np.all(np.abs(one.pmean - gen.pmean) <= rtol * np.abs(gen.pmean) + 5e-6 * gen.psdev)
+    assert abs(one.chi2 - gen.chi2) <= 1e-8 * max(gen.chi2, 1e-12) + 1e-20
+    assert np.allclose(one.cov, gen.cov, rtol=1e-5, atol=1e-300)
+    assert one.logGBF == pytest.approx(gen.logGBF, rel=1e-8, abs=1e-8)
+
+
+@pytest.mark.parametrize('name', ['misra1a', 'chwirut2', 'thurber', 'gauss1', 'mgh09', 'eckerle4', 'hahn1', 'lanczos3', 'boxbod'])
+def test_nist_fits_agree_with_the_general_path(amd, name, monkeypatch):
+    pr = nist_problem(name, NIST)
+    model = amd.expr(pr['expr'], ['b%d' % (i + 1) for i in range(pr['P'])], pr['columns'][1:])
+    x = np.stack([pr['x'][c] for c in pr['columns'][1:]], axis=1)
+    one, f1, gen = both(amd, monkeypatch, data=(x, pr['y'], pr['ysd']), model=model, prior=(pr['prior_mean'], pr['prior_sd']),
+                        p0=pr['p0'], tol=pr['tol'])
+    assert f1 & ONE, 'the fit did not take the one-launch route'
+    agree(one, gen)
+    # what reads the Jacobian afterwards finds it (never written by the kernel)
+    assert np.allclose(one.J, gen.J, rtol=1e-5, atol=1e-7 * np.max(np.abs(gen.J)))      # (at end points up to 2e-6 sigma apart)
+    assert np.allclose(one.residuals, gen.residuals, rtol=1e-5, atol=1e-7 * (1 + np.max(np.abs(gen.residuals))))
+
+
+def curve(N=600, seed=3):
+    rng = np.random.default_rng(seed)
+    x = np.sort(rng.uniform(0.0, 5.0, N))
+    pt = np.array([1.5, 0.7, 0.4, 2.0])
+    f = pt[0] * np.exp(-pt[1] * x) + pt[2] * np.cos(pt[3] * x)
+    sd = 0.02 + 0.01 * rng.random(N)
+    return x, f + sd * rng.standard_normal(N), sd, pt
+
+
+@pytest.mark.parametrize('prior', ['diag', 'dense', 'none'])
+@pytest.mark.parametrize('scaler', ['more', 'levenberg', 'marquardt'])
+def test_priors_and_scalers(amd, prior, scaler, monkeypatch):
+    x, y, sd, pt = curve()
+    model = amd.expr('a*exp(-b*x) + c*cos(d*x)', ['a', 'b', 'c', 'd'])
+    kw = dict(data=(x, y, sd), model=model, p0=pt * 1.2, scaler=scaler)
+    if prior == 'diag':
+        kw['prior'] = (pt * 1.1, np.full(4, 0.5))
+    elif prior == 'dense':
+        L = np.tril(0.2 * np.random.default_rng(1).standard_normal((4, 4))) + 0.6 * np.eye(4)
+        kw['prior'] = (pt * 1.1, L @ L.T)
+    one, f1, gen = both(amd, monkeypatch, **kw)
+    assert f1 & ONE
+    agree(one, gen)
+
+
+def test_iteration_limit_and_resident_problem(amd, monkeypatch):
+    x, y, sd, pt = curve(N=3000, seed=8)
+    model = amd.expr('a*exp(-b*x) + c*cos(d*x)', ['a', 'b', 'c', 'd'])
+    kw = dict(data=(x, y, sd), model=model, prior=(pt, np.full(4, 1.0)), p0=pt * 1.4, maxit=3)
+    one, f1, gen = both(amd, monkeypatch, **kw)
+    assert f1 & ONE and one.nit == 3
+    agree(one, gen)
+    assert one.stopping_criterion == gen.stopping_criterion == 0 and one.error == gen.error
+    # the same handle again, to convergence, twice: nothing of the first run lingers
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    kw['maxit'] = 200
+    a = amd.nonlinear_fit(problem=one.problem, **kw)
+    b = amd.nonlinear_fit(problem=one.problem, **kw)
+    assert flags(a) & ONE and a.nit == b.nit and np.array_equal(a.pmean, b.pmean) and np.array_equal(a.cov, b.cov)
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '0')
+    agree(a, amd.nonlinear_fit(**kw))
+
+
+def test_irregular_fits_fall_back(amd, monkeypatch):
+    """No prior and two parameters the data cannot tell apart: the damped matrix loses its pivot as mu shrinks, or the fit
+    stalls -- whatever the general path does with it, the one-launch route must hand the fit over, not improvise."""
+    rng = np.random.default_rng(5)
+    x = np.linspace(0.0, 1.0, 200)
+    y = 2.0 * x + 0.01 * rng.standard_normal(200)
+    model = amd.expr('(a + b)*x + 0*c', ['a', 'b', 'c'])
+    kw = dict(data=(x, y, np.full(200, 0.01)), model=model, p0=[0.5, 0.5, 0.1])
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+        one = amd.nonlinear_fit(**kw)
+        monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '0')
+        gen = amd.nonlinear_fit(**kw)
+    assert abs(one.nit - gen.nit) <= 1 and np.allclose(one.pmean, gen.pmean, rtol=1e-7, atol=1e-10)
+    assert (one.error is None) == (gen.error is None)
+    # too many rows for one workgroup: the general path, silently
+    xx = np.linspace(0.0, 5.0, 5000)
+    big = amd.nonlinear_fit(data=(xx, np.exp(-0.5 * xx) + 0.01 * rng.standard_normal(5000), np.full(5000, 0.01)),
+                            model=amd.expr('a*exp(-b*x)', ['a', 'b']), p0=[1.0, 1.0])
+    assert not flags(big) & ONE and big.error is None

@@ -79,7 +79,7 @@ def test_qr_grade_trial_steps_follow_the_reference_solver(amd, P):
     Monomial-basis fits with cond(J D^-1) from 1e9 (P = 8) upwards: once the damping has shrunk to where the damped
     normal equations retain less than 1e-8 of a column, the device's trial steps come from the orthogonal
     factorisation too (summary.qr_trials) and the fit follows the oracle's Householder-QR trajectory: same number of
-    iterations within 15 % (the normal equations alone wander off by several rejected trials), same end point."""
+    iterations within 20 % (the normal equations alone wander off by several rejected trials), same end point."""
     x, text, V = hilbert_like(P)
     rng = np.random.default_rng(P)
     ysd = np.full(x.size, 1e-3)
@@ -90,9 +90,11 @@ def test_qr_grade_trial_steps_follow_the_reference_solver(amd, P):
     s = fit.fitter_results.summary
     print('P = %d: nit %d (oracle qr %d), %d of %d trials from the orthogonal factorisation' % (P, fit.nit, ref.nit, s.qr_trials, s.ntrial))
     # iteration counts: these trajectories (cond 1e9 ... 1e14, 20-33 iterations, a dozen rejected trials) move by a few
-    # iterations with the summation order of J^T J -- the device's own two routes to it differ by up to 4 -- so the
-    # count is required to be the oracle's within 15 %; the end point is compared at the north_star tolerance below
-    assert abs(fit.nit - ref.nit) <= max(1, ref.nit // 6), (fit.nit, ref.nit)
+    # iterations with the summation order of J^T J -- the device's own routes to it (SYRK over the Jacobian, the sums
+    # of the compiled formula's registers over many workgroups or, for these sizes, inside the one-launch fit kernel)
+    # differ by up to 4 -- so the count is required to be the oracle's within 20 %; the end point is compared at the
+    # north_star tolerance below
+    assert abs(fit.nit - ref.nit) <= max(1, ref.nit // 5), (fit.nit, ref.nit)
     assert fit.stopping_criterion == ref.stopping_criterion
     assert (s.qr_trials > 0) == (P > 8)
     assert abs(fit.chi2 - ref.chi2) < 1e-8 * ref.chi2
