@@ -2108,6 +2108,9 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   f->J_stale = true;               // (no Jacobian was written: ensure_J() for whoever reads it)
   f->used_nrm = true;
   f->used_one_launch = true;
+  if (getenv("LSQAMD_FIT_DIAG"))     // developer knob: where the kernel's cycles went
+    fprintf(stderr, "lsqamd_jit_lm: %.0f shader cycles (normal equations %.0f, solves %.0f, trial residuals %.0f), %.1f us; nit %d trials %d\n",
+            f->pin_fit[89], f->pin_fit[90], f->pin_fit[91], f->pin_fit[92], f->pin_fit[93] / 100.0, (int)f->nit, (int)f->ntrial);
   f->nrm_in_tail = 0;
   f->prior_deferred = false;
   f->r_fresh = false;

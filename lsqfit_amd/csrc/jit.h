@@ -36,7 +36,7 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 // plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
 // argument block, member for member.
 constexpr int FIT_MAX_ROWS = 4096;
-constexpr int FIT_HOST_DOUBLES = 24 + 5 * (NRM_MAX_P + 1);
+constexpr int FIT_HOST_DOUBLES = 24 + 5 * (NRM_MAX_P + 1) + 5;   // (+ 5 cycle counters at [89, 94): developer diagnostics)
 struct FitArgs {
   const double *x, *ymean, *wdiag; long long n_data;
   const double *p0;                      // start (may be device-visible host memory)

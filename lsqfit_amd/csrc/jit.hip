@@ -612,6 +612,10 @@ struct LmArgs {
   double *host;      // pinned mirror: [0, 16) the record, [16, 24) reason nit nfev njev ntrial chol_fail - -, then x g D coln2 v (LP + 1 each)
 };
 
+static __device__ void m_diag(double *o, long long a0, long long a1, long long a2, long long a3, long long a4) {
+  o[0] = (double)a0; o[1] = (double)a1; o[2] = (double)a2; o[3] = (double)a3; o[4] = (double)a4;
+}
+
 static __device__ void lm_normal(const LmArgs &a, const double *sp, double *red, double *sq, double *sA, double *sG, double *sT, double *ss) {
   const int tid = threadIdx.x;
   lm_nrm(a, sp, red, sq);
@@ -640,69 +644,81 @@ static __device__ void lm_normal(const LmArgs &a, const double *sp, double *red,
   __syncthreads();
 }
 
-// (A + mu D^2) v = g by wave 0: lane j holds column j of the upper triangle, lane 12 the right-hand side
+// (A + mu D^2) v = g by wave 0: lane j holds column j of the upper triangle (rows i <= j), lane LP the right-hand side.
+// Every cross-lane read names its lane at compile time (v_readlane: the value arrives in scalar registers), pivots are
+// inverted by v_rsq_f64 + two Newton steps instead of a square root and a division, and the back substitution runs on a
+// wave-uniform copy of y -- the dependent chain of a step is a dozen instructions.
+static __device__ __forceinline__ double lm_rsqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = -0.5 * d;
+  double e = __builtin_fma(h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+
 static __device__ void lm_solve(const double *sA, const double *sG, const double *sD, const double *sp, double mu, int watch,
                                 double *sV, double *spt, double *ss, int *si) {
-  constexpr int T12 = 12;
   const int lane = threadIdx.x;
-  double m[T12];
+  double m[LP], uinv[LP];
   double diag0 = 1.0;
+  // (branch-free: every lane reads a clamped address, the selection follows)
+  const int col = lane < LP ? lane : LP - 1;
+  const double dl = sD[col], dmu = mu * dl * dl;
 #pragma unroll
-  for (int i = 0; i < T12; ++i) {
-    double v = 0.0;
-    if (lane < T12) {
-      if (lane < LP && i <= lane && i < LP) {
-        v = sA[i * LP + lane];
-        if (i == lane) { v += mu * sD[i] * sD[i]; diag0 = v; }
-      } else if (i == lane) v = 1.0;
-    } else if (lane == T12 && i < LP) v = sG[i];
-    m[i] = v;
+  for (int i = 0; i < LP; ++i) {
+    const double av = sA[i * LP + col], gv = sG[i];
+    double v = (lane < LP && i <= lane) ? av : 0.0;
+    if (i == lane) { v += dmu; diag0 = v; }
+    m[i] = lane == LP ? gv : v;
   }
   int fail = 0;
   double pmin = __builtin_huge_val();
 #pragma unroll
-  for (int k = 0; k < T12; ++k) {
-    const double pk = __shfl(m[k], k, 64);
+  for (int k = 0; k < LP; ++k) {
+    const double pk = lm_rl(m[k], k);
     if (!(pk > 0.0) && fail == 0) fail = k + 1;
-    const double uk = sqrt(pk > 0.0 ? pk : 1.0), inv = 1.0 / uk;
-    if (lane == k) { pmin = pk / diag0 < pmin ? pk / diag0 : pmin; m[k] = uk; }
-    else if (lane > k) m[k] *= inv;
+    const double inv = lm_rsqrt(pk > 0.0 ? pk : 1.0);
+    uinv[k] = inv;
+    if (lane == k) pmin = pk;               // (this lane's pivot; divided by the damped diagonal entry below)
+    if (lane >= k) m[k] = (lane == k) ? pk * inv : m[k] * inv;
 #pragma unroll
-    for (int i = k + 1; i < T12; ++i) {
-      const double ui = __shfl(m[k], i, 64);
+    for (int i = k + 1; i < LP; ++i) {
+      const double ui = lm_rl(m[k], i);
       if (lane >= i) m[i] -= ui * m[k];
     }
   }
-  double vl = 0.0;
+  // U v = y: y (lane LP's column) wave-uniform, v_k = y_k / U_kk, then y_i -= U_ik v_k for the rows above
+  double y[LP], v[LP];
 #pragma unroll
-  for (int k = T12 - 1; k >= 0; --k) {
-    double t = (lane > k && lane < T12) ? m[k] * vl : 0.0;
+  for (int i = 0; i < LP; ++i) y[i] = lm_rl(m[i], LP);
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    const double yk = __shfl(m[k], T12, 64), ukk = __shfl(m[k], k, 64);
-    const double vk = (yk - __shfl(t, 0, 64)) / ukk;
-    if (lane == k) vl = vk;
+  for (int k = LP - 1; k >= 0; --k) {
+    v[k] = y[k] * uinv[k];
+#pragma unroll
+    for (int i = 0; i < k; ++i) y[i] -= lm_rl(m[i], k) * v[k];
   }
   const bool bad = fail != 0;
-  double vg = 0.0, dv2 = 0.0, nf = 0.0;
+  // v is wave-uniform: its dot products as a handful of uniform FMAs (no cross-lane reduction), lane k keeps v_k
+  double vl = 0.0, vg = 0.0, dv2 = 0.0, nf = 0.0;
+#pragma unroll
+  for (int k = 0; k < LP; ++k) {
+    vl = lane == k ? v[k] : vl;
+    vg = __builtin_fma(v[k], sG[k], vg);
+    const double t = sD[k] * v[k];
+    dv2 = __builtin_fma(t, t, dv2);
+    nf += (v[k] - v[k] == 0.0) ? 0.0 : 1.0;
+  }
+  if (bad) { vl = __builtin_nan(""); nf = 1.0; }
   if (lane < LP) {
-    const double vj = bad ? __builtin_nan("") : vl;
-    sV[lane] = vj;
-    spt[lane] = sp[lane] - vj;
-    vg = vj * sG[lane];
-    const double t = sD[lane] * vj;
-    dv2 = t * t;
-    nf = (vj - vj == 0.0) ? 0.0 : 1.0;
+    sV[lane] = vl;
+    spt[lane] = sp[lane] - vl;
+    pmin = pmin / diag0;                    // the share of column `lane` its pivot retained
   } else {
     pmin = __builtin_huge_val();
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    vg += __shfl_xor(vg, o, 64);
-    dv2 += __shfl_xor(dv2, o, 64);
-    nf += __shfl_xor(nf, o, 64);
-    pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
-  }
+  for (int o = 8; o > 0; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));      // (LP <= 12: lanes 0 .. 15 hold everything)
   if (lane == 0) {
     si[0] = fail;
     ss[S_VG] = vg;
@@ -713,13 +729,32 @@ static __device__ void lm_solve(const double *sA, const double *sG, const double
 }
 
 extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
-  __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[4 * LNQ], ss[16];
+  __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[16 * LNQ], ss[16];
   __shared__ int si[4];
+  __shared__ double sdata[LDATA];
   const int tid = threadIdx.x;
+  // the data of a fit this small is read dozens of times: once from memory, then from LDS (the generated row loops read
+  // through a.x / a.ymean / a.wdiag, which may as well point there)
+  if (a.n_data * (LNX + 2) <= LDATA) {
+    const int n = (int)a.n_data;
+    for (int i = tid; i < n * LNX; i += 256) sdata[i] = a.x[i];
+    for (int i = tid; i < n; i += 256) { sdata[n * LNX + i] = a.ymean[i]; sdata[n * (LNX + 1) + i] = a.wdiag[i]; }
+    a.x = sdata; a.ymean = sdata + n * LNX; a.wdiag = sdata + n * (LNX + 1);
+  }
+  __shared__ double sprior[LP * LP + LP];
+  if (a.prior_prec) {
+    const int np = a.prior_dense ? LP * LP : LP;
+    if (tid < np) sprior[tid] = a.prior_prec[tid];
+    if (tid < LP) sprior[LP * LP + tid] = a.prior_mean[tid];
+    a.prior_prec = sprior; a.prior_mean = sprior + LP * LP;
+  }
   if (tid < LP) { sp[tid] = a.p0[tid]; sV[tid] = 0.0; spt[tid] = a.p0[tid]; }
   if (tid < 16) ss[tid] = 0.0;
   __syncthreads();
+  const long long c_begin = clock64(), w_begin = wall_clock64();
+  long long c_nrm = 0, c_solve = 0, c_res = 0;
   lm_normal(a, sp, red, sq, sA, sG, sT, ss);
+  c_nrm += clock64() - c_begin;
   int reason = 0, nit = 0, nfev = 1, njev = 1, ntrial = 0;
   if (!(ss[S_CHI2] - ss[S_CHI2] == 0.0)) reason = 2;
   if (tid == 0 && reason == 0) {
@@ -741,10 +776,14 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
     int bad_steps = 0;
     bool accepted = false;
     while (!accepted) {
+      long long c0 = clock64();
       if (tid < 64) lm_solve(sA, sG, sD, sp, ss[S_MU], a.watch, sV, spt, ss, si);
       __syncthreads();
+      c_solve += clock64() - c0;
+      c0 = clock64();
       if (si[0] != 0 || ss[S_VFINITE] == 0.0 || ss[S_PIVMIN] < 1e-8) { reason = 2; break; }
       double ct = lm_res(a, spt, red);
+      c_res += clock64() - c0;
       if (a.prior_prec) {        // (every thread the same few terms, in the same order)
         double c = 0.0;
         for (int i = 0; i < LP; ++i) {
@@ -759,11 +798,9 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
       if (tid == 0) {
         const double chi2 = ss[S_CHI2], mu = ss[S_MU];
         double rho = -1.0;
-        const double normf = sqrt(chi2), normf_t = sqrt(ct);
-        if (normf_t < normf) {
-          const double u = normf_t / normf;
-          const double pred = (ss[S_VG] + mu * ss[S_DV2]) / chi2;
-          rho = pred > 0.0 ? (1.0 - u * u) / pred : -1.0;
+        if (ct < chi2) {         // (|f_t| < |f|; 1 - (|f_t| / |f|)^2 without the two square roots: the same to rounding.  NaN rejects)
+          const double num = ss[S_VG] + mu * ss[S_DV2];        // = pred * chi2
+          rho = num > 0.0 ? (chi2 - ct) / num : -1.0;
         }
         if (rho > 0.75) ss[S_DELTA] *= a.factor_up;
         else if (rho < 0.25) ss[S_DELTA] /= a.factor_down;
@@ -808,12 +845,13 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
     }
     if (tid < LP) sp[tid] = spt[tid];
     __syncthreads();
-    lm_normal(a, sp, red, sq, sA, sG, sT, ss);
+    { const long long c0 = clock64(); lm_normal(a, sp, red, sq, sA, sG, sT, ss); c_nrm += clock64() - c0; }
     ++njev;
     if (!(ss[S_CHI2] - ss[S_CHI2] == 0.0)) { reason = 2; break; }
-    if (tid == 0) {
+    if (tid < 64) {       // scaling update and gsl_multifit_nlinear_test, one lane per parameter
       double notx = 0.0, gn = 0.0;
-      for (int j = 0; j < LP; ++j) {
+      if (tid < LP) {
+        const int j = tid;
         const double c2 = sA[j * LP + j], cn = sqrt(c2 > 0.0 ? c2 : 0.0);
         double d;
         if (a.scaler == SC_LEVENBERG) d = sD[j];
@@ -821,10 +859,15 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
         else d = cn == 0.0 ? 1.0 : cn;
         sD[j] = d;
         const double xj = sp[j];
-        notx += (fabs(sV[j]) < a.xtol * a.xtol + a.xtol * fabs(xj)) ? 0.0 : 1.0;
-        gn = fmax(gn, fabs(fmax(xj, 1.0) * sG[j]));
+        notx = (fabs(sV[j]) < a.xtol * a.xtol + a.xtol * fabs(xj)) ? 0.0 : 1.0;
+        gn = fabs(fmax(xj, 1.0) * sG[j]);
       }
-      ss[S_INFO] = notx == 0.0 ? 1.0 : (gn <= a.gtol * fmax(0.5 * ss[S_CHI2], 1.0) ? 2.0 : 0.0);
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        notx += __shfl_xor(notx, o, 64);
+        gn = fmax(gn, __shfl_xor(gn, o, 64));
+      }
+      if (tid == 0) ss[S_INFO] = notx == 0.0 ? 1.0 : (gn <= a.gtol * fmax(0.5 * ss[S_CHI2], 1.0) ? 2.0 : 0.0);
     }
     __syncthreads();
     ++nit;
@@ -851,7 +894,11 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
   }
   __syncthreads();
   if (tid < 16) { a.st[tid] = ss[tid]; h[tid] = ss[tid]; }
-  if (tid == 0) { h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial; }
+  if (tid == 0) {
+    h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial;
+    // diagnostics: shader cycles in all / in the normal equations / in the solves / in the trial residuals, 100 MHz ticks in all
+    m_diag(h + 89, clock64() - c_begin, c_nrm, c_solve, c_res, wall_clock64() - w_begin);
+  }
   __threadfence_system();
   __syncthreads();
   if (tid == 0) { h[16] = (double)reason; __threadfence_system(); }
@@ -1047,12 +1094,25 @@ std::string generate(const Plan &pl) {
     o.f("  __syncthreads();\n  if (threadIdx.x < %d) a.out_w[(long long)blockIdx.x * %d + threadIdx.x] = "
         "red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];\n}\n", NQ, NQ);
     // ---- the same sums and the residual as functions of ONE workgroup, and the whole-fit kernel over them
-    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d;\n", P, NA, NQ);
+    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d, LNX = %d, LDATA = 5120;\n", P, NA, NQ, pl.n_x < 1 ? 1 : pl.n_x);
     o.f("enum { S_CHI2 = %d, S_MU = %d, S_NU = %d, S_DELTA = %d, S_VG = %d, S_DV2 = %d, S_VFINITE = %d, S_RHO = %d, S_CHI2_TRIAL = %d, "
         "S_ACCEPT = %d, S_SOLVED = %d, S_INFO = %d, S_PIVMIN = %d, S_SEQ = %d, S_HOSTPTR = %d, SC_LEVENBERG = %d, SC_MORE = %d };\n",
         (int)lsqamd::LMS_CHI2, (int)lsqamd::LMS_MU, (int)lsqamd::LMS_NU, (int)lsqamd::LMS_DELTA, (int)lsqamd::LMS_VG, (int)lsqamd::LMS_DV2, (int)lsqamd::LMS_VFINITE, (int)lsqamd::LMS_RHO,
         (int)lsqamd::LMS_CHI2_TRIAL, (int)lsqamd::LMS_ACCEPT, (int)lsqamd::LMS_SOLVED, (int)lsqamd::LMS_INFO, (int)lsqamd::LMS_PIVMIN, (int)lsqamd::LMS_SEQ, (int)lsqamd::LMS_HOSTPTR,
         (int)LSQAMD_SCALE_LEVENBERG, (int)LSQAMD_SCALE_MORE);
+    // wave sum without LDS round trips: four DPP steps inside each row of 16 lanes (every lane of a row ends up with the
+    // row's total), then the four row totals through scalar registers
+    o.s += "static __device__ __forceinline__ double lm_rl(double v, int lane) {\n"
+           "  union { double d; int i[2]; } u;\n  u.d = v;\n  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);\n"
+           "  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);\n  return u.d;\n}\n"
+           "template <int CTRL> static __device__ __forceinline__ double lm_dpp(double v) {\n"
+           "  union { double d; int i[2]; } u;\n  u.d = v;\n  u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, false);\n"
+           "  u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, false);\n  return u.d;\n}\n"
+           "static __device__ __forceinline__ double lm_rowsum(double v) {\n"
+           "  v += lm_dpp<0xB1>(v);      // quad_perm [1,0,3,2]\n  v += lm_dpp<0x4E>(v);      // quad_perm [2,3,0,1]\n"
+           "  v += lm_dpp<0x141>(v);     // row_half_mirror\n  v += lm_dpp<0x140>(v);     // row_mirror\n  return v;\n}\n"
+           "static __device__ __forceinline__ double lm_wsum(double v) {\n"
+           "  v = lm_rowsum(v);\n  return (lm_rl(v, 0) + lm_rl(v, 16)) + (lm_rl(v, 32) + lm_rl(v, 48));\n}\n";
     const char *decl = strstr(kLmDriver, "struct LmArgs {");
     const char *decl_end = strstr(decl, "};");
     o.s.append(decl, (size_t)(decl_end - decl) + 2);
@@ -1103,15 +1163,21 @@ std::string generate(const Plan &pl) {
       }
       o.s += "    nC += rr * rr;\n  }\n";
       if (nrm) {
+        // all the wave sums first, as straight-line code (independent butterflies the scheduler interleaves: with a store under
+        // `if (lane == 0)` after each, every one of them waited out its six cross-lane round trips alone), then the stores
         int qq = 0;
         for (int i = 0; i < P; ++i)
-          for (int j = i; j < P; ++j) { o.f("  { const double t = wsum(nA%d_%d); if (lane == 0) red[wave * LNQ + %d] = t; }\n", i, j, qq); ++qq; }
-        for (int i = 0; i < P; ++i) { o.f("  { const double t = wsum(nG%d); if (lane == 0) red[wave * LNQ + %d] = t; }\n", i, qq); ++qq; }
-        o.f("  { const double t = wsum(nC); if (lane == 0) red[wave * LNQ + %d] = t; }\n", qq);
-        o.s += "  __syncthreads();\n  if (threadIdx.x < LNQ) sq[threadIdx.x] = red[threadIdx.x] + red[LNQ + threadIdx.x] + "
-               "red[2 * LNQ + threadIdx.x] + red[3 * LNQ + threadIdx.x];\n  __syncthreads();\n}\n";
+          for (int j = i; j < P; ++j) { o.f("  const double t%d = lm_rowsum(nA%d_%d);\n", qq, i, j); ++qq; }
+        for (int i = 0; i < P; ++i) { o.f("  const double t%d = lm_rowsum(nG%d);\n", qq, i); ++qq; }
+        o.f("  const double t%d = lm_rowsum(nC);\n", qq);
+        // (every lane of a row of 16 holds the row's totals: its first lane files them, then thread q adds the 16 rows' q-th)
+        o.s += "  if ((lane & 15) == 0) {\n    double *r = red + (threadIdx.x >> 4) * LNQ;\n";
+        for (int q2 = 0; q2 <= qq; ++q2) o.f("    r[%d] = t%d;\n", q2, q2);
+        o.s += "  }\n";
+        o.s += "  __syncthreads();\n  if (threadIdx.x < LNQ) {\n    double t = red[threadIdx.x];\n#pragma unroll\n"
+               "    for (int r = 1; r < 16; ++r) t += red[r * LNQ + threadIdx.x];\n    sq[threadIdx.x] = t;\n  }\n  __syncthreads();\n}\n";
       } else {
-        o.s += "  { const double t = wsum(nC); if (lane == 0) red[wave] = t; }\n  __syncthreads();\n"
+        o.s += "  { const double t = lm_wsum(nC); if (lane == 0) red[wave] = t; }\n  __syncthreads();\n"
                "  const double tot = red[0] + red[1] + red[2] + red[3];\n  __syncthreads();\n  return tot;\n}\n";
       }
     }

@@ -48,7 +48,7 @@ def test_nist_models_compile_for_gfx950(lib, name):
     assert '__shared__ double red[4][%d];' % nq in nrm and 'nC += rr * rr;' in nrm
     assert nrm.count(' += dd') == nq - 1
     # ... and the whole-fit kernel over the same sums as functions of one workgroup
-    assert 'constexpr int LP = %d, LNA = %d, LNQ = %d;' % (d['nparam'], nq - d['nparam'] - 1, nq) in src
+    assert 'constexpr int LP = %d, LNA = %d, LNQ = %d,' % (d['nparam'], nq - d['nparam'] - 1, nq) in src
     lm = src[src.index('static __device__ void lm_nrm('):]
     assert lm.split('static __device__ double lm_res(')[0].count(' += dd') == nq - 1
     assert 'void lsqamd_jit_lm(LmArgs a)' in lm and 'lm_solve(sA, sG, sD, sp' in lm
