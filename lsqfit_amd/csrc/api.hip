@@ -17,6 +17,8 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -49,13 +51,99 @@ struct Carver {
 
 namespace lsqamd_host {
 
+// ---- process-wide recycling of pinned blocks and events (see fit_state.h) -------------------------------------------
+namespace {
+struct Recycler {
+  std::mutex mu;
+  std::multimap<std::pair<int, size_t>, void *> pinned;   // (device, size class) -> block
+  size_t pinned_bytes = 0;
+  std::multimap<int, hipEvent_t> events;
+};
+Recycler &recycler() {
+  static Recycler *r = new Recycler;    // never destroyed: no runtime calls from a static destructor at exit
+  return *r;
+}
+int current_device() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = -1; }
+  return d;
+}
+constexpr size_t PIN_CLASS = 4096, PIN_KEEP_MAX = 64 << 10, PIN_KEEP_TOTAL = 2 << 20;
+}  // namespace
+
+void *pinned_take(size_t bytes, size_t *granted) {
+  const size_t cls = (bytes + PIN_CLASS - 1) / PIN_CLASS * PIN_CLASS;
+  *granted = cls;
+  const int dev = current_device();
+  {
+    Recycler &r = recycler();
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto it = r.pinned.find({dev, cls});
+    if (it != r.pinned.end()) {
+      void *p = it->second;
+      r.pinned.erase(it);
+      r.pinned_bytes -= cls;
+      return p;
+    }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+
+void pinned_give(void *p, size_t granted) {
+  if (!p) return;
+  const int dev = current_device();
+  if (granted > 0 && granted <= PIN_KEEP_MAX && dev >= 0) {
+    Recycler &r = recycler();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.pinned_bytes + granted <= PIN_KEEP_TOTAL) {
+      r.pinned.insert({{dev, granted}, p});
+      r.pinned_bytes += granted;
+      return;
+    }
+  }
+  (void)hipHostFree(p);
+}
+
+hipEvent_t event_take() {
+  const int dev = current_device();
+  {
+    Recycler &r = recycler();
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto it = r.events.find(dev);
+    if (it != r.events.end()) {
+      hipEvent_t e = it->second;
+      r.events.erase(it);
+      return e;
+    }
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void event_give(hipEvent_t e) {
+  if (!e) return;
+  const int dev = current_device();
+  if (dev >= 0) {
+    Recycler &r = recycler();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.events.size() < 256) {
+      r.events.insert({dev, e});
+      return;
+    }
+  }
+  (void)hipEventDestroy(e);
+}
+
 hipEvent_t take_event(lsqamd_fit *f) {  // events are recycled: creating one costs ~10 us
   hipEvent_t e = nullptr;
   if (!f->event_pool.empty()) {
     e = f->event_pool.back();
     f->event_pool.pop_back();
   } else {
-    (void)hipEventCreate(&e);
+    e = event_take();
   }
   return e;
 }
@@ -1601,7 +1689,8 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.avmax = 0.75;
   {
     const size_t P1 = (size_t)f->P + 1;
-    if (hipHostMalloc((void **)&f->pin, sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 96), hipHostMallocDefault) != hipSuccess) {
+    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 96), &f->pin_bytes));
+    if (!f->pin) {
       delete f;
       return LSQAMD_ENOMEM;
     }

@@ -14,6 +14,12 @@
 namespace lsqamd_host {
 
 void comm_release(lsqamd_fit *f);                                  // comm.hip
+// process-wide recycling of what a handle needs from the runtime besides its workspace (api.hip): creating and releasing a
+// pinned block or an event costs tens to hundreds of microseconds (hipHostFree waits for the device) -- more than a small fit
+void *pinned_take(size_t bytes, size_t *granted);
+void pinned_give(void *p, size_t granted);
+hipEvent_t event_take();
+void event_give(hipEvent_t e);
 int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count);   // sums enqueued on f->st
 
 struct TimerSlot {
@@ -131,6 +137,7 @@ struct lsqamd_fit {
   double *pin_fit = nullptr;  // what the one-launch fit kernel hands back (jit.h FitArgs::host)
   bool used_one_launch = false;   // the last lsqamd_run was ONE launch (api.hip run_one_launch); lsqamd_debug_flags bit 5
   std::vector<hipEvent_t> event_pool;
+  size_t pin_bytes = 0;     // size class the pinned block came with (pinned_take)
 
   // timing
   bool timing = false;
@@ -159,8 +166,8 @@ struct lsqamd_fit {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
       }
-    for (hipEvent_t e : event_pool) (void)hipEventDestroy(e);
-    if (pin) (void)hipHostFree(pin);
+    for (hipEvent_t e : event_pool) lsqamd_host::event_give(e);
+    if (pin) lsqamd_host::pinned_give(pin, pin_bytes);
     lsqamd_host::comm_release(this);
   }
 };

@@ -21,6 +21,8 @@ from . import _lib
 from .models import MODEL_IDENTITY, MODEL_TAPE, Model
 from .whiten import Whitening
 
+_STREAMS = {}     # device index -> idle streams of closed problems (creating one costs tens of microseconds: a small fit's worth)
+
 _SCALERS = dict(more=0, levenberg=1, marquardt=2)
 _SOLVERS = dict(cholesky=0, qr=1, svd=1)                               # _gsl.pyx:646-653; svd -> the QR-grade route
 _ALGS = dict(lm=0, lmaccel=1, dogleg=2, ddogleg=3, subspace2D=4)      # _gsl.pyx:622-635
@@ -121,7 +123,8 @@ class DeviceProblem:
         # a stream of its own: the caller's current stream may be the legacy default stream, which cannot be
         # captured (the LM step of small problems is replayed from graphs); every entry point of the
         # library synchronises its stream before handing results back, so callers see no difference
-        self.stream = torch.cuda.Stream(device=self.device)
+        idle = _STREAMS.get(self.device.index)
+        self.stream = idle.pop() if idle else torch.cuda.Stream(device=self.device)
         # device-made whitening weights (block_arrays above: torch.cat on the caller's current stream)
         # are read by lsqamd_set_data on OUR stream: order the two
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
@@ -474,8 +477,12 @@ class DeviceProblem:
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
-            self.lib.lsqamd_destroy(self.h)
+            self.lib.lsqamd_destroy(self.h)               # (waits for the stream)
             self.h = None
+            idle = _STREAMS.setdefault(self.device.index, [])
+            if len(idle) < 8 and getattr(self, 'stream', None) is not None:
+                idle.append(self.stream)
+                self.stream = None
 
     def __del__(self):
         try:
