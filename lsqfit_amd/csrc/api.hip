@@ -1582,6 +1582,7 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
 // covariance + logdet at the current point: factor A (mu = 0), invert
 static int do_covariance_chol(lsqamd_fit *f);
 int do_covariance(lsqamd_fit *f) {
+  f->cov_host_valid = false;
   f->cov_inaccurate = false;
   f->cov_dropped = 0;
   const int rc = f->opt.solver == LSQAMD_SOLVER_QR ? do_covariance_qr(f) : do_covariance_chol(f);
@@ -1689,15 +1690,15 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.avmax = 0.75;
   {
     const size_t P1 = (size_t)f->P + 1;
-    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 96), &f->pin_bytes));
+    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 256), &f->pin_bytes));
     if (!f->pin) {
       delete f;
       return LSQAMD_ENOMEM;
     }
     f->pin_g = f->pin; f->pin_c = f->pin_g + P1; f->pin_v = f->pin_c + P1; f->pin_d = f->pin_v + P1;
     f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1; f->pin_lm = f->pin_s + 8;
-    f->pin_fit = f->pin_lm + LMS_COUNT;       // 96 doubles: what the one-launch fit kernel hands back (jit.h FitArgs::host)
-    static_assert(lsqamd_jit::FIT_HOST_DOUBLES <= 96, "pin_fit");
+    f->pin_fit = f->pin_lm + LMS_COUNT;       // 256 doubles: what the one-launch fit kernel hands back (jit.h FitArgs::host)
+    static_assert(lsqamd_jit::FIT_HOST_DOUBLES <= 256, "pin_fit");
   }
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
@@ -2158,6 +2159,8 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   const long long bits = zc_off ? 0 : (long long)(intptr_t)dlm;
   std::memcpy(&a.hostptr_bits, &bits, sizeof(double));
   a.host = static_cast<double *>(dfit);
+  // the covariance of the normal-equation route rides along (solver = qr factors the Jacobian itself: do_covariance_qr)
+  a.cov = f->cov; a.ldc = f->ldm; a.want_cov = f->opt.solver == LSQAMD_SOLVER_QR ? 0 : 1; a.pad_ = 0;
   HIPCHK(f, lsqamd_jit::launch_fit(k, f->st, a));
   {   // the kernel writes `reason` last, behind a system-scope fence: poll for it, then fall back to sleeping on the stream
     const auto t0 = std::chrono::steady_clock::now();
@@ -2204,6 +2207,14 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   f->prior_deferred = false;
   f->r_fresh = false;
   f->have_cov = false;
+  f->cov_host_valid = false;
+  if (a.want_cov && f->pin_fit[21] == 1.0) {     // (else: do_covariance, the caller's next step)
+    f->have_cov = true;
+    f->cov_host_valid = true;
+    f->cov_inaccurate = false;
+    f->cov_dropped = 0;
+    f->logdet = f->pin_fit[22];
+  }
   f->have_dense_A = false;
   f->initialised = true;
   *iter = (int)f->nit;
@@ -2221,6 +2232,7 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   } ev(f);
   (void)hipEventRecord(ev.a, f->st);
   f->used_one_launch = false;
+  f->cov_host_valid = false;
   int rc = 0;
   int iter = 0, info = 0, status = -2;
   bool early = false;
@@ -2257,7 +2269,7 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   } else {
     status = 0;
   }
-  rc = do_covariance(f);
+  rc = (f->used_one_launch && f->have_cov) ? 0 : do_covariance(f);
   if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
   (void)hipEventRecord(ev.b, f->st);
   (void)hipEventSynchronize(ev.b);
@@ -2476,6 +2488,10 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
   if (!f->have_cov) {
     const int rc = do_covariance(f);
     if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+  }
+  if (f->cov_host_valid) {       // the one-launch fit kernel mirrored it into pinned memory: no copy, no synchronisation
+    std::memcpy(out, f->pin_fit + 96, sizeof(double) * (size_t)(P * P));
+    return 0;
   }
   HIPCHK(f, hipMemcpy2DAsync(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P,
                              (size_t)P, hipMemcpyDeviceToHost, f->st));

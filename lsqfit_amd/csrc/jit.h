@@ -36,7 +36,7 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 // plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
 // argument block, member for member.
 constexpr int FIT_MAX_ROWS = 4096;
-constexpr int FIT_HOST_DOUBLES = 24 + 5 * (NRM_MAX_P + 1) + 5;   // (+ 5 cycle counters at [89, 94): developer diagnostics)
+constexpr int FIT_HOST_DOUBLES = 96 + NRM_MAX_P * NRM_MAX_P;   // ([89, 94): five cycle counters, developer diagnostics; [96, ..): the covariance)
 struct FitArgs {
   const double *x, *ymean, *wdiag; long long n_data;
   const double *p0;                      // start (may be device-visible host memory)
@@ -44,8 +44,10 @@ struct FitArgs {
   const double *prior_prec, *prior_mean; // prior_prec null: no prior
   int prior_dense, scaler, maxit, watch;
   double xtol, gtol, factor_up, factor_down, hostptr_bits;
+  double *cov; long long ldc; int want_cov, pad_;   // want_cov: (J^T J + prior)^-1 at the end point -> cov[i * ldc + j] and host[96 + i * P + j]
   double *host;                          // device-visible pinned block of FIT_HOST_DOUBLES: [0,16) record, [16] reason (written last:
-                                         // 1 done, 2 hand the fit to the general path), [17..20] nit nfev njev ntrial, [24..) x g D coln2 v
+                                         // 1 done, 2 hand the fit to the general path), [17..20] nit nfev njev ntrial, [21] 1 when the
+                                         // covariance was formed, [22] its log det(J^T J + prior), [24..) x g D coln2 v
 };
 bool has_fit_kernel(const Kernel *k);
 hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a);

@@ -609,6 +609,7 @@ struct LmArgs {
   const double *prior_prec, *prior_mean;
   int prior_dense, scaler, maxit, watch;
   double xtol, gtol, factor_up, factor_down, hostptr_bits;
+  double *cov; long long ldc; int want_cov, pad_;     // (A)^-1 at the end point: cov[i * ldc + j], when want_cov
   double *host;      // pinned mirror: [0, 16) the record, [16, 24) reason nit nfev njev ntrial chol_fail - -, then x g D coln2 v (LP + 1 each)
 };
 
@@ -726,6 +727,57 @@ static __device__ void lm_solve(const double *sA, const double *sG, const double
     ss[S_VFINITE] = nf == 0.0 ? 1.0 : 0.0;
     ss[S_PIVMIN] = (watch && !bad) ? pmin : 1.0;
   }
+}
+
+// (J^T J + prior)^-1 and its log det at the end point by wave 0: the elimination of lm_solve with the LP columns of the
+// identity as right-hand sides in lanes LP .. 2 LP - 1 (they are forward-substituted along the way), then one back
+// substitution per lane.  -> 0, or the failed pivot + 1 (the host then takes the general route, which knows what to do
+// with a rank-deficient matrix)
+static __device__ int lm_cov(const double *sA, double *cov, long long ldc, double *hcov, double *logdet) {
+  const int lane = threadIdx.x;
+  double m[LP], uinv[LP];
+  const int col = lane < LP ? lane : LP - 1;
+#pragma unroll
+  for (int i = 0; i < LP; ++i) {
+    const double av = sA[i * LP + col];
+    double v = (lane < LP && i <= lane) ? av : 0.0;
+    if (lane == LP + i) v = 1.0;
+    m[i] = v;
+  }
+  int fail = 0;
+  double ld = 0.0;
+#pragma unroll
+  for (int k = 0; k < LP; ++k) {
+    const double pk = lm_rl(m[k], k);
+    if (!(pk > 0.0) && fail == 0) fail = k + 1;
+    const double inv = lm_rsqrt(pk > 0.0 ? pk : 1.0);
+    uinv[k] = inv;
+    ld += log(pk > 0.0 ? pk : 1.0);
+    if (lane >= k) m[k] = (lane == k) ? pk * inv : m[k] * inv;
+#pragma unroll
+    for (int i = k + 1; i < LP; ++i) {
+      const double ui = lm_rl(m[k], i);
+      if (lane >= i) m[i] -= ui * m[k];
+    }
+  }
+  double v[LP];
+#pragma unroll
+  for (int k = LP - 1; k >= 0; --k) {
+    v[k] = m[k] * uinv[k];                 // (lanes LP ..: m holds this lane's forward-substituted right-hand side)
+#pragma unroll
+    for (int i = 0; i < k; ++i) m[i] -= lm_rl(m[i], k) * v[k];
+  }
+  if (fail == 0 && lane >= LP && lane < 2 * LP) {
+    const int c = lane - LP;               // column c of the inverse; the upper triangle is written, and mirrored
+#pragma unroll
+    for (int k = 0; k < LP; ++k)
+      if (k <= c) {
+        cov[k * ldc + c] = v[k]; cov[c * ldc + k] = v[k];
+        hcov[k * LP + c] = v[k]; hcov[c * LP + k] = v[k];
+      }
+  }
+  if (lane == 0) *logdet = ld;             // log det = sum of log pivots (U_kk^2 = pivot k)
+  return fail;
 }
 
 extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
@@ -894,6 +946,10 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
   }
   __syncthreads();
   if (tid < 16) { a.st[tid] = ss[tid]; h[tid] = ss[tid]; }
+  if (tid < 64 && reason == 1 && a.want_cov) {
+    const int bad = lm_cov(sA, a.cov, a.ldc, h + 96, h + 22);
+    if (tid == 0) h[21] = bad == 0 ? 1.0 : 0.0;
+  } else if (tid == 0) h[21] = 0.0;
   if (tid == 0) {
     h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial;
     // diagnostics: shader cycles in all / in the normal equations / in the solves / in the trial residuals, 100 MHz ticks in all
