@@ -1097,8 +1097,13 @@ int iterate_varpro(lsqamd_fit *f) {
 // the device
 int ensure_J(lsqamd_fit *f) {
   if (!f->J_stale) return 0;
-  ModelArgs m = model_args(f, f->p_dev);     // (the fused path runs for uncorrelated rows only: no whitening product to redo)
+  ModelArgs m = model_args(f, f->p_dev);
   HIPCHK(f, launch_jacobian_ex(f->st, m, f->J, f->Jraw, f->ld));
+  if (f->cfg.n_blocks > 0) {   // (the one-launch fit kernel takes correlated rows too: their whitening product is redone here)
+    int64_t fused = 0;
+    const int rc = whiten_jacobian(f, &fused, false);
+    if (rc) return rc;
+  }
   f->J_stale = false;
   return 0;
 }
@@ -2131,7 +2136,9 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   const lsqamd_jit::Kernel *k = static_cast<const lsqamd_jit::Kernel *>(f->jit);
   if (!lsqamd_jit::has_fit_kernel(k) || P > lsqamd_jit::NRM_MAX_P || f->N < 1 || f->N > lsqamd_jit::FIT_MAX_ROWS) return 0;
   if (f->opt.trs != LSQAMD_TRS_LM || !f->linear.empty() || getenv("LSQAMD_HOST_LM") || f->opt.maxit < 1) return 0;
-  if (f->comm || f->reduce || f->timing || !small_fuse(f) || !f->progs.empty() || f->cfg.n_blocks != 0 || f->have_param_rows) return 0;
+  if (f->comm || f->reduce || f->timing || !small_fuse(f) || !f->progs.empty() || f->have_param_rows) return 0;
+  // correlated rows: the workgroup whitens them itself (one row per thread, the raw rows in LDS) -- up to 256 rows in all
+  if (f->cfg.n_blocks != 0 && (f->N > lsqamd_jit::FIT_MAX_BLOCK_ROWS || f->cfg.n_blocks > 64)) return 0;
   if (f->cfg.has_prior && !f->adds_prior) return 0;
   int rc = ready(f);
   if (rc) return rc;
@@ -2148,6 +2155,9 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   std::atomic_thread_fence(std::memory_order_release);
   lsqamd_jit::FitArgs a;
   a.x = f->x; a.ymean = f->ymean; a.wdiag = f->wdiag; a.n_data = f->N;
+  a.in_block = f->in_block; a.wt = f->wt;
+  a.blk_row0 = reinterpret_cast<const long long *>(f->blk_row0); a.blk_size = reinterpret_cast<const long long *>(f->blk_size);
+  a.blk_woff = reinterpret_cast<const long long *>(f->blk_woff); a.n_blocks = f->cfg.n_blocks;
   a.p0 = static_cast<const double *>(dx);
   a.p = f->p_dev; a.p_trial = f->p_trial; a.dscale = f->dscale; a.apk = f->redbuf; a.gvec = f->redbuf + f->npk;
   a.v_out = f->yv + P; a.coln2 = f->diag_dev; a.st = f->lmd;

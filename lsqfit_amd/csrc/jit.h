@@ -35,10 +35,12 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 // A whole small fit in one launch (same formulas as the normal-equation kernel: <= NRM_MAX_P parameters, uncorrelated rows):
 // plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
 // argument block, member for member.
-constexpr int FIT_MAX_ROWS = 4096;
+constexpr int FIT_MAX_ROWS = 4096, FIT_MAX_BLOCK_ROWS = 256;
 constexpr int FIT_HOST_DOUBLES = 96 + NRM_MAX_P * NRM_MAX_P;   // ([89, 94): five cycle counters, developer diagnostics; [96, ..): the covariance)
 struct FitArgs {
   const double *x, *ymean, *wdiag; long long n_data;
+  // correlated rows (n_blocks > 0: at most FIT_MAX_BLOCK_ROWS rows in all): the handle's block tables and W^T factors
+  const unsigned char *in_block; const double *wt; const long long *blk_row0, *blk_size, *blk_woff; long long n_blocks;
   const double *p0;                      // start (may be device-visible host memory)
   double *p, *p_trial, *dscale, *apk, *gvec, *v_out, *coln2, *st;
   const double *prior_prec, *prior_mean; // prior_prec null: no prior

@@ -604,6 +604,7 @@ void gen_group(const Plan &pl, Src &o, const Group &g, int gid, int mode, const 
 const char *kLmDriver = R"LSQLM(
 struct LmArgs {
   const double *x, *ymean, *wdiag; long long n_data;
+  const unsigned char *in_block; const double *wt; const long long *blk_row0, *blk_size, *blk_woff; long long n_blocks;
   const double *p0;
   double *p, *p_trial, *dscale, *apk, *gvec, *v_out, *coln2, *st;
   const double *prior_prec, *prior_mean;
@@ -617,9 +618,10 @@ static __device__ void m_diag(double *o, long long a0, long long a1, long long a
   o[0] = (double)a0; o[1] = (double)a1; o[2] = (double)a2; o[3] = (double)a3; o[4] = (double)a4;
 }
 
-static __device__ void lm_normal(const LmArgs &a, const double *sp, double *red, double *sq, double *sA, double *sG, double *sT, double *ss) {
+static __device__ void lm_normal(const LmArgs &a, const double *sp, double *red, double *sq, double *sA, double *sG, double *sT, double *ss,
+                                 double *srow, const int *sblk) {
   const int tid = threadIdx.x;
-  lm_nrm(a, sp, red, sq);
+  lm_nrm(a, sp, red, sq, srow, sblk);
   for (int e = tid; e < LP * LP; e += 256) {
     const int i = e / LP, j = e % LP;
     const int lo = i < j ? i : j, hi = i < j ? j : i;
@@ -784,7 +786,15 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
   __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[16 * LNQ], ss[16];
   __shared__ int si[4];
   __shared__ double sdata[LDATA];
+  __shared__ double srow[LROWS * (LP + 1)];
+  __shared__ int sblk[LROWS];
   const int tid = threadIdx.x;
+  if (a.n_blocks) {          // row -> its covariance block (or none); the host sends such fits here with at most LROWS rows
+    int b = -1;
+    for (int q = 0; q < (int)a.n_blocks; ++q)
+      if (tid >= a.blk_row0[q] && tid < a.blk_row0[q] + a.blk_size[q]) b = q;
+    sblk[tid] = b;
+  }
   // the data of a fit this small is read dozens of times: once from memory, then from LDS (the generated row loops read
   // through a.x / a.ymean / a.wdiag, which may as well point there)
   if (a.n_data * (LNX + 2) <= LDATA) {
@@ -805,7 +815,7 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
   __syncthreads();
   const long long c_begin = clock64(), w_begin = wall_clock64();
   long long c_nrm = 0, c_solve = 0, c_res = 0;
-  lm_normal(a, sp, red, sq, sA, sG, sT, ss);
+  lm_normal(a, sp, red, sq, sA, sG, sT, ss, srow, sblk);
   c_nrm += clock64() - c_begin;
   int reason = 0, nit = 0, nfev = 1, njev = 1, ntrial = 0;
   if (!(ss[S_CHI2] - ss[S_CHI2] == 0.0)) reason = 2;
@@ -834,7 +844,7 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
       c_solve += clock64() - c0;
       c0 = clock64();
       if (si[0] != 0 || ss[S_VFINITE] == 0.0 || ss[S_PIVMIN] < 1e-8) { reason = 2; break; }
-      double ct = lm_res(a, spt, red);
+      double ct = lm_res(a, spt, red, srow, sblk);
       c_res += clock64() - c0;
       if (a.prior_prec) {        // (every thread the same few terms, in the same order)
         double c = 0.0;
@@ -897,7 +907,7 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
     }
     if (tid < LP) sp[tid] = spt[tid];
     __syncthreads();
-    { const long long c0 = clock64(); lm_normal(a, sp, red, sq, sA, sG, sT, ss); c_nrm += clock64() - c0; }
+    { const long long c0 = clock64(); lm_normal(a, sp, red, sq, sA, sG, sT, ss, srow, sblk); c_nrm += clock64() - c0; }
     ++njev;
     if (!(ss[S_CHI2] - ss[S_CHI2] == 0.0)) { reason = 2; break; }
     if (tid < 64) {       // scaling update and gsl_multifit_nlinear_test, one lane per parameter
@@ -1150,7 +1160,12 @@ std::string generate(const Plan &pl) {
     o.f("  __syncthreads();\n  if (threadIdx.x < %d) a.out_w[(long long)blockIdx.x * %d + threadIdx.x] = "
         "red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];\n}\n", NQ, NQ);
     // ---- the same sums and the residual as functions of ONE workgroup, and the whole-fit kernel over them
-    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d, LNX = %d, LDATA = 5120;\n", P, NA, NQ, pl.n_x < 1 ? 1 : pl.n_x);
+    // LDS budget (64 KB of static LDS per workgroup): rows of a correlated fit (<= 256 of them, P + 1 values each), the 16 row
+    // totals of every sum, the prior, ~2 KB of small arrays -- the rest stages x, y, w
+    const int lds_fixed = 8 * (256 * (P + 1) + 16 * NQ + P * P + P + NQ + 8 * P + 64) + 4 * 256 + 1024;
+    int ldata = (64512 - lds_fixed) / 8;
+    if (ldata > 12288) ldata = 12288;
+    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d, LNX = %d, LDATA = %d, LROWS = 256;\n", P, NA, NQ, pl.n_x < 1 ? 1 : pl.n_x, ldata);
     o.f("enum { S_CHI2 = %d, S_MU = %d, S_NU = %d, S_DELTA = %d, S_VG = %d, S_DV2 = %d, S_VFINITE = %d, S_RHO = %d, S_CHI2_TRIAL = %d, "
         "S_ACCEPT = %d, S_SOLVED = %d, S_INFO = %d, S_PIVMIN = %d, S_SEQ = %d, S_HOSTPTR = %d, SC_LEVENBERG = %d, SC_MORE = %d };\n",
         (int)lsqamd::LMS_CHI2, (int)lsqamd::LMS_MU, (int)lsqamd::LMS_NU, (int)lsqamd::LMS_DELTA, (int)lsqamd::LMS_VG, (int)lsqamd::LMS_DV2, (int)lsqamd::LMS_VFINITE, (int)lsqamd::LMS_RHO,
@@ -1173,10 +1188,21 @@ std::string generate(const Plan &pl) {
     const char *decl_end = strstr(decl, "};");
     o.s.append(decl, (size_t)(decl_end - decl) + 2);
     o.s += "\n";
+    // correlated rows (a.n_blocks > 0, at most LROWS rows, one per thread): row m of block b comes out as
+    // sum_k Wt_b[k][m] raw[row0_b + k] -- what block_whiten_vec_kernel and the whitening GEMM compute -- from the raw rows
+    // the workgroup has just filed in LDS; rows outside blocks pass through (they were weighted when they were formed)
+    o.s += "template <int NC> static __device__ __forceinline__ void lm_whiten_row(const LmArgs &a, const double *srow, const int *sblk, int row, double *o) {\n"
+           "  const int b = sblk[row];\n"
+           "  if (b < 0) {\n#pragma unroll\n    for (int c = 0; c < NC; ++c) o[c] = srow[row * NC + c];\n    return;\n  }\n"
+           "  const int B = (int)a.blk_size[b], r0 = (int)a.blk_row0[b], m = row - r0;\n"
+           "  const double *W = a.wt + a.blk_woff[b] + m;\n"
+           "#pragma unroll\n  for (int c = 0; c < NC; ++c) o[c] = 0.0;\n"
+           "  for (int k = 0; k < B; ++k) {\n    const double wv = W[(long long)k * B];\n    const double *sr = srow + (r0 + k) * NC;\n"
+           "#pragma unroll\n    for (int c = 0; c < NC; ++c) o[c] = __builtin_fma(wv, sr[c], o[c]);\n  }\n}\n";
     for (int fn = 0; fn < 2; ++fn) {
       const bool nrm = fn == 0;
-      if (nrm) o.s += "static __device__ void lm_nrm(const LmArgs &a, const double *sp, double *red, double *sq) {\n";
-      else o.s += "static __device__ double lm_res(const LmArgs &a, const double *sp, double *red) {\n";
+      if (nrm) o.s += "static __device__ void lm_nrm(const LmArgs &a, const double *sp, double *red, double *sq, double *srow, const int *sblk) {\n";
+      else o.s += "static __device__ double lm_res(const LmArgs &a, const double *sp, double *red, double *srow, const int *sblk) {\n";
       o.s += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
       if (nrm) {
         for (int i = 0; i < P; ++i)
@@ -1187,7 +1213,7 @@ std::string generate(const Plan &pl) {
       o.s += "  for (long long row = threadIdx.x; row < a.n_data; row += 256) {\n";
       for (int i = 0; i < pl.n_x; ++i)
         if (xused[(size_t)i]) o.f("    const double x%d = a.x[row * %d + %d];\n", i, pl.n_x, i);
-      o.s += "    const double w = a.wdiag[row];\n";
+      o.s += "    const double w = (a.n_blocks && a.in_block[row]) ? 1.0 : a.wdiag[row];\n";
       if (nrm)
         for (int j = 0; j < nout; ++j) o.f("    double oacc%d = 0.0;\n", j);
       {
@@ -1213,11 +1239,24 @@ std::string generate(const Plan &pl) {
           if (slot[(size_t)i] >= 0) o.f("    const double dd%d = w * oacc%d;\n", i, slot[(size_t)i]);
           else o.f("    const double dd%d = 0.0;\n", i);
         }
+        o.s += "    if (!a.n_blocks) {\n";
         for (int i = 0; i < P; ++i)
-          for (int j = i; j < P; ++j) o.f("    nA%d_%d += dd%d * dd%d;\n", i, j, i, j);
-        for (int i = 0; i < P; ++i) o.f("    nG%d += dd%d * rr;\n", i, i);
+          for (int j = i; j < P; ++j) o.f("      nA%d_%d += dd%d * dd%d;\n", i, j, i, j);
+        for (int i = 0; i < P; ++i) o.f("      nG%d += dd%d * rr;\n", i, i);
+        o.s += "      nC += rr * rr;\n    } else {\n      double *sr = srow + row * (LP + 1);\n";
+        for (int i = 0; i < P; ++i) o.f("      sr[%d] = dd%d;\n", i, i);
+        o.s += "      sr[LP] = rr;\n    }\n  }\n";
+        o.s += "  if (a.n_blocks) {\n    __syncthreads();\n    if (threadIdx.x < a.n_data) {\n      double o[LP + 1];\n"
+               "      lm_whiten_row<LP + 1>(a, srow, sblk, threadIdx.x, o);\n";
+        for (int i = 0; i < P; ++i)
+          for (int j = i; j < P; ++j) o.f("      nA%d_%d += o[%d] * o[%d];\n", i, j, i, j);
+        for (int i = 0; i < P; ++i) o.f("      nG%d += o[%d] * o[LP];\n", i, i);
+        o.s += "      nC += o[LP] * o[LP];\n    }\n  }\n";
+      } else {
+        o.s += "    if (!a.n_blocks) nC += rr * rr;\n    else srow[row] = rr;\n  }\n";
+        o.s += "  if (a.n_blocks) {\n    __syncthreads();\n    if (threadIdx.x < a.n_data) {\n      double o[1];\n"
+               "      lm_whiten_row<1>(a, srow, sblk, threadIdx.x, o);\n      nC += o[0] * o[0];\n    }\n  }\n";
       }
-      o.s += "    nC += rr * rr;\n  }\n";
       if (nrm) {
         // all the wave sums first, as straight-line code (independent butterflies the scheduler interleaves: with a store under
         // `if (lane == 0)` after each, every one of them waited out its six cross-lane round trips alone), then the stores

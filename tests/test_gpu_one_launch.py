@@ -129,3 +129,59 @@ def test_irregular_fits_fall_back(amd, monkeypatch):
     big = amd.nonlinear_fit(data=(xx, np.exp(-0.5 * xx) + 0.01 * rng.standard_normal(5000), np.full(5000, 0.01)),
                             model=amd.expr('a*exp(-b*x)', ['a', 'b']), p0=[1.0, 1.0])
     assert not flags(big) & ONE and big.error is None
+
+
+def correlated(N, seed, nblocks, rho=0.6):
+    """A decaying curve with correlated errors: `nblocks` dense covariance blocks over the first rows, the rest uncorrelated."""
+    rng = np.random.default_rng(seed)
+    x = np.linspace(0.1, 4.0, N)
+    pt = np.array([2.0, 0.9, 0.5, 0.25])
+    f = pt[0] * np.exp(-pt[1] * x) + pt[2] * np.exp(-pt[3] * x)
+    sd = 0.01 * (1.0 + x)
+    bs = (N * 3 // 4) // nblocks
+    blocks, cov = [], np.diag(sd ** 2)
+    for b in range(nblocks):
+        r0 = b * bs
+        idx = np.arange(r0, r0 + bs)
+        c = np.outer(sd[idx], sd[idx]) * rho ** np.abs(np.subtract.outer(idx, idx))
+        blocks.append((r0, c))
+        cov[np.ix_(idx, idx)] = c
+    y = f + np.linalg.cholesky(cov) @ rng.standard_normal(N)
+    return x, y, dict(sdev=sd, blocks=blocks), pt
+
+
+@pytest.mark.parametrize('N,nblocks', [(40, 1), (96, 3), (256, 2), (17, 1)])
+@pytest.mark.parametrize('solver', ['cholesky', 'qr'])
+def test_correlated_data_is_whitened_inside_the_kernel(amd, N, nblocks, solver, monkeypatch):
+    """The everyday lsqfit shape: a few dozen correlated points, a handful of parameters.  The workgroup files the raw rows
+    in LDS and every thread forms its whitened row from them (W^T from the handle's whitening, as the general path's
+    whitening product does)."""
+    x, y, yerr, pt = correlated(N, seed=N + nblocks, nblocks=nblocks)
+    model = amd.expr('a*exp(-b*x) + c*exp(-d*x)', ['a', 'b', 'c', 'd'])
+    kw = dict(data=(x, y, yerr), model=model, prior=(pt, np.array([1.0, 0.5, 0.5, 0.2])), p0=pt * 1.1, solver=solver)
+    one, f1, gen = both(amd, monkeypatch, **kw)
+    assert f1 & ONE, 'the fit did not take the one-launch route'
+    agree(one, gen)
+    assert one.dof == gen.dof and one.Q == pytest.approx(gen.Q, rel=1e-7, abs=1e-12)
+    assert np.allclose(one.J, gen.J, rtol=1e-6, atol=1e-8 * np.max(np.abs(gen.J)))          # (ensure_J: whitened rows)
+    assert np.allclose(one.residuals, gen.residuals, rtol=1e-6, atol=1e-8)
+
+
+def test_correlated_data_with_a_binding_svdcut(amd, monkeypatch):
+    """A nearly singular block: the svdcut floor binds, the block is whitened through its eigen-modes (W^T with fewer
+    modes than rows) -- the kernel reads the same factor."""
+    rng = np.random.default_rng(11)
+    N = 24
+    x = np.linspace(0.2, 3.0, N)
+    pt = np.array([1.5, 0.8])
+    sd = np.full(N, 0.02)
+    u = rng.standard_normal((N, 3))
+    cov = 1e-4 * (u @ u.T) + np.diag(sd ** 2) * 1e-9            # rank 3 + a sliver
+    y = pt[0] * np.exp(-pt[1] * x) + np.linalg.cholesky(cov + 1e-12 * np.eye(N)) @ rng.standard_normal(N)
+    model = amd.expr('a*exp(-b*x)', ['a', 'b'])
+    kw = dict(data=(x, y, dict(sdev=np.sqrt(np.diag(cov)), blocks=[(0, cov)])), model=model, prior=(pt, np.array([1.0, 1.0])),
+              svdcut=1e-3)
+    one, f1, gen = both(amd, monkeypatch, **kw)
+    assert f1 & ONE and one.svdn == gen.svdn and one.svdn > 0
+    agree(one, gen)
+    assert one.dof == gen.dof
