@@ -1197,7 +1197,8 @@ std::string generate(const Plan &pl) {
            "  const int B = (int)a.blk_size[b], r0 = (int)a.blk_row0[b], m = row - r0;\n"
            "  const double *W = a.wt + a.blk_woff[b] + m;\n"
            "#pragma unroll\n  for (int c = 0; c < NC; ++c) o[c] = 0.0;\n"
-           "  for (int k = 0; k < B; ++k) {\n    const double wv = W[(long long)k * B];\n    const double *sr = srow + (r0 + k) * NC;\n"
+           "#pragma unroll 8\n  for (int k = 0; k < B; ++k) {      // (eight W^T rows requested before the first is used)\n"
+           "    const double wv = W[(long long)k * B];\n    const double *sr = srow + (r0 + k) * NC;\n"
            "#pragma unroll\n    for (int c = 0; c < NC; ++c) o[c] = __builtin_fma(wv, sr[c], o[c]);\n  }\n}\n";
     for (int fn = 0; fn < 2; ++fn) {
       const bool nrm = fn == 0;

@@ -29,3 +29,26 @@ for name in ('misra1a', 'chwirut2', 'thurber', 'gauss1'):
     resident = (time.perf_counter() - t0) / 20
     print('%-10s N=%4d P=%d  nit %3d  whole fit %.2f ms (min %.2f)   on a resident problem %.2f ms   device run %.2f ms'
           % (name, pr['y'].size, pr['P'], fit.nit, 1e3 * np.median(ts), 1e3 * min(ts), 1e3 * resident, s.t_run_ms))
+
+# the everyday shape: a few dozen CORRELATED points (one dense covariance block), a handful of parameters
+rng = np.random.default_rng(7)
+for N in (48, 200):
+    xs = np.linspace(0.1, 4.0, N)
+    pt = np.array([2.0, 0.9, 0.5, 0.25])
+    sd = 0.01 * (1.0 + xs)
+    cov = np.outer(sd, sd) * 0.6 ** np.abs(np.subtract.outer(np.arange(N), np.arange(N)))
+    ys = pt[0] * np.exp(-pt[1] * xs) + pt[2] * np.exp(-pt[3] * xs) + np.linalg.cholesky(cov) @ rng.standard_normal(N)
+    kw = dict(data=(xs, ys, dict(sdev=sd, blocks=[(0, cov)])), model=amd.expr('a*exp(-b*x) + c*exp(-d*x)', ['a', 'b', 'c', 'd']),
+              prior=(pt, np.array([1.0, 0.5, 0.5, 0.2])), p0=pt * 1.1)
+    fit = amd.nonlinear_fit(**kw)
+    ts = []
+    for rep in range(20):
+        t0 = time.perf_counter()
+        fit = amd.nonlinear_fit(**kw)
+        ts.append(time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    for rep in range(20):
+        again = amd.nonlinear_fit(problem=fit.problem, **kw)
+    resident = (time.perf_counter() - t0) / 20
+    print('%-10s N=%4d P=4  nit %3d  whole fit %.2f ms (min %.2f)   on a resident problem %.2f ms   device run %.2f ms'
+          % ('corr-block', N, fit.nit, 1e3 * np.median(ts), 1e3 * min(ts), 1e3 * resident, fit.fitter_results.summary.t_run_ms))
