@@ -417,6 +417,7 @@ int lsqamdb_run(lsqamdb_fits *fits, const double *p0, lsqamd_summary *summaries,
 int lsqamdb_get_x(lsqamdb_fits *fits, double *out, size_t cap);                         /* B*P */
 int lsqamdb_covariance(lsqamdb_fits *fits, double *logdet_jtj_out, size_t cap);         /* B */
 int lsqamdb_get_cov(lsqamdb_fits *fits, int32_t fit, double *out, size_t cap);          /* P*P */
+int lsqamdb_get_cov_all(lsqamdb_fits *fits, double *out, size_t cap);                    /* n_fits*P*P, one copy */
 int32_t lsqamdb_rounds(const lsqamdb_fits *fits);
 
 /* ---- measurement ------------------------------------------------------------ */

@@ -120,6 +120,7 @@ PROTOTYPES = {
     'lsqamdb_get_x': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamdb_covariance': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamdb_get_cov': (C.c_int, [_vp, C.c_int32, _dp, C.c_size_t]),
+    'lsqamdb_get_cov_all': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamdb_rounds': (C.c_int32, [_vp]),
     'lsqamd_timing_enable': (C.c_int, [_vp, C.c_int32]),
     'lsqamd_timing_get': (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(C.c_int64)]),

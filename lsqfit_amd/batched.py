@@ -182,13 +182,19 @@ class BatchedFits:
                 out['logGBF'] = 0.5 * (-ld - logdet_c - out['chi2'] - dof * np.log(2. * np.pi))
             else:
                 out['logGBF'] = None              # src/lsqfit/__init__.py:711-712
-            out['psdev'] = np.sqrt(np.array([np.diag(self.cov(b)) for b in range(B)])) if B * P * P <= 1 << 26 else None
+            out['psdev'] = np.sqrt(np.einsum('bii->bi', self.cov_all())) if B * P * P <= 1 << 26 else None
         return out
 
     def cov(self, b):
         out = np.empty(self.P * self.P)
         self._check(self.lib.lsqamdb_get_cov(self.h, int(b), _lib.dptr(out), out.size), 'get_cov')
         return out.reshape(self.P, self.P)
+
+    def cov_all(self):
+        """-> [B, P, P]: every fit's covariance in one copy."""
+        out = np.empty(self.B * self.P * self.P)
+        self._check(self.lib.lsqamdb_get_cov_all(self.h, _lib.dptr(out), out.size), 'get_cov_all')
+        return out.reshape(self.B, self.P, self.P)
 
     def close(self):
         if getattr(self, 'h', None):

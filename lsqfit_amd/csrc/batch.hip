@@ -523,6 +523,7 @@ struct lsqamdb_fits {
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   int32_t graph_used = 0, rounds = 0;
+  bool one_launch = false, have_cov_from_run = false;   // the last run was one launch (lsqamd_jit_lmb) / it formed the covariances too
 };
 
 namespace {
@@ -943,7 +944,64 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     BHIP(f, hipMemcpyAsync(f->s.active, ones.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, f->st));
     BHIP(f, hipStreamSynchronize(f->st));
   }
-  int rc = normal_all(f, f->s.active);
+  // Small fits (a compiled formula, <= 12 parameters, <= 4096 uncorrelated rows or <= 256 with covariance blocks): every
+  // fit of the batch is ONE workgroup of ONE launch (jit.hip lsqamd_jit_lmb -- the loop of the single-fit kernel, api.hip
+  // run_one_launch) instead of ~20 lockstep launches per round.  Any irregular fit sends the whole batch through the
+  // lockstep engine below.  LSQAMD_ONE_LAUNCH_FIT=0 disables.
+  f->one_launch = false;
+  {
+    const char *e = getenv("LSQAMD_ONE_LAUNCH_FIT");
+    const lsqamd_jit::Kernel *k = static_cast<const lsqamd_jit::Kernel *>(f->jit);
+    const bool rows_ok = f->cfg.n_blocks == 0 ? f->N <= lsqamd_jit::FIT_MAX_ROWS
+                                              : (f->N <= lsqamd_jit::FIT_MAX_BLOCK_ROWS && f->cfg.n_blocks <= 64);
+    if (!(e && e[0] == '0') && lsqamd_jit::has_batch_fit_kernel(k) && P <= lsqamd_jit::NRM_MAX_P && f->N >= 1 && rows_ok &&
+        f->opt.maxit >= 1 && f->opt.trs == LSQAMD_TRS_LM) {
+      const int64_t red_stride = f->npk + P + 1, w_stride = f->nblk * 128 * 128;
+      lsqamd_jit::FitArgs a;
+      a.x = f->x; a.ymean = f->ymean; a.wdiag = f->wdiag; a.n_data = f->N;
+      a.in_block = f->in_block; a.wt = f->wt;
+      a.blk_row0 = reinterpret_cast<const long long *>(f->blk_row0); a.blk_size = reinterpret_cast<const long long *>(f->blk_size);
+      a.blk_woff = reinterpret_cast<const long long *>(f->blk_woff); a.n_blocks = f->cfg.n_blocks;
+      a.p0 = f->px; a.p = f->px; a.p_trial = f->pxt; a.dscale = f->diag; a.apk = f->red; a.gvec = f->red + f->npk;
+      a.v_out = f->dx; a.coln2 = nullptr; a.st = nullptr;
+      a.prior_prec = f->cfg.has_prior ? f->pprec : nullptr;
+      a.prior_mean = f->cfg.has_prior ? f->pmean : nullptr;
+      a.prior_dense = f->cfg.prior_dense; a.scaler = f->opt.scaler; a.maxit = f->opt.maxit; a.watch = 0;
+      a.xtol = f->opt.xtol; a.gtol = f->opt.gtol; a.factor_up = f->opt.factor_up; a.factor_down = f->opt.factor_down;
+      a.hostptr_bits = 0.0;
+      a.cov = f->cov; a.ldc = f->ldm; a.want_cov = 1; a.pad_ = 0;
+      a.host = f->chol_work;                       // (free until a covariance is asked for: 16384 doubles per fit)
+      lsqamd_jit::FitBatch bt;
+      bt.ymean_stride = f->ymean_stride; bt.prec_stride = f->cfg.prior_dense ? 0 : P; bt.tile_stride = red_stride;
+      bt.cov_stride = P * f->ldm; bt.scratch_stride = w_stride;
+      bt.logdet = f->logdet; bt.mu = f->s.mu; bt.chi2 = f->s.chi2;
+      bt.nit = f->s.nit; bt.info = f->s.info; bt.status = f->s.status; bt.nfev = f->s.nfev; bt.njev = f->s.njev;
+      bt.active = f->s.active; bt.reason = f->s.bad;
+      BHIP(f, lsqamd_jit::launch_fit_batch(k, f->st, a, bt, (int)B));
+      std::vector<int32_t> reason((size_t)B, 0);
+      BHIP(f, hipMemcpyAsync(reason.data(), f->s.bad, sizeof(int32_t) * B, hipMemcpyDeviceToHost, f->st));
+      BHIP(f, hipStreamSynchronize(f->st));
+      bool all_done = true, all_cov = true;
+      for (int64_t b = 0; b < B; ++b) {
+        all_done = all_done && (reason[(size_t)b] == 1 || reason[(size_t)b] == 3);
+        all_cov = all_cov && reason[(size_t)b] == 1;
+      }
+      if (all_done) {
+        f->one_launch = true;
+        f->rounds = 1;
+        f->graph_used = 0;
+        f->have_cov_from_run = all_cov;
+      } else {   // the lockstep engine from the start: p0 again, every fit active
+        BHIP(f, hipMemcpyAsync(f->px, p0, sizeof(double) * B * P, hipMemcpyHostToDevice, f->st));
+        std::vector<int32_t> ones((size_t)B, 1);
+        BHIP(f, hipMemcpyAsync(f->s.active, ones.data(), sizeof(int32_t) * B, hipMemcpyHostToDevice, f->st));
+        BHIP(f, hipStreamSynchronize(f->st));
+      }
+    }
+  }
+  int rc = 0;
+  if (!f->one_launch) {
+  rc = normal_all(f, f->s.active);
   if (rc) return rc;
   hipLaunchKernelGGL(b_init_kernel, dim3((unsigned)B), dim3(256), 0, f->st, P, f->T, f->red, f->npk + P + 1,
                      f->red + f->npk, f->npk + P + 1, f->diag, f->opt.scaler, f->s);
@@ -989,6 +1047,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     BHIP(f, hipMemcpyAsync(&n_active, f->s.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
     BHIP(f, hipStreamSynchronize(f->st));
   }
+  }   // (!one_launch)
   (void)hipEventRecord(e1, f->st);
   (void)hipEventSynchronize(e1);
   float ms = 0.f;
@@ -996,7 +1055,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
   f->ran = true;
-  f->have_cov = false;
+  f->have_cov = f->one_launch && f->have_cov_from_run;     // (the one-launch kernel leaves covariances and log dets behind)
   if (summaries) {
     std::vector<double> mu((size_t)B), chi2((size_t)B);
     std::vector<int32_t> nit((size_t)B), info((size_t)B), status((size_t)B), nfev((size_t)B), njev((size_t)B);
@@ -1034,6 +1093,13 @@ int lsqamdb_get_x(lsqamdb_fits *f, double *out, size_t cap) {
 int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) {
   if (!f) return LSQAMD_EINVAL;
   if (!f->ran) BFAIL(f, LSQAMD_EINVAL, "covariance: run first");
+  if (f->have_cov && f->one_launch) {     // formed by the fit kernel itself
+    if (logdet_out) {
+      if (cap < (size_t)f->B) BFAIL(f, LSQAMD_ECAPACITY, "covariance: need %lld", (long long)f->B);
+      BHIP(f, hipMemcpy(logdet_out, f->logdet, sizeof(double) * f->B, hipMemcpyDeviceToHost));
+    }
+    return 0;
+  }
   const int64_t P = f->P, B = f->B, m_stride = P * f->ldm, w_stride = f->nblk * 128 * 128;
   const int64_t red_stride = f->npk + P + 1;
   const unsigned ntile = (unsigned)(f->T * (f->T + 1) / 2);
@@ -1074,6 +1140,20 @@ int lsqamdb_get_cov(lsqamdb_fits *f, int32_t fit, double *out, size_t cap) {
   }
   BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov + (int64_t)fit * P * f->ldm, sizeof(double) * f->ldm,
                       sizeof(double) * P, (size_t)P, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lsqamdb_get_cov_all(lsqamdb_fits *f, double *out, size_t cap) {
+  if (!f || !out) return LSQAMD_EINVAL;
+  const int64_t P = f->P, B = f->B;
+  if (cap < (size_t)(B * P * P)) BFAIL(f, LSQAMD_ECAPACITY, "get_cov_all: need %lld", (long long)(B * P * P));
+  if (!f->have_cov) {
+    const int rc = lsqamdb_covariance(f, nullptr, 0);
+    if (rc) return rc;
+  }
+  // fit b's rows follow fit b - 1's in f->cov (P rows of ldm doubles each): one strided copy of B * P rows
+  BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P, (size_t)(B * P),
+                      hipMemcpyDeviceToHost));
   return 0;
 }
 

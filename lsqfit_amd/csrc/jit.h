@@ -53,5 +53,14 @@ struct FitArgs {
 };
 bool has_fit_kernel(const Kernel *k);
 hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a);
+// ... and many same-shape fits, one workgroup each (the kernel's second argument block, member for member; the pointers
+// of FitArgs are those of fit 0, `host` is DEVICE scratch of scratch_stride >= 272 + P doubles per fit)
+struct FitBatch {
+  long long ymean_stride, prec_stride, tile_stride, cov_stride, scratch_stride;
+  double *logdet, *mu, *chi2;
+  int *nit, *info, *status, *nfev, *njev, *active, *reason;   // reason: 1 done + covariance, 3 done, 2 irregular
+};
+bool has_batch_fit_kernel(const Kernel *k);
+hipError_t launch_fit_batch(const Kernel *k, hipStream_t st, const FitArgs &a, const FitBatch &b, int n_fits);
 
 }  // namespace lsqamd_jit

@@ -782,7 +782,7 @@ static __device__ int lm_cov(const double *sA, double *cov, long long ldc, doubl
   return fail;
 }
 
-extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
+static __device__ __forceinline__ void lm_fit(LmArgs a) {
   __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[16 * LNQ], ss[16];
   __shared__ int si[4];
   __shared__ double sdata[LDATA];
@@ -969,6 +969,44 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) {
   __syncthreads();
   if (tid == 0) { h[16] = (double)reason; __threadfence_system(); }
 }
+
+extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) { lm_fit(a); }
+
+// Many same-shape fits (bootstrap / simulated copies, a sweep of priors): one workgroup per fit, the same loop.  Per-fit
+// inputs and outputs are strided; a fit's record (the block the single-fit kernel mirrors to the host) goes to device
+// scratch and its scalars into the batched engine's per-fit arrays.  reason: 1 done (covariance formed), 3 done (not
+// formed), 2 irregular -- the host then runs the lockstep engine.
+struct LmBatch {
+  long long ymean_stride, prec_stride, tile_stride, cov_stride, scratch_stride;
+  double *logdet, *mu, *chi2;
+  int *nit, *info, *status, *nfev, *njev, *active, *reason;
+};
+
+extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lmb(LmArgs a, LmBatch b) {
+  const long long fit = blockIdx.x;
+  a.ymean += fit * b.ymean_stride;
+  a.p0 += fit * LP; a.p += fit * LP; a.p_trial += fit * LP; a.dscale += fit * LP; a.v_out += fit * LP;
+  a.apk += fit * b.tile_stride; a.gvec += fit * b.tile_stride;
+  if (a.prior_prec) { a.prior_mean += fit * LP; a.prior_prec += fit * b.prec_stride; }
+  a.cov += fit * b.cov_stride;
+  a.host += fit * b.scratch_stride;          // [0, 256) the record block, [256, 272) the LM record, [272, ..) column norms
+  a.st = a.host + 256;
+  a.coln2 = a.host + 272;
+  lm_fit(a);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double *h = a.host;
+    const int reason = (int)h[16];
+    b.mu[fit] = h[S_MU]; b.chi2[fit] = h[S_CHI2];
+    b.nit[fit] = (int)h[17]; b.nfev[fit] = (int)h[18]; b.njev[fit] = (int)h[19];
+    b.info[fit] = (int)h[S_INFO];
+    b.status[fit] = h[S_INFO] != 0.0 ? 0 : -2;
+    b.logdet[fit] = h[22];
+    b.active[fit] = 0;
+    b.reason[fit] = reason == 1 ? (h[21] == 1.0 ? 1 : 3) : 2;
+  }
+}
+
 )LSQLM";
 
 std::string generate(const Plan &pl) {
@@ -1358,7 +1396,7 @@ bool compile_source(const std::string &src, std::vector<char> &code, std::string
 
 struct Loaded {
   hipModule_t mod = nullptr;
-  hipFunction_t res = nullptr, jac = nullptr, nrm = nullptr, lm = nullptr;
+  hipFunction_t res = nullptr, jac = nullptr, nrm = nullptr, lm = nullptr, lmb = nullptr;
   bool wave_per_row = false;
   int n_param = 0;
   bool nrm_ok = false;          // few parameters, no wide sums: a third kernel forms J^T J, J^T f and chi2 without writing J
@@ -1432,6 +1470,10 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
     (void)hipGetLastError();
     k.l.lm = nullptr;
   }
+  if (has_nrm && hipModuleGetFunction(&k.l.lmb, k.l.mod, "lsqamd_jit_lmb") != hipSuccess) {
+    (void)hipGetLastError();
+    k.l.lmb = nullptr;
+  }
   const Kernel *kp = &kernels.emplace(key, k).first->second;
   if (by_tape.size() < 4096) by_tape[tkey] = kp;
   return kp;
@@ -1468,6 +1510,15 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 }
 
 bool has_fit_kernel(const Kernel *k) { return k && k->l.lm; }
+bool has_batch_fit_kernel(const Kernel *k) { return k && k->l.lmb; }
+
+hipError_t launch_fit_batch(const Kernel *k, hipStream_t st, const FitArgs &a, const FitBatch &b, int n_fits) {
+  if (!k || !k->l.lmb || n_fits < 1) return hipErrorInvalidValue;
+  struct { FitArgs a; FitBatch b; } args = {a, b};
+  size_t sz = sizeof(args);
+  void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(k->l.lmb, (unsigned)n_fits, 1, 1, 256, 1, 1, 0, st, nullptr, cfg);
+}
 
 hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a) {
   if (!k || !k->l.lm) return hipErrorInvalidValue;

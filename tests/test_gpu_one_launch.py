@@ -185,3 +185,51 @@ def test_correlated_data_with_a_binding_svdcut(amd, monkeypatch):
     assert f1 & ONE and one.svdn == gen.svdn and one.svdn > 0
     agree(one, gen)
     assert one.dof == gen.dof
+
+
+def test_bootstrap_copies_are_one_launch_too(amd, monkeypatch):
+    """Simulated / bootstrap copies of a small fit: one workgroup per copy in ONE launch (lsqamd_jit_lmb) instead of the
+    lockstep engine's rounds; both engines must agree copy by copy, and a copy equals the single fit of its data."""
+    pr = nist_problem('gauss1', NIST)
+    model = amd.expr(pr['expr'], ['b%d' % (i + 1) for i in range(pr['P'])], pr['columns'][1:])
+    x = np.stack([pr['x'][c] for c in pr['columns'][1:]], axis=1)
+    kw = dict(model=model, prior=(pr['prior_mean'], pr['prior_sd']), p0=pr['p0'], tol=1e-8)
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    fit = amd.nonlinear_fit(data=(x, pr['y'], pr['ysd']), **kw)
+    one = fit.bootstrapped_fits(64, seed=3)
+    assert one['rounds'] == 1
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '0')
+    lock = fit.bootstrapped_fits(64, seed=3)
+    assert lock['rounds'] > 1
+    assert np.array_equal(one['ymeans'], lock['ymeans'])
+    assert np.max(np.abs(one['pmean'] - lock['pmean']) / lock['psdev']) < 1e-5
+    assert np.allclose(one['chi2'], lock['chi2'], rtol=1e-8) and np.allclose(one['psdev'], lock['psdev'], rtol=1e-5)
+    assert np.allclose(one['logGBF'], lock['logGBF'], rtol=1e-8, atol=1e-7)
+    assert np.all(np.abs(one['nit'] - lock['nit']) <= 1) and np.array_equal(one['stopping_criterion'], lock['stopping_criterion'])
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    for k in (0, 17, 63):
+        single = amd.nonlinear_fit(data=(x, one['ymeans'][k], pr['ysd']), model=model, prior=(one['prior_means'][k], pr['prior_sd']),
+                                   p0=fit.pmean, tol=1e-8)
+        assert single.nit == one['nit'][k] and np.array_equal(single.pmean, one['pmean'][k])      # (the same kernel body)
+        assert np.array_equal(single.psdev, one['psdev'][k]) and single.chi2 == one['chi2'][k]
+
+
+def test_batch_with_an_irregular_copy_takes_the_lockstep_engine(amd, monkeypatch):
+    """One copy whose start makes the damped matrix lose a pivot sends the whole batch through the lockstep engine."""
+    from lsqfit_amd import BatchedFits
+    x, y, sd, pt = curve(N=300, seed=21)
+    model = amd.expr('a*exp(-b*x) + c*cos(d*x) + 0*e', ['a', 'b', 'c', 'd', 'e'])
+    B = 8
+    pm = np.tile(np.append(pt, 0.0), (B, 1))
+    ps = np.tile(np.array([1.0, 1.0, 1.0, 1.0, 1.0]), (B, 1))
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    eng = BatchedFits(model, x, y, sd, pm, ps)
+    good = eng.run(p0=pm * 1.05)
+    assert good['rounds'] == 1 and np.all(good['stopping_criterion'] > 0)
+    p0 = pm * 1.05
+    p0[3] = np.nan                                  # a start that is not a number: chi2 is not finite at the first evaluation
+    bad = eng.run(p0=p0)
+    assert bad['rounds'] != 1 or not np.all(np.isfinite(bad['chi2']))
+    ok = [b for b in range(B) if b != 3]
+    assert np.allclose(bad['pmean'][ok], good['pmean'][ok], rtol=1e-6, atol=1e-9)
+    eng.close()
