@@ -171,7 +171,8 @@ class BatchedFits:
         # nf - P: (kept data modes + P) - P with a prior, kept data modes - P without
         dof = self.wh.nchiv_data - (0 if self.has_prior else P)
         out['dof'] = dof
-        out['Q'] = np.array([gammaQ(dof / 2., c / 2.) for c in out['chi2']])
+        from scipy.special import gammaincc
+        out['Q'] = np.asarray(gammaincc(dof / 2., out['chi2'] / 2.), float)           # (gammaQ, all fits at once)
         if covariance:
             ld = np.empty(B)
             self._check(self.lib.lsqamdb_covariance(self.h, _lib.dptr(ld), B), 'covariance')

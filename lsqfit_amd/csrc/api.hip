@@ -58,6 +58,7 @@ struct Recycler {
   std::multimap<std::pair<int, size_t>, void *> pinned;   // (device, size class) -> block
   size_t pinned_bytes = 0;
   std::multimap<int, hipEvent_t> events;
+  std::multimap<int, hipStream_t> streams;
 };
 Recycler &recycler() {
   static Recycler *r = new Recycler;    // never destroyed: no runtime calls from a static destructor at exit
@@ -135,6 +136,37 @@ void event_give(hipEvent_t e) {
     }
   }
   (void)hipEventDestroy(e);
+}
+
+hipStream_t stream_take() {
+  const int dev = current_device();
+  {
+    Recycler &r = recycler();
+    std::lock_guard<std::mutex> lk(r.mu);
+    auto it = r.streams.find(dev);
+    if (it != r.streams.end()) {
+      hipStream_t s = it->second;
+      r.streams.erase(it);
+      return s;
+    }
+  }
+  hipStream_t s = nullptr;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return s;
+}
+
+void stream_give(hipStream_t s) {
+  if (!s) return;
+  const int dev = current_device();
+  if (dev >= 0) {
+    Recycler &r = recycler();
+    std::lock_guard<std::mutex> lk(r.mu);
+    if (r.streams.size() < 16) {
+      r.streams.insert({dev, s});
+      return;
+    }
+  }
+  (void)hipStreamDestroy(s);
 }
 
 hipEvent_t take_event(lsqamd_fit *f) {  // events are recycled: creating one costs ~10 us

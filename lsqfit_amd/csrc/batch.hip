@@ -28,6 +28,13 @@
 #include "common.h"
 #include "jit.h"
 
+namespace lsqamd_host {   // process-wide recycling of streams and events (api.hip; see fit_state.h)
+hipEvent_t event_take();
+void event_give(hipEvent_t e);
+hipStream_t stream_take();
+void stream_give(hipStream_t s);
+}  // namespace lsqamd_host
+
 namespace lsqamd {
 
 constexpr int TBK = 128;  // packed tile edge (vecops.hip)
@@ -776,7 +783,8 @@ int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace
   if (carve_b(f, dev_workspace, true) > workspace_bytes) { delete f; return LSQAMD_ENOMEM; }
   carve_b(f, dev_workspace, false);
   // own (capturable) stream: the caller's may be the legacy default stream
-  if (hipStreamCreateWithFlags(&f->st, hipStreamNonBlocking) != hipSuccess) { delete f; return LSQAMD_EHIP; }
+  f->st = lsqamd_host::stream_take();
+  if (!f->st) { delete f; return LSQAMD_EHIP; }
   f->opt.xtol = 1e-8; f->opt.gtol = 1e-10; f->opt.ftol = 1e-10;
   f->opt.maxit = 1000; f->opt.scaler = LSQAMD_SCALE_MORE; f->opt.solver = LSQAMD_SOLVER_CHOLESKY;
   f->opt.factor_up = 3.0; f->opt.factor_down = 2.0; f->opt.trs = LSQAMD_TRS_LM; f->opt.avmax = 0.75;
@@ -785,7 +793,8 @@ int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace
   if (hipMemcpyAsync(f->syrk_map, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice, f->st) != hipSuccess ||
       hipMemsetAsync(f->M, 0, sizeof(double) * (size_t)(f->B * f->P * f->ldm), f->st) != hipSuccess ||
       hipStreamSynchronize(f->st) != hipSuccess) {
-    (void)hipStreamDestroy(f->st);
+    (void)hipStreamSynchronize(f->st);
+    lsqamd_host::stream_give(f->st);
     delete f;
     return LSQAMD_EHIP;
   }
@@ -798,7 +807,7 @@ int lsqamdb_destroy(lsqamdb_fits *f) {
   (void)hipStreamSynchronize(f->st);
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
   if (f->graph) (void)hipGraphDestroy(f->graph);
-  (void)hipStreamDestroy(f->st);
+  lsqamd_host::stream_give(f->st);       // (synchronised above)
   delete f;
   return 0;
 }
@@ -934,9 +943,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     BFAIL(f, LSQAMD_EINVAL, "run: inputs missing");
   const int64_t P = f->P, B = f->B;
   (void)hipStreamSynchronize(f->user_st);
-  hipEvent_t e0, e1;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
+  hipEvent_t e0 = lsqamd_host::event_take(), e1 = lsqamd_host::event_take();
   (void)hipEventRecord(e0, f->st);
   BHIP(f, hipMemcpyAsync(f->px, p0, sizeof(double) * B * P, hipMemcpyHostToDevice, f->st));
   {  // everything active for the initial evaluation
@@ -1052,8 +1059,8 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
   (void)hipEventSynchronize(e1);
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
+  lsqamd_host::event_give(e0);
+  lsqamd_host::event_give(e1);
   f->ran = true;
   f->have_cov = f->one_launch && f->have_cov_from_run;     // (the one-launch kernel leaves covariances and log dets behind)
   if (summaries) {

@@ -20,6 +20,8 @@ void *pinned_take(size_t bytes, size_t *granted);
 void pinned_give(void *p, size_t granted);
 hipEvent_t event_take();
 void event_give(hipEvent_t e);
+hipStream_t stream_take();          // a non-blocking stream (recycled ones are idle: their last owner synchronised them)
+void stream_give(hipStream_t s);
 int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count);   // sums enqueued on f->st
 
 struct TimerSlot {
