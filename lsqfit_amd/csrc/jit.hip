@@ -782,7 +782,7 @@ static __device__ int lm_cov(const double *sA, double *cov, long long ldc, doubl
   return fail;
 }
 
-static __device__ __forceinline__ void lm_fit(LmArgs a) {
+static __device__ __attribute__((noinline)) void lm_fit(LmArgs a) {      // (one body for both kernels: half the build time)
   __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[16 * LNQ], ss[16];
   __shared__ int si[4];
   __shared__ double sdata[LDATA];
