@@ -1727,15 +1727,15 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.avmax = 0.75;
   {
     const size_t P1 = (size_t)f->P + 1;
-    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 256), &f->pin_bytes));
+    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 1280), &f->pin_bytes));
     if (!f->pin) {
       delete f;
       return LSQAMD_ENOMEM;
     }
     f->pin_g = f->pin; f->pin_c = f->pin_g + P1; f->pin_v = f->pin_c + P1; f->pin_d = f->pin_v + P1;
     f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1; f->pin_lm = f->pin_s + 8;
-    f->pin_fit = f->pin_lm + LMS_COUNT;       // 256 doubles: what the one-launch fit kernel hands back (jit.h FitArgs::host)
-    static_assert(lsqamd_jit::FIT_HOST_DOUBLES <= 256, "pin_fit");
+    f->pin_fit = f->pin_lm + LMS_COUNT;       // 1280 doubles: what the one-launch fit kernel hands back (jit.h FitArgs::host)
+    static_assert(lsqamd_jit::FIT_HOST_DOUBLES <= 1280, "pin_fit");
   }
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
@@ -2166,11 +2166,12 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   if (e && e[0] == '0') return 0;
   const int64_t P = f->P;
   const lsqamd_jit::Kernel *k = static_cast<const lsqamd_jit::Kernel *>(f->jit);
-  if (!lsqamd_jit::has_fit_kernel(k) || P > lsqamd_jit::NRM_MAX_P || f->N < 1 || f->N > lsqamd_jit::FIT_MAX_ROWS) return 0;
+  if (!lsqamd_jit::has_fit_kernel(k) || P > lsqamd_jit::FIT_MAX_P || f->N < 1 ||
+      f->N > lsqamd_jit::fit_row_limit(k, f->cfg.n_blocks != 0)) return 0;
   if (f->opt.trs != LSQAMD_TRS_LM || !f->linear.empty() || getenv("LSQAMD_HOST_LM") || f->opt.maxit < 1) return 0;
   if (f->comm || f->reduce || f->timing || !small_fuse(f) || !f->progs.empty() || f->have_param_rows) return 0;
   // correlated rows: the workgroup whitens them itself (one row per thread, the raw rows in LDS) -- up to 256 rows in all
-  if (f->cfg.n_blocks != 0 && (f->N > lsqamd_jit::FIT_MAX_BLOCK_ROWS || f->cfg.n_blocks > 64)) return 0;
+  if (f->cfg.n_blocks > 64) return 0;
   if (f->cfg.has_prior && !f->adds_prior) return 0;
   int rc = ready(f);
   if (rc) return rc;
@@ -2244,7 +2245,8 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   f->used_one_launch = true;
   if (getenv("LSQAMD_FIT_DIAG"))     // developer knob: where the kernel's cycles went
     fprintf(stderr, "lsqamd_jit_lm: %.0f shader cycles (normal equations %.0f, solves %.0f, trial residuals %.0f), %.1f us; nit %d trials %d\n",
-            f->pin_fit[89], f->pin_fit[90], f->pin_fit[91], f->pin_fit[92], f->pin_fit[93] / 100.0, (int)f->nit, (int)f->ntrial);
+            f->pin_fit[lsqamd_jit::fit_host_diag((int)P)], f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 1], f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 2],
+            f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 3], f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 4] / 100.0, (int)f->nit, (int)f->ntrial);
   f->nrm_in_tail = 0;
   f->prior_deferred = false;
   f->r_fresh = false;
@@ -2532,7 +2534,7 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
     if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
   }
   if (f->cov_host_valid) {       // the one-launch fit kernel mirrored it into pinned memory: no copy, no synchronisation
-    std::memcpy(out, f->pin_fit + 96, sizeof(double) * (size_t)(P * P));
+    std::memcpy(out, f->pin_fit + lsqamd_jit::fit_host_cov((int)P), sizeof(double) * (size_t)(P * P));
     return 0;
   }
   HIPCHK(f, hipMemcpy2DAsync(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P,

@@ -36,7 +36,13 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 // plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
 // argument block, member for member.
 constexpr int FIT_MAX_ROWS = 4096, FIT_MAX_BLOCK_ROWS = 256;
-constexpr int FIT_HOST_DOUBLES = 96 + NRM_MAX_P * NRM_MAX_P;   // ([89, 94): five cycle counters, developer diagnostics; [96, ..): the covariance)
+// ... 13 to FIT_MAX_P parameters: the rows of the Jacobian go to LDS, at most FIT_MAX_WIDE_ROWS of them
+constexpr int FIT_MAX_P = 32, FIT_MAX_WIDE_ROWS = 128;
+// record block of a fit with P parameters: [24, 24 + 5 (P + 1)) x g D coln2 v, then 8 (five cycle counters: developer
+// diagnostics), then the covariance (P x P)
+constexpr int fit_host_diag(int P) { return 24 + 5 * (P + 1); }
+constexpr int fit_host_cov(int P) { return fit_host_diag(P) + 8; }
+constexpr int FIT_HOST_DOUBLES = fit_host_cov(FIT_MAX_P) + FIT_MAX_P * FIT_MAX_P;
 struct FitArgs {
   const double *x, *ymean, *wdiag; long long n_data;
   // correlated rows (n_blocks > 0: at most FIT_MAX_BLOCK_ROWS rows in all): the handle's block tables and W^T factors
@@ -52,9 +58,10 @@ struct FitArgs {
                                          // covariance was formed, [22] its log det(J^T J + prior), [24..) x g D coln2 v
 };
 bool has_fit_kernel(const Kernel *k);
+int64_t fit_row_limit(const Kernel *k, bool correlated);   // most rows the kernel takes (0: no kernel)
 hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a);
 // ... and many same-shape fits, one workgroup each (the kernel's second argument block, member for member; the pointers
-// of FitArgs are those of fit 0, `host` is DEVICE scratch of scratch_stride >= 272 + P doubles per fit)
+// of FitArgs are those of fit 0, `host` is DEVICE scratch of scratch_stride >= fit_host_cov(P) + P * P + 32 + P doubles per fit)
 struct FitBatch {
   long long ymean_stride, prec_stride, tile_stride, cov_stride, scratch_stride;
   double *logdet, *mu, *chi2;

@@ -151,6 +151,7 @@ struct Plan {
   int P = 0, n_x = 1;
   bool wave_per_row = false;
   bool nrm_ok = false;          // few parameters, no wide sums: a third kernel forms J^T J, J^T f and chi2 without writing J
+  bool fit_ok = false;          // ... and the whole-fit kernels (lsqamd_jit_lm / _lmb): up to FIT_MAX_P parameters
 };
 
 bool is_push(int op) { return op <= LSQAMD_OP_P; }
@@ -408,6 +409,7 @@ bool make_plan(const int32_t *code, int n_code, const double *consts, int n_cons
   if ((int)pl.out_params.size() > MAX_OUT_PARAMS) { why = "too many parameters outside the wide sums"; return false; }
   pl.wave_per_row = !pl.wsums.empty();
   pl.nrm_ok = !pl.wave_per_row && P >= 1 && P <= lsqamd_jit::NRM_MAX_P;
+  pl.fit_ok = !pl.wave_per_row && P >= 1 && P <= lsqamd_jit::FIT_MAX_P;
   return true;
 }
 
@@ -721,7 +723,7 @@ static __device__ void lm_solve(const double *sA, const double *sG, const double
     pmin = __builtin_huge_val();
   }
 #pragma unroll
-  for (int o = 8; o > 0; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));      // (LP <= 12: lanes 0 .. 15 hold everything)
+  for (int o = 32; o > 0; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
   if (lane == 0) {
     si[0] = fail;
     ss[S_VG] = vg;
@@ -782,14 +784,14 @@ static __device__ int lm_cov(const double *sA, double *cov, long long ldc, doubl
   return fail;
 }
 
-static __device__ __attribute__((noinline)) void lm_fit(LmArgs a) {      // (one body for both kernels: half the build time)
-  __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[16 * LNQ], ss[16];
+static __device__ __forceinline__ void lm_fit(LmArgs a) {
+  __shared__ double sp[LP], spt[LP], sD[LP], sV[LP], sT[LP], sG[LP], sA[LP * LP], sq[LNQ], red[LRED], ss[16];
   __shared__ int si[4];
   __shared__ double sdata[LDATA];
   __shared__ double srow[LROWS * (LP + 1)];
   __shared__ int sblk[LROWS];
   const int tid = threadIdx.x;
-  if (a.n_blocks) {          // row -> its covariance block (or none); the host sends such fits here with at most LROWS rows
+  if (a.n_blocks && tid < LROWS) {   // row -> its covariance block (or none); the host sends such fits here with at most LROWS rows
     int b = -1;
     for (int q = 0; q < (int)a.n_blocks; ++q)
       if (tid >= a.blk_row0[q] && tid < a.blk_row0[q] + a.blk_size[q]) b = q;
@@ -925,7 +927,7 @@ static __device__ __attribute__((noinline)) void lm_fit(LmArgs a) {      // (one
         gn = fabs(fmax(xj, 1.0) * sG[j]);
       }
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
+      for (int o = 32; o > 0; o >>= 1) {
         notx += __shfl_xor(notx, o, 64);
         gn = fmax(gn, __shfl_xor(gn, o, 64));
       }
@@ -943,34 +945,36 @@ static __device__ __attribute__((noinline)) void lm_fit(LmArgs a) {      // (one
   if (tid < LP) {
     a.p[tid] = sp[tid]; a.p_trial[tid] = spt[tid]; a.dscale[tid] = sD[tid]; a.v_out[tid] = sV[tid];
     a.coln2[tid] = sA[tid * LP + tid]; a.gvec[tid] = sG[tid];
-    double *m = h + 24;
+    double *m = h + HMIR;
     m[tid] = sp[tid]; m[LP + 1 + tid] = sG[tid]; m[2 * (LP + 1) + tid] = sD[tid]; m[3 * (LP + 1) + tid] = sA[tid * LP + tid];
     m[4 * (LP + 1) + tid] = sV[tid];
   }
   for (int e = tid; e < LP * LP; e += 256) a.apk[(e / LP) * 128 + (e % LP)] = sA[e];
   if (tid == 0) {
     a.gvec[LP] = ss[S_CHI2];
-    h[24 + LP + 1 + LP] = ss[S_CHI2];
+    h[HMIR + LP + 1 + LP] = ss[S_CHI2];
     ss[S_SEQ] = 0.0;
     ss[S_HOSTPTR] = a.hostptr_bits;
   }
   __syncthreads();
   if (tid < 16) { a.st[tid] = ss[tid]; h[tid] = ss[tid]; }
   if (tid < 64 && reason == 1 && a.want_cov) {
-    const int bad = lm_cov(sA, a.cov, a.ldc, h + 96, h + 22);
+    const int bad = lm_cov(sA, a.cov, a.ldc, h + HCOV, h + 22);
     if (tid == 0) h[21] = bad == 0 ? 1.0 : 0.0;
   } else if (tid == 0) h[21] = 0.0;
   if (tid == 0) {
     h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial;
     // diagnostics: shader cycles in all / in the normal equations / in the solves / in the trial residuals, 100 MHz ticks in all
-    m_diag(h + 89, clock64() - c_begin, c_nrm, c_solve, c_res, wall_clock64() - w_begin);
+    m_diag(h + HDIAG, clock64() - c_begin, c_nrm, c_solve, c_res, wall_clock64() - w_begin);
   }
   __threadfence_system();
   __syncthreads();
   if (tid == 0) { h[16] = (double)reason; __threadfence_system(); }
 }
 
+// ===SINGLE===
 extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lm(LmArgs a) { lm_fit(a); }
+// ===BATCH===
 
 // Many same-shape fits (bootstrap / simulated copies, a sweep of priors): one workgroup per fit, the same loop.  Per-fit
 // inputs and outputs are strided; a fit's record (the block the single-fit kernel mirrors to the host) goes to device
@@ -989,9 +993,9 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lmb(LmArgs a, LmBat
   a.apk += fit * b.tile_stride; a.gvec += fit * b.tile_stride;
   if (a.prior_prec) { a.prior_mean += fit * LP; a.prior_prec += fit * b.prec_stride; }
   a.cov += fit * b.cov_stride;
-  a.host += fit * b.scratch_stride;          // [0, 256) the record block, [256, 272) the LM record, [272, ..) column norms
-  a.st = a.host + 256;
-  a.coln2 = a.host + 272;
+  a.host += fit * b.scratch_stride;          // [0, HREC) the record block, then the LM record (16) and the column norms (LP)
+  a.st = a.host + HREC;
+  a.coln2 = a.host + HREC + 16;
   lm_fit(a);
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1009,7 +1013,8 @@ extern "C" __global__ __launch_bounds__(256) void lsqamd_jit_lmb(LmArgs a, LmBat
 
 )LSQLM";
 
-std::string generate(const Plan &pl) {
+// batch_only: the module with the batched whole-fit kernel alone (built the first time a batch asks for it)
+std::string generate(const Plan &pl, bool batch_only = false) {
   Src o;
   o.s += "// generated by lsqfit_amd (jit.hip) from an expression tape\n";
   o.s += kDevmath;
@@ -1045,7 +1050,7 @@ std::string generate(const Plan &pl) {
   for (const Node &nd : pl.nodes)
     if (nd.op == LSQAMD_OP_X) xused[(size_t)nd.arg] = 1;
   const int nout = (int)pl.out_params.size();
-  for (int jac = 0; jac < 2; ++jac) {
+  for (int jac = 0; jac < (batch_only ? 0 : 2); ++jac) {
     o.f("extern \"C\" __global__ __launch_bounds__(256) void %s(Args a) {\n", jac ? "lsqamd_jit_jac" : "lsqamd_jit_res");
     // blockIdx.y = fit of a batch (lockstep fits, chi2 at many points): its parameters, data means and output rows
     o.s += "  if (a.batch_active && !a.batch_active[blockIdx.y]) return;\n";
@@ -1151,7 +1156,7 @@ std::string generate(const Plan &pl) {
     }
     o.s += "  }\n}\n";
   }
-  if (pl.nrm_ok) {
+  if (pl.nrm_ok && !batch_only) {
     // ---- normal equations without the Jacobian: per lane P (P + 1) / 2 + P + 1 running sums over its rows
     const int P = pl.P, NA = P * (P + 1) / 2, NQ = NA + P + 1;
     o.f("extern \"C\" __global__ __launch_bounds__(256) void lsqamd_jit_nrm(Args a) {\n");
@@ -1197,13 +1202,32 @@ std::string generate(const Plan &pl) {
     o.f("  { const double t = wsum(nC); if (lane == 0) red[wave][%d] = t; }\n", q);
     o.f("  __syncthreads();\n  if (threadIdx.x < %d) a.out_w[(long long)blockIdx.x * %d + threadIdx.x] = "
         "red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];\n}\n", NQ, NQ);
-    // ---- the same sums and the residual as functions of ONE workgroup, and the whole-fit kernel over them
-    // LDS budget (64 KB of static LDS per workgroup): rows of a correlated fit (<= 256 of them, P + 1 values each), the 16 row
-    // totals of every sum, the prior, ~2 KB of small arrays -- the rest stages x, y, w
-    const int lds_fixed = 8 * (256 * (P + 1) + 16 * NQ + P * P + P + NQ + 8 * P + 64) + 4 * 256 + 1024;
+  }
+  if (pl.fit_ok) {
+    // ---- the same sums and the residual as functions of ONE workgroup, and the whole-fit kernels over them.  Two forms of the
+    // normal equations: up to NRM_MAX_P parameters every thread keeps all the sums of its rows in registers (any number of
+    // rows); beyond that (up to FIT_MAX_P) the rows go to LDS -- at most 128 of them -- and thread q adds up product q.
+    const int P = pl.P, NA = P * (P + 1) / 2, NQ = NA + P + 1;
+    const bool regs = P <= lsqamd_jit::NRM_MAX_P;
+    const int lrows = regs ? lsqamd_jit::FIT_MAX_BLOCK_ROWS : lsqamd_jit::FIT_MAX_WIDE_ROWS, lred = regs ? 16 * NQ : 16;
+    // LDS budget (64 KB of static LDS per workgroup): the rows of a correlated (or wide) fit, P + 1 values each, the row totals
+    // of the register form, A, the prior, ~2 KB of small arrays -- the rest stages x, y, w
+    const int lds_fixed = 8 * (lrows * (P + 1) + lred + 2 * P * P + 8 * P + NQ + 32) + 4 * lrows + 768;
     int ldata = (64512 - lds_fixed) / 8;
     if (ldata > 12288) ldata = 12288;
-    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d, LNX = %d, LDATA = %d, LROWS = 256;\n", P, NA, NQ, pl.n_x < 1 ? 1 : pl.n_x, ldata);
+    if (ldata < 16) ldata = 16;
+    o.f("constexpr int LP = %d, LNA = %d, LNQ = %d, LNX = %d, LDATA = %d, LROWS = %d, LRED = %d;\n", P, NA, NQ, pl.n_x < 1 ? 1 : pl.n_x,
+        ldata, lrows, lred);
+    o.f("constexpr int HMIR = 24, HDIAG = %d, HCOV = %d, HREC = %d;      // the record block: mirrors, cycle counters, covariance, size\n",
+        24 + 5 * (P + 1), 24 + 5 * (P + 1) + 8, (24 + 5 * (P + 1) + 8 + P * P + 15) / 16 * 16);
+    if (!regs) {   // which two columns of a row product q multiplies: A upper row-major, then J^T f, then |f|^2
+      std::string qi = "static __device__ const unsigned char QI[LNQ] = {", qj = "static __device__ const unsigned char QJ[LNQ] = {";
+      for (int i = 0; i < P; ++i)
+        for (int j = i; j < P; ++j) { qi += std::to_string(i) + ","; qj += std::to_string(j) + ","; }
+      for (int i = 0; i < P; ++i) { qi += std::to_string(i) + ","; qj += std::to_string(P) + ","; }
+      qi += std::to_string(P) + "};\n"; qj += std::to_string(P) + "};\n";
+      o.s += qi + qj;
+    }
     o.f("enum { S_CHI2 = %d, S_MU = %d, S_NU = %d, S_DELTA = %d, S_VG = %d, S_DV2 = %d, S_VFINITE = %d, S_RHO = %d, S_CHI2_TRIAL = %d, "
         "S_ACCEPT = %d, S_SOLVED = %d, S_INFO = %d, S_PIVMIN = %d, S_SEQ = %d, S_HOSTPTR = %d, SC_LEVENBERG = %d, SC_MORE = %d };\n",
         (int)lsqamd::LMS_CHI2, (int)lsqamd::LMS_MU, (int)lsqamd::LMS_NU, (int)lsqamd::LMS_DELTA, (int)lsqamd::LMS_VG, (int)lsqamd::LMS_DV2, (int)lsqamd::LMS_VFINITE, (int)lsqamd::LMS_RHO,
@@ -1235,15 +1259,21 @@ std::string generate(const Plan &pl) {
            "  const int B = (int)a.blk_size[b], r0 = (int)a.blk_row0[b], m = row - r0;\n"
            "  const double *W = a.wt + a.blk_woff[b] + m;\n"
            "#pragma unroll\n  for (int c = 0; c < NC; ++c) o[c] = 0.0;\n"
-           "#pragma unroll 8\n  for (int k = 0; k < B; ++k) {      // (eight W^T rows requested before the first is used)\n"
-           "    const double wv = W[(long long)k * B];\n    const double *sr = srow + (r0 + k) * NC;\n"
+           "  if (NC <= 8) {      // few columns: the compiler's own eight-fold unrolling keeps the loads ahead of their use\n"
+           "#pragma unroll 8\n    for (int k = 0; k < B; ++k) {\n      const double wv = W[(long long)k * B];\n      const double *sr = srow + (r0 + k) * NC;\n"
+           "#pragma unroll\n      for (int c = 0; c < NC; ++c) o[c] = __builtin_fma(wv, sr[c], o[c]);\n    }\n    return;\n  }\n"
+           "  int k0 = 0;\n  for (; k0 + 8 <= B; k0 += 8) {      // many columns: eight W^T rows requested explicitly before the first is used\n"
+           "    double wv[8];\n#pragma unroll\n    for (int u = 0; u < 8; ++u) wv[u] = W[(long long)(k0 + u) * B];\n"
+           "#pragma unroll\n    for (int u = 0; u < 8; ++u) {\n      const double *sr = srow + (r0 + k0 + u) * NC;\n"
+           "#pragma unroll\n      for (int c = 0; c < NC; ++c) o[c] = __builtin_fma(wv[u], sr[c], o[c]);\n    }\n  }\n"
+           "  for (; k0 < B; ++k0) {\n    const double wv = W[(long long)k0 * B];\n    const double *sr = srow + (r0 + k0) * NC;\n"
            "#pragma unroll\n    for (int c = 0; c < NC; ++c) o[c] = __builtin_fma(wv, sr[c], o[c]);\n  }\n}\n";
     for (int fn = 0; fn < 2; ++fn) {
       const bool nrm = fn == 0;
       if (nrm) o.s += "static __device__ void lm_nrm(const LmArgs &a, const double *sp, double *red, double *sq, double *srow, const int *sblk) {\n";
       else o.s += "static __device__ double lm_res(const LmArgs &a, const double *sp, double *red, double *srow, const int *sblk) {\n";
       o.s += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
-      if (nrm) {
+      if (nrm && regs) {
         for (int i = 0; i < P; ++i)
           for (int j = i; j < P; ++j) o.f("  double nA%d_%d = 0.0;\n", i, j);
         for (int i = 0; i < P; ++i) o.f("  double nG%d = 0.0;\n", i);
@@ -1277,6 +1307,20 @@ std::string generate(const Plan &pl) {
         for (int i = 0; i < P; ++i) {
           if (slot[(size_t)i] >= 0) o.f("    const double dd%d = w * oacc%d;\n", i, slot[(size_t)i]);
           else o.f("    const double dd%d = 0.0;\n", i);
+        }
+        if (!regs) {
+          // wide form: the row goes to LDS; whitened in place (every thread forms its row from the raw ones, then all write)
+          o.s += "    double *sr = srow + row * (LP + 1);\n";
+          for (int i = 0; i < P; ++i) o.f("    sr[%d] = dd%d;\n", i, i);
+          o.s += "    sr[LP] = rr;\n  }\n  __syncthreads();\n";
+          o.s += "  if (a.n_blocks) {\n    double o[LP + 1];\n    const bool mine = threadIdx.x < a.n_data && sblk[threadIdx.x] >= 0;\n"
+                 "    if (mine) lm_whiten_row<LP + 1>(a, srow, sblk, threadIdx.x, o);\n    __syncthreads();\n"
+                 "    if (mine) {\n#pragma unroll\n      for (int c = 0; c <= LP; ++c) srow[threadIdx.x * (LP + 1) + c] = o[c];\n    }\n"
+                 "    __syncthreads();\n  }\n";
+          o.s += "  for (int q = threadIdx.x; q < LNQ; q += 256) {\n    const int ci = QI[q], cj = QJ[q];\n    double t = 0.0;\n"
+                 "    for (int r = 0; r < (int)a.n_data; ++r) t = __builtin_fma(srow[r * (LP + 1) + ci], srow[r * (LP + 1) + cj], t);\n"
+                 "    sq[q] = t;\n  }\n  __syncthreads();\n  (void)lane; (void)wave; (void)nC; (void)red;\n}\n";
+          continue;
         }
         o.s += "    if (!a.n_blocks) {\n";
         for (int i = 0; i < P; ++i)
@@ -1315,7 +1359,12 @@ std::string generate(const Plan &pl) {
                "  const double tot = red[0] + red[1] + red[2] + red[3];\n  __syncthreads();\n  return tot;\n}\n";
       }
     }
-    o.s += decl_end + 2;      // the driver: lm_normal, lm_solve, lsqamd_jit_lm
+    {   // the driver: lm_normal, lm_solve, lm_fit, then ONE of the two kernels over it
+      const char *rest = decl_end + 2, *single = strstr(rest, "// ===SINGLE==="), *batch = strstr(rest, "// ===BATCH===");
+      o.s.append(rest, (size_t)(single - rest));
+      if (batch_only) o.s += batch;
+      else o.s.append(single, (size_t)(batch - single));
+    }
   }
   return o.s;
 }
@@ -1409,15 +1458,23 @@ namespace lsqamd_jit {
 
 struct Kernel {
   Loaded l;
+  // what it takes to build the batched whole-fit kernel later (ensure_batch): a module of its own, compiled the first time a
+  // batch of fits asks for it -- inlined into the main module it doubled every formula's build time
+  std::vector<int32_t> code;
+  std::vector<double> consts;
+  int n_x = 1;
+  bool fit_ok = false, batch_tried = false;
+  hipModule_t modb = nullptr;
 };
 
 int plan_and_generate(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x,
-                      std::string &src, int *variant, std::string &why, bool *has_nrm = nullptr) {
+                      std::string &src, int *variant, std::string &why, bool *has_nrm = nullptr, bool *has_fit = nullptr) {
   Plan pl;
   if (!make_plan(code, n_code, consts, n_consts, P, n_x, pl, why)) return 1;
   src = generate(pl);
   if (variant) *variant = pl.wave_per_row ? 1 : 0;
   if (has_nrm) *has_nrm = pl.nrm_ok;
+  if (has_fit) *has_fit = pl.fit_ok;
   return 0;
 }
 
@@ -1439,8 +1496,8 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
   }
   std::string src;
   int variant = 0;
-  bool has_nrm = false;
-  if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why, &has_nrm)) return nullptr;
+  bool has_nrm = false, has_fit = false;
+  if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why, &has_nrm, &has_fit)) return nullptr;
   const std::pair<int, uint64_t> key{dev, fnv1a(src)};
   std::lock_guard<std::mutex> lk(g_mu);
   static std::map<std::pair<int, uint64_t>, Kernel> kernels;
@@ -1466,14 +1523,14 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
     (void)hipGetLastError();
     k.l.nrm = nullptr;
   }
-  if (has_nrm && hipModuleGetFunction(&k.l.lm, k.l.mod, "lsqamd_jit_lm") != hipSuccess) {
+  if (has_fit && hipModuleGetFunction(&k.l.lm, k.l.mod, "lsqamd_jit_lm") != hipSuccess) {
     (void)hipGetLastError();
     k.l.lm = nullptr;
   }
-  if (has_nrm && hipModuleGetFunction(&k.l.lmb, k.l.mod, "lsqamd_jit_lmb") != hipSuccess) {
-    (void)hipGetLastError();
-    k.l.lmb = nullptr;
-  }
+  k.fit_ok = has_fit && k.l.lm != nullptr;
+  k.code.assign(code, code + n_code);
+  k.consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
+  k.n_x = n_x;
   const Kernel *kp = &kernels.emplace(key, k).first->second;
   if (by_tape.size() < 4096) by_tape[tkey] = kp;
   return kp;
@@ -1510,7 +1567,30 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 }
 
 bool has_fit_kernel(const Kernel *k) { return k && k->l.lm; }
-bool has_batch_fit_kernel(const Kernel *k) { return k && k->l.lmb; }
+int64_t fit_row_limit(const Kernel *k, bool correlated) {
+  if (!k || !k->l.lm) return 0;
+  if (k->l.n_param > NRM_MAX_P) return FIT_MAX_WIDE_ROWS;
+  return correlated ? FIT_MAX_BLOCK_ROWS : FIT_MAX_ROWS;
+}
+bool has_batch_fit_kernel(const Kernel *kc) {
+  if (!kc || !kc->fit_ok) return false;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Kernel *k = const_cast<Kernel *>(kc);      // (the cache owns the object; its batch half is filled in under the lock)
+  if (!k->batch_tried) {
+    k->batch_tried = true;
+    Plan pl;
+    std::string why, log;
+    std::vector<char> obj;
+    if (make_plan(k->code.data(), (int)k->code.size(), k->consts.data(), (int)k->consts.size(), k->l.n_param, k->n_x, pl, why) &&
+        pl.fit_ok && compile_source(generate(pl, true), obj, log) && hipModuleLoadData(&k->modb, obj.data()) == hipSuccess &&
+        hipModuleGetFunction(&k->l.lmb, k->modb, "lsqamd_jit_lmb") == hipSuccess) {
+    } else {
+      (void)hipGetLastError();
+      k->l.lmb = nullptr;
+    }
+  }
+  return k->l.lmb != nullptr;
+}
 
 hipError_t launch_fit_batch(const Kernel *k, hipStream_t st, const FitArgs &a, const FitBatch &b, int n_fits) {
   if (!k || !k->l.lmb || n_fits < 1) return hipErrorInvalidValue;

