@@ -2158,7 +2158,8 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
 // A whole small fit in ONE launch (jit.hip lsqamd_jit_lm): a compiled formula with at most a dozen parameters, uncorrelated rows,
 // a few thousand of them at most, plain lm on one rank -- the fits of examples/nist.py and tests/test_lsqfit.py, where the
 // half dozen launches and two host round trips of an iteration of iterate_device cost more than its arithmetic.  One workgroup
-// runs gsl_multifit_nlinear_driver's loop from p0 to the stopping criterion and hands back the state where do_init / iterate_device
+// runs gsl_multifit_nlinear_init + _driver (src/lsqfit/_gsl.pyx:676-677) from p0 to the stopping criterion -- and, for the
+// normal-equation route, gsl_multifit_nlinear_covar (:706) -- and hands back the state where do_init / iterate_device
 // would have left it (device buffers and host mirrors).  -> 1: done (iter, info set); 0: not this fit's route, or the kernel met
 // something irregular and the general path runs the fit from the start; < 0: error.  LSQAMD_ONE_LAUNCH_FIT=0 disables (read per call).
 static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info) {

@@ -597,7 +597,8 @@ void gen_group(const Plan &pl, Src &o, const Group &g, int gid, int mode, const 
 
 
 // ---- a whole small fit in ONE launch (lsqamd_jit_lm): the text below follows the LM_* functions generate() emits -------
-// Plain Levenberg-Marquardt as api.hip iterate_device runs it over half a dozen launches per iteration -- the same solve
+// Plain Levenberg-Marquardt (what the reference gets from gsl_multifit_nlinear_init / _driver / _covar, src/lsqfit/_gsl.pyx:
+// 676-677,:706, with trs = lm) as api.hip iterate_device runs it over half a dozen launches per iteration -- the same solve
 // (vecops.hip lm_tiny12_solve_kernel), the same decision (lm_trial_tail_small_kernel), the same scaling update and
 // convergence test (lm_accept_tail_kernel) -- by one workgroup that keeps x, D, J^T J, J^T f in LDS from the first
 // evaluation to the last.  Anything irregular (no positive pivot, a step that is not finite, a pivot that retained too
