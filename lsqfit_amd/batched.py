@@ -21,7 +21,7 @@ from .models import MODEL_IDENTITY, MODEL_TAPE
 
 class BatchedFits:
     def __init__(self, model, x, ymean, ysdev, prior_mean, prior_sdev, device=None, svdcut=1e-12,
-                 whitening=None, n_fits=None, prior_prec=None, prior_logdet=None):
+                 whitening=None, n_fits=None, prior_prec=None, prior_logdet=None, rows_permuted=False):
         """``prior_sdev``: per-fit diagonal priors ([n_fits, P] or broadcastable).  Alternatively
         ``prior_prec`` (P x P) + ``prior_logdet``: ONE correlated prior covariance shared by all
         fits (its inverse and log-determinant, e.g. from :class:`Whitening`), per-fit means only."""
@@ -40,7 +40,8 @@ class BatchedFits:
                 yerr = np.broadcast_to(yerr, ymean.shape)
             whitening = Whitening(ymean, yerr, svdcut=svdcut)
         self.wh = wh = whitening
-        if getattr(wh, 'perm', None) is not None:
+        if getattr(wh, 'perm', None) is not None and not rows_permuted:
+            # (resample.refit hands x and the data means over in the whitening's own row order: rows_permuted=True)
             raise NotImplementedError('BatchedFits: covariance components that interleave; reorder the data rows')
         row0, size, modes, tri, wt = wh.block_arrays()
         self.has_prior = prior_mean is not None

@@ -188,10 +188,6 @@ class nonlinear_fit(object):
         if getattr(self.whitening, 'joint', False):
             raise NotImplementedError('not available for fits with data-prior cross-correlations')
 
-    def _no_perm(self):
-        if getattr(self.whitening, 'perm', None) is not None:
-            raise NotImplementedError('not available for data whose covariance components interleave')
-
     def dp_dinputs(self, G=None):
         """``D[a, i] = d pmean[a] / d buf[i]`` for ``buf = concat(y, prior)``: the matrix
         ``_getp`` (src/lsqfit/__init__.py:897-911) turns into the derivatives of ``fit.p``
@@ -232,14 +228,12 @@ class nonlinear_fit(object):
     def simulated_fits(self, n, pexact=None, add_priornoise=False, seed=0, **kw):
         """``simulated_fit_iter`` (src/lsqfit/__init__.py:1391-1469) as one device batch."""
         self._no_joint()
-        self._no_perm()
         from .resample import simulated_fits
         return simulated_fits(self, n, pexact, add_priornoise, seed, **kw)
 
     def bootstrapped_fits(self, n, seed=0, **kw):
         """``bootstrapped_fit_iter`` (src/lsqfit/__init__.py:1548-1642) as one device batch."""
         self._no_joint()
-        self._no_perm()
         from .resample import bootstrapped_fits
         return bootstrapped_fits(self, n, seed, **kw)
 

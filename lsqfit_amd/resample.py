@@ -17,6 +17,17 @@ import numpy as np
 from .batched import BatchedFits
 
 
+def _data_order(wh, a):
+    """Rows in the whitening's own order (interleaved covariance components are made contiguous by a permutation) ->
+    the caller's row order."""
+    perm = getattr(wh, 'perm', None)
+    if perm is None:
+        return a
+    out = np.empty_like(a)
+    out[..., perm] = a
+    return out
+
+
 def simulated_data(fit, n, pexact=None, add_priornoise=False, seed=0):
     """-> (ymeans[n, N], prior_means[n, P] or None): ``simulated_data_iter``
     (__init__.py:1519-1543): data means = fcn(pexact) + noise with the covariance of
@@ -25,7 +36,7 @@ def simulated_data(fit, n, pexact=None, add_priornoise=False, seed=0):
     rng = np.random.Generator(np.random.PCG64(seed))
     pexact = fit.pmean if pexact is None else np.asarray(pexact, float)
     f = fit.problem.fcn(pexact)
-    ymeans = f[None, :] + wh.draw_data(rng, n)
+    ymeans = f[None, :] + _data_order(wh, wh.draw_data(rng, n))
     if not wh.has_prior:
         return ymeans, None
     pm = np.broadcast_to(wh.prior_mean, (n, wh.prior_mean.size)).copy()
@@ -40,7 +51,7 @@ def bootstrap_data(fit, n, seed=0):
     their original values."""
     wh = fit.whitening
     rng = np.random.Generator(np.random.PCG64(seed))
-    ymeans = wh.ymean[None, :] + wh.draw_data(rng, n)
+    ymeans = _data_order(wh, wh.ymean[None, :] + wh.draw_data(rng, n))
     if not wh.has_prior:
         return ymeans, None
     return ymeans, wh.prior_mean[None, :] + wh.draw_prior(rng, n)
@@ -61,11 +72,16 @@ def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
     maxit = fit.maxit if maxit is None else maxit
     p0 = np.broadcast_to(np.asarray(p0, float), (n, P))
     dense = wh.has_prior and wh.prior_dense
-    bf = BatchedFits(fit.model, fit.problem_x, ymeans, None,
+    x, ym = fit.problem_x, ymeans
+    perm = getattr(wh, 'perm', None)
+    if perm is not None:             # the engine works in the whitening's row order
+        x = np.asarray(x, float).reshape(wh.n_data, fit.model.n_x)[perm]
+        ym = np.ascontiguousarray(np.asarray(ymeans, float)[:, perm])
+    bf = BatchedFits(fit.model, x, ym, None,
                      prior_means if wh.has_prior else None,
                      None if (dense or not wh.has_prior) else wh.prior_sdev, whitening=wh, n_fits=n,
                      prior_prec=wh.prior_prec if dense else None,
-                     prior_logdet=(wh.logdet - wh.logdet_data) if dense else None)
+                     prior_logdet=(wh.logdet - wh.logdet_data) if dense else None, rows_permuted=perm is not None)
     out = bf.run(p0=p0, tol=tol, maxit=maxit, covariance=covariance)
     bf.close()
     res = ResampledFits(out)

@@ -63,8 +63,13 @@ def test_fit_with_interleaved_components_matches_oracle(amd, svdcut):
     assert D.shape == Dref.shape and gu.relmax(D, Dref) < 1e-6
     pts = fit.pmean + 1e-3 * rng.standard_normal((4, P))
     np.testing.assert_allclose(fit.dchi2(pts), [ofit.dchi2(ref, q) for q in pts], rtol=1e-6)
-    with pytest.raises(NotImplementedError):
-        fit.simulated_fits(2)
+    # resampled copies run in the whitening's row order; their data come back in the caller's
+    for res in (fit.bootstrapped_fits(4, seed=5), fit.simulated_fits(4, seed=6)):
+        assert res.ymeans.shape == (4, N)
+        for k in (0, 3):
+            single = amd.nonlinear_fit(data=(x, res.ymeans[k], ycov), model=model, prior=(res.prior_means[k], pcov),
+                                       p0=fit.pmean, svdcut=svdcut, tol=fit.tol)
+            assert gu.relmax(res.pmean[k], single.pmean) < 1e-6 and res.chi2[k] == pytest.approx(single.chi2, rel=1e-7)
     with pytest.raises(ValueError):
         amd.DeviceProblem(model, x, wh, rows=(0, 48))
 
