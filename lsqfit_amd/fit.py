@@ -110,8 +110,6 @@ class nonlinear_fit(object):
         self.dof = nf - self.p0.size
         self._chiv = _Chiv(problem)
         t1 = clock()
-        if getattr(wh, 'joint', False) and maxit == 0:
-            raise NotImplementedError('maxit = 0 with data-prior cross-correlations')
         if maxit == 0:
             # src/lsqfit/__init__.py:683-706: no fit -- parameters are the prior (or p0 with infinite
             # errors); chi2 is still evaluated on the device
@@ -121,6 +119,10 @@ class nonlinear_fit(object):
                 self.pmean = self.p0.copy()
                 self.psdev = np.full(self.p0.size, np.inf)
                 self.cov = np.diag(self.psdev ** 2)
+            elif getattr(wh, 'joint', False):      # data correlated with the prior: the joint whitening kept the prior's own block
+                self.pmean = np.array(wh.prior_mean_host)
+                self.psdev = np.array(wh.prior_sdev)
+                self.cov = np.array(wh.prior_cov_host)
             else:
                 self.pmean = np.array(wh.prior_mean)
                 self.psdev = np.array(wh.prior_sdev)

@@ -615,3 +615,29 @@ def test_wavg_svd_literal_on_device(amd):
         fit = amd.nonlinear_fit(data=(np.zeros(3), np.ones(3), WAVG_SVD_COV), model=amd.expr('p + 0*x', ['p']), p0=[1.0],
                                 svdcut=svdcut)
         assert round(abs(fit.cov[0, 0] - var), 7) == 0 and fit.svdn == nmod
+
+
+def test_cross_correlated_maxit0_matches_oracle(amd):
+    """maxit = 0 (no fit: parameters = prior, chi2 and logGBF at the prior, src/lsqfit/__init__.py:683-725) for data
+    correlated with the prior -- the joint whitening's residual at the prior and its log det."""
+    rng = np.random.default_rng(17)
+    N, P = 10, 3
+    A = rng.standard_normal((N + P, N + P))
+    full = (A @ A.T + (N + P) * np.eye(N + P)) * 1e-4
+    x = np.linspace(0.1, 2.0, N)
+    truth = np.array([1.0, 0.7, 0.3])
+    dev = np.linalg.cholesky(full) @ rng.standard_normal(N + P)
+    y = truth[0] * np.exp(-truth[1] * x) + truth[2] + dev[:N]
+    pm = truth + dev[N:]
+    model = amd.expr('b1*exp(-b2*x) + b3', ['b1', 'b2', 'b3'])
+    fit = amd.nonlinear_fit(data=(x, y, full[:N, :N]), model=model, prior=(pm, full[N:, N:]), cross=full[:N, N:], maxit=0)
+    extra = [((i, N + j), full[i, N + j]) for i in range(N) for j in range(P)]
+
+    def fcn(xx, p):
+        from oracle import dual
+        return p[0] * dual.exp(-p[1] * xx) + p[2]
+    ref = ofit.nonlinear_fit(x, y, full[:N, :N], fcn, prior_mean=pm, prior_err=full[N:, N:], extra_cov=extra, maxit=0)
+    assert fit.nit == 0 and fit.error is None and fit.dof == ref.dof
+    assert np.array_equal(fit.pmean, ref.pmean) and np.allclose(fit.cov, ref.cov, rtol=1e-12)
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-8) and fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-7)
+    assert fit.Q == pytest.approx(ref.Q, rel=1e-7, abs=1e-12)
