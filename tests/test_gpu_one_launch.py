@@ -275,3 +275,21 @@ def test_up_to_32_parameters_with_the_rows_in_lds(amd, K, N, correlated, bg, mon
     x2, y2, yerr2, _, _, _ = bumps(K, 200, seed=1, correlated=False, background=bg)
     big = amd.nonlinear_fit(data=(x2, y2, yerr2), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
     assert not flags(big) & ONE and big.error is None
+
+
+@pytest.mark.parametrize('N,P,maxit', [(1, 1, 5), (3, 2, 1), (5, 1, 50), (4096, 3, 30)])
+def test_smallest_and_largest_shapes(amd, N, P, maxit, monkeypatch):
+    """One data point, one parameter, one iteration; and the largest row count the kernel takes."""
+    rng = np.random.default_rng(N + P)
+    x = np.linspace(0.5, 3.0, N)
+    names = ['a', 'b', 'c'][:P]
+    text = {1: 'a*x', 2: 'a*exp(-b*x)', 3: 'a*exp(-b*x) + c'}[P]
+    pt = np.array([1.3, 0.6, 0.2])[:P]
+    f = {1: pt[0] * x, 2: pt[0] * np.exp(-pt[min(1, P - 1)] * x), 3: pt[0] * np.exp(-pt[min(1, P - 1)] * x) + pt[P - 1]}[P]
+    sd = np.full(N, 0.05)
+    y = f + sd * rng.standard_normal(N)
+    kw = dict(data=(x, y, sd), model=amd.expr(text, names), prior=(pt, np.full(P, 0.5)), p0=pt * 1.2, maxit=maxit)
+    one, f1, gen = both(amd, monkeypatch, **kw)
+    assert f1 & ONE
+    agree(one, gen)
+    assert one.stopping_criterion == gen.stopping_criterion and (one.error is None) == (gen.error is None)
