@@ -436,7 +436,7 @@ int lsqamd_timing_reset(lsqamd_fit *fit);
  * interpreter kernels, bit 2 = LM steps replayed from captured graphs (small
  * single-rank problems without phase timing; LSQAMD_STEP_GRAPH=0 disables), bit 5 = the last lsqamd_run was ONE
  * kernel launch (compiled formula; <= 12 parameters and <= 4096 uncorrelated or <= 256 correlated rows, or <= 32
- * parameters and <= 128 rows; plain lm: every iteration of
+ * parameters and a few hundred to two thousand rows, fewer when correlated; plain lm: every iteration of
  * gsl_multifit_nlinear_init + _driver + _covar, src/lsqfit/_gsl.pyx:676-677,:706, by one workgroup;
  * LSQAMD_ONE_LAUNCH_FIT=0 disables),
  * bits 8..31 = split-K factor of the J^T J kernel, bits 32.. = block count */

@@ -36,8 +36,10 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 // plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
 // argument block, member for member.
 constexpr int FIT_MAX_ROWS = 4096, FIT_MAX_BLOCK_ROWS = 256;
-// ... 13 to FIT_MAX_P parameters: the rows of the Jacobian go to LDS, at most FIT_MAX_WIDE_ROWS of them
-constexpr int FIT_MAX_P = 32, FIT_MAX_WIDE_ROWS = 128;
+// ... 13 to FIT_MAX_P parameters: the rows of the Jacobian go through LDS, fit_wide_rows(P) of them at a time (a correlated fit
+// must fit one such chunk)
+constexpr int FIT_MAX_P = 32;
+constexpr int fit_wide_rows(int P) { return P <= 20 ? 256 : 128; }
 // record block of a fit with P parameters: [24, 24 + 5 (P + 1)) x g D coln2 v, then 8 (five cycle counters: developer
 // diagnostics), then the covariance (P x P)
 constexpr int fit_host_diag(int P) { return 24 + 5 * (P + 1); }

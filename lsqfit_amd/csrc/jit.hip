@@ -1206,11 +1206,11 @@ std::string generate(const Plan &pl, bool batch_only = false) {
   }
   if (pl.fit_ok) {
     // ---- the same sums and the residual as functions of ONE workgroup, and the whole-fit kernels over them.  Two forms of the
-    // normal equations: up to NRM_MAX_P parameters every thread keeps all the sums of its rows in registers (any number of
-    // rows); beyond that (up to FIT_MAX_P) the rows go to LDS -- at most 128 of them -- and thread q adds up product q.
+    // normal equations: up to NRM_MAX_P parameters every thread keeps all the sums of its rows in registers; beyond that (up to
+    // FIT_MAX_P) the rows go through LDS, fit_wide_rows(P) at a time, and thread q adds up product q of the chunk.
     const int P = pl.P, NA = P * (P + 1) / 2, NQ = NA + P + 1;
     const bool regs = P <= lsqamd_jit::NRM_MAX_P;
-    const int lrows = regs ? lsqamd_jit::FIT_MAX_BLOCK_ROWS : lsqamd_jit::FIT_MAX_WIDE_ROWS, lred = regs ? 16 * NQ : 16;
+    const int lrows = regs ? lsqamd_jit::FIT_MAX_BLOCK_ROWS : lsqamd_jit::fit_wide_rows(P), lred = regs ? 16 * NQ : 16;
     // LDS budget (64 KB of static LDS per workgroup): the rows of a correlated (or wide) fit, P + 1 values each, the row totals
     // of the register form, A, the prior, ~2 KB of small arrays -- the rest stages x, y, w
     const int lds_fixed = 8 * (lrows * (P + 1) + lred + 2 * P * P + 8 * P + NQ + 32) + 4 * lrows + 768;
@@ -1280,7 +1280,14 @@ std::string generate(const Plan &pl, bool batch_only = false) {
         for (int i = 0; i < P; ++i) o.f("  double nG%d = 0.0;\n", i);
       }
       o.s += "  double nC = 0.0;\n";
-      o.s += "  for (long long row = threadIdx.x; row < a.n_data; row += 256) {\n";
+      if (nrm && !regs) {
+        // wide form: LROWS rows at a time through LDS (the products of a chunk are added to the running sums of thread q)
+        for (int k = 0; k < (NQ + 255) / 256; ++k) o.f("  double qa%d = 0.0;\n", k);
+        o.s += "  for (long long base = 0; base < a.n_data; base += LROWS) {\n  const long long row = base + threadIdx.x;\n"
+               "  if (threadIdx.x < LROWS && row < a.n_data) {\n";
+      } else {
+        o.s += "  for (long long row = threadIdx.x; row < a.n_data; row += 256) {\n";
+      }
       for (int i = 0; i < pl.n_x; ++i)
         if (xused[(size_t)i]) o.f("    const double x%d = a.x[row * %d + %d];\n", i, pl.n_x, i);
       o.s += "    const double w = (a.n_blocks && a.in_block[row]) ? 1.0 : a.wdiag[row];\n";
@@ -1310,17 +1317,23 @@ std::string generate(const Plan &pl, bool batch_only = false) {
           else o.f("    const double dd%d = 0.0;\n", i);
         }
         if (!regs) {
-          // wide form: the row goes to LDS; whitened in place (every thread forms its row from the raw ones, then all write)
-          o.s += "    double *sr = srow + row * (LP + 1);\n";
+          // wide form: the row goes to LDS; whitened in place (every thread forms its row from the raw ones, then all write:
+          // correlated fits come with at most LROWS rows, i.e. one chunk)
+          o.s += "    double *sr = srow + threadIdx.x * (LP + 1);\n";
           for (int i = 0; i < P; ++i) o.f("    sr[%d] = dd%d;\n", i, i);
           o.s += "    sr[LP] = rr;\n  }\n  __syncthreads();\n";
           o.s += "  if (a.n_blocks) {\n    double o[LP + 1];\n    const bool mine = threadIdx.x < a.n_data && sblk[threadIdx.x] >= 0;\n"
                  "    if (mine) lm_whiten_row<LP + 1>(a, srow, sblk, threadIdx.x, o);\n    __syncthreads();\n"
                  "    if (mine) {\n#pragma unroll\n      for (int c = 0; c <= LP; ++c) srow[threadIdx.x * (LP + 1) + c] = o[c];\n    }\n"
                  "    __syncthreads();\n  }\n";
-          o.s += "  for (int q = threadIdx.x; q < LNQ; q += 256) {\n    const int ci = QI[q], cj = QJ[q];\n    double t = 0.0;\n"
-                 "    for (int r = 0; r < (int)a.n_data; ++r) t = __builtin_fma(srow[r * (LP + 1) + ci], srow[r * (LP + 1) + cj], t);\n"
-                 "    sq[q] = t;\n  }\n  __syncthreads();\n  (void)lane; (void)wave; (void)nC; (void)red;\n}\n";
+          o.s += "  const int nr = (int)(a.n_data - base < LROWS ? a.n_data - base : LROWS);\n";
+          for (int k = 0; k < (NQ + 255) / 256; ++k)
+            o.f("  if (threadIdx.x + %d < LNQ) {\n    const int ci = QI[threadIdx.x + %d], cj = QJ[threadIdx.x + %d];\n    double t = qa%d;\n"
+                "    for (int r = 0; r < nr; ++r) t = __builtin_fma(srow[r * (LP + 1) + ci], srow[r * (LP + 1) + cj], t);\n    qa%d = t;\n  }\n",
+                256 * k, 256 * k, 256 * k, k, k);
+          o.s += "  __syncthreads();\n  }\n";
+          for (int k = 0; k < (NQ + 255) / 256; ++k) o.f("  if (threadIdx.x + %d < LNQ) sq[threadIdx.x + %d] = qa%d;\n", 256 * k, 256 * k, k);
+          o.s += "  __syncthreads();\n  (void)lane; (void)wave; (void)nC; (void)red;\n}\n";
           continue;
         }
         o.s += "    if (!a.n_blocks) {\n";
@@ -1570,8 +1583,13 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 bool has_fit_kernel(const Kernel *k) { return k && k->l.lm; }
 int64_t fit_row_limit(const Kernel *k, bool correlated) {
   if (!k || !k->l.lm) return 0;
-  if (k->l.n_param > NRM_MAX_P) return FIT_MAX_WIDE_ROWS;
-  return correlated ? FIT_MAX_BLOCK_ROWS : FIT_MAX_ROWS;
+  const int P = k->l.n_param;
+  if (correlated) return P > NRM_MAX_P ? fit_wide_rows(P) : FIT_MAX_BLOCK_ROWS;
+  if (P <= NRM_MAX_P) return FIT_MAX_ROWS;
+  // wide form: one workgroup adds up N products for each of P (P + 1) / 2 + P + 1 sums -- beyond ~250 000 of them per evaluation
+  // the general path's many workgroups are faster (P = 16, N = 1000: 0.43 ms here, 1.08 there; P = 32, N = 1000: 3.4 against 2.5)
+  const int64_t cap = 250000 / (P * (P + 1) / 2 + P + 1);
+  return cap < FIT_MAX_ROWS ? cap : FIT_MAX_ROWS;
 }
 bool has_batch_fit_kernel(const Kernel *kc) {
   if (!kc || !kc->fit_ok) return false;

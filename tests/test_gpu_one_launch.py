@@ -46,7 +46,7 @@ def agree(one, gen, rtol=1e-8):
     assert s1.nit == one.nit and s1.njev in (s1.nit, s1.nit + 1) and s1.nfev > s1.nit
     assert np.all(np.abs(one.pmean - gen.pmean) <= rtol * np.abs(gen.pmean) + 5e-6 * gen.psdev)
     assert abs(one.chi2 - gen.chi2) <= 1e-8 * max(gen.chi2, 1e-12) + 1e-20
-    assert np.allclose(one.cov, gen.cov, rtol=1e-5, atol=1e-300)
+    assert np.allclose(one.cov, gen.cov, rtol=1e-5, atol=1e-9 * np.max(np.abs(gen.cov)))
     assert one.logGBF == pytest.approx(gen.logGBF, rel=1e-8, abs=1e-8)
 
 
@@ -271,8 +271,25 @@ def test_up_to_32_parameters_with_the_rows_in_lds(amd, K, N, correlated, bg, mon
     assert f1 & ONE, 'the fit did not take the one-launch route'
     agree(one, gen)
     assert np.allclose(one.J, gen.J, rtol=1e-6, atol=1e-8 * np.max(np.abs(gen.J)))
-    # more rows than the kernel takes at this width: the general path, silently
-    x2, y2, yerr2, _, _, _ = bumps(K, 200, seed=1, correlated=False, background=bg)
+    # more CORRELATED rows than one chunk of the kernel's LDS rows: the general path, silently
+    x2, y2, yerr2, _, _, _ = bumps(K, 300, seed=1, correlated=True, background=bg)
+    big = amd.nonlinear_fit(data=(x2, y2, yerr2), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
+    assert not flags(big) & ONE and big.error is None
+
+
+@pytest.mark.parametrize('K,N', [(7, 1000), (10, 700), (15, 400), (6, 2000)])
+def test_wide_fits_with_many_uncorrelated_rows(amd, K, N, monkeypatch):
+    """13 .. 32 parameters on up to 4096 uncorrelated points (a spectrum with a dozen peaks): the rows pass through LDS a
+    chunk at a time, thread q keeps the running sum of product q."""
+    x, y, yerr, text, names, pt = bumps(K, N, seed=K + N, correlated=False, background=True)
+    model = amd.expr(text, names)
+    one, f1, gen = both(amd, monkeypatch, data=(x, y, yerr), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
+    assert f1 & ONE, 'the fit did not take the one-launch route'
+    agree(one, gen)
+    print('P = %d, N = %d: device run %.3f ms (general path %.3f ms), %d iterations' % (
+        pt.size, N, one.fitter_results.summary.t_run_ms, gen.fitter_results.summary.t_run_ms, one.nit))
+    # beyond ~250 000 row products per evaluation one workgroup loses to the general path's many: not taken
+    x2, y2, yerr2, _, _, _ = bumps(K, 4000, seed=2, correlated=False, background=True)
     big = amd.nonlinear_fit(data=(x2, y2, yerr2), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
     assert not flags(big) & ONE and big.error is None
 
