@@ -28,6 +28,7 @@ PYTHONPATH=$ROOT python3 $ROOT/tools/time_small_steps.py > $OUT/${R}_small_steps
 PYTHONPATH=$ROOT python3 $ROOT/tools/time_small_fit.py > $OUT/${R}_small_fits.txt 2>/dev/null
 { echo "# the same four fits through the general path (LSQAMD_ONE_LAUNCH_FIT=0)"; LSQAMD_ONE_LAUNCH_FIT=0 PYTHONPATH=$ROOT python3 $ROOT/tools/time_small_fit.py 2>/dev/null; } >> $OUT/${R}_small_fits.txt
 PYTHONPATH=$ROOT python3 $ROOT/tools/cmp_one_launch.py > $OUT/${R}_one_launch_vs_general.txt 2>/dev/null
+PYTHONPATH=$ROOT python3 $ROOT/tools/time_resample.py > $OUT/${R}_resample_small.txt 2>/dev/null
 cd $ROOT
 { echo "# the tape COMPILED at lsqamd_set_tape time (jit.hip, hiprtc; the default; this run under rocprofv3)"; grep -E "P =|residual|tape runs" $OUT/tape_default.txt
   echo "# the interpreter kernels of round 2 (LSQAMD_TAPE=i: by terms where the root is a sum, whole-tape reverse sweep otherwise)"; LSQAMD_TAPE=i PYTHONPATH=$ROOT python3 tools/time_tape.py 2>/dev/null | grep -E "P =|residual|tape runs"
