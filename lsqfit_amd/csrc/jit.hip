@@ -1329,7 +1329,7 @@ std::string generate(const Plan &pl, bool batch_only = false) {
           o.s += "  const int nr = (int)(a.n_data - base < LROWS ? a.n_data - base : LROWS);\n";
           for (int k = 0; k < (NQ + 255) / 256; ++k)
             o.f("  if (threadIdx.x + %d < LNQ) {\n    const int ci = QI[threadIdx.x + %d], cj = QJ[threadIdx.x + %d];\n    double t = qa%d;\n"
-                "    for (int r = 0; r < nr; ++r) t = __builtin_fma(srow[r * (LP + 1) + ci], srow[r * (LP + 1) + cj], t);\n    qa%d = t;\n  }\n",
+                "#pragma unroll 8\n    for (int r = 0; r < nr; ++r) t = __builtin_fma(srow[r * (LP + 1) + ci], srow[r * (LP + 1) + cj], t);\n    qa%d = t;\n  }\n",
                 256 * k, 256 * k, 256 * k, k, k);
           o.s += "  __syncthreads();\n  }\n";
           for (int k = 0; k < (NQ + 255) / 256; ++k) o.f("  if (threadIdx.x + %d < LNQ) sq[threadIdx.x + %d] = qa%d;\n", 256 * k, 256 * k, k);
@@ -1586,9 +1586,9 @@ int64_t fit_row_limit(const Kernel *k, bool correlated) {
   const int P = k->l.n_param;
   if (correlated) return P > NRM_MAX_P ? fit_wide_rows(P) : FIT_MAX_BLOCK_ROWS;
   if (P <= NRM_MAX_P) return FIT_MAX_ROWS;
-  // wide form: one workgroup adds up N products for each of P (P + 1) / 2 + P + 1 sums -- beyond ~250 000 of them per evaluation
+  // wide form: one workgroup adds up N products for each of P (P + 1) / 2 + P + 1 sums -- beyond ~400 000 of them per evaluation
   // the general path's many workgroups are faster (P = 16, N = 1000: 0.43 ms here, 1.08 there; P = 32, N = 1000: 3.4 against 2.5)
-  const int64_t cap = 250000 / (P * (P + 1) / 2 + P + 1);
+  const int64_t cap = 400000 / (P * (P + 1) / 2 + P + 1);
   return cap < FIT_MAX_ROWS ? cap : FIT_MAX_ROWS;
 }
 bool has_batch_fit_kernel(const Kernel *kc) {

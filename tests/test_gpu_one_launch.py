@@ -277,7 +277,7 @@ def test_up_to_32_parameters_with_the_rows_in_lds(amd, K, N, correlated, bg, mon
     assert not flags(big) & ONE and big.error is None
 
 
-@pytest.mark.parametrize('K,N', [(7, 1000), (10, 700), (15, 400), (6, 2000)])
+@pytest.mark.parametrize('K,N', [(7, 1000), (7, 2600), (10, 700), (15, 400), (15, 700), (6, 2000)])
 def test_wide_fits_with_many_uncorrelated_rows(amd, K, N, monkeypatch):
     """13 .. 32 parameters on up to 4096 uncorrelated points (a spectrum with a dozen peaks): the rows pass through LDS a
     chunk at a time, thread q keeps the running sum of product q."""
@@ -288,7 +288,7 @@ def test_wide_fits_with_many_uncorrelated_rows(amd, K, N, monkeypatch):
     agree(one, gen)
     print('P = %d, N = %d: device run %.3f ms (general path %.3f ms), %d iterations' % (
         pt.size, N, one.fitter_results.summary.t_run_ms, gen.fitter_results.summary.t_run_ms, one.nit))
-    # beyond ~250 000 row products per evaluation one workgroup loses to the general path's many: not taken
+    # beyond ~400 000 row products per evaluation one workgroup loses to the general path's many: not taken
     x2, y2, yerr2, _, _, _ = bumps(K, 4000, seed=2, correlated=False, background=True)
     big = amd.nonlinear_fit(data=(x2, y2, yerr2), model=model, prior=(pt, np.full(pt.size, 0.5)), p0=pt * 1.05)
     assert not flags(big) & ONE and big.error is None
