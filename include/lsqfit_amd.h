@@ -435,7 +435,7 @@ int lsqamd_timing_reset(lsqamd_fit *fit);
  * parameters, compiled formula, uncorrelated rows), bit 3 = the tape model's formula runs as compiled code (hiprtc) rather than through the
  * interpreter kernels, bit 2 = LM steps replayed from captured graphs (small
  * single-rank problems without phase timing; LSQAMD_STEP_GRAPH=0 disables), bit 5 = the last lsqamd_run was ONE
- * kernel launch (compiled formula; <= 12 parameters and <= 4096 uncorrelated or <= 256 correlated rows, or <= 32
+ * kernel launch (compiled formula; <= 12 parameters and <= 8192 uncorrelated or <= 256 correlated rows, or <= 32
  * parameters and a few hundred to two thousand rows, fewer when correlated; plain lm: every iteration of
  * gsl_multifit_nlinear_init + _driver + _covar, src/lsqfit/_gsl.pyx:676-677,:706, by one workgroup;
  * LSQAMD_ONE_LAUNCH_FIT=0 disables),

@@ -35,7 +35,7 @@ hipError_t launch_normal(const Kernel *k, hipStream_t st, const LaunchArgs &a, d
 // A whole small fit in one launch (same formulas as the normal-equation kernel: <= NRM_MAX_P parameters, uncorrelated rows):
 // plain Levenberg-Marquardt from p0 to convergence by ONE workgroup, see kLmDriver in jit.hip.  The struct is the kernel's
 // argument block, member for member.
-constexpr int FIT_MAX_ROWS = 4096, FIT_MAX_BLOCK_ROWS = 256;
+constexpr int FIT_MAX_ROWS = 8192, FIT_MAX_BLOCK_ROWS = 256;
 // ... 13 to FIT_MAX_P parameters: the rows of the Jacobian go through LDS, fit_wide_rows(P) of them at a time (a correlated fit
 // must fit one such chunk)
 constexpr int FIT_MAX_P = 32;

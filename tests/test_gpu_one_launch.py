@@ -125,8 +125,8 @@ def test_irregular_fits_fall_back(amd, monkeypatch):
     assert abs(one.nit - gen.nit) <= 1 and np.allclose(one.pmean, gen.pmean, rtol=1e-7, atol=1e-10)
     assert (one.error is None) == (gen.error is None)
     # too many rows for one workgroup: the general path, silently
-    xx = np.linspace(0.0, 5.0, 5000)
-    big = amd.nonlinear_fit(data=(xx, np.exp(-0.5 * xx) + 0.01 * rng.standard_normal(5000), np.full(5000, 0.01)),
+    xx = np.linspace(0.0, 5.0, 9000)
+    big = amd.nonlinear_fit(data=(xx, np.exp(-0.5 * xx) + 0.01 * rng.standard_normal(9000), np.full(9000, 0.01)),
                             model=amd.expr('a*exp(-b*x)', ['a', 'b']), p0=[1.0, 1.0])
     assert not flags(big) & ONE and big.error is None
 
@@ -279,7 +279,7 @@ def test_up_to_32_parameters_with_the_rows_in_lds(amd, K, N, correlated, bg, mon
 
 @pytest.mark.parametrize('K,N', [(7, 1000), (7, 2600), (10, 700), (15, 400), (15, 700), (6, 2000)])
 def test_wide_fits_with_many_uncorrelated_rows(amd, K, N, monkeypatch):
-    """13 .. 32 parameters on up to 4096 uncorrelated points (a spectrum with a dozen peaks): the rows pass through LDS a
+    """13 .. 32 parameters on up to a few thousand uncorrelated points (a spectrum with a dozen peaks): the rows pass through LDS a
     chunk at a time, thread q keeps the running sum of product q."""
     x, y, yerr, text, names, pt = bumps(K, N, seed=K + N, correlated=False, background=True)
     model = amd.expr(text, names)
@@ -294,7 +294,7 @@ def test_wide_fits_with_many_uncorrelated_rows(amd, K, N, monkeypatch):
     assert not flags(big) & ONE and big.error is None
 
 
-@pytest.mark.parametrize('N,P,maxit', [(1, 1, 5), (3, 2, 1), (5, 1, 50), (4096, 3, 30)])
+@pytest.mark.parametrize('N,P,maxit', [(1, 1, 5), (3, 2, 1), (5, 1, 50), (8192, 3, 30)])
 def test_smallest_and_largest_shapes(amd, N, P, maxit, monkeypatch):
     """One data point, one parameter, one iteration; and the largest row count the kernel takes."""
     rng = np.random.default_rng(N + P)
