@@ -1179,13 +1179,17 @@ static int enqueue_trial(lsqamd_fit *f) {
   const int64_t P = f->P;
   double *gvec = f->redbuf + f->npk;
   const bool watch = f->opt.solver == LSQAMD_SOLVER_QR;    // solver = qr: how much of each column its pivot retained
-  if (small_fuse(f) && P <= 12) {
-    // a dozen parameters at most: the whole trial solve (build, factor, substitute, trial point, record) by one wave
+  if (small_fuse(f) && P <= 32) {
+    // up to 32 parameters: the whole trial solve (build, factor, substitute, trial point, record) by one wave
     // out of the packed tile -- one launch instead of six
     {
       Scope sc(f, LSQAMD_T_CHOLESKY);
-      HIPCHK(f, launch_lm_tiny12_solve(f->st, f->redbuf, P, gvec, f->dscale, f->p_dev, f->p_trial, f->yv + P, f->lmd, f->info_dev,
-                                       watch ? 1 : 0));
+      if (P <= 12)
+        HIPCHK(f, launch_lm_tiny12_solve(f->st, f->redbuf, P, gvec, f->dscale, f->p_dev, f->p_trial, f->yv + P, f->lmd, f->info_dev,
+                                         watch ? 1 : 0));
+      else
+        HIPCHK(f, launch_lm_small_solve(f->st, f->redbuf, P, gvec, f->dscale, f->p_dev, f->p_trial, f->yv + P, f->lmd, f->info_dev,
+                                        watch ? 1 : 0));
     }
     const int rct = eval_residual_launch(f, f->p_trial, true);
     if (rct) return rct;

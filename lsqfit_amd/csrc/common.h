@@ -265,6 +265,9 @@ hipError_t launch_lm_solve_tail_small(hipStream_t st, const double *M, int64_t l
 // P <= 12: build (A + mu D^2 | g) from the packed tile, factor, solve, trial point, record -- one wave, one launch
 hipError_t launch_lm_tiny12_solve(hipStream_t st, const double *apk, int64_t P, const double *g, const double *d,
                                   const double *x, double *xt, double *v_out, double *lmd, int32_t *chol_info, int watch);
+// 13 <= P <= 32: the same, T = 16 / 24 / 32 elimination steps with scalar-register broadcasts
+hipError_t launch_lm_small_solve(hipStream_t st, const double *apk, int64_t P, const double *g, const double *d,
+                                 const double *x, double *xt, double *v_out, double *lmd, int32_t *chol_info, int watch);
 // q = [J^T J upper | J^T f | chi2] of the fused normal-equation kernel -> packed tile (+ prior precision), gvec
 hipError_t launch_nrm_unpack(hipStream_t st, const double *q, int64_t P, double *apk, double *gvec, const double *prior,
                              int32_t prior_dense);

@@ -1058,6 +1058,115 @@ hipError_t launch_lm_tiny12_solve(hipStream_t stream, const double *apk, int64_t
   return hipGetLastError();
 }
 
+// ---- 13 .. 32 parameters: the same one-launch trial solve, one wave, T = 16 / 24 / 32 elimination steps ----------------
+// The formulation of the whole-fit kernel's solve (jit.hip lm_solve): lane j holds column j of the upper triangle, lane T
+// the right-hand side; every cross-lane read names its lane at compile time (v_readlane: the value arrives in scalar
+// registers), pivots are inverted by v_rsq_f64 + two Newton steps, the back substitution runs on a wave-uniform copy of
+// the right-hand side.  P < T: unit diagonal in the padding.  Outputs as lm_tiny12_solve_kernel.
+__device__ __forceinline__ double rl_d(double v, int lane) {
+  union { double d; int i[2]; } u;
+  u.d = v;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+  return u.d;
+}
+
+__device__ __forceinline__ double rsqrt_newton2(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  const double h = -0.5 * d;
+  double e = __builtin_fma(h * y, y, 0.5);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(h * y, y, 0.5);
+  return __builtin_fma(y, e, y);
+}
+
+template <int T>
+__global__ __launch_bounds__(64) void lm_small_solve_kernel(const double *apk, int P, const double *g, const double *d,
+                                                            const double *x, double *xt, double *v_out, double *st,
+                                                            int32_t *chol_info, int watch) {
+  const int lane = threadIdx.x;
+  const double mu = st[LMS_MU];
+  const int col = lane < P ? lane : P - 1;
+  const double dl = d[col], gl = g[col], dmu = mu * dl * dl;
+  double m[T], uinv[T];
+  double diag0 = 1.0;
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const int ic = i < P ? i : P - 1;                       // (clamped address; selected below)
+    const double av = apk[ic * TB + col], gv = g[ic];
+    double v = (lane < P && i <= lane && i < P) ? av : 0.0;
+    if (i == lane) {
+      if (i < P) { v += dmu; diag0 = v; }
+      else v = 1.0;                                          // padding: unit diagonal
+    }
+    m[i] = lane == T ? (i < P ? gv : 0.0) : v;
+  }
+  int fail = 0;
+  double pmin = INFINITY;
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    const double pk = rl_d(m[k], k);
+    if (!(pk > 0.0) && fail == 0) fail = k + 1;
+    const double inv = rsqrt_newton2(pk > 0.0 ? pk : 1.0);
+    uinv[k] = inv;
+    if (lane == k) pmin = pk;
+    if (lane >= k) m[k] = (lane == k) ? pk * inv : m[k] * inv;
+#pragma unroll
+    for (int i = k + 1; i < T; ++i) {
+      const double ui = rl_d(m[k], i);
+      if (lane >= i) m[i] -= ui * m[k];
+    }
+  }
+  double y[T], v[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) y[i] = rl_d(m[i], T);
+#pragma unroll
+  for (int k = T - 1; k >= 0; --k) {
+    v[k] = y[k] * uinv[k];
+#pragma unroll
+    for (int i = 0; i < k; ++i) y[i] -= rl_d(m[i], k) * v[k];
+  }
+  const bool bad = fail != 0;
+  double vl = 0.0, vg = 0.0, dv2 = 0.0, nf = 0.0;
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    vl = lane == k ? v[k] : vl;
+    const double gk = rl_d(gl, k < 63 ? k : 63), dk = rl_d(dl, k < 63 ? k : 63);
+    if (k < P) {                                             // (uniform)
+      vg = __builtin_fma(v[k], gk, vg);
+      const double t = dk * v[k];
+      dv2 = __builtin_fma(t, t, dv2);
+      nf += (v[k] - v[k] == 0.0) ? 0.0 : 1.0;
+    }
+  }
+  if (bad) { vl = NAN; nf = 1.0; }
+  if (lane < P) {
+    v_out[lane] = vl;
+    xt[lane] = x[lane] - vl;
+    pmin = pmin / diag0;
+  } else {
+    pmin = INFINITY;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pmin = fmin(pmin, __shfl_xor(pmin, o, 64));
+  if (lane == 0) {
+    chol_info[0] = fail;
+    st[LMS_VG] = vg;
+    st[LMS_DV2] = dv2;
+    st[LMS_VFINITE] = nf == 0.0 ? 1.0 : 0.0;
+    st[LMS_PIVMIN] = (watch && !bad) ? pmin : 1.0;
+  }
+}
+
+hipError_t launch_lm_small_solve(hipStream_t stream, const double *apk, int64_t P, const double *g, const double *d,
+                                 const double *x, double *xt, double *v_out, double *st, int32_t *chol_info, int watch) {
+  if (P < 1 || P > 32) return hipErrorInvalidValue;
+  if (P <= 16) hipLaunchKernelGGL(lm_small_solve_kernel<16>, dim3(1), dim3(64), 0, stream, apk, (int)P, g, d, x, xt, v_out, st, chol_info, watch);
+  else if (P <= 24) hipLaunchKernelGGL(lm_small_solve_kernel<24>, dim3(1), dim3(64), 0, stream, apk, (int)P, g, d, x, xt, v_out, st, chol_info, watch);
+  else hipLaunchKernelGGL(lm_small_solve_kernel<32>, dim3(1), dim3(64), 0, stream, apk, (int)P, g, d, x, xt, v_out, st, chol_info, watch);
+  return hipGetLastError();
+}
+
 // ---- small fits: the tail of a trial in ONE single-workgroup launch ------------------------------------------
 // |f_trial|^2 over n <= 65536 residuals, the prior's share for a diagonal (or absent) prior -- t = Lambda (p - pbar)
 // is left in tvec for the accepted branch, as prior_vec_kernel does -- and the decision of lm_trial_tail_kernel:

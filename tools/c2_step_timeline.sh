@@ -2,7 +2,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/r3_c2gaps
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-PYTHONPATH=$ROOT rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $ROOT/tools/time_small_steps.py 4096 256 > $OUT/out.txt 2> $OUT/err.txt
+PYTHONPATH=$ROOT rocprofv3 --kernel-trace --output-format csv -d $OUT/t -- python3 $ROOT/tools/time_small_steps.py ${SHAPE:-4096 256} > $OUT/out.txt 2> $OUT/err.txt
 f=$(find $OUT/t -name "*kernel_trace.csv" | head -1)
 python3 - "$f" > $OUT/gaps.txt <<'PY'
 import csv, sys
