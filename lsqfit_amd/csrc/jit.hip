@@ -687,12 +687,9 @@ static __device__ void lm_solve(const double *sA, const double *sG, const double
     const double inv = lm_rsqrt(pk > 0.0 ? pk : 1.0);
     uinv[k] = inv;
     if (lane == k) pmin = pk;               // (this lane's pivot; divided by the damped diagonal entry below)
-    if (lane >= k) m[k] = (lane == k) ? pk * inv : m[k] * inv;
+    m[k] *= inv;                            // (unconditional, like the updates: what lands below the diagonal is never read)
 #pragma unroll
-    for (int i = k + 1; i < LP; ++i) {
-      const double ui = lm_rl(m[k], i);
-      if (lane >= i) m[i] -= ui * m[k];
-    }
+    for (int i = k + 1; i < LP; ++i) m[i] = __builtin_fma(-lm_rl(m[k], i), m[k], m[i]);
   }
   // U v = y: y (lane LP's column) wave-uniform, v_k = y_k / U_kk, then y_i -= U_ik v_k for the rows above
   double y[LP], v[LP];
@@ -758,17 +755,16 @@ static __device__ int lm_cov(const double *sA, double *cov, long long ldc, doubl
     const double inv = lm_rsqrt(pk > 0.0 ? pk : 1.0);
     uinv[k] = inv;
     ld += log(pk > 0.0 ? pk : 1.0);
-    if (lane >= k) m[k] = (lane == k) ? pk * inv : m[k] * inv;
+    m[k] *= inv;
 #pragma unroll
-    for (int i = k + 1; i < LP; ++i) {
-      const double ui = lm_rl(m[k], i);
-      if (lane >= i) m[i] -= ui * m[k];
-    }
+    for (int i = k + 1; i < LP; ++i) m[i] = __builtin_fma(-lm_rl(m[k], i), m[k], m[i]);
   }
   double v[LP];
 #pragma unroll
   for (int k = LP - 1; k >= 0; --k) {
-    v[k] = m[k] * uinv[k];                 // (lanes LP ..: m holds this lane's forward-substituted right-hand side)
+    // (lanes LP ..: m holds this lane's forward-substituted right-hand side; the lanes that hold U itself must not move --
+    //  what the unconditional elimination left below their diagonals would otherwise be fed back into U)
+    v[k] = lane >= LP ? m[k] * uinv[k] : 0.0;
 #pragma unroll
     for (int i = 0; i < k; ++i) m[i] -= lm_rl(m[i], k) * v[k];
   }

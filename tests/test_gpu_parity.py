@@ -270,10 +270,13 @@ def test_maxit_reports_nonconvergence(amd):
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-8
 
 
-def test_reduce_hook_on_device_single_rank(amd):
+def test_reduce_hook_on_device_single_rank(amd, monkeypatch):
     """The all-reduce hook path (RCCL through torch.distributed on a float64 view of the
     handle's workspace) with a one-rank group: identical results to the hook-free fit."""
     import os
+    # (a hook-free single-rank fit of this size takes fused single-wave / single-workgroup kernels a handle with a hook does
+    #  not -- same arithmetic up to the order of a few sums; bit-for-bit identity is a statement about the general kernels)
+    monkeypatch.setenv('LSQAMD_SMALL_FUSE', '0')
     import torch.distributed as dist
     from lsqfit_amd import synth
     from lsqfit_amd.dist import cuda_sync, make_reduce_hook
