@@ -35,6 +35,13 @@ def fcn(x, p):
     return p[0] * dual.exp(-p[1] * X) + p[2] / (1 + p[3] * X ** 2) + p[4] * X + 0.0 * p[5]
 
 
+@pytest.fixture(autouse=True)
+def general_path(monkeypatch):
+    # (these tests are about the many-workgroup route of larger fits; a fit of up to 8192 rows would otherwise be ONE launch,
+    #  tests/test_gpu_one_launch.py)
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '0')
+
+
 @pytest.fixture(scope='module')
 def amd():
     import lsqfit_amd
@@ -81,7 +88,7 @@ def test_fused_and_unfused_paths_agree(amd, tmp_path):
             'fit = amd.nonlinear_fit(data=(x, y, sd), model=amd.expr(TEXT, NAMES), prior=prior, tol=1e-10)\n'
             'assert not (fit.problem.lib.lsqamd_debug_flags(fit.problem.h) & 16)\n'
             'np.savez(%r, pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit)\n' % (ROOT, str(tmp_path / 'o.npz')))
-    r = subprocess.run([sys.executable, '-c', prog], env=dict(os.environ, LSQAMD_FUSED_NORMAL='0'), cwd=ROOT,
+    r = subprocess.run([sys.executable, '-c', prog], env=dict(os.environ, LSQAMD_FUSED_NORMAL='0', LSQAMD_ONE_LAUNCH_FIT='0'), cwd=ROOT,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     o = np.load(str(tmp_path / 'o.npz'))
