@@ -310,3 +310,30 @@ def test_smallest_and_largest_shapes(amd, N, P, maxit, monkeypatch):
     assert f1 & ONE
     agree(one, gen)
     assert one.stopping_criterion == gen.stopping_criterion and (one.error is None) == (gen.error is None)
+
+
+@pytest.mark.parametrize('wide', [False, True])
+def test_bootstrap_copies_of_a_correlated_fit(amd, wide, monkeypatch):
+    """Copies of a fit with covariance blocks (and, `wide`, with more than a dozen parameters): the batched kernel whitens
+    each copy's rows itself; against the lockstep engine and against single fits of the copies' data."""
+    if wide:
+        x, y, yerr, text, names, pt = bumps(7, 96, seed=5, correlated=True)
+        psd = np.full(pt.size, 0.5)
+    else:
+        x, y, yerr, pt = correlated(96, seed=4, nblocks=3)
+        text, names, psd = 'a*exp(-b*x) + c*exp(-d*x)', ['a', 'b', 'c', 'd'], np.array([1.0, 0.5, 0.5, 0.2])
+    model = amd.expr(text, names)
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    fit = amd.nonlinear_fit(data=(x, y, yerr), model=model, prior=(pt, psd), p0=pt * 1.05)
+    one = fit.bootstrapped_fits(24, seed=9)
+    assert one['rounds'] == 1
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '0')
+    lock = fit.bootstrapped_fits(24, seed=9)
+    assert lock['rounds'] > 1 and np.array_equal(one['ymeans'], lock['ymeans'])
+    assert np.max(np.abs(one['pmean'] - lock['pmean']) / lock['psdev']) < 1e-5
+    assert np.allclose(one['chi2'], lock['chi2'], rtol=1e-8) and np.allclose(one['psdev'], lock['psdev'], rtol=1e-5)
+    assert np.allclose(one['logGBF'], lock['logGBF'], rtol=1e-8, atol=1e-7)
+    monkeypatch.setenv('LSQAMD_ONE_LAUNCH_FIT', '1')
+    for k in (0, 23):
+        single = amd.nonlinear_fit(data=(x, one['ymeans'][k], yerr), model=model, prior=(one['prior_means'][k], psd), p0=fit.pmean)
+        assert single.nit == one['nit'][k] and np.array_equal(single.pmean, one['pmean'][k])
