@@ -692,6 +692,10 @@ static __device__ void lm_solve(const double *sA, const double *sG, const double
     for (int i = k + 1; i < LP; ++i) m[i] = __builtin_fma(-lm_rl(m[k], i), m[k], m[i]);
   }
   // U v = y: y (lane LP's column) wave-uniform, v_k = y_k / U_kk, then y_i -= U_ik v_k for the rows above
+  // (the compiler sees that the back substitution broadcasts what the sweep broadcast already and keeps all of it alive in
+  //  spilled scalar registers -- two v_writelane and two v_readlane per value: cheaper to broadcast again)
+#pragma unroll
+  for (int i = 0; i < LP; ++i) asm volatile("" : "+v"(m[i]));
   double y[LP], v[LP];
 #pragma unroll
   for (int i = 0; i < LP; ++i) y[i] = lm_rl(m[i], LP);
@@ -759,6 +763,8 @@ static __device__ int lm_cov(const double *sA, double *cov, long long ldc, doubl
 #pragma unroll
     for (int i = k + 1; i < LP; ++i) m[i] = __builtin_fma(-lm_rl(m[k], i), m[k], m[i]);
   }
+#pragma unroll
+  for (int i = 0; i < LP; ++i) asm volatile("" : "+v"(m[i]));
   double v[LP];
 #pragma unroll
   for (int k = LP - 1; k >= 0; --k) {

@@ -1087,20 +1087,29 @@ __global__ __launch_bounds__(64) void lm_small_solve_kernel(const double *apk, i
   const int lane = threadIdx.x;
   const double mu = st[LMS_MU];
   const int col = lane < P ? lane : P - 1;
-  const double dl = d[col], gl = g[col], dmu = mu * dl * dl;
-  double m[T], uinv[T];
-  double diag0 = 1.0;
-#pragma unroll
-  for (int i = 0; i < T; ++i) {
-    const int ic = i < P ? i : P - 1;                       // (clamped address; selected below)
-    const double av = apk[ic * TB + col], gv = g[ic];
-    double v = (lane < P && i <= lane && i < P) ? av : 0.0;
-    if (i == lane) {
-      if (i < P) { v += dmu; diag0 = v; }
-      else v = 1.0;                                          // padding: unit diagonal
-    }
-    m[i] = lane == T ? (i < P ? gv : 0.0) : v;
+  const double dl = d[col], gl = g[col];
+  // the damped matrix and the right-hand side (column T) go through LDS: filled element-parallel (padding included), read back
+  // as one unconditional load per register -- loaded straight from the tile, every register came with its own address
+  // clamp and three lane masks, all set up front: 1200 scalar-register spills
+  __shared__ double sM[T * (T + 1)];
+  for (int e = lane; e < T * (T + 1); e += 64) {
+    const int i = e / (T + 1), j = e % (T + 1);
+    double v = 0.0;
+    if (i < P) {
+      if (j == T) v = g[i];
+      else if (j < P && i <= j) {
+        v = apk[i * TB + j];
+        if (i == j) { const double di = d[i]; v += mu * di * di; }
+      }
+    } else if (i == j) v = 1.0;                  // padding: unit diagonal
+    sM[e] = v;
   }
+  __syncthreads();
+  double m[T], uinv[T];
+  const int jc = lane < T ? lane : T;            // (lanes beyond T: a copy of the right-hand side, never read)
+#pragma unroll
+  for (int i = 0; i < T; ++i) m[i] = sM[i * (T + 1) + jc];
+  const double diag0 = lane < P ? sM[lane * (T + 1) + lane] : 1.0;
   int fail = 0;
   double pmin = INFINITY;
 #pragma unroll
@@ -1116,6 +1125,10 @@ __global__ __launch_bounds__(64) void lm_small_solve_kernel(const double *apk, i
 #pragma unroll
     for (int i = k + 1; i < T; ++i) m[i] = __builtin_fma(-rl_d(m[k], i), m[k], m[i]);
   }
+  // (the compiler sees that the back substitution broadcasts the values the sweep broadcast already and keeps all 500 of them
+  //  alive in spilled scalar registers, two v_writelane and two v_readlane each: cheaper to broadcast them again)
+#pragma unroll
+  for (int i = 0; i < T; ++i) asm volatile("" : "+v"(m[i]));
   double y[T], v[T];
 #pragma unroll
   for (int i = 0; i < T; ++i) y[i] = rl_d(m[i], T);
