@@ -169,6 +169,46 @@ void stream_give(hipStream_t s) {
   (void)hipStreamDestroy(s);
 }
 
+// ---- host inputs of small problems: staged through pinned memory, uploaded without a wait -------------------------------
+// A pageable source makes hipMemcpyAsync + the synchronisation the caller's buffer needs cost 14-20 us per setter -- four of
+// them were a fifth of a whole small fit.  Small inputs (<= 16 KB each, 64 KB between two drains of the stream) are copied
+// into a pinned arena the handle owns and uploaded from there: the setter returns at once, the stream orders the rest.
+struct Upload {
+  lsqamd_fit *f;
+  bool waited_for = false;      // something went the direct way: the caller must synchronise before it returns
+  explicit Upload(lsqamd_fit *fit) : f(fit) {}
+  static bool is_host(const void *p) {
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return true; }   // unregistered host memory
+    return a.type != hipMemoryTypeDevice && a.type != hipMemoryTypeManaged;
+  }
+  hipError_t operator()(void *dst, const void *src, size_t bytes, bool maybe_device = false) {
+    constexpr size_t ARENA = 64 << 10, ONE = 16 << 10;
+    if (bytes == 0) return hipSuccess;
+    if (bytes <= ONE && (!maybe_device || is_host(src))) {
+      if (!f->stage) {
+        f->stage = static_cast<char *>(pinned_take(ARENA, &f->stage_bytes));
+        f->stage_off = 0;
+      }
+      if (f->stage) {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (f->stage_off + need > f->stage_bytes) {       // arena full: drain the stream, start over
+          hipError_t e = hipStreamSynchronize(f->st);
+          if (e != hipSuccess) return e;
+          f->stage_off = 0;
+        }
+        std::memcpy(f->stage + f->stage_off, src, bytes);
+        hipError_t e = hipMemcpyAsync(dst, f->stage + f->stage_off, bytes, hipMemcpyHostToDevice, f->st);
+        f->stage_off += need;
+        return e;
+      }
+    }
+    waited_for = true;
+    return hipMemcpyAsync(dst, src, bytes, maybe_device ? hipMemcpyDefault : hipMemcpyHostToDevice, f->st);
+  }
+  hipError_t finish() { return waited_for ? hipStreamSynchronize(f->st) : hipSuccess; }
+};
+
 hipEvent_t take_event(lsqamd_fit *f) {  // events are recycled: creating one costs ~10 us
   hipEvent_t e = nullptr;
   if (!f->event_pool.empty()) {
@@ -1752,8 +1792,8 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   {
     std::vector<int32_t> wm(4 * (size_t)f->syrk_nwork);
     syrk_work_fill(f->P, f->splits, wm.data());
-    if (hipMemcpyAsync(f->syrk_map, wm.data(), wm.size() * sizeof(int32_t), hipMemcpyHostToDevice, f->st) != hipSuccess ||
-        hipStreamSynchronize(f->st) != hipSuccess) {
+    Upload up(f);     // (a local: staged through pinned memory when small, else waited for)
+    if (up(f->syrk_map, wm.data(), wm.size() * sizeof(int32_t)) != hipSuccess || up.finish() != hipSuccess) {
       delete f;
       return LSQAMD_EHIP;
     }
@@ -1776,8 +1816,11 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
   if (!f) return LSQAMD_EINVAL;
   if (!x || n_rows != f->N || n_x != (f->cfg.n_x > 0 ? f->cfg.n_x : 1))
     FAIL(f, LSQAMD_EINVAL, "set_x: expected %lld x %d", (long long)f->N, f->cfg.n_x);
-  HIPCHK(f, hipMemcpyAsync(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice, f->st));
-  HIPCHK(f, hipStreamSynchronize(f->st));
+  {
+    Upload up(f);
+    HIPCHK(f, up(f->x, x, sizeof(double) * n_rows * n_x));
+    HIPCHK(f, up.finish());
+  }
   f->drop_step_graphs();   // captured steps bake xmax (and the path choices behind have_x) in by value
   f->xmax = 0.0;
   for (int64_t i = 0; i < n_rows * n_x; ++i) {
@@ -1888,15 +1931,17 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
       f->tape_single = most <= 1 ? (least == 1 ? 2 : 1) : 0;
     }
     f->tape_n_seg = (int32_t)(seg.size() / 3);
-    HIPCHK(f, hipMemcpyAsync(f->tape_poff, poff.data(), sizeof(int32_t) * (n_code + 1), hipMemcpyHostToDevice, f->st));
-    if (!seg.empty())
-      HIPCHK(f, hipMemcpyAsync(f->tape_seg, seg.data(), sizeof(int32_t) * seg.size(), hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipStreamSynchronize(f->st));   // (poff, seg are locals)
+    Upload up(f);
+    HIPCHK(f, up(f->tape_poff, poff.data(), sizeof(int32_t) * (n_code + 1)));
+    if (!seg.empty()) HIPCHK(f, up(f->tape_seg, seg.data(), sizeof(int32_t) * seg.size()));
+    HIPCHK(f, up.finish());   // (poff, seg are locals: staged copies or a wait)
   }
-  HIPCHK(f, hipMemcpyAsync(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice, f->st));
-  if (n_consts > 0)
-    HIPCHK(f, hipMemcpyAsync(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice, f->st));
-  HIPCHK(f, hipStreamSynchronize(f->st));
+  {
+    Upload up(f);
+    HIPCHK(f, up(f->tape, code, sizeof(int32_t) * n_code));
+    if (n_consts > 0) HIPCHK(f, up(f->consts, consts, sizeof(double) * n_consts));
+    HIPCHK(f, up.finish());
+  }
   f->n_tape = n_code;
   f->have_tape = true;
   // the formula as straight-line code for gfx950 (hiprtc, cached by content); without it the interpreter
@@ -1988,19 +2033,20 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
   f->uniform_tri = all_tri ? 1 : 0;  // mixed blocks run batched without the triangular shortcut
   if (off > f->cfg.sum_block_sq || maxb > f->cfg.max_block)
     FAIL(f, LSQAMD_EINVAL, "set_data: blocks exceed the sizes promised in the config");
+  Upload up(f);
   if (N > 0) {
-    HIPCHK(f, hipMemcpyAsync(f->ymean, ymean, sizeof(double) * N, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->wdiag, wdiag, sizeof(double) * N, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->in_block, inb.data(), (size_t)N, hipMemcpyHostToDevice, f->st));
+    HIPCHK(f, up(f->ymean, ymean, sizeof(double) * N));
+    HIPCHK(f, up(f->wdiag, wdiag, sizeof(double) * N));
+    HIPCHK(f, up(f->in_block, inb.data(), (size_t)N));
   }
   if (n_blocks > 0) {
     if (!wt) FAIL(f, LSQAMD_EINVAL, "set_data: null block weights");
-    HIPCHK(f, hipMemcpyAsync(f->blk_row0, f->h_row0.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->blk_size, f->h_size.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->blk_woff, f->h_woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice, f->st));
-    HIPCHK(f, hipMemcpyAsync(f->wt, wt, sizeof(double) * off, hipMemcpyDefault, f->st));   // host or device source
+    HIPCHK(f, up(f->blk_row0, f->h_row0.data(), sizeof(int64_t) * n_blocks));
+    HIPCHK(f, up(f->blk_size, f->h_size.data(), sizeof(int64_t) * n_blocks));
+    HIPCHK(f, up(f->blk_woff, f->h_woff.data(), sizeof(int64_t) * n_blocks));
+    HIPCHK(f, up(f->wt, wt, sizeof(double) * off, true));   // host or device source
   }
-  HIPCHK(f, hipStreamSynchronize(f->st));
+  HIPCHK(f, up.finish());
   f->have_data = true;
   return 0;
 }
@@ -2008,8 +2054,11 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
 int lsqamd_set_ymean(lsqamd_fit *f, const double *ymean) {
   if (!f || !ymean) return LSQAMD_EINVAL;
   if (!f->have_data) FAIL(f, LSQAMD_EINVAL, "set_ymean: call lsqamd_set_data first");
-  if (f->N > 0) HIPCHK(f, hipMemcpyAsync(f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice, f->st));
-  HIPCHK(f, hipStreamSynchronize(f->st));
+  {
+    Upload up(f);
+    if (f->N > 0) HIPCHK(f, up(f->ymean, ymean, sizeof(double) * f->N));
+    HIPCHK(f, up.finish());
+  }
   f->have_cov = false;
   return 0;
 }
@@ -2019,10 +2068,12 @@ int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) {
   if (!f->cfg.has_prior) FAIL(f, LSQAMD_EINVAL, "set_prior: the config says has_prior = 0");
   if (!mean || !prec) FAIL(f, LSQAMD_EINVAL, "set_prior: null argument");
   const int64_t P = f->P;
-  HIPCHK(f, hipMemcpyAsync(f->prior_mean, mean, sizeof(double) * P, hipMemcpyHostToDevice, f->st));
-  HIPCHK(f, hipMemcpyAsync(f->prior_prec, prec, sizeof(double) * (f->cfg.prior_dense ? P * P : P),
-                           hipMemcpyDefault, f->st));   // host or device source
-  HIPCHK(f, hipStreamSynchronize(f->st));
+  {
+    Upload up(f);
+    HIPCHK(f, up(f->prior_mean, mean, sizeof(double) * P));
+    HIPCHK(f, up(f->prior_prec, prec, sizeof(double) * (f->cfg.prior_dense ? P * P : P), true));   // host or device source
+    HIPCHK(f, up.finish());
+  }
   f->have_prior = true;
   return 0;
 }
@@ -2321,7 +2372,7 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   rc = (f->used_one_launch && f->have_cov) ? 0 : do_covariance(f);
   if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
   (void)hipEventRecord(ev.b, f->st);
-  (void)hipEventSynchronize(ev.b);
+  if (hipEventSynchronize(ev.b) == hipSuccess) f->stage_off = 0;   // (the stream has drained: the staging arena is free again)
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, ev.a, ev.b);
   if (f->timing) resolve_timers(f);

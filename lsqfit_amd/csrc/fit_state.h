@@ -141,6 +141,10 @@ struct lsqamd_fit {
   bool used_one_launch = false;   // the last lsqamd_run was ONE launch (api.hip run_one_launch); lsqamd_debug_flags bit 5
   std::vector<hipEvent_t> event_pool;
   size_t pin_bytes = 0;     // size class the pinned block came with (pinned_take)
+  // pinned staging arena for small host inputs (api.hip Upload): a setter copies in, queues the upload and returns
+  // without waiting for the stream; regions are not reused before a point where the stream is known to have drained
+  char *stage = nullptr;
+  size_t stage_bytes = 0, stage_off = 0;
 
   // timing
   bool timing = false;
@@ -171,6 +175,7 @@ struct lsqamd_fit {
       }
     for (hipEvent_t e : event_pool) lsqamd_host::event_give(e);
     if (pin) lsqamd_host::pinned_give(pin, pin_bytes);
+    if (stage) lsqamd_host::pinned_give(stage, stage_bytes);
     lsqamd_host::comm_release(this);
   }
 };
