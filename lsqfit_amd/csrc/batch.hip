@@ -1063,15 +1063,15 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
   f->ran = true;
   f->have_cov = f->one_launch && f->have_cov_from_run;     // (the one-launch kernel leaves covariances and log dets behind)
   if (summaries) {
-    std::vector<double> mu((size_t)B), chi2((size_t)B);
-    std::vector<int32_t> nit((size_t)B), info((size_t)B), status((size_t)B), nfev((size_t)B), njev((size_t)B);
-    BHIP(f, hipMemcpy(mu.data(), f->s.mu, sizeof(double) * B, hipMemcpyDeviceToHost));
-    BHIP(f, hipMemcpy(chi2.data(), f->s.chi2, sizeof(double) * B, hipMemcpyDeviceToHost));
-    BHIP(f, hipMemcpy(nit.data(), f->s.nit, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    BHIP(f, hipMemcpy(info.data(), f->s.info, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    BHIP(f, hipMemcpy(status.data(), f->s.status, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    BHIP(f, hipMemcpy(nfev.data(), f->s.nfev, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
-    BHIP(f, hipMemcpy(njev.data(), f->s.njev, sizeof(int32_t) * B, hipMemcpyDeviceToHost));
+    // the per-fit scalars lie one after the other in the workspace (carve_b: s.mu .. s.njev): ONE copy instead of seven
+    const char *lo = reinterpret_cast<const char *>(f->s.mu), *hi = reinterpret_cast<const char *>(f->s.njev + B);
+    std::vector<char> span((size_t)(hi - lo));
+    BHIP(f, hipMemcpy(span.data(), lo, span.size(), hipMemcpyDeviceToHost));
+    auto at = [&](const void *dev) { return span.data() + (reinterpret_cast<const char *>(dev) - lo); };
+    const double *mu = reinterpret_cast<const double *>(at(f->s.mu)), *chi2 = reinterpret_cast<const double *>(at(f->s.chi2));
+    const int32_t *nit = reinterpret_cast<const int32_t *>(at(f->s.nit)), *info = reinterpret_cast<const int32_t *>(at(f->s.info));
+    const int32_t *status = reinterpret_cast<const int32_t *>(at(f->s.status)), *nfev = reinterpret_cast<const int32_t *>(at(f->s.nfev));
+    const int32_t *njev = reinterpret_cast<const int32_t *>(at(f->s.njev));
     for (int64_t b = 0; b < B; ++b) {
       lsqamd_summary &s = summaries[b];
       std::memset(&s, 0, sizeof(s));
