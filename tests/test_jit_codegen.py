@@ -130,3 +130,27 @@ def test_constants_that_differ_from_term_to_term_become_a_table(lib):
     assert 'static __device__ const double CT0_0[16] = {0x1p+0,0x1p+1,0x1.8p+1,0x1p+2,0x1.4p+2,0x1.8p+2,0x1.cp+2,0x1p+3,' in src
     jac = body(src, 'lsqamd_jit_jac')
     assert 'CT0_0[k]' in jac and '0x1p-1' in jac and 'CT0_1' not in src
+
+
+def test_whole_fit_kernel_forms(lib):
+    """The whole-fit kernel (lsqamd_jit_lm): register sums up to a dozen parameters, rows through LDS up to 32, none beyond
+    that or for formulas with wide sums (one wave per data row); the batched entry point is a module of its own."""
+    import lsqfit_amd as amd
+
+    def peaks(K):
+        names = ['a%d' % k for k in range(K)] + ['b%d' % k for k in range(K)]
+        return amd.expr(' + '.join('a%d*exp(-b%d*(x - %d.5)**2)' % (k, k, k) for k in range(K)), names)
+    rc, variant, src = codegen(lib, peaks(4))                 # P = 8: sums in registers
+    assert rc == 0 and variant == 0 and 'void lsqamd_jit_lm(LmArgs a)' in src
+    assert 'constexpr int LP = 8,' in src and 'LROWS = 256, LRED = %d;' % (16 * (8 * 9 // 2 + 9)) in src and 'QI[LNQ]' not in src
+    assert 'lsqamd_jit_lmb' not in src                        # (built on demand, from the same generator)
+    rc, variant, src = codegen(lib, peaks(15))                # P = 30: rows through LDS, 128 at a time
+    assert rc == 0 and variant == 0 and 'void lsqamd_jit_lm(LmArgs a)' in src
+    assert 'constexpr int LP = 30,' in src and 'LROWS = 128, LRED = 16;' in src and 'QI[LNQ]' in src and 'QJ[LNQ]' in src
+    assert 'lsqamd_jit_nrm' not in src                        # (the many-workgroup sums stop at a dozen parameters)
+    rc, variant, src = codegen(lib, peaks(9))                 # P = 18: 256 rows at a time
+    assert rc == 0 and 'LROWS = 256, LRED = 16;' in src
+    rc, variant, src = codegen(lib, peaks(17), compile=0)     # P = 34: beyond the kernel
+    assert rc == 0 and 'lsqamd_jit_lm' not in src
+    rc, variant, src = codegen(lib, amd.models.tape_sum('a*cos(w*x)', 16), compile=0)   # 16 look-alike terms: one wave per row
+    assert rc == 0 and variant == 1 and 'lsqamd_jit_lm' not in src
