@@ -2225,7 +2225,7 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   if (!lsqamd_jit::has_fit_kernel(k) || P > lsqamd_jit::FIT_MAX_P || f->N < 1 ||
       f->N > lsqamd_jit::fit_row_limit(k, f->cfg.n_blocks != 0)) return 0;
   if (f->opt.trs != LSQAMD_TRS_LM || !f->linear.empty() || getenv("LSQAMD_HOST_LM") || f->opt.maxit < 1) return 0;
-  if (f->opt.maxit > 100000) return 0;     // (a kernel cannot be interrupted: runs of that length stay on the host-driven path)
+  if (f->opt.maxit > 20000) return 0;      // (a kernel cannot be interrupted: runs of that length stay on the host-driven path)
   if (f->comm || f->reduce || f->timing || !small_fuse(f) || !f->progs.empty() || f->have_param_rows) return 0;
   // correlated rows: the workgroup whitens them itself (one row per thread, the raw rows in LDS) -- up to 256 rows in all
   if (f->cfg.n_blocks > 64) return 0;

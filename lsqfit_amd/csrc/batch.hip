@@ -961,7 +961,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     const lsqamd_jit::Kernel *k = static_cast<const lsqamd_jit::Kernel *>(f->jit);
     const bool rows_ok = f->N <= lsqamd_jit::fit_row_limit(k, f->cfg.n_blocks != 0) && f->cfg.n_blocks <= 64;
     if (!(e && e[0] == '0') && lsqamd_jit::has_batch_fit_kernel(k) && P <= lsqamd_jit::FIT_MAX_P && f->N >= 1 && rows_ok &&
-        f->opt.maxit >= 1 && f->opt.maxit <= 100000 && f->opt.trs == LSQAMD_TRS_LM) {
+        f->opt.maxit >= 1 && f->opt.maxit <= 20000 && f->opt.trs == LSQAMD_TRS_LM) {
       const int64_t red_stride = f->npk + P + 1, w_stride = f->nblk * 128 * 128;
       lsqamd_jit::FitArgs a;
       a.x = f->x; a.ymean = f->ymean; a.wdiag = f->wdiag; a.n_data = f->N;
