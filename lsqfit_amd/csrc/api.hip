@@ -649,7 +649,6 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   }
   f->J_stale = false;
   f->nrm_in_tail = 0;
-  f->cs_in_tail = 0;
   if (nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
       f->h_row0[0] == 0 && (int64_t)nbk * B0 == f->N && whiten_synth_eligible(f->cfg.model, B0, P) &&
       (int64_t)nbk * (B0 / 128) * P <= slab_doubles) {
@@ -722,14 +721,11 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     // the slab sum and the prior precision in ONE pass over the packed tiles
     HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
                                    with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
-    f->prior_deferred = with_prior && r_here && !mirror && small_fuse(f);
-    // small single-rank fits: the accept-tail kernel totals the per-split sums of J^T f itself (same order as colsum_reduce:
-    // one launch fewer); the prior's share must then be the deferred one, which that kernel adds afterwards
-    f->cs_in_tail = (syrk_colsum && !mirror && small_fuse(f) && P <= 1024 && (!with_prior || f->prior_deferred)) ? f->splits : 0;
-    if (syrk_colsum && !f->cs_in_tail)
+    if (syrk_colsum)
       HIPCHK(f, launch_colsum_reduce(f->st, f->partial, f->splits, P + 1, gvec));
-    else if (!syrk_colsum && fused_chunks == 0)
+    else if (fused_chunks == 0)
       HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
+    f->prior_deferred = with_prior && r_here && !mirror && small_fuse(f);
     if (with_prior && !f->prior_deferred)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)
       HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
                                  f->prior_mean, p, f->tvec, gvec, 0, r_here ? 1 : 0));
@@ -1272,7 +1268,7 @@ static int enqueue_accept(lsqamd_fit *f) {   // p_trial becomes the point; the c
   HIPCHK(f, launch_lm_accept_tail(f->st, f->redbuf, P, f->opt.scaler, f->diag_dev, f->dscale, f->p_trial, f->yv + P, gvec,
                                   f->opt.xtol, f->opt.gtol, f->lmd, f->prior_deferred ? f->tvec : nullptr, f->prior_mean,
                                   f->nrm_in_tail ? f->nrm_part : nullptr, f->nrm_in_tail, (f->nrm_in_tail && wp) ? f->prior_prec : nullptr,
-                                  f->cfg.prior_dense, f->cs_in_tail ? f->partial : nullptr, f->cs_in_tail));
+                                  f->cfg.prior_dense));
   if (!f->lm_zero_copy) HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
   return 0;
 }

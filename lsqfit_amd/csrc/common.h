@@ -257,10 +257,7 @@ hipError_t launch_lm_accept_tail(hipStream_t st, const double *apk, int64_t P, i
                                  // nrm_part: the <= 64 per-workgroup sums of the fused normal-equation kernel are totalled and
                                  // unpacked (into apk / gvec, prior precision added) by this launch first
                                  const double *nrm_part = nullptr, int nrm_blocks = 0, const double *nrm_prior = nullptr,
-                                 int nrm_prior_dense = 0,
-                                 // cs_part: gvec[0..P] = the sum of cs_splits per-split partials [split][P + 1] (what the J^T J launch's
-                                 // diagonal tiles left behind), in colsum_reduce's order, formed by this launch first
-                                 const double *cs_part = nullptr, int cs_splits = 0);
+                                 int nrm_prior_dense = 0);
 // small systems (n <= 256): back substitution + trial point + the record's dot products in one single-workgroup launch
 hipError_t launch_lm_solve_tail_small(hipStream_t st, const double *M, int64_t ld, int64_t n, const double *uinv,
                                       const double *x, const double *g, const double *d, double *xt, double *v_out,

@@ -137,7 +137,6 @@ struct lsqamd_fit {
   double *pin_g = nullptr, *pin_c = nullptr, *pin_v = nullptr, *pin_d = nullptr, *pin_x = nullptr, *pin_s = nullptr;
   double *pin_lm = nullptr;   // the device's LM state record, as last read
   double *pin_fit = nullptr;  // what the one-launch fit kernel hands back (jit.h FitArgs::host)
-  int cs_in_tail = 0;             // > 0: the accept-tail kernel sums that many per-split partials of J^T f itself (eval_normal_dev)
   bool cov_host_valid = false;    // pin_fit[96 ..] holds the covariance f->cov holds (get_cov serves it without a copy)
   bool used_one_launch = false;   // the last lsqamd_run was ONE launch (api.hip run_one_launch); lsqamd_debug_flags bit 5
   std::vector<hipEvent_t> event_pool;

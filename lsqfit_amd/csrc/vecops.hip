@@ -1270,24 +1270,9 @@ __global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, 
                                                              const double *v, double *gvec, double xtol,
                                                              double gtol, double *st, const double *tvec,
                                                              const double *pmean, const double *nrm_part, int nrm_blocks,
-                                                             const double *nrm_prior, int nrm_prior_dense, double *apk_w,
-                                                             const double *cs_part, int cs_splits) {
+                                                             const double *nrm_prior, int nrm_prior_dense, double *apk_w) {
   __shared__ double sh[4];
   __shared__ double nq_s[96];
-  if (cs_part) {
-    // J^T f and chi2 as the J^T J launch's diagonal tiles left them, one partial per K-split: totalled here in the order of
-    // colsum_reduce_kernel (16 interleaved groups of splits, then the groups) -- bit for bit what that launch would have written
-    for (int64_t j = threadIdx.x; j <= P; j += 256) {
-      double t = 0.0;
-      for (int g = 0; g < 16; ++g) {
-        double a = 0.0;
-        for (int k = g; k < cs_splits; k += 16) a += cs_part[(int64_t)k * (P + 1) + j];
-        t += a;
-      }
-      gvec[j] = t;
-    }
-    __syncthreads();
-  }
   if (nrm_part) {
     // few parameters, few rows (jit.hip lsqamd_jit_nrm, <= 64 workgroups): the per-workgroup sums are added up here, in
     // workgroup order, and unpacked into the packed tile / gvec -- colsum_reduce + nrm_unpack folded into this launch
@@ -1355,11 +1340,10 @@ __global__ __launch_bounds__(256) void lm_accept_tail_kernel(const double *apk, 
 hipError_t launch_lm_accept_tail(hipStream_t stream, const double *apk, int64_t P, int scaler, double *coln2,
                                  double *dscale, const double *x, const double *v, double *gvec, double xtol,
                                  double gtol, double *st, const double *tvec, const double *pmean, const double *nrm_part,
-                                 int nrm_blocks, const double *nrm_prior, int nrm_prior_dense, const double *cs_part, int cs_splits) {
+                                 int nrm_blocks, const double *nrm_prior, int nrm_prior_dense) {
   const int64_t T = (P + TB - 1) / TB;
   hipLaunchKernelGGL(lm_accept_tail_kernel, dim3(1), dim3(256), 0, stream, apk, P, T, scaler, coln2, dscale, x, v, gvec,
-                     xtol, gtol, st, tvec, pmean, nrm_part, nrm_blocks, nrm_prior, nrm_prior_dense, const_cast<double *>(apk),
-                     cs_part, cs_splits);
+                     xtol, gtol, st, tvec, pmean, nrm_part, nrm_blocks, nrm_prior, nrm_prior_dense, const_cast<double *>(apk));
   return hipGetLastError();
 }
 
