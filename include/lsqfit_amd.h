@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQAMD_ABI_VERSION 5
+#define LSQAMD_ABI_VERSION 6
 
 /* error codes (negative = backend, positive = GSL numbering) */
 #define LSQAMD_SUCCESS 0
@@ -441,6 +441,13 @@ int lsqamd_timing_reset(lsqamd_fit *fit);
  * LSQAMD_ONE_LAUNCH_FIT=0 disables),
  * bits 8..31 = split-K factor of the J^T J kernel, bits 32.. = block count */
 int64_t lsqamd_debug_flags(const lsqamd_fit *fit);
+/* Small fits hand their results to the host through pinned memory the host polls (no reference counterpart: the
+ * reference's driver runs on the host, src/lsqfit/_gsl.pyx:676-701).  Device stores to host memory arrive in no
+ * particular order, so every such block carries a sequence number and a checksum and the host acts on a snapshot
+ * only when both fit.  out3[0] = snapshots that did not verify yet (polled again), out3[1] = hand-offs served from
+ * device memory after a stream synchronisation instead, out3[2] = words the test knob LSQAMD_VERIFY_HANDOFF=1 found
+ * different from the device's own copy after the host had acted on them (must stay 0).  Process-wide counters. */
+int lsqamd_handoff_stats(int64_t *out3);
 /* The formula of a tape model as the straight-line gfx950 code lsqamd_set_tape builds with hiprtc in
  * place of interpreting the tape (bit 3 of lsqamd_debug_flags: the compiled route is in use; it stands
  * in for the Python fit function the reference differentiates with gvar.valder, src/lsqfit/_gsl.pyx:

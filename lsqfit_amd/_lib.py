@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'liblsqfit_amd.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 COMM_ID_BYTES = 128
 
@@ -126,6 +126,7 @@ PROTOTYPES = {
     'lsqamd_timing_get': (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(C.c_int64)]),
     'lsqamd_timing_reset': (C.c_int, [_vp]),
     'lsqamd_debug_flags': (C.c_int64, [_vp]),
+    'lsqamd_handoff_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_debug_set_potf2_stamps': (None, [_vp]),
 }
 

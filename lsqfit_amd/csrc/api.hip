@@ -22,6 +22,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <sched.h>
 
 #include "fit_state.h"
 #include "jit.h"
@@ -72,6 +73,23 @@ int current_device() {
 constexpr size_t PIN_CLASS = 4096, PIN_KEEP_MAX = 64 << 10, PIN_KEEP_TOTAL = 2 << 20;
 }  // namespace
 
+// Hand-offs through polled pinned memory (wait_record, run_one_launch), over the process: snapshots that did not verify (yet),
+// hand-offs served from device memory after the stream had drained, words the test knob LSQAMD_VERIFY_HANDOFF=1 found different
+// from the device's own copy (must stay 0).  lsqamd_handoff_stats reads them.
+std::atomic<int64_t> g_handoff[3];
+
+// LSQAMD_POISON_PINNED=1 (test knob): every pinned block handed out, and every region a kernel is about to publish into, is
+// filled with a recognisable NaN first -- a host that acts on words the device has not written yet then acts on NaNs, loudly
+bool poison_pinned() {
+  static const bool on = [] { const char *e = getenv("LSQAMD_POISON_PINNED"); return e && e[0] == '1'; }();
+  return on;
+}
+void poison_fill(void *p, size_t bytes) {
+  const uint64_t nan_bits = 0x7ff8dead0000beefULL;
+  uint64_t *w = static_cast<uint64_t *>(p);
+  for (size_t i = 0; i < bytes / 8; ++i) w[i] = nan_bits;
+}
+
 void *pinned_take(size_t bytes, size_t *granted) {
   const size_t cls = (bytes + PIN_CLASS - 1) / PIN_CLASS * PIN_CLASS;
   *granted = cls;
@@ -84,17 +102,19 @@ void *pinned_take(size_t bytes, size_t *granted) {
       void *p = it->second;
       r.pinned.erase(it);
       r.pinned_bytes -= cls;
+      if (poison_pinned()) poison_fill(p, cls);
       return p;
     }
   }
   void *p = nullptr;
   if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (poison_pinned()) poison_fill(p, cls);
   return p;
 }
 
-void pinned_give(void *p, size_t granted) {
+void pinned_give(void *p, size_t granted, int dev_taken) {
   if (!p) return;
-  const int dev = current_device();
+  const int dev = dev_taken >= 0 ? dev_taken : current_device();
   if (granted > 0 && granted <= PIN_KEEP_MAX && dev >= 0) {
     Recycler &r = recycler();
     std::lock_guard<std::mutex> lk(r.mu);
@@ -124,9 +144,9 @@ hipEvent_t event_take() {
   return e;
 }
 
-void event_give(hipEvent_t e) {
+void event_give(hipEvent_t e, int dev_taken) {
   if (!e) return;
-  const int dev = current_device();
+  const int dev = dev_taken >= 0 ? dev_taken : current_device();
   if (dev >= 0) {
     Recycler &r = recycler();
     std::lock_guard<std::mutex> lk(r.mu);
@@ -327,6 +347,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->cov = cv.take<double>(P * f->ldm);
   f->scal = cv.take<double>(16);
   f->lmd = cv.take<double>(LMS_COUNT);
+  if (c.model == LSQAMD_MODEL_TAPE && P <= lsqamd_jit::FIT_MAX_P) f->fit_block = cv.take<double>(lsqamd_jit::FIT_HOST_DOUBLES);
   f->info_dev = cv.take<int32_t>(16);
   f->trig_far = cv.take<int32_t>(16);
   f->tape_cap = c.tape_len > 1024 ? c.tape_len : 1024;
@@ -1326,18 +1347,56 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
 static int wait_record(lsqamd_fit *f) {
   static const bool poll = [] { const char *e = getenv("LSQAMD_POLL"); return !(e && e[0] == '0'); }();
   f->lm_seq_expect += 1.0;
-  if (f->lm_zero_copy && poll) {
-    volatile double *h = f->pin_lm;
+  if (!f->lm_zero_copy) {     // (the caller queued a copy of the record behind the kernels)
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    return 0;
+  }
+  // The kernels' stores to the mirror arrive in no particular order (vecops.hip lm_publish): a snapshot counts only when its
+  // sequence number is the awaited one AND its checksum fits.  Once one does, every word of this half step has landed and
+  // nothing writes the mirror again before the host queues the next half step: the callers read pin_lm itself afterwards.
+  volatile unsigned long long *h = reinterpret_cast<volatile unsigned long long *>(f->pin_lm);
+  unsigned long long w[LMS_COUNT];
+  auto arrived = [&]() {
+    double seq;
+    w[LMS_SEQ] = h[LMS_SEQ];
+    std::memcpy(&seq, &w[LMS_SEQ], sizeof(double));
+    if (!(seq >= f->lm_seq_expect)) return false;
+    std::atomic_thread_fence(std::memory_order_acquire);
+    for (int i = 0; i < LMS_COUNT; ++i) w[i] = h[i];
+    std::memcpy(&seq, &w[LMS_SEQ], sizeof(double));
+    if (seq >= f->lm_seq_expect && w[LMS_CHECK] == lm_record_checksum(w)) return true;
+    g_handoff[0]++;
+    return false;
+  };
+  auto audited = [&]() -> int {    // test knob: the record the host is about to act on vs the device's own, once the stream has drained
+    if (!getenv("LSQAMD_VERIFY_HANDOFF")) return 0;
+    unsigned long long dev[LMS_COUNT];
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    HIPCHK(f, hipMemcpy(dev, f->lmd, sizeof(dev), hipMemcpyDeviceToHost));
+    for (int i = 0; i < LMS_COUNT; ++i)
+      if (dev[i] != w[i]) {
+        fprintf(stderr, "lsqamd HANDOFF MISMATCH record word %d: host %016llx device %016llx\n", i, w[i], dev[i]);
+        g_handoff[2]++;
+      }
+    return 0;
+  };
+  if (poll) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
-      if (h[LMS_SEQ] >= f->lm_seq_expect) {
-        std::atomic_thread_fence(std::memory_order_acquire);
-        return 0;
+      if (arrived()) return audited();
+      __builtin_ia32_pause();
+      if ((spins & 63) == 0) {
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt > std::chrono::microseconds(3000)) break;
+        if (dt > std::chrono::microseconds(200)) sched_yield();   // (a long half step: stop hogging the core)
       }
-      if ((spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(3000)) break;
     }
   }
   HIPCHK(f, hipStreamSynchronize(f->st));
+  if (arrived()) return audited();
+  // the stream has drained and the mirror still does not verify: take the record from the device
+  g_handoff[1]++;
+  HIPCHK(f, hipMemcpy(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1623,7 +1682,8 @@ int do_init(lsqamd_fit *f, const double *p0) {
     f->pin_lm[LMS_CHI2] = f->chi2; f->pin_lm[LMS_MU] = f->mu; f->pin_lm[LMS_NU] = (double)f->nu;
     f->pin_lm[LMS_DELTA] = f->delta;
     {   // the kernels that finish a half step mirror the record into this pinned block themselves (LSQAMD_ZERO_COPY=0: a copy per read)
-      static const bool off = [] { const char *e = getenv("LSQAMD_ZERO_COPY"); return e && e[0] == '0'; }();
+      const char *zc = getenv("LSQAMD_ZERO_COPY");      // (read per call: a tested mode)
+      const bool off = zc && zc[0] == '0';
       void *dp = nullptr;
       f->lm_zero_copy = !off && hipHostGetDevicePointer(&dp, f->pin_lm, 0) == hipSuccess && dp != nullptr;
       if (!f->lm_zero_copy) (void)hipGetLastError();
@@ -1755,6 +1815,8 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   if (!f) return LSQAMD_ENOMEM;
   f->cfg = *cfg;
   f->st = reinterpret_cast<hipStream_t>(stream);
+  f->st_used = true;
+  f->dev = current_device();
   const size_t need = carve(f, dev_workspace, workspace_bytes, true);
   if (need > workspace_bytes) {
     delete f;
@@ -1771,15 +1833,18 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
   f->opt.avmax = 0.75;
   {
     const size_t P1 = (size_t)f->P + 1;
-    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (5 * P1 + 8 + LMS_COUNT + 1280), &f->pin_bytes));
+    const size_t head = (5 * P1 + 8 + 15) / 16 * 16;     // (the two regions the device writes start on 128-byte lines)
+    f->pin = static_cast<double *>(pinned_take(sizeof(double) * (head + LMS_COUNT + 1280), &f->pin_bytes));
     if (!f->pin) {
       delete f;
       return LSQAMD_ENOMEM;
     }
     f->pin_g = f->pin; f->pin_c = f->pin_g + P1; f->pin_v = f->pin_c + P1; f->pin_d = f->pin_v + P1;
-    f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1; f->pin_lm = f->pin_s + 8;
-    f->pin_fit = f->pin_lm + LMS_COUNT;       // 1280 doubles: what the one-launch fit kernel hands back (jit.h FitArgs::host)
+    f->pin_x = f->pin_d + P1; f->pin_s = f->pin_x + P1; f->pin_lm = f->pin + head;
+    f->pin_fit = f->pin_lm + LMS_COUNT;       // 1280 doubles: what the one-launch fit kernel publishes (jit.h FitArgs::pub)
     static_assert(lsqamd_jit::FIT_HOST_DOUBLES <= 1280, "pin_fit");
+    for (int i = 0; i < LMS_COUNT; ++i) f->pin_lm[i] = 0.0;
+    f->pin_fit[16] = 0.0;
   }
   if (hipMemsetAsync(f->in_block, 0, (size_t)(f->N > 0 ? f->N : 1), f->st) != hipSuccess) {
     delete f;
@@ -2233,15 +2298,23 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   int rc = ready(f);
   if (rc) return rc;
   void *dfit = nullptr, *dx = nullptr, *dlm = nullptr;
-  if (hipHostGetDevicePointer(&dfit, f->pin_fit, 0) != hipSuccess || hipHostGetDevicePointer(&dx, f->pin_x, 0) != hipSuccess ||
+  if (!f->fit_block || hipHostGetDevicePointer(&dfit, f->pin_fit, 0) != hipSuccess || hipHostGetDevicePointer(&dx, f->pin_x, 0) != hipSuccess ||
       hipHostGetDevicePointer(&dlm, f->pin_lm, 0) != hipSuccess || !dfit || !dx || !dlm) {
     (void)hipGetLastError();
     return 0;
   }
-  static const bool zc_off = [] { const char *z = getenv("LSQAMD_ZERO_COPY"); return z && z[0] == '0'; }();
+  // LSQAMD_ZERO_COPY=0 (read per call: a tested mode): nothing is published to host memory; the host waits for the stream and
+  // copies the kernel's device block -- also what happens when a published block does not verify in time
+  const char *z = getenv("LSQAMD_ZERO_COPY");
+  const bool zc_off = z && z[0] == '0';
+  const int nw = lsqamd_jit::fit_host_cov((int)P) + (int)(P * P);       // words of the record block of a P-parameter fit
+  static std::atomic<unsigned> g_seq{0};
+  unsigned long long seq = 0;
+  while (seq == 0) seq = (g_seq.fetch_add(1, std::memory_order_relaxed) + 1u) & 0xffffffu;   // 24 bits, never 0
   std::memcpy(f->pin_x, p0, sizeof(double) * P);
-  volatile double *h = f->pin_fit;
-  h[16] = 0.0;
+  volatile unsigned long long *hw = reinterpret_cast<volatile unsigned long long *>(f->pin_fit);
+  if (poison_pinned()) poison_fill(f->pin_fit, sizeof(double) * lsqamd_jit::FIT_HOST_DOUBLES);
+  hw[16] = 0;
   std::atomic_thread_fence(std::memory_order_release);
   lsqamd_jit::FitArgs a;
   a.x = f->x; a.ymean = f->ymean; a.wdiag = f->wdiag; a.n_data = f->N;
@@ -2258,24 +2331,70 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   a.xtol = f->opt.xtol; a.gtol = f->opt.gtol; a.factor_up = f->opt.factor_up; a.factor_down = f->opt.factor_down;
   const long long bits = zc_off ? 0 : (long long)(intptr_t)dlm;
   std::memcpy(&a.hostptr_bits, &bits, sizeof(double));
-  a.host = static_cast<double *>(dfit);
+  a.host = f->fit_block;
+  a.pub = zc_off ? nullptr : static_cast<unsigned long long *>(dfit);
+  a.seq = seq;
   // the covariance of the normal-equation route rides along (solver = qr factors the Jacobian itself: do_covariance_qr)
   a.cov = f->cov; a.ldc = f->ldm; a.want_cov = f->opt.solver == LSQAMD_SOLVER_QR ? 0 : 1; a.pad_ = 0;
   HIPCHK(f, lsqamd_jit::launch_fit(k, f->st, a));
-  {   // the kernel writes `reason` last, behind a system-scope fence: poll for it, then fall back to sleeping on the stream
+  f->fit_rec.resize((size_t)nw);
+  unsigned long long *rec = reinterpret_cast<unsigned long long *>(f->fit_rec.data());
+  bool have = false;
+  if (a.pub) {
+    // The flag word is this launch's only when it carries this launch's sequence number; the block behind it counts only when
+    // its checksum (seeded with the same number) fits the snapshot taken -- the kernel's stores arrive in no particular
+    // order (jit.hip, end of lm_fit).  A short spin (most small fits end within 100 us), then yielding the core, then the
+    // stream; a block that still does not verify once the stream has drained is replaced by the device copy.
+    auto arrived = [&]() {
+      const unsigned long long flag = hw[16];
+      if ((flag >> 40) != seq) return false;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      for (int i = 0; i < nw; ++i) rec[i] = hw[i];
+      if (rec[16] != flag || rec[23] != lsqamd_jit::fit_checksum(rec, nw, seq)) { g_handoff[0]++; return false; }
+      // the flag IS the decision: reason | info | nit; the record behind it must say the same
+      const int reason = (int)(flag & 0xff), info = (int)(int8_t)((flag >> 8) & 0xff), nit = (int)((flag >> 16) & 0xffffff);
+      if ((int)f->fit_rec[LMS_INFO] != info || (int)f->fit_rec[17] != nit) { g_handoff[0]++; return false; }
+      f->fit_rec[16] = (double)reason;
+      f->fit_rec[23] = 0.0;
+      return true;
+    };
     const auto t0 = std::chrono::steady_clock::now();
-    for (unsigned spins = 1; h[16] == 0.0; ++spins)
-      if ((spins & 255) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(5000)) {
-        HIPCHK(f, hipStreamSynchronize(f->st));
-        break;
+    for (unsigned spins = 1; !(have = arrived()); ++spins) {
+      __builtin_ia32_pause();
+      if ((spins & 63) == 0) {
+        const auto dt = std::chrono::steady_clock::now() - t0;
+        if (dt > std::chrono::microseconds(5000)) break;
+        if (dt > std::chrono::microseconds(200)) sched_yield();
       }
-    std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!have) {
+      HIPCHK(f, hipStreamSynchronize(f->st));
+      have = arrived();
+      if (!have) g_handoff[1]++;
+    }
   }
-  if (h[16] != 1.0) {                 // irregular (or nothing came back): the general path from the start
+  if (!have) {
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    HIPCHK(f, hipMemcpy(f->fit_rec.data(), f->fit_block, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost));
+  }
+  if (getenv("LSQAMD_VERIFY_HANDOFF")) {   // test knob: the block the host acted on vs the device's own copy once the stream has drained
+    std::vector<double> dev((size_t)nw);
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    HIPCHK(f, hipMemcpy(dev.data(), f->fit_block, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < nw; ++i)
+      if (i != 23 && std::memcmp(&dev[(size_t)i], &f->fit_rec[(size_t)i], sizeof(double)) != 0) {
+        fprintf(stderr, "lsqamd HANDOFF MISMATCH word %d: host %a device %a\n", i, f->fit_rec[(size_t)i], dev[(size_t)i]);
+        ++bad;
+      }
+    if (bad) { g_handoff[2] += bad; fprintf(stderr, "lsqamd HANDOFF: %d mismatches (P %lld N %lld)\n", bad, (long long)P, (long long)f->N); }
+  }
+  const double *R = f->fit_rec.data();
+  if (R[16] != 1.0) {                 // irregular: the general path from the start
     HIPCHK(f, hipStreamSynchronize(f->st));
     return 0;
   }
-  const double *m = f->pin_fit + 24;
+  const double *m = R + 24;
   f->hx.assign(m, m + P);
   f->hg.assign(m + (P + 1), m + (P + 1) + P);
   f->hdiag.assign(m + 2 * (P + 1), m + 2 * (P + 1) + P);
@@ -2286,13 +2405,13 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
     f->hv[j] = v;
     f->hdx[j] = -v;
   }
-  for (int i = 0; i < LMS_COUNT; ++i) f->pin_lm[i] = f->pin_fit[i];
-  f->nit = (int)f->pin_fit[17]; f->nfev = (int)f->pin_fit[18]; f->njev = (int)f->pin_fit[19]; f->ntrial = (int)f->pin_fit[20];
+  for (int i = 0; i < LMS_COUNT; ++i) f->pin_lm[i] = R[i];
+  f->nit = (int)R[17]; f->nfev = (int)R[18]; f->njev = (int)R[19]; f->ntrial = (int)R[20];
   f->chol_fail = f->qr_trials = 0;
   f->qr_steps_on = false;
   f->logdet = NAN;
-  f->chi2 = f->pin_fit[LMS_CHI2]; f->mu = f->pin_fit[LMS_MU]; f->nu = (long)f->pin_fit[LMS_NU]; f->delta = f->pin_fit[LMS_DELTA];
-  f->conv_info_dev = (int32_t)f->pin_fit[LMS_INFO];
+  f->chi2 = R[LMS_CHI2]; f->mu = R[LMS_MU]; f->nu = (long)R[LMS_NU]; f->delta = R[LMS_DELTA];
+  f->conv_info_dev = (int32_t)R[LMS_INFO];
   f->dev_lm = true;
   f->lm_zero_copy = bits != 0;
   f->lm_seq_expect = 0.0;
@@ -2302,19 +2421,19 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   f->used_one_launch = true;
   if (getenv("LSQAMD_FIT_DIAG"))     // developer knob: where the kernel's cycles went
     fprintf(stderr, "lsqamd_jit_lm: %.0f shader cycles (normal equations %.0f, solves %.0f, trial residuals %.0f), %.1f us; nit %d trials %d\n",
-            f->pin_fit[lsqamd_jit::fit_host_diag((int)P)], f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 1], f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 2],
-            f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 3], f->pin_fit[lsqamd_jit::fit_host_diag((int)P) + 4] / 100.0, (int)f->nit, (int)f->ntrial);
+            R[lsqamd_jit::fit_host_diag((int)P)], R[lsqamd_jit::fit_host_diag((int)P) + 1], R[lsqamd_jit::fit_host_diag((int)P) + 2],
+            R[lsqamd_jit::fit_host_diag((int)P) + 3], R[lsqamd_jit::fit_host_diag((int)P) + 4] / 100.0, (int)f->nit, (int)f->ntrial);
   f->nrm_in_tail = 0;
   f->prior_deferred = false;
   f->r_fresh = false;
   f->have_cov = false;
   f->cov_host_valid = false;
-  if (a.want_cov && f->pin_fit[21] == 1.0) {     // (else: do_covariance, the caller's next step)
+  if (a.want_cov && R[21] == 1.0) {     // (else: do_covariance, the caller's next step)
     f->have_cov = true;
     f->cov_host_valid = true;
     f->cov_inaccurate = false;
     f->cov_dropped = 0;
-    f->logdet = f->pin_fit[22];
+    f->logdet = R[22];
   }
   f->have_dense_A = false;
   f->initialised = true;
@@ -2376,7 +2495,7 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   if (f->used_one_launch && f->have_cov && rc == 0) {
     // the whole run was the one kernel whose last word the host has already seen: nothing is left on the stream to wait for
     // (an event synchronisation is ~15 us of sleeping and waking); the kernel timed itself (100 MHz ticks)
-    ms = (float)(f->pin_fit[lsqamd_jit::fit_host_diag((int)f->P) + 4] * 1e-5);
+    ms = (float)(f->fit_rec[(size_t)lsqamd_jit::fit_host_diag((int)f->P) + 4] * 1e-5);
     f->stage_off = 0;
   } else {
     (void)hipEventRecord(ev.b, f->st);
@@ -2598,7 +2717,7 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
     if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
   }
   if (f->cov_host_valid) {       // the one-launch fit kernel mirrored it into pinned memory: no copy, no synchronisation
-    std::memcpy(out, f->pin_fit + lsqamd_jit::fit_host_cov((int)P), sizeof(double) * (size_t)(P * P));
+    std::memcpy(out, f->fit_rec.data() + lsqamd_jit::fit_host_cov((int)P), sizeof(double) * (size_t)(P * P));
     return 0;
   }
   HIPCHK(f, hipMemcpy2DAsync(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P,
@@ -2784,6 +2903,12 @@ int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scra
     HIPCHK(f, hipStreamSynchronize(f->st));
     f->nfev += (int32_t)mm;
   }
+  return 0;
+}
+
+int lsqamd_handoff_stats(int64_t *out3) {
+  if (!out3) return LSQAMD_EINVAL;
+  for (int i = 0; i < 3; ++i) out3[i] = g_handoff[i].load();
   return 0;
 }
 

@@ -30,7 +30,7 @@
 
 namespace lsqamd_host {   // process-wide recycling of streams and events (api.hip; see fit_state.h)
 hipEvent_t event_take();
-void event_give(hipEvent_t e);
+void event_give(hipEvent_t e, int dev = -1);
 hipStream_t stream_take();
 void stream_give(hipStream_t s);
 }  // namespace lsqamd_host
@@ -977,6 +977,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
       a.hostptr_bits = 0.0;
       a.cov = f->cov; a.ldc = f->ldm; a.want_cov = 1; a.pad_ = 0;
       a.host = f->chol_work;                       // (free until a covariance is asked for: 16384 doubles per fit)
+      a.pub = nullptr; a.seq = 0;                  // (the batch's results are copied after a stream synchronisation)
       lsqamd_jit::FitBatch bt;
       bt.ymean_stride = f->ymean_stride; bt.prec_stride = f->cfg.prior_dense ? 0 : P; bt.tile_stride = red_stride;
       bt.cov_stride = P * f->ldm; bt.scratch_stride = w_stride;

@@ -240,7 +240,16 @@ enum { LMS_CHI2 = 0, LMS_MU, LMS_NU, LMS_DELTA, LMS_VG, LMS_DV2, LMS_VFINITE, LM
        LMS_SOLVED, LMS_INFO, LMS_PIVMIN,
        LMS_SEQ /* counts the half steps published: the host may poll the mirror for it instead of sleeping in a stream synchronisation */,
        LMS_HOSTPTR /* bits of a device-visible HOST address the record is mirrored to by the kernels that finish a half step (0: none) */,
+       LMS_CHECK /* lm_record_checksum of the other fifteen words, as bits: what makes the host mirror self-verifying */,
        LMS_COUNT = 16 };
+// position-weighted sum over the record's words (all but LMS_CHECK): the device writes it with the record, the host recomputes it
+// over a snapshot of the mirror -- stores to host memory arrive in no particular order, a sum that fits means they all have
+__host__ __device__ inline unsigned long long lm_record_checksum(const unsigned long long *w) {
+  unsigned long long acc = 0;
+  for (int i = 0; i < LMS_COUNT; ++i)
+    if (i != LMS_CHECK) acc += (w[i] ^ 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long)i + 1ull);
+  return acc;
+}
 // U / ldu / a_diag given: state[LMS_PIVMIN] = min_i U_ii^2 / (a_diag_i + mu d_i^2), the smallest share of a column of the
 // damped matrix that its Cholesky pivot retained (1 / it ~ the condition number the solve has just gone through)
 hipError_t launch_lm_trial(hipStream_t st, int64_t P, const double *x, const double *v, const double *g,

@@ -17,9 +17,9 @@ void comm_release(lsqamd_fit *f);                                  // comm.hip
 // process-wide recycling of what a handle needs from the runtime besides its workspace (api.hip): creating and releasing a
 // pinned block or an event costs tens to hundreds of microseconds (hipHostFree waits for the device) -- more than a small fit
 void *pinned_take(size_t bytes, size_t *granted);
-void pinned_give(void *p, size_t granted);
+void pinned_give(void *p, size_t granted, int dev = -1);   // dev: the device it was taken on (-1: the current one)
 hipEvent_t event_take();
-void event_give(hipEvent_t e);
+void event_give(hipEvent_t e, int dev = -1);
 hipStream_t stream_take();          // a non-blocking stream (recycled ones are idle: their last owner synchronised them)
 void stream_give(hipStream_t s);
 int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count);   // sums enqueued on f->st
@@ -36,6 +36,8 @@ struct lsqamd_fit {
   lsqamd_config cfg;
   lsqamd_options opt;
   hipStream_t st = nullptr;
+  int dev = -1;                // the device that was current at lsqamd_create: recycled blocks and events are filed under it
+  bool st_used = false;        // the handle has been given a stream (lsqamd_create): the destructor waits for it
   std::string err;
 
   int64_t N = 0, P = 0, ld = 0, ldm = 0, npk = 0, ncols_aug = 0;
@@ -136,7 +138,9 @@ struct lsqamd_fit {
   double *pin = nullptr;
   double *pin_g = nullptr, *pin_c = nullptr, *pin_v = nullptr, *pin_d = nullptr, *pin_x = nullptr, *pin_s = nullptr;
   double *pin_lm = nullptr;   // the device's LM state record, as last read
-  double *pin_fit = nullptr;  // what the one-launch fit kernel hands back (jit.h FitArgs::host)
+  double *pin_fit = nullptr;  // where the one-launch fit kernel publishes its record block (jit.h FitArgs::pub)
+  double *fit_block = nullptr;          // that block in DEVICE memory (FitArgs::host): what the kernel writes first, the fallback
+  std::vector<double> fit_rec;          // the block as the host verified it (run_one_launch): everything later reads THIS
   bool cov_host_valid = false;    // pin_fit[96 ..] holds the covariance f->cov holds (get_cov serves it without a copy)
   bool used_one_launch = false;   // the last lsqamd_run was ONE launch (api.hip run_one_launch); lsqamd_debug_flags bit 5
   std::vector<hipEvent_t> event_pool;
@@ -167,15 +171,18 @@ struct lsqamd_fit {
   }
 
   ~lsqamd_fit() {  // every exit path (including the failure returns of lsqamd_create) ends here
+    // staged uploads read the pinned arena, kernels write the pinned block: neither goes back to the process-wide recycler
+    // (where the next handle may take it at once) before the stream has drained
+    if (st_used) (void)hipStreamSynchronize(st);
     drop_step_graphs();
     for (auto &t : timers)
       for (auto &pr : t.pending) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
       }
-    for (hipEvent_t e : event_pool) lsqamd_host::event_give(e);
-    if (pin) lsqamd_host::pinned_give(pin, pin_bytes);
-    if (stage) lsqamd_host::pinned_give(stage, stage_bytes);
+    for (hipEvent_t e : event_pool) lsqamd_host::event_give(e, dev);
+    if (pin) lsqamd_host::pinned_give(pin, pin_bytes, dev);
+    if (stage) lsqamd_host::pinned_give(stage, stage_bytes, dev);
     lsqamd_host::comm_release(this);
   }
 };

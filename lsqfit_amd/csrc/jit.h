@@ -55,10 +55,25 @@ struct FitArgs {
   int prior_dense, scaler, maxit, watch;
   double xtol, gtol, factor_up, factor_down, hostptr_bits;
   double *cov; long long ldc; int want_cov, pad_;   // want_cov: (J^T J + prior)^-1 at the end point -> cov[i * ldc + j] and host[96 + i * P + j]
-  double *host;                          // device-visible pinned block of FIT_HOST_DOUBLES: [0,16) record, [16] reason (written last:
-                                         // 1 done, 2 hand the fit to the general path), [17..20] nit nfev njev ntrial, [21] 1 when the
-                                         // covariance was formed, [22] its log det(J^T J + prior), [24..) x g D coln2 v
+  double *host;                          // record block, DEVICE memory, FIT_HOST_DOUBLES: [0,16) record, [16] reason (1 done, 2 hand
+                                         // the fit to the general path), [17..20] nit nfev njev ntrial, [21] 1 when the covariance
+                                         // was formed, [22] its log det(J^T J + prior), [23] -, [24..) x g D coln2 v, counters, covariance
+  // pub != null: device-visible pinned HOST block the finished record block is published to for a host that polls instead of
+  // waiting for the stream.  Stores to host memory land in no particular order, so the block is self-verifying: words
+  // [0, fit_host_cov(P) + P * P) are the record block, except [23] = fit_checksum over the others seeded with seq, and
+  // [16] = fit_flag(reason, info, nit, seq), the word the host waits for (api.hip run_one_launch)
+  unsigned long long *pub, seq;
 };
+// the self-verification of a published record block (host side; the kernel's twin is at the end of lm_fit in jit.hip)
+inline unsigned long long fit_checksum(const unsigned long long *w, int n_words, unsigned long long seq) {
+  unsigned long long acc = seq * 0xD6E8FEB86659FD93ull;
+  for (int i = 0; i < n_words; ++i)
+    if (i != 16 && i != 23) acc += (w[i] ^ 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long)i + 1ull);
+  return acc;
+}
+inline unsigned long long fit_flag(int reason, int info, int nit, unsigned long long seq) {
+  return (unsigned long long)(reason & 0xff) | ((unsigned long long)(info & 0xff) << 8) | ((unsigned long long)(nit & 0xffffff) << 16) | (seq << 40);
+}
 bool has_fit_kernel(const Kernel *k);
 int64_t fit_row_limit(const Kernel *k, bool correlated);   // most rows the kernel takes (0: no kernel)
 hipError_t launch_fit(const Kernel *k, hipStream_t st, const FitArgs &a);

@@ -614,7 +614,8 @@ struct LmArgs {
   int prior_dense, scaler, maxit, watch;
   double xtol, gtol, factor_up, factor_down, hostptr_bits;
   double *cov; long long ldc; int want_cov, pad_;     // (A)^-1 at the end point: cov[i * ldc + j], when want_cov
-  double *host;      // pinned mirror: [0, 16) the record, [16, 24) reason nit nfev njev ntrial chol_fail - -, then x g D coln2 v (LP + 1 each)
+  double *host;      // record block (DEVICE memory): [0, 16) the record, [16, 24) reason nit nfev njev ntrial cov-formed logdet -, then x g D coln2 v (LP + 1 each)
+  unsigned long long *pub, seq;   // pub != 0: device-visible HOST block the finished record block is published to (see the end of lm_fit)
 };
 
 static __device__ void m_diag(double *o, long long a0, long long a1, long long a2, long long a3, long long a4) {
@@ -811,7 +812,7 @@ static __device__ __forceinline__ void lm_fit(LmArgs a) {
   __shared__ double sprior[LP * LP + LP];
   if (a.prior_prec) {
     const int np = a.prior_dense ? LP * LP : LP;
-    if (tid < np) sprior[tid] = a.prior_prec[tid];
+    for (int i = tid; i < np; i += 256) sprior[i] = a.prior_prec[i];      // (up to 32 x 32 entries: more than one per thread)
     if (tid < LP) sprior[LP * LP + tid] = a.prior_mean[tid];
     a.prior_prec = sprior; a.prior_mean = sprior + LP * LP;
   }
@@ -966,13 +967,47 @@ static __device__ __forceinline__ void lm_fit(LmArgs a) {
     if (tid == 0) h[21] = bad == 0 ? 1.0 : 0.0;
   } else if (tid == 0) h[21] = 0.0;
   if (tid == 0) {
-    h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial;
+    h[16] = (double)reason; h[17] = nit; h[18] = nfev; h[19] = njev; h[20] = ntrial; h[23] = 0.0;
     // diagnostics: shader cycles in all / in the normal equations / in the solves / in the trial residuals, 100 MHz ticks in all
     m_diag(h + HDIAG, clock64() - c_begin, c_nrm, c_solve, c_res, wall_clock64() - w_begin);
   }
-  __threadfence_system();
-  __syncthreads();
-  if (tid == 0) { h[16] = (double)reason; __threadfence_system(); }
+  if (a.pub) {
+    // Hand-off to a host that POLLS pinned memory instead of waiting for the stream.  Stores to host memory reach it in no
+    // particular order -- a system-scope fence between two of them does not make the first visible to the CPU before the
+    // second (measured: the flag was seen with the covariance words of the PREVIOUS fit still in place, 3 times in 3600
+    // fits) -- so nothing here relies on order.  The finished block (device memory, above) is copied out word by word with a
+    // position-weighted sum over the words; the sum (seeded with this launch's sequence number) goes to word 23 and the flag
+    // word 16 = reason | info << 8 | nit << 16 | seq << 40 is what the host waits for.  The host takes a snapshot, recomputes
+    // the sum and believes the snapshot only when both agree (api.hip run_one_launch); otherwise it keeps polling, then
+    // falls back to hipStreamSynchronize + a copy of the device block.
+    __threadfence();
+    __syncthreads();
+    constexpr int NW = HCOV + LP * LP;
+    const unsigned long long *hw = reinterpret_cast<const unsigned long long *>(h);
+    unsigned long long acc = 0;
+    for (int i = tid; i < NW; i += 256) {
+      if (i == 16 || i == 23) continue;
+      const unsigned long long w = hw[i];
+      a.pub[i] = w;
+      acc += (w ^ 0x9E3779B97F4A7C15ull) * (2ull * (unsigned long long)i + 1ull);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)(acc & 0xffffffffull), m, 64), hi = __shfl_xor((unsigned)(acc >> 32), m, 64);
+      acc += ((unsigned long long)hi << 32) | lo;
+    }
+    unsigned long long *spub = reinterpret_cast<unsigned long long *>(red);
+    if ((tid & 63) == 0) spub[tid >> 6] = acc;
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      a.pub[23] = spub[0] + spub[1] + spub[2] + spub[3] + a.seq * 0xD6E8FEB86659FD93ull;
+      __threadfence_system();
+      a.pub[16] = (unsigned long long)(reason & 0xff) | ((unsigned long long)((int)ss[S_INFO] & 0xff) << 8) |
+                  ((unsigned long long)(nit & 0xffffff) << 16) | (a.seq << 40);
+      __threadfence_system();
+    }
+  }
 }
 
 // ===SINGLE===

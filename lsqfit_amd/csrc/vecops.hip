@@ -778,23 +778,27 @@ __device__ __forceinline__ double block_sum(double a, double *sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// the record, mirrored into pinned host memory by the kernel that completes a half step: the host reads it after
-// the stream synchronisation it needs anyway -- no copy kernel (4 us + a dependent-launch gap each, 2.6 per step)
+// the record, mirrored into pinned host memory by the kernel that completes a half step: the host polls the mirror instead
+// of sleeping in a stream synchronisation -- no copy kernel (4 us + a dependent-launch gap each, 2.6 per step)
 __device__ __forceinline__ void lm_publish(double *st) {
-  // called by ONE thread after it has written the record.  The sequence number goes last, behind a system-scope
-  // fence: a host that polls the mirror for it finds the rest of the record complete.
+  // called by ONE thread after it has written the record.  Stores to host memory become visible to the CPU in no
+  // particular order -- a system-scope fence between two of them does not help (measured on the one-launch fit's larger
+  // block, jit.hip lm_fit) -- so the mirror is self-verifying: word LMS_CHECK carries lm_record_checksum of the other
+  // fifteen, the new sequence number among them; the host believes a snapshot only when the sum fits (api.hip wait_record).
   const long long hp = __double_as_longlong(st[LMS_HOSTPTR]);
   const double seq = st[LMS_SEQ] + 1.0;
   st[LMS_SEQ] = seq;
   if (hp == 0) return;
-  double *h = reinterpret_cast<double *>(hp);
-  typedef double v2 __attribute__((ext_vector_type(2)));
+  unsigned long long w[LMS_COUNT];
 #pragma unroll
-  for (int i = 0; i < LMS_COUNT; i += 2)      // 16-byte stores: eight posted writes instead of sixteen
-    if (i != (LMS_SEQ & ~1)) __builtin_nontemporal_store((v2){st[i], st[i + 1]}, reinterpret_cast<v2 *>(h + i));
-  __threadfence_system();
-  __builtin_nontemporal_store((v2){(LMS_SEQ & 1) ? st[LMS_SEQ - 1] : seq, (LMS_SEQ & 1) ? seq : st[LMS_SEQ + 1]},
-                              reinterpret_cast<v2 *>(h + (LMS_SEQ & ~1)));
+  for (int i = 0; i < LMS_COUNT; ++i) w[i] = (unsigned long long)__double_as_longlong(st[i]);
+  w[LMS_CHECK] = lm_record_checksum(w);
+  st[LMS_CHECK] = __longlong_as_double((long long)w[LMS_CHECK]);
+  typedef unsigned long long u2 __attribute__((ext_vector_type(2)));
+  u2 *h = reinterpret_cast<u2 *>(hp);           // (128-byte aligned: lsqamd_create)
+#pragma unroll
+  for (int i = 0; i < LMS_COUNT; i += 2)        // 16-byte stores: eight posted writes instead of sixteen
+    __builtin_nontemporal_store((u2){w[i], w[i + 1]}, h + i / 2);
   __threadfence_system();
 }
 
