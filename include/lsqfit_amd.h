@@ -107,7 +107,13 @@ enum {
   LSQAMD_OP_POW = 7,   /* a ** b */
   LSQAMD_OP_NEG = 8, LSQAMD_OP_EXP = 9, LSQAMD_OP_LOG = 10, LSQAMD_OP_SIN = 11,
   LSQAMD_OP_COS = 12, LSQAMD_OP_ATAN = 13, LSQAMD_OP_SQRT = 14,
-  LSQAMD_OP_POWI = 15  /* a ** (int)arg */
+  LSQAMD_OP_POWI = 15, /* a ** (int)arg */
+  /* the rest of what a gvar-overloaded fit function may call on a parameter (gvar's tan sinh cosh tanh arcsin arccos and
+   * abs / fabs -- numpy.fabs on fit-function output: src/lsqfit/_extras.py:2569; cosh: the periodic two-point correlator
+   * models lsqfit's documentation fits).  d|a|/da = +1 at a = 0, as gvar's GVar.__abs__ (returns self when mean >= 0). */
+  LSQAMD_OP_TAN = 16, LSQAMD_OP_SINH = 17, LSQAMD_OP_COSH = 18, LSQAMD_OP_TANH = 19, LSQAMD_OP_ASIN = 20,
+  LSQAMD_OP_ACOS = 21, LSQAMD_OP_ABS = 22,
+  LSQAMD_OP_LAST = 22
 };
 #define LSQAMD_TAPE_MAX_PARAM 4096 /* parameters of a tape model */
 #define LSQAMD_TAPE_CHUNK 16       /* interpreter fallback of batched fits: differentiated 16 at a time, ceil(P/16) forward passes per row */

@@ -1905,7 +1905,7 @@ static int validate_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, int
     else if (op == LSQAMD_OP_X) { if (arg < 0 || arg >= (f->cfg.n_x > 0 ? f->cfg.n_x : 1)) FAIL(f, LSQAMD_EINVAL, "tape: bad x index"); ++sp; }
     else if (op == LSQAMD_OP_P) { if (arg < 0 || arg >= f->P) FAIL(f, LSQAMD_EINVAL, "tape: bad parameter index"); ++sp; }
     else if (op >= LSQAMD_OP_ADD && op <= LSQAMD_OP_POW) { if (sp < 2) FAIL(f, LSQAMD_EINVAL, "tape: stack underflow"); --sp; }
-    else if (op >= LSQAMD_OP_NEG && op <= LSQAMD_OP_POWI) { if (sp < 1) FAIL(f, LSQAMD_EINVAL, "tape: stack underflow"); }
+    else if (op >= LSQAMD_OP_NEG && op <= LSQAMD_OP_LAST) { if (sp < 1) FAIL(f, LSQAMD_EINVAL, "tape: stack underflow"); }
     else FAIL(f, LSQAMD_EINVAL, "tape: unknown opcode %d", op);
     if (sp > LSQAMD_TAPE_MAX_STACK) FAIL(f, LSQAMD_EINVAL, "tape: stack deeper than %d", LSQAMD_TAPE_MAX_STACK);
   }

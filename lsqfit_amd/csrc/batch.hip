@@ -835,7 +835,7 @@ int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const
       else if (op == LSQAMD_OP_X) { ok = arg >= 0 && arg < (f->cfg.n_x > 0 ? f->cfg.n_x : 1); ++sp; }
       else if (op == LSQAMD_OP_P) { ok = arg >= 0 && arg < f->P; ++sp; }
       else if (op >= LSQAMD_OP_ADD && op <= LSQAMD_OP_POW) { ok = sp >= 2; --sp; }
-      else if (op >= LSQAMD_OP_NEG && op <= LSQAMD_OP_POWI) ok = sp >= 1;
+      else if (op >= LSQAMD_OP_NEG && op <= LSQAMD_OP_LAST) ok = sp >= 1;
       else ok = false;
       if (!ok || sp > LSQAMD_TAPE_MAX_STACK) BFAIL(f, LSQAMD_EINVAL, "set_tape: malformed tape at instruction %d", t);
     }

@@ -235,6 +235,20 @@ hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, 
                                double *dscale);
 // xt = x - v
 hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt);
+// tape functions beyond LSQAMD_OP_POWI (the interpreter kernels of model.hip / batch.hip; jit.hip emits the same formulas):
+// value and derivative
+__device__ __forceinline__ void tape_unary_ext(int op, double x, double &v, double &d) {
+  switch (op) {
+    case LSQAMD_OP_TAN: v = tan(x); d = 1.0 + v * v; break;
+    case LSQAMD_OP_SINH: v = sinh(x); d = cosh(x); break;
+    case LSQAMD_OP_COSH: v = cosh(x); d = sinh(x); break;
+    case LSQAMD_OP_TANH: v = tanh(x); d = 1.0 - v * v; break;
+    case LSQAMD_OP_ASIN: v = asin(x); d = 1.0 / sqrt(1.0 - x * x); break;
+    case LSQAMD_OP_ACOS: v = acos(x); d = -1.0 / sqrt(1.0 - x * x); break;
+    case LSQAMD_OP_ABS: v = fabs(x); d = x >= 0.0 ? 1.0 : -1.0; break;
+    default: v = x; d = 1.0; break;
+  }
+}
 // LM state record on the device (plain lm; vecops.hip)
 enum { LMS_CHI2 = 0, LMS_MU, LMS_NU, LMS_DELTA, LMS_VG, LMS_DV2, LMS_VFINITE, LMS_RHO, LMS_CHI2_TRIAL, LMS_ACCEPT,
        LMS_SOLVED, LMS_INFO, LMS_PIVMIN,

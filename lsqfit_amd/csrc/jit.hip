@@ -36,6 +36,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "fit_state.h"
@@ -510,7 +511,36 @@ struct TreeGen {
           if (jac) o.f("%sconst double %s = %d.0 * pow(%s, %d.0);\n", i, d(n, 'a').c_str(), nd.arg, a, nd.arg - 1);
         }
         break;
-      default: o.f("%sconst double %s = %s;\n", i, vv, a); break;
+      // (the formulas of common.h tape_unary_ext)
+      case LSQAMD_OP_TAN:
+        o.f("%sconst double %s = tan(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = 1.0 + %s * %s;\n", i, d(n, 'a').c_str(), vv, vv);
+        break;
+      case LSQAMD_OP_SINH:
+        o.f("%sconst double %s = sinh(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = cosh(%s);\n", i, d(n, 'a').c_str(), a);
+        break;
+      case LSQAMD_OP_COSH:
+        o.f("%sconst double %s = cosh(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = sinh(%s);\n", i, d(n, 'a').c_str(), a);
+        break;
+      case LSQAMD_OP_TANH:
+        o.f("%sconst double %s = tanh(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = 1.0 - %s * %s;\n", i, d(n, 'a').c_str(), vv, vv);
+        break;
+      case LSQAMD_OP_ASIN:
+        o.f("%sconst double %s = asin(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = 1.0 / sqrt(1.0 - %s * %s);\n", i, d(n, 'a').c_str(), a, a);
+        break;
+      case LSQAMD_OP_ACOS:
+        o.f("%sconst double %s = acos(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = -1.0 / sqrt(1.0 - %s * %s);\n", i, d(n, 'a').c_str(), a, a);
+        break;
+      case LSQAMD_OP_ABS:
+        o.f("%sconst double %s = fabs(%s);\n", i, vv, a);
+        if (jac) o.f("%sconst double %s = %s >= 0.0 ? 1.0 : -1.0;\n", i, d(n, 'a').c_str(), a);
+        break;
+      default: o.f("%sconst double %s = %s;\n", i, vv, a); if (jac) o.f("%sconst double %s = 1.0;\n", i, d(n, 'a').c_str()); break;
     }
   }
 
@@ -1426,6 +1456,7 @@ uint64_t fnv1a(const std::string &s, uint64_t h = 1469598103934665603ull) {
   return h;
 }
 
+// The on-disk cache of code objects.  A directory that is not ours alone is not used: its files are loaded and RUN on the GPU.
 std::string cache_dir() {
   const char *e = getenv("LSQAMD_JIT_CACHE");
   std::string d;
@@ -1441,26 +1472,61 @@ std::string cache_dir() {
       (void)mkdir(acc.c_str(), 0700);
     }
   }
+  struct stat sb;
+  if (lstat(d.c_str(), &sb) != 0 || !S_ISDIR(sb.st_mode) || sb.st_uid != getuid() || (sb.st_mode & (S_IWGRP | S_IWOTH)))
+    return "";      // missing, a link, someone else's, or writable by others: no disk cache
   return d;
 }
 
-bool compile_source(const std::string &src, std::vector<char> &code, std::string &log) {
+// cache file = header {magic, byte count, FNV-1a of the bytes} + the code object: a truncated or damaged file is recognised
+// (and removed) here, not by a failing hipModuleLoadData that would leave the formula on the interpreter for good
+constexpr uint64_t CACHE_MAGIC = 0x314a444d4151534cull;   // "LSQAMDJ1"
+uint64_t fnv1a_bytes(const char *p, size_t n, uint64_t h = 1469598103934665603ull) {
+  for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string cache_file(const std::string &src) {
   Rtc &r = rtc();
-  if (!r.ok) { log = r.why; return false; }
   char name[64];
   snprintf(name, sizeof(name), "%016" PRIx64 "%016" PRIx64, fnv1a(src), fnv1a(src + std::to_string(r.vmajor * 1000 + r.vminor), 88172645463325252ull));
   const std::string dir = cache_dir();
-  const std::string file = dir.empty() ? "" : dir + "/" + name + ".hsaco";
-  if (!file.empty()) {
-    if (FILE *fh = fopen(file.c_str(), "rb")) {
-      fseek(fh, 0, SEEK_END);
-      const long n = ftell(fh);
-      fseek(fh, 0, SEEK_SET);
-      code.resize(n > 0 ? (size_t)n : 0);
-      const bool ok = n > 0 && fread(code.data(), 1, (size_t)n, fh) == (size_t)n;
-      fclose(fh);
-      if (ok) return true;
-    }
+  return dir.empty() ? "" : dir + "/" + name + ".hsaco";
+}
+
+bool cache_read(const std::string &file, std::vector<char> &code) {
+  FILE *fh = fopen(file.c_str(), "rb");
+  if (!fh) return false;
+  uint64_t head[3] = {0, 0, 0};
+  bool ok = fread(head, sizeof(uint64_t), 3, fh) == 3 && head[0] == CACHE_MAGIC && head[1] > 0 && head[1] < (1ull << 31);
+  if (ok) {
+    code.resize((size_t)head[1]);
+    ok = fread(code.data(), 1, code.size(), fh) == code.size() && fgetc(fh) == EOF && fnv1a_bytes(code.data(), code.size()) == head[2];
+  }
+  fclose(fh);
+  if (!ok) { code.clear(); (void)unlink(file.c_str()); }
+  return ok;
+}
+
+void cache_write(const std::string &file, const std::vector<char> &code) {
+  const std::string tmp = file + ".tmp" + std::to_string((long)getpid());
+  FILE *fh = fopen(tmp.c_str(), "wb");
+  if (!fh) return;
+  const uint64_t head[3] = {CACHE_MAGIC, (uint64_t)code.size(), fnv1a_bytes(code.data(), code.size())};
+  const bool ok = fwrite(head, sizeof(uint64_t), 3, fh) == 3 && fwrite(code.data(), 1, code.size(), fh) == code.size();
+  if (fclose(fh) == 0 && ok) (void)rename(tmp.c_str(), file.c_str());
+  else (void)unlink(tmp.c_str());
+}
+
+// from_cache (optional): *from_cache <- the code came from the disk cache; fresh: do not read the cache (rebuild and rewrite)
+bool compile_source(const std::string &src, std::vector<char> &code, std::string &log, bool *from_cache = nullptr, bool fresh = false) {
+  Rtc &r = rtc();
+  if (from_cache) *from_cache = false;
+  if (!r.ok) { log = r.why; return false; }
+  const std::string file = cache_file(src);
+  if (!file.empty() && !fresh && cache_read(file, code)) {
+    if (from_cache) *from_cache = true;
+    return true;
   }
   Prog p = nullptr;
   if (r.Create(&p, src.c_str(), "lsqamd_tape.hip", 0, nullptr, nullptr) != 0) { log = "hiprtcCreateProgram failed"; return false; }
@@ -1482,16 +1548,26 @@ bool compile_source(const std::string &src, std::vector<char> &code, std::string
   const int rg = r.Code(p, code.data());
   (void)r.Destroy(&p);
   if (rg != 0) { log = "hiprtcGetCode failed"; return false; }
-  if (!file.empty()) {
-    const std::string tmp = file + ".tmp" + std::to_string((long)getpid());
-    if (FILE *fh = fopen(tmp.c_str(), "wb")) {
-      const bool ok = fwrite(code.data(), 1, code.size(), fh) == code.size();
-      fclose(fh);
-      if (ok) (void)rename(tmp.c_str(), file.c_str());
-      else (void)unlink(tmp.c_str());
-    }
-  }
+  if (!file.empty()) cache_write(file, code);
   return true;
+}
+
+// build (or fetch) and load: a cached object that does not load -- stale for this runtime, damaged in a way the checksum
+// cannot see -- is removed and the source compiled afresh, once
+hipError_t build_module(const std::string &src, hipModule_t *mod, std::string &log) {
+  std::vector<char> obj;
+  bool cached = false;
+  if (!compile_source(src, obj, log, &cached)) return hipErrorInvalidSource;
+  hipError_t e = hipModuleLoadData(mod, obj.data());
+  if (e != hipSuccess && cached) {
+    (void)hipGetLastError();
+    const std::string file = cache_file(src);
+    if (!file.empty()) (void)unlink(file.c_str());
+    if (!compile_source(src, obj, log, nullptr, true)) return hipErrorInvalidSource;
+    e = hipModuleLoadData(mod, obj.data());
+  }
+  if (e != hipSuccess) { (void)hipGetLastError(); log = "the compiled tape could not be loaded"; }
+  return e;
 }
 
 struct Loaded {
@@ -1549,19 +1625,20 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
   int variant = 0;
   bool has_nrm = false, has_fit = false;
   if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why, &has_nrm, &has_fit)) return nullptr;
-  const std::pair<int, uint64_t> key{dev, fnv1a(src)};
+  // (the source itself is not kept: two independent 64-bit hashes and the length stand for it)
+  const std::tuple<int, uint64_t, uint64_t, size_t> key{dev, fnv1a(src), fnv1a(src, 88172645463325252ull), src.size()};
   std::lock_guard<std::mutex> lk(g_mu);
-  static std::map<std::pair<int, uint64_t>, Kernel> kernels;
+  static std::map<std::tuple<int, uint64_t, uint64_t, size_t>, Kernel> kernels;
   auto it = kernels.find(key);
   if (it != kernels.end()) {
     if (by_tape.size() < 4096) by_tape[tkey] = &it->second;
     return &it->second;
   }
-  std::vector<char> obj;
   std::string log;
-  if (!compile_source(src, obj, log)) { why = "hiprtc: " + log.substr(0, 400); return nullptr; }
   Kernel k;
-  if (hipModuleLoadData(&k.l.mod, obj.data()) != hipSuccess ||
+  const hipError_t be = build_module(src, &k.l.mod, log);
+  if (be == hipErrorInvalidSource) { why = "hiprtc: " + log.substr(0, 400); return nullptr; }
+  if (be != hipSuccess ||
       hipModuleGetFunction(&k.l.res, k.l.mod, "lsqamd_jit_res") != hipSuccess ||
       hipModuleGetFunction(&k.l.jac, k.l.mod, "lsqamd_jit_jac") != hipSuccess) {
     (void)hipGetLastError();
@@ -1636,9 +1713,8 @@ bool has_batch_fit_kernel(const Kernel *kc) {
     k->batch_tried = true;
     Plan pl;
     std::string why, log;
-    std::vector<char> obj;
     if (make_plan(k->code.data(), (int)k->code.size(), k->consts.data(), (int)k->consts.size(), k->l.n_param, k->n_x, pl, why) &&
-        pl.fit_ok && compile_source(generate(pl, true), obj, log) && hipModuleLoadData(&k->modb, obj.data()) == hipSuccess &&
+        pl.fit_ok && build_module(generate(pl, true), &k->modb, log) == hipSuccess &&
         hipModuleGetFunction(&k->l.lmb, k->modb, "lsqamd_jit_lmb") == hipSuccess) {
     } else {
       (void)hipGetLastError();
@@ -1677,7 +1753,7 @@ extern "C" int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const do
   for (int t = 0; t < n_code; ++t) {
     const int op = code[t] & 0xff, arg = code[t] >> 8;
     if ((op == LSQAMD_OP_P && (arg < 0 || arg >= n_param)) || (op == LSQAMD_OP_CONST && (arg < 0 || arg >= n_consts)) ||
-        (op == LSQAMD_OP_X && (arg < 0 || arg >= (n_x < 1 ? 1 : n_x))) || op > LSQAMD_OP_POWI)
+        (op == LSQAMD_OP_X && (arg < 0 || arg >= (n_x < 1 ? 1 : n_x))) || op > LSQAMD_OP_LAST)
       return LSQAMD_EINVAL;
   }
   std::string src, why;

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
               da = (n == 0) ? 0.0 : n * pow(a, (double)(n - 1));
               break;
             }
-            default: v = a; da = 1.0; break;
+            default: tape_unary_ext(op, a, v, da); break;
           }
           if (JAC) for (int j = 0; j < MP; ++j) sd[sp - 1][j] *= da;
           sv[sp - 1] = v;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void tape_model_kernel(ModelDev m) {
 // slots of local partial derivatives an instruction stores in the forward sweep
 __host__ __device__ inline int tape_slots_of(int op) {
   if (op == LSQAMD_OP_MUL || op == LSQAMD_OP_DIV || op == LSQAMD_OP_POW) return 2;
-  if (op >= LSQAMD_OP_EXP && op <= LSQAMD_OP_POWI) return 1;
+  if (op >= LSQAMD_OP_EXP && op <= LSQAMD_OP_LAST) return 1;
   return 0;   // pushes, ADD, SUB, NEG: constants
 }
 
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
             case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
             case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
             case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
-            default: v = x; break;
+            default: tape_unary_ext(op, x, v, d); break;
           }
           if (op != LSQAMD_OP_NEG) pd[0] = d;
         } else {   // the values the Jacobian sweep computes, from the same library calls (sincos(x).s == sin(x) bit for bit is not promised: keep sincos)
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
             case LSQAMD_OP_ATAN: v = atan(x); break;
             case LSQAMD_OP_SQRT: v = sqrt(x); break;
             case LSQAMD_OP_POWI: v = pow(x, (double)arg); break;
-            default: v = x; break;
+            default: tape_unary_ext(op, x, v, d); break;
           }
           (void)d;
         }
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
               case LSQAMD_OP_ATAN: v = atan(x); d = 1.0 / (1.0 + x * x); break;
               case LSQAMD_OP_SQRT: v = sqrt(x); d = 0.5 / v; break;
               case LSQAMD_OP_POWI: v = pow(x, (double)arg); d = (arg == 0) ? 0.0 : arg * pow(x, (double)(arg - 1)); break;
-              default: v = x; break;
+              default: tape_unary_ext(op, x, v, d); break;
             }
             if (op != LSQAMD_OP_NEG) pd[r * 64] = d;
           } else {   // the values the Jacobian sweep computes, from the same library calls (sincos(x).s == sin(x) bit for bit is not promised: keep sincos)
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void t
               case LSQAMD_OP_ATAN: v = atan(x); break;
               case LSQAMD_OP_SQRT: v = sqrt(x); break;
               case LSQAMD_OP_POWI: v = pow(x, (double)arg); break;
-              default: v = x; break;
+              default: tape_unary_ext(op, x, v, d); break;
             }
             (void)d;
           }

@@ -15,8 +15,11 @@ MODEL_COSMIX, MODEL_MULTIEXP, MODEL_TAPE, MODEL_IDENTITY = 1, 2, 3, 4
 TAPE_MAX_PARAM, TAPE_MAX_STACK = 4096, 16
 
 OP = dict(CONST=0, X=1, P=2, ADD=3, SUB=4, MUL=5, DIV=6, POW=7, NEG=8, EXP=9, LOG=10,
-          SIN=11, COS=12, ATAN=13, SQRT=14, POWI=15)
-_FUNCS = dict(exp='EXP', log='LOG', sin='SIN', cos='COS', arctan='ATAN', atan='ATAN', sqrt='SQRT')
+          SIN=11, COS=12, ATAN=13, SQRT=14, POWI=15, TAN=16, SINH=17, COSH=18, TANH=19, ASIN=20, ACOS=21, ABS=22)
+# the functions gvar overloads for GVars (what a reference fit function may call on its parameters); numpy spellings and
+# the math-module ones
+_FUNCS = dict(exp='EXP', log='LOG', sin='SIN', cos='COS', arctan='ATAN', atan='ATAN', sqrt='SQRT', tan='TAN', sinh='SINH',
+              cosh='COSH', tanh='TANH', arcsin='ASIN', asin='ASIN', arccos='ACOS', acos='ACOS', abs='ABS', fabs='ABS')
 _BIN = {ast.Add: 'ADD', ast.Sub: 'SUB', ast.Mult: 'MUL', ast.Div: 'DIV', ast.Pow: 'POW'}
 
 

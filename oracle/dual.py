@@ -139,7 +139,14 @@ sin = _unary(np.sin, np.cos)
 cos = _unary(np.cos, lambda v: -np.sin(v))
 tan = _unary(np.tan, lambda v: 1.0 / np.cos(v) ** 2)
 arctan = _unary(np.arctan, lambda v: 1.0 / (1.0 + v * v))
-fabs = _unary(np.fabs, np.sign)
+# gvar (pinned dependency, not under /root/reference): GVar.__abs__ / fabs return self when the mean is >= 0 and -self
+# otherwise -- the derivative at 0 is +1, not sign(0) = 0
+fabs = _unary(np.fabs, lambda v: np.where(v >= 0.0, 1.0, -1.0))
+sinh = _unary(np.sinh, np.cosh)
+cosh = _unary(np.cosh, np.sinh)
+tanh = _unary(np.tanh, lambda v: 1.0 - np.tanh(v) ** 2)
+arcsin = _unary(np.arcsin, lambda v: 1.0 / np.sqrt(1.0 - v * v))
+arccos = _unary(np.arccos, lambda v: -1.0 / np.sqrt(1.0 - v * v))
 
 
 def concatenate(parts):
@@ -164,4 +171,5 @@ def stack_sum(terms):
 
 
 NAMESPACE = dict(exp=exp, log=log, sqrt=sqrt, sin=sin, cos=cos, tan=tan,
-                 arctan=arctan, fabs=fabs, pi=np.pi)
+                 arctan=arctan, atan=arctan, fabs=fabs, abs=fabs, sinh=sinh, cosh=cosh, tanh=tanh,
+                 arcsin=arcsin, asin=arcsin, arccos=arccos, acos=arccos, pi=np.pi)

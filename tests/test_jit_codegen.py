@@ -154,3 +154,50 @@ def test_whole_fit_kernel_forms(lib):
     assert rc == 0 and 'lsqamd_jit_lm' not in src
     rc, variant, src = codegen(lib, amd.models.tape_sum('a*cos(w*x)', 16), compile=0)   # 16 look-alike terms: one wave per row
     assert rc == 0 and variant == 1 and 'lsqamd_jit_lm' not in src
+
+
+def test_hyperbolic_and_inverse_functions_compile(lib):
+    """tan sinh cosh tanh arcsin arccos abs (LSQAMD_OP_TAN .. LSQAMD_OP_ABS): generated and built for gfx950, the whole-fit
+    kernel and its hand-off included."""
+    import lsqfit_amd as amd
+    model = amd.expr('a*cosh(b*(x - 16))/cosh(16*b) + c*tanh(sinh(d*x)) + abs(tan(0.1*a*x)) + arcsin(0.1*b) + arccos(0.1*c) + fabs(d)',
+                     ['a', 'b', 'c', 'd'])
+    assert sorted(set(int(t) & 0xff for t in model.tape) & set(range(16, 23))) == list(range(16, 23))
+    rc, variant, src = codegen(lib, model)
+    assert rc == 0, src[:2000]
+    for fn in ('cosh(', 'sinh(', 'tanh(', 'tan(', 'asin(', 'acos(', 'fabs('):
+        assert fn in body(src, 'lsqamd_jit_jac')
+    lm = src[src.index('static __device__ __forceinline__ void lm_fit('):]
+    # the published block is self-verifying: checksum word, then the flag word that carries the sequence number
+    assert 'a.pub[23] =' in lm and 'a.pub[16] =' in lm and lm.index('a.pub[23] =') < lm.index('a.pub[16] =')
+    with pytest.raises(ValueError):
+        amd.expr('a*erf(x)', ['a'])
+
+
+def test_disk_cache_is_verified_and_private(lib, tmp_path, monkeypatch):
+    """Cached code objects carry a length and a checksum: a truncated or damaged file is thrown away and rebuilt, never handed
+    to the loader; a cache directory others can write to is not used at all."""
+    import os
+    import struct
+    import lsqfit_amd as amd
+    model = amd.expr('a*exp(-b*x) + 0.125*c', ['a', 'b', 'c'])
+    d = tmp_path / 'cache'
+    monkeypatch.setenv('LSQAMD_JIT_CACHE', str(d))
+    assert codegen(lib, model)[0] == 0
+    files = [f for f in os.listdir(d) if f.endswith('.hsaco')]
+    assert len(files) == 1
+    path = os.path.join(d, files[0])
+    blob = open(path, 'rb').read()
+    magic, n, h = struct.unpack('<QQQ', blob[:24])
+    assert magic == int.from_bytes(b'LSQAMDJ1', 'little') and n == len(blob) - 24 and blob[24:28] == b'\x7fELF'
+    for damaged in (blob[:len(blob) // 2], blob[:24] + bytes([blob[24] ^ 1]) + blob[25:], blob + b'x', b'', blob[24:]):
+        with open(path, 'wb') as fh:
+            fh.write(damaged)
+        assert codegen(lib, model)[0] == 0
+        assert open(path, 'rb').read() == blob            # rebuilt, byte for byte (hiprtc is deterministic)
+    # a directory that is group / world writable (or not ours) is ignored: nothing is read from it, nothing written
+    shared = tmp_path / 'shared'
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    monkeypatch.setenv('LSQAMD_JIT_CACHE', str(shared))
+    assert codegen(lib, model)[0] == 0 and os.listdir(shared) == []
