@@ -284,6 +284,19 @@ int lsqamd_qr_info(const lsqamd_fit *fit, int32_t *passes, double *delta);
  * (src/lsqfit/__init__.py:641-655, tests/test_lsqfit.py:1780-1808).  LSQAMD_TRS_TRF and
  * LSQAMD_TRS_DOGBOX read them; p0 must lie inside (else lsqamd_run returns LSQAMD_EINVAL, as scipy raises). */
 int lsqamd_set_bounds(lsqamd_fit *fit, const double *lower, const double *upper);
+/* scipy_least_squares' other pass-through options (src/lsqfit/_scipy.py:76-79 names them, :147-153 forwards
+ * **extra_args verbatim to scipy.optimize.least_squares).
+ * loss / f_scale: scipy's robust losses rho(z), z = (f_i / f_scale)^2, over the elements of the whitened residual
+ * vector -- LSQAMD_TRS_TRF and LSQAMD_TRS_DOGBOX only (scipy's 'lm' refuses them too: LSQAMD_EINVAL).  Every
+ * residual must then be a ROW (a prior goes in through lsqamd_set_param_rows, not lsqamd_set_prior:
+ * LSQAMD_EUNSUPPORTED otherwise).  As in the reference the fit point minimises the robust cost, cov comes from the
+ * loss-scaled Jacobian scipy returns (:165-169), chi2 and logdet_jtj from the true residuals and Jacobian
+ * (src/lsqfit/__init__.py:667,:719), which is also what the getters return afterwards.
+ * x_scale[P] > 0 (NULL: scipy's default 1.0): characteristic scale of each parameter; read with scaler
+ * LSQAMD_SCALE_LEVENBERG by the three scipy methods (scaler MORE is x_scale = 'jac'). */
+enum { LSQAMD_LOSS_LINEAR = 0, LSQAMD_LOSS_SOFT_L1 = 1, LSQAMD_LOSS_HUBER = 2, LSQAMD_LOSS_CAUCHY = 3, LSQAMD_LOSS_ARCTAN = 4 };
+int lsqamd_set_loss(lsqamd_fit *fit, int32_t loss, double f_scale);
+int lsqamd_set_x_scale(lsqamd_fit *fit, const double *x_scale);
 /* nonlinear_fit's `linear=` (src/lsqfit/__init__.py:738-787, _varpro_fit; tests/test_lsqfit.py:1642-1682):
  * index[n] names the parameters the fit function is linear in (n = 0 clears): variable projection.
  * The reference wraps the residual so that every evaluation first solves for them exactly; so does

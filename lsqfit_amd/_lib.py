@@ -70,6 +70,8 @@ PROTOTYPES = {
     'lsqamd_set_bounds': (C.c_int, [_vp, _dp, _dp]),
     'lsqamd_set_linear': (C.c_int, [_vp, C.POINTER(C.c_int32), C.c_int32]),
     'lsqamd_set_param_rows': (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    'lsqamd_set_loss': (C.c_int, [_vp, C.c_int32, C.c_double]),
+    'lsqamd_set_x_scale': (C.c_int, [_vp, _vp]),
     'lsqamd_set_reduce': (C.c_int, [_vp, REDUCE_FN, _vp]),
     'lsqamd_set_adds_prior': (C.c_int, [_vp, C.c_int32]),
     'lsqamd_comm_unique_id': (C.c_int, [_vp, C.c_size_t]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblsqfit_amd.so')
 SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'potf2_mfma.hip', 'model.hip', 'vecops.hip', 'api.hip', 'scipy_methods.hip',
-           'batch.hip', 'comm.hip', 'whiten.hip', 'qr.hip', 'jit.hip', 'rankdef.hip']
+           'batch.hip', 'comm.hip', 'whiten.hip', 'qr.hip', 'jit.hip', 'rankdef.hip', 'robust.hip']
 # per-file code-generation switches (reasons in the files' headers)
 EXTRA = {'potf2_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

@@ -502,7 +502,10 @@ int eval_residual_launch(lsqamd_fit *f, const double *p, bool decide = false) {
     Scope sc(f, LSQAMD_T_RESIDUAL);
     const int rc = residual_vector_launch(f, p);
     if (rc) return rc;
-    HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, f->red_scalar));
+    if (f->robust())    // scipy's loss_function(f, cost_only=True), as 2 x cost
+      HIPCHK(f, launch_robust_cost(f->st, f->r, f->N, 1, f->loss, f->f_scale, f->partial, f->red_scalar));
+    else
+      HIPCHK(f, launch_sumsq(f->st, f->r, f->N, f->partial, f->red_scalar));
     if (f->cfg.has_prior && f->adds_prior)
       HIPCHK(f, launch_prior_chi2(f->st, f->P, f->prior_prec, f->cfg.prior_dense, f->prior_mean, p,
                                   f->tvec, f->red_scalar));
@@ -524,7 +527,7 @@ int eval_residual_dev(lsqamd_fit *f, const double *p, double *chi2_out) {
 // Whitening of the block rows of the Jacobian (and of its residual column).  *fused_chunks > 0 on
 // return: the bulk GEMM also left per-tile-row partial sums of J^T f in f->slabs
 // (fused_chunks x P, to be reduced before the SYRK reuses the slabs).
-int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks, bool r_here) {
+int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks, bool r_here, bool plain = false) {   // plain: no J^T f out of the product's epilogue (the rows are rescaled afterwards)
   *fused_chunks = 0;
   const int nb = f->cfg.n_blocks;
   if (nb <= 0) return 0;
@@ -567,7 +570,7 @@ int whiten_jacobian(lsqamd_fit *f, int64_t *fused_chunks, bool r_here) {
       }
       g.N = f->P;
       const int64_t chunks = (int64_t)nb * (B / 128);
-      if (f->h_row0[0] == 0 && (int64_t)nb * B == f->N && chunks * f->P <= slab_doubles) {
+      if (!plain && f->h_row0[0] == 0 && (int64_t)nb * B == f->N && chunks * f->P <= slab_doubles) {
         g.colsum_out = f->slabs;
         g.colsum_ld = f->P;
         g.colsum_rcol = f->P;
@@ -630,7 +633,8 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   // (jit.hip lsqamd_jit_nrm) -- the Jacobian is never written, the evaluation reads x, y, w once.  Device-resident LM only
   // (the host-side drivers and the getters call ensure_J() when they need the rows).  LSQAMD_FUSED_NORMAL=0 disables.
   static const bool nrm_off = [] { const char *e = getenv("LSQAMD_FUSED_NORMAL"); return e && e[0] == '0'; }();
-  const int nq = (!mirror && !nrm_off && f->nrm_part && f->progs.empty() && nbk == 0 && !f->have_param_rows && f->N > 0)
+  const bool robust = f->robust();     // rows rescaled by the loss before the products below see them: the unfused route
+  const int nq = (!mirror && !robust && !nrm_off && f->nrm_part && f->progs.empty() && nbk == 0 && !f->have_param_rows && f->N > 0)
                      ? lsqamd_jit::normal_nq(static_cast<const lsqamd_jit::Kernel *>(f->jit)) : 0;
   if (nq > 0) {
     double *gv = f->redbuf + f->npk;
@@ -670,7 +674,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   }
   f->J_stale = false;
   f->nrm_in_tail = 0;
-  if (nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
+  if (!robust && nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
       f->h_row0[0] == 0 && (int64_t)nbk * B0 == f->N && whiten_synth_eligible(f->cfg.model, B0, P) &&
       (int64_t)nbk * (B0 / 128) * P <= slab_doubles) {
     // the raw Jacobian rows are synthesised inside the whitening product (never written, never re-read);
@@ -704,8 +708,14 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
         HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, f->ld, p, f->ymean, f->wdiag,
                                     f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->J, f->Jraw, 1));
     }
-    rc = whiten_jacobian(f, &fused_chunks, r_here);
+    rc = whiten_jacobian(f, &fused_chunks, r_here, robust);
     if (rc) return rc;
+    if (robust) {
+      // scipy's scale_for_robust_loss_function on the whitened rows [J | f] (robust.hip); the cost of this point
+      // (red_scalar[2], put in chi2's place once J^T f has been formed) from the residual column before it is rescaled
+      HIPCHK(f, launch_robust_cost(f->st, f->J + P, f->N, f->ld, f->loss, f->f_scale, f->partial, f->red_scalar + 2));
+      HIPCHK(f, launch_robust_scale_rows(f->st, f->J, f->N, P, f->ld, f->loss, f->f_scale));
+    }
   }
   bool syrk_colsum = false;
   {
@@ -746,6 +756,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
       HIPCHK(f, launch_colsum_reduce(f->st, f->partial, f->splits, P + 1, gvec));
     else if (fused_chunks == 0)
       HIPCHK(f, launch_colsum_dot(f->st, f->J, f->N, f->ld, P + 1, P, f->partial, f->npartial, gvec));
+    if (robust) HIPCHK(f, launch_copy_strided(f->st, f->red_scalar + 2, 1, gvec + P, 1, 1, 1));   // 2 x cost, not |f_scaled|^2
     f->prior_deferred = with_prior && r_here && !mirror && small_fuse(f);
     if (with_prior && !f->prior_deferred)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)
       HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
@@ -843,7 +854,8 @@ int solve_damped_dev(lsqamd_fit *f, double mu, const double *diag_host, const do
 void scale_init(lsqamd_fit *f) {
   (void)launch_scale_update(f->st, f->P, f->opt.scaler, 1, f->diag_dev, f->dscale);  // diag_dev = coln^2
   for (int64_t j = 0; j < f->P; ++j) {
-    if (f->opt.scaler == LSQAMD_SCALE_LEVENBERG) f->hdiag[j] = 1.0;
+    if (f->opt.scaler == LSQAMD_SCALE_LEVENBERG)    // (scipy methods: D = 1 / x_scale, lsqamd_set_x_scale)
+      f->hdiag[j] = (f->opt.trs >= LSQAMD_TRS_TRF && !f->x_scale.empty()) ? 1.0 / f->x_scale[j] : 1.0;
     else f->hdiag[j] = f->hcoln[j] == 0.0 ? 1.0 : f->hcoln[j];
   }
 }
@@ -1720,6 +1732,21 @@ void fill_summary(lsqamd_fit *f, lsqamd_summary *s, int status, int info) {
   s->logdet_jtj = f->logdet;
 }
 
+// f->logdet = log det of the normal matrix in f->redbuf (NaN when it has no Cholesky factor); f->cov is left alone
+int logdet_normal(lsqamd_fit *f) {
+  const int64_t P = f->P;
+  int32_t info = 0;
+  double ld = 0.0;
+  HIPCHK(f, launch_build_damped(f->st, f->redbuf, P, f->ldm, 0.0, f->diag_dev, nullptr, f->M));
+  HIPCHK(f, potrf_upper(f->st, f->M, P, f->ldm, P, f->chol_work, f->info_dev));
+  HIPCHK(f, logdiag_sum(f->st, f->M, P, f->ldm, f->scal));
+  HIPCHK(f, hipMemcpyAsync(&info, f->info_dev, sizeof(int32_t), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipMemcpyAsync(&ld, f->scal, sizeof(double), hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
+  f->logdet = info != 0 ? NAN : 2.0 * ld;
+  return info != 0 ? LSQAMD_ENOTPD : 0;
+}
+
 // covariance + logdet at the current point: factor A (mu = 0), invert
 static int do_covariance_chol(lsqamd_fit *f);
 int do_covariance(lsqamd_fit *f) {
@@ -2193,6 +2220,28 @@ int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
   return 0;
 }
 
+int lsqamd_set_loss(lsqamd_fit *f, int32_t loss, double f_scale) {
+  if (!f) return LSQAMD_EINVAL;
+  if (loss < LSQAMD_LOSS_LINEAR || loss > LSQAMD_LOSS_ARCTAN) FAIL(f, LSQAMD_EINVAL, "set_loss: `loss` must be linear, soft_l1, huber, cauchy or arctan");
+  if (!(f_scale > 0.0) || !std::isfinite(f_scale)) FAIL(f, LSQAMD_EINVAL, "set_loss: f_scale must be positive");
+  f->loss = loss;
+  f->f_scale = f_scale;
+  f->drop_step_graphs();
+  return 0;
+}
+
+int lsqamd_set_x_scale(lsqamd_fit *f, const double *x_scale) {
+  if (!f) return LSQAMD_EINVAL;
+  std::vector<double> v;
+  if (x_scale) {
+    v.assign(x_scale, x_scale + f->P);
+    for (int64_t j = 0; j < f->P; ++j)
+      if (!(v[j] > 0.0) || !std::isfinite(v[j])) FAIL(f, LSQAMD_EINVAL, "set_x_scale: `x_scale` must be 'jac' or array_like with positive numbers");
+  }
+  f->x_scale.swap(v);
+  return 0;
+}
+
 int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
@@ -2459,6 +2508,12 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   const int maxit = f->opt.maxit;
   if (f->opt.trs >= LSQAMD_TRS_TRF) {
     int st = 0;
+    if (f->loss != LSQAMD_LOSS_LINEAR && f->opt.trs == LSQAMD_TRS_MINPACK_LM)
+      FAIL(f, LSQAMD_EINVAL, "method='lm' supports only 'linear' loss function.");      // scipy's wording
+    if (f->robust() && f->cfg.has_prior)
+      FAIL(f, LSQAMD_EUNSUPPORTED, "a robust loss acts on residual rows: pass the prior as rows (lsqamd_set_param_rows), not through lsqamd_set_prior");
+    if (f->robust() && (f->comm || f->reduce))
+      FAIL(f, LSQAMD_EUNSUPPORTED, "robust losses are single-rank");
     rc = f->opt.trs == LSQAMD_TRS_TRF ? run_trf(f, p0, &st)
          : f->opt.trs == LSQAMD_TRS_DOGBOX ? run_dogbox(f, p0, &st) : run_minpack(f, p0, &st);
     if (rc) return rc;
@@ -2491,6 +2546,19 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
   }
   rc = (f->used_one_launch && f->have_cov) ? 0 : do_covariance(f);
   if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
+  if (f->robust()) {
+    // the covariance above is that of the loss-scaled Jacobian scipy returns (src/lsqfit/_scipy.py:165-169); chi2 and
+    // log det(J^T J) -- and what the getters hand out from here on -- are those of the TRUE residuals and Jacobian
+    // at the fit point (:160-161, src/lsqfit/__init__.py:667,:719): one more evaluation, without the loss
+    const int32_t loss = f->loss;
+    f->loss = LSQAMD_LOSS_LINEAR;
+    int r2 = eval_normal_dev(f, f->p_dev, true);
+    if (r2 == 0) r2 = logdet_normal(f);
+    f->loss = loss;
+    f->njev--;                      // (bookkeeping of the library, not an evaluation of the method)
+    if (r2 < 0 && r2 != LSQAMD_ENOTPD) return r2;
+    f->have_cov = true;
+  }
   float ms = 0.f;
   if (f->used_one_launch && f->have_cov && rc == 0) {
     // the whole run was the one kernel whose last word the host has already seen: nothing is left on the stream to wait for

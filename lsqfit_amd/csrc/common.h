@@ -235,6 +235,11 @@ hipError_t launch_scale_update(hipStream_t st, int64_t P, int scaler, int init, 
                                double *dscale);
 // xt = x - v
 hipError_t launch_trial_point(hipStream_t st, int64_t P, const double *x, const double *v, double *xt);
+// robust losses of the scipy plugin (robust.hip): out[0] = f_scale^2 sum rho((r_i / f_scale)^2) over r[i * stride]; rows of
+// [J | f] rescaled in place (scipy's scale_for_robust_loss_function)
+hipError_t launch_robust_cost(hipStream_t st, const double *r, int64_t n, int64_t stride, int loss, double f_scale, double *partial,
+                              double *out);
+hipError_t launch_robust_scale_rows(hipStream_t st, double *J, int64_t n, int64_t P, int64_t ld, int loss, double f_scale);
 // tape functions beyond LSQAMD_OP_POWI (the interpreter kernels of model.hip / batch.hip; jit.hip emits the same formulas):
 // value and derivative
 __device__ __forceinline__ void tape_unary_ext(int op, double x, double &v, double &d) {
@@ -242,7 +247,7 @@ __device__ __forceinline__ void tape_unary_ext(int op, double x, double &v, doub
     case LSQAMD_OP_TAN: v = tan(x); d = 1.0 + v * v; break;
     case LSQAMD_OP_SINH: v = sinh(x); d = cosh(x); break;
     case LSQAMD_OP_COSH: v = cosh(x); d = sinh(x); break;
-    case LSQAMD_OP_TANH: v = tanh(x); d = 1.0 - v * v; break;
+    case LSQAMD_OP_TANH: { v = tanh(x); const double e = exp(-2.0 * fabs(x)); d = 4.0 * e / ((1.0 + e) * (1.0 + e)); break; }   // sech^2 without 1 - v^2's cancellation
     case LSQAMD_OP_ASIN: v = asin(x); d = 1.0 / sqrt(1.0 - x * x); break;
     case LSQAMD_OP_ACOS: v = acos(x); d = -1.0 / sqrt(1.0 - x * x); break;
     case LSQAMD_OP_ABS: v = fabs(x); d = x >= 0.0 ? 1.0 : -1.0; break;

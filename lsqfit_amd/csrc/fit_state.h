@@ -109,6 +109,11 @@ struct lsqamd_fit {
 
   // box bounds of the reflective trust-region method (empty: none)
   std::vector<double> lb, ub;
+  // scipy plugin: robust loss over the rows of the whitened residual (robust.hip), characteristic parameter scales
+  int32_t loss = 0;
+  double f_scale = 1.0;
+  std::vector<double> x_scale;
+  bool robust() const { return loss != 0 && (opt.trs == LSQAMD_TRS_TRF || opt.trs == LSQAMD_TRS_DOGBOX); }
   // parameters the residual is linear in (empty: none): variable projection (api.hip iterate_varpro)
   std::vector<char> linear;
 

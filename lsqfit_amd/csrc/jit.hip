@@ -526,7 +526,7 @@ struct TreeGen {
         break;
       case LSQAMD_OP_TANH:
         o.f("%sconst double %s = tanh(%s);\n", i, vv, a);
-        if (jac) o.f("%sconst double %s = 1.0 - %s * %s;\n", i, d(n, 'a').c_str(), vv, vv);
+        if (jac) o.f("%sconst double %se = exp(-2.0 * fabs(%s)), %s = 4.0 * %se / ((1.0 + %se) * (1.0 + %se));\n", i, vv, a, d(n, 'a').c_str(), vv, vv, vv);
         break;
       case LSQAMD_OP_ASIN:
         o.f("%sconst double %s = asin(%s);\n", i, vv, a);

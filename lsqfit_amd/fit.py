@@ -77,8 +77,18 @@ class nonlinear_fit(object):
         uncorrelated = data is None
         x, ymean, yerr = udata if uncorrelated else data
         pm, perr = (None, None) if prior is None else prior
+        # scipy_least_squares' robust losses (src/lsqfit/_scipy.py:76-79,:147-153) act on every ELEMENT of the whitened residual
+        # vector: the prior then travels as rows and every block is whitened in gvar's (eigen) basis (whiten.rows_whitening)
+        loss = fitterargs.get('loss', 'linear')
+        robust = self.fitter == 'mi355x_trf' and isinstance(loss, str) and loss != 'linear'
         if problem is None:
-            if cross is not None:
+            if robust:
+                if cross is not None or eps is not None or np.any(noise):
+                    raise NotImplementedError('a robust loss with cross= / eps / noise')
+                from .whiten import rows_whitening
+                wh = rows_whitening(ymean, yerr, pm, perr, svdcut=svdcut, udata=uncorrelated)
+                problem = DeviceProblem(model, x, wh)
+            elif cross is not None:
                 # data correlated with the prior (examples/y-noerr.py): ``cross`` is the N x P
                 # covariance between y and the prior; concat(y, prior) is whitened as one vector
                 # (src/lsqfit/__init__.py:1892-1900)
@@ -91,9 +101,12 @@ class nonlinear_fit(object):
             else:
                 wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, eps=eps, udata=uncorrelated, noise=noise,
                                rng=rng)
-            problem = DeviceProblem(model, x, wh)
+            if not robust:
+                problem = DeviceProblem(model, x, wh)
         else:
             wh = problem.wh
+            if robust and (wh.has_prior or getattr(wh, 'engine', None) != 'eig'):
+                raise ValueError('a robust loss needs a problem built for it (prior as rows, blocks in their eigen basis)')
         self.problem = problem
         self.problem_x = x
         self.whitening = wh

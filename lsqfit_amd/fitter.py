@@ -37,6 +37,18 @@ def _check(lib, h, rc, what):
     return rc
 
 
+def describe(alg, scaler, solver, avmax=0.75):
+    """``description`` of an mi355x_lm fit (src/lsqfit/_gsl.pyx:611-618 prints ``methods = alg/scaler/solver``): names what RAN.
+    gsl's ``'svd'`` solver (:650-651) has no counterpart here -- such a fit runs the QR-grade route (qr.hip) and says so."""
+    ran = 'qr' if solver == 'svd' else solver
+    d = 'methods = {}/{}/{}'.format(alg, scaler, ran)
+    if solver == 'svd':
+        d += "    (solver 'svd' runs as 'qr')"
+    if alg == 'lmaccel':
+        d += '    avmax = {}'.format(avmax)          # _gsl.pyx:617-618
+    return d
+
+
 def normalize_tol(tol):
     """src/lsqfit/_gsl.pyx:594-603."""
     shape = np.shape(tol)
@@ -521,9 +533,7 @@ class mi355x_lm(object):
         self.x0 = np.ascontiguousarray(x0, np.float64)
         self.n = n
         self.error = None
-        self.description = 'methods = {}/{}/{}'.format(alg, scaler, solver)
-        if alg == 'lmaccel':
-            self.description += '    avmax = {}'.format(avmax)          # _gsl.pyx:617-618
+        self.description = describe(alg, scaler, solver, avmax)
         pr = self.problem = problem
         if self.x0.size != pr.P:
             raise ValueError('len(x0) = %d but the model has %d parameters' % (self.x0.size, pr.P))
@@ -598,32 +608,60 @@ class mi355x_trf(mi355x_lm):
     ``x0, n, f, tol, maxit`` as there (``tol`` default ``(1e-8, 1e-8, 1e-8)``, ``maxit`` = cap on
     function evaluations); ``method`` None / ``'trf'``, ``'dogbox'`` or ``'lm'`` (no bounds, all
     tolerances above machine epsilon); ``bounds=(lower, upper)``;
-    ``x_scale`` 1.0 or ``'jac'``.  ``nit`` counts function evaluations (:161),
-    ``stopping_criterion`` follows :176-181, ``cov`` is ``inv(J^T J)`` at the fit point (what
-    :165-169 gives for a full-rank Jacobian; a rank-deficient one is an error here).
+    ``x_scale`` a positive number, an array of P of them, or ``'jac'``; ``loss`` one of scipy's ``'linear'``,
+    ``'soft_l1'``, ``'huber'``, ``'cauchy'``, ``'arctan'`` with ``f_scale`` (methods trf and dogbox; a callable loss is not
+    something a device can run); ``tr_solver`` None or ``'exact'`` (``'lsmr'`` -- scipy's iterative solver for sparse
+    Jacobians -- is declined), ``tr_options`` must be empty, ``jac_sparsity`` None: the pass-through options
+    :76-79 names and :147-153 forwards.  ``nit`` counts function evaluations (:161),
+    ``stopping_criterion`` follows :176-181, ``cov`` is ``inv(J^T J)`` of the (loss-scaled) Jacobian scipy returns (what
+    :165-169 gives for a full-rank Jacobian; a rank-deficient one gives the truncated inverse).
     """
+    LOSSES = dict(linear=0, soft_l1=1, huber=2, cauchy=3, arctan=4)
 
     def __init__(self, x0, n, f=None, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method=None, bounds=None,
-                 x_scale=1.0, problem=None):
+                 x_scale=1.0, loss='linear', f_scale=1.0, tr_solver=None, tr_options=None, jac_sparsity=None, problem=None):
         if problem is None:
             raise ValueError("mi355x_trf needs problem=DeviceProblem(...)")
         if method is None:
             method = 'trf'                                                 # _scipy.py:135-139
         if method not in ('trf', 'dogbox', 'lm'):
             raise ValueError("`method` must be 'trf', 'dogbox' or 'lm'.")
+        xs = None
         if isinstance(x_scale, str):
             if x_scale != 'jac':
-                raise ValueError("`x_scale` must be 'jac' or 1.0")
+                raise ValueError("`x_scale` must be 'jac' or array_like with positive numbers.")     # scipy's wording
             scaler = 'more'
-        elif np.all(np.asarray(x_scale, float) == 1.0):
-            scaler = 'levenberg'
         else:
-            raise NotImplementedError("x_scale is 1.0 or 'jac' on the device")
+            scaler = 'levenberg'
+            xs = np.asarray(x_scale, float)
+            if xs.ndim > 1 or not np.all(np.isfinite(xs)) or np.any(xs <= 0):
+                raise ValueError("`x_scale` must be 'jac' or array_like with positive numbers.")
+            if xs.ndim == 1 and xs.size != np.size(x0):
+                raise ValueError('Inconsistent shapes between `x_scale` and `x0`.')
+            xs = None if np.all(xs == 1.0) else np.ascontiguousarray(np.broadcast_to(xs, (np.size(x0),)), np.float64)
+        if callable(loss):
+            raise NotImplementedError('a callable loss cannot run on the device; use one of %s' % sorted(self.LOSSES))
+        if loss not in self.LOSSES:
+            raise ValueError('`loss` must be one of %s or a callable.' % list(self.LOSSES))           # scipy's wording
+        if method == 'lm' and loss != 'linear':
+            raise ValueError("method='lm' supports only 'linear' loss function.")
+        f_scale = float(f_scale)
+        if loss != 'linear' and not f_scale > 0:
+            raise ValueError('`f_scale` must be positive')
+        if tr_solver not in (None, 'exact'):
+            if tr_solver == 'lsmr':
+                raise NotImplementedError("tr_solver='lsmr' (iterative, for sparse Jacobians) is not built; the device solves the "
+                                          "trust-region sub-problems exactly")
+            raise ValueError("`tr_solver` must be None, 'exact' or 'lsmr'.")
+        if tr_options:
+            raise NotImplementedError("tr_options are lsmr's; the exact solver takes none")
+        if jac_sparsity is not None:
+            raise NotImplementedError('jac_sparsity: the device Jacobian is dense')
         if maxit is not None and maxit <= 0:
             raise ValueError('`max_nfev` must be None or positive integer.')
         self.tol = normalize_tol(tol)
         self.maxit = maxit
-        self.method, self.x_scale = method, x_scale
+        self.method, self.x_scale, self.loss, self.f_scale = method, x_scale, loss, f_scale
         self.x0 = np.ascontiguousarray(x0, np.float64)
         self.n = n
         self.error = None
@@ -639,6 +677,8 @@ class mi355x_trf(mi355x_lm):
         lib = pr.lib
         s = _lib.Summary()
         try:
+            _check(lib, pr.h, lib.lsqamd_set_loss(pr.h, self.LOSSES[loss], f_scale), 'set_loss')
+            _check(lib, pr.h, lib.lsqamd_set_x_scale(pr.h, None if xs is None else _lib.dptr(xs)), 'set_x_scale')
             rc = lib.lsqamd_run(pr.h, _lib.dptr(self.x0), C.byref(s))
             pr._raise_reduce()
             if rc == -1:                     # infeasible x0 / tolerances: scipy raises ValueError
@@ -646,6 +686,8 @@ class mi355x_trf(mi355x_lm):
             _check(lib, pr.h, rc, 'run')
         finally:
             pr.set_bounds(None)
+            lib.lsqamd_set_loss(pr.h, 0, 1.0)
+            lib.lsqamd_set_x_scale(pr.h, None)
         self.summary = s
         self.nit = s.nit
         self.chi2 = s.chi2

@@ -168,8 +168,8 @@ def regulate_blocks(covs, svdcut, want_prec=False, engine=None):
     back and for ``engine='host'``."""
     if engine is None:
         engine = 'device' if device_available() else 'host'
-    if engine not in ('device', 'host'):
-        raise ValueError("engine must be 'device' or 'host'")
+    if engine not in ('device', 'host', 'eig'):
+        raise ValueError("engine must be 'device', 'host' or 'eig'")
     out = [None] * len(covs)
     if engine == 'device':
         by_size = {}
@@ -180,7 +180,9 @@ def regulate_blocks(covs, svdcut, want_prec=False, engine=None):
                 out[i] = k
     for i, c in enumerate(covs):
         if out[i] is None:
-            out[i] = _Block(_regulate_block(c, svdcut, force_eig=(engine == 'device')))
+            # 'eig': every block through its eigen-modes, the basis gvar whitens in -- needed where the fit is NOT invariant under
+            # a rotation of a block's whitened rows (robust losses, rows_whitening)
+            out[i] = _Block(_regulate_block(c, svdcut, force_eig=(engine in ('device', 'eig'))))
             out[i]['cov'] = np.asarray(c, float)
     return out
 
@@ -513,7 +515,7 @@ def _components(cov):
     return out
 
 
-def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12):
+def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, engine=None):
     """Whitening of concat(y, prior) when data and prior are correlated (``cross`` = the N x P
     covariance between them): what src/lsqfit/__init__.py:1892-1900 hands to gvar.PDF.
 
@@ -552,7 +554,7 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12):
         if c.size > 1:
             blocks.append((r0, full[np.ix_(c, c)]))
         r0 += c.size
-    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut)
+    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut, engine=engine)
     wh.joint = True
     wh.row_src = perm
     wh.row_param = np.where(perm >= N, perm - N, -1).astype(np.int32)
@@ -561,4 +563,43 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12):
     wh.prior_mean_host = pm                       # host-side bookkeeping only (default p0, maxit = 0)
     wh.prior_sdev = np.sqrt(np.diag(full))[N:]
     wh.prior_cov_host = full[N:, N:]
+    return wh
+
+
+def rows_whitening(ymean, yerr, prior_mean, prior_err, svdcut=1e-12, udata=False):
+    """Whitening of concat(y, prior) with the prior entries as ROWS (``row_param``, as :func:`joint_whitening` -- but without a
+    dense (N + P)^2 matrix) and every correlated block whitened in its eigen basis, rows = modes, as gvar.PDF does
+    (src/lsqfit/__init__.py:1892-1900).  For fits that are not invariant under a rotation of a block's whitened rows: scipy's
+    robust losses act on each element of the residual vector the plugin hands over (src/lsqfit/_scipy.py:147-153)."""
+    ymean = np.array(ymean, float).reshape(-1)
+    N = ymean.size
+    ysd, yblocks, yperm = _as_blocks(yerr, N)
+    if udata:
+        if yperm is not None:
+            ysd = ysd[np.argsort(yperm)]
+        yblocks, yperm = [], None
+    if prior_mean is None:
+        wh = Whitening(ymean, yerr if not udata else ysd, svdcut=svdcut, engine='eig')
+        return wh
+    pm = np.array(prior_mean, float).reshape(-1)
+    P = pm.size
+    psd, pblocks, pperm = _as_blocks(prior_err, P)
+    if yperm is not None or pperm is not None:
+        # interleaved covariance components: the joint construction permutes data and prior entries alike (dense, small fits)
+        wh = joint_whitening(ymean, yerr, pm, prior_err, np.zeros((N, P)), svdcut=svdcut, engine='eig')
+        return wh
+    z = np.concatenate([ymean, pm])
+    wh = Whitening(z, dict(sdev=np.concatenate([ysd, psd]), blocks=yblocks + [(N + r0, c) for r0, c in pblocks]), svdcut=svdcut,
+                   engine='eig')
+    wh.joint = True
+    wh.row_src = np.arange(N + P)
+    wh.row_param = np.concatenate([np.full(N, -1), np.arange(P)]).astype(np.int32)
+    wh.model_rows = np.arange(N)
+    wh.n_model = N
+    wh.prior_mean_host = pm
+    wh.prior_sdev = psd
+    pc = np.diag(psd ** 2)
+    for r0, c in pblocks:
+        pc[r0:r0 + c.shape[0], r0:r0 + c.shape[0]] = c
+    wh.prior_cov_host = pc
     return wh

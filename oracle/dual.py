@@ -144,7 +144,7 @@ arctan = _unary(np.arctan, lambda v: 1.0 / (1.0 + v * v))
 fabs = _unary(np.fabs, lambda v: np.where(v >= 0.0, 1.0, -1.0))
 sinh = _unary(np.sinh, np.cosh)
 cosh = _unary(np.cosh, np.sinh)
-tanh = _unary(np.tanh, lambda v: 1.0 - np.tanh(v) ** 2)
+tanh = _unary(np.tanh, lambda v: 1.0 / np.cosh(np.clip(v, -700.0, 700.0)) ** 2)
 arcsin = _unary(np.arcsin, lambda v: 1.0 / np.sqrt(1.0 - v * v))
 arccos = _unary(np.arccos, lambda v: -1.0 / np.sqrt(1.0 - v * v))
 

@@ -27,11 +27,51 @@ problems and demands the same iterates (identical nfev, x to rounding).
           > 0.75 on the boundary doubles it; ftol / xtol tests after every trial
   status  0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 ftol and xtol
 
-x_scale: 1.0 (scipy's default, what the reference passes on) or 'jac'.
+x_scale: 1.0 (scipy's default, what the reference passes on), an array, or 'jac'.
+loss / f_scale (passed through by the reference, src/lsqfit/_scipy.py:76-79,:147-153): scipy's robust losses
+rho(z), z = (f / f_scale)^2 -- 'linear', 'soft_l1', 'huber', 'cauchy', 'arctan' (optimize/_lsq/least_squares.py) --
+enter through scale_for_robust_loss_function (optimize/_lsq/common.py): row i of J is multiplied by
+sqrt(max(eps, rho' + 2 rho'' f_i^2)), f_i by rho' over that; cost = 0.5 f_scale^2 sum rho(z).
 """
 import numpy as np
 
 EPS = np.finfo(float).eps
+LOSSES = ('linear', 'soft_l1', 'huber', 'cauchy', 'arctan')
+
+
+def loss_rho(f, loss, f_scale, cost_only=False):
+    """scipy's construct_loss_function: -> cost (cost_only) or rho = [rho, rho', rho''] of z = (f / f_scale)^2, the value
+    scaled by f_scale^2 and the second derivative by 1 / f_scale^2."""
+    z = (f / f_scale) ** 2
+    if loss == 'linear':
+        r0, r1, r2 = z, np.ones_like(z), np.zeros_like(z)
+    elif loss == 'huber':
+        big = z > 1
+        r0 = np.where(big, 2 * np.sqrt(np.where(big, z, 1.0)) - 1, z)
+        r1 = np.where(big, np.where(big, z, 1.0) ** -0.5, 1.0)
+        r2 = np.where(big, -0.5 * np.where(big, z, 1.0) ** -1.5, 0.0)
+    elif loss == 'soft_l1':
+        t = 1 + z
+        r0, r1, r2 = 2 * (t ** 0.5 - 1), t ** -0.5, -0.5 * t ** -1.5
+    elif loss == 'cauchy':
+        t = 1 + z
+        r0, r1, r2 = np.log1p(z), 1 / t, -1 / t ** 2
+    elif loss == 'arctan':
+        t = 1 + z ** 2
+        r0, r1, r2 = np.arctan(z), 1 / t, -2 * z / t ** 2
+    else:
+        raise ValueError('`loss` must be one of %s.' % (LOSSES,))
+    if cost_only:
+        return 0.5 * f_scale ** 2 * np.sum(r0)
+    return np.array([r0 * f_scale ** 2, r1, r2 / f_scale ** 2])
+
+
+def scale_for_loss(J, f, rho):
+    """scipy's scale_for_robust_loss_function -> (J scaled, f scaled)."""
+    js = rho[1] + 2 * rho[2] * f ** 2
+    js[js < EPS] = EPS
+    js **= 0.5
+    return J * js[:, None], f * rho[1] / js
 
 
 def cl_scaling(x, g, lb, ub):
@@ -211,9 +251,12 @@ class TRFResult:
     pass
 
 
-def trf(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=None, x_scale=1.0):
-    """Counterpart of ``least_squares(fun, x0, jac, bounds, 'trf', ftol, xtol, gtol, x_scale,
-    max_nfev=...)`` for dense Jacobians and the linear loss."""
+def trf(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=None, x_scale=1.0, loss='linear', f_scale=1.0):
+    """Counterpart of ``least_squares(fun, x0, jac, bounds, 'trf', ftol, xtol, gtol, x_scale, loss, f_scale,
+    max_nfev=...)`` for dense Jacobians."""
+    robust = loss != 'linear'
+    if loss not in LOSSES:
+        raise ValueError('`loss` must be one of %s.' % (LOSSES,))
     x0 = np.atleast_1d(np.asarray(x0, float))
     n = x0.size
     if bounds is None:
@@ -235,7 +278,13 @@ def trf(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=Non
     J = np.atleast_2d(np.asarray(jac(x), float))
     njev = 1
     m = f.size
-    cost = 0.5 * (f @ f)
+    f_true = f
+    if robust:
+        rho = loss_rho(f, loss, f_scale)
+        cost = 0.5 * np.sum(rho[0])
+        J, f = scale_for_loss(J, f, rho)
+    else:
+        cost = 0.5 * (f @ f)
     g = J.T @ f
     jac_scale = isinstance(x_scale, str) and x_scale == 'jac'
 
@@ -293,7 +342,7 @@ def trf(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=Non
             if not np.all(np.isfinite(f_new)):
                 Delta = 0.25 * sh_norm
                 continue
-            cost_new = 0.5 * (f_new @ f_new)
+            cost_new = loss_rho(f_new, loss, f_scale, cost_only=True) if robust else 0.5 * (f_new @ f_new)
             actual = cost - cost_new
             if predicted > 0:
                 ratio = actual / predicted
@@ -315,13 +364,16 @@ def trf(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=Non
             Delta = Delta_new
         if actual > 0:
             x, f, cost = x_new, f_new, cost_new
+            f_true = f
             J = np.atleast_2d(np.asarray(jac(x), float))
             njev += 1
+            if robust:
+                J, f = scale_for_loss(J, f, loss_rho(f, loss, f_scale))
             g = J.T @ f
             if jac_scale:
                 scale, scale_inv = jscale(J, scale_inv)
     res = TRFResult()
-    res.x, res.cost, res.fun, res.jac, res.grad = x, cost, f, J, g
+    res.x, res.cost, res.fun, res.jac, res.grad = x, cost, f_true, J, g
     res.optimality, res.nfev, res.njev = g_norm, nfev, njev
     res.status = 0 if status is None else status
     return res
@@ -347,8 +399,8 @@ def _dogleg_in_box(x, newton, g, a, b, tr, lb, ub):
     return cauchy + t * diff, lands, tr_hit
 
 
-def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=None, x_scale=1.0):
-    """Counterpart of ``least_squares(..., method='dogbox')`` (dense Jacobian, linear loss): dogleg
+def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=None, x_scale=1.0, loss='linear', f_scale=1.0):
+    """Counterpart of ``least_squares(..., method='dogbox')`` (dense Jacobian): dogleg
     steps in a rectangular trust region, variables that reach a wall with the gradient pushing
     outwards leave the active problem (optimize/_lsq/dogbox.py)."""
     x0 = np.atleast_1d(np.asarray(x0, float))
@@ -370,7 +422,16 @@ def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=
         raise ValueError('Residuals are not finite in the initial point.')
     nfev = njev = 1
     J = np.atleast_2d(np.asarray(jac(x), float))
-    cost = 0.5 * (f @ f)
+    robust = loss != 'linear'
+    if loss not in LOSSES:
+        raise ValueError('`loss` must be one of %s.' % (LOSSES,))
+    f_true = f
+    if robust:
+        rho = loss_rho(f, loss, f_scale)
+        cost = 0.5 * np.sum(rho[0])
+        J, f = scale_for_loss(J, f, rho)
+    else:
+        cost = 0.5 * (f @ f)
     g = J.T @ f
     jac_scale = isinstance(x_scale, str) and x_scale == 'jac'
 
@@ -426,7 +487,7 @@ def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=
             if not np.all(np.isfinite(f_new)):
                 Delta = 0.25 * sh_norm
                 continue
-            cost_new = 0.5 * (f_new @ f_new)
+            cost_new = loss_rho(f_new, loss, f_scale, cost_only=True) if robust else 0.5 * (f_new @ f_new)
             actual = cost - cost_new
             if predicted > 0:
                 ratio = actual / predicted
@@ -449,15 +510,18 @@ def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=
             x[on_bound == -1] = lb[on_bound == -1]
             x[on_bound == 1] = ub[on_bound == 1]
             f, cost = f_new, cost_new
+            f_true = f
             J = np.atleast_2d(np.asarray(jac(x), float))
             njev += 1
+            if robust:
+                J, f = scale_for_loss(J, f, loss_rho(f, loss, f_scale))
             g = J.T @ f
             if jac_scale:
                 scale, scale_inv = jscale(J, scale_inv)
         else:
             g = g_full
     res = TRFResult()
-    res.x, res.cost, res.fun, res.jac, res.grad = x, cost, f, J, g_full
+    res.x, res.cost, res.fun, res.jac, res.grad = x, cost, f_true, J, g_full
     res.optimality, res.nfev, res.njev = g_norm, nfev, njev
     res.status = 0 if status is None else status
     res.active_mask = on_bound
@@ -465,7 +529,7 @@ def dogbox(fun, jac, x0, bounds=None, xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=
 
 
 def scipy_least_squares(x0, n, f, df, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method=None, bounds=None,
-                        x_scale=1.0):
+                        x_scale=1.0, loss='linear', f_scale=1.0):
     """Counterpart of ``lsqfit.scipy_least_squares`` (src/lsqfit/_scipy.py:115-181) for
     method 'trf', with an explicit Jacobian callback in place of the GVar trick."""
     from .lm import normalize_tol
@@ -476,10 +540,12 @@ def scipy_least_squares(x0, n, f, df, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method
         from .minpack import least_squares_lm
         if bounds is not None and not (np.all(np.isneginf(bounds[0])) and np.all(np.isposinf(bounds[1]))):
             raise ValueError("Method 'lm' doesn't support bounds.")
+        if loss != 'linear':
+            raise ValueError("method='lm' supports only 'linear' loss function.")
         fit = least_squares_lm(f, df, x0, xtol=tol[0], gtol=tol[1], ftol=tol[2], max_nfev=maxit, x_scale=x_scale)
     else:
         fit = (dogbox if method == 'dogbox' else trf)(f, df, x0, bounds=bounds, xtol=tol[0], gtol=tol[1],
-                                                      ftol=tol[2], max_nfev=maxit, x_scale=x_scale)
+                                                      ftol=tol[2], max_nfev=maxit, x_scale=x_scale, loss=loss, f_scale=f_scale)
     res = TRFResult()
     res.tol = tol
     res.description = 'method = {}'.format('trf' if method is None else method)      # :134-139

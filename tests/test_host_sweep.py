@@ -103,3 +103,30 @@ def test_prior_width_sweep_old_positional_form_is_still_accepted(monkeypatch):
     assert [f.width for f in new] == [f.width for f in old] == [0.1, 1.0, 10.0] and new[2].logGBF == 2.0
     with pytest.raises(TypeError):
         sw.prior_width_sweep(data, 'model')
+
+
+def test_description_names_what_ran():
+    """solver='svd' (src/lsqfit/_gsl.pyx:650-651) runs the QR-grade route: the description says so instead of printing a solver
+    that did not run; the others print the reference's string (:611-618)."""
+    from lsqfit_amd.fitter import describe
+    assert describe('lm', 'more', 'qr') == 'methods = lm/more/qr'
+    assert describe('lm', 'more', 'cholesky') == 'methods = lm/more/cholesky'
+    assert describe('lmaccel', 'levenberg', 'qr', 0.5) == 'methods = lmaccel/levenberg/qr    avmax = 0.5'
+    d = describe('lm', 'more', 'svd')
+    assert d.startswith('methods = lm/more/qr') and "'svd' runs as 'qr'" in d
+
+
+def test_scipy_plugin_option_validation_needs_no_device():
+    """The pass-through options of scipy_least_squares (src/lsqfit/_scipy.py:76-79): what is refused is refused in scipy's words
+    before anything touches the device."""
+    import pytest
+    from lsqfit_amd.fitter import mi355x_trf
+    with pytest.raises(ValueError, match='problem=DeviceProblem'):
+        mi355x_trf([1.0], 1)
+    for kw, exc in [(dict(loss='tukey'), ValueError), (dict(loss=lambda z: z), NotImplementedError), (dict(x_scale='jack'), ValueError),
+                    (dict(x_scale=[1.0, -1.0]), ValueError), (dict(x_scale=[1.0, 2.0, 3.0]), ValueError), (dict(tr_solver='lsmr'), NotImplementedError),
+                    (dict(tr_solver='cg'), ValueError), (dict(method='lm', loss='huber'), ValueError), (dict(loss='huber', f_scale=0.0), ValueError),
+                    (dict(tr_options={'atol': 1e-3}), NotImplementedError), (dict(jac_sparsity=[[1]]), NotImplementedError),
+                    (dict(method='newton'), ValueError)]:
+        with pytest.raises(exc):
+            mi355x_trf([1.0, 2.0], 5, problem=object(), **kw)

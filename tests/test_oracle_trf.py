@@ -151,3 +151,51 @@ def test_minpack_lm_reference_case_and_limits():
         assert (got.nfev, got.status) == (ref.nfev, ref.status)
     with pytest.raises(ValueError, match='machine epsilon'):
         minpack.least_squares_lm(f, df, np.zeros(3), xtol=1e-17)
+
+
+def outlier_problem(seed, k=2, m=60):
+    """exp_problem with a tenth of the points knocked far off: what a robust loss is for."""
+    fun0, jac, truth = exp_problem(300 + seed, m=m, k=k)
+    rng = np.random.default_rng(seed)
+    bad = rng.choice(m, m // 10, replace=False)
+    shift = np.zeros(m)
+    shift[bad] = rng.choice([-1.0, 1.0], bad.size) * rng.uniform(0.2, 0.6, bad.size)
+
+    def fun(p):
+        return (fun0(p) - shift) / 0.02          # residuals in units of a 0.02 error bar: outliers at 10 .. 30 sigma
+    return fun, (lambda p: jac(p) / 0.02), truth
+
+
+@pytest.mark.parametrize('method', ['trf', 'dogbox'])
+@pytest.mark.parametrize('loss', ['soft_l1', 'huber', 'cauchy', 'arctan'])
+@pytest.mark.parametrize('f_scale', [1.0, 2.5])
+@pytest.mark.parametrize('seed', range(3))
+def test_robust_losses_same_iterates_as_scipy(seed, f_scale, loss, method):
+    """loss / f_scale (src/lsqfit/_scipy.py:76-79 documents them, :147-153 forwards them): the restated losses and
+    scale_for_robust_loss_function against scipy itself, with an array x_scale and with bounds."""
+    fun, jac, truth = outlier_problem(seed, k=1 + seed % 2)
+    n = truth.size
+    x0 = truth * (1.0 + 0.2 * np.cos(np.arange(n) + seed))
+    bounds = None if seed != 1 else (np.minimum(truth, x0) - 0.3, np.maximum(truth, x0) + 0.3)
+    x_scale = 1.0 if seed == 0 else np.linspace(0.5, 2.0, n)
+    kw = dict(xtol=1e-8, gtol=1e-8, ftol=1e-8, max_nfev=300, x_scale=x_scale, loss=loss, f_scale=f_scale)
+    ref = scipy_opt.least_squares(fun, x0, jac=jac, method=method, bounds=(-np.inf, np.inf) if bounds is None else bounds, **kw)
+    got = getattr(trf, method)(fun, jac, x0, bounds=bounds, **kw)
+    assert got.nfev == ref.nfev and got.njev == ref.njev and got.status == ref.status
+    # (two look-alike exponentials under a non-convex loss: the SVD-based sub-problem amplifies rounding differences to
+    #  ~1e-8 of x over a few dozen iterations; the iteration counts above are identical)
+    np.testing.assert_allclose(got.x, ref.x, rtol=2e-7, atol=1e-12)
+    assert abs(got.cost - ref.cost) <= 1e-9 * ref.cost
+    np.testing.assert_allclose(got.fun, ref.fun, rtol=1e-6, atol=1e-6)        # the TRUE residuals ...
+    np.testing.assert_allclose(got.jac, ref.jac, rtol=1e-6, atol=1e-6)        # ... and the SCALED Jacobian (the plugin's covariance, :165-169)
+    # the outliers do not drag the fit: closer to the truth than the plain least-squares answer
+    plain = scipy_opt.least_squares(fun, x0, jac=jac, method=method)
+    assert np.linalg.norm(got.x - truth) < np.linalg.norm(plain.x - truth)
+
+
+def test_lm_takes_only_the_linear_loss():
+    fun, jac, truth = outlier_problem(0)
+    with pytest.raises(ValueError):
+        trf.scipy_least_squares(truth, 60, fun, jac, method='lm', loss='huber')
+    with pytest.raises(ValueError):
+        trf.trf(fun, jac, truth, loss='tukey')
