@@ -116,3 +116,18 @@ def test_reduce_hook_rejects_foreign_pointer():
         v(ws.data_ptr() + 250, 4)
     with pytest.raises(ValueError):
         v(ws.data_ptr() - 8, 1)
+
+
+def test_headline_blocks_over_eight_ranks():
+    """C4: 65536 rows in 256 covariance blocks of 256 -> 8 ranks, 32 whole blocks (8192 rows) each; ragged cases never cut a block."""
+    from lsqfit_amd.dist import shard_rows
+    blocks = [(r0, 256) for r0 in range(0, 65536, 256)]
+    ranges = shard_rows(65536, blocks, 8)
+    assert ranges == [(k * 8192, (k + 1) * 8192) for k in range(8)]
+    # 250 blocks of 256 + 1536 loose rows: every boundary on a block edge or among the loose rows, rows balanced to a block
+    n = 250 * 256 + 1536
+    ranges = shard_rows(n, [(r0, 256) for r0 in range(0, 250 * 256, 256)], 8)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    for a, b in ranges:
+        assert a >= 250 * 256 or a % 256 == 0
+        assert abs((b - a) - n / 8) <= 256

@@ -80,3 +80,23 @@ def test_self_launch_has_a_wall_clock_limit():
                         '--nparam', '256'], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 124, (r.returncode, r.stderr[-1000:])
     assert 'LSQAMD_BENCH_TIMEOUT_S' in r.stderr and time.time() - t0 < 120
+
+
+def test_eight_rank_self_launch_at_the_shard_shape(tmp_path):
+    """`python bench.py --gpus 8 --ndata 8192` (P = 4096: what each of 8 GPUs sees of the headline configuration is N = 8192 rows; here 8
+    ranks share 8192 rows and ONE GPU through the RCCL stand-in): the launch line, the library collective with 8 ranks, 8 per-rank
+    entries.  Correctness of the sharded sums is tests/test_gpu_comm_multi.py's; nothing here measures scaling."""
+    fake = str(tmp_path / 'libfake_rccl.so')
+    b = subprocess.run([os.environ.get('HIPCC', 'hipcc'), '-O2', '-std=c++17', '-fPIC', '-shared',
+                        os.path.join(ROOT, 'tests', 'fake_rccl.cpp'), '-o', fake, '-lrt'], capture_output=True, text=True)
+    assert b.returncode == 0, b.stderr
+    env = dict(os.environ, LSQAMD_DIST_BACKEND='gloo', LSQAMD_COLLECTIVE='rccl', LSQAMD_RCCL_PATH=fake)
+    r = subprocess.run([sys.executable, 'bench.py', '--gpus', '8', '--steps', '2', '--warmup', '1', '--ndata', '8192', '--whole-fit-maxit', '0'],
+                       cwd=ROOT, capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = last_json(r.stdout)
+    assert d['n_gpus'] == 8 and d['config']['collective'].startswith('RCCL reduce-scatter + all-gather inside the library')
+    assert len(d['per_rank']['reduce_ms_per_call']) == 8 and len(d['per_rank']['ms_per_step']) == 8
+    assert all(t > 0 for t in d['per_rank']['reduce_ms_per_call'])
+    assert '(65536,4096)' not in d['metric'] and '(8192,4096)' in d['metric']
+    assert d['phases_calls']['reduce'] >= 2 * d['phases_calls']['jacobian']

@@ -33,8 +33,12 @@ def _problem(case):
     from lsqfit_amd import synth
     if case == 'blocks':      # P = 384: npk + P + 1 = 6 tiles * 128^2 + 385 = 98689 doubles (odd; slices of 49344 / 32896 + tails)
         return synth.make_cosmix(N=1536, P=384, seed=191, block=256, prior_corr=True)
-    if case == 'small':       # P = 30: the packed buffer is below the 64 KiB-per-rank switch -> single all-reduce
+    if case in ('small', 'small8'):       # P = 30: the packed buffer is below the 64 KiB-per-rank switch -> single all-reduce
         return synth.make_cosmix(N=1000, P=30, seed=192, block=0, prior_corr=False)
+    if case == 'eight':       # 8 blocks for 8 ranks; 98689 doubles = 8 slices of 12320 (whole 256-byte lines) + a tail of 129
+        return synth.make_cosmix(N=2048, P=384, seed=193, block=256, prior_corr=True)
+    if case == 'c4_packed':   # the named shape's parameter count: ONE packed buffer of 528 tiles * 128^2 + 4097 doubles = 69.2 MB per exchange
+        return synth.make_cosmix(N=2048, P=4096, seed=194, block=256, prior_corr=True)
     raise ValueError(case)
 
 
@@ -78,11 +82,13 @@ def _worker(rank, world, outdir, case, fake, algo, missing):
     pr.comm_init(uid, rank, world)
     assert pr.comm_info() == (rank, world)
     pr.timing(True)
-    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], problem=pr)
+    kw = dict(maxit=2) if case == 'c4_packed' else {}
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], problem=pr, **kw)
     tm = pr.timings()
     s = fit.fitter_results.summary
-    pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
-    c2 = pr.chi2_points(pts)                         # m = 5 sums through the communicator (count 5: all-reduce form)
+    m = 65536 if case == 'small8' else 5             # 65536 sums over 8 ranks: 8 slices of exactly 8192 doubles, no tail
+    pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((m, d['p0'].size))
+    c2 = pr.chi2_points(pts)                         # m sums through the communicator (count 5: all-reduce form)
     np.savez(os.path.join(outdir, 'r%d.npz' % rank), pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit,
              logGBF=fit.logGBF, c2=c2, reduces=tm['reduce'][1], expect=s.njev + s.nfev - 1, error='')
     pr.comm_destroy()
@@ -140,3 +146,44 @@ def test_rsag_and_allreduce_forms_agree_bit_for_bit(tmp_path, fake_rccl):
 def test_missing_rank_is_an_error_not_a_hang(tmp_path, fake_rccl):
     res = _run(2, tmp_path, 'small', fake_rccl, 'rsag', missing=True, nstart=1)
     assert 'EREDUCE' in str(res[0]['error']) or 'missing' in str(res[0]['error'])
+
+
+@pytest.mark.parametrize('case', ['eight', 'small8'])
+def test_eight_ranks(case, tmp_path, fake_rccl):
+    """The node the north star names has 8 GPUs: 8 ranks through comm.hip's slicing -- 98689 doubles (8 slices of 12320 + a tail of
+    129; `eight`), 65536 many-point sums (8 slices of exactly 8192, no tail; `small8`), the count-1 trial scalar -- on the stand-in.
+    Every rank bit-identical, equal to the unsharded fit.  (Says nothing about xGMI: no scaling number follows from this.)"""
+    import lsqfit_amd as amd
+    res = _run(8, tmp_path, case, fake_rccl, 'rsag')
+    assert len(res) == 8
+    for r in res:
+        assert int(r['reduces']) == int(r['expect'])
+    for r in res[1:]:
+        for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
+            assert np.array_equal(res[0][k], r[k]), k
+    d = _problem(case)
+    ref = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(res[0]['pmean'], ref.pmean) < 1e-9 and rel(res[0]['cov'], ref.cov) < 1e-8
+    assert abs(res[0]['chi2'] / ref.chi2 - 1) < 1e-10 and int(res[0]['nit']) == ref.nit
+    m = res[0]['c2'].size
+    pts = ref.pmean + 1e-3 * np.random.default_rng(2).standard_normal((m, d['p0'].size))
+    assert rel(res[0]['c2'], ref.problem.chi2_points(pts)) < 1e-8
+
+
+def test_named_parameter_count_packed_exchange_over_eight_ranks(tmp_path, fake_rccl):
+    """P = 4096 as in the headline configuration: the 69.2 MB packed [J^T J | J^T f | chi2] buffer goes through the reduce-scatter +
+    all-gather of 8 ranks once per Jacobian (two LM iterations; 256 rows = one covariance block per rank)."""
+    import lsqfit_amd as amd
+    res = _run(8, tmp_path, 'c4_packed', fake_rccl, 'rsag')
+    for r in res[1:]:
+        for k in ('pmean', 'cov', 'chi2', 'nit'):
+            assert np.array_equal(res[0][k], r[k]), k
+    d = _problem('c4_packed')
+    ref = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], maxit=2)
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert int(res[0]['nit']) == ref.nit == 2
+    assert rel(res[0]['pmean'], ref.pmean) < 1e-9 and abs(res[0]['chi2'] / ref.chi2 - 1) < 1e-9
+    # (2048 rows for 4096 parameters, two iterations from the start: A = J^T J + prior has cond ~ 1e6 and its entries carry the 1e-11
+    #  of differently ordered sums at chi2 ~ 4e9 -- the inverse agrees to cond x that)
+    assert rel(res[0]['cov'], ref.cov) < 1e-3
