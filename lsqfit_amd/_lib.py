@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(HERE, 'liblsqfit_amd.so')
+LIBPATH = os.environ.get('LSQAMD_LIBPATH') or os.path.join(HERE, 'liblsqfit_amd.so')   # (the variable: developer builds, tools/build_variant.sh)
 ABI_VERSION = 6
 
 COMM_ID_BYTES = 128

@@ -370,6 +370,20 @@ __device__ __forceinline__ void leaf_slab(v4d &DA, v4d &DE, int &bad, int lane) 
   const int col = lane & 15;
   const v4d zero = {0.0, 0.0, 0.0, 0.0};
   const double mo = pivot4_reg<R>(DA[R], bad, lane);
+#ifdef LSQAMD_LEAF_CHAIN_FIRST
+  // experiment (round 4): the two MFMAs the next pivot block waits for first, the identity half behind them
+  const v4d ta = mfma4(mo, DA[R], zero);
+  DA[R] = ta[0];
+  double a = 0.0;
+  if constexpr (R < 3) {
+    a = (col > 4 * R + 3) ? -ta[0] : 0.0;
+    DA = mfma4(a, DA[R], DA);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  const v4d te = mfma4(mo, DE[R], zero);
+  DE[R] = te[0];
+  if constexpr (R < 3) DE = mfma4(a, DE[R], DE);
+#else
   const v4d ta = mfma4(mo, DA[R], zero);
   const v4d te = mfma4(mo, DE[R], zero);
   DA[R] = ta[0];
@@ -379,6 +393,7 @@ __device__ __forceinline__ void leaf_slab(v4d &DA, v4d &DE, int &bad, int lane) 
     DA = mfma4(a, DA[R], DA);
     DE = mfma4(a, DE[R], DE);
   }
+#endif
 }
 
 // 16 x 16 leaf [D | I] -> [U | U^-T] in place in the owner's registers (accumulator layout), then
