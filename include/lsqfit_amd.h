@@ -268,8 +268,9 @@ int lsqamd_set_prior(lsqamd_fit *fit, const double *mean, const double *prec);  
  * n_data = N + (number of prior entries), give the prior entries as extra rows of ymean / wdiag /
  * the covariance blocks (any block may mix both kinds), and flag them here: row_param[n_data] holds
  * -1 for a model row and j >= 0 for a row whose "model" is the parameter p_j itself (its x is
- * ignored).  NULL clears.  Single-device fits only; lsqamd_eval_fcn declines;
- * lsqamd_dpdy returns columns for the rows as given (data and prior entries alike). */
+ * ignored).  NULL clears.  Such rows shard like any others (a shard is a range of whole covariance
+ * blocks); lsqamd_eval_fcn returns p_j for them; lsqamd_dpdy returns columns for the rows as given
+ * (data and prior entries alike). */
 int lsqamd_set_param_rows(lsqamd_fit *fit, const int32_t *row_param);
 int lsqamd_set_options(lsqamd_fit *fit, const lsqamd_options *opt);
 /* Device scratch of the QR-grade covariance (LSQAMD_SOLVER_QR): a transposed copy of J, the

@@ -2592,7 +2592,6 @@ int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) {
 
 int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) {
   if (!f || !p || !out) return LSQAMD_EINVAL;
-  if (f->have_param_rows) FAIL(f, LSQAMD_EUNSUPPORTED, "eval_fcn: not available with parameter rows (lsqamd_set_param_rows)");
   int rc = ready(f);
   if (rc) return rc;
   const int64_t N = f->N;
@@ -2602,6 +2601,9 @@ int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) {
   HIPCHK(f, hipMemcpyAsync(f->p_trial, p, sizeof(double) * f->P, hipMemcpyHostToDevice, f->st));
   ModelArgs m = model_args(f, f->p_trial);
   HIPCHK(f, launch_residual_ex(f->st, m, f->r, f->r_raw));
+  if (f->have_param_rows)     // rows that ARE parameters (lsqamd_set_param_rows): their "function value" is p_j
+    HIPCHK(f, launch_param_rows(f->st, f->row_param, f->N, f->P, 1, f->p_trial, f->ymean, f->wdiag,
+                                f->cfg.n_blocks > 0 ? f->in_block : nullptr, f->r, f->r_raw, 0));
   std::vector<double> r((size_t)N), rr((size_t)N, 0.0), y((size_t)N), w((size_t)N);
   std::vector<uint8_t> inb((size_t)N, 0);
   HIPCHK(f, hipMemcpyAsync(r.data(), f->r, sizeof(double) * N, hipMemcpyDeviceToHost, f->st));

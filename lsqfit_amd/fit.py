@@ -211,6 +211,8 @@ class nonlinear_fit(object):
         Jacobian; ``G`` (m x P) returns ``G @ D`` for m derived quantities instead."""
         D = self.problem.dpdy(G)
         wh = self.whitening
+        if self.problem.N != wh.n_data and (getattr(wh, 'joint', False) or getattr(wh, 'perm', None) is not None):
+            return D                             # a shard of reordered rows: columns in the whitening's order (problem.rows)
         if getattr(wh, 'joint', False):          # device rows are the permuted joint vector
             out = np.empty_like(D)
             out[:, wh.row_src] = D

@@ -94,17 +94,16 @@ class DeviceProblem:
         a, b = (0, whitening.n_data) if rows is None else rows
         joint = getattr(whitening, 'joint', False)     # concat(y, prior) whitened as one vector
         if joint:
-            if rows is not None or model.kind == MODEL_IDENTITY:
-                raise ValueError('data-prior cross-correlations: unsharded fits of x-dependent models only')
+            if model.kind == MODEL_IDENTITY:
+                raise ValueError('data-prior cross-correlations: x-dependent models only')
             xe = np.zeros((whitening.n_data, model.n_x))
             xe[whitening.model_rows] = np.asarray(x, np.float64).reshape(whitening.n_model, model.n_x)[
                 whitening.row_src[whitening.model_rows]]
             x = xe
         self.perm = None if joint else getattr(whitening, 'perm', None)
         if self.perm is not None:
-            # interleaved covariance components: the whitening reordered the rows; x follows
-            if rows is not None:
-                raise ValueError('row sharding is not available for interleaved covariance components')
+            # interleaved covariance components: the whitening reordered the rows; x follows (a shard is a range of the
+            # REORDERED rows: whole components, see dist.shard_rows)
             if model.kind == MODEL_IDENTITY:
                 raise ValueError('identity model with interleaved covariance components: reorder the data')
             x = np.asarray(x, np.float64).reshape(whitening.n_data, model.n_x)[self.perm]
@@ -196,7 +195,7 @@ class DeviceProblem:
             dev = getattr(whitening, 'prior_prec_dev', None)      # made on the device: stays there
             self.set_prior(whitening.prior_mean, whitening.prior_prec if dev is None else dev)
         if joint:
-            rp = np.ascontiguousarray(whitening.row_param, np.int32)
+            rp = np.ascontiguousarray(whitening.row_param[a:b], np.int32)
             _check(lib, h, lib.lsqamd_set_param_rows(h, rp.ctypes.data_as(C.POINTER(C.c_int32))), 'set_param_rows')
         self._reduce_cb = None
         if reduce_hook is not None:
@@ -246,11 +245,11 @@ class DeviceProblem:
         p = np.ascontiguousarray(p, np.float64)
         out = np.empty(self.N)
         _check(self.lib, self.h, self.lib.lsqamd_eval_fcn(self.h, _lib.dptr(p), _lib.dptr(out), out.size), 'eval_fcn')
-        if self.perm is not None:
+        if self.perm is not None and self.N == self.wh.n_data:
             back = np.empty_like(out)
             back[self.perm] = out
             return back
-        return out
+        return out          # (a shard of reordered rows: in the whitening's order, rows self.rows of wh.perm)
 
     def set_reduce(self, hook):
         """hook(dev_ptr:int, count:int) -> None sums count doubles over ranks in place."""

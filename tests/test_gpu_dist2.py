@@ -24,8 +24,34 @@ def _free_port():
     return p
 
 
+def _special(case):
+    """Data whose covariance components interleave (rows 0, 7, 14.. tied together: the whitening reorders the rows and a shard is
+    a range of the REORDERED rows), and data correlated with the prior (concat(y, prior) whitened as one vector, prior entries
+    travelling as rows -- on whichever rank their component lands)."""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=420, P=12, seed=93, block=0, prior_corr=False)
+    N, P = 420, 12
+    sd = np.asarray(d['yerr'], float)
+    rng = np.random.default_rng(7)
+    cov = np.diag(sd ** 2)
+    if case == 'interleaved':
+        for start in range(7):                      # seven components of 20 rows each, stride 7, inside the first 140 rows
+            idx = np.arange(start, 140, 7)
+            cov[np.ix_(idx, idx)] = np.outer(sd[idx], sd[idx]) * 0.5 ** np.abs(np.subtract.outer(np.arange(idx.size), np.arange(idx.size)))
+        d['yerr'] = cov
+        return d, None
+    cross = np.zeros((N, P))                        # every prior entry tied to three data rows of its own
+    psd = np.asarray(d['prior'][1], float)
+    for j in range(P):
+        rows = 30 * j + np.array([3, 4, 11])
+        cross[rows, j] = 0.3 * sd[rows] * psd[j] * rng.uniform(0.5, 1.0, 3)
+    return d, cross
+
+
 def _problem(case):
     from lsqfit_amd import synth
+    if case in ('interleaved', 'cross'):
+        return _special(case)[0]
     if case in ('blocks', 'trf', 'varpro', 'qr'):
         return synth.make_cosmix(N=1536, P=128, seed=91, block=256, prior_corr=True)
     return synth.make_cosmix(N=1000, P=30, seed=92, block=0, prior_corr=False)
@@ -54,10 +80,17 @@ def _worker(rank, world, port, outdir, case):
     import lsqfit_amd as amd
     from lsqfit_amd.dist import sharded_problem
     d = _problem(case)
-    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    if case == 'cross':
+        from lsqfit_amd.whiten import joint_whitening
+        wh = joint_whitening(d['ymean'], d['yerr'], d['prior'][0], d['prior'][1], _special(case)[1])
+    else:
+        wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
     pr = sharded_problem(d['model'], d['x'], wh, rank, world)
     fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'],
                             problem=pr, **_fit_kw(case, d['p0'].size))
+    if case in ('interleaved', 'cross'):
+        f_rows = pr.fcn(fit.pmean)                   # this shard's rows in the whitening's order
+        np.savez(os.path.join(outdir, 'extra%d.npz' % rank), f_rows=f_rows)
     G = np.random.default_rng(1).standard_normal((2, d['p0'].size))
     GD = pr.dpdy(G)                                  # this rank's data columns, then the prior's
     pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
@@ -66,6 +99,48 @@ def _worker(rank, world, port, outdir, case):
              logGBF=fit.logGBF, rows=np.array(pr.rows), GD=GD, c2=c2)
     pr.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case,world', [('interleaved', 2), ('interleaved', 3), ('cross', 2), ('cross', 3)])
+def test_sharded_fit_of_reordered_rows(case, world, tmp_path):
+    """Row sharding for data with interleaved covariance components and for data correlated with the prior (declared limits of
+    rounds 2-3): shards are ranges of the whitening's reordered rows, never cutting a component."""
+    import torch.multiprocessing as mp
+    import lsqfit_amd as amd
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker, args=(r, world, 0, str(tmp_path), case)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    for r in res[1:]:
+        for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
+            assert np.array_equal(res[0][k], r[k]), k
+    d, cross = _special(case)
+    ref = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], cross=cross)
+    rel = lambda a, b: np.max(np.abs(a - b)) / np.max(np.abs(b))
+    assert rel(res[0]['pmean'], ref.pmean) < 1e-9 and rel(res[0]['cov'], ref.cov) < 1e-8
+    # (twelve parameters: the unsharded fit is ONE launch, DESIGN 16, whose last rounding-sized step may fall the other side of
+    #  the xtol test than the general path's the shards take -- same end point, an iteration apart)
+    assert abs(res[0]['chi2'] / ref.chi2 - 1) < 1e-10 and abs(int(res[0]['nit']) - ref.nit) <= 1
+    assert res[0]['logGBF'] == pytest.approx(ref.logGBF, rel=1e-10)
+    # the shards tile the reordered rows, whole components each; the function values they report are those of the unsharded fit
+    wh = ref.whitening
+    order = wh.row_src if case == 'cross' else wh.perm
+    rows = [tuple(r['rows']) for r in res]
+    assert rows[0][0] == 0 and rows[-1][1] == wh.n_data and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    for b in wh.blocks:
+        assert sum(1 for a, e in rows if a <= b['row0'] and b['row0'] + b['size'] <= e) == 1
+    full = ref.problem.fcn(ref.pmean)
+    if case == 'interleaved':
+        full = full[order]                       # (unsharded fcn() hands the rows back in the caller's order)
+    for r, (a, e) in enumerate(rows):
+        got = np.load(os.path.join(str(tmp_path), 'extra%d.npz' % r))['f_rows']
+        assert got.shape == (e - a,) and np.allclose(got, full[a:e], rtol=1e-7, atol=1e-9)      # (at each fit's own end point: 1e-9 apart)
+    pts = ref.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
+    assert rel(res[0]['c2'], ref.problem.chi2_points(pts)) < 1e-8
 
 
 @pytest.mark.parametrize('case,world', [('blocks', 2), ('blocks', 3), ('diag', 2), ('trf', 2), ('varpro', 2), ('qr', 2)])

@@ -70,8 +70,13 @@ def test_fit_with_interleaved_components_matches_oracle(amd, svdcut):
             single = amd.nonlinear_fit(data=(x, res.ymeans[k], ycov), model=model, prior=(res.prior_means[k], pcov),
                                        p0=fit.pmean, svdcut=svdcut, tol=fit.tol)
             assert gu.relmax(res.pmean[k], single.pmean) < 1e-6 and res.chi2[k] == pytest.approx(single.chi2, rel=1e-7)
-    with pytest.raises(ValueError):
-        amd.DeviceProblem(model, x, wh, rows=(0, 48))
+    # a shard is a range of the REORDERED rows and must hold whole components (sharded fits: tests/test_gpu_dist2.py)
+    with pytest.raises(ValueError, match='cuts through a covariance block'):
+        amd.DeviceProblem(model, x, wh, rows=(0, 10))           # rows 1..14 of the reordered data are one component
+    part = amd.DeviceProblem(model, x, wh, rows=(0, 20))        # [0], the 14-row component, the 5-row one
+    assert part.N == 20
+    np.testing.assert_allclose(part.fcn(fit.pmean), gu.cosmix_fcn(x[wh.perm[:20]], fit.pmean), rtol=1e-12, atol=1e-13)
+    part.close()
 
 
 def test_fit_with_eps_regulation_matches_oracle(amd):
