@@ -95,9 +95,9 @@ class nonlinear_fit(object):
                 if prior is None or uncorrelated:
                     raise ValueError('cross needs data= and prior=')
                 from .whiten import joint_whitening
-                if eps is not None or np.any(noise):
-                    raise NotImplementedError('eps / noise with data-prior cross-correlations')
-                wh = joint_whitening(ymean, yerr, pm, perr, cross, svdcut=svdcut)
+                if np.any(noise):
+                    raise NotImplementedError('noise= with data-prior cross-correlations')
+                wh = joint_whitening(ymean, yerr, pm, perr, cross, svdcut=svdcut, eps=eps)
             else:
                 wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, eps=eps, udata=uncorrelated, noise=noise,
                                rng=rng)
@@ -244,13 +244,11 @@ class nonlinear_fit(object):
     # -- simulated / bootstrap copies ------------------------------------------
     def simulated_fits(self, n, pexact=None, add_priornoise=False, seed=0, **kw):
         """``simulated_fit_iter`` (src/lsqfit/__init__.py:1391-1469) as one device batch."""
-        self._no_joint()
         from .resample import simulated_fits
         return simulated_fits(self, n, pexact, add_priornoise, seed, **kw)
 
     def bootstrapped_fits(self, n, seed=0, **kw):
         """``bootstrapped_fit_iter`` (src/lsqfit/__init__.py:1548-1642) as one device batch."""
-        self._no_joint()
         from .resample import bootstrapped_fits
         return bootstrapped_fits(self, n, seed, **kw)
 

@@ -91,10 +91,81 @@ def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
     return res
 
 
+# ---- data correlated with the prior (nonlinear_fit(..., cross=...): concat(y, prior) whitened as one vector) ---------------
+# What the reference's iterators do with such data follows from gvar.bootstrap_iter, which returns NEW gvars carrying the
+# covariance of what it was handed (src/lsqfit/__init__.py:1519-1543,:1607-1626):
+#   bootstrapped_fit_iter           hands it y AND the prior together: every copy keeps the full joint covariance;
+#   simulated_fit_iter, priornoise  likewise (yp = [y, prior]);
+#   simulated_fit_iter, no noise    hands it y alone: the copies' data are no longer correlated with the (unchanged) prior.
+# The first two are refits of the SAME joint problem with new means -- data rows and the prior entries that travel as rows
+# alike -- run one after the other on the fit's resident device problem (the batched engine has no parameter rows); the
+# third is an ordinary resampled fit of y with its own covariance and the prior with its own, one lockstep batch.
+def _joint_copies(fit, zmeans, p0, tol=None, maxit=None):
+    from .fit import nonlinear_fit
+    wh, pr = fit.whitening, fit.problem
+    n, P, N = zmeans.shape[0], fit.pmean.size, fit.whitening.n_model
+    tol = fit.tol if tol is None else tol
+    maxit = fit.maxit if maxit is None else maxit
+    keys = ('pmean', 'psdev', 'chi2', 'Q', 'nit', 'stopping_criterion', 'logGBF')
+    out = {k: [] for k in keys}
+    cov = []
+    z0 = wh.ymean.copy()
+    back = np.empty(N + P, int)
+    back[wh.row_src] = np.arange(N + P)              # caller's index -> joint row
+    try:
+        for k in range(n):
+            wh.ymean = zmeans[k]                     # (the whitening's means, in ITS row order: what maxit = 0 / default p0 read)
+            pr.set_ymean(zmeans[k])
+            prior_k = zmeans[k][back[N:]]
+            f = nonlinear_fit(data=(fit.problem_x, zmeans[k][back[:N]], None), model=fit.model,
+                              prior=(prior_k, wh.prior_cov_host), p0=p0, problem=pr, tol=tol, maxit=maxit)
+            for key in keys:
+                out[key].append(getattr(f, key))
+            cov.append(f.cov)
+    finally:
+        wh.ymean = z0
+        pr.set_ymean(z0)
+    res = ResampledFits({k: np.array(v) for k, v in out.items()})
+    res['cov'] = np.array(cov)
+    res['dof'] = np.full(n, fit.dof)
+    res['engine'] = 'sequential (joint rows)'
+    res['ymeans'] = zmeans[:, back[:N]]
+    res['prior_means'] = zmeans[:, back[N:]]
+    res['rounds'] = n
+    return res
+
+
+def _joint_draws(fit, n, seed, centre):
+    """(n, N + P) means in the joint whitening's row order: centre + deviates with the regulated joint covariance"""
+    wh = fit.whitening
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return centre[None, :] + wh.draw_data(rng, n)
+
+
 def simulated_fits(fit, n, pexact=None, add_priornoise=False, seed=0, **kw):
     """n simulated copies of ``fit`` refitted from ``p0 = pexact`` (``simulated_fit_iter``,
     __init__.py:1453-1469).  ``result.pexact`` holds the generating parameters."""
     pexact = fit.pmean if pexact is None else np.asarray(pexact, float)
+    wh = fit.whitening
+    if getattr(wh, 'joint', False):
+        f = fit.problem.fcn(pexact)                  # joint row order; rows that are parameters hold p_j
+        if add_priornoise:
+            centre = np.where(wh.row_param >= 0, wh.ymean, f)       # data rows: fcn(pexact); prior rows: the prior means
+            res = _joint_copies(fit, _joint_draws(fit, n, seed, centre), pexact, **kw)
+        else:
+            # the copies' data are new, independent of the prior: an ordinary fit of (y + noise_y, prior) without cross terms
+            from .fit import nonlinear_fit
+            N = wh.n_model
+            back = np.empty(wh.n_data, int)
+            back[wh.row_src] = np.arange(wh.n_data)
+            plain = nonlinear_fit(data=(fit.problem_x, f[back[:N]], wh.data_cov_host), model=fit.model,
+                                  prior=(wh.prior_mean_host, wh.prior_cov_host), p0=pexact, svdcut=fit.svdcut, tol=fit.tol, maxit=0)
+            rng = np.random.Generator(np.random.PCG64(seed))
+            ymeans = f[back[:N]][None, :] + _data_order(plain.whitening, plain.whitening.draw_data(rng, n))
+            pm = np.broadcast_to(wh.prior_mean_host, (n, pexact.size)).copy()
+            res = refit(plain, ymeans, pm, pexact, **dict(dict(tol=fit.tol, maxit=fit.maxit), **kw))
+        res['pexact'] = pexact
+        return res
     ymeans, pm = simulated_data(fit, n, pexact, add_priornoise, seed)
     res = refit(fit, ymeans, pm, pexact, **kw)
     res['pexact'] = pexact
@@ -104,5 +175,7 @@ def simulated_fits(fit, n, pexact=None, add_priornoise=False, seed=0, **kw):
 def bootstrapped_fits(fit, n, seed=0, **kw):
     """n bootstrap copies of ``fit`` refitted from ``p0 = fit.pmean``
     (``bootstrapped_fit_iter``, __init__.py:1607-1626)."""
+    if getattr(fit.whitening, 'joint', False):
+        return _joint_copies(fit, _joint_draws(fit, n, seed, fit.whitening.ymean), fit.pmean, **kw)
     ymeans, pm = bootstrap_data(fit, n, seed)
     return refit(fit, ymeans, pm, fit.pmean, **kw)

@@ -515,7 +515,7 @@ def _components(cov):
     return out
 
 
-def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, engine=None):
+def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, engine=None, eps=None):
     """Whitening of concat(y, prior) when data and prior are correlated (``cross`` = the N x P
     covariance between them): what src/lsqfit/__init__.py:1892-1900 hands to gvar.PDF.
 
@@ -554,7 +554,7 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, eng
         if c.size > 1:
             blocks.append((r0, full[np.ix_(c, c)]))
         r0 += c.size
-    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut, engine=engine)
+    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut, engine=engine, eps=eps)
     wh.joint = True
     wh.row_src = perm
     wh.row_param = np.where(perm >= N, perm - N, -1).astype(np.int32)
@@ -563,6 +563,7 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, eng
     wh.prior_mean_host = pm                       # host-side bookkeeping only (default p0, maxit = 0)
     wh.prior_sdev = np.sqrt(np.diag(full))[N:]
     wh.prior_cov_host = full[N:, N:]
+    wh.data_cov_host = full[:N, :N]               # (resample.py: simulated copies without prior noise lose the cross terms)
     return wh
 
 

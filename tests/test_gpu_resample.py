@@ -181,3 +181,71 @@ def test_dense_prior_batch_matches_single_engine_and_oracle(amd):
         assert gu.relmax(res.pmean[k], ref.pmean) < 1e-6
         assert gu.relmax(res.psdev[k], ref.psdev) < 1e-6
         assert abs(res.chi2[k] / ref.chi2 - 1) < 1e-6
+
+
+def _cross_problem(seed=31, N=24, P=3):
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((N + P, N + P))
+    full = (A @ A.T + (N + P) * np.eye(N + P)) * 1e-4
+    x = np.linspace(0.1, 2.0, N)
+    truth = np.array([1.0, 0.7, 0.3])
+    dev = np.linalg.cholesky(full) @ rng.standard_normal(N + P)
+    y = truth[0] * np.exp(-truth[1] * x) + truth[2] + dev[:N]
+    return x, y, truth + dev[N:], full, N, P
+
+
+def _cross_fcn(xx, p):
+    from oracle import dual
+    return p[0] * dual.exp(-p[1] * xx) + p[2]
+
+
+def test_resampled_copies_of_a_fit_correlated_with_its_prior(amd):
+    """Data correlated with the prior (examples/y-noerr.py; a declared limit of rounds 2-3).  What gvar.bootstrap_iter is handed
+    decides what a copy's covariance is (src/lsqfit/__init__.py:1519-1543,:1607-1626): bootstrap copies and simulated copies with
+    prior noise keep the full joint covariance -- refits of the same joint problem with new means; simulated copies without prior
+    noise get data that are no longer correlated with the prior.  Copies against independent fits of their inputs and the oracle."""
+    x, y, pm, full, N, P = _cross_problem()
+    model = amd.expr('b1*exp(-b2*x) + b3', ['b1', 'b2', 'b3'])
+    Cyy, Cpp, Cyp = full[:N, :N], full[N:, N:], full[:N, N:]
+    fit = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10)
+    extra = [((i, N + j), full[i, N + j]) for i in range(N) for j in range(P)]
+    for res in (fit.bootstrapped_fits(5, seed=4), fit.simulated_fits(5, add_priornoise=True, seed=5)):
+        assert res.pmean.shape == (5, P) and res.ymeans.shape == (5, N) and res.prior_means.shape == (5, P)
+        assert np.std(res.prior_means[:, 0]) > 0 and np.std(res.ymeans[:, 0]) > 0
+        for k in (0, 4):
+            single = amd.nonlinear_fit(data=(x, res.ymeans[k], Cyy), model=model, prior=(res.prior_means[k], Cpp), cross=Cyp,
+                                       p0=res.get('pexact', fit.pmean), tol=1e-10)
+            assert gu.relmax(res.pmean[k], single.pmean) < 1e-9 and res.chi2[k] == pytest.approx(single.chi2, rel=1e-9)
+            assert res.logGBF[k] == pytest.approx(single.logGBF, rel=1e-9, abs=1e-9) and gu.relmax(res.cov[k], single.cov) < 1e-8
+            ref = ofit.nonlinear_fit(x, res.ymeans[k], Cyy, _cross_fcn, prior_mean=res.prior_means[k], prior_err=Cpp, extra_cov=extra,
+                                     p0=res.get('pexact', fit.pmean), tol=1e-10, solver='cholesky')
+            assert np.all(np.abs(res.pmean[k] - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-6 * ref.psdev)
+            assert res.chi2[k] == pytest.approx(ref.chi2, rel=1e-6) and gu.relmax(res.cov[k], ref.cov) < 1e-6
+    # the handle is back where it was: the original fit again, bit for bit
+    again = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), problem=fit.problem, tol=1e-10)
+    assert np.array_equal(again.pmean, fit.pmean) and again.chi2 == fit.chi2
+    # simulated copies without prior noise: y alone went through bootstrap_iter -- no cross terms in the refits, prior means fixed
+    res = fit.simulated_fits(4, seed=6)
+    assert np.all(res.prior_means == pm[None, :]) and res.engine == 'batched'
+    for k in (0, 3):
+        ref = ofit.nonlinear_fit(x, res.ymeans[k], Cyy, _cross_fcn, prior_mean=pm, prior_err=Cpp, p0=fit.pmean, tol=1e-10, solver='cholesky')
+        assert np.all(np.abs(res.pmean[k] - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-6 * ref.psdev)
+        assert res.chi2[k] == pytest.approx(ref.chi2, rel=1e-6)
+    # the scatter of the copies is the fit's own covariance (loosely: 200 copies)
+    many = fit.bootstrapped_fits(200, seed=9)
+    assert np.all(np.abs(np.std(many.pmean, axis=0) / fit.psdev - 1) < 0.25)
+
+
+def test_eps_regulation_with_data_correlated_with_the_prior(amd):
+    """eps (gvar.regulate's other mode, src/lsqfit/__init__.py:240-245) on the joint vector: against the oracle's restatement."""
+    x, y, pm, full, N, P = _cross_problem(seed=33)
+    model = amd.expr('b1*exp(-b2*x) + b3', ['b1', 'b2', 'b3'])
+    extra = [((i, N + j), full[i, N + j]) for i in range(N) for j in range(P)]
+    fit = amd.nonlinear_fit(data=(x, y, full[:N, :N]), model=model, prior=(pm, full[N:, N:]), cross=full[:N, N:], svdcut=None, eps=1e-3,
+                            tol=1e-10)
+    ref = ofit.nonlinear_fit(x, y, full[:N, :N], _cross_fcn, prior_mean=pm, prior_err=full[N:, N:], extra_cov=extra, svdcut=None, eps=1e-3,
+                             tol=1e-10, solver='cholesky')
+    assert fit.dof == ref.dof and gu.relmax(fit.pmean, ref.pmean) < 1e-6 and fit.chi2 == pytest.approx(ref.chi2, rel=1e-6)
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6 and fit.logGBF == pytest.approx(ref.logGBF, rel=1e-6, abs=1e-6)
+    plain = amd.nonlinear_fit(data=(x, y, full[:N, :N]), model=model, prior=(pm, full[N:, N:]), cross=full[:N, N:], tol=1e-10)
+    assert abs(plain.chi2 - fit.chi2) > 1e-6 * fit.chi2           # (the regulation did something)
