@@ -40,9 +40,14 @@ class BatchedFits:
                 yerr = np.broadcast_to(yerr, ymean.shape)
             whitening = Whitening(ymean, yerr, svdcut=svdcut)
         self.wh = wh = whitening
-        if getattr(wh, 'perm', None) is not None and not rows_permuted:
-            # (resample.refit hands x and the data means over in the whitening's own row order: rows_permuted=True)
-            raise NotImplementedError('BatchedFits: covariance components that interleave; reorder the data rows')
+        # covariance components that interleave: the whitening made them contiguous by a row permutation; x and every vector of
+        # data means follow it (resample.refit hands both over already reordered: rows_permuted=True)
+        self._perm = None if rows_permuted else getattr(wh, 'perm', None)
+        if self._perm is not None:
+            if model.kind == MODEL_IDENTITY:
+                raise ValueError('identity model with interleaved covariance components: reorder the data')
+            x = np.asarray(x, np.float64).reshape(ymean.size, model.n_x)[self._perm]
+            ymean = np.ascontiguousarray(ymean[self._perm])
         row0, size, modes, tri, wt = wh.block_arrays()
         self.has_prior = prior_mean is not None
         self.prior_dense = prior_prec is not None
@@ -124,6 +129,8 @@ class BatchedFits:
         ymeans = np.ascontiguousarray(ymeans, np.float64)
         if ymeans.shape != (self.B, self.N):
             raise ValueError('ymeans must be [n_fits, N]')
+        if self._perm is not None:
+            ymeans = np.ascontiguousarray(ymeans[:, self._perm])
         self._check(self.lib.lsqamdb_set_data_means(self.h, _lib.dptr(ymeans)), 'set_data_means')
 
     def set_prior_means(self, mean):
