@@ -384,7 +384,7 @@ def main():
         # FETCH_SIZE x2 gfx950 correction): taken from the committed profile of this workload
         traffic, traffic_src, clk = None, None, None
         try:
-            pmc = [f for f in ('r03_syrk_pmc.json', 'r02_syrk_pmc.json', 'r01_syrk_pmc.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))][0]
+            pmc = [f for f in ('r04_syrk_pmc.json', 'r03_syrk_pmc.json', 'r02_syrk_pmc.json', 'r01_syrk_pmc.json') if os.path.exists(os.path.join(ROOT, 'profiles', f))][0]
             prof = json.load(open(os.path.join(ROOT, 'profiles', pmc)))
             clk = prof['summary'].get('effective_clock_GHz')
             if world == 1 and (N, P) == (65536, 4096):

@@ -3,7 +3,7 @@
 # the rocprofv3 kernel trace of the c4 bench, the three PMC passes of the J^T J launch, and the
 # tape-model Jacobian timings.  gpurun -- 'bash tools/collect_round_profiles.sh'
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-R=${LSQAMD_ROUND:-r03}
+R=${LSQAMD_ROUND:-r04}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd $ROOT

@@ -4,7 +4,7 @@
 #   gpurun -- 'bash tools/collect_syrk_pmc.sh'
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/pmc_${LSQAMD_ROUND:-r02}
+OUT=$ROOT/gpurun_out/pmc_${LSQAMD_ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, counters...
