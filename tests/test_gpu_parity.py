@@ -571,8 +571,9 @@ def test_y_noerr_out_on_device(amd):
                 assert np.max(np.abs(alt.pmean - fit.pmean) / fit.psdev) < 1e-3, kw
                 assert abs(alt.chi2 - fit.chi2) < 1e-6
         p0 = fit.pmean
-    with pytest.raises(NotImplementedError):
-        fit.simulated_fits(2)
+    # resampled copies work for such fits since round 4 (tests/test_gpu_resample.py); here: they run and scatter
+    res = fit.bootstrapped_fits(3, seed=2)
+    assert res.pmean.shape == (3, fit.pmean.size) and np.all(np.isfinite(res.chi2)) and np.std(res.pmean[:, 0]) > 0
     # chi2 at many points works for such fits since round 3 (tests/test_gpu_points.py); at the minimum it is the fit's chi2
     assert abs(fit.problem.chi2_points(np.atleast_2d(fit.pmean))[0] - fit.chi2) < 1e-6 * max(1.0, fit.chi2)
 
