@@ -42,22 +42,17 @@ def _problem(case):
     raise ValueError(case)
 
 
-def _worker(rank, world, outdir, case, fake, algo, missing):
-    os.environ['LSQAMD_RCCL_PATH'] = fake
-    os.environ['LSQAMD_COMM_ALGO'] = algo
-    if missing:
-        os.environ['LSQAMD_FAKE_RCCL_TIMEOUT_S'] = '3'
-    sys.path.insert(0, ROOT)
-    import torch
-    torch.cuda.set_device(0)
+def _one(rank, world, outdir, case, fake, algo, missing):
     import lsqfit_amd as amd
     from lsqfit_amd.dist import shard_rows
+    os.environ['LSQAMD_COMM_ALGO'] = algo
+    tag = '%s_%s' % (case, algo)
     d = _problem(case)
     wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
     ranges = shard_rows(wh.n_data, [(b['row0'], b['size']) for b in wh.blocks], world)
     pr = amd.DeviceProblem(d['model'], d['x'], wh, rows=ranges[rank], adds_prior=(rank == 0))
     # the id travels through a file (any host channel will do: lsqamd_comm_unique_id's contract)
-    idf = os.path.join(outdir, 'comm_id')
+    idf = os.path.join(outdir, 'comm_id_' + tag)
     if rank == 0:
         uid = pr.comm_unique_id()
         with open(idf + '.tmp', 'wb') as fh:
@@ -68,15 +63,15 @@ def _worker(rank, world, outdir, case, fake, algo, missing):
         t0 = time.time()
         while not os.path.exists(idf):
             time.sleep(0.01)
-            assert time.time() - t0 < 120
+            assert time.time() - t0 < 300
         uid = open(idf, 'rb').read()
     if missing:
         # rank 1 of 2 never joins: rank 0's init must come back with an error inside the bounded wait
         try:
             pr.comm_init(uid, rank, world)
-            np.savez(os.path.join(outdir, 'r%d.npz' % rank), error='')
+            np.savez(os.path.join(outdir, '%s_r%d.npz' % (tag, rank)), error='')
         except RuntimeError as e:
-            np.savez(os.path.join(outdir, 'r%d.npz' % rank), error=str(e))
+            np.savez(os.path.join(outdir, '%s_r%d.npz' % (tag, rank)), error=str(e))
         pr.close()
         return
     pr.comm_init(uid, rank, world)
@@ -89,33 +84,68 @@ def _worker(rank, world, outdir, case, fake, algo, missing):
     m = 65536 if case == 'small8' else 5             # 65536 sums over 8 ranks: 8 slices of exactly 8192 doubles, no tail
     pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((m, d['p0'].size))
     c2 = pr.chi2_points(pts)                         # m sums through the communicator (count 5: all-reduce form)
-    np.savez(os.path.join(outdir, 'r%d.npz' % rank), pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit,
+    np.savez(os.path.join(outdir, '%s_r%d.npz' % (tag, rank)), pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit,
              logGBF=fit.logGBF, c2=c2, reduces=tm['reduce'][1], expect=s.njev + s.nfev - 1, error='')
     pr.comm_destroy()
     pr.close()
 
 
-def _run(world, tmp_path, case, fake, algo, missing=False, nstart=None):
+def _worker(rank, world, outdir, jobs, fake, missing):
+    """One set of `world` processes runs all (case, algo) jobs of that world size, a fresh communicator each (a process costs an
+    import of torch and a HIP context: on a slow box that, not the fits, is what these tests take)."""
+    os.environ['LSQAMD_RCCL_PATH'] = fake
+    if missing:
+        os.environ['LSQAMD_FAKE_RCCL_TIMEOUT_S'] = '3'
+    sys.path.insert(0, ROOT)
+    import torch
+    torch.cuda.set_device(0)
+    for case, algo in jobs:
+        _one(rank, world, outdir, case, fake, algo, missing)
+
+
+JOBS = {2: [('blocks', 'rsag'), ('blocks', 'allreduce')], 3: [('blocks', 'rsag'), ('small', 'rsag')],
+        8: [('eight', 'rsag'), ('small8', 'rsag'), ('c4_packed', 'rsag')]}
+
+
+def _spawn(world, outdir, jobs, fake, missing=False, nstart=None):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_worker, args=(r, world, str(tmp_path), case, fake, algo, missing))
+    procs = [ctx.Process(target=_worker, args=(r, world, outdir, jobs, fake, missing))
              for r in range(world if nstart is None else nstart)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
+        p.join(900)
     for p in procs:
         if p.is_alive():
             p.kill()
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    return [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(len(procs))]
+    return [p.exitcode for p in procs]
+
+
+@pytest.fixture(scope='module')
+def runs(tmp_path_factory, fake_rccl):
+    done = {}
+
+    def get(world):
+        if world not in done:
+            out = str(tmp_path_factory.mktemp('ranks%d' % world))
+            done[world] = (out, _spawn(world, out, JOBS[world], fake_rccl))
+        return done[world]
+    return get
+
+
+def _results(runs, world, case, algo='rsag'):
+    out, codes = runs(world)
+    files = [os.path.join(out, '%s_%s_r%d.npz' % (case, algo, r)) for r in range(world)]
+    assert all(os.path.exists(f) for f in files), 'job (%s, %s) did not finish on every rank (exit codes %s)' % (case, algo, codes)
+    return [np.load(f) for f in files]
 
 
 @pytest.mark.parametrize('case,world,algo', [('blocks', 2, 'rsag'), ('blocks', 3, 'rsag'), ('blocks', 2, 'allreduce'),
                                              ('small', 3, 'rsag')])
-def test_library_collective_with_several_ranks(case, world, algo, tmp_path, fake_rccl):
+def test_library_collective_with_several_ranks(case, world, algo, runs):
     import lsqfit_amd as amd
-    res = _run(world, tmp_path, case, fake_rccl, algo)
+    res = _results(runs, world, case, algo)
     for r in res:
         assert int(r['reduces']) == int(r['expect'])       # one packed exchange per Jacobian, one scalar per trial
     for r in res[1:]:                                      # every rank received the same bytes: identical decisions
@@ -132,29 +162,29 @@ def test_library_collective_with_several_ranks(case, world, algo, tmp_path, fake
     assert rel(res[0]['c2'], ref.problem.chi2_points(pts)) < 1e-8
 
 
-def test_rsag_and_allreduce_forms_agree_bit_for_bit(tmp_path, fake_rccl):
+def test_rsag_and_allreduce_forms_agree_bit_for_bit(runs):
     """Both forms sum in rank order in the stand-in, so the fits must be the same bits: what differs
     is only comm.hip's slicing (offsets, tail), which this pins."""
-    (tmp_path / 'a').mkdir()
-    (tmp_path / 'b').mkdir()
-    a = _run(2, tmp_path / 'a', 'blocks', fake_rccl, 'rsag')
-    b = _run(2, tmp_path / 'b', 'blocks', fake_rccl, 'allreduce')
+    a = _results(runs, 2, 'blocks', 'rsag')
+    b = _results(runs, 2, 'blocks', 'allreduce')
     for k in ('pmean', 'cov', 'chi2', 'nit'):
         assert np.array_equal(a[0][k], b[0][k]), k
 
 
 def test_missing_rank_is_an_error_not_a_hang(tmp_path, fake_rccl):
-    res = _run(2, tmp_path, 'small', fake_rccl, 'rsag', missing=True, nstart=1)
+    codes = _spawn(2, str(tmp_path), [('small', 'rsag')], fake_rccl, missing=True, nstart=1)
+    assert codes == [0]
+    res = [np.load(os.path.join(str(tmp_path), 'small_rsag_r0.npz'))]
     assert 'EREDUCE' in str(res[0]['error']) or 'missing' in str(res[0]['error'])
 
 
 @pytest.mark.parametrize('case', ['eight', 'small8'])
-def test_eight_ranks(case, tmp_path, fake_rccl):
+def test_eight_ranks(case, runs):
     """The node the north star names has 8 GPUs: 8 ranks through comm.hip's slicing -- 98689 doubles (8 slices of 12320 + a tail of
     129; `eight`), 65536 many-point sums (8 slices of exactly 8192, no tail; `small8`), the count-1 trial scalar -- on the stand-in.
     Every rank bit-identical, equal to the unsharded fit.  (Says nothing about xGMI: no scaling number follows from this.)"""
     import lsqfit_amd as amd
-    res = _run(8, tmp_path, case, fake_rccl, 'rsag')
+    res = _results(runs, 8, case)
     assert len(res) == 8
     for r in res:
         assert int(r['reduces']) == int(r['expect'])
@@ -171,11 +201,11 @@ def test_eight_ranks(case, tmp_path, fake_rccl):
     assert rel(res[0]['c2'], ref.problem.chi2_points(pts)) < 1e-8
 
 
-def test_named_parameter_count_packed_exchange_over_eight_ranks(tmp_path, fake_rccl):
+def test_named_parameter_count_packed_exchange_over_eight_ranks(runs):
     """P = 4096 as in the headline configuration: the 69.2 MB packed [J^T J | J^T f | chi2] buffer goes through the reduce-scatter +
     all-gather of 8 ranks once per Jacobian (two LM iterations; 256 rows = one covariance block per rank)."""
     import lsqfit_amd as amd
-    res = _run(8, tmp_path, 'c4_packed', fake_rccl, 'rsag')
+    res = _results(runs, 8, 'c4_packed')
     for r in res[1:]:
         for k in ('pmean', 'cov', 'chi2', 'nit'):
             assert np.array_equal(res[0][k], r[k]), k

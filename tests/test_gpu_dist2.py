@@ -6,7 +6,6 @@ step), reduce hook for the packed normal equations and for every trial chi2, rep
 Checks: all ranks bit-identical to each other, equal to the unsharded device fit to 1e-9, plus
 fit.p sensitivities (f1) and chi2 at many points (f2) on the shards."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -14,14 +13,6 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
 
 
 def _special(case):
@@ -70,7 +61,9 @@ def _fit_kw(case, P):
     return dict(alg=('lm' if case == 'blocks' else 'dogleg'))
 
 
-def _worker(rank, world, port, outdir, case):
+def _worker(rank, world, outdir, cases):
+    """One set of `world` processes runs ALL the cases of that world size one after the other (a process costs an import of
+    torch and a HIP context: on a slow box that, not the fits, is what these tests take)."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -79,42 +72,69 @@ def _worker(rank, world, port, outdir, case):
     dist.init_process_group('gloo', init_method='file://' + os.path.join(outdir, 'rendezvous'), rank=rank, world_size=world)
     import lsqfit_amd as amd
     from lsqfit_amd.dist import sharded_problem
-    d = _problem(case)
-    if case == 'cross':
-        from lsqfit_amd.whiten import joint_whitening
-        wh = joint_whitening(d['ymean'], d['yerr'], d['prior'][0], d['prior'][1], _special(case)[1])
-    else:
-        wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
-    pr = sharded_problem(d['model'], d['x'], wh, rank, world)
-    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'],
-                            problem=pr, **_fit_kw(case, d['p0'].size))
-    if case in ('interleaved', 'cross'):
-        f_rows = pr.fcn(fit.pmean)                   # this shard's rows in the whitening's order
-        np.savez(os.path.join(outdir, 'extra%d.npz' % rank), f_rows=f_rows)
-    G = np.random.default_rng(1).standard_normal((2, d['p0'].size))
-    GD = pr.dpdy(G)                                  # this rank's data columns, then the prior's
-    pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
-    c2 = pr.chi2_points(pts)                         # reduced over ranks through the hook
-    np.savez(os.path.join(outdir, 'r%d.npz' % rank), pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit,
-             logGBF=fit.logGBF, rows=np.array(pr.rows), GD=GD, c2=c2)
-    pr.close()
+    for case in cases:
+        d = _problem(case)
+        if case == 'cross':
+            from lsqfit_amd.whiten import joint_whitening
+            wh = joint_whitening(d['ymean'], d['yerr'], d['prior'][0], d['prior'][1], _special(case)[1])
+        else:
+            wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+        pr = sharded_problem(d['model'], d['x'], wh, rank, world)
+        fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'],
+                                problem=pr, **_fit_kw(case, d['p0'].size))
+        extra = {}
+        if case in ('interleaved', 'cross'):
+            extra['f_rows'] = pr.fcn(fit.pmean)          # this shard's rows in the whitening's order
+        G = np.random.default_rng(1).standard_normal((2, d['p0'].size))
+        GD = pr.dpdy(G)                                  # this rank's data columns, then the prior's
+        pts = fit.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
+        c2 = pr.chi2_points(pts)                         # reduced over ranks through the hook
+        np.savez(os.path.join(outdir, '%s_r%d.npz' % (case, rank)), pmean=fit.pmean, cov=fit.cov, chi2=fit.chi2, nit=fit.nit,
+                 logGBF=fit.logGBF, rows=np.array(pr.rows), GD=GD, c2=c2, **extra)
+        pr.close()
+        dist.barrier()
     dist.destroy_process_group()
 
 
+CASES = {2: ['blocks', 'diag', 'trf', 'varpro', 'qr', 'interleaved', 'cross'], 3: ['blocks', 'interleaved', 'cross']}
+
+
+@pytest.fixture(scope='module')
+def runs(tmp_path_factory):
+    """world -> directory with every case's per-rank results (the processes of a world size are started once, on first use)."""
+    done = {}
+
+    def get(world):
+        if world not in done:
+            import torch.multiprocessing as mp
+            out = str(tmp_path_factory.mktemp('world%d' % world))
+            ctx = mp.get_context('spawn')
+            procs = [ctx.Process(target=_worker, args=(r, world, out, CASES[world])) for r in range(world)]
+            for p in procs:
+                p.start()
+            for p in procs:
+                p.join(900)
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+            done[world] = (out, [p.exitcode for p in procs])
+        return done[world]
+    return get
+
+
+def _results(runs, case, world):
+    out, codes = runs(world)
+    files = [os.path.join(out, '%s_r%d.npz' % (case, r)) for r in range(world)]
+    assert all(os.path.exists(f) for f in files), 'case %s did not finish on every rank (exit codes %s)' % (case, codes)
+    return [np.load(f) for f in files]
+
+
 @pytest.mark.parametrize('case,world', [('interleaved', 2), ('interleaved', 3), ('cross', 2), ('cross', 3)])
-def test_sharded_fit_of_reordered_rows(case, world, tmp_path):
+def test_sharded_fit_of_reordered_rows(case, world, runs):
     """Row sharding for data with interleaved covariance components and for data correlated with the prior (declared limits of
     rounds 2-3): shards are ranges of the whitening's reordered rows, never cutting a component."""
-    import torch.multiprocessing as mp
     import lsqfit_amd as amd
-    ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_worker, args=(r, world, 0, str(tmp_path), case)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    res = _results(runs, case, world)
     for r in res[1:]:
         for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
             assert np.array_equal(res[0][k], r[k]), k
@@ -137,25 +157,16 @@ def test_sharded_fit_of_reordered_rows(case, world, tmp_path):
     if case == 'interleaved':
         full = full[order]                       # (unsharded fcn() hands the rows back in the caller's order)
     for r, (a, e) in enumerate(rows):
-        got = np.load(os.path.join(str(tmp_path), 'extra%d.npz' % r))['f_rows']
+        got = res[r]['f_rows']
         assert got.shape == (e - a,) and np.allclose(got, full[a:e], rtol=1e-7, atol=1e-9)      # (at each fit's own end point: 1e-9 apart)
     pts = ref.pmean + 1e-3 * np.random.default_rng(2).standard_normal((5, d['p0'].size))
     assert rel(res[0]['c2'], ref.problem.chi2_points(pts)) < 1e-8
 
 
 @pytest.mark.parametrize('case,world', [('blocks', 2), ('blocks', 3), ('diag', 2), ('trf', 2), ('varpro', 2), ('qr', 2)])
-def test_sharded_device_fit(case, world, tmp_path):
-    import torch.multiprocessing as mp
+def test_sharded_device_fit(case, world, runs):
     import lsqfit_amd as amd
-    port = _free_port()
-    ctx = mp.get_context('spawn')
-    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), case)) for r in range(world)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(300)
-    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    res = [np.load(os.path.join(str(tmp_path), 'r%d.npz' % r)) for r in range(world)]
+    res = _results(runs, case, world)
     for r in res[1:]:                                  # replicated decisions: bit-identical ranks
         for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
             assert np.array_equal(res[0][k], r[k]), k

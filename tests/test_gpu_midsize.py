@@ -77,26 +77,33 @@ np.savez(sys.argv[1], **out)
 '''
 
 
-@pytest.mark.parametrize('knob', ['LSQAMD_BACKSOLVE=g', 'LSQAMD_BACKSOLVE=s', 'LSQAMD_HOST_LM=1', 'LSQAMD_FUSE_MIN_TILES=-1',
-                                  'LSQAMD_TRAIL_HALVES=1', 'LSQAMD_SYNTH_NARROW=100000000', 'LSQAMD_POTF2=v3', 'LSQAMD_SYNTH_PAIR=1'])
-def test_developer_knobs_select_equivalent_paths(tmp_path, knob):
-    """Every alternative path a developer knob selects (grouped / per-block back substitution, host-side LM
-    bookkeeping, unfused factorisation, half tiles everywhere, 32-term whitening tiles everywhere, the four-wave
-    diagonal kernel, the eight-wave whitening kernel that synthesises every raw row once) gives the default path's fit to rounding: a P = 384 fit to convergence and six LM steps of a
-    P = 3200 fit (25 tile rows: fused launches, half tiles, the chained back substitution)."""
+def _knob_run(tmp_path, extra, name):
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / 'knob.py'
     script.write_text(_KNOB_SCRIPT % dict(root=root))
-    res = []
-    for extra in ({}, dict([knob.split('=')])):
-        path = str(tmp_path / ('res%d.npz' % len(res)))
-        r = subprocess.run([sys.executable, str(script), path], env=dict(os.environ, **extra), capture_output=True, text=True,
-                           timeout=900)
-        assert r.returncode == 0, r.stderr[-2000:]
-        res.append(np.load(path))
+    path = str(tmp_path / (name + '.npz'))
+    r = subprocess.run([sys.executable, str(script), path], env=dict(os.environ, **extra), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(path)
+
+
+@pytest.fixture(scope='module')
+def default_path_result(tmp_path_factory):
+    """The fits of _KNOB_SCRIPT on the default paths: one process for the whole module, not one per knob."""
+    return _knob_run(tmp_path_factory.mktemp('knob_default'), {}, 'default')
+
+
+@pytest.mark.parametrize('knob', ['LSQAMD_BACKSOLVE=g', 'LSQAMD_BACKSOLVE=s', 'LSQAMD_HOST_LM=1', 'LSQAMD_FUSE_MIN_TILES=-1',
+                                  'LSQAMD_TRAIL_HALVES=1', 'LSQAMD_SYNTH_NARROW=100000000', 'LSQAMD_POTF2=v3', 'LSQAMD_SYNTH_PAIR=1'])
+def test_developer_knobs_select_equivalent_paths(tmp_path, knob, default_path_result):
+    """Every alternative path a developer knob selects (grouped / per-block back substitution, host-side LM
+    bookkeeping, unfused factorisation, half tiles everywhere, 32-term whitening tiles everywhere, the four-wave
+    diagonal kernel, the eight-wave whitening kernel that synthesises every raw row once) gives the default path's fit to rounding: a P = 384 fit to convergence and six LM steps of a
+    P = 3200 fit (25 tile rows: fused launches, half tiles, the chained back substitution)."""
+    res = [default_path_result, _knob_run(tmp_path, dict([knob.split('=')]), 'knob')]
     for k in res[0].files:
         # different summation orders: the iterates agree to rounding amplified by the conditioning of the step;
         # the covariance (P = 3200 on 3328 data rows leans on the prior) to cond * eps
