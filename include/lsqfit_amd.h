@@ -468,6 +468,10 @@ int64_t lsqamd_debug_flags(const lsqamd_fit *fit);
  * device memory after a stream synchronisation instead, out3[2] = words the test knob LSQAMD_VERIFY_HANDOFF=1 found
  * different from the device's own copy after the host had acted on them (must stay 0).  Process-wide counters. */
 int lsqamd_handoff_stats(int64_t *out3);
+/* The process-wide cache of compiled formulas (lsqamd_set_tape compiles with hiprtc and keeps the loaded code object):
+ * out3[0] = kernels loaded now, out3[1] = of those, held by a live handle, out3[2] = kernels unloaded so far.  At most
+ * LSQAMD_JIT_CACHE_CAP (default 1024) stay loaded; beyond that the ones no handle holds go, least recently used first. */
+int lsqamd_jit_cache_stats(int64_t *out3);
 /* The formula of a tape model as the straight-line gfx950 code lsqamd_set_tape builds with hiprtc in
  * place of interpreting the tape (bit 3 of lsqamd_debug_flags: the compiled route is in use; it stands
  * in for the Python fit function the reference differentiates with gvar.valder, src/lsqfit/_gsl.pyx:

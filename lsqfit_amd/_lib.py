@@ -129,6 +129,7 @@ PROTOTYPES = {
     'lsqamd_timing_reset': (C.c_int, [_vp]),
     'lsqamd_debug_flags': (C.c_int64, [_vp]),
     'lsqamd_handoff_stats': (C.c_int, [C.POINTER(C.c_int64)]),
+    'lsqamd_jit_cache_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_debug_set_potf2_stamps': (None, [_vp]),
 }
 

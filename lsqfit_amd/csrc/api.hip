@@ -1944,6 +1944,7 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
                     int32_t n_consts) {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
+  f->drop_jit();
   f->progs.clear();
   f->used_nrm = false;
   f->J_stale = false;
@@ -2072,7 +2073,8 @@ int lsqamd_set_tape_programs(lsqamd_fit *f, int32_t n_prog, const int64_t *row0,
   HIPCHK(f, hipStreamSynchronize(f->st));
   // every formula compiled on its own (hiprtc, cached by content); one that cannot be runs through the
   // forward-mode interpreter kernel over its rows
-  f->jit = nullptr;
+  f->drop_jit();
+  f->progs.clear();
   f->jit_why.clear();
   int compiled = 0;
   for (int i = 0; i < n_prog; ++i) {

@@ -808,6 +808,7 @@ int lsqamdb_destroy(lsqamdb_fits *f) {
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
   if (f->graph) (void)hipGraphDestroy(f->graph);
   lsqamd_host::stream_give(f->st);       // (synchronised above)
+  if (f->jit) lsqamd_jit::release(static_cast<const lsqamd_jit::Kernel *>(f->jit));
   delete f;
   return 0;
 }
@@ -845,6 +846,7 @@ int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const
   // interpreter route (forward mode, ceil(P / 16) passes per row) remains for tapes of <= 1024 instructions when
   // hiprtc is absent or the generator declines
   std::string why;
+  if (f->jit) lsqamd_jit::release(static_cast<const lsqamd_jit::Kernel *>(f->jit));
   f->jit = lsqamd_jit::compile_tape(code, n_code, consts, n_consts, (int)f->P, f->cfg.n_x > 0 ? f->cfg.n_x : 1, why);
   if (!f->jit && (n_code > 1024 || n_consts > 256))
     BFAIL(f, LSQAMD_EUNSUPPORTED, "set_tape: %d instructions need the compiled route, which is unavailable (%s)", n_code, why.c_str());

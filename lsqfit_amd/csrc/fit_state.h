@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include "jit.h"
 
 namespace lsqamd_host {
 
@@ -175,7 +176,16 @@ struct lsqamd_fit {
     for (auto &row : step_seen) row[0] = row[1] = 0;
   }
 
+  // compiled formulas are held (retained by lsqamd_jit::compile_tape): handed back when the tape is replaced or the handle goes
+  void drop_jit() {
+    if (jit) lsqamd_jit::release(static_cast<const lsqamd_jit::Kernel *>(jit));
+    jit = nullptr;
+    for (auto &pg : progs)
+      if (pg.jit) { lsqamd_jit::release(static_cast<const lsqamd_jit::Kernel *>(pg.jit)); pg.jit = nullptr; }
+  }
+
   ~lsqamd_fit() {  // every exit path (including the failure returns of lsqamd_create) ends here
+    drop_jit();
     // staged uploads read the pinned arena, kernels write the pinned block: neither goes back to the process-wide recycler
     // (where the next handle may take it at once) before the stream has drained
     if (st_used) (void)hipStreamSynchronize(st);

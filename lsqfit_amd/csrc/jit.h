@@ -20,8 +20,14 @@ struct LaunchArgs {
   const int *batch_active = nullptr;
 };
 
-// nullptr (and why) when hiprtc is not available or the formula is outside what the generator handles
+// nullptr (and why) when hiprtc is not available or the formula is outside what the generator handles.  The kernel comes back
+// RETAINED: whoever keeps the pointer hands it back with release() when done (a handle: when its tape is replaced or it is
+// destroyed).  The cache keeps at most LSQAMD_JIT_CACHE_CAP (default 1024) loaded kernels: beyond that, kernels nobody holds are
+// unloaded, least recently used first (a sweep whose literal constants change per data set no longer grows without bound).
 const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x, std::string &why);
+void release(const Kernel *k);
+// {loaded kernels, kernels currently held by someone, kernels unloaded so far}
+void cache_stats(long long out[3]);
 // residual: out[row] (ld ignored); Jacobian: out[row * ld + 0..P] with the residual in column P
 hipError_t launch(const Kernel *k, hipStream_t st, bool jac, const LaunchArgs &a);
 bool available(std::string *why);

@@ -33,6 +33,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <algorithm>
+#include <iterator>
 #include <map>
 #include <mutex>
 #include <string>
@@ -1592,6 +1594,8 @@ struct Kernel {
   int n_x = 1;
   bool fit_ok = false, batch_tried = false;
   hipModule_t modb = nullptr;
+  int refs = 0;               // holders (guarded by g_mu)
+  unsigned long long used = 0;   // cache clock at the last compile_tape that returned it
 };
 
 int plan_and_generate(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x,
@@ -1605,6 +1609,53 @@ int plan_and_generate(const int32_t *code, int n_code, const double *consts, int
   return 0;
 }
 
+namespace {
+typedef std::tuple<int, uint64_t, uint64_t, size_t> SrcKey;
+std::map<std::string, Kernel *> g_by_tape;          // tape bytes -> kernel (shortcut past planning and code generation)
+std::map<SrcKey, Kernel> g_kernels;                 // generated source (two hashes + length) -> loaded kernel
+unsigned long long g_clock = 0, g_evicted = 0;
+
+size_t cache_cap() {
+  const char *e = getenv("LSQAMD_JIT_CACHE_CAP");
+  const long v = e ? atol(e) : 0;
+  return v > 0 ? (size_t)v : (size_t)1024;
+}
+
+// (g_mu held) unload kernels nobody holds, least recently used first, until the cache is three quarters full
+void evict_unheld() {
+  const size_t cap = cache_cap();
+  if (g_kernels.size() < cap) return;
+  std::vector<std::pair<unsigned long long, SrcKey>> idle;
+  for (auto &kv : g_kernels)
+    if (kv.second.refs == 0) idle.push_back({kv.second.used, kv.first});
+  std::sort(idle.begin(), idle.end());
+  size_t target = cap - cap / 4;
+  for (size_t i = 0; i < idle.size() && g_kernels.size() > target; ++i) {
+    auto it = g_kernels.find(idle[i].second);
+    Kernel *k = &it->second;
+    for (auto bt = g_by_tape.begin(); bt != g_by_tape.end();) bt = bt->second == k ? g_by_tape.erase(bt) : std::next(bt);
+    if (k->modb) (void)hipModuleUnload(k->modb);
+    if (k->l.mod) (void)hipModuleUnload(k->l.mod);
+    g_kernels.erase(it);
+    ++g_evicted;
+  }
+}
+}  // namespace
+
+void release(const Kernel *kc) {
+  if (!kc) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Kernel *k = const_cast<Kernel *>(kc);
+  if (k->refs > 0) --k->refs;
+}
+
+void cache_stats(long long out[3]) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  long long held = 0;
+  for (auto &kv : g_kernels) held += kv.second.refs > 0;
+  out[0] = (long long)g_kernels.size(); out[1] = held; out[2] = (long long)g_evicted;
+}
+
 const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts, int n_consts, int P, int n_x, std::string &why) {
   if (!rtc().ok) { why = rtc().why; return nullptr; }
   int dev = 0;
@@ -1615,25 +1666,30 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
   tkey.append(reinterpret_cast<const char *>(consts), sizeof(double) * (size_t)(n_consts > 0 ? n_consts : 0));
   const int dims[3] = {P, n_x, dev};
   tkey.append(reinterpret_cast<const char *>(dims), sizeof(dims));
-  static std::map<std::string, const Kernel *> by_tape;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto bt = by_tape.find(tkey);
-    if (bt != by_tape.end()) return bt->second;
+    auto bt = g_by_tape.find(tkey);
+    if (bt != g_by_tape.end()) {
+      ++bt->second->refs;
+      bt->second->used = ++g_clock;
+      return bt->second;
+    }
   }
   std::string src;
   int variant = 0;
   bool has_nrm = false, has_fit = false;
   if (plan_and_generate(code, n_code, consts, n_consts, P, n_x, src, &variant, why, &has_nrm, &has_fit)) return nullptr;
   // (the source itself is not kept: two independent 64-bit hashes and the length stand for it)
-  const std::tuple<int, uint64_t, uint64_t, size_t> key{dev, fnv1a(src), fnv1a(src, 88172645463325252ull), src.size()};
+  const SrcKey key{dev, fnv1a(src), fnv1a(src, 88172645463325252ull), src.size()};
   std::lock_guard<std::mutex> lk(g_mu);
-  static std::map<std::tuple<int, uint64_t, uint64_t, size_t>, Kernel> kernels;
-  auto it = kernels.find(key);
-  if (it != kernels.end()) {
-    if (by_tape.size() < 4096) by_tape[tkey] = &it->second;
+  auto it = g_kernels.find(key);
+  if (it != g_kernels.end()) {
+    if (g_by_tape.size() < 4096) g_by_tape[tkey] = &it->second;
+    ++it->second.refs;
+    it->second.used = ++g_clock;
     return &it->second;
   }
+  evict_unheld();
   std::string log;
   Kernel k;
   const hipError_t be = build_module(src, &k.l.mod, log);
@@ -1642,6 +1698,7 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
       hipModuleGetFunction(&k.l.res, k.l.mod, "lsqamd_jit_res") != hipSuccess ||
       hipModuleGetFunction(&k.l.jac, k.l.mod, "lsqamd_jit_jac") != hipSuccess) {
     (void)hipGetLastError();
+    if (k.l.mod) (void)hipModuleUnload(k.l.mod);
     why = "the compiled tape could not be loaded";
     return nullptr;
   }
@@ -1659,8 +1716,10 @@ const Kernel *compile_tape(const int32_t *code, int n_code, const double *consts
   k.code.assign(code, code + n_code);
   k.consts.assign(consts, consts + (n_consts > 0 ? n_consts : 0));
   k.n_x = n_x;
-  const Kernel *kp = &kernels.emplace(key, k).first->second;
-  if (by_tape.size() < 4096) by_tape[tkey] = kp;
+  k.refs = 1;
+  k.used = ++g_clock;
+  Kernel *kp = &g_kernels.emplace(key, k).first->second;
+  if (g_by_tape.size() < 4096) g_by_tape[tkey] = kp;
   return kp;
 }
 
@@ -1707,21 +1766,29 @@ int64_t fit_row_limit(const Kernel *k, bool correlated) {
 }
 bool has_batch_fit_kernel(const Kernel *kc) {
   if (!kc || !kc->fit_ok) return false;
-  std::lock_guard<std::mutex> lk(g_mu);
   Kernel *k = const_cast<Kernel *>(kc);      // (the cache owns the object; its batch half is filled in under the lock)
-  if (!k->batch_tried) {
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (k->batch_tried) return k->l.lmb != nullptr;     // (a build in flight on another thread: that call takes the lockstep engine)
     k->batch_tried = true;
-    Plan pl;
-    std::string why, log;
-    if (make_plan(k->code.data(), (int)k->code.size(), k->consts.data(), (int)k->consts.size(), k->l.n_param, k->n_x, pl, why) &&
-        pl.fit_ok && build_module(generate(pl, true), &k->modb, log) == hipSuccess &&
-        hipModuleGetFunction(&k->l.lmb, k->modb, "lsqamd_jit_lmb") == hipSuccess) {
-    } else {
-      (void)hipGetLastError();
-      k->l.lmb = nullptr;
-    }
   }
-  return k->l.lmb != nullptr;
+  // the build itself (0.9 - 1.6 s of hiprtc for a new formula) runs outside the cache's lock; the caller holds the kernel
+  Plan pl;
+  std::string why, log;
+  hipModule_t modb = nullptr;
+  hipFunction_t lmb = nullptr;
+  if (!(make_plan(k->code.data(), (int)k->code.size(), k->consts.data(), (int)k->consts.size(), k->l.n_param, k->n_x, pl, why) &&
+        pl.fit_ok && build_module(generate(pl, true), &modb, log) == hipSuccess &&
+        hipModuleGetFunction(&lmb, modb, "lsqamd_jit_lmb") == hipSuccess)) {
+    (void)hipGetLastError();
+    if (modb) (void)hipModuleUnload(modb);
+    modb = nullptr;
+    lmb = nullptr;
+  }
+  std::lock_guard<std::mutex> lk(g_mu);
+  k->modb = modb;
+  k->l.lmb = lmb;
+  return lmb != nullptr;
 }
 
 hipError_t launch_fit_batch(const Kernel *k, hipStream_t st, const FitArgs &a, const FitBatch &b, int n_fits) {
@@ -1746,6 +1813,14 @@ bool available(std::string *why) {
 }
 
 }  // namespace lsqamd_jit
+
+extern "C" int lsqamd_jit_cache_stats(int64_t *out3) {
+  if (!out3) return LSQAMD_EINVAL;
+  long long v[3];
+  lsqamd_jit::cache_stats(v);
+  for (int i = 0; i < 3; ++i) out3[i] = v[i];
+  return 0;
+}
 
 extern "C" int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts, int32_t n_param,
                                    int32_t n_x, char *src_out, size_t cap, int32_t *variant, int32_t compile) {

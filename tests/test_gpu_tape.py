@@ -135,3 +135,37 @@ def test_segmented_tape_kernel_matches_the_whole_tape_and_forward_mode_kernels(t
             assert np.max(np.abs(J - Jo) / scale) < 1e-13, (name, other)
             fo = np.array(res[other][name]['f'])
             assert np.max(np.abs(np.array(res[''][name]['f']) - fo)) <= 1e-14 * np.max(np.abs(fo)), (name, other)
+
+
+def test_compiled_formula_cache_is_bounded(monkeypatch):
+    """A sweep whose literal constants change per data set builds a code object per variant: the cache keeps at most
+    LSQAMD_JIT_CACHE_CAP loaded, unloads the ones no handle holds (least recently used first) and never one that is held."""
+    import ctypes as C
+    import lsqfit_amd as amd
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+
+    def stats():
+        st = (C.c_int64 * 3)()
+        assert lib.lsqamd_jit_cache_stats(st) == 0
+        return st[0], st[1], st[2]
+    rng = np.random.default_rng(3)
+    x = np.linspace(0.1, 2.0, 50)
+    sd = np.full(50, 0.01)
+    keep_y = 1.3 * np.exp(-0.7 * x) + 0.25
+    held = amd.nonlinear_fit(data=(x, keep_y, sd), model=amd.expr('a*exp(-b*x) + 0.25', ['a', 'b']), p0=[1.0, 1.0])
+    monkeypatch.setenv('LSQAMD_JIT_CACHE_CAP', '8')
+    ev0 = stats()[2]
+    for k in range(30):
+        c = 0.25 + 0.001 * (k + 1)                       # a new literal -> a new formula -> a new code object
+        y = 1.3 * np.exp(-0.7 * x) + c + sd * rng.standard_normal(50)
+        fit = amd.nonlinear_fit(data=(x, y, sd), model=amd.expr('a*exp(-b*x) + %r' % c, ['a', 'b']), p0=[1.0, 1.0])
+        assert fit.problem.lib.lsqamd_debug_flags(fit.problem.h) & 8 and abs(fit.pmean[0] - 1.3) < 0.05
+        fit.problem.close()
+        del fit
+        loaded, n_held, evicted = stats()
+        assert loaded <= 8 and n_held >= 1
+    assert stats()[2] - ev0 >= 20
+    # the kernel of the problem that stayed open was never unloaded: it still runs, same bits
+    again = amd.nonlinear_fit(data=(x, keep_y, sd), model=held.model, p0=[1.0, 1.0], problem=held.problem)
+    assert np.array_equal(again.pmean, held.pmean) and again.chi2 == held.chi2
