@@ -63,7 +63,24 @@ def main():
     bad = 0
     fits = 0
     t0 = time.time()
+    # a wide fit (30 parameters: a record block of ~1100 words, most of it covariance) and a correlated one, every tenth loop
+    rngw = np.random.default_rng(4)
+    xw = np.linspace(0.0, 10.0, 128)
+    cs = np.linspace(0.7, 9.3, 15)
+    aw, bw = 1.0 + 0.5 * rngw.random(15), 2.0 + rngw.random(15)
+    ptw = np.concatenate([aw, bw])
+    yw = sum(aw[k] * np.exp(-bw[k] * (xw - cs[k]) ** 2) for k in range(15)) + 0.02 * rngw.standard_normal(128)
+    namesw = ['a%d' % k for k in range(15)] + ['b%d' % k for k in range(15)]
+    wide = amd.expr(' + '.join('a%d*exp(-b%d*(x - %r)**2)' % (k, k, float(cs[k])) for k in range(15)), namesw)
     for it in range(loops):
+        if it % 10 == 0:
+            kw = dict(data=(xw, yw * (1.0 + 1e-3 * (it % 7)), np.full(128, 0.02)), model=wide, prior=(ptw, np.full(30, 0.5)), p0=ptw * 1.05)
+            one, f1, gen = both(**kw)
+            fits += 1
+            d = differ(one, gen)
+            if d or not f1 & ONE:
+                bad += 1
+                print('loop %d wide: route %d %s' % (it, f1 & ONE, d), flush=True)
         for prior in ('diag', 'dense', 'none'):
             for scaler in ('more', 'levenberg', 'marquardt'):
                 kw = dict(data=(x, y, sd), model=model, p0=pt * 1.2, scaler=scaler)
