@@ -645,3 +645,21 @@ def test_cross_correlated_maxit0_matches_oracle(amd):
     assert np.array_equal(fit.pmean, ref.pmean) and np.allclose(fit.cov, ref.cov, rtol=1e-12)
     assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-8) and fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-7)
     assert fit.Q == pytest.approx(ref.Q, rel=1e-7, abs=1e-12)
+
+
+def test_unusual_cases_on_device(amd):
+    """tests/test_lsqfit.py:456-472 (test_unusual_cases): a scalar y with a scalar prior, fcn(p) = p, and a two-element y with
+    fcn(p) = [p, p] -- the fits must print as the weighted average of their inputs (str(fit.p) == str(wavg(...)))."""
+    for ys, ysd in (([1.5], [0.1]), ([1.5, 1.7], [0.1, 0.2])):
+        y, sd = np.array(ys), np.array(ysd)
+        fit = amd.nonlinear_fit(data=(np.zeros(y.size), y, sd), model=amd.expr('p + 0*x', ['p']), prior=(np.array([2.0]), np.array([0.5])),
+                                tol=1e-8)
+        w = np.concatenate([1.0 / sd ** 2, [1.0 / 0.25]])
+        mean, sdev = float(np.sum(w * np.concatenate([y, [2.0]])) / np.sum(w)), float(1.0 / np.sqrt(np.sum(w)))
+        assert gvar_lite.fmt(fit.pmean[0], fit.psdev[0]) == gvar_lite.fmt(mean, sdev)
+        assert fit.pmean[0] == pytest.approx(mean, rel=1e-12) and fit.psdev[0] == pytest.approx(sdev, rel=1e-10)
+        assert fit.dof == y.size and fit.error is None
+        ref = ofit.nonlinear_fit(False, y, sd, lambda p: y.size * [p[0]],
+                                 prior_mean=[2.0], prior_err=[0.5], tol=1e-8, jac=lambda p: np.ones((y.size, 1)))
+        assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-9) and fit.logGBF == pytest.approx(ref.logGBF, rel=1e-9)
+    assert gvar_lite.fmt(1.5192307692307692, 0.09805806756909202) == '1.519(98)'

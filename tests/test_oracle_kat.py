@@ -700,3 +700,17 @@ def test_wavg_svd_literal():
         fit = ofit.nonlinear_fit(False, np.ones(3), WAVG_SVD_COV, lambda p: p[0] * np.ones(3), p0=[1.0],
                                  jac=lambda p: np.ones((3, 1)), svdcut=svdcut)
         assert abs(fit.cov[0, 0] - var) < 5e-8 and fit.svdn == nmod
+
+
+def test_unusual_cases_print_as_weighted_averages():
+    """tests/test_lsqfit.py:456-472: scalar y + scalar prior with fcn(p) = p, and y of two elements with fcn(p) = [p, p]:
+    str(fit.p) == str(wavg(inputs))."""
+    import numpy as np
+    from oracle import fit as ofit, gvar_lite
+    for ys, ysd, want in (([1.5], [0.1], '1.519(98)'), ([1.5, 1.7], [0.1, 0.2], '1.554(88)')):
+        y, sd = np.array(ys), np.array(ysd)
+        ref = ofit.nonlinear_fit(False, y, sd, lambda p: y.size * [p[0]], prior_mean=[2.0], prior_err=[0.5], tol=1e-8,
+                                 jac=lambda p: np.ones((y.size, 1)))
+        w = np.concatenate([1.0 / sd ** 2, [4.0]])
+        mean, sdev = np.sum(w * np.concatenate([y, [2.0]])) / np.sum(w), 1.0 / np.sqrt(np.sum(w))
+        assert gvar_lite.fmt(ref.pmean[0], ref.psdev[0]) == gvar_lite.fmt(mean, sdev) == want
