@@ -130,3 +130,33 @@ def test_tape_model_and_no_prior(amd):
                             tol=(1e-8, 1e-8, 1e-8))
     ref2 = ofit.nonlinear_fit(x, y, sd, fcn, p0=pt * 1.2, fitter='scipy_least_squares', tol=(1e-8, 1e-8, 1e-8))
     assert gu.relmax(lin.pmean, ref2.pmean) < 1e-6 and gu.relmax(lin.cov, ref2.cov) < 1e-6
+
+
+def test_c_abi_refusals(amd):
+    """The C ABI's own guards (a host in another language sees these, not the Python checks): a loss outside the five, a
+    non-positive f_scale or x_scale; a robust loss with lsqamd_set_prior (the prior must travel as rows), with MINPACK's lm."""
+    import ctypes as C
+    from lsqfit_amd import _lib
+    x, y, ysd, pm, psd, truth, fcn, jac = with_outliers(9, 1)
+    pr = amd.DeviceProblem(amd.multiexp(1), x, amd.Whitening(y, ysd, pm, psd))           # prior through lsqamd_set_prior
+    lib, h = pr.lib, pr.h
+    assert lib.lsqamd_set_loss(h, 7, 1.0) == -1 and b'loss' in lib.lsqamd_last_error(h)
+    assert lib.lsqamd_set_loss(h, 2, 0.0) == -1 and lib.lsqamd_set_loss(h, 2, float('nan')) == -1
+    bad = np.array([1.0, -2.0])
+    assert lib.lsqamd_set_x_scale(h, _lib.dptr(bad)) == -1 and b'x_scale' in lib.lsqamd_last_error(h)
+    assert lib.lsqamd_set_loss(h, 2, 1.5) == 0
+    s = _lib.Summary()
+    p0 = np.ascontiguousarray(pm, np.float64)
+    pr.set_options((1e-8, 1e-8, 1e-8), 100, 'levenberg', alg='trf')
+    rc = lib.lsqamd_run(h, _lib.dptr(p0), C.byref(s))
+    assert _lib.ERRORS.get(rc) == 'EUNSUPPORTED' and b'rows' in lib.lsqamd_last_error(h)
+    pr.set_options((1e-8, 1e-8, 1e-8), 100, 'levenberg', alg='minpack_lm')
+    rc = lib.lsqamd_run(h, _lib.dptr(p0), C.byref(s))
+    assert rc == -1 and b"supports only 'linear' loss" in lib.lsqamd_last_error(h)
+    # the plain lm method ignores a loss that was left set (it is an option of the scipy methods): same fit as without
+    pr.set_options((1e-8, 1e-10, 1e-10), 100)
+    assert lib.lsqamd_run(h, _lib.dptr(p0), C.byref(s)) == 0
+    chi2_with = s.chi2
+    assert lib.lsqamd_set_loss(h, 0, 1.0) == 0 and lib.lsqamd_run(h, _lib.dptr(p0), C.byref(s)) == 0
+    assert s.chi2 == chi2_with
+    pr.close()
