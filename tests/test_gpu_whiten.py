@@ -117,7 +117,7 @@ def test_config3_setup_time(amd):
     dt = time.perf_counter() - t0
     print('config 3 set-up (whitening + problem): %.3f s' % dt)
     assert wh.blocks[0]['tri'] == 1 and 'Wt_dev' in wh.blocks[0]
-    assert dt < 3.0
+    assert dt < 6.0            # (0.03 - 0.2 s on the pool's boxes; the host path it replaced took 23.9 s)
     # log det against LAPACK's Cholesky of the same block
     c = d['yerr']['blocks'][0][1]
     L = np.linalg.cholesky(c)
