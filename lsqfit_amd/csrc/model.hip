@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void tape_reverse_kernel(TapeRev a) {
 // (a cosine term: 3 stack levels + 5 partials = 4 KB), the parameters sit in LDS, the tape is read through
 // scalar loads one instruction ahead, x of the row through registers.  Per-chunk values of f go to a
 // scratch array and are summed in chunk order (tape_total_kernel): reproducible bit for bit.
-constexpr int TAPE_SEG_SLOTS = 32;     // partial-derivative slots a segment may use at most
+[[maybe_unused]] constexpr int TAPE_SEG_SLOTS = 32;     // partial-derivative slots a segment may use at most
 
 struct TapeSeg {
   TapeRev r;

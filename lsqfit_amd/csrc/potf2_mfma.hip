@@ -1236,7 +1236,8 @@ __device__ __forceinline__ void fused_diag_wave4(const TrailArgs &t, double *Adi
 __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *Adiag, int nb, double *uinv,
                                                           int32_t *info, int32_t k0n, int pivot_wave) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
+  [[maybe_unused]] const int lane = tid & 63;
   // workgroup 0: the next diagonal block (update + factorisation); dispatched first, it works while
   // the other CUs do the remaining tiles of the update
   if (blockIdx.x > 0) {
