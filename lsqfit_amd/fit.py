@@ -95,9 +95,7 @@ class nonlinear_fit(object):
                 if prior is None or uncorrelated:
                     raise ValueError('cross needs data= and prior=')
                 from .whiten import joint_whitening
-                if np.any(noise):
-                    raise NotImplementedError('noise= with data-prior cross-correlations')
-                wh = joint_whitening(ymean, yerr, pm, perr, cross, svdcut=svdcut, eps=eps)
+                wh = joint_whitening(ymean, yerr, pm, perr, cross, svdcut=svdcut, eps=eps, noise=noise, rng=rng)
             else:
                 wh = Whitening(ymean, yerr, pm, perr, svdcut=svdcut, eps=eps, udata=uncorrelated, noise=noise,
                                rng=rng)

@@ -515,7 +515,7 @@ def _components(cov):
     return out
 
 
-def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, engine=None, eps=None):
+def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, engine=None, eps=None, noise=False, rng=None):
     """Whitening of concat(y, prior) when data and prior are correlated (``cross`` = the N x P
     covariance between them): what src/lsqfit/__init__.py:1892-1900 hands to gvar.PDF.
 
@@ -545,6 +545,13 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, eng
     full[N:, N:] = dense(prior_err, P)
     full[:N, N:] = cross
     full[N:, :N] = cross.T
+    # noise (src/lsqfit/__init__.py:247-256): noise[1] moves the prior means by a draw from the prior's own covariance before
+    # anything else (:535-536); noise[0] adds, to the JOINT vector, a draw from what the regulation added (:1896, gvar.PDF's noise)
+    noise = (bool(noise), bool(noise)) if np.ndim(noise) == 0 else (bool(noise[0]), bool(noise[1]))
+    gen = np.random.default_rng(rng)
+    if noise[1]:
+        w, v = np.linalg.eigh(full[N:, N:])
+        pm = pm + v @ (np.sqrt(np.clip(w, 0.0, None)) * gen.standard_normal(P))
     comps = _components(full)
     perm = np.concatenate(comps)
     z = np.concatenate([ymean, pm])[perm]
@@ -554,7 +561,9 @@ def joint_whitening(ymean, yerr, prior_mean, prior_err, cross, svdcut=1e-12, eng
         if c.size > 1:
             blocks.append((r0, full[np.ix_(c, c)]))
         r0 += c.size
-    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut, engine=engine, eps=eps)
+    wh = Whitening(z, dict(sdev=sd, blocks=blocks), svdcut=svdcut, engine=engine, eps=eps, noise=(noise[0], False),
+                   rng=gen.integers(1 << 62))
+    wh.noise = noise
     wh.joint = True
     wh.row_src = perm
     wh.row_param = np.where(perm >= N, perm - N, -1).astype(np.int32)

@@ -249,3 +249,26 @@ def test_eps_regulation_with_data_correlated_with_the_prior(amd):
     assert gu.relmax(fit.cov, ref.cov) < 1e-6 and fit.logGBF == pytest.approx(ref.logGBF, rel=1e-6, abs=1e-6)
     plain = amd.nonlinear_fit(data=(x, y, full[:N, :N]), model=model, prior=(pm, full[N:, N:]), cross=full[:N, N:], tol=1e-10)
     assert abs(plain.chi2 - fit.chi2) > 1e-6 * fit.chi2           # (the regulation did something)
+
+
+def test_noise_with_data_correlated_with_the_prior(amd):
+    """noise= (src/lsqfit/__init__.py:247-256,:535-536,:1896) for the joint vector: noise[1] shifts the prior means by a draw from
+    the prior's covariance before the fit, noise[0] adds a draw from what the regulation added to concat(y, prior).  gvar's random
+    stream is not reproduced (unpinned): the fit with noise must BE the plain fit of the shifted means, bit for bit."""
+    x, y, pm, full, N, P = _cross_problem(seed=35)
+    model = amd.expr('b1*exp(-b2*x) + b3', ['b1', 'b2', 'b3'])
+    Cyy, Cpp, Cyp = full[:N, :N], full[N:, N:], full[:N, N:]
+    plain = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10)
+    pn = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10, noise=(False, True), rng=7)
+    shifted = pn.whitening.prior_mean_host
+    assert np.all(shifted != pm) and np.all(np.abs(shifted - pm) < 6 * np.sqrt(np.diag(Cpp)))
+    same = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(shifted, Cpp), cross=Cyp, tol=1e-10, p0=pm)
+    assert np.array_equal(pn.pmean, same.pmean) and pn.chi2 == same.chi2 and pn.logGBF == same.logGBF
+    assert not np.array_equal(pn.pmean, plain.pmean)
+    # nothing is regulated at the default svdcut here: data noise adds nothing; with a binding svdcut it moves the joint means
+    dn = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10, noise=(True, False), rng=7)
+    assert np.array_equal(dn.pmean, plain.pmean) and dn.svdn == 0
+    cut = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10, svdcut=0.3)
+    cutn = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10, svdcut=0.3, noise=(True, False), rng=7)
+    assert cut.svdn > 0 and cutn.svdn == cut.svdn and not np.array_equal(cutn.pmean, cut.pmean)
+    assert np.all(np.abs(cutn.pmean - cut.pmean) < 8 * cut.psdev)
