@@ -57,6 +57,7 @@ struct GemmDev {
   int64_t kchunk, split_stride;
   const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
   int32_t n_work;
+  int32_t persist;          // work list walked by 8 x (gridDim.x / 8) resident workgroups in rounds (experiment, see launch_gemm_tn)
   const int32_t *batch_active;  // optional: skip batch entries whose flag is 0
   double *colsum_out;           // optional (XTRI interior kernel): fused column sums, see GemmTN
   int64_t colsum_ld, colsum_rcol;
@@ -261,11 +262,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn, split;
+  int w_first = 0, w_stride = 0, n_items = 1;     // WORKMAP: this workgroup's entries of the list
   if (WORKMAP) {
     const int nw = g.n_work, bid = blockIdx.x;
     const int xcd = bid & 7, q = nw >> 3, r = nw & 7;
-    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
+    const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, runlen = q + (xcd < r ? 1 : 0);
+    if (g.persist) {       // resident workgroups: slot s of an XCD takes entries s, s + slots, ... of the XCD's run
+      const int slots = (int)(gridDim.x >> 3), slot = bid >> 3;
+      w_first = run0 + slot;
+      w_stride = slots;
+      n_items = slot < runlen ? (runlen - slot + slots - 1) / slots : 0;
+      if (n_items == 0) return;
+    } else {
+      w_first = run0 + (bid >> 3);
+    }
+    const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w_first];
     tm = e.x; tn = e.y; split = e.z;
   } else {
     tm = blockIdx.x / g.tiles_n;
@@ -276,9 +287,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   // T-1-tm one after the other, so every workgroup sees the same total K (the k-range of a
   // tile row grows with tm: unpaired, the last rows take 64x as long as the first)
   const int tm_other = (XTRI && g.pair_rows) ? g.tiles_m - 1 - tm : tm;
-  const int npass = tm_other != tm ? 2 : 1;
+  const int npass = WORKMAP ? n_items : (tm_other != tm ? 2 : 1);
   for (int pass = 0; pass < npass; ++pass) {
-  if (pass == 1) { tm = tm_other; __syncthreads(); }
+  if (pass >= 1) {
+    if (WORKMAP) {
+      const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w_first + pass * w_stride];
+      tm = e.x; tn = e.y; split = e.z;
+    } else {
+      tm = tm_other;
+    }
+    __syncthreads();
+  }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
   if (g.upper_only && n0 + BN <= m0) return;
   const int64_t b = blockIdx.z;
@@ -915,6 +934,14 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
   g.work_map = a.work_map;
   g.n_work = a.n_work;
+  // Experiment (round 4, review item 9): LSQAMD_SYRK_PERSIST=1 walks the work list with 512 RESIDENT workgroups (64 per XCD) in
+  // rounds of one 8 x 8 patch each, so that the tiles of a patch stay in step in their K loops and share their panel fetches in
+  // the XCD's L2 (dynamic dispatch lets them drift: 72 % hit rate).  Measured: see DESIGN.md section 9; off by default.
+  g.persist = 0;
+  if (a.work_map && a.n_work >= 1024) {
+    const char *e = getenv("LSQAMD_SYRK_PERSIST");
+    if (e && e[0] == '1') g.persist = 1;
+  }
   const bool diag_off = syrk_diag_off();
   g.syrk_diag = a.work_map && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy && a.M == a.N &&
                 (g.splits > 1 || a.beta == 0.0) && !diag_off;
@@ -923,7 +950,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.colsum_ld = a.colsum_ld;
   g.colsum_rcol = a.colsum_rcol;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
-  if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
+  if (a.work_map) grid = dim3((unsigned)(g.persist ? 512 : a.n_work), 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
                         !a.force_generic && !(a.x_upper_tri && a.work_map);  // no <XTRI, WORKMAP> instantiation
   // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups); threshold from a
