@@ -663,3 +663,28 @@ def test_unusual_cases_on_device(amd):
                                  prior_mean=[2.0], prior_err=[0.5], tol=1e-8, jac=lambda p: np.ones((y.size, 1)))
         assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-9) and fit.logGBF == pytest.approx(ref.logGBF, rel=1e-9)
     assert gvar_lite.fmt(1.5192307692307692, 0.09805806756909202) == '1.519(98)'
+
+
+def test_uncorrelated_example_shape_on_device(amd):
+    """examples/uncorrelated.py: 50 000 points handed over as udata=(x, y) (correlations ignored, src/lsqfit/__init__.py:1892-1893),
+    p[0] + p[1] exp(-p[2] x), priors 0(1).  The example's data come from gvar's random stream (its printed digits cannot be
+    reproduced without gvar); the same recipe with numpy's -- noise of HALF the quoted error, hence chi2/dof ~ 0.25 as in
+    uncorrelated.out -- against the oracle, and the printed figures' structure (dof = N, logGBF ~ 2.9e5, errors ~ 8e-5)."""
+    rng = np.random.default_rng(12)
+    N = 50000
+    x = np.linspace(0.2, 2.0, N)
+    ptrue = np.array([0.5, 0.4, 0.7])
+    y = ptrue[0] + ptrue[1] * np.exp(-ptrue[2] * x) + 0.5 * 0.001 * rng.standard_normal(N)
+    sd = np.full(N, 0.001)
+    fit = amd.nonlinear_fit(udata=(x, y, sd), model=amd.expr('a + b*exp(-c*x)', ['a', 'b', 'c']), prior=(np.zeros(3), np.ones(3)))
+
+    def fcn(xx, p):
+        from oracle import dual
+        return p[0] + p[1] * dual.exp(-p[2] * xx)
+    ref = ofit.nonlinear_fit(x, y, sd, fcn, prior_mean=np.zeros(3), prior_err=np.ones(3), udata=True, solver='cholesky')
+    assert fit.dof == ref.dof == N and abs(fit.nit - ref.nit) <= 1 and fit.stopping_criterion == ref.stopping_criterion
+    assert np.all(np.abs(fit.pmean - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-5 * ref.psdev)
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-6) and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-6)
+    assert abs(fit.chi2 / fit.dof - 0.25) < 0.01 and 2.9e5 < fit.logGBF < 2.95e5            # uncorrelated.out: 0.25 [50000], 2.9318e+05
+    assert np.all(np.abs(fit.pmean - ptrue) < 5 * fit.psdev) and np.allclose(fit.psdev, [7.9e-5, 5.9e-5, 2.8e-4], rtol=0.1)
