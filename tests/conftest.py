@@ -45,3 +45,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """With the hand-off audit on for the whole run (LSQAMD_VERIFY_HANDOFF=1: after the host has acted on a polled pinned block, the
+    library waits for the stream and compares it with the device's own copy), a single differing word fails the session."""
+    if not os.environ.get('LSQAMD_VERIFY_HANDOFF'):
+        return
+    try:
+        import ctypes
+        from lsqfit_amd import _lib
+        if _lib._lib is None:
+            return
+        st = (ctypes.c_int64 * 3)()
+        _lib._lib.lsqamd_handoff_stats(st)
+        print('\nhand-offs of this process: %d snapshots polled again, %d served from device memory, %d words differed from the device copy'
+              % (st[0], st[1], st[2]))
+        if st[2] and session.exitstatus == 0:
+            session.exitstatus = 1
+    except Exception as e:       # the audit must never hide the suite's own result
+        print('hand-off statistics unavailable: %r' % (e,))
