@@ -8,6 +8,7 @@ CPU fallback -- importing the compute entry points without the built library
 raises.
 
   models     row models the kernels can differentiate (replaces user fcn + gvar AD)
+  trace      ``trace(fcn, x, p0)``: the user's Python fit function recorded into a device tape (one call on tracer arrays)
   whiten     host mirror of gvar.PDF: block structure, svdcut, whitening weights
   fitter     ``mi355x_lm``: the fitter plugin class (mirror of gsl_multifit);
              ``mi355x_trf``: bounded fits (mirror of scipy_least_squares, method 'trf')
@@ -19,6 +20,7 @@ raises.
 """
 from .models import Model, cosmix, multiexp, identity, expr, piecewise  # noqa: F401
 from .whiten import Whitening  # noqa: F401
+from .trace import trace, trace_residual, TraceError  # noqa: F401
 from .fitter import mi355x_lm, mi355x_trf, DeviceProblem, register  # noqa: F401
 from .fit import nonlinear_fit, gammaQ  # noqa: F401
 from .sweep import empbayes_fit, prior_width_sweep  # noqa: F401

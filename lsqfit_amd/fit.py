@@ -53,13 +53,37 @@ class nonlinear_fit(object):
 
     def __init__(self, data=None, model=None, prior=None, p0=None, svdcut=False, tol=None,
                  maxit=None, udata=None, fitter=None, problem=None, linear=None, cross=None, eps=False,
-                 noise=False, rng=None, **fitterargs):
+                 noise=False, rng=None, fcn=None, **fitterargs):
         if data is None and udata is None:
             raise ValueError('neither data nor udata is specified')
-        if model is None:
-            raise ValueError('no fit function (model) specified')
+        if model is None and fcn is None:
+            raise ValueError('no fit function (fcn or model) specified')
         if p0 is None and prior is None:
             raise ValueError('neither p0 nor prior is specified')
+        self.fcn = fcn
+        self.traced = None
+        if model is None:
+            # the reference's own call form: an ordinary Python function of (x, p) -- or of p alone when the data carry no x
+            # (data = (y, yerr) / x False, src/lsqfit/__init__.py:2013-2016) -- with array or dictionary parameters and
+            # outputs.  It is CALLED once on tracer arrays and the recording compiled for the device (lsqfit_amd.trace)
+            from .trace import flatten_mean_err, trace
+            dd = udata if data is None else data
+            if len(dd) == 2:
+                dd = (False,) + tuple(dd)
+            xx, ymean_in, yerr_in = dd
+            template = prior[0] if prior is not None else p0
+            self.traced = trace(fcn, xx, template, y=ymean_in)
+            model = self.traced.model
+            ymean_f, yerr_f = flatten_mean_err(ymean_in, yerr_in)
+            dd = (self.traced.x, ymean_f, yerr_f)
+            if data is None:
+                udata = dd
+            else:
+                data = dd
+            if prior is not None:
+                prior = flatten_mean_err(prior[0], prior[1])
+            if p0 is not None:
+                p0 = self.traced.pack_params(p0)
         # src/lsqfit/__init__.py:471-479: neither given -> the default svdcut; eps alone -> no svdcut
         if svdcut is False and eps is False:
             svdcut, eps = DEFAULTS['svdcut'], None
@@ -125,6 +149,7 @@ class nonlinear_fit(object):
             # src/lsqfit/__init__.py:683-706: no fit -- parameters are the prior (or p0 with infinite
             # errors); chi2 is still evaluated on the device
             self.fitter_results = None
+            self.fitterargs = dict(fitterargs)
             self.error = None
             if prior is None:
                 self.pmean = self.p0.copy()
@@ -169,6 +194,7 @@ class nonlinear_fit(object):
             if self.linear:
                 problem.set_linear(None)
         self.fitter_results = fit
+        self.fitterargs = dict(fitterargs)          # what resampled copies are refitted with (src/lsqfit/__init__.py:1457-1459)
         self.error = fit.error
         self.cov = fit.cov
         self.chi2 = fit.chi2                       # = sum(fit.f**2), computed on the device
@@ -191,6 +217,12 @@ class nonlinear_fit(object):
     @property
     def residuals(self):
         return self.fitter_results.f
+
+    @property
+    def p(self):
+        """best-fit parameter MEANS in the shape the fit function takes them (array or dictionary; traced fits only --
+        ``pmean`` is the flat vector, ``psdev`` / ``cov`` its errors)"""
+        return self.pmean if self.traced is None else self.traced.unpack_params(self.pmean)
 
     @property
     def J(self):

@@ -76,6 +76,23 @@ def _cov_failed(fit, summary):
             fit.error = msg
 
 
+def _problem_from_residual(x0, n, f):
+    """No ``problem=``: the plugin was called exactly as lsqfit calls its fitters, ``FITTERS[name](p0, nf, chiv, ...)``
+    (src/lsqfit/__init__.py:662-664).  ``f`` -- lsqfit's ``chiv``: p -> whitened residual, prior rows included -- is called
+    ONCE on tracer numbers (the way ``_c_df`` calls it on GVars, src/lsqfit/_gsl.pyx:748-750) and the recording becomes the
+    device model; the residual is already whitened, so the device sees unit weights and no separate prior."""
+    if f is None or not callable(f):
+        raise ValueError("the MI355X fitters need the residual function f (as lsqfit hands it over) or problem=DeviceProblem(...)")
+    from .trace import trace_residual
+    from .whiten import Whitening
+    P = int(np.size(x0))
+    tr = trace_residual(f, P)
+    if n is not None and int(n) != tr.n_rows:
+        raise ValueError('n = %d but the residual function returned %d values' % (int(n), tr.n_rows))
+    wh = Whitening(np.zeros(tr.n_rows), np.ones(tr.n_rows), svdcut=None)
+    return DeviceProblem(tr.model, tr.x, wh)
+
+
 class DeviceProblem:
     """Model + data + whitening resident on one GPU (one C-ABI handle).
 
@@ -519,8 +536,7 @@ class mi355x_lm(object):
     def __init__(self, x0, n, f=None, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm', solver='cholesky',
                  scaler='more', factor_up=3.0, factor_down=2.0, avmax=0.75, problem=None):
         if problem is None:
-            raise ValueError("mi355x_lm needs problem=DeviceProblem(...): the fit function must be "
-                             "given as a device model, the Python callable cannot run on the GPU")
+            problem = _problem_from_residual(x0, n, f)
         if alg not in _ALGS:
             raise ValueError('unkown algorithm ' + str(alg))            # _gsl.pyx:634-635
         if solver not in _SOLVERS:
@@ -620,7 +636,7 @@ class mi355x_trf(mi355x_lm):
     def __init__(self, x0, n, f=None, tol=(1e-8, 1e-8, 1e-8), maxit=1000, method=None, bounds=None,
                  x_scale=1.0, loss='linear', f_scale=1.0, tr_solver=None, tr_options=None, jac_sparsity=None, problem=None):
         if problem is None:
-            raise ValueError("mi355x_trf needs problem=DeviceProblem(...)")
+            problem = _problem_from_residual(x0, n, f)
         if method is None:
             method = 'trf'                                                 # _scipy.py:135-139
         if method not in ('trf', 'dogbox', 'lm'):

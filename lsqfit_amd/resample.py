@@ -64,8 +64,71 @@ class ResampledFits(dict):
     __getattr__ = dict.__getitem__
 
 
+_BATCHED_ARGS = {'alg', 'scaler', 'factor_up', 'factor_down', 'solver', 'avmax'}
+
+
+def _batchable(fit):
+    """the lockstep engine runs plain LM: a fit made with another fitter, another algorithm, a robust loss, bounds or
+    ``x_scale`` is refitted copy by copy with ITS fitter and arguments (src/lsqfit/__init__.py:1457-1459,:1603-1604)"""
+    args = getattr(fit, 'fitterargs', {})
+    return fit.fitter == 'mi355x_lm' and args.get('alg', 'lm') == 'lm' and set(args) <= _BATCHED_ARGS and not getattr(fit, 'linear', None)
+
+
+def _sequential_copies(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
+    """the copies one after the other on the fit's resident device problem, through ``nonlinear_fit`` with the original
+    fit's fitter and fitter arguments"""
+    from .fit import nonlinear_fit
+    wh, pr = fit.whitening, fit.problem
+    n = ymeans.shape[0]
+    tol = fit.tol if tol is None else tol
+    maxit = fit.maxit if maxit is None else maxit
+    keys = ('pmean', 'psdev', 'chi2', 'Q', 'nit', 'stopping_criterion', 'logGBF')
+    out = {k: [] for k in keys}
+    cov = []
+    y0 = wh.ymean.copy()
+    pm0 = wh.prior_mean.copy() if wh.has_prior else None
+    perm = getattr(wh, 'perm', None)
+    prec = None
+    if wh.has_prior:
+        prec = getattr(wh, 'prior_prec_dev', None)
+        prec = wh.prior_prec if prec is None else prec
+    try:
+        for k in range(n):
+            yk = np.asarray(ymeans[k], float)
+            wh.ymean = yk if perm is None else yk[perm]
+            pr.set_ymean(yk)
+            prior_k = None
+            if wh.has_prior:
+                wh.prior_mean = np.asarray(prior_means[k], float)
+                pr.set_prior(wh.prior_mean, prec)
+                prior_k = (wh.prior_mean, None)
+            f = nonlinear_fit(data=(fit.problem_x, yk, None), model=fit.model, prior=prior_k, p0=np.asarray(p0, float).reshape(n, -1)[k]
+                              if np.ndim(p0) == 2 else p0, problem=pr, tol=tol, maxit=maxit, fitter=fit.fitter,
+                              linear=getattr(fit, 'linear', None) or None, **getattr(fit, 'fitterargs', {}))
+            for key in keys:
+                out[key].append(getattr(f, key))
+            cov.append(f.cov)
+    finally:
+        wh.ymean = y0
+        pr.set_ymean(y0 if perm is None else _data_order(wh, y0))
+        if wh.has_prior:
+            wh.prior_mean = pm0
+            pr.set_prior(pm0, prec)
+    res = ResampledFits({k: np.array(v) for k, v in out.items()})
+    if covariance:
+        res['cov'] = np.array(cov)
+    res['dof'] = np.full(n, fit.dof)
+    res['engine'] = 'sequential (%s)' % fit.fitter
+    res['ymeans'] = ymeans
+    res['prior_means'] = prior_means
+    res['rounds'] = n
+    return res
+
+
 def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
     """Refit ``fit``'s problem for every row of ``ymeans`` (and ``prior_means``)."""
+    if not _batchable(fit):
+        return _sequential_copies(fit, ymeans, prior_means, p0, tol, maxit, covariance)
     wh = fit.whitening
     n, P = ymeans.shape[0], fit.pmean.size
     tol = fit.tol if tol is None else tol
@@ -118,7 +181,8 @@ def _joint_copies(fit, zmeans, p0, tol=None, maxit=None):
             pr.set_ymean(zmeans[k])
             prior_k = zmeans[k][back[N:]]
             f = nonlinear_fit(data=(fit.problem_x, zmeans[k][back[:N]], None), model=fit.model,
-                              prior=(prior_k, wh.prior_cov_host), p0=p0, problem=pr, tol=tol, maxit=maxit)
+                              prior=(prior_k, wh.prior_cov_host), p0=p0, problem=pr, tol=tol, maxit=maxit,
+                              fitter=fit.fitter, **getattr(fit, 'fitterargs', {}))      # (src/lsqfit/__init__.py:1457-1459,:1603-1604)
             for key in keys:
                 out[key].append(getattr(f, key))
             cov.append(f.cov)
@@ -149,9 +213,12 @@ def simulated_fits(fit, n, pexact=None, add_priornoise=False, seed=0, **kw):
     wh = fit.whitening
     if getattr(wh, 'joint', False):
         f = fit.problem.fcn(pexact)                  # joint row order; rows that are parameters hold p_j
-        if add_priornoise:
+        if add_priornoise or getattr(wh, 'rows_only', False):
             centre = np.where(wh.row_param >= 0, wh.ymean, f)       # data rows: fcn(pexact); prior rows: the prior means
-            res = _joint_copies(fit, _joint_draws(fit, n, seed, centre), pexact, **kw)
+            zm = _joint_draws(fit, n, seed, centre)
+            if not add_priornoise:       # (rows_only: data and prior are uncorrelated, so leaving the prior rows where they are IS a draw of y alone)
+                zm[:, wh.row_param >= 0] = centre[wh.row_param >= 0]
+            res = _joint_copies(fit, zm, pexact, **kw)
         else:
             # the copies' data are new, independent of the prior: an ordinary fit of (y + noise_y, prior) without cross terms
             from .fit import nonlinear_fit

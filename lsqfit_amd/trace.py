@@ -1,0 +1,972 @@
+"""Trace a Python fit function into the device tape.
+
+The reference hands its plugins ``f``, built from the user's ``fcn(x, p)`` / ``fcn(p)`` with array- or dict-valued
+parameters and outputs (``_unpack_fcn``, ``flatfcn_aa/ad/da/dd``, src/lsqfit/__init__.py:1997-2042) and differentiates
+it by CALLING it on overloaded numbers (``gvar.valder``, src/lsqfit/_gsl.pyx:742-760).  A GPU cannot call Python, but
+the same trick records what the function does: :func:`trace` calls ``fcn`` ONCE on tracer arrays (:class:`TArr`:
+operator overloads, ``__array_ufunc__`` / ``__array_function__`` for numpy's functions, indexing, broadcasting against
+``x`` and any constants the function closes over), turns the recorded expression graph into one RPN program per
+contiguous range of output rows (the opcodes of :mod:`lsqfit_amd.models`; arrays of constants the function uses
+row by row become predictor columns) and hands that to the formula compiler the string front end
+(:func:`lsqfit_amd.expr`, :func:`lsqfit_amd.piecewise`) already feeds.
+
+A function whose control flow depends on parameter values (``if p[0] > 0``, ``np.where(p > 0, ...)``, ``math.exp(p[0])``)
+cannot be recorded by one call and is refused with :class:`TraceError`.
+"""
+import numpy as np
+
+from .models import MODEL_TAPE, OP, TAPE_MAX_PARAM, TAPE_MAX_STACK, Model
+
+
+class TraceError(TypeError):
+    pass
+
+
+_UNARY = dict(exp='EXP', log='LOG', sin='SIN', cos='COS', tan='TAN', arctan='ATAN', sqrt='SQRT', sinh='SINH', cosh='COSH',
+              tanh='TANH', arcsin='ASIN', arccos='ACOS', absolute='ABS', fabs='ABS', negative='NEG')
+_BINARY = dict(add='ADD', subtract='SUB', multiply='MUL', true_divide='DIV', divide='DIV', power='POW', float_power='POW')
+_NP_UN = dict(EXP=np.exp, LOG=np.log, SIN=np.sin, COS=np.cos, TAN=np.tan, ATAN=np.arctan, SQRT=np.sqrt, SINH=np.sinh,
+              COSH=np.cosh, TANH=np.tanh, ASIN=np.arcsin, ACOS=np.arccos, ABS=np.abs, NEG=np.negative)
+_NP_BIN = dict(ADD=np.add, SUB=np.subtract, MUL=np.multiply, DIV=np.true_divide, POW=np.power)
+_COMPARE = {'greater', 'greater_equal', 'less', 'less_equal', 'equal', 'not_equal', 'logical_and', 'logical_or', 'logical_not',
+            'maximum', 'minimum', 'fmax', 'fmin', 'sign', 'heaviside', 'isnan', 'isfinite', 'isinf', 'floor', 'ceil', 'rint'}
+MAX_PROGRAMS = 512
+_FOLD = [True]          # arithmetic between ARRAYS of constants is done by numpy during the recording (see trace(fold=))
+
+
+def _foldable(*nodes):
+    return _FOLD[0] or all(n.shape == () for n in nodes)
+
+
+def _control_flow(what):
+    return TraceError('cannot trace %s of a parameter-dependent value: the fit function\'s control flow or a non-smooth '
+                      'selection depends on the parameters, which one recording call cannot capture (write the model '
+                      'with arithmetic and the functions exp log sqrt sin cos tan arctan sinh cosh tanh arcsin arccos abs)'
+                      % what)
+
+
+class TArr(object):
+    """A traced array: shape + how its elements follow from parameters and constants."""
+    __array_priority__ = 1.0e6
+    __slots__ = ('op', 'args', 'shape', 'aux')
+
+    def __init__(self, op, args, shape, aux=None):
+        self.op, self.args, self.shape, self.aux = op, args, tuple(int(s) for s in shape), aux
+
+    # -- shape protocol ---------------------------------------------------------------------
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    dtype = np.dtype(object)
+
+    def __len__(self):
+        if not self.shape:
+            raise TypeError('len() of a 0-d traced value')
+        return self.shape[0]
+
+    def __iter__(self):
+        if not self.shape:
+            raise TypeError('iteration over a 0-d traced value')
+        for i in range(self.shape[0]):
+            yield self[i]
+
+    def __repr__(self):
+        return 'TArr(%s, shape=%s)' % (self.op, self.shape)
+
+    # -- refusals ----------------------------------------------------------------------------
+    def __bool__(self):
+        raise _control_flow('the truth value')
+
+    def __float__(self):
+        raise _control_flow('float()')
+
+    __int__ = __index__ = __float__
+
+    def _cmp(self, other):
+        raise _control_flow('a comparison')
+
+    __lt__ = __le__ = __gt__ = __ge__ = _cmp
+    __hash__ = object.__hash__
+
+    def __eq__(self, other):
+        raise _control_flow('a comparison')
+
+    def __ne__(self, other):
+        raise _control_flow('a comparison')
+
+    def __setitem__(self, key, value):
+        raise TraceError('item assignment into a traced array is not supported: build the output with numpy.concatenate / '
+                         'numpy.stack, a list, or a dictionary')
+
+    # -- arithmetic ---------------------------------------------------------------------------
+    def __add__(self, o):
+        return _binary('ADD', self, o)
+
+    def __radd__(self, o):
+        return _binary('ADD', o, self)
+
+    def __sub__(self, o):
+        return _binary('SUB', self, o)
+
+    def __rsub__(self, o):
+        return _binary('SUB', o, self)
+
+    def __mul__(self, o):
+        return _binary('MUL', self, o)
+
+    def __rmul__(self, o):
+        return _binary('MUL', o, self)
+
+    def __truediv__(self, o):
+        return _binary('DIV', self, o)
+
+    def __rtruediv__(self, o):
+        return _binary('DIV', o, self)
+
+    def __pow__(self, o):
+        return _binary('POW', self, o)
+
+    def __rpow__(self, o):
+        return _binary('POW', o, self)
+
+    def __neg__(self):
+        return _unary('NEG', self)
+
+    def __pos__(self):
+        return self
+
+    def __abs__(self):
+        return _unary('ABS', self)
+
+    def __matmul__(self, o):
+        return _matmul(self, o)
+
+    def __rmatmul__(self, o):
+        return _matmul(o, self)
+
+    # the methods numpy's object loops and gvar-style code call
+    def exp(self):
+        return _unary('EXP', self)
+
+    def log(self):
+        return _unary('LOG', self)
+
+    def sqrt(self):
+        return _unary('SQRT', self)
+
+    def sin(self):
+        return _unary('SIN', self)
+
+    def cos(self):
+        return _unary('COS', self)
+
+    def tan(self):
+        return _unary('TAN', self)
+
+    def arctan(self):
+        return _unary('ATAN', self)
+
+    def sinh(self):
+        return _unary('SINH', self)
+
+    def cosh(self):
+        return _unary('COSH', self)
+
+    def tanh(self):
+        return _unary('TANH', self)
+
+    def arcsin(self):
+        return _unary('ASIN', self)
+
+    def arccos(self):
+        return _unary('ACOS', self)
+
+    # -- indexing and shape changes: all of them are gathers through an index map ---------------
+    def _index_map(self):
+        return np.arange(self.size, dtype=np.int64).reshape(self.shape)
+
+    def __getitem__(self, key):
+        for k in (key if isinstance(key, tuple) else (key,)):
+            if isinstance(k, TArr):
+                raise _control_flow('an index')
+        return _gather(self, self._index_map()[key])
+
+    def reshape(self, *shape, **kw):
+        if len(shape) == 1 and not isinstance(shape[0], (int, np.integer)):
+            shape = tuple(shape[0])
+        return _gather(self, self._index_map().reshape(shape))
+
+    def ravel(self, order='C'):
+        return _gather(self, self._index_map().ravel())
+
+    flatten = ravel
+
+    @property
+    def flat(self):
+        return self.ravel()
+
+    def transpose(self, *axes):
+        if len(axes) == 1 and not isinstance(axes[0], (int, np.integer)):
+            axes = axes[0]
+        return _gather(self, self._index_map().transpose(*axes) if axes and axes[0] is not None else self._index_map().T)
+
+    @property
+    def T(self):
+        return _gather(self, self._index_map().T)
+
+    def squeeze(self, axis=None):
+        return _gather(self, self._index_map().squeeze(axis))
+
+    def sum(self, axis=None, dtype=None, out=None, keepdims=False, **kw):
+        return _sum(self, axis, keepdims)
+
+    def mean(self, axis=None, dtype=None, out=None, keepdims=False, **kw):
+        s = _sum(self, axis, keepdims)
+        return s / (self.size / max(s.size, 1))
+
+    def dot(self, o):
+        return _dot(self, o)
+
+    def cumsum(self, axis=None):
+        return _cumsum(self, axis)
+
+    # -- numpy protocols ----------------------------------------------------------------------
+    def __array_ufunc__(self, ufunc, method, *inputs, **kw):
+        if kw.get('out') is not None:
+            raise TraceError('out= is not supported while tracing')
+        name = ufunc.__name__
+        if method == '__call__':
+            if name in _UNARY:
+                return _unary(_UNARY[name], inputs[0])
+            if name in _BINARY:
+                return _binary(_BINARY[name], inputs[0], inputs[1])
+            if name == 'positive':
+                return _lift(inputs[0])
+            if name == 'square':
+                return _binary('POW', inputs[0], 2.0)
+            if name == 'reciprocal':
+                return _binary('DIV', 1.0, inputs[0])
+            if name == 'exp2':
+                return _unary('EXP', _binary('MUL', inputs[0], float(np.log(2.0))))
+            if name == 'expm1':
+                return _binary('SUB', _unary('EXP', inputs[0]), 1.0)
+            if name == 'log1p':
+                return _unary('LOG', _binary('ADD', 1.0, inputs[0]))
+            if name == 'log10':
+                return _binary('DIV', _unary('LOG', inputs[0]), float(np.log(10.0)))
+            if name == 'log2':
+                return _binary('DIV', _unary('LOG', inputs[0]), float(np.log(2.0)))
+            if name == 'matmul':
+                return _matmul(inputs[0], inputs[1])
+            if name in _COMPARE:
+                raise _control_flow('numpy.' + name)
+        elif method == 'reduce' and name == 'add':
+            return _sum(inputs[0], kw.get('axis', 0), kw.get('keepdims', False))
+        raise TraceError('numpy.%s%s has no counterpart on the device tape' % (name, '' if method == '__call__' else '.' + method))
+
+    def __array_function__(self, func, types, args, kwargs):
+        h = _FUNCTIONS.get(func)
+        if h is None:
+            raise TraceError('numpy.%s is not supported while tracing a fit function' % getattr(func, '__name__', str(func)))
+        return h(*args, **kwargs)
+
+
+# ---- construction --------------------------------------------------------------------------------------------------
+def _data(a):
+    a = np.asarray(a, np.float64)
+    return TArr('data', (), a.shape, a)
+
+
+def _from_objects(o):
+    """object ndarray (or nested list) whose elements are numbers and 0-d traced values -> one traced array"""
+    o = np.asarray(o, dtype=object) if not isinstance(o, np.ndarray) else o
+    flat = o.ravel()
+    n = flat.size
+    nums = np.zeros(n)
+    which = np.zeros(n, np.int64)
+    pos = np.arange(n, dtype=np.int64)
+    kids = [None]
+    for i in range(n):
+        e = flat[i]
+        if isinstance(e, TArr):
+            if e.shape != ():
+                if e.size != 1:
+                    raise TraceError('ragged traced output: element %d has shape %s' % (i, e.shape))
+                e = e.reshape(())
+            which[i] = len(kids)
+            pos[i] = 0
+            kids.append(e)
+        else:
+            nums[i] = float(e)
+    kids[0] = _data(nums)
+    if len(kids) == 1:
+        return TArr('data', (), o.shape, nums.reshape(o.shape))
+    return TArr('cat', tuple(kids), o.shape, (which.reshape(o.shape), pos.reshape(o.shape)))
+
+
+def _lift(v):
+    if isinstance(v, TArr):
+        return v
+    if isinstance(v, memoryview):
+        v = np.asarray(v)
+    if isinstance(v, (list, tuple)):
+        v = np.array(v, dtype=object) if _has_tracer(v) else np.asarray(v, np.float64)
+    if isinstance(v, np.ndarray) and v.dtype == object:
+        return _from_objects(v)
+    try:
+        return _data(v)
+    except (TypeError, ValueError):
+        raise TraceError('cannot use a %s inside a traced fit function' % type(v).__name__)
+
+
+def _has_tracer(v):
+    if isinstance(v, TArr):
+        return True
+    if isinstance(v, (list, tuple)):
+        return any(_has_tracer(e) for e in v)
+    if isinstance(v, np.ndarray) and v.dtype == object:
+        return any(isinstance(e, TArr) for e in v.ravel())
+    return False
+
+
+def _gather(a, idx):
+    idx = np.asarray(idx, np.int64)
+    if a.op == 'data':
+        return TArr('data', (), idx.shape, a.aux.ravel()[idx])
+    if a.op == 'param':
+        return TArr('param', (), idx.shape, a.aux.ravel()[idx])
+    if a.op == 'gather':            # compose
+        return TArr('gather', a.args, idx.shape, a.aux.ravel()[idx])
+    return TArr('gather', (a,), idx.shape, idx)
+
+
+def _unary(op, a):
+    a = _lift(a)
+    if a.op == 'data' and _foldable(a):
+        with np.errstate(all='ignore'):
+            return _data(_NP_UN[op](a.aux))
+    return TArr('un', (a,), a.shape, op)
+
+
+def _binary(op, a, b):
+    a, b = _lift(a), _lift(b)
+    if a.op == 'data' and b.op == 'data' and _foldable(a, b):
+        with np.errstate(all='ignore'):
+            return _data(_NP_BIN[op](a.aux, b.aux))
+    shape = np.broadcast_shapes(a.shape, b.shape)
+    # ``sum(generator)`` starts from the integer 0
+    if op == 'ADD' and a.op == 'data' and a.shape == () and a.aux == 0.0 and b.shape == shape:
+        return b
+    return TArr('bin', (a, b), shape, op)
+
+
+def _sum(a, axis=None, keepdims=False):
+    a = _lift(a)
+    if isinstance(axis, tuple):
+        for ax in sorted((x % a.ndim for x in axis), reverse=True):
+            a = _sum(a, ax, keepdims)
+        return a
+    if a.op == 'data':
+        return _data(a.aux.sum(axis=axis, keepdims=keepdims))
+    idx = a._index_map()
+    if axis is None:
+        mat = idx.reshape(-1)
+        shape = (1,) * a.ndim if keepdims else ()
+        mat = mat.reshape((mat.size,) + shape)
+    else:
+        mat = np.moveaxis(idx, axis, 0)
+        if keepdims:
+            mat = np.expand_dims(mat, (axis % a.ndim) + 1)
+        shape = mat.shape[1:]
+    if mat.shape[0] == 0:
+        return _data(np.zeros(shape))
+    if mat.shape[0] == 1:
+        return _gather(a, mat[0])
+    return TArr('nsum', (a,), shape, mat)
+
+
+def _cumsum(a, axis=None):
+    a = _lift(a)
+    if axis is None:
+        a, axis = a.ravel(), 0
+    parts = [_sum(a[(slice(None),) * (axis % a.ndim) + (slice(0, k + 1),)], axis, True) for k in range(a.shape[axis])]
+    return _concatenate(parts, axis)
+
+
+def _concatenate(arrays, axis=0, **kw):
+    kids = [_lift(a) for a in arrays]
+    if axis is None:
+        kids, axis = [k.ravel() for k in kids], 0
+    if all(k.op == 'data' for k in kids):
+        return _data(np.concatenate([k.aux for k in kids], axis))
+    which = np.concatenate([np.full(k.shape, i, np.int64) for i, k in enumerate(kids)], axis)
+    pos = np.concatenate([k._index_map() for k in kids], axis)
+    return TArr('cat', tuple(kids), which.shape, (which, pos))
+
+
+def _stack(arrays, axis=0, **kw):
+    kids = [_lift(a) for a in arrays]
+    shape = np.broadcast_shapes(*[k.shape for k in kids])
+    kids = [_broadcast_to(k, shape) for k in kids]
+    ax = axis % (len(shape) + 1)
+    return _concatenate([_gather(k, np.expand_dims(k._index_map(), ax)) for k in kids], ax)
+
+
+def _broadcast_to(a, shape, **kw):
+    a = _lift(a)
+    return _gather(a, np.broadcast_to(a._index_map(), shape))
+
+
+def _matmul(a, b):
+    a, b = _lift(a), _lift(b)
+    if a.ndim == 0 or b.ndim == 0:
+        raise TraceError('matmul of a 0-d value')
+    a2 = a if a.ndim > 1 else a.reshape((1,) + a.shape)
+    b2 = b if b.ndim > 1 else b.reshape(b.shape + (1,))
+    ia = np.expand_dims(a2._index_map(), -1)            # (..., m, k, 1)
+    ib = np.expand_dims(b2._index_map(), -3)            # (..., 1, k, n)
+    out = _sum(_binary('MUL', _gather(a2, ia), _gather(b2, ib)), -2)
+    if a.ndim == 1:
+        out = out.squeeze(-2)
+    if b.ndim == 1:
+        out = out.squeeze(-1)
+    return out
+
+
+def _dot(a, b, **kw):
+    a, b = _lift(a), _lift(b)
+    if a.ndim == 0 or b.ndim == 0:
+        return _binary('MUL', a, b)
+    if b.ndim <= 2:
+        return _matmul(a, b)
+    raise TraceError('numpy.dot with more than two dimensions on the right')
+
+
+def _outer(a, b, **kw):
+    a, b = _lift(a).ravel(), _lift(b).ravel()
+    return _binary('MUL', a.reshape((a.size, 1)), b.reshape((1, b.size)))
+
+
+def _where(*a, **kw):
+    raise _control_flow('numpy.where')
+
+
+_FUNCTIONS = {
+    np.sum: lambda a, axis=None, dtype=None, out=None, keepdims=False, **kw: _sum(a, axis, keepdims),
+    np.mean: lambda a, axis=None, dtype=None, out=None, keepdims=False, **kw: _lift(a).mean(axis, keepdims=keepdims),
+    np.cumsum: lambda a, axis=None, **kw: _cumsum(a, axis),
+    np.concatenate: _concatenate,
+    np.stack: _stack,
+    np.hstack: lambda t, **kw: _concatenate([np.atleast_1d(x) if not isinstance(x, TArr) else (x if x.ndim else x.reshape(1)) for x in t],
+                                            0 if _lift(t[0]).ndim <= 1 else 1),
+    np.vstack: lambda t, **kw: _concatenate([(lambda k: k if k.ndim >= 2 else k.reshape((1, k.size)))(_lift(x)) for x in t], 0),
+    np.reshape: lambda a, *s, **kw: _lift(a).reshape(*(s or (kw.get('newshape', kw.get('shape')),))),
+    np.transpose: lambda a, axes=None: _lift(a).transpose(axes),
+    np.ravel: lambda a, order='C': _lift(a).ravel(),
+    np.squeeze: lambda a, axis=None: _lift(a).squeeze(axis),
+    np.expand_dims: lambda a, axis: _gather(_lift(a), np.expand_dims(_lift(a)._index_map(), axis)),
+    np.broadcast_to: _broadcast_to,
+    np.atleast_1d: lambda a: _lift(a) if _lift(a).ndim else _lift(a).reshape(1),
+    np.outer: _outer,
+    np.dot: _dot,
+    np.matmul: lambda a, b, **kw: _matmul(a, b),
+    np.shape: lambda a: _lift(a).shape,
+    np.size: lambda a, axis=None: _lift(a).size if axis is None else _lift(a).shape[axis],
+    np.ndim: lambda a: _lift(a).ndim,
+    np.where: _where,
+    np.absolute: lambda a: _unary('ABS', a),
+    np.take: lambda a, indices, axis=None, **kw: _gather(_lift(a), np.take(_lift(a)._index_map(), indices, axis)),
+    np.flip: lambda a, axis=None: _gather(_lift(a), np.flip(_lift(a)._index_map(), axis)),
+    np.moveaxis: lambda a, s, d: _gather(_lift(a), np.moveaxis(_lift(a)._index_map(), s, d)),
+    np.swapaxes: lambda a, s, d: _gather(_lift(a), np.swapaxes(_lift(a)._index_map(), s, d)),
+    np.diff: lambda a, n=1, axis=-1, **kw: _diff(a, axis),
+}
+
+
+def _diff(a, axis=-1):
+    a = _lift(a)
+    idx = a._index_map()
+    hi = np.take(idx, np.arange(1, a.shape[axis]), axis)
+    lo = np.take(idx, np.arange(0, a.shape[axis] - 1), axis)
+    return _binary('SUB', _gather(a, hi), _gather(a, lo))
+
+
+# ---- resolution: the expression of every output row --------------------------------------------------------------------
+# Trees: ('P', int[n]) | ('D', float[n]) | ('U', OP, t) | ('B', OP, l, r) | ('S', [t...]) | ('C', [rows...], [t...])
+# leaves carry one entry per row of the set they were resolved for.
+def _child_index(idx, shape, cshape):
+    """flat indices into an array of ``shape`` -> flat indices into a child of ``cshape`` that broadcasts to it"""
+    if cshape == shape:
+        return idx
+    if int(np.prod(cshape, dtype=np.int64)) == 1:
+        return np.zeros_like(idx)
+    multi = np.unravel_index(idx, shape)
+    multi = multi[len(shape) - len(cshape):]
+    multi = tuple(m if s != 1 else np.zeros_like(m) for m, s in zip(multi, cshape))
+    return np.ravel_multi_index(multi, cshape)
+
+
+def _resolve(node, idx, memo):
+    key = (id(node), idx.ctypes.data, idx.size)
+    hit = memo.get(key)
+    if hit is not None and hit[0] is idx:
+        return hit[1]
+    op = node.op
+    if op == 'param':
+        t = ('P', node.aux.ravel()[idx])
+    elif op == 'data':
+        t = ('D', node.aux.ravel()[idx])
+    elif op == 'gather':
+        t = _resolve(node.args[0], node.aux.ravel()[idx], memo)
+    elif op == 'un':
+        k = _resolve(node.args[0], idx, memo)
+        if k[0] == 'D' and _FOLD[0]:
+            with np.errstate(all='ignore'):
+                t = ('D', _NP_UN[node.aux](k[1]))
+        else:
+            t = ('U', node.aux, k)
+    elif op == 'bin':
+        a, b = node.args
+        l = _resolve(a, _child_index(idx, node.shape, a.shape), memo)
+        r = _resolve(b, _child_index(idx, node.shape, b.shape), memo)
+        if l[0] == 'D' and r[0] == 'D' and _FOLD[0]:
+            with np.errstate(all='ignore'):
+                t = ('D', _NP_BIN[node.aux](l[1], r[1]))
+        else:
+            t = ('B', node.aux, l, r)
+    elif op == 'nsum':
+        mat = node.aux.reshape(node.aux.shape[0], -1)
+        t = ('S', [_resolve(node.args[0], np.ascontiguousarray(mat[k][idx]), memo) for k in range(mat.shape[0])])
+    elif op == 'cat':
+        which, pos = node.aux[0].ravel()[idx], node.aux[1].ravel()[idx]
+        kids = np.unique(which)
+        if kids.size == 1:
+            t = _resolve(node.args[int(kids[0])], np.ascontiguousarray(pos), memo)
+        else:
+            rows, trees = [], []
+            for c in kids:
+                sel = np.nonzero(which == c)[0]
+                rows.append(sel)
+                trees.append(_resolve(node.args[int(c)], np.ascontiguousarray(pos[sel]), memo))
+            t = ('C', rows, trees)
+    else:
+        raise TraceError('internal: unknown node ' + op)
+    memo[key] = (idx, t)
+    return t
+
+
+def _restrict(t, sub):
+    k = t[0]
+    if k == 'P' or k == 'D':
+        return (k, t[1][sub])
+    if k == 'U':
+        return ('U', t[1], _restrict(t[2], sub))
+    if k == 'B':
+        return ('B', t[1], _restrict(t[2], sub), _restrict(t[3], sub))
+    if k == 'S':
+        return ('S', [_restrict(x, sub) for x in t[1]])
+    raise TraceError('internal: restrict on ' + k)
+
+
+def _combine(parts, n, build):
+    """parts: per operand a list of (rows | None, tree); -> list of (rows | None, build(trees))"""
+    if all(len(p) == 1 and p[0][0] is None for p in parts):
+        return [(None, build([p[0][1] for p in parts]))]
+    label = np.zeros(n, np.int64)
+    full = []
+    for p in parts:
+        lab = np.zeros(n, np.int64)
+        norm = []
+        for i, (rows, tree) in enumerate(p):
+            rows = np.arange(n) if rows is None else rows
+            lab[rows] = i
+            norm.append((rows, tree))
+        full.append(norm)
+        label = label * len(p) + lab
+    out = []
+    for v in np.unique(label):
+        rows = np.nonzero(label == v)[0]
+        trees = []
+        digits = int(v)
+        picks = []
+        for p in reversed(full):
+            picks.append(digits % len(p))
+            digits //= len(p)
+        for p, i in zip(full, reversed(picks)):
+            prow, tree = p[i]
+            trees.append(_restrict(tree, np.searchsorted(prow, rows)))
+        out.append((rows, build(trees)))
+    return out
+
+
+def _pieces(t, n):
+    """split a resolved tree at its 'C' nodes: -> [(rows | None (all n), tree without 'C')]; rows ascending"""
+    k = t[0]
+    if k == 'P' or k == 'D':
+        return [(None, t)]
+    if k == 'U':
+        return [(rows, ('U', t[1], s)) for rows, s in _pieces(t[2], n)]
+    if k == 'B':
+        return _combine([_pieces(t[2], n), _pieces(t[3], n)], n, lambda ts: ('B', t[1], ts[0], ts[1]))
+    if k == 'S':
+        return _combine([_pieces(x, n) for x in t[1]], n, lambda ts: ('S', list(ts)))
+    out = []
+    for sel, sub in zip(t[1], t[2]):
+        for rows, s in _pieces(sub, sel.size):
+            out.append((sel if rows is None else sel[rows], s))
+    return out
+
+
+def _leaves(t, out):
+    k = t[0]
+    if k == 'P' or k == 'D':
+        out.append(t)
+    elif k == 'U':
+        _leaves(t[2], out)
+    elif k == 'B':
+        _leaves(t[2], out)
+        _leaves(t[3], out)
+    else:
+        for x in t[1]:
+            _leaves(x, out)
+    return out
+
+
+def _signature(t):
+    k = t[0]
+    if k == 'P':
+        return ('P', int(t[1][0]))
+    if k == 'D':
+        return 'D'
+    if k == 'U':
+        return ('U', t[1], _signature(t[2]))
+    if k == 'B':
+        return ('B', t[1], _signature(t[2]), _signature(t[3]))
+    return ('S',) + tuple(_signature(x) for x in t[1])
+
+
+def _rebuild(t, it):
+    k = t[0]
+    if k == 'P' or k == 'D':
+        return (k, next(it))
+    if k == 'U':
+        return ('U', t[1], _rebuild(t[2], it))
+    if k == 'B':
+        l = _rebuild(t[2], it)
+        return ('B', t[1], l, _rebuild(t[3], it))
+    return ('S', [_rebuild(x, it) for x in t[1]])
+
+
+class _Emitter(object):
+    def __init__(self, consts):
+        self.consts = consts
+        self.cidx = {v: i for i, v in enumerate(consts)}
+        self.code = []
+        self.cols, self.colkey = [], {}
+        self.depth = self.maxdepth = 0
+
+    def put(self, op, arg=0, push=0):
+        self.code.append((OP[op] & 0xff) | (int(arg) << 8))
+        self.depth += push
+        self.maxdepth = max(self.maxdepth, self.depth)
+
+    def const(self, v):
+        v = float(v)
+        key = v if v == v else 'nan'
+        if key not in self.cidx:
+            self.cidx[key] = len(self.consts)
+            self.consts.append(v)
+        self.put('CONST', self.cidx[key], +1)
+
+    def column(self, a):
+        key = a.tobytes()
+        if key not in self.colkey:
+            self.colkey[key] = len(self.cols)
+            self.cols.append(a)
+        self.put('X', self.colkey[key], +1)
+
+    def emit(self, t, reorder):
+        k = t[0]
+        if k == 'P':
+            self.put('P', int(t[1][0]), +1)
+        elif k == 'D':
+            a = t[1]
+            if a.size == 0 or np.all(a == a[0]) or (a[0] != a[0] and np.all(a != a)):
+                self.const(a[0] if a.size else 0.0)
+            else:
+                self.column(np.ascontiguousarray(a, np.float64))
+        elif k == 'U':
+            self.emit(t[2], reorder)
+            self.put(t[1])
+        elif k == 'B':
+            op, l, r = t[1], t[2], t[3]
+            if op == 'POW' and r[0] == 'D' and r[1].size and np.all(r[1] == r[1][0]):
+                e = float(r[1][0])
+                if e == int(e) and abs(e) < 2 ** 20:      # the string front end's rule (models._Compiler.visit_BinOp)
+                    self.emit(l, reorder)
+                    return self.put('POWI', int(e))
+            if reorder and op in ('ADD', 'MUL') and _need(r) > _need(l):
+                l, r = r, l
+            self.emit(l, reorder)
+            self.emit(r, reorder)
+            self.put(op, 0, -1)
+        else:
+            for i, x in enumerate(t[1]):
+                self.emit(x, reorder)
+                if i:
+                    self.put('ADD', 0, -1)
+
+
+def _need(t):
+    k = t[0]
+    if k == 'P' or k == 'D':
+        return 1
+    if k == 'U':
+        return _need(t[2])
+    if k == 'B':
+        a, b = _need(t[2]), _need(t[3])
+        return max(a, b + 1)
+    return 1 + max(_need(x) for x in t[1])
+
+
+class Traced(object):
+    """What :func:`trace` returns: ``model`` (a tape :class:`Model`, piecewise when rows differ in formula), ``x`` (the
+    predictor matrix the tape's X instructions index: N x n_x, built from the arrays the function used row by row),
+    ``n_rows``, ``n_param`` and the layouts (``pkeys`` / ``pshapes``, ``ykeys`` / ``yshapes``; keys are None for arrays)."""
+
+    def __init__(self, model, x, pkeys, pshapes, ykeys, yshapes):
+        self.model, self.x = model, x
+        self.n_rows, self.n_param = x.shape[0], model.n_param
+        self.pkeys, self.pshapes, self.ykeys, self.yshapes = pkeys, pshapes, ykeys, yshapes
+
+    def pack_params(self, p):
+        """array / dict of parameters -> flat vector in the traced order"""
+        if self.pkeys is None:
+            return np.asarray(p, float).reshape(-1)
+        return np.concatenate([np.asarray(p[k], float).reshape(-1) for k in self.pkeys])
+
+    def unpack_params(self, flat):
+        flat = np.asarray(flat)
+        if self.pkeys is None:
+            return flat.reshape(self.pshapes[0])
+        out, i = {}, 0
+        for k, s in zip(self.pkeys, self.pshapes):
+            n = int(np.prod(s, dtype=np.int64))
+            out[k] = flat[i:i + n].reshape(s)
+            i += n
+        return out
+
+
+def param_tracers(p0):
+    """-> (tracer(s) shaped like ``p0``, P, keys | None, shapes): the flattened order is the reference's -- arrays in C
+    order, dictionaries key by key in insertion order (``gvar.BufferDict``, src/lsqfit/__init__.py:1935-1993)"""
+    if hasattr(p0, 'keys'):
+        keys, shapes, out, i = list(p0.keys()), [], {}, 0
+        for k in keys:
+            s = np.shape(p0[k])
+            n = int(np.prod(s, dtype=np.int64))
+            out[k] = TArr('param', (), s, np.arange(i, i + n, dtype=np.int64).reshape(s))
+            shapes.append(s)
+            i += n
+        return out, i, keys, shapes
+    s = np.shape(p0)
+    n = int(np.prod(s, dtype=np.int64))
+    return TArr('param', (), s, np.arange(n, dtype=np.int64).reshape(s)), n, None, [s]
+
+
+def flatten_output(out, y=None):
+    """the function's return value -> (one 1-d traced array, ykeys | None, yshapes), flattened as ``flatfcn_*`` do
+    (src/lsqfit/__init__.py:2013-2042): arrays through ``.flat``, dictionaries key by key in the order of the DATA's keys"""
+    if hasattr(out, 'keys'):
+        keys = list(y.keys()) if (y is not None and hasattr(y, 'keys')) else list(out.keys())
+        parts, shapes = [], []
+        for k in keys:
+            if k not in out:
+                raise ValueError('the fit function returned no entry for data key %r' % (k,))
+            v = _lift(out[k])
+            if y is not None and hasattr(y, 'keys') and np.shape(y[k]) != v.shape:
+                raise ValueError('shape mismatch between data and fit function for key %r: %s vs %s' % (k, np.shape(y[k]), v.shape))
+            shapes.append(v.shape)
+            parts.append(v.ravel())
+        return _concatenate(parts, 0) if len(parts) > 1 else parts[0], keys, shapes
+    if y is not None and hasattr(y, 'keys'):
+        raise ValueError('the data are a dictionary but the fit function returned an array')
+    v = _lift(out)
+    if y is not None and np.shape(y) != v.shape and np.size(y) != v.size:
+        raise ValueError('shape mismatch between data and fit function: %s vs %s' % (np.shape(y), v.shape))
+    return v.ravel(), None, [v.shape]
+
+
+def programs_of(flat):
+    """one 1-d traced array -> ([(row0, row1, tree)], N): the resolved expression of every contiguous range of rows that
+    shares one formula (same operations, same parameters; constants may differ row by row)"""
+    N = flat.size
+    tree = _resolve(flat, np.arange(N, dtype=np.int64), {})
+    pieces = []
+    for rows, t in _pieces(tree, N):
+        rows = np.arange(N) if rows is None else rows
+        # rows that read different parameters through the same expression (p[index_array]) are different formulas
+        pl = [l[1] for l in _leaves(t, []) if l[0] == 'P']
+        if pl and any(a.size and np.any(a != a[0]) for a in pl):
+            mat = np.stack(pl, 1)
+            uniq, inv = np.unique(mat, axis=0, return_inverse=True)
+            inv = inv.reshape(-1)
+            for g in range(uniq.shape[0]):
+                sub = np.nonzero(inv == g)[0]
+                pieces.append((rows[sub], _restrict(t, sub)))
+        else:
+            pieces.append((rows, t))
+    # the same formula reached along different paths (an output assembled element by element) is one formula
+    merged, order = {}, []
+    for rows, t in pieces:
+        if rows.size == 0:
+            continue
+        sig = _signature(t)
+        if sig not in merged:
+            merged[sig] = []
+            order.append(sig)
+        merged[sig].append((rows, t))
+    groups = []
+    for sig in order:
+        lst = merged[sig]
+        if len(lst) == 1:
+            rows, t = lst[0]
+        else:
+            rows = np.concatenate([r for r, _ in lst])
+            leaf_lists = [_leaves(t, []) for _, t in lst]
+            arrays = [np.concatenate([ll[i][1] for ll in leaf_lists]) for i in range(len(leaf_lists[0]))]
+            t = _rebuild(lst[0][1], iter(arrays))
+        o = np.argsort(rows, kind='stable')
+        if np.any(o != np.arange(o.size)):
+            rows, t = rows[o], _restrict(t, o)
+        groups.append((rows, t))
+    gid = np.full(N, -1, np.int64)
+    for g, (rows, _) in enumerate(groups):
+        gid[rows] = g
+    if N and gid.min() < 0:
+        raise TraceError('internal: output rows without a formula')
+    out = []
+    r0 = 0
+    while r0 < N:
+        g = gid[r0]
+        r1 = r0 + 1
+        while r1 < N and gid[r1] == g:
+            r1 += 1
+        rows, t = groups[g]
+        a = int(np.searchsorted(rows, r0))
+        out.append((r0, r1, _restrict(t, np.arange(a, a + (r1 - r0)))))
+        if len(out) > MAX_PROGRAMS:
+            raise TraceError('the fit function uses more than %d different formulas over contiguous ranges of its output; '
+                             'order the output so that rows with the same formula are adjacent' % MAX_PROGRAMS)
+        r0 = r1
+    return out, N
+
+
+def emit_programs(progs, N, P, text='traced'):
+    """[(row0, row1, tree)] -> (Model, X[N, n_x])"""
+    if P > TAPE_MAX_PARAM:
+        raise ValueError('tape models support at most %d parameters' % TAPE_MAX_PARAM)
+    consts, codes, cols = [], [], []
+    for r0, r1, t in progs:
+        em = _Emitter(consts)
+        em.emit(t, False)
+        if em.maxdepth > TAPE_MAX_STACK:
+            em2 = _Emitter(consts)
+            em2.emit(t, True)
+            em = em2
+        if em.maxdepth > TAPE_MAX_STACK:
+            raise ValueError('expression needs a stack deeper than %d' % TAPE_MAX_STACK)
+        codes.append(np.asarray(em.code, np.int32))
+        cols.append(em.cols)
+    n_x = max([1] + [len(c) for c in cols])
+    X = np.zeros((N, n_x))
+    for (r0, r1, _), c in zip(progs, cols):
+        for j, a in enumerate(c):
+            X[r0:r1, j] = a
+    if len(consts) > 1024:
+        raise ValueError('a traced model may hold at most 1024 distinct constants (arrays of row data do not count); got %d' % len(consts))
+    if len(progs) == 1:
+        return Model(MODEL_TAPE, P, n_x, tape=codes[0], consts=consts, text=text), X
+    programs = [(r1 - r0, c) for (r0, r1, _), c in zip(progs, codes)]
+    return Model(MODEL_TAPE, P, n_x, tape=np.concatenate(codes), consts=consts,
+                 text='%s{%d formulas}' % (text, len(programs)), programs=programs), X
+
+
+def trace(fcn, x=False, p0=None, y=None, fold=True):
+    """Record ``fcn(x, p)`` (``fcn(p)`` when ``x is False``, the reference's convention, src/lsqfit/__init__.py:2013-2016)
+    for parameters shaped like ``p0`` (an array or a dictionary of arrays) -> :class:`Traced`.  ``y`` (optional: the data's
+    mean, array or dictionary) fixes the key order of a dictionary-valued function and is checked for shape.
+    ``fold``: arithmetic that involves no parameter (``x**2``, ``cos(2 * pi * x / 12)``) is done by numpy while the function is
+    recorded and reaches the device as one more predictor column; ``fold=False`` keeps it on the tape, operation by
+    operation, exactly as the formula string front end (:func:`lsqfit_amd.expr`) would write it."""
+    if p0 is None:
+        raise ValueError('trace needs p0 (or the prior mean): the shape of the parameters')
+    p, P, pkeys, pshapes = param_tracers(p0)
+    saved = _FOLD[0]
+    _FOLD[0] = bool(fold)
+    try:
+        if not fold and x is not False:      # (numpy would otherwise do x's arithmetic before the tracer sees any of it)
+            x = {k: _data(v) for k, v in x.items()} if hasattr(x, 'keys') else _data(x)
+        out = fcn(p) if x is False else fcn(x, p)
+        flat, ykeys, yshapes = flatten_output(out, y)
+        progs, N = programs_of(flat)
+    finally:
+        _FOLD[0] = saved
+    name = getattr(fcn, '__name__', 'fcn')
+    model, X = emit_programs(progs, N, P, text='traced:' + name)
+    return Traced(model, X, pkeys, pshapes, ykeys, yshapes)
+
+
+def trace_residual(f, P):
+    """Record a flat residual function ``f(p) -> r`` -- what lsqfit hands its plugins (``chiv``, src/lsqfit/_utilities.pyx:50-94,
+    called on an object array the way ``_c_df`` calls it on GVars, src/lsqfit/_gsl.pyx:748-750) -- with the parameters as an
+    object array of 0-d tracers (so that ``p.reshape(shape)``, ``numpy.concatenate((fcn(p), p))`` and assignment into object
+    arrays work as they do for GVars).  ``mixed=True`` asks ``chiv`` for its object-array branch (:71-73,:78-80)."""
+    tr = TArr('param', (), (P,), np.arange(P, dtype=np.int64))
+    p = np.empty(P, object)
+    for j in range(P):
+        p[j] = tr[j]
+    try:
+        out = f(p, mixed=True)
+    except TypeError as e:
+        if isinstance(e, TraceError) or 'mixed' not in str(e):
+            raise
+        out = f(p)
+    flat, _, _ = flatten_output(out, None)
+    progs, N = programs_of(flat)
+    model, X = emit_programs(progs, N, P, text='traced:residual')
+    return Traced(model, X, None, [(P,)], None, [(N,)])
+
+
+def flatten_mean_err(mean, err):
+    """(mean, err) as arrays or dictionaries of arrays -> (flat mean, error spec for :class:`lsqfit_amd.Whitening`).
+    Dictionary entries are flattened key by key in insertion order (``gvar.BufferDict``); an entry's error is a standard
+    deviation array shaped like its mean, or the covariance matrix (size x size) of its flattened values."""
+    if not hasattr(mean, 'keys'):
+        m = np.asarray(mean, float)
+        e = np.asarray(err, float) if err is not None and not isinstance(err, dict) else err
+        if isinstance(e, np.ndarray) and e.shape == m.shape and m.ndim > 1:
+            e = e.reshape(-1)
+        return m.reshape(-1), e
+    flat, sdev, blocks, r0 = [], [], [], 0
+    for k in mean.keys():
+        m = np.asarray(mean[k], float)
+        e = np.asarray(err[k], float)
+        n = m.size
+        if e.ndim == 2 and e.shape == (n, n) and (m.ndim != 2 or m.shape != e.shape):
+            sdev.append(np.sqrt(np.diag(e)))
+            if n > 1 and np.any(e - np.diag(np.diag(e)) != 0.0):
+                blocks.append((r0, e))
+        elif e.shape == m.shape or e.size == 1:
+            sdev.append(np.broadcast_to(e, m.shape).reshape(-1).astype(float))
+        else:
+            raise ValueError('error of entry %r has shape %s, its mean %s' % (k, e.shape, m.shape))
+        flat.append(m.reshape(-1))
+        r0 += n
+    flat, sdev = np.concatenate(flat), np.concatenate(sdev)
+    return flat, (dict(sdev=sdev, blocks=blocks) if blocks else sdev)

@@ -596,7 +596,9 @@ def rows_whitening(ymean, yerr, prior_mean, prior_err, svdcut=1e-12, udata=False
     psd, pblocks, pperm = _as_blocks(prior_err, P)
     if yperm is not None or pperm is not None:
         # interleaved covariance components: the joint construction permutes data and prior entries alike (dense, small fits)
-        wh = joint_whitening(ymean, yerr, pm, prior_err, np.zeros((N, P)), svdcut=svdcut, engine='eig')
+        # (udata: the correlations of y are dropped, src/lsqfit/__init__.py:1892-1893 -- ysd is back in the caller's order)
+        wh = joint_whitening(ymean, ysd if udata else yerr, pm, prior_err, np.zeros((N, P)), svdcut=svdcut, engine='eig')
+        wh.rows_only = True                           # prior entries travel as rows, but nothing correlates them with the data
         return wh
     z = np.concatenate([ymean, pm])
     wh = Whitening(z, dict(sdev=np.concatenate([ysd, psd]), blocks=yblocks + [(N + r0, c) for r0, c in pblocks]), svdcut=svdcut,
@@ -612,4 +614,6 @@ def rows_whitening(ymean, yerr, prior_mean, prior_err, svdcut=1e-12, udata=False
     for r0, c in pblocks:
         pc[r0:r0 + c.shape[0], r0:r0 + c.shape[0]] = c
     wh.prior_cov_host = pc
+    wh.data_cov_host = dict(sdev=ysd, blocks=yblocks)       # (resample.py: simulated copies without prior noise)
+    wh.rows_only = True
     return wh

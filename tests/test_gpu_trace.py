@@ -1,0 +1,145 @@
+"""-m gpu: fits whose fit function is a PYTHON callable, traced into the device tape (lsqfit_amd.trace) -- the reference's
+call form ``nonlinear_fit(data=(x, y), fcn=fcn, prior=prior)`` (src/lsqfit/__init__.py:1997-2042, _gsl.pyx:742-760) --
+against the formula-string front end (bit for bit), the reference's golden values and the oracle."""
+import numpy as np
+import pytest
+
+from oracle import fit as ofit
+from oracle.dual import Dual
+from tests import gpu_util as gu
+from tests.helpers import load, nist_problem
+from tests.nist_lambdas import MODELS
+
+pytestmark = pytest.mark.gpu
+NIST = load('nist.json')
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import lsqfit_amd
+    from lsqfit_amd import _lib
+    _lib.load()
+    return lsqfit_amd
+
+
+@pytest.mark.parametrize('name', sorted(NIST))
+def test_nist_numpy_function_fits_like_the_formula_string(amd, name):
+    pr = nist_problem(name, NIST)
+    cols = pr['columns'][1:]
+    x = pr['x'] if len(cols) > 1 else pr['x'][cols[0]]
+    kw = dict(prior=(pr['prior_mean'], pr['prior_sd']), p0=pr['p0'], tol=pr['tol'], solver='qr')
+    ref = amd.nonlinear_fit(data=(np.stack([pr['x'][c] for c in cols], axis=1), pr['y'], pr['ysd']),
+                            model=amd.expr(pr['expr'], ['b%d' % (i + 1) for i in range(pr['P'])], cols), **kw)
+    # operation for operation the string's tape (fold=False): the same compiled code, the same bits
+    tr = amd.trace(MODELS[name], x, pr['p0'], fold=False)
+    same = amd.nonlinear_fit(data=(tr.x, pr['y'], pr['ysd']), model=tr.model, **kw)
+    assert np.array_equal(same.pmean, ref.pmean) and np.array_equal(same.cov, ref.cov)
+    assert same.chi2 == ref.chi2 and same.nit == ref.nit and same.logGBF == ref.logGBF
+    # the call a user of the reference makes: fcn=, nothing else (parameter-free arithmetic folded into predictor columns)
+    fit = amd.nonlinear_fit(data=(x, pr['y'], pr['ysd']), fcn=MODELS[name], **kw)
+    assert np.all(np.abs(fit.pmean - pr['certified']) <= 1e-2 * pr['certified_sd'] + 1e-9 * np.abs(pr['certified']))
+    np.testing.assert_allclose(fit.psdev, pr['certified_sd'], rtol=2e-3)
+    assert np.all(np.abs(fit.pmean - ref.pmean) <= 1e-6 * np.abs(ref.pmean) + 1e-4 * ref.psdev)
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=2e-3 if name == 'lanczos1' else 1e-6)
+    assert fit.dof == pr['out']['dof'] and fit.stopping_criterion == 1
+
+
+def test_dictionary_parameter_multiexponential_matches_oracle(amd):
+    """p['a'], p['E'] on correlated data with a correlated prior block: the canonical lsqfit fit (examples/y-vs-x.py)"""
+    rng = np.random.default_rng(20265)
+    K, N = 3, 40
+    x = np.linspace(0.2, 4.0, N)
+    ptrue = dict(a=np.array([1.0, 0.6, 0.3]), E=np.array([0.5, 1.1, 1.9]))
+
+    def fcn(x, p):
+        return np.sum(p['a'][:, None] * np.exp(-p['E'][:, None] * x[None, :]), axis=0)
+
+    def flat_fcn(x, p):           # the oracle's view: flat parameters, Dual-capable
+        a, E = p[:K], p[K:]
+        if isinstance(p, Dual):
+            return sum(a[k] * (-(E[k] * x)).exp() for k in range(K))
+        return np.exp(-np.outer(x, E)) @ a
+
+    f0 = fcn(x, ptrue)
+    sd = 0.01 * np.abs(f0)
+    U = rng.uniform(0.1, 0.9, (N, 2 * N))
+    corr = U @ U.T
+    corr /= np.sqrt(np.outer(np.diag(corr), np.diag(corr)))
+    ycov = corr * np.outer(sd, sd)
+    y = f0 + np.linalg.cholesky(ycov) @ rng.standard_normal(N)
+    pa_cov = np.diag([0.5, 0.5, 0.5]) ** 2
+    pa_cov[0, 1] = pa_cov[1, 0] = 0.3 * 0.25
+    prior = (dict(a=np.array([1.0, 0.5, 0.5]), E=np.array([0.5, 1.0, 2.0])), dict(a=pa_cov, E=np.array([0.2, 0.3, 0.4])))
+    fit = amd.nonlinear_fit(data=(x, y, ycov), fcn=fcn, prior=prior, tol=1e-10)
+    pm = np.concatenate([prior[0]['a'], prior[0]['E']])
+    pcov = np.zeros((2 * K, 2 * K))
+    pcov[:K, :K] = pa_cov
+    pcov[K:, K:] = np.diag(prior[1]['E'] ** 2)
+    ref = ofit.nonlinear_fit(x, y, ycov, flat_fcn, prior_mean=pm, prior_err=pcov, tol=1e-10, solver='cholesky')
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert fit.chi2 / fit.dof == pytest.approx(ref.chi2 / ref.dof, rel=1e-6)
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    assert set(fit.p) == {'a', 'E'} and fit.p['E'].shape == (K,) and np.array_equal(fit.p['E'], fit.pmean[K:])
+
+
+def test_dictionary_data_and_output(amd):
+    """examples/simple.py's shape: y is a dictionary with a covariance for one entry, the function returns a dictionary"""
+    xa = np.array([1., 2., 3., 4.])
+    ptrue = np.array([0.25, 0.5])
+    ya = np.exp(ptrue[0] + xa * ptrue[1]) * np.array([1.01, 0.98, 1.02, 0.99])
+    cov_a = np.diag((0.05 * ya) ** 2)
+    cov_a[0, 1] = cov_a[1, 0] = 0.5 * 0.05 * ya[0] * 0.05 * ya[1]
+    y = dict(a=ya, b=np.array(2.05))
+    yerr = dict(a=cov_a, b=np.array(0.1))
+
+    def fcn(x, p):
+        return dict(a=np.exp(p[0] + x['a'] * p[1]), b=p[1] / p[0])
+
+    fit = amd.nonlinear_fit(data=(dict(a=xa), y, yerr), fcn=fcn, prior=(np.array([0.3, 0.4]), np.array([0.5, 0.5])), tol=1e-10)
+    full = np.zeros((5, 5))
+    full[:4, :4] = cov_a
+    full[4, 4] = 0.01
+
+    def flat_fcn(x, p):
+        if isinstance(p, Dual):
+            from oracle.dual import concatenate
+            return concatenate([(p[0] + p[1] * xa).exp(), (p[1] / p[0]).reshape(1)])
+        return np.concatenate([np.exp(p[0] + xa * p[1]), [p[1] / p[0]]])
+
+    ref = ofit.nonlinear_fit(None, np.concatenate([ya, [2.05]]), full, flat_fcn, prior_mean=np.array([0.3, 0.4]),
+                             prior_err=np.array([0.5, 0.5]), tol=1e-10, solver='cholesky')
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.chi2 == pytest.approx(ref.chi2, rel=1e-6) and fit.nblocks == ref.nblocks
+
+
+def test_control_flow_on_parameters_is_refused(amd):
+    x = np.linspace(0, 1, 6)
+    with pytest.raises(amd.TraceError, match='control flow'):
+        amd.nonlinear_fit(data=(x, x, 0.1 * np.ones(6)), fcn=lambda x, p: p[0] * x if p[0] > 0 else p[1], p0=np.ones(2))
+
+
+def test_plugin_called_the_way_lsqfit_calls_it(amd):
+    """``FITTERS[name](p0, nf, chiv, tol=, maxit=)`` (src/lsqfit/__init__.py:662-664) with NOTHING else: the plugin records the
+    residual function it is handed and fits on the device; same minimum, covariance and chi2 as the fit set up from parts"""
+    rng = np.random.default_rng(77)
+    x = np.linspace(0.2, 3.0, 30)
+    y = 1.4 * np.exp(-0.7 * x) + 0.3 + 0.01 * rng.standard_normal(30)
+    sd = np.full(30, 0.01)
+    pm, psd = np.array([1.0, 1.0, 0.0]), np.array([1.0, 1.0, 1.0])
+    mean = np.concatenate([y, pm])
+    w = 1.0 / np.concatenate([sd, psd])
+
+    def chiv(p, mixed=False):
+        delta = np.concatenate(((p[0] * np.exp(-p[1] * x) + p[2]).flat, p)) - mean
+        ans = np.zeros(33, object if mixed else float)
+        ans[:] = np.multiply(w, delta)
+        return ans
+
+    got = amd.mi355x_lm(pm.copy(), 33, chiv, tol=(1e-10, 1e-10, 1e-10), maxit=200)
+    ref = amd.nonlinear_fit(data=(x, y, sd), model=amd.expr('a*exp(-b*x)+c', ['a', 'b', 'c']), prior=(pm, psd), p0=pm, tol=1e-10)
+    assert gu.relmax(got.x, ref.pmean) < 1e-8 and gu.relmax(got.cov, ref.cov) < 1e-7
+    assert got.chi2 == pytest.approx(ref.chi2, rel=1e-8)
+    assert got.f.shape == (33,) and got.J.shape == (33, 3)
+    np.testing.assert_allclose(got.f, chiv(got.x), rtol=1e-9, atol=1e-12)
+    assert got.stopping_criterion in (1, 2) and got.error is None

@@ -1,0 +1,213 @@
+"""The tracer front end (lsqfit_amd.trace; CPU): a Python fit function called once on tracer arrays becomes the device
+tape.  Spec: the four flattening layouts of src/lsqfit/__init__.py:1997-2042 (array / dict parameters x array / dict
+outputs), the functions gvar overloads, and loud refusal of what one recording cannot capture."""
+import numpy as np
+import pytest
+
+import lsqfit_amd as amd
+from lsqfit_amd import trace as T
+from lsqfit_amd.models import OP
+from oracle.dual import Dual
+from tests.helpers import load, nist_problem
+from tests.nist_lambdas import MODELS
+
+NIST = load('nist.json')
+INV = {v: k for k, v in OP.items()}
+
+
+def run_tape(model, X, p):
+    """reference interpreter of the RPN tape (tests only): values of every row"""
+    progs = model.programs or [(X.shape[0], model.tape)]
+    out, r0 = np.empty(X.shape[0]), 0
+    old = np.seterr(all='ignore')
+    for n_rows, code in progs:
+        x = X[r0:r0 + n_rows]
+        st = []
+        for ins in code:
+            op, arg = INV[int(ins) & 0xff], int(ins) >> 8
+            if op == 'CONST':
+                st.append(np.full(n_rows, model.consts[arg]))
+            elif op == 'X':
+                st.append(x[:, arg].copy())
+            elif op == 'P':
+                st.append(np.full(n_rows, p[arg]))
+            elif op in ('ADD', 'SUB', 'MUL', 'DIV', 'POW'):
+                b = st.pop()
+                a = st.pop()
+                st.append({'ADD': a + b, 'SUB': a - b, 'MUL': a * b, 'DIV': a / b, 'POW': a ** b}[op])
+            elif op == 'POWI':
+                st.append(st.pop() ** arg)
+            else:
+                f = dict(NEG=np.negative, EXP=np.exp, LOG=np.log, SIN=np.sin, COS=np.cos, ATAN=np.arctan, SQRT=np.sqrt, TAN=np.tan,
+                         SINH=np.sinh, COSH=np.cosh, TANH=np.tanh, ASIN=np.arcsin, ACOS=np.arccos, ABS=np.abs)[op]
+                st.append(f(st.pop()))
+        assert len(st) == 1
+        out[r0:r0 + n_rows] = st[0]
+        r0 += n_rows
+    np.seterr(**old)
+    return out
+
+
+@pytest.mark.parametrize('name', sorted(NIST))
+def test_nist_lambda_traces_to_the_formula_tape(name):
+    """the user's numpy function and the formula string give THE SAME tape, instruction for instruction: the fits are then
+    bit-identical by construction (same compiled code)"""
+    pr = nist_problem(name, NIST)
+    cols = pr['columns'][1:]
+    x = pr['x'] if len(cols) > 1 else pr['x'][cols[0]]
+    tr = amd.trace(MODELS[name], x, np.zeros(pr['P']), fold=False)
+    ref = amd.expr(pr['expr'], ['b%d' % (i + 1) for i in range(pr['P'])], cols)
+    assert tr.model.programs is None
+    got = [(INV[int(c) & 0xff], int(c) >> 8) for c in tr.model.tape]
+    want = [(INV[int(c) & 0xff], int(c) >> 8) for c in ref.tape]
+    # constants are numbered by first use in both front ends; compare them through their values
+    def resolve(seq, consts):
+        return [(o, float(consts[a])) if o == 'CONST' else (o, a) for o, a in seq]
+    assert resolve(got, tr.model.consts) == resolve(want, ref.consts), (name, got, want)
+    assert tr.x.shape == (pr['y'].size, len(cols))
+    # the default (fold=True): what involves no parameter -- x**2, cos(2 pi x / 12) -- was evaluated by numpy during the
+    # recording and is one more predictor column: never a longer tape, the same function
+    tf = amd.trace(MODELS[name], x, np.zeros(pr['P']))
+    assert tf.model.tape.size <= tr.model.tape.size
+    if name in ('enso', 'hahn1', 'kirby2', 'thurber', 'mgh09'):
+        assert tf.model.tape.size < tr.model.tape.size and tf.x.shape[1] > len(cols)
+    np.testing.assert_allclose(run_tape(tf.model, tf.x, pr['p0']), MODELS[name](x, pr['p0']), rtol=1e-14)
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, pr['p0']), MODELS[name](x, pr['p0']), rtol=1e-14)
+
+
+def test_dictionary_parameters_wide_sum():
+    """p['a'], p['E'] (the canonical lsqfit model, examples/y-vs-x.py:58-61): flattened key by key, the sum over states
+    unrolled term by term in the layout the formula compiler recognises (a_k at k, E_k at K + k)"""
+    x = np.linspace(0.1, 3.0, 13)
+    K = 5
+
+    def fcn(x, p):
+        return np.sum(p['a'][:, None] * np.exp(-p['E'][:, None] * x[None, :]), axis=0)
+
+    tr = amd.trace(fcn, x, dict(a=np.zeros(K), E=np.zeros(K)))
+    assert tr.pkeys == ['a', 'E'] and tr.model.n_param == 2 * K and tr.model.programs is None
+    ps = [int(c) >> 8 for c in tr.model.tape if INV[int(c) & 0xff] == 'P']
+    assert ps == [v for k in range(K) for v in (k, K + k)]
+    rng = np.random.default_rng(1)
+    p = dict(a=rng.uniform(0.5, 1.5, K), E=rng.uniform(0.2, 2.0, K))
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(p)), fcn(x, p), rtol=1e-14)
+    back = tr.unpack_params(tr.pack_params(p))
+    assert np.array_equal(back['E'], p['E'])
+
+
+def test_dictionary_output_gives_one_program_per_formula():
+    """examples/simple.py: a dictionary-valued function; rows flattened in the order of the DATA's keys"""
+    xa = np.array([1., 2., 3., 4.])
+
+    def fcn(x, p):
+        return dict(b=p[1] / p[0], a=np.exp(p[0] + x['a'] * p[1]))
+
+    y = dict(a=np.zeros(4), b=0.0)
+    tr = amd.trace(fcn, dict(a=xa), np.zeros(2), y=y)
+    assert tr.ykeys == ['a', 'b'] and [n for n, _ in tr.model.programs] == [4, 1]
+    ref = amd.piecewise([(4, 'exp(a + x*b)'), (1, 'b/a')], ['a', 'b'])
+    for (n1, c1), (n2, c2) in zip(tr.model.programs, ref.programs):
+        assert n1 == n2 and [INV[int(c) & 0xff] for c in c1] == [INV[int(c) & 0xff] for c in c2]
+    p = np.array([0.3, 0.7])
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), np.concatenate([np.exp(p[0] + xa * p[1]), [p[1] / p[0]]]), rtol=1e-15)
+
+
+def test_no_x_closure_constants_indexing_and_every_function():
+    t = np.linspace(0.05, 0.9, 11)
+    w = np.linspace(1.0, 2.0, 11)
+
+    def fcn(p):            # data = y only: the function closes over its constants (src/lsqfit/__init__.py:2013-2016, x False)
+        a, b, c = p
+        s = np.sin(a * t) + np.cos(b * t) * np.tan(c * t) + np.arctan(a * t) + np.sqrt(b + t) + np.log(c + t)
+        s = s + np.sinh(a * t) - np.cosh(b * t) + np.tanh(c * t) + np.arcsin(a * t / 4) + np.arccos(b * t / 4) + abs(c - t)
+        s = s + np.exp(-a * t) * w + (b * t) ** 2 + (c + t) ** 0.5 + 2.0 ** (a * t) + np.square(b) + 1 / c
+        return s[::-1]
+
+    tr = amd.trace(fcn, False, np.zeros(3))
+    p = np.array([0.7, 1.3, 0.4])
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), fcn(p), rtol=1e-13)
+    assert tr.model.programs is None and tr.x.shape[1] >= 2      # t and w became predictor columns
+
+
+def test_rows_that_read_different_parameters_are_different_formulas():
+    x = np.arange(6.0)
+    group = np.array([0, 0, 0, 1, 1, 1])
+
+    def fcn(x, p):
+        return p['norm'][group] * np.exp(-p['E'] * x)
+
+    tr = amd.trace(fcn, x, dict(norm=np.zeros(2), E=0.0))
+    assert [n for n, _ in tr.model.programs] == [3, 3]
+    p = dict(norm=np.array([2.0, 3.0]), E=0.25)
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(p)), fcn(x, p), rtol=1e-15)
+
+
+def test_output_built_element_by_element_is_merged_again():
+    x = np.linspace(0, 1, 9)
+
+    def fcn(x, p):
+        return [p[0] * np.exp(-p[1] * xi) for xi in x] + [p[0] + p[1]]
+
+    tr = amd.trace(fcn, x, np.zeros(2))
+    assert [n for n, _ in tr.model.programs] == [9, 1]
+    p = np.array([1.5, 0.5])
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), np.array(fcn(x, p), float), rtol=1e-15)
+
+
+def test_matmul_stack_concatenate():
+    A = np.random.default_rng(3).standard_normal((7, 3))
+
+    def fcn(p):
+        lin = A @ p[:3]
+        return np.concatenate([lin, np.stack([p[3] * p[0], p[3] + 1.0]), np.dot(A[:2], p[:3]) * p[3]])
+
+    tr = amd.trace(fcn, False, np.zeros(4))
+    p = np.array([0.3, -1.2, 2.0, 0.7])
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), fcn(p), rtol=1e-13)
+
+
+@pytest.mark.parametrize('bad', [
+    lambda x, p: p[0] * x if p[0] > 0 else p[1] * x,
+    lambda x, p: np.where(p[0] * x > 1, p[0], p[1]),
+    lambda x, p: np.maximum(p[0] * x, 0.0),
+    lambda x, p: __import__('math').exp(p[0]) * x,
+    lambda x, p: x[int(p[0])] * p[1],
+])
+def test_data_dependent_control_flow_is_refused(bad):
+    with pytest.raises(amd.TraceError):
+        amd.trace(bad, np.linspace(0, 1, 5), np.ones(2))
+
+
+def test_unsupported_numpy_function_is_refused_by_name():
+    with pytest.raises(amd.TraceError, match='arctan2'):
+        amd.trace(lambda x, p: np.arctan2(p[0] * x, p[1]), np.linspace(0, 1, 5), np.ones(2))
+
+
+def test_residual_function_as_lsqfit_hands_it_over():
+    """``chiv`` called on an object array of overloaded numbers (src/lsqfit/_utilities.pyx:65-94 with mixed=True): the data
+    part weighted row by row, one correlated block multiplied by its weight matrix, the prior rows appended"""
+    x = np.linspace(0.2, 2.0, 8)
+    y = 1.7 * np.exp(-0.6 * x)
+    rng = np.random.default_rng(5)
+    wd = rng.uniform(5, 9, 5)
+    Wb = rng.standard_normal((3, 3)) + 4 * np.eye(3)
+    pm, pw = np.array([1.0, 1.0]), np.array([2.0, 3.0])
+    mean = np.concatenate([y, pm])
+    iw0 = np.concatenate([np.arange(5), [8, 9]])
+    w0 = np.concatenate([wd, pw])
+    iw1 = np.arange(5, 8)
+
+    def flat_fcn(p):
+        return (p[0] * np.exp(-p[1] * x)).flat
+
+    def chiv(p, mixed=False):
+        delta = np.concatenate((flat_fcn(p), p)) - mean
+        ans = np.zeros(10, object if mixed else float)
+        ans[:7] = np.multiply(memoryview(w0), delta[iw0])
+        ans[7:] = np.dot(Wb, delta[iw1])
+        return ans
+
+    tr = amd.trace_residual(chiv, 2)
+    assert tr.n_rows == 10
+    for p in (np.array([1.7, 0.6]), np.array([0.9, 1.4])):
+        np.testing.assert_allclose(run_tape(tr.model, tr.x, p), chiv(p), rtol=1e-13, atol=1e-14)
