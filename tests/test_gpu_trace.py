@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import fit as ofit
+from oracle import dual
 from oracle.dual import Dual
 from tests import gpu_util as gu
 from tests.helpers import load, nist_problem
@@ -57,7 +58,7 @@ def test_dictionary_parameter_multiexponential_matches_oracle(amd):
     def flat_fcn(x, p):           # the oracle's view: flat parameters, Dual-capable
         a, E = p[:K], p[K:]
         if isinstance(p, Dual):
-            return sum(a[k] * (-(E[k] * x)).exp() for k in range(K))
+            return dual.stack_sum([a[k] * dual.exp(-(E[k] * x)) for k in range(K)])
         return np.exp(-np.outer(x, E)) @ a
 
     f0 = fcn(x, ptrue)
@@ -103,8 +104,7 @@ def test_dictionary_data_and_output(amd):
 
     def flat_fcn(x, p):
         if isinstance(p, Dual):
-            from oracle.dual import concatenate
-            return concatenate([(p[0] + p[1] * xa).exp(), (p[1] / p[0]).reshape(1)])
+            return dual.concatenate([dual.exp(p[0] + p[1] * xa), (p[1] / p[0]).reshape(1)])
         return np.concatenate([np.exp(p[0] + xa * p[1]), [p[1] / p[0]]])
 
     ref = ofit.nonlinear_fit(None, np.concatenate([ya, [2.05]]), full, flat_fcn, prior_mean=np.array([0.3, 0.4]),
