@@ -310,7 +310,7 @@ int lsqamd_set_linear(lsqamd_fit *fit, const int32_t *index, int32_t n);
 int lsqamd_set_reduce(lsqamd_fit *fit, lsqamd_reduce_fn fn, void *user);
 /* The exchange inside the library (what a host in any language uses; the hook above stays for
  * transports RCCL does not cover, e.g. the CPU-side gloo tests): a persistent RCCL communicator
- * per handle, one rank per GPU.  Rank 0 calls lsqamd_comm_unique_id and ships the
+ * per process and id (shared by the handles that name it, see lsqamd_comm_stats), one rank per GPU.  Rank 0 calls lsqamd_comm_unique_id and ships the
  * LSQAMD_COMM_ID_BYTES bytes to the other ranks by whatever channel the host has (MPI, a file,
  * torch.distributed); then EVERY rank calls lsqamd_comm_init (collective: returns when all
  * nranks have joined).  From then on the sums of the row-sharded fit -- the packed
@@ -326,6 +326,13 @@ int lsqamd_comm_init(lsqamd_fit *fit, const void *id, size_t id_bytes, int32_t r
 int lsqamd_comm_destroy(lsqamd_fit *fit);
 /* *rank / *nranks of the handle's communicator (-1 / 0 when there is none) */
 int lsqamd_comm_info(const lsqamd_fit *fit, int32_t *rank, int32_t *nranks);
+/* Communicators belong to the PROCESS: the first lsqamd_comm_init that names an id creates it (ncclCommInitRank, collective),
+ * every later handle that names the same id on the same device shares it (no collective call; handles sharing one must not
+ * run their sums at the same time), lsqamd_comm_destroy / lsqamd_destroy only drop the handle's reference.
+ * lsqamd_comm_stats: *init_ms = what creating the handle's communicator took, *handles = handles holding it now.
+ * lsqamd_comm_shutdown: destroys every communicator no handle holds; returns how many are still held. */
+int lsqamd_comm_stats(const lsqamd_fit *fit, double *init_ms, int32_t *handles);
+int lsqamd_comm_shutdown(void);
 /* Row-sharded fits: exactly one rank (on != 0) contributes the replicated prior
  * terms to the sums before the all-reduce.  Default on. */
 int lsqamd_set_adds_prior(lsqamd_fit *fit, int32_t on);
@@ -485,6 +492,20 @@ int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const double *const
 /* developer builds (-DLSQAMD_POTF2_TIMING): device buffer of 32 int64 cycle stamps written by the
  * diagonal-block Cholesky kernel; NULL (default) disables */
 void lsqamd_debug_set_potf2_stamps(void *dev_ptr);
+/* developer probe: where do the workgroups of a launch on `stream` run?  dev_out[2 b] = XCC_ID, dev_out[2 b + 1] = HW_ID of
+ * workgroup b (n_wg workgroups of one wave that ask for lds_bytes of LDS each; tools/exp_cumask.py) */
+int lsqamd_debug_where(void *stream, int32_t n_wg, uint32_t *dev_out, int32_t lds_bytes);
+/* developer / test entry points of the factorisation streamed behind the J^T J product (csrc/sf_chol.hip; the first trial solve
+ * after an accepted LM step: replaces gsl's solver init + solve behind src/lsqfit/_gsl.pyx:646-653,:677).  Device pointers.
+ *   J [n_rows][ldj] (P columns used), prior (nullable: dense P x P or diagonal), g [P], mu, d [P] (updated like the LM scaling)
+ *   -> apk (packed upper 128 x 128 tiles of A = J^T J + prior), M [P][P + 128] (U with A + mu D^2 = U^T U; column P = U^-T g).
+ * reserve_per_xcd CUs of every XCD run the latency chain (hipExtStreamCreateWithCUMask; mask_mode 'c' / 'i': bit layout);
+ * 0 = no masks (plain streams: results only). */
+size_t lsqamd_op_sf_work_bytes(int64_t n_rows, int64_t P, int32_t splits);
+int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_rows, int64_t P, int32_t splits, int32_t group_rows,
+                        int32_t reserve_per_xcd, int32_t mask_mode, const double *prior, int32_t prior_dense, const double *g,
+                        double mu, int32_t scaler, double *d, double *apk, double *M, void *work, size_t work_bytes,
+                        int32_t *info_host, long long *dev_stamps /* nullable: [24 + 4 P / 128] wall-clock stamps and per-item-type time sums */, int32_t idle_max);
 
 #ifdef __cplusplus
 }

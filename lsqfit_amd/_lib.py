@@ -78,6 +78,8 @@ PROTOTYPES = {
     'lsqamd_comm_init': (C.c_int, [_vp, _vp, C.c_size_t, C.c_int32, C.c_int32]),
     'lsqamd_comm_destroy': (C.c_int, [_vp]),
     'lsqamd_comm_info': (C.c_int, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    'lsqamd_comm_stats': (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    'lsqamd_comm_shutdown': (C.c_int, []),
     'lsqamd_set_tape_programs': (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp,
                                            C.c_int32]),
     'lsqamd_tape_codegen': (C.c_int, [C.POINTER(C.c_int32), C.c_int32, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_char_p,
@@ -131,6 +133,10 @@ PROTOTYPES = {
     'lsqamd_handoff_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_jit_cache_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_debug_set_potf2_stamps': (None, [_vp]),
+    'lsqamd_debug_where': (C.c_int, [_vp, C.c_int32, _vp, C.c_int32]),
+    'lsqamd_op_sf_work_bytes': (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
+    'lsqamd_op_sf_factor': (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp,
+                                      C.c_int32, _vp, C.c_double, C.c_int32, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_int32]),
 }
 
 _lib = None

@@ -4,13 +4,18 @@
 // node needs ONE exchange per Jacobian evaluation -- the sum of the packed [J^T J | J^T f | chi2]
 // buffer (69 MB at P = 4096) -- and one scalar per trial step.  The reference has no distributed
 // path; there is nothing to mirror.  Design:
-//   * a persistent communicator per handle (lsqamd_comm_init: ncclCommInitRank with an id made by
-//     rank 0's lsqamd_comm_unique_id and carried to the other ranks by ANY host-side channel:
-//     torch.distributed in lsqfit_amd/dist.py, MPI / a file / a socket for another host);
+//   * ONE persistent communicator per (process, device, id), shared by the handles that name the same id
+//     (lsqamd_comm_init: ncclCommInitRank -- timed, lsqamd_comm_stats -- the first time an id made by rank 0's
+//     lsqamd_comm_unique_id is seen; later handles with that id just take a reference: a fit per problem no
+//     longer pays a communicator set-up per problem.  The id travels to the other ranks by ANY host-side
+//     channel: torch.distributed in lsqfit_amd/dist.py, MPI / a file / a socket for another host.  Handles that
+//     share a communicator must not run collectives at the same time: they are consecutive problems of one job);
 //   * the sum is enqueued on the handle's stream as reduce-scatter + all-gather over 256-byte
 //     aligned slices (every xGMI link carries 1/n of the buffer in each phase; every rank ends
 //     up with the SAME bytes, which is what lets all ranks take identical LM decisions), the few
-//     leftover elements and short vectors as one all-reduce;
+//     leftover elements and short vectors as one all-reduce -- grouped with the reduce-scatter
+//     (ncclGroupStart / End: independent regions, one launch; the all-gather depends on the reduce-scatter
+//     and stays a launch of its own);
 //   * no stream synchronisation, no host callback: the kernels queued behind the collective on
 //     the same stream see the sums.
 // RCCL is bound at run time (dlopen): inside a PyTorch process the librccl.so torch already
@@ -18,8 +23,12 @@
 // path decide; a build without RCCL on the box still loads and every other entry point works.
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
 
 #include "fit_state.h"
 
@@ -41,6 +50,8 @@ struct Api {
   int (*ReduceScatter)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
+  int (*GroupStart)() = nullptr;      // optional
+  int (*GroupEnd)() = nullptr;
   std::string why;
   bool ok = false;
 };
@@ -87,10 +98,25 @@ Api &api() {
         return t;
       }
     }
+    t.GroupStart = (int (*)())dlsym(t.lib, "ncclGroupStart");
+    t.GroupEnd = (int (*)())dlsym(t.lib, "ncclGroupEnd");
+    if (!t.GroupStart || !t.GroupEnd) t.GroupStart = t.GroupEnd = nullptr;
     t.ok = true;
     return t;
   }();
   return a;
+}
+
+// communicators of this process: key = device + id bytes
+struct Shared {
+  Comm comm = nullptr;
+  int refs = 0, rank = 0, nranks = 1;
+  double init_ms = 0.0;
+};
+std::mutex g_reg_mu;
+std::map<std::string, Shared> &registry() {
+  static std::map<std::string, Shared> r;
+  return r;
 }
 
 // LSQAMD_COMM_ALGO=allreduce: one ncclAllReduce for everything (A/B switch, developer knob)
@@ -120,18 +146,24 @@ int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count) {
     return 0;
   }
   double *mine = buf + (int64_t)f->comm_rank * slice;
-  NCCLCHK(f, a.ReduceScatter(buf, mine, (size_t)slice, DT_FLOAT64, OP_SUM, c, f->st));
-  NCCLCHK(f, a.AllGather(mine, buf, (size_t)slice, DT_FLOAT64, c, f->st));
   const int64_t done = slice * n;
+  const bool group = a.GroupStart && done < count;
+  if (group) NCCLCHK(f, a.GroupStart());
+  NCCLCHK(f, a.ReduceScatter(buf, mine, (size_t)slice, DT_FLOAT64, OP_SUM, c, f->st));
   if (done < count) NCCLCHK(f, a.AllReduce(buf + done, buf + done, (size_t)(count - done), DT_FLOAT64, OP_SUM, c, f->st));
+  if (group) NCCLCHK(f, a.GroupEnd());
+  NCCLCHK(f, a.AllGather(mine, buf, (size_t)slice, DT_FLOAT64, c, f->st));
   return 0;
 }
 
 void comm_release(lsqamd_fit *f) {
-  if (f->comm) {
-    (void)api().CommDestroy((Comm)f->comm);
+  if (f->comm) {     // the communicator itself stays with the process (lsqamd_comm_shutdown ends it): the next handle reuses it
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = registry().find(f->comm_key);
+    if (it != registry().end() && it->second.refs > 0) it->second.refs--;
     f->comm = nullptr;
   }
+  f->comm_key.clear();
   f->comm_rank = 0;
   f->comm_nranks = 1;
 }
@@ -157,14 +189,58 @@ int lsqamd_comm_init(lsqamd_fit *f, const void *id, size_t id_bytes, int32_t ran
   Api &a = api();
   if (!a.ok) FAIL(f, LSQAMD_EUNSUPPORTED, "comm_init: %s", a.why.c_str());
   lsqamd_host::comm_release(f);
-  UniqueId u;
-  std::memcpy(u.internal, id, LSQAMD_COMM_ID_BYTES);
-  Comm c = nullptr;
-  NCCLCHK(f, a.CommInitRank(&c, nranks, u, rank));
-  f->comm = c;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::string key = std::to_string(dev) + ":";
+  key.append(static_cast<const char *>(id), LSQAMD_COMM_ID_BYTES);
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = registry().find(key);
+  if (it != registry().end()) {
+    if (it->second.rank != rank || it->second.nranks != nranks)
+      FAIL(f, LSQAMD_EINVAL, "comm_init: this id already names a communicator with rank %d of %d", it->second.rank, it->second.nranks);
+    it->second.refs++;
+    f->comm = it->second.comm;
+  } else {
+    UniqueId u;
+    std::memcpy(u.internal, id, LSQAMD_COMM_ID_BYTES);
+    Comm c = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    NCCLCHK(f, a.CommInitRank(&c, nranks, u, rank));
+    Shared sh;
+    sh.comm = c; sh.refs = 1; sh.rank = rank; sh.nranks = nranks;
+    sh.init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    registry()[key] = sh;
+    f->comm = c;
+  }
+  f->comm_key = key;
   f->comm_rank = rank;
   f->comm_nranks = nranks;
   return 0;
+}
+
+int lsqamd_comm_stats(const lsqamd_fit *f, double *init_ms, int32_t *handles) {
+  if (!f) return LSQAMD_EINVAL;
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  auto it = registry().find(f->comm_key);
+  const bool have = f->comm && it != registry().end();
+  if (init_ms) *init_ms = have ? it->second.init_ms : 0.0;
+  if (handles) *handles = have ? it->second.refs : 0;
+  return 0;
+}
+
+int lsqamd_comm_shutdown(void) {
+  std::lock_guard<std::mutex> lk(g_reg_mu);
+  int busy = 0;
+  for (auto it = registry().begin(); it != registry().end();) {
+    if (it->second.refs > 0) {
+      ++busy;
+      ++it;
+      continue;
+    }
+    (void)api().CommDestroy(it->second.comm);
+    it = registry().erase(it);
+  }
+  return busy;
 }
 
 int lsqamd_comm_destroy(lsqamd_fit *f) {

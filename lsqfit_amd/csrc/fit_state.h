@@ -99,6 +99,7 @@ struct lsqamd_fit {
   // in-library RCCL communicator (comm.hip); takes precedence over the hook
   void *comm = nullptr;
   int32_t comm_rank = 0, comm_nranks = 1;
+  std::string comm_key;            // its entry in the process-wide registry of communicators (comm.hip)
 
   // solver = qr: caller-provided device scratch (lsqamd_set_qr_work) and what the last run did
   void *qr_work = nullptr;

@@ -1,0 +1,52 @@
+// The factorisation streamed behind the J^T J product (sf_chol.hip): host-side interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lsqamd {
+
+constexpr int32_t SF_TIMEOUT_INFO = -88;     // *info when a bounded wait of the streamed factorisation gave up
+
+struct SfLaunch {
+  hipStream_t st_main = nullptr;    // the handle's stream: everything before is waited for, everything after waits for both
+  hipStream_t st_work = nullptr;    // CU-masked: the chip minus the reserved CUs
+  hipStream_t st_chain = nullptr;   // CU-masked: the reserved CUs
+  hipEvent_t ev_fork = nullptr, ev_work = nullptr, ev_chain = nullptr;
+  int32_t n_workers = 0;            // resident workgroups of the worker launch (2 per CU of st_work)
+  const double *J = nullptr;        // whitened Jacobian [n_rows][ldj]
+  int64_t ldj = 0, n_rows = 0;
+  int32_t splits = 1;
+  double *slabs = nullptr;          // [splits][P][ld_slab]
+  int64_t ld_slab = 0, split_stride = 0;
+  double *M = nullptr;              // [P][ldm], ldm >= P + 128
+  int64_t ldm = 0;
+  double *uinv = nullptr;           // potrf work: inverses of the diagonal blocks
+  double *apk = nullptr;            // packed upper tiles of A (written here)
+  const double *prior = nullptr;    // prior precision added into A (nullable)
+  int32_t prior_dense = 0;
+  const double *gvec = nullptr;     // [P] right-hand side (complete before the call)
+  int64_t P = 0;
+  const int32_t *q1 = nullptr;      // device lists (sf_q1_fill / sf_q2_fill)
+  int32_t q1_run0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int32_t *q2 = nullptr;
+  int32_t *sync = nullptr;          // sf_sync_bytes(P)
+  int32_t *info = nullptr;          // pivot failure word (as potrf_upper's)
+  int32_t scaler = 0;               // LSQAMD_SCALE_*: the scaling D is updated block by block on the way
+  double *dscale = nullptr;
+  const double *mu_dev = nullptr;   // damping parameter (device)
+  long long *dbg = nullptr;         // optional device buffer [8 + 4 T]: wall-clock stamps of the chain (developer tool)
+  int32_t idle_max = 16;            // longest idle sleep of a worker, x ~0.2 us
+};
+
+size_t sf_sync_bytes(int64_t P);
+int64_t sf_q1_count(int64_t P, int32_t splits);
+int64_t sf_q2_count(int64_t P);
+void sf_q1_fill(int64_t P, int32_t splits, int group_rows, int32_t *out, int32_t run0[9]);
+void sf_q2_fill(int64_t P, int32_t *out);
+// Enqueues: J^T J (slabs + packed tiles + prior), M = U with A + mu D^2 = U^T U, column P of M = U^-T g, block inverses,
+// D updated.  Requires P a multiple of 128, P >= 256, n_rows a multiple of 16, 16-byte aligned rows.
+hipError_t sf_launch(const SfLaunch &a);
+// 0 on success; the two CU-masked streams and the number of CUs the worker stream may use
+int sf_streams_create(int reserve_per_xcd, int mode, hipStream_t *work, hipStream_t *chain, int *n_work_cus);
+
+}  // namespace lsqamd

@@ -1,0 +1,864 @@
+// The factorisation of the damped normal matrix STREAMED behind the J^T J product (round 5).
+//
+// Replaces, for the first trial solve after an accepted LM step, the serial chain
+//     J^T J (split-K slabs) -> slab sum -> (A + mu D^2 | g) -> blocked Cholesky
+// (gsl_multifit_nlinear's solver init + solve behind src/lsqfit/_gsl.pyx:646-653,:677) by two CONCURRENT launch sets:
+//
+//   stream A, the chip minus a few reserved CUs (hipExtStreamCreateWithCUMask): ONE persistent launch of
+//     `sf_worker_kernel` whose workgroups pull work items from two queues --
+//       Q1  J^T J tiles (tm, tn, K-chunk), ordered by groups of tile ROWS, so that the rows of A complete in order;
+//           the workgroup that finishes the last K-chunk of a tile also sums the tile's slabs into the packed tile
+//           (+ prior precision): the separate slab-sum pass is gone;
+//       Q2  tiles of the factorisation, taken FIRST whenever their inputs are ready: row-panel tiles
+//           U[k, tn] = inv(U_kk)^T (A[k, tn] + updates) and trailing updates M[tm, tn] -= U[k, tm]^T U[k, tn];
+//   stream B, the reserved CUs: the latency chain -- per 128 columns the diagonal block (updated in registers with the row
+//     above it and factored: trail_potf2_kernel's workgroup 0) and the ONE panel tile the next diagonal block needs.
+//
+// Updates are accumulated into M before the rows of A they belong to exist (M[tm, tn] collects -sum_k U_k^T U_k from
+// step 0 on; A[tm, tn] (+ mu D^2) is added when row tm is about to be factored): the factorisation never waits for more
+// of J^T J than the row it is working on.  Every sum has a fixed order: results do not depend on which workgroup ran what.
+//
+// Inter-workgroup hand-offs follow cdna_hip_programming.md section 6, Guideline 16: producer waves drain their stores,
+// barrier, one lane's agent-scope release, then a relaxed agent-scope flag store; consumers poll relaxed, one agent-scope
+// acquire, barrier, plain loads.  All waits are bounded: a timeout sets the abort word and *info = SF_TIMEOUT_INFO, every
+// workgroup leaves, and the caller falls back to the serial path.
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+#include "sf_chol.h"
+
+namespace lsqamd {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BM = 128, BK = 16;
+constexpr int LDT = BM + 16;                       // padded LDS row (doubles), as gemm_tn_f64.hip
+constexpr int STAGE = 2 * BK * LDT;
+constexpr size_t SF_LDS_BYTES = 2 * STAGE * sizeof(double);
+constexpr int TB = 128;
+constexpr unsigned SPIN_LIMIT = 1u << 20;          // x (an L2 load + s_sleep(2)) ~ 1 us: about a second
+
+__device__ __forceinline__ int ld_relaxed(const int32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed(int32_t *p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// producer side of a hand-off; call with all threads of the workgroup
+__device__ __forceinline__ void publish_begin() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+__device__ __forceinline__ void release_agent() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+
+__device__ __forceinline__ int64_t tile_index(int tm, int tn, int T) { return (int64_t)tm * T - (int64_t)tm * (tm - 1) / 2 + (tn - tm); }
+
+struct SfDev {
+  const double *J;            // whitened Jacobian rows (column P = residual, not used here)
+  int64_t ldj, K, kchunk;
+  int32_t splits;
+  double *slabs;              // [splits][P][lds]
+  int64_t lds, split_stride;
+  double *M;                  // [P][ldm]: the factor grows here; column P (tile column T) carries the right-hand side
+  int64_t ldm;
+  const double *uinv;         // inverses of the diagonal blocks (block k at + k * 128 * 128)
+  double *apk;                // packed upper tiles of A = J^T J + prior
+  const double *prior;        // nullable
+  int32_t prior_dense;
+  const double *gvec;         // [P] right-hand side
+  int64_t P;
+  int32_t T;
+  const int4 *q1;
+  int32_t q1_run0[9];
+  const int4 *q2;
+  int32_t q2_len;
+  int32_t *sync;
+  int32_t *info;
+  long long *dbg;             // nullable: wall-clock stamps (100 MHz) of the chain's steps, see tools/exp_sf.py
+  int32_t idle_max;           // longest idle sleep of a worker without work, in units of s_sleep(8) (~0.2 us)
+  int32_t dflags;             // developer switches (timing experiments only; results may be wrong): 1 no release after J^T J items,
+                              // 2 no release at all, 4 no slab sum, 8 no acquire after taking an item
+};
+
+// layout of the sync words (zeroed before every use)
+__host__ __device__ inline int sy_q1_head(int x) { return x; }                 // [8]
+constexpr int SY_Q2_HEAD = 8, SY_DIAGPUB = 9, SY_ABORT = 10, SY_EPOCH = 11, SY_ROWFINAL = 16;   // row_final[T] from 16
+__host__ __device__ inline int sy_ver(int T, int tm, int tn) { return SY_ROWFINAL + T + tm * (T + 1) + tn; }
+__host__ __device__ inline int sy_pdone(int T, int k, int tn) { return SY_ROWFINAL + T + T * (T + 1) + k * (T + 1) + tn; }
+__host__ __device__ inline int sy_tilecnt(int T, int64_t t) { return SY_ROWFINAL + T + 2 * T * (T + 1) + (int)t; }
+inline size_t sy_words(int T) { return (size_t)SY_ROWFINAL + T + 2 * (size_t)T * (T + 1) + (size_t)T * (T + 1) / 2; }
+
+__device__ __forceinline__ void timeout(const SfDev &g) {
+  st_relaxed(g.sync + SY_ABORT, 1);
+  atomicCAS(g.info, 0, SF_TIMEOUT_INFO);
+}
+
+// one lane: wait until *w >= target (or the abort word is set); false = give up
+__device__ __forceinline__ bool wait_ge(const SfDev &g, const int32_t *w, int target) {
+  for (unsigned spins = 0;; ++spins) {
+    if (ld_relaxed(w) >= target) return true;
+    if ((spins & 63) == 63) {
+      if (ld_relaxed(g.sync + SY_ABORT) != 0) return false;
+      if (spins > SPIN_LIMIT) {
+        timeout(g);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// something a waiting worker may be waiting for has changed (idle workers poll this ONE word, with growing sleeps, instead of
+// hammering the flags themselves: 448 pollers on the lines the chain's hand-offs go through made every hand-off crawl)
+__device__ __forceinline__ void bump_epoch(const SfDev &g) { atomicAdd(g.sync + SY_EPOCH, 1); }
+__device__ __forceinline__ void stamp(const SfDev &g, int slot) {
+  if (g.dbg) g.dbg[slot] = wall_clock64();
+}
+
+enum { IT_NONE = -1, IT_SYRK = 0, IT_PANEL = 1, IT_TRAIL = 2 };
+
+// ---- the tile product: acc = sum over k in [kb, ke) of X[k][m0 + .]^T Y[k][n0 + .]  (gemm_tn_f64_interior_kernel's loop) ----
+// ROLE 0: all 16 sub-tiles of the wave; 1 / 2: the triangular schedule of a diagonal J^T J tile (Y == X, not staged)
+template <int ROLE>
+__device__ __forceinline__ void tile_product(v4d (&acc)[4][4], const double *X, int64_t ldx, const double *Y, int64_t ldy,
+                                             int64_t kb, int64_t ke, double *smem, int wave, int lane, int arow0, int bcol0,
+                                             double sgn = 1.0) {
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const double *xp = X + (kb + wave) * ldx + 2 * lane;
+  const double *yp = Y + (kb + wave) * ldy + 2 * lane;
+  const int64_t xstep = 4 * ldx, ystep = 4 * ldy;
+  const int fr = lane & 15, fq = lane >> 4;
+  auto stage = [&](int buf) {
+    double *Xs = smem + buf * STAGE + wave * LDT;
+    double *Ys = Xs + BK * LDT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
+      if (ROLE == 0) __builtin_amdgcn_global_load_lds((glb_void *)(yp + i * ystep), (lds_void *)(Ys + 4 * i * LDT), 16, 0, 0);
+    }
+    xp += 4 * xstep;
+    yp += 4 * ystep;
+  };
+  if (kb < ke) stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int64_t k0 = kb; k0 < ke; k0 += BK) {
+    if (k0 + BK < ke) stage(cur ^ 1);
+    const double *Xs = smem + cur * STAGE;
+    const double *Ys = ROLE == 0 ? Xs + BK * LDT : Xs;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      const int kr = kk * 4 + fq;
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < (ROLE == 2 ? 2 : 4); ++i) a[i] = ROLE == 0 ? sgn * Xs[kr * LDT + arow0 + i * 16 + fr] : Xs[kr * LDT + arow0 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = Ys[kr * LDT + bcol0 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < (ROLE == 2 ? 2 : 4); ++i)
+#pragma unroll
+        for (int j = (ROLE == 1 ? i : 0); j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---- the worker: stream A ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void sf_worker_kernel(SfDev g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_item[4];
+  __shared__ int s_flag;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int T = g.T;
+  // (observed: 0..7; speed only -- which run of Q1 this workgroup starts from)
+  const int xcd = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);
+  unsigned exhausted = 0;
+  for (;;) {
+    if (tid == 0) {
+      int type = IT_NONE, a = 0, b = 0, c = 0;
+      int idle = 1;
+      const long long t_pick0 = g.dbg ? wall_clock64() : 0;
+      for (unsigned spins = 0;; ++spins) {
+        if (ld_relaxed(g.sync + SY_ABORT) != 0) break;
+        const int epoch = ld_relaxed(g.sync + SY_EPOCH);       // (read BEFORE the checks: a publication in between is not missed)
+        const int h = ld_relaxed(g.sync + SY_Q2_HEAD);
+        bool q2_left = h < g.q2_len;
+        // the factorisation's tiles first.  Entries are taken with ONE atomic add as soon as the step of the entry at the head
+        // is open (inv(U_kk) published); what exactly the entry taken needs -- its panel tiles, the previous update of its
+        // tile -- is waited for inside the item: those are entries taken before this one or steps of the chain, never later
+        // ones.  (Taking only a READY head entry, one CAS at a time, serialised a step's ~400 tiles at 4 us each.)
+        if (q2_left && ld_relaxed(g.sync + SY_DIAGPUB) > g.q2[h].y) {
+          const int h2 = atomicAdd(g.sync + SY_Q2_HEAD, 1);
+          if (h2 < g.q2_len) {
+            const int4 it = g.q2[h2];
+            type = it.x; a = it.y; b = it.z; c = it.w;
+            break;
+          }
+          q2_left = false;
+        }
+        bool got = false;
+        for (int i = 0; i < 8 && !got; ++i) {
+          const int x = (xcd + i) & 7;
+          if ((exhausted >> x) & 1u) continue;
+          const int len = g.q1_run0[x + 1] - g.q1_run0[x];
+          const int s = atomicAdd(g.sync + sy_q1_head(x), 1);
+          if (s < len) {
+            const int4 it = g.q1[g.q1_run0[x] + s];
+            type = IT_SYRK; a = it.x; b = it.y; c = it.z;
+            got = true;
+          } else {
+            exhausted |= 1u << x;
+            if (exhausted == 0xffu && g.dbg) atomicCAS(reinterpret_cast<unsigned long long *>(g.dbg + 1), 0ull, (unsigned long long)wall_clock64());
+          }
+        }
+        if (got) break;
+        if (!q2_left) break;              // both queues are empty: done
+        // idle: sleep until something is published (growing sleeps: the hand-offs of the chain share these cache lines)
+        for (;;) {
+          for (int i = 0; i < idle; ++i) __builtin_amdgcn_s_sleep(8);
+          if (ld_relaxed(g.sync + SY_EPOCH) != epoch) {
+            idle = 1;
+            break;
+          }
+          if (idle < g.idle_max) idle *= 2;
+          spins += (unsigned)idle;
+          if (spins > SPIN_LIMIT) break;
+          if ((spins & 1023u) < (unsigned)idle && ld_relaxed(g.sync + SY_ABORT) != 0) break;
+        }
+        if (spins > SPIN_LIMIT) {
+          timeout(g);
+          break;
+        }
+      }
+      if (type != IT_NONE && !(g.dflags & 8)) acquire_agent();
+      if (g.dbg) atomicAdd(reinterpret_cast<unsigned long long *>(g.dbg + 8 + 4 * T + 9), (unsigned long long)(wall_clock64() - t_pick0));
+      s_item[0] = type; s_item[1] = a; s_item[2] = b; s_item[3] = c;
+    }
+    __syncthreads();
+    const int type = s_item[0], ia = s_item[1], ib = s_item[2], ic = s_item[3];
+    if (type == IT_NONE) {
+      if (tid == 0 && g.dbg) atomicMax(reinterpret_cast<unsigned long long *>(g.dbg + 2), (unsigned long long)wall_clock64());
+      return;
+    }
+
+    if (type != IT_SYRK) {
+      // what this tile needs: panel tile -- inv(U_kk) and every earlier update of the tile; trailing update -- both panel
+      // tiles of row k and the previous update of the tile
+      if (tid == 0) {
+        bool good;
+        const long long t_w0 = g.dbg ? wall_clock64() : 0;
+        if (type == IT_PANEL) {
+          good = wait_ge(g, g.sync + SY_DIAGPUB, ia + 1) && wait_ge(g, g.sync + sy_ver(T, ia, ic), ia);
+        } else {
+          good = wait_ge(g, g.sync + sy_pdone(T, ia, ib), 1) && wait_ge(g, g.sync + sy_pdone(T, ia, ic), 1) &&
+                 wait_ge(g, g.sync + sy_ver(T, ib, ic), ia);
+        }
+        if (good) acquire_agent();
+        if (g.dbg) atomicAdd(reinterpret_cast<unsigned long long *>(g.dbg + 8 + 4 * T + 10), (unsigned long long)(wall_clock64() - t_w0));
+        s_flag = good;
+      }
+      __syncthreads();
+      if (!s_flag) return;
+      __syncthreads();
+    }
+    const long long t_item0 = g.dbg ? wall_clock64() : 0;
+    v4d acc[4][4];
+    if (type == IT_TRAIL && ia > 0) {
+      // the tile itself is the accumulator's starting value: M[tm, tn] - U[k, tm]^T U[k, tn] comes out of the MFMA chain
+      // (the loads are in flight while the first stage is fetched; no read-modify-write epilogue)
+      const double *Cin = g.M + (int64_t)ib * BM * g.ldm + (int64_t)ic * BM;
+      const int lo = fq * (int)g.ldm + fr;          // (lane part of the address; the rest is wave-uniform)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double *crow = Cin + (int64_t)(wm * 64 + i * 16 + 4 * r) * g.ldm + wn * 64;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j][r] = crow[lo + j * 16];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+
+    // operands of the tile product by item type
+    const double *X, *Y;
+    double *C;
+    int64_t ldx, ldy, ldc, kb, ke;
+    bool neg = false;
+    const bool syrk_diag = type == IT_SYRK && ia == ib;
+    if (type == IT_SYRK) {
+      const int64_t m0 = (int64_t)ia * BM, n0 = (int64_t)ib * BM;
+      kb = (int64_t)ic * g.kchunk;
+      ke = kb + g.kchunk < g.K ? kb + g.kchunk : g.K;
+      X = g.J + m0; Y = g.J + n0; ldx = ldy = g.ldj;
+      C = g.slabs + (int64_t)ic * g.split_stride + m0 * g.lds + n0; ldc = g.lds;
+    } else if (type == IT_PANEL) {
+      // U[k, tn] = inv(U_kk)^T (A[k, tn] + accumulated updates), in place in M; tile column T is the right-hand side
+      const int k = ia, tn = ic;
+      C = g.M + (int64_t)k * BM * g.ldm + (int64_t)tn * BM; ldc = g.ldm;
+      X = g.uinv + (int64_t)k * BM * BM; ldx = BM;
+      Y = C; ldy = g.ldm;
+      kb = 0; ke = BM;
+      {
+        const int c2 = 2 * (tid & 63);
+        const double *src = tn < T ? g.apk + tile_index(k, tn, T) * TB * TB : nullptr;
+#pragma unroll 4
+        for (int h = 0; h < 32; ++h) {
+          const int r = (tid >> 6) + 4 * h;
+          v2d v;
+          if (src) {
+            v = *reinterpret_cast<const v2d *>(src + r * TB + c2);
+          } else {
+            v.x = c2 == 0 ? g.gvec[(int64_t)k * BM + r] : 0.0;
+            v.y = 0.0;
+          }
+          if (k > 0) {
+            const v2d m = *reinterpret_cast<const v2d *>(C + (int64_t)r * g.ldm + c2);
+            v.x += m.x;
+            v.y += m.y;
+          }
+          *reinterpret_cast<v2d *>(C + (int64_t)r * g.ldm + c2) = v;
+        }
+      }
+      publish_begin();
+      if (tid == 0) acquire_agent();       // (this CU's L1 may hold the tile as it was)
+      __syncthreads();
+    } else {
+      // M[tm, tn] -= U[k, tm]^T U[k, tn]   (the first update of a tile writes: nothing is there yet)
+      const int k = ia, tm = ib, tn = ic;
+      const double *Uk = g.M + (int64_t)k * BM * g.ldm;
+      X = Uk + (int64_t)tm * BM; Y = Uk + (int64_t)tn * BM; ldx = ldy = g.ldm;
+      C = g.M + (int64_t)tm * BM * g.ldm + (int64_t)tn * BM; ldc = g.ldm;
+      kb = 0; ke = BM;
+      neg = true;
+    }
+    if (syrk_diag) {
+      // diagonal tile of J^T J: the triangular schedule of gemm_tn_f64_interior_kernel (waves 0 and 3 the sub-tiles i <= j of
+      // the diagonal quadrants, waves 1 and 2 two 16-row strips of the upper-right quadrant each), mirrored epilogue
+      const int arow0 = wave == 2 ? 32 : (wave == 3 ? 64 : 0);
+      const int bcol0 = wave == 0 ? 0 : 64;
+      const bool tri = wave == 0 || wave == 3;
+      if (tri) tile_product<1>(acc, X, ldx, X, ldx, kb, ke, smem, wave, lane, arow0, bcol0);
+      else tile_product<2>(acc, X, ldx, X, ldx, kb, ke, smem, wave, lane, arow0, bcol0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!tri && i >= 2) break;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (tri && j < i) continue;
+          const int col = bcol0 + j * 16 + fr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = arow0 + i * 16 + fq + 4 * r;
+            const double v = acc[i][j][r];
+            C[(int64_t)row * ldc + col] = v;
+            if (!(tri && i == j)) C[(int64_t)col * ldc + row] = v;
+          }
+        }
+      }
+    } else {
+      tile_product<0>(acc, X, ldx, Y, ldy, kb, ke, smem, wave, lane, wm * 64, wn * 64, neg ? -1.0 : 1.0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double *crow = C + (int64_t)(wm * 64 + i * 16 + 4 * r) * ldc + wn * 64;
+          const int lo = fq * (int)ldc + fr;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) crow[lo + j * 16] = acc[i][j][r];
+        }
+    }
+    const long long t_item1 = g.dbg ? wall_clock64() : 0;
+    publish_begin();
+    if (type == IT_SYRK) {
+      // the workgroup that completes the tile's last K-chunk sums the slabs (fixed order: bit-identical to finalize_pack_kernel)
+      const int tm = ia, tn = ib;
+      if (tid == 0) {
+        if (!(g.dflags & 3)) release_agent();
+        const int done = atomicAdd(g.sync + sy_tilecnt(T, tile_index(tm, tn, T)), 1);
+        s_flag = done == g.splits - 1;
+        if (s_flag) acquire_agent();
+      }
+      __syncthreads();
+      if (s_flag && (g.dflags & 4)) {
+        if (tid == 0) atomicAdd(g.sync + SY_ROWFINAL + tm, 1);
+      } else if (s_flag) {
+        const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BM;
+        double *dst = g.apk + tile_index(tm, tn, T) * TB * TB;
+        const int c2 = 2 * (tid & 63);
+        const int64_t j = n0 + c2;
+        for (int h0 = 0; h0 < 32; h0 += 4) {
+          double a0[4], a1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a0[u] = a1[u] = 0.0;
+          for (int s = 0; s < g.splits; ++s) {     // (K-chunks in order: bit-identical to finalize_pack_kernel; four rows' loads in flight)
+            v2d v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              v[u] = *reinterpret_cast<const v2d *>(g.slabs + (m0 + (tid >> 6) + 4 * (h0 + u)) * g.lds + j + s * g.split_stride);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              a0[u] += v[u].x;
+              a1[u] += v[u].y;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int r = (tid >> 6) + 4 * (h0 + u);
+            const int64_t i = m0 + r;
+            if (g.prior) {
+              if (g.prior_dense) {
+                a0[u] += g.prior[i * g.P + j];
+                a1[u] += g.prior[i * g.P + j + 1];
+              } else {
+                if (i == j) a0[u] += g.prior[i];
+                if (i == j + 1) a1[u] += g.prior[i];
+              }
+            }
+            v2d o;
+            o.x = a0[u]; o.y = a1[u];
+            *reinterpret_cast<v2d *>(dst + r * TB + c2) = o;
+          }
+        }
+        publish_begin();
+        if (tid == 0) {
+          if (!(g.dflags & 2)) release_agent();
+          atomicAdd(g.sync + SY_ROWFINAL + tm, 1);
+        }
+      }
+    } else if (tid == 0) {
+      if (!(g.dflags & 2)) release_agent();
+      if (type == IT_PANEL) st_relaxed(g.sync + sy_pdone(T, ia, ic), 1);
+      else st_relaxed(g.sync + sy_ver(T, ib, ic), ia + 1);
+    }
+    if (g.dbg && tid == 0) {      // per item type: [count, ticks of the product + epilogue, ticks of the hand-off] at dbg[8 + 4 T + 3 type]
+      const long long t2 = wall_clock64();
+      unsigned long long *acct = reinterpret_cast<unsigned long long *>(g.dbg + 8 + 4 * T + 3 * type);
+      atomicAdd(acct, 1ull);
+      atomicAdd(acct + 1, (unsigned long long)(t_item1 - t_item0));
+      atomicAdd(acct + 2, (unsigned long long)(t2 - t_item1));
+    }
+    __syncthreads();      // s_item / s_flag and the stage buffers are free again
+  }
+}
+
+// ---- the chain's small kernels: stream B ---------------------------------------------------------------------------
+// diagonal block k before it is factored: M[k, k] = (accumulated updates) + A[k, k] + mu D^2, with the update of the
+// scaling D for these 128 parameters (lm_accept_tail_kernel's rule: the later launch finds D as it would make it).
+// Before that: the panel tile (k - 1, k) the previous launch made is published.  grid = 8 workgroups x 16 rows.
+__global__ __launch_bounds__(256) void sf_diag_prep_kernel(SfDev g, int k, int scaler, double *dscale, const double *mu_dev) {
+  __shared__ int ok;
+  const int T = g.T, tid = threadIdx.x;
+  if (tid == 0) {
+    if (blockIdx.x == 0 && k > 0) {
+      release_agent();
+      st_relaxed(g.sync + sy_pdone(T, k - 1, k), 1);
+      bump_epoch(g);
+      stamp(g, 8 + 4 * (k - 1) + 3);
+    }
+    if (blockIdx.x == 0 && k == 0) {
+      *g.info = 0;
+      stamp(g, 0);
+    }
+    bool good = wait_ge(g, g.sync + SY_ROWFINAL + k, T - k);
+    if (good && k >= 2) good = wait_ge(g, g.sync + sy_ver(T, k, k), k - 1);
+    if (good) acquire_agent();
+    if (blockIdx.x == 0) stamp(g, 8 + 4 * k + 0);
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  const double mu = *mu_dev;
+  const double *src = g.apk + tile_index(k, k, T) * TB * TB;
+  double *C = g.M + (int64_t)k * BM * g.ldm + (int64_t)k * BM;
+  const int c2 = 2 * (tid & 63);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int r = blockIdx.x * 16 + (tid >> 6) + 4 * h;
+    v2d v = *reinterpret_cast<const v2d *>(src + r * TB + c2);
+    if (r == c2 || r == c2 + 1) {
+      const int64_t j = (int64_t)k * BM + r;
+      const double a = r == c2 ? v.x : v.y;
+      const double cn = sqrt(a > 0.0 ? a : 0.0);
+      double d;
+      if (scaler == LSQAMD_SCALE_LEVENBERG) d = dscale[j];
+      else if (scaler == LSQAMD_SCALE_MORE) d = fmax(dscale[j], cn);
+      else d = cn == 0.0 ? 1.0 : cn;
+      dscale[j] = d;
+      if (mu != 0.0) {
+        if (r == c2) v.x += mu * d * d;
+        else v.y += mu * d * d;
+      }
+    }
+    if (k >= 2) {
+      const v2d m = *reinterpret_cast<const v2d *>(C + (int64_t)r * g.ldm + c2);
+      v.x += m.x;
+      v.y += m.y;
+    }
+    *reinterpret_cast<v2d *>(C + (int64_t)r * g.ldm + c2) = v;
+  }
+}
+
+// after the diagonal block: inv(U_kk) is published (the workers may start row k's panel tiles), then the tile right of
+// the diagonal -- tile column k + 1, the right-hand side when k is the last row -- gets its share of A.  8 workgroups.
+__global__ __launch_bounds__(256) void sf_next_prep_kernel(SfDev g, int k) {
+  __shared__ int ok;
+  const int T = g.T, tid = threadIdx.x, tn = k + 1;
+  if (tid == 0) {
+    if (blockIdx.x == 0) {
+      release_agent();
+      st_relaxed(g.sync + SY_DIAGPUB, k + 1);
+      bump_epoch(g);
+      stamp(g, 8 + 4 * k + 1);
+    }
+    bool good = wait_ge(g, g.sync + sy_ver(T, k, tn), k);
+    if (good) acquire_agent();
+    if (blockIdx.x == 0) stamp(g, 8 + 4 * k + 2);
+    ok = good;
+  }
+  __syncthreads();
+  if (!ok) return;
+  const double *src = tn < T ? g.apk + tile_index(k, tn, T) * TB * TB : nullptr;
+  double *C = g.M + (int64_t)k * BM * g.ldm + (int64_t)tn * BM;
+  const int c2 = 2 * (tid & 63);
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    const int r = blockIdx.x * 16 + (tid >> 6) + 4 * h;
+    v2d v;
+    if (src) {
+      v = *reinterpret_cast<const v2d *>(src + r * TB + c2);
+    } else {
+      v.x = c2 == 0 ? g.gvec[(int64_t)k * BM + r] : 0.0;
+      v.y = 0.0;
+    }
+    if (k > 0) {
+      const v2d m = *reinterpret_cast<const v2d *>(C + (int64_t)r * g.ldm + c2);
+      v.x += m.x;
+      v.y += m.y;
+    }
+    *reinterpret_cast<v2d *>(C + (int64_t)r * g.ldm + c2) = v;
+  }
+}
+
+__global__ void sf_publish_last_kernel(SfDev g, int k) {
+  if (threadIdx.x == 0) {
+    release_agent();
+    st_relaxed(g.sync + sy_pdone(g.T, k, k + 1), 1);
+    bump_epoch(g);
+    stamp(g, 8 + 4 * k + 3);
+  }
+}
+
+}  // namespace
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+size_t sf_sync_bytes(int64_t P) { return sy_words((int)(P / BM)) * sizeof(int32_t); }
+
+int64_t sf_q1_count(int64_t P, int32_t splits) {
+  const int64_t T = P / BM;
+  return T * (T + 1) / 2 * (splits < 1 ? 1 : splits);
+}
+
+int64_t sf_q2_count(int64_t P) {
+  const int64_t T = P / BM;
+  int64_t n = 0;
+  for (int64_t k = 0; k < T; ++k) {
+    n += T - (k + 2) + 1 > 0 ? T - (k + 2) + 1 : 0;                       // panel tiles tn = k + 2 .. T
+    for (int64_t tm = k + 1; tm < T; ++tm) n += (T - tm + 1) - (tm == k + 1 ? 1 : 0);
+  }
+  return n;
+}
+
+// Q1: groups of `group_rows` tile rows in order; inside a group K-chunk by K-chunk, tile columns left to right; the group's
+// list is cut into eight equal runs, one per XCD (neighbours share the K-chunk and row / column panels), and every XCD's
+// run of the whole list is the concatenation of its runs of the groups: all XCDs work on the same rows at the same time.
+void sf_q1_fill(int64_t P, int32_t splits, int group_rows, int32_t *out, int32_t run0[9]) {
+  const int T = (int)(P / BM);
+  if (splits < 1) splits = 1;
+  if (group_rows < 1) group_rows = 1;
+  std::vector<std::vector<int32_t>> runs(8);
+  std::vector<int32_t> grp;
+  for (int r0 = 0; r0 < T; r0 += group_rows) {
+    const int r1 = r0 + group_rows < T ? r0 + group_rows : T;
+    grp.clear();
+    for (int s = 0; s < splits; ++s)
+      for (int tn = r0; tn < T; ++tn)
+        for (int tm = r0; tm < r1 && tm <= tn; ++tm) {
+          grp.push_back(tm); grp.push_back(tn); grp.push_back(s); grp.push_back(0);
+        }
+    const int64_t nw = (int64_t)grp.size() / 4, q = nw / 8, r = nw % 8;
+    int64_t b = 0;
+    for (int x = 0; x < 8; ++x) {
+      const int64_t n = q + (x < r ? 1 : 0);
+      runs[x].insert(runs[x].end(), grp.begin() + 4 * b, grp.begin() + 4 * (b + n));
+      b += n;
+    }
+  }
+  int64_t o = 0;
+  for (int x = 0; x < 8; ++x) {
+    run0[x] = (int32_t)(o / 4);
+    for (int32_t v : runs[x]) out[o++] = v;
+  }
+  run0[8] = (int32_t)(o / 4);
+}
+
+void sf_q2_fill(int64_t P, int32_t *out) {
+  const int T = (int)(P / BM);
+  int64_t o = 0;
+  for (int k = 0; k < T; ++k) {
+    for (int tn = k + 2; tn <= T; ++tn) {
+      out[o++] = IT_PANEL; out[o++] = k; out[o++] = k; out[o++] = tn;
+    }
+    for (int tm = k + 1; tm < T; ++tm)
+      for (int tn = tm; tn <= T; ++tn) {
+        if (tm == k + 1 && tn == k + 1) continue;       // the chain updates the next diagonal block itself
+        out[o++] = IT_TRAIL; out[o++] = k; out[o++] = tm; out[o++] = tn;
+      }
+  }
+}
+
+static bool g_sf_attr = false;
+
+hipError_t sf_launch(const SfLaunch &a) {
+  if (!g_sf_attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sf_worker_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)SF_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    g_sf_attr = true;
+  }
+  const int T = (int)(a.P / BM);
+  SfDev g;
+  g.J = a.J; g.ldj = a.ldj; g.K = a.n_rows;
+  g.splits = a.splits < 1 ? 1 : a.splits;
+  int64_t kchunk = (a.n_rows + g.splits - 1) / g.splits;
+  kchunk = (kchunk + BK - 1) / BK * BK;
+  g.kchunk = kchunk;
+  g.slabs = a.slabs; g.lds = a.ld_slab; g.split_stride = a.split_stride;
+  g.M = a.M; g.ldm = a.ldm;
+  g.uinv = a.uinv;
+  g.apk = a.apk; g.prior = a.prior; g.prior_dense = a.prior_dense;
+  g.gvec = a.gvec;
+  g.P = a.P; g.T = T;
+  g.q1 = reinterpret_cast<const int4 *>(a.q1);
+  for (int i = 0; i < 9; ++i) g.q1_run0[i] = a.q1_run0[i];
+  g.q2 = reinterpret_cast<const int4 *>(a.q2);
+  g.q2_len = (int32_t)sf_q2_count(a.P);
+  g.sync = a.sync;
+  g.info = a.info;
+  g.dbg = a.dbg;
+  g.idle_max = a.idle_max < 1 ? 1 : a.idle_max;
+  {
+    const char *e = getenv("LSQAMD_SF_DEBUG");      // developer switches, read per call
+    g.dflags = e ? atoi(e) : 0;
+  }
+  hipError_t e = hipMemsetAsync(a.sync, 0, sf_sync_bytes(a.P), a.st_main);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(a.ev_fork, a.st_main);
+  if (e != hipSuccess) return e;
+  e = hipStreamWaitEvent(a.st_work, a.ev_fork, 0);
+  if (e != hipSuccess) return e;
+  e = hipStreamWaitEvent(a.st_chain, a.ev_fork, 0);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sf_worker_kernel, dim3((unsigned)a.n_workers), dim3(256), SF_LDS_BYTES, a.st_work, g);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // the chain: diagonal block, the tile to its right, its panel -- row by row
+  for (int k = 0; k < T; ++k) {
+    hipLaunchKernelGGL(sf_diag_prep_kernel, dim3(8), dim3(256), 0, a.st_chain, g, k, a.scaler, a.dscale, a.mu_dev);
+    double *Akk = a.M + (int64_t)k * BM * a.ldm + (int64_t)k * BM;
+    double *uinv_k = a.uinv + (int64_t)k * BM * BM;
+    if (k == 0) {
+      e = launch_potf2_mfma(a.st_chain, Akk, a.ldm, BM, uinv_k, a.info, 0, 1, 0, 0, nullptr);
+    } else {
+      // panel rows k - 1 over the 128 columns of block k; workgroup 0's part of the fused launch only
+      const double *Pk = a.M + (int64_t)(k - 1) * BM * a.ldm + (int64_t)k * BM;
+      e = launch_trail_potf2(a.st_chain, Pk, Akk, a.ldm, BM, BM, BM, uinv_k, a.info, (int32_t)(k * BM));
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sf_next_prep_kernel, dim3(8), dim3(256), 0, a.st_chain, g, k);
+    GemmTN p;  // the one panel tile the chain makes itself: U[k, k + 1] (the right-hand side for the last row)
+    p.X = uinv_k; p.ldx = BM;
+    p.Y = a.M + (int64_t)k * BM * a.ldm + (int64_t)(k + 1) * BM; p.ldy = a.ldm;
+    p.C = const_cast<double *>(p.Y); p.ldc = a.ldm;
+    p.M = BM; p.N = BM; p.K = BM;
+    p.x_upper_tri = 1;
+    e = launch_gemm_tn(a.st_chain, p);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(sf_publish_last_kernel, dim3(1), dim3(64), 0, a.st_chain, g, T - 1);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(a.ev_work, a.st_work);
+  if (e != hipSuccess) return e;
+  e = hipEventRecord(a.ev_chain, a.st_chain);
+  if (e != hipSuccess) return e;
+  e = hipStreamWaitEvent(a.st_main, a.ev_work, 0);
+  if (e != hipSuccess) return e;
+  return hipStreamWaitEvent(a.st_main, a.ev_chain, 0);
+}
+
+// ---- CU-masked streams ----------------------------------------------------------------------------------------------
+// reserve `r` CUs on every XCD for the chain, the rest for the workers.  How mask bits map to (XCD, CU) is not documented for
+// this runtime: mode 'c' takes bit 32 x + j as CU j of XCD x, mode 'i' bit 8 j + x (tools/exp_cumask.py measures which).
+int sf_streams_create(int reserve_per_xcd, int mode, hipStream_t *work, hipStream_t *chain, int *n_work_cus) {
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+  const int ncu = prop.multiProcessorCount;
+  if (ncu != 256 || reserve_per_xcd < 1 || reserve_per_xcd > 16) return -2;
+  uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int x = 0; x < 8; ++x)
+    for (int j = 0; j < 32; ++j) {
+      const int bit = mode == 'i' ? 8 * j + x : 32 * x + j;
+      if (j < reserve_per_xcd) mc[bit >> 5] |= 1u << (bit & 31);
+      else mw[bit >> 5] |= 1u << (bit & 31);
+    }
+  if (hipExtStreamCreateWithCUMask(work, 8, mw) != hipSuccess) {
+    (void)hipGetLastError();
+    return -3;
+  }
+  if (hipExtStreamCreateWithCUMask(chain, 8, mc) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(*work);
+    return -3;
+  }
+  *n_work_cus = ncu - 8 * reserve_per_xcd;
+  return 0;
+}
+
+namespace {
+__global__ void sf_where_kernel(uint32_t *out) {
+  if (threadIdx.x == 0) {
+    out[2 * blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20);        // XCC_ID
+    out[2 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_ID
+  }
+  // stay resident long enough for the whole grid to be placed side by side
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 20000) __builtin_amdgcn_s_sleep(8);
+}
+}  // namespace
+
+}  // namespace lsqamd
+
+extern "C" {
+
+// developer probe (tools/exp_cumask.py): where do the workgroups of a launch on `stream` run?  out[2 b] = XCC_ID, out[2 b + 1] = HW_ID
+int lsqamd_debug_where(void *stream, int32_t n_wg, uint32_t *dev_out, int32_t lds_bytes) {
+  hipLaunchKernelGGL(lsqamd::sf_where_kernel, dim3((unsigned)n_wg), dim3(64), (size_t)lds_bytes, reinterpret_cast<hipStream_t>(stream), dev_out);
+  return hipGetLastError() == hipSuccess ? 0 : LSQAMD_EHIP;
+}
+
+size_t lsqamd_op_sf_work_bytes(int64_t n_rows, int64_t P, int32_t splits) {
+  using namespace lsqamd;
+  if (P % 128 || P < 256) return 0;
+  const int64_t ldm = P + 128;
+  size_t b = 0;
+  auto add = [&](size_t n) { b += (n + 255) / 256 * 256; };
+  add(sizeof(double) * (size_t)splits * P * ldm);       // slabs
+  add(sizeof(double) * (size_t)(P / 128) * 128 * 128);  // uinv
+  add(sizeof(int32_t) * 4 * (size_t)sf_q1_count(P, splits));
+  add(sizeof(int32_t) * 4 * (size_t)sf_q2_count(P));
+  add(sf_sync_bytes(P));
+  add(256);                                             // info, mu
+  return b;
+}
+
+// developer / test entry point: the streamed factorisation on its own.
+//   J [n_rows][ldj] (P columns used), prior (nullable; dense P x P or diagonal), g [P], mu, d [P] (updated like the LM scaling),
+//   -> apk (packed tiles of A = J^T J + prior), M [P][P + 128] (U; column P = U^-T g), info.
+// reserve_per_xcd 0: no CU masks (both launch sets on plain streams: for checking results only -- may not overlap)
+int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_rows, int64_t P, int32_t splits, int32_t group_rows,
+                        int32_t reserve_per_xcd, int32_t mask_mode, const double *prior, int32_t prior_dense, const double *g,
+                        double mu, int32_t scaler, double *d, double *apk, double *M, void *work, size_t work_bytes,
+                        int32_t *info_host, long long *dbg, int32_t idle_max) {
+  using namespace lsqamd;
+  if (P % 128 || P < 256 || n_rows % 16 || splits < 1 || work_bytes < lsqamd_op_sf_work_bytes(n_rows, P, splits)) return LSQAMD_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int64_t ldm = P + 128;
+  char *w = static_cast<char *>(work);
+  auto take = [&](size_t n) { char *p = w; w += (n + 255) / 256 * 256; return p; };
+  double *slabs = reinterpret_cast<double *>(take(sizeof(double) * (size_t)splits * P * ldm));
+  double *uinv = reinterpret_cast<double *>(take(sizeof(double) * (size_t)(P / 128) * 128 * 128));
+  int32_t *q1 = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * 4 * (size_t)sf_q1_count(P, splits)));
+  int32_t *q2 = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * 4 * (size_t)sf_q2_count(P)));
+  int32_t *sync = reinterpret_cast<int32_t *>(take(sf_sync_bytes(P)));
+  char *misc = take(256);
+  int32_t *info = reinterpret_cast<int32_t *>(misc);
+  double *mu_dev = reinterpret_cast<double *>(misc + 64);
+  SfLaunch a;
+  // (the lists are uploaded when the shape or the buffer changes: repeated calls -- timing loops -- only launch)
+  static int64_t c_P = 0, c_key = 0;
+  static void *c_work = nullptr;
+  static double c_mu = -1.0;
+  static int32_t c_run0[9];
+  const int64_t lkey = ((int64_t)splits << 16) | group_rows;
+  if (c_P != P || c_key != lkey || c_work != work || c_mu != mu) {
+    std::vector<int32_t> h1(4 * (size_t)sf_q1_count(P, splits)), h2(4 * (size_t)sf_q2_count(P));
+    sf_q1_fill(P, splits, group_rows, h1.data(), c_run0);
+    sf_q2_fill(P, h2.data());
+    if (hipMemcpyAsync(q1, h1.data(), h1.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(q2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(mu_dev, &mu, sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemsetAsync(info, 0, 64, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+      return LSQAMD_EHIP;
+    c_P = P; c_key = lkey; c_work = work; c_mu = mu;
+  }
+  for (int i = 0; i < 9; ++i) a.q1_run0[i] = c_run0[i];
+  static hipStream_t s_work = nullptr, s_chain = nullptr;
+  static int s_key = -1, s_cus = 256;
+  const int key = reserve_per_xcd * 256 + (mask_mode & 255);
+  if (key != s_key) {
+    if (s_work) { (void)hipStreamDestroy(s_work); (void)hipStreamDestroy(s_chain); s_work = s_chain = nullptr; }
+    if (reserve_per_xcd > 0) {
+      if (sf_streams_create(reserve_per_xcd, mask_mode, &s_work, &s_chain, &s_cus) != 0) return LSQAMD_EUNSUPPORTED;
+    } else {
+      if (hipStreamCreateWithFlags(&s_work, hipStreamNonBlocking) != hipSuccess ||
+          hipStreamCreateWithFlags(&s_chain, hipStreamNonBlocking) != hipSuccess) return LSQAMD_EHIP;
+      s_cus = 224;       // leave room for the chain's launches next to the resident workers
+    }
+    s_key = key;
+  }
+  static hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+  if (!ev[0])
+    for (int i = 0; i < 3; ++i)
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return LSQAMD_EHIP;
+  a.st_main = st; a.st_work = s_work; a.st_chain = s_chain;
+  a.ev_fork = ev[0]; a.ev_work = ev[1]; a.ev_chain = ev[2];
+  a.n_workers = 2 * s_cus;
+  a.J = J; a.ldj = ldj; a.n_rows = n_rows; a.splits = splits;
+  a.slabs = slabs; a.ld_slab = ldm; a.split_stride = P * ldm;
+  a.M = M; a.ldm = ldm; a.uinv = uinv; a.apk = apk;
+  a.prior = prior; a.prior_dense = prior_dense; a.gvec = g; a.P = P;
+  a.q1 = q1; a.q2 = q2; a.sync = sync; a.info = info;
+  a.scaler = scaler; a.dscale = d; a.mu_dev = mu_dev;
+  a.dbg = dbg; a.idle_max = idle_max;
+  if (dbg && hipMemsetAsync(dbg, 0, sizeof(long long) * (size_t)(8 + 4 * (P / 128) + 16), st) != hipSuccess) return LSQAMD_EHIP;
+  if (sf_launch(a) != hipSuccess) {
+    (void)hipGetLastError();
+    return LSQAMD_EHIP;
+  }
+  if (info_host) {
+    if (hipMemcpyAsync(info_host, info, sizeof(int32_t), hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) return LSQAMD_EHIP;
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -78,10 +78,18 @@ def cuda_sync():
     torch.cuda.current_stream().synchronize()
 
 
+_COMM_IDS = {}      # (group, world) -> the id of the communicator this process already joined
+
+
 def attach_rccl(problem, rank, world, group=None):
     """Library-side communicator for this handle: rank 0 makes the id, torch.distributed
-    carries it (setup only), every rank joins."""
+    carries it (setup only), every rank joins.  The communicator belongs to the process: the second problem of a
+    job names the same id and shares it (no second ncclCommInitRank, no second broadcast)."""
     import torch.distributed as dist
+    key = (id(group) if group is not None else None, world)
+    if key in _COMM_IDS:
+        problem.comm_init(_COMM_IDS[key], rank, world)
+        return
     box = [None]
     if rank == 0:
         try:
@@ -93,6 +101,7 @@ def attach_rccl(problem, rank, world, group=None):
     if isinstance(box[0], Exception):
         raise RuntimeError(str(box[0]))
     problem.comm_init(box[0], rank, world)
+    _COMM_IDS[key] = box[0]
 
 
 def sharded_problem(model, x, whitening, rank, world, group=None, collective=None):

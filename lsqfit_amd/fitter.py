@@ -297,6 +297,12 @@ class DeviceProblem:
         _check(self.lib, self.h, self.lib.lsqamd_comm_init(self.h, uid, len(uid), int(rank), int(nranks)),
                'comm_init')
 
+    def comm_stats(self):
+        """(milliseconds the handle's communicator took to create, handles of this process sharing it)"""
+        ms, n = C.c_double(0.0), C.c_int32(0)
+        self.lib.lsqamd_comm_stats(self.h, C.byref(ms), C.byref(n))
+        return ms.value, n.value
+
     def comm_info(self):
         r, n = C.c_int32(), C.c_int32()
         self.lib.lsqamd_comm_info(self.h, C.byref(r), C.byref(n))

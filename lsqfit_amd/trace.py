@@ -953,6 +953,7 @@ def flatten_mean_err(mean, err):
         if isinstance(e, np.ndarray) and e.shape == m.shape and m.ndim > 1:
             e = e.reshape(-1)
         return m.reshape(-1), e
+    from .whiten import _components
     flat, sdev, blocks, r0 = [], [], [], 0
     for k in mean.keys():
         m = np.asarray(mean[k], float)
@@ -960,8 +961,11 @@ def flatten_mean_err(mean, err):
         n = m.size
         if e.ndim == 2 and e.shape == (n, n) and (m.ndim != 2 or m.shape != e.shape):
             sdev.append(np.sqrt(np.diag(e)))
-            if n > 1 and np.any(e - np.diag(np.diag(e)) != 0.0):
-                blocks.append((r0, e))
+            # one block per connected component of the entry's covariance, as gvar.evalcov_blocks finds them
+            # (tests/test_lsqfit.py:1011-1012,1047-1050)
+            for c in _components(e):
+                if c.size > 1:
+                    blocks.append((r0, c, e[np.ix_(c, c)]))
         elif e.shape == m.shape or e.size == 1:
             sdev.append(np.broadcast_to(e, m.shape).reshape(-1).astype(float))
         else:
@@ -969,4 +973,12 @@ def flatten_mean_err(mean, err):
         flat.append(m.reshape(-1))
         r0 += n
     flat, sdev = np.concatenate(flat), np.concatenate(sdev)
-    return flat, (dict(sdev=sdev, blocks=blocks) if blocks else sdev)
+    if not blocks:
+        return flat, sdev
+    if all(int(c[-1]) - int(c[0]) + 1 == c.size for _, c, _ in blocks):
+        return flat, dict(sdev=sdev, blocks=[(b0 + int(c[0]), cov) for b0, c, cov in blocks])
+    # components that interleave inside an entry: hand the whole covariance over, the whitening reorders the rows
+    full = np.diag(sdev ** 2)
+    for b0, c, cov in blocks:
+        full[np.ix_(b0 + c, b0 + c)] = cov
+    return flat, full

@@ -76,3 +76,76 @@ def oracle_fit(d, solver='cholesky', tol=1e-8, svdcut=1e-12, p0=None, fcn=cosmix
 def relmax(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def numpy_normal_equations(d):
+    """An independent numpy / LAPACK restatement of the whitened normal equations of a cosmix problem (tests only): every
+    covariance block whitened with its Cholesky factor -- any W with W^T W = inv(C) gives the same J^T J, J^T f, chi2
+     -- -> (normal_eq(p) -> (A, g, chi2), chi2_fn(p), log det of the whole covariance)."""
+    import scipy.linalg as sla
+    x, ymean = np.asarray(d['x'], float), np.asarray(d['ymean'], float)
+    yerr = d['yerr']
+    sd = np.asarray(yerr['sdev'] if isinstance(yerr, dict) else yerr, float)
+    blocks = yerr['blocks'] if isinstance(yerr, dict) else []
+    in_block = np.zeros(x.size, bool)
+    Ls = []
+    logdet = 0.0
+    for r0, c in blocks:
+        L = sla.cholesky(np.asarray(c, float), lower=True)
+        Ls.append((r0, L))
+        in_block[r0:r0 + L.shape[0]] = True
+        logdet += 2.0 * np.sum(np.log(np.diag(L)))
+    logdet += 2.0 * np.sum(np.log(sd[~in_block]))
+    pm, perr = np.asarray(d['prior'][0], float), np.asarray(d['prior'][1], float)
+    P = pm.size
+    if perr.ndim == 2:
+        Lp = sla.cholesky(perr, lower=True)
+        prec = sla.cho_solve((Lp, True), np.eye(P))
+        logdet += 2.0 * np.sum(np.log(np.diag(Lp)))
+    else:
+        prec = np.diag(1.0 / perr ** 2)
+        logdet += 2.0 * np.sum(np.log(perr))
+    K = P // 2
+
+    def whiten(v):
+        out = v / (sd[:, None] if v.ndim == 2 else sd)
+        for r0, L in Ls:
+            B = L.shape[0]
+            out[r0:r0 + B] = sla.solve_triangular(L, v[r0:r0 + B], lower=True)
+        return out
+
+    def chi2_fn(p):
+        r = whiten(np.cos(np.outer(x, p[K:])) @ p[:K] - ymean)
+        dp = p - pm
+        return float(r @ r + dp @ prec @ dp)
+
+    def normal_eq(p):
+        wx = np.outer(x, p[K:])
+        c, s = np.cos(wx), np.sin(wx)
+        J = whiten(np.hstack([c, -p[:K] * x[:, None] * s]))
+        r = whiten(c @ p[:K] - ymean)
+        dp = p - pm
+        return J.T @ J + prec, J.T @ r + prec @ dp, float(r @ r + dp @ prec @ dp)
+
+    return normal_eq, chi2_fn, float(logdet)
+
+
+def check_fit_vs_normal_oracle(fit, d, p0, tol=1e-6, lm_tol=(1e-8, 1e-10, 1e-10), seed=17):
+    """a converged device fit against the oracle's LM driver (oracle.lm.lm_normal: the restated gsl_multifit_nlinear trust
+    / lm / nielsen / more / convergence, src/lsqfit/_gsl.pyx:563-706) run on numpy_normal_equations from the same start:
+    p, chi2/dof, the diagonal and 64 random columns of cov, logGBF at ``tol``; -> the oracle's result"""
+    from oracle import lm as olm
+    normal_eq, chi2_fn, logdet_c = numpy_normal_equations(d)
+    ref = olm.lm_normal(p0, normal_eq, chi2_fn, tol=lm_tol, maxit=1000)
+    P = ref.x.size
+    assert relmax(fit.pmean, ref.x) < tol, relmax(fit.pmean, ref.x)
+    chi2_ref = chi2_fn(ref.x)
+    assert abs(fit.chi2 / fit.dof - chi2_ref / fit.dof) <= tol * chi2_ref / fit.dof
+    assert relmax(np.diag(fit.cov), np.diag(ref.cov)) < tol
+    cols = np.random.default_rng(seed).choice(P, size=min(64, P), replace=False)
+    assert relmax(fit.cov[:, cols], ref.cov[:, cols]) < tol
+    sign, ld = np.linalg.slogdet(ref.A)
+    logGBF_ref = 0.5 * (-ld - logdet_c - chi2_ref - fit.dof * np.log(2 * np.pi))
+    assert sign > 0 and abs(fit.logGBF - logGBF_ref) <= tol * abs(logGBF_ref), (fit.logGBF, logGBF_ref)
+    assert fit.stopping_criterion == ref.stopping_criterion or {fit.stopping_criterion, ref.stopping_criterion} <= {1, 2}
+    return ref

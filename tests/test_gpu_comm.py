@@ -64,3 +64,36 @@ def test_comm_argument_checks(amd):
     with pytest.raises(RuntimeError, match='EINVAL'):
         pr.comm_init(pr.comm_unique_id(), 2, 2)
     pr.close()
+
+
+def test_two_handles_share_one_communicator(amd):
+    """communicators belong to the process: the second handle that names an id takes a reference (no second
+    ncclCommInitRank), both fit through it one after the other, and it outlives the handle that created it"""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=512, P=128, seed=78, block=64, prior_corr=True)
+    kw = dict(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'])
+    ref = amd.nonlinear_fit(**kw)
+    wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
+    a = amd.DeviceProblem(d['model'], d['x'], wh)
+    b = amd.DeviceProblem(d['model'], d['x'], wh)
+    assert a.comm_stats() == (0.0, 0)
+    uid = a.comm_unique_id()
+    a.comm_init(uid, 0, 1)
+    ms, n = a.comm_stats()
+    assert ms > 0.0 and n == 1
+    b.comm_init(uid, 0, 1)
+    assert a.comm_stats() == (ms, 2) and b.comm_stats() == (ms, 2)          # same communicator, same set-up time
+    with pytest.raises(RuntimeError):
+        b.comm_init(uid, 0, 2)                                                 # the id names a one-rank communicator
+    b.comm_init(uid, 0, 1)
+    fa = amd.nonlinear_fit(problem=a, **kw)
+    fb = amd.nonlinear_fit(problem=b, **kw)
+    for f in (fa, fb):
+        assert np.allclose(f.pmean, ref.pmean, rtol=1e-12, atol=0) and f.nit == ref.nit
+    a.close()
+    assert b.comm_stats() == (ms, 1)
+    fb2 = amd.nonlinear_fit(problem=b, **kw)
+    assert np.array_equal(fb2.pmean, fb.pmean)
+    b.close()
+    from lsqfit_amd import _lib
+    assert _lib.load().lsqamd_comm_shutdown() == 0

@@ -95,6 +95,21 @@ def test_config3_full_size_dense_block_8192x1024(amd):
     pr.close()
 
 
+def test_config3_full_size_fit_vs_oracle(amd):
+    """configs[2] at its full size, a CONVERGED fit against the oracle's LM driver on an independent numpy restatement of the
+    whitened normal equations (Cholesky-whitened: the oracle's eigen route takes minutes at 8192^2): p, chi2/dof, diag(cov)
+    and 64 random columns of cov, logGBF at the north_star tolerance 1e-6.  Spec: src/lsqfit/_gsl.pyx:676-706,
+    src/lsqfit/__init__.py:665-725."""
+    from lsqfit_amd import synth
+    N, P = 8192, 1024
+    d = synth.make_cosmix(N=N, P=P, seed=20262, block=N, prior_corr=True)
+    p0 = d['p_true'] * (1 + 1e-6 * np.random.default_rng(3).standard_normal(P))
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=p0)
+    assert fit.error is None and fit.dof == N
+    ref = gu.check_fit_vs_normal_oracle(fit, d, p0)
+    assert abs(fit.nit - ref.nit) <= 1, (fit.nit, ref.nit)
+
+
 def test_config4_like_blocks_8192x1024(amd):
     """configs[3] scaled 8x down in both dimensions: 256-row blocks + dense prior."""
     from lsqfit_amd import synth
@@ -172,6 +187,22 @@ def test_config4_full_size_normal_equations_vs_numpy(amd, c4):
     assert gu.relmax(g, J.T @ r + prec @ dp) < 1e-8
     assert chi2 == pytest.approx(r @ r + dp @ prec @ dp, rel=1e-8)
     assert wh.logdet == pytest.approx(logdet, rel=1e-10)
+
+
+def test_config4_full_size_fit_vs_oracle(amd, c4):
+    """configs[3] -- the shape the metric is quoted on, N = 65536, P = 4096, 256-row blocks, dense correlated prior -- a CONVERGED
+    device fit against the oracle's LM driver (oracle.lm.lm_normal) on the numpy normal equations, both started 1e-4 from the
+    generating values: p, chi2/dof, diag(cov) + 64 random columns of cov, logGBF at 1e-6 (north_star).  An oracle step costs
+    ~10 s on the GPU box's host cores.  Spec: src/lsqfit/_gsl.pyx:676-706, src/lsqfit/__init__.py:665-725."""
+    d, wh = c4
+    P = 4096
+    pr = amd.DeviceProblem(d['model'], d['x'], wh)
+    p0 = d['p_true'] * (1 + 1e-4 * np.random.default_rng(6).standard_normal(P))
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=p0, problem=pr)
+    assert fit.error is None and fit.dof == 65536
+    ref = gu.check_fit_vs_normal_oracle(fit, d, p0)
+    assert abs(fit.nit - ref.nit) <= 1, (fit.nit, ref.nit)
+    pr.close()
 
 
 def test_config4_full_size_fit_properties(amd, c4):
