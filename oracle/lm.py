@@ -216,6 +216,9 @@ def _solve_tr_2d(B, g, delta):
     return V @ (-gt / (w + lam))
 
 
+TRACE = None      # a list: _drive appends one record per trial step (developer tool)
+
+
 def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor_down,
            alg='lm', avmax=0.75, h_fvv=0.02, eval_fvec=None, undamped=None, stop=None):
     """Shared trust.c/fdf.c logic.  ``evaluate(x)`` refreshes ``lin`` with the
@@ -379,6 +382,9 @@ def _drive(x0, evaluate, eval_fnorm2, lin, tol, maxit, scaler, factor_up, factor
                 actual = 1.0 - u * u
                 pred = preduction(dx, normf)
                 rho = actual / pred if pred > 0.0 else -1.0
+            if TRACE is not None:     # (developer hook, tools/trace_cosmix.py: one entry per trial step)
+                TRACE.append(dict(it=res.njev, mu=float(mu), rho=float(rho), chi2=float(fnorm2), chi2_trial=float(ft2),
+                                  Ddx=float(np.linalg.norm(diag * dx)), dx=float(np.linalg.norm(dx))))
             if rho > 0.75:
                 delta *= factor_up
             elif rho < 0.25:

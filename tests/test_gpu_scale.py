@@ -110,6 +110,27 @@ def test_config3_full_size_fit_vs_oracle(amd):
     assert abs(fit.nit - ref.nit) <= 1, (fit.nit, ref.nit)
 
 
+def test_iteration_count_from_the_prior_mean_matches_oracle(amd):
+    """the benchmark model started at SURVEY.md 8d's start, the prior mean: ~50 LM iterations at (4096, 512) (102 at the
+    headline shape: data errors of 0.1 % leave a tiny region where the Gauss-Newton model holds, tools/trace_cosmix.py) --
+    device and oracle walk the same trajectory: same number of iterations (+-1), same number of rejected trials (+-1),
+    same end point at 1e-6.  Spec: SURVEY.md App. A; src/lsqfit/_gsl.pyx:563-603."""
+    from lsqfit_amd import synth
+    from oracle import lm as olm
+    d = synth.make_cosmix(N=4096, P=512, seed=20263, block=256, prior_corr=True)
+    fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=d['p0'])
+    normal_eq, chi2_fn, _ = gu.numpy_normal_equations(d)
+    olm.TRACE = []
+    ref = olm.lm_normal(d['p0'], normal_eq, chi2_fn, tol=(1e-8, 1e-10, 1e-10), maxit=1000)
+    trace, olm.TRACE = olm.TRACE, None
+    assert ref.nit > 30                                   # (the crawl is real, not a device artefact)
+    assert abs(fit.nit - ref.nit) <= 1, (fit.nit, ref.nit)
+    s = fit.fitter_results.summary
+    assert abs((s.ntrial - s.nit) - sum(1 for r in trace if not r['rho'] > 0)) <= 1
+    assert gu.relmax(fit.pmean, ref.x) < 1e-6 and fit.chi2 == pytest.approx(chi2_fn(ref.x), rel=1e-6)
+    assert fit.stopping_criterion == ref.stopping_criterion
+
+
 def test_config4_like_blocks_8192x1024(amd):
     """configs[3] scaled 8x down in both dimensions: 256-row blocks + dense prior."""
     from lsqfit_amd import synth
