@@ -212,17 +212,18 @@ def test_config4_full_size_normal_equations_vs_numpy(amd, c4):
 
 def test_config4_full_size_fit_vs_oracle(amd, c4):
     """configs[3] -- the shape the metric is quoted on, N = 65536, P = 4096, 256-row blocks, dense correlated prior -- a CONVERGED
-    device fit against the oracle's LM driver (oracle.lm.lm_normal) on the numpy normal equations, both started 1e-4 from the
-    generating values: p, chi2/dof, diag(cov) + 64 random columns of cov, logGBF at 1e-6 (north_star).  An oracle step costs
-    ~10 s on the GPU box's host cores.  Spec: src/lsqfit/_gsl.pyx:676-706, src/lsqfit/__init__.py:665-725."""
+    device fit against the oracle's LM driver (oracle.lm.lm_normal) on the numpy normal equations: p, chi2/dof, diag(cov) + 64
+    random columns of cov, logGBF at 1e-6 (north_star).  An oracle iteration costs ~15 s on the GPU box's host cores and the fit
+    needs 15-26 of them even from 1e-7 ... 1e-4 off the generating values, so the oracle is started at the device's answer and
+    must declare convergence there (gu.check_fit_vs_normal_oracle, restart=True); the iteration-for-iteration comparison of a
+    whole trajectory runs at (4096, 512) above.  Spec: src/lsqfit/_gsl.pyx:676-706, src/lsqfit/__init__.py:665-725."""
     d, wh = c4
     P = 4096
     pr = amd.DeviceProblem(d['model'], d['x'], wh)
     p0 = d['p_true'] * (1 + 1e-4 * np.random.default_rng(6).standard_normal(P))
     fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=p0, problem=pr)
-    assert fit.error is None and fit.dof == 65536
-    ref = gu.check_fit_vs_normal_oracle(fit, d, p0)
-    assert abs(fit.nit - ref.nit) <= 1, (fit.nit, ref.nit)
+    assert fit.error is None and fit.dof == 65536 and fit.stopping_criterion in (1, 2)
+    gu.check_fit_vs_normal_oracle(fit, d, p0, restart=True)
     pr.close()
 
 
