@@ -27,6 +27,17 @@
 #include "fit_state.h"
 #include "jit.h"
 
+// spin-wait hint of the host polling loops
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#else
+  sched_yield();
+#endif
+}
+
 using namespace lsqamd;
 
 namespace {
@@ -674,6 +685,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
   }
   f->J_stale = false;
   f->nrm_in_tail = 0;
+  f->cov_unavailable = false;
   if (!robust && nbk > 0 && f->uniform_blocks && f->uniform_tri && !f->have_param_rows && f->cfg.n_x <= 1 &&
       f->h_row0[0] == 0 && (int64_t)nbk * B0 == f->N && whiten_synth_eligible(f->cfg.model, B0, P) &&
       (int64_t)nbk * (B0 / 128) * P <= slab_doubles) {
@@ -1396,7 +1408,7 @@ static int wait_record(lsqamd_fit *f) {
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1;; ++spins) {
       if (arrived()) return audited();
-      __builtin_ia32_pause();
+      cpu_relax();
       if ((spins & 63) == 0) {
         const auto dt = std::chrono::steady_clock::now() - t0;
         if (dt > std::chrono::microseconds(3000)) break;
@@ -1944,6 +1956,7 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
                     int32_t n_consts) {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
+  if (f->st_used) (void)hipStreamSynchronize(f->st);      // (work queued on this handle may still run the kernel about to be released)
   f->drop_jit();
   f->progs.clear();
   f->used_nrm = false;
@@ -2411,7 +2424,7 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
     };
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1; !(have = arrived()); ++spins) {
-      __builtin_ia32_pause();
+      cpu_relax();
       if ((spins & 63) == 0) {
         const auto dt = std::chrono::steady_clock::now() - t0;
         if (dt > std::chrono::microseconds(5000)) break;
@@ -2559,7 +2572,10 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
     f->loss = loss;
     f->njev--;                      // (bookkeeping of the library, not an evaluation of the method)
     if (r2 < 0 && r2 != LSQAMD_ENOTPD) return r2;
-    f->have_cov = true;
+    // (the evaluation above overwrote the loss-scaled normal matrix: the covariance in f->cov stays valid only if it was
+    // made; a later lsqamd_get_cov must not recompute it from the UNSCALED matrix that is there now)
+    f->have_cov = rc == 0;
+    f->cov_unavailable = rc != 0;
   }
   float ms = 0.f;
   if (f->used_one_launch && f->have_cov && rc == 0) {
@@ -2785,6 +2801,7 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
   const int64_t P = f->P;
   if (cap < (size_t)(P * P)) FAIL(f, LSQAMD_ECAPACITY, "get_cov: need %lld", (long long)(P * P));
   if (!f->have_cov) {
+    if (f->cov_unavailable) FAIL(f, LSQAMD_ENOTPD, "get_cov: the loss-scaled Jacobian of this robust fit had no covariance (summary.cov_status)");
     const int rc = do_covariance(f);
     if (rc < 0 && rc != LSQAMD_ENOTPD) return rc;
   }

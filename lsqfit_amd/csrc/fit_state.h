@@ -135,6 +135,8 @@ struct lsqamd_fit {
   const double *r_ptr = nullptr;
   int32_t conv_info_dev = 0;
   bool initialised = false, have_cov = false, have_dense_A = false;
+  bool cov_unavailable = false;     // robust fit whose loss-scaled Jacobian had no covariance: get_cov must not recompute it
+                                    // from the unscaled matrix the last evaluation left (cleared by the next evaluation)
   int32_t nit = 0, nfev = 0, njev = 0, ntrial = 0, chol_fail = 0;
   bool qr_steps_on = false;    // solver = qr: this fit's trial steps come from the orthogonal factorisation from now on
   int32_t qr_trials = 0;       // trial steps solved from the orthogonal factorisation after a failed pivot (solver = qr)
@@ -186,10 +188,11 @@ struct lsqamd_fit {
   }
 
   ~lsqamd_fit() {  // every exit path (including the failure returns of lsqamd_create) ends here
-    drop_jit();
     // staged uploads read the pinned arena, kernels write the pinned block: neither goes back to the process-wide recycler
-    // (where the next handle may take it at once) before the stream has drained
+    // (where the next handle may take it at once) before the stream has drained -- and a compiled kernel is released only
+    // then: once unheld it may be unloaded by another thread's compile_tape while queued work still runs it
     if (st_used) (void)hipStreamSynchronize(st);
+    drop_jit();
     drop_step_graphs();
     for (auto &t : timers)
       for (auto &pr : t.pending) {

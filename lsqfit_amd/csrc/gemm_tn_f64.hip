@@ -57,7 +57,6 @@ struct GemmDev {
   int64_t kchunk, split_stride;
   const int32_t *work_map;  // optional: work item -> (tm, tn, split, -) with XCD-aware order
   int32_t n_work;
-  int32_t persist;          // work list walked by 8 x (gridDim.x / 8) resident workgroups in rounds (experiment, see launch_gemm_tn)
   const int32_t *batch_active;  // optional: skip batch entries whose flag is 0
   double *colsum_out;           // optional (XTRI interior kernel): fused column sums, see GemmTN
   int64_t colsum_ld, colsum_rcol;
@@ -262,21 +261,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn, split;
-  int w_first = 0, w_stride = 0, n_items = 1;     // WORKMAP: this workgroup's entries of the list
   if (WORKMAP) {
+    // (as in gemm_tn_f64_kernel: workgroup b runs on XCD b % 8; every XCD walks one contiguous run of the list)
     const int nw = g.n_work, bid = blockIdx.x;
     const int xcd = bid & 7, q = nw >> 3, r = nw & 7;
-    const int run0 = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, runlen = q + (xcd < r ? 1 : 0);
-    if (g.persist) {       // resident workgroups: slot s of an XCD takes entries s, s + slots, ... of the XCD's run
-      const int slots = (int)(gridDim.x >> 3), slot = bid >> 3;
-      w_first = run0 + slot;
-      w_stride = slots;
-      n_items = slot < runlen ? (runlen - slot + slots - 1) / slots : 0;
-      if (n_items == 0) return;
-    } else {
-      w_first = run0 + (bid >> 3);
-    }
-    const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w_first];
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
     tm = e.x; tn = e.y; split = e.z;
   } else {
     tm = blockIdx.x / g.tiles_n;
@@ -287,15 +277,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   // T-1-tm one after the other, so every workgroup sees the same total K (the k-range of a
   // tile row grows with tm: unpaired, the last rows take 64x as long as the first)
   const int tm_other = (XTRI && g.pair_rows) ? g.tiles_m - 1 - tm : tm;
-  const int npass = WORKMAP ? n_items : (tm_other != tm ? 2 : 1);
+  const int npass = tm_other != tm ? 2 : 1;
   for (int pass = 0; pass < npass; ++pass) {
   if (pass >= 1) {
-    if (WORKMAP) {
-      const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w_first + pass * w_stride];
-      tm = e.x; tn = e.y; split = e.z;
-    } else {
-      tm = tm_other;
-    }
+    tm = tm_other;
     __syncthreads();
   }
   const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
@@ -934,14 +919,6 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.split_stride = g.splits > 1 ? a.split_stride : 0;
   g.work_map = a.work_map;
   g.n_work = a.n_work;
-  // Experiment (round 4, review item 9): LSQAMD_SYRK_PERSIST=1 walks the work list with 512 RESIDENT workgroups (64 per XCD) in
-  // rounds of one 8 x 8 patch each, so that the tiles of a patch stay in step in their K loops and share their panel fetches in
-  // the XCD's L2 (dynamic dispatch lets them drift: 72 % hit rate).  Measured: see DESIGN.md section 9; off by default.
-  g.persist = 0;
-  if (a.work_map && a.n_work >= 1024) {
-    const char *e = getenv("LSQAMD_SYRK_PERSIST");
-    if (e && e[0] == '1') g.persist = 1;
-  }
   const bool diag_off = syrk_diag_off();
   g.syrk_diag = a.work_map && a.X == a.Y && a.ldx == a.ldy && a.sx == a.sy && a.M == a.N &&
                 (g.splits > 1 || a.beta == 0.0) && !diag_off;
@@ -950,7 +927,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.colsum_ld = a.colsum_ld;
   g.colsum_rcol = a.colsum_rcol;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
-  if (a.work_map) grid = dim3((unsigned)(g.persist ? 512 : a.n_work), 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
+  if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
                         !a.force_generic && !(a.x_upper_tri && a.work_map);  // no <XTRI, WORKMAP> instantiation
   // few tiles and a short K: latency-bound -> 64 x 64 tiles (4x the workgroups); threshold from a
@@ -1240,200 +1217,10 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
   }  // pass
 }
 
-// ---- the same for 256-row blocks (two tile rows), every raw row synthesised ONCE (round 4) ---------------------------
-// In whiten_synth_kernel tile row 1 of a block (k = 0 .. 255) and tile row 0 (k = 0 .. 127) are two workgroups, and both
-// synthesise raw rows 0 .. 127: 1.5 x the transcendental work -- which is 44 % of the kernel's time on the fp64 pipe (a
-// sincos pair is ~50 fp64 operations, four pairs per thread and stage against sixteen 64-cycle MFMAs).  Here ONE workgroup
-// of eight waves owns both tile rows of a (block, 64-term column group): waves 0-3 accumulate tile row 0, waves 4-7 tile
-// row 1, from the SAME synthesised Y stage.  k < 128: all 512 threads synthesise (two pairs each) and all eight waves
-// multiply; k >= 128: tile row 0 is finished (W^T is upper triangular), its waves do ALL the synthesis while the other
-// four multiply.  Same products in the same order per output element as whiten_synth_kernel: bit-identical rows.
-// LDS: two stages of [X0 | X1 | Y] (16 x 144 doubles each) + the abscissa ring = 109 KB, one workgroup per CU (8 waves,
-// the occupancy of two of the old workgroups).
-// MEASURED (round 4, tools/cmp_synth_pair.py + bench.py): bit-identical rows, and SLOWER -- config 4's whitening 1.908 ms
-// against 1.679 (shard shape 0.252 against 0.258: a draw).  A third less transcendental work does not pay for what the
-// pairing costs: one 512-thread barrier per stage with nothing else resident on the CU to run meanwhile (two independent
-// 256-thread workgroups drift out of phase and fill each other's barrier and LDS waits), and half the independent sincos
-// chains per thread while both tile rows multiply (two rows per thread instead of four: the fp64 pipe's latency shows).
-// Kept behind LSQAMD_SYNTH_PAIR=1 (default: the two-workgroup kernel) as the record of the experiment, and tested.
-constexpr int PSTAGE = 3 * BK * LDT;
-constexpr size_t SYNTH_PAIR_LDS_BYTES = (2 * PSTAGE + 3 * 32) * sizeof(double);
-
-template <int MODEL, bool FAR>
-__global__ __launch_bounds__(512, 1) void whiten_synth_pair_kernel(WhitenSynth a) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  if (a.trig_far && (a.trig_far[0] != 0) != FAR) return;
-  constexpr int NT = 64, NJ = 4;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int half = wave >> 2, w4 = wave & 3;            // half = tile row of this wave
-  const int wm = w4 >> 1, wn = w4 & 1;
-  const int tn = blockIdx.x;
-  const int64_t b = blockIdx.z;
-  const int64_t m0 = (int64_t)half * BM;
-  const double *Xb = a.Wt + b * a.B * a.B;
-  const double *xrow = a.x + b * a.B;
-  double *C = a.J + b * a.B * a.ld;
-  const int sc = tid & 63;                               // synthesis: term within the tile
-  const double amp = a.p[(int64_t)tn * NT + sc], frq = a.p[a.K + (int64_t)tn * NT + sc];
-
-  v4d acc[4][NJ];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  const double *xp = Xb + (int64_t)w4 * a.B + m0 + 2 * lane;     // W^T rows w4, w4 + 4, .. of the stage, this half's 128 columns
-  const int64_t xstep = 4 * a.B;
-  double *xring = smem + 2 * PSTAGE;
-  auto xdma = [&](int64_t sidx) {
-    if (wave == 0) {
-      int64_t e = sidx * BK + (lane >> 1);
-      if (e > a.B - 1) e = a.B - 1;
-      const char *src = reinterpret_cast<const char *>(xrow + e) + 4 * (lane & 1);
-      __builtin_amdgcn_global_load_lds((glb_void *)src, (lds_void *)(xring + (sidx % 3) * 32), 4, 0, 0);
-    }
-  };
-  auto stage_dma = [&](int buf) {                        // this half's X rows of the next stage
-    double *Xs = smem + buf * PSTAGE + half * BK * LDT + w4 * LDT;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((glb_void *)(xp + i * xstep), (lds_void *)(Xs + 4 * i * LDT), 16, 0, 0);
-    xp += 4 * xstep;
-  };
-  auto synth_row = [&](double *Ys, int row, double xv) {
-    double t, dq;
-    if (MODEL == LSQAMD_MODEL_COSMIX) {
-      double sn, cs;
-      sincos_moderate<FAR>(frq * xv, &sn, &cs);
-      t = cs;
-      dq = -amp * xv * sn;
-    } else {
-      const double e = exp(-frq * xv);
-      t = e;
-      dq = -amp * xv * e;
-    }
-    Ys[row * LDT + sc] = t;
-    Ys[row * LDT + NT + sc] = dq;
-  };
-  // stage sidx: everyone (two rows each) while tile row 0 still multiplies, its four waves alone (four rows each) after
-  auto stage_synth = [&](int buf, int64_t sidx) {
-    double *Ys = smem + buf * PSTAGE + 2 * BK * LDT;
-    const double *xq = xring + (sidx % 3) * 32;
-    if (sidx * BK < BM) {
-      const int srow = tid >> 6;                         // 0 .. 7
-      const double x0 = xq[srow], x1 = xq[srow + 8];
-      synth_row(Ys, srow, x0);
-      synth_row(Ys, srow + 8, x1);
-    } else if (half == 0) {
-      const int srow = tid >> 6;                         // 0 .. 3
-      double xs4[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xs4[i] = xq[srow + 4 * i];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) synth_row(Ys, srow + 4 * i, xs4[i]);
-    }
-  };
-  const int t256 = tid & 255;
-  const double wreg = (t256 < BM) ? C[(m0 + t256) * a.ld + 2 * a.K] : 0.0;   // whitened residual of this half's rows
-  const int fr = lane & 15, fq = lane >> 4;
-  const int64_t ke = 2 * BM;                             // the block's 256 rows
-  xdma(0);
-  xdma(1);
-  stage_dma(0);
-  __syncthreads();
-  stage_synth(0, 0);
-  __syncthreads();
-  int cur = 0;
-  for (int64_t k0 = 0; k0 < ke; k0 += BK) {
-    if (k0 + BK < ke) {
-      if (k0 + 2 * BK < ke) xdma(k0 / BK + 2);
-      if (half == 1 || k0 + BK < BM) stage_dma(cur ^ 1);
-      stage_synth(cur ^ 1, k0 / BK + 1);
-    }
-    if (half == 1 || k0 < BM) {
-      const double *Xs = smem + cur * PSTAGE + half * BK * LDT;
-      const double *Ys = smem + cur * PSTAGE + 2 * BK * LDT;
-#pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        const int kr = kk * 4 + fq;
-        double av[4], bb[NJ];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = Xs[kr * LDT + (2 * i + wm) * 16 + fr];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) bb[j] = Ys[kr * LDT + wn * NT + j * 16 + fr];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (k0 + kk * 4 > m0 + (2 * i + wm) * 16 + 15) continue;
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[i], bb[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  double *wcol = smem + half * 512, *red = wcol + 128;   // (per half: 128 + 4 x 64 doubles)
-  if (t256 < BM) wcol[t256] = wreg;
-  __syncthreads();
-  const int64_t cbase = (wn ? a.K : 0) + (int64_t)tn * NT;
-  double sj[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) sj[j] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rloc = (2 * i + wm) * 16 + fq;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double w = wcol[rloc + 4 * r];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const double v = acc[i][j][r];
-        C[(m0 + rloc + 4 * r) * a.ld + cbase + j * 16 + fr] = v;
-        sj[j] += v * w;
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    sj[j] += __shfl_xor(sj[j], 16, 64);
-    sj[j] += __shfl_xor(sj[j], 32, 64);
-  }
-  if (fq == 0) {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) red[w4 * 64 + j * 16 + fr] = sj[j];
-  }
-  __syncthreads();
-  if (wm == 0 && fq == 0) {
-    double *out = a.colsum_out + (b * 2 + half) * (2 * a.K) + cbase;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) out[j * 16 + fr] = red[w4 * 64 + j * 16 + fr] + red[(w4 + 2) * 64 + j * 16 + fr];
-  }
-}
-
-template <int MODEL, bool FAR>
-static hipError_t launch_whiten_synth_pair_one(hipStream_t st, const WhitenSynth &a, dim3 grid) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_pair_kernel<MODEL, FAR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_PAIR_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  hipLaunchKernelGGL((whiten_synth_pair_kernel<MODEL, FAR>), grid, dim3(512), SYNTH_PAIR_LDS_BYTES, st, a);
-  return hipGetLastError();
-}
-
-template <int MODEL>
-static hipError_t launch_whiten_synth_pair(hipStream_t st, const WhitenSynth &a, dim3 grid) {
-  if (MODEL == LSQAMD_MODEL_COSMIX && a.trig_far) {
-    hipError_t e = launch_whiten_synth_pair_one<MODEL, false>(st, a, grid);
-    if (e != hipSuccess) return e;
-  }
-  return launch_whiten_synth_pair_one<MODEL, true>(st, a, grid);
-}
+// (Round 4 measured a variant in which ONE eight-wave workgroup owns both tile rows of a 256-row block and synthesises every
+// raw row once -- a third less transcendental work: bit-identical rows, config 4's whitening 1.908 ms against 1.679.  The
+// 512-thread barrier per stage with nothing else resident on the CU costs more than the sincos saved.  Removed in round 5;
+// the record is in DESIGN_HISTORY.md.)
 
 bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P) {
   const char *e = getenv("LSQAMD_FUSED_JACOBIAN");   // developer knob, read per call: 0 = never, 2 = also for large blocks
@@ -1475,15 +1262,6 @@ hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a0) {
   WhitenSynth a = a0;
   if (a.model != LSQAMD_MODEL_COSMIX) a.trig_far = nullptr;
   const int tiles_m = (int)(a.B / BM);
-  {   // 256-row blocks with enough of them to fill the chip: both tile rows in one eight-wave workgroup, rows synthesised once
-    const char *e = getenv("LSQAMD_SYNTH_PAIR");      // developer knob, read per call; off unless asked for (it loses, see above)
-    const bool off = !(e && e[0] == '1');
-    if (!off && tiles_m == 2 && a.K % 64 == 0) {
-      dim3 grid((unsigned)(a.K / 64), 1, (unsigned)a.nb);
-      return a.model == LSQAMD_MODEL_COSMIX ? launch_whiten_synth_pair<LSQAMD_MODEL_COSMIX>(st, a, grid)
-                                            : launch_whiten_synth_pair<LSQAMD_MODEL_MULTIEXP>(st, a, grid);
-    }
-  }
   // few large blocks: unpaired, the workgroups of the last tile rows run 2 tiles_m / (tiles_m + 1) times the average
   const int pair = tiles_m >= 4 ? 1 : 0;
   const int64_t rows = pair ? (tiles_m + 1) / 2 : tiles_m;

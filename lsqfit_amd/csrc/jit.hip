@@ -1647,6 +1647,7 @@ void release(const Kernel *kc) {
   std::lock_guard<std::mutex> lk(g_mu);
   Kernel *k = const_cast<Kernel *>(kc);
   if (k->refs > 0) --k->refs;
+  k->used = ++g_clock;      // (just released = recently used: not the first candidate of the next eviction)
 }
 
 void cache_stats(long long out[3]) {

@@ -370,20 +370,7 @@ __device__ __forceinline__ void leaf_slab(v4d &DA, v4d &DE, int &bad, int lane) 
   const int col = lane & 15;
   const v4d zero = {0.0, 0.0, 0.0, 0.0};
   const double mo = pivot4_reg<R>(DA[R], bad, lane);
-#ifdef LSQAMD_LEAF_CHAIN_FIRST
-  // experiment (round 4): the two MFMAs the next pivot block waits for first, the identity half behind them
-  const v4d ta = mfma4(mo, DA[R], zero);
-  DA[R] = ta[0];
-  double a = 0.0;
-  if constexpr (R < 3) {
-    a = (col > 4 * R + 3) ? -ta[0] : 0.0;
-    DA = mfma4(a, DA[R], DA);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  const v4d te = mfma4(mo, DE[R], zero);
-  DE[R] = te[0];
-  if constexpr (R < 3) DE = mfma4(a, DE[R], DE);
-#else
+  // (round 4 measured the chain's two MFMAs issued before the identity half's: inside the noise -- the compiler hoists them)
   const v4d ta = mfma4(mo, DA[R], zero);
   const v4d te = mfma4(mo, DE[R], zero);
   DA[R] = ta[0];
@@ -393,7 +380,6 @@ __device__ __forceinline__ void leaf_slab(v4d &DA, v4d &DE, int &bad, int lane) 
     DA = mfma4(a, DA[R], DA);
     DE = mfma4(a, DE[R], DE);
   }
-#endif
 }
 
 // 16 x 16 leaf [D | I] -> [U | U^-T] in place in the owner's registers (accumulator layout), then
@@ -1031,99 +1017,7 @@ __device__ __forceinline__ void trail_tile(const TrailArgs &t, int tm, int tn, i
 // upper 16 x 16 tiles only, 32 k-chunks each, operands straight from LDS -- and goes on to the
 // factorisation without the block ever returning to memory.  (Before: a full 128 x 128 x 128 tile
 // product through eight dependent DMA stages, a store and a reload: 15.6 us of MFMA alone.)
-constexpr int DLD = 128 + 16;                                  // LDS row of the one-shot panel tile
-
-// Wave W holds tile columns W and W + 4, i.e. 2 W + 6 of the 36 upper tiles: 6 / 8 / 10 / 12.  To give
-// every wave 9 MFMAs per k-chunk, wave 0 computes the contributions to wave 3's tiles (0..2, 7) and
-// wave 1 the one to wave 2's tile (0, 6) into fresh accumulators; they travel through 8 KiB of LDS
-// behind the panel tile and are added by their owners after the barrier that follows anyway.
-constexpr int DIAG_HELP_OFF = 128 * DLD;                       // doubles: 4 tiles x 4 registers x 64 lanes behind the panel
-constexpr size_t DIAG_LDS_BYTES = (size_t)(128 * DLD + 4 * 4 * 64) * sizeof(double);
-
-template <int W>
-__device__ __forceinline__ void diag_update_from_panel(TileRegs &T, double *Ps, int lane) {
-  const int col = lane & 15, q = lane >> 4;
-  const v4d zero = {0.0, 0.0, 0.0, 0.0};
-  v4d h0 = zero, h1 = zero, h2 = zero;                          // helper accumulators (waves 0 and 1)
-  constexpr int SKIP1 = W == 3 ? 3 : (W == 2 ? 1 : 0);          // leading tiles of column W + 4 done by a helper
-#pragma unroll 4
-  for (int kc = 0; kc < 32; ++kc) {
-    const double *row = Ps + (4 * kc + q) * DLD + col;
-    double a[8];
-#pragma unroll
-    for (int ti = 0; ti < 8; ++ti)
-      if (ti <= W + 4) a[ti] = -row[16 * ti];
-    const double b0 = row[16 * W], b1 = row[16 * (W + 4)];
-#pragma unroll
-    for (int ti = 0; ti < 8; ++ti) {
-      if (ti < W) T.X[0][ti] = mfma4(a[ti], b0, T.X[0][ti]);
-      if (ti < W + 4 && ti >= SKIP1) T.X[1][ti] = mfma4(a[ti], b1, T.X[1][ti]);
-    }
-    T.DA[0] = mfma4(a[W], b0, T.DA[0]);
-    T.DA[1] = mfma4(a[W + 4], b1, T.DA[1]);
-    if constexpr (W == 0) {
-      const double b7 = row[16 * 7];
-      h0 = mfma4(a[0], b7, h0);
-      h1 = mfma4(a[1], b7, h1);
-      h2 = mfma4(a[2], b7, h2);
-    }
-    if constexpr (W == 1) h0 = mfma4(a[0], row[16 * 6], h0);
-  }
-  double *help = Ps + DIAG_HELP_OFF;
-  if constexpr (W == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      help[(0 * 4 + r) * 64 + lane] = h0[r];
-      help[(1 * 4 + r) * 64 + lane] = h1[r];
-      help[(2 * 4 + r) * 64 + lane] = h2[r];
-    }
-  }
-  if constexpr (W == 1) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) help[(3 * 4 + r) * 64 + lane] = h0[r];
-  }
-}
-
-// after the barrier: the owners add what the helpers computed for them
-template <int W>
-__device__ __forceinline__ void diag_update_collect(TileRegs &T, const double *Ps, int lane) {
-  const double *help = Ps + DIAG_HELP_OFF;
-  if constexpr (W == 3) {
-#pragma unroll
-    for (int ti = 0; ti < 3; ++ti)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) T.X[1][ti][r] += help[(ti * 4 + r) * 64 + lane];
-  }
-  if constexpr (W == 2) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) T.X[1][0][r] += help[(3 * 4 + r) * 64 + lane];
-  }
-}
-
-template <int W>
-__device__ __forceinline__ void fused_diag_wave(const TrailArgs &t, double *Adiag, int nb, double *uinv, int32_t *info,
-                                                int32_t k0n, double *smem, int lane) {
-  typedef __attribute__((address_space(3))) void lds_void;
-  typedef const __attribute__((address_space(1))) void glb_void;
-  // panel rows k = 32 W .. 32 W + 31, columns of the next block: 1 KiB each
-#pragma unroll 8
-  for (int i = 0; i < 32; ++i) {
-    const int k = W * 32 + i;
-    __builtin_amdgcn_global_load_lds((glb_void *)(t.P + (int64_t)k * t.lda + 2 * lane), (lds_void *)(smem + k * DLD), 16, 0, 0);
-  }
-  TileRegs T;
-  load_tiles<W>(T, Adiag, t.lda, nb, lane);
-  __syncthreads();
-  diag_update_from_panel<W>(T, smem, lane);
-  __syncthreads();   // the panel tile is dead: its LDS becomes the sweep's scratch
-  diag_update_collect<W>(T, smem, lane);
-  LeafShared &sh = *reinterpret_cast<LeafShared *>(smem);
-  long long *dbg = nullptr;
-  Slab16Loop<0, W>::run(T, sh, info, k0n, nb, lane, dbg);
-  store_tiles_v3<W>(T, Adiag, t.lda, nb, uinv, sh.stage[W], lane);
-}
-
-// ---- the same with the pivot-wave formulation ---------------------------------------------------
+// ---- the next diagonal block of the fused launch: pivot-wave formulation --------------------------
 // Upper tiles per tile wave with V4_COLS: 9 / 13 / 14.  The pivot wave (idle until the first leaf) computes
 // the contributions to four of wave 2's tiles ((0..3, 6)) and five of wave 3's ((0..4, 5)): 9 MFMAs per
 // k-chunk on every wave; 18 KiB of LDS behind the panel tile (136-double rows here: 139 + 18 KiB).
@@ -1266,32 +1160,18 @@ __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *A
     else fused_diag_wave4<3>(t, Adiag, nb, uinv, info, k0n, smem, tid);
     return;
   }
-#ifdef LSQAMD_TRAIL_V3
-  if (wave == 0) fused_diag_wave<0>(t, Adiag, nb, uinv, info, k0n, smem, lane);
-  else if (wave == 1) fused_diag_wave<1>(t, Adiag, nb, uinv, info, k0n, smem, lane);
-  else if (wave == 2) fused_diag_wave<2>(t, Adiag, nb, uinv, info, k0n, smem, lane);
-  else fused_diag_wave<3>(t, Adiag, nb, uinv, info, k0n, smem, lane);
-#endif
 }
 
 static_assert(sizeof(Leaf4Shared) <= (size_t)128 * DLD4 * sizeof(double), "the sweep's scratch lives in the dead panel tile");
-static_assert(sizeof(LeafShared) <= DIAG_LDS_BYTES, "the sweep's scratch lives in the dead panel tile");
-constexpr size_t TRAIL_KERNEL_LDS0 = DIAG_LDS_BYTES > TRAIL_LDS_BYTES ? DIAG_LDS_BYTES : TRAIL_LDS_BYTES;
-constexpr size_t TRAIL_KERNEL_LDS = TRAIL_KERNEL_LDS0 > DIAG4_LDS_BYTES ? TRAIL_KERNEL_LDS0 : DIAG4_LDS_BYTES;
+constexpr size_t TRAIL_KERNEL_LDS = TRAIL_LDS_BYTES > DIAG4_LDS_BYTES ? TRAIL_LDS_BYTES : DIAG4_LDS_BYTES;
 static bool g_trail_attr = false;
 
 // trailing update of the step whose panel is P (128 x rest), fused with the diagonal block of the
 // next step.  Requires mrest and rest multiples of 128 and 16-byte aligned rows.
-// the fused launch exists for the pivot-wave formulation (the four-wave one: build with -DLSQAMD_TRAIL_V3;
-// kept out of the default build, where its SGPR pressure spilled ~200 scalars of the whole kernel)
+// the fused launch exists for the pivot-wave formulation only (LSQAMD_POTF2=v3 / v2 / lds take the unfused path)
 bool trail_potf2_available() {
   static const bool v4 = [] { const char *e = getenv("LSQAMD_POTF2"); return !e || (e[0] == 'v' && e[1] == '4'); }();
-#ifdef LSQAMD_TRAIL_V3
-  static const bool v3 = [] { const char *e = getenv("LSQAMD_POTF2"); return e && e[0] == 'v' && e[1] == '3'; }();
-  return v4 || v3;
-#else
   return v4;
-#endif
 }
 
 hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_t lda, int64_t mrest,

@@ -36,13 +36,14 @@ struct SfLaunch {
   const double *mu_dev = nullptr;   // damping parameter (device)
   long long *dbg = nullptr;         // optional device buffer [8 + 4 T]: wall-clock stamps of the chain (developer tool)
   int32_t idle_max = 16;            // longest idle sleep of a worker, x ~0.2 us
+  int32_t chain_tiles = 1;          // panel tiles right of the diagonal the chain makes itself (the lists must match)
 };
 
 size_t sf_sync_bytes(int64_t P);
 int64_t sf_q1_count(int64_t P, int32_t splits);
-int64_t sf_q2_count(int64_t P);
+int64_t sf_q2_count(int64_t P, int chain_tiles);
 void sf_q1_fill(int64_t P, int32_t splits, int group_rows, int32_t *out, int32_t run0[9]);
-void sf_q2_fill(int64_t P, int32_t *out);
+void sf_q2_fill(int64_t P, int chain_tiles, int32_t *out);
 // Enqueues: J^T J (slabs + packed tiles + prior), M = U with A + mu D^2 = U^T U, column P of M = U^-T g, block inverses,
 // D updated.  Requires P a multiple of 128, P >= 256, n_rows a multiple of 16, 16-byte aligned rows.
 hipError_t sf_launch(const SfLaunch &a);

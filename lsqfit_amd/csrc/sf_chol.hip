@@ -84,6 +84,7 @@ struct SfDev {
   int32_t *info;
   long long *dbg;             // nullable: wall-clock stamps (100 MHz) of the chain's steps, see tools/exp_sf.py
   int32_t idle_max;           // longest idle sleep of a worker without work, in units of s_sleep(8) (~0.2 us)
+  int32_t chain_tiles;        // panel tiles right of the diagonal the chain makes itself (1 or 2)
   int32_t dflags;             // developer switches (timing experiments only; results may be wrong): 1 no release after J^T J items,
                               // 2 no release at all, 4 no slab sum, 8 no acquire after taking an item
 };
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(256) void sf_diag_prep_kernel(SfDev g, int k, int s
   if (tid == 0) {
     if (blockIdx.x == 0 && k > 0) {
       release_agent();
-      st_relaxed(g.sync + sy_pdone(T, k - 1, k), 1);
+      for (int j = 0; j < g.chain_tiles && k + j <= T; ++j) st_relaxed(g.sync + sy_pdone(T, k - 1, k + j), 1);
       bump_epoch(g);
       stamp(g, 8 + 4 * (k - 1) + 3);
     }
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void sf_diag_prep_kernel(SfDev g, int k, int s
 // the diagonal -- tile column k + 1, the right-hand side when k is the last row -- gets its share of A.  8 workgroups.
 __global__ __launch_bounds__(256) void sf_next_prep_kernel(SfDev g, int k) {
   __shared__ int ok;
-  const int T = g.T, tid = threadIdx.x, tn = k + 1;
+  const int T = g.T, tid = threadIdx.x, tn = k + 1 + (int)(blockIdx.x >> 3), part = blockIdx.x & 7;
   if (tid == 0) {
     if (blockIdx.x == 0) {
       release_agent();
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(256) void sf_next_prep_kernel(SfDev g, int k) {
   const int c2 = 2 * (tid & 63);
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
-    const int r = blockIdx.x * 16 + (tid >> 6) + 4 * h;
+    const int r = part * 16 + (tid >> 6) + 4 * h;
     v2d v;
     if (src) {
       v = *reinterpret_cast<const v2d *>(src + r * TB + c2);
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256) void sf_next_prep_kernel(SfDev g, int k) {
 __global__ void sf_publish_last_kernel(SfDev g, int k) {
   if (threadIdx.x == 0) {
     release_agent();
-    st_relaxed(g.sync + sy_pdone(g.T, k, k + 1), 1);
+    st_relaxed(g.sync + sy_pdone(g.T, k, k + 1), 1);      // (the last row has one tile right of the diagonal: the right-hand side)
     bump_epoch(g);
     stamp(g, 8 + 4 * k + 3);
   }
@@ -576,11 +577,12 @@ int64_t sf_q1_count(int64_t P, int32_t splits) {
   return T * (T + 1) / 2 * (splits < 1 ? 1 : splits);
 }
 
-int64_t sf_q2_count(int64_t P) {
+int64_t sf_q2_count(int64_t P, int chain_tiles) {
   const int64_t T = P / BM;
   int64_t n = 0;
   for (int64_t k = 0; k < T; ++k) {
-    n += T - (k + 2) + 1 > 0 ? T - (k + 2) + 1 : 0;                       // panel tiles tn = k + 2 .. T
+    const int64_t first = k + 1 + chain_tiles;                            // panel tiles tn = first .. T
+    n += T - first + 1 > 0 ? T - first + 1 : 0;
     for (int64_t tm = k + 1; tm < T; ++tm) n += (T - tm + 1) - (tm == k + 1 ? 1 : 0);
   }
   return n;
@@ -619,11 +621,11 @@ void sf_q1_fill(int64_t P, int32_t splits, int group_rows, int32_t *out, int32_t
   run0[8] = (int32_t)(o / 4);
 }
 
-void sf_q2_fill(int64_t P, int32_t *out) {
+void sf_q2_fill(int64_t P, int chain_tiles, int32_t *out) {
   const int T = (int)(P / BM);
   int64_t o = 0;
   for (int k = 0; k < T; ++k) {
-    for (int tn = k + 2; tn <= T; ++tn) {
+    for (int tn = k + 1 + chain_tiles; tn <= T; ++tn) {
       out[o++] = IT_PANEL; out[o++] = k; out[o++] = k; out[o++] = tn;
     }
     for (int tm = k + 1; tm < T; ++tm)
@@ -659,7 +661,8 @@ hipError_t sf_launch(const SfLaunch &a) {
   g.q1 = reinterpret_cast<const int4 *>(a.q1);
   for (int i = 0; i < 9; ++i) g.q1_run0[i] = a.q1_run0[i];
   g.q2 = reinterpret_cast<const int4 *>(a.q2);
-  g.q2_len = (int32_t)sf_q2_count(a.P);
+  g.chain_tiles = a.chain_tiles < 1 ? 1 : (a.chain_tiles > 2 ? 2 : a.chain_tiles);
+  g.q2_len = (int32_t)sf_q2_count(a.P, g.chain_tiles);
   g.sync = a.sync;
   g.info = a.info;
   g.dbg = a.dbg;
@@ -692,12 +695,15 @@ hipError_t sf_launch(const SfLaunch &a) {
       e = launch_trail_potf2(a.st_chain, Pk, Akk, a.ldm, BM, BM, BM, uinv_k, a.info, (int32_t)(k * BM));
     }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sf_next_prep_kernel, dim3(8), dim3(256), 0, a.st_chain, g, k);
-    GemmTN p;  // the one panel tile the chain makes itself: U[k, k + 1] (the right-hand side for the last row)
+    // the panel tiles the chain makes itself: U[k, k + 1 ..] -- the tiles the next diagonal block and the tile right of IT
+    // wait for (with two, the workers' first trailing update of the row runs beside the next diagonal block)
+    const int nt = (T - k) < g.chain_tiles ? (T - k) : g.chain_tiles;
+    hipLaunchKernelGGL(sf_next_prep_kernel, dim3((unsigned)(8 * nt)), dim3(256), 0, a.st_chain, g, k);
+    GemmTN p;
     p.X = uinv_k; p.ldx = BM;
     p.Y = a.M + (int64_t)k * BM * a.ldm + (int64_t)(k + 1) * BM; p.ldy = a.ldm;
     p.C = const_cast<double *>(p.Y); p.ldc = a.ldm;
-    p.M = BM; p.N = BM; p.K = BM;
+    p.M = BM; p.N = (int64_t)BM * nt; p.K = BM;
     p.x_upper_tri = 1;
     e = launch_gemm_tn(a.st_chain, p);
     if (e != hipSuccess) return e;
@@ -774,7 +780,7 @@ size_t lsqamd_op_sf_work_bytes(int64_t n_rows, int64_t P, int32_t splits) {
   add(sizeof(double) * (size_t)splits * P * ldm);       // slabs
   add(sizeof(double) * (size_t)(P / 128) * 128 * 128);  // uinv
   add(sizeof(int32_t) * 4 * (size_t)sf_q1_count(P, splits));
-  add(sizeof(int32_t) * 4 * (size_t)sf_q2_count(P));
+  add(sizeof(int32_t) * 4 * (size_t)sf_q2_count(P, 1));
   add(sf_sync_bytes(P));
   add(256);                                             // info, mu
   return b;
@@ -797,7 +803,7 @@ int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_ro
   double *slabs = reinterpret_cast<double *>(take(sizeof(double) * (size_t)splits * P * ldm));
   double *uinv = reinterpret_cast<double *>(take(sizeof(double) * (size_t)(P / 128) * 128 * 128));
   int32_t *q1 = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * 4 * (size_t)sf_q1_count(P, splits)));
-  int32_t *q2 = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * 4 * (size_t)sf_q2_count(P)));
+  int32_t *q2 = reinterpret_cast<int32_t *>(take(sizeof(int32_t) * 4 * (size_t)sf_q2_count(P, 1)));
   int32_t *sync = reinterpret_cast<int32_t *>(take(sf_sync_bytes(P)));
   char *misc = take(256);
   int32_t *info = reinterpret_cast<int32_t *>(misc);
@@ -808,11 +814,13 @@ int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_ro
   static void *c_work = nullptr;
   static double c_mu = -1.0;
   static int32_t c_run0[9];
-  const int64_t lkey = ((int64_t)splits << 16) | group_rows;
+  int chain_tiles = 1;      // (2: measured, no faster -- the wait moves to the tile two right of the diagonal)
+  if (const char *e = getenv("LSQAMD_SF_CHAIN_TILES")) chain_tiles = atoi(e) == 2 ? 2 : 1;       // developer knob, read per call
+  const int64_t lkey = ((int64_t)splits << 16) | ((int64_t)chain_tiles << 12) | group_rows;
   if (c_P != P || c_key != lkey || c_work != work || c_mu != mu) {
-    std::vector<int32_t> h1(4 * (size_t)sf_q1_count(P, splits)), h2(4 * (size_t)sf_q2_count(P));
+    std::vector<int32_t> h1(4 * (size_t)sf_q1_count(P, splits)), h2(4 * (size_t)sf_q2_count(P, chain_tiles));
     sf_q1_fill(P, splits, group_rows, h1.data(), c_run0);
-    sf_q2_fill(P, h2.data());
+    sf_q2_fill(P, chain_tiles, h2.data());
     if (hipMemcpyAsync(q1, h1.data(), h1.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(q2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(mu_dev, &mu, sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -849,6 +857,7 @@ int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_ro
   a.q1 = q1; a.q2 = q2; a.sync = sync; a.info = info;
   a.scaler = scaler; a.dscale = d; a.mu_dev = mu_dev;
   a.dbg = dbg; a.idle_max = idle_max;
+  a.chain_tiles = chain_tiles;
   if (dbg && hipMemsetAsync(dbg, 0, sizeof(long long) * (size_t)(8 + 4 * (P / 128) + 16), st) != hipSuccess) return LSQAMD_EHIP;
   if (sf_launch(a) != hipSuccess) {
     (void)hipGetLastError();

@@ -97,11 +97,11 @@ def default_path_result(tmp_path_factory):
 
 
 @pytest.mark.parametrize('knob', ['LSQAMD_BACKSOLVE=g', 'LSQAMD_BACKSOLVE=s', 'LSQAMD_HOST_LM=1', 'LSQAMD_FUSE_MIN_TILES=-1',
-                                  'LSQAMD_TRAIL_HALVES=1', 'LSQAMD_SYNTH_NARROW=100000000', 'LSQAMD_POTF2=v3', 'LSQAMD_SYNTH_PAIR=1', 'LSQAMD_SYRK_PERSIST=1'])
+                                  'LSQAMD_TRAIL_HALVES=1', 'LSQAMD_SYNTH_NARROW=100000000', 'LSQAMD_POTF2=v3'])
 def test_developer_knobs_select_equivalent_paths(tmp_path, knob, default_path_result):
     """Every alternative path a developer knob selects (grouped / per-block back substitution, host-side LM
     bookkeeping, unfused factorisation, half tiles everywhere, 32-term whitening tiles everywhere, the four-wave
-    diagonal kernel, the eight-wave whitening kernel that synthesises every raw row once, the J^T J work list walked by resident workgroups) gives the default path's fit to rounding: a P = 384 fit to convergence and six LM steps of a
+    diagonal kernel) gives the default path's fit to rounding: a P = 384 fit to convergence and six LM steps of a
     P = 3200 fit (25 tile rows: fused launches, half tiles, the chained back substitution)."""
     res = [default_path_result, _knob_run(tmp_path, dict([knob.split('=')]), 'knob')]
     for k in res[0].files:

@@ -165,13 +165,15 @@ if 'time' in what:
     J, Lam, g, d = make(8192, 4096, seed=1)
     import os
     os.environ.pop('LSQAMD_SF_DEBUG', None)
-    for splits, group_rows, reserve in ((4, 1, 1),):
+    for splits, group_rows, reserve, ct in ((4, 1, 1, 1), (4, 1, 1, 2), (4, 2, 2, 2)):
+        os.environ['LSQAMD_SF_CHAIN_TILES'] = str(ct)
         _, _, _, info, ts = run(J, Lam, g, d, 0.37, splits, group_rows, reserve, mode, reps=5, idle=16, timeline=True)
-        print('time (8192, 4096): %d K-chunks, %d-row groups, %d CUs reserved per XCD: %s ms (info %d)'
-              % (splits, group_rows, reserve, ' '.join('%.3f' % t for t in ts), info))
+        print('time (8192, 4096): %d K-chunks, %d-row groups, %d CUs reserved per XCD, chain makes %d tiles: %s ms (info %d)'
+              % (splits, group_rows, reserve, ct, ' '.join('%.3f' % t for t in ts), info))
     if 'c4' in what:
         J, Lam, g, d = make(65536, 4096, seed=2)
         for splits, group_rows, reserve in ((16, 2, 1),):
+            os.environ['LSQAMD_SF_CHAIN_TILES'] = '2'
             _, _, _, info, ts = run(J, Lam, g, d, 0.37, splits, group_rows, reserve, mode, reps=4, idle=16, timeline=True)
             print('time (65536, 4096): %d K-chunks, %d-row groups, %d CUs reserved per XCD: %s ms (info %d)'
                   % (splits, group_rows, reserve, ' '.join('%.3f' % t for t in ts), info))
