@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQAMD_ABI_VERSION 6
+#define LSQAMD_ABI_VERSION 7
 
 /* error codes (negative = backend, positive = GSL numbering) */
 #define LSQAMD_SUCCESS 0

@@ -8,7 +8,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.environ.get('LSQAMD_LIBPATH') or os.path.join(HERE, 'liblsqfit_amd.so')   # (the variable: developer builds, tools/build_variant.sh)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 COMM_ID_BYTES = 128
 
