@@ -70,30 +70,10 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
     __syncthreads();
     pp = sp;
   }
-  // the row's header (abscissa, weight, block flag, data mean) is requested one row ahead: with few terms per row -- K = 256
-  // is two trips of the term loop -- a wave otherwise sits out a global-load latency per row (rocprofv3 --pmc, config 5: 62 %
-  // of the wave-cycles parked)
-  const int64_t rstep = (int64_t)gridDim.x * 4;
-  int64_t row = (int64_t)blockIdx.x * 4 + wave;
-  double x_n = 0.0, w_n = 0.0, y_n = 0.0;
-  bool blk_n = false;
-  if (row < m.n_data) {
-    x_n = m.x[row * m.n_x];
-    blk_n = m.in_block && m.in_block[row];
-    w_n = m.wdiag[row];
-    y_n = m.ymean[row];
-  }
-  for (; row < m.n_data; row += rstep) {
-    const double x = x_n, ymean_row = y_n;
-    const bool blk = blk_n;
-    const double w = blk ? 1.0 : w_n;
-    if (row + rstep < m.n_data) {
-      const int64_t nr = row + rstep;
-      x_n = m.x[nr * m.n_x];
-      blk_n = m.in_block && m.in_block[nr];
-      w_n = m.wdiag[nr];
-      y_n = m.ymean[nr];
-    }
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < m.n_data; row += (int64_t)gridDim.x * 4) {
+    const double x = m.x[row * m.n_x];
+    const bool blk = m.in_block && m.in_block[row];
+    const double w = blk ? 1.0 : m.wdiag[row];
     double *dst = blk ? m.out_raw : m.out_w;
     double f = 0.0;
     if (JAC && !(K & 1)) {
@@ -147,7 +127,7 @@ __global__ __launch_bounds__(256) void sum_model_kernel(ModelDev m) {
     }
     f = wave_sum_all(f);
     if (lane == 0) {
-      const double delta = f - ymean_row;
+      const double delta = f - m.ymean[row];
       if (JAC)
         dst[row * m.ld + P] = w * delta;
       else
