@@ -363,10 +363,13 @@ def main():
             'ms_per_accepted_step': per_call('jacobian') + per_call('whiten') + per_call('syrk') + per_call('grad') + per_call('reduce')
                                     + per_call('cholesky') + per_call('solve') + per_call('residual'),
         }
-        # the same fit started 1e-4 (relative) from the generating values: inside the region where the Gauss-Newton model holds
+        # the same fit started a hundredth of the prior's widths from the generating values: inside the region where the Gauss-Newton model holds
         # (tools/trace_cosmix.py: with data errors of 0.1 % the fit from the prior mean spends ~9 iterations in ten on damped
         # steps that take chi2 down by 15-30 % each -- SURVEY.md 8d's "5-10 steps" is what the near start needs)
-        p_near = np.ascontiguousarray(d['p_true'] * (1 + 1e-4 * np.random.default_rng(6).standard_normal(P)))
+        # (in units of the prior's widths: a RELATIVE perturbation grows with the frequency index -- 1e-4 (k + 1) is 0.2 at k = 2048,
+        #  a phase error of 1.3 rad at x_max and outside the basin: that start does not converge in 200 iterations)
+        p_near = np.ascontiguousarray(d['p_true'] + 0.01 * np.concatenate([np.full(P // 2, 0.5), np.full(P // 2, 0.1)])
+                                      * np.random.default_rng(6).standard_normal(P))
         sn = _lib.Summary()
         t0 = time.perf_counter()
         rc_near = lib.lsqamd_run(h, _lib.dptr(p_near), C.byref(sn))
@@ -374,7 +377,7 @@ def main():
         torch.cuda.synchronize()
         near_s = time.perf_counter() - t0
         whole_fit['steps_per_s_to_convergence'] = sf.nit / fit_s if fit_s > 0 else None
-        whole_fit['near_start'] = {'start': 'p_true (1 + 1e-4 delta)', 'rc': int(rc_near), 'nit_to_convergence': int(sn.nit),
+        whole_fit['near_start'] = {'start': 'p_true + 0.01 sigma_prior delta', 'rc': int(rc_near), 'nit_to_convergence': int(sn.nit),
                                    'trials_total': int(sn.ntrial), 'stopping_criterion': int(sn.stopping_criterion),
                                    'chi2_dof': sn.chi2 / max(1, wh.nchiv - P), 'wall_s': near_s,
                                    'steps_per_s_to_convergence': sn.nit / near_s if near_s > 0 else None}
@@ -423,6 +426,12 @@ def main():
                                        'dense correlated' if dense_prior else 'diagonal', world),
                        'solver': 'lm/more/cholesky', 'collective': collective, 'restarts_in_timed_region': state['reinits'],
                        'setup_s': round(t_setup, 3), 'generate_s': round(t_generate, 3),
+                       # N > 1: what creating the library's communicator took on rank 0 (inside setup_s), and how many handles share it
+                       'comm_init_ms': (round(pr.comm_stats()[0], 3) if pr.collective == 'rccl' else None),
+                       'comm_handles': (pr.comm_stats()[1] if pr.collective == 'rccl' else None),
+                       # per-rank exchange: `reduce_ms_per_call` below is the phase between HIP events around the collective on the
+                       # step's stream -- ALL of it is exposed (the exchange is not overlapped with anything: DESIGN.md 6.2)
+                       'exchange_exposed_share': (1.0 if world > 1 else None),
                        # (the timed steps are steps of fits restarted from random points 0.3 sigma off the prior mean: far
                        #  from converged -- whole_fit below is the fit they belong to)
                        'chi2_dof_last': s.chi2 / max(1, wh.nchiv - P), 'whole_fit': whole_fit},

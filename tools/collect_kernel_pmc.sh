@@ -30,3 +30,4 @@ for tag in potrf whiten c5; do
 done
 cd $ROOT
 python3 tools/summarize_kernel_pmc.py $OUT
+for tag in potrf whiten c5; do rm -rf $OUT/$tag; done      # raw per-dispatch CSVs: tens of MB

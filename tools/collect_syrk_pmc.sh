@@ -16,3 +16,5 @@ run fetch FETCH_SIZE TCC_HIT_sum
 run write WRITE_SIZE TCC_MISS_sum
 cd $ROOT
 python3 tools/summarize_pmc.py $OUT
+# (the raw per-dispatch CSVs are tens of MB per pass: only the summary and the trimmed J^T J rows travel back)
+rm -rf $OUT/sq $OUT/fetch $OUT/write
