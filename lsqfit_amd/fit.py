@@ -84,6 +84,9 @@ class nonlinear_fit(object):
                 prior = flatten_mean_err(prior[0], prior[1])
             if p0 is not None:
                 p0 = self.traced.pack_params(p0)
+            if fitterargs.get('bounds') is not None:          # (lower, upper) shaped like the parameters, __init__.py:641-655
+                lower, upper = fitterargs['bounds']
+                fitterargs['bounds'] = (self.traced.pack_params(lower), self.traced.pack_params(upper))
         # src/lsqfit/__init__.py:471-479: neither given -> the default svdcut; eps alone -> no svdcut
         if svdcut is False and eps is False:
             svdcut, eps = DEFAULTS['svdcut'], None

@@ -11,7 +11,8 @@ row by row become predictor columns) and hands that to the formula compiler the 
 (:func:`lsqfit_amd.expr`, :func:`lsqfit_amd.piecewise`) already feeds.
 
 A function whose control flow depends on parameter values (``if p[0] > 0``, ``np.where(p > 0, ...)``, ``math.exp(p[0])``)
-cannot be recorded by one call and is refused with :class:`TraceError`.
+cannot be recorded by one call and is refused with :class:`TraceError`; a selection on the DATA (``np.where(x < 1, ...)``,
+boolean masks of ``x``) is a piecewise model and is recorded as one formula per range of rows.
 """
 import numpy as np
 
@@ -452,8 +453,21 @@ def _outer(a, b, **kw):
     return _binary('MUL', a.reshape((a.size, 1)), b.reshape((1, b.size)))
 
 
-def _where(*a, **kw):
-    raise _control_flow('numpy.where')
+def _where(cond, a=None, b=None, **kw):
+    """``numpy.where(cond, a, b)`` with a condition that does not depend on the parameters (``x < x0``: numpy has evaluated it to a
+    boolean array before the tracer sees it) is a selection by ROW -- a piecewise model, one formula per range of rows; a
+    condition on parameter values is control flow one recording cannot capture."""
+    if isinstance(cond, TArr) or _has_tracer(cond) or a is None or b is None:
+        raise _control_flow('numpy.where')
+    cond = np.asarray(cond, bool)
+    a, b = _lift(a), _lift(b)
+    shape = np.broadcast_shapes(cond.shape, a.shape, b.shape)
+    a, b = _broadcast_to(a, shape), _broadcast_to(b, shape)
+    which = np.where(np.broadcast_to(cond, shape), 0, 1).astype(np.int64)
+    pos = np.arange(int(np.prod(shape, dtype=np.int64)), dtype=np.int64).reshape(shape)
+    if a.op == 'data' and b.op == 'data':
+        return _data(np.where(np.broadcast_to(cond, shape), a.aux, b.aux))
+    return TArr('cat', (a, b), shape, (which, pos))
 
 
 _FUNCTIONS = {

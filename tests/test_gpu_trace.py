@@ -143,3 +143,34 @@ def test_plugin_called_the_way_lsqfit_calls_it(amd):
     assert got.f.shape == (33,) and got.J.shape == (33, 3)
     np.testing.assert_allclose(got.f, chiv(got.x), rtol=1e-9, atol=1e-12)
     assert got.stopping_criterion in (1, 2) and got.error is None
+
+
+def test_bounded_fit_with_dictionary_parameters(amd):
+    """fitter='mi355x_trf' with bounds given in the parameters' own shape (dictionaries, src/lsqfit/__init__.py:641-655) on a traced
+    function; one amplitude ends on its wall.  Against the oracle's restated scipy method at 1e-6."""
+    rng = np.random.default_rng(31)
+    x = np.linspace(0.1, 3.0, 60)
+
+    def fcn(x, p):
+        return p['a'][0] * np.exp(-p['E'][0] * x) + p['a'][1] * np.exp(-p['E'][1] * x) + np.where(x > 2.0, p['c'], 0.0)
+
+    def flat(x, p):
+        step = (x > 2.0).astype(float)
+        if isinstance(p, Dual):
+            return p[0] * dual.exp(-(p[2] * x)) + p[1] * dual.exp(-(p[3] * x)) + p[4] * step
+        return p[0] * np.exp(-p[2] * x) + p[1] * np.exp(-p[3] * x) + p[4] * step
+
+    truth = np.array([1.0, 0.4, 0.5, 1.6, 0.05])
+    sd = 0.01 * np.ones(60)
+    y = flat(x, truth) + sd * rng.standard_normal(60)
+    p0 = dict(a=np.array([0.8, 0.3]), E=np.array([0.4, 1.2]), c=0.0)
+    lower = dict(a=np.array([0.0, 0.0]), E=np.array([0.0, 0.0]), c=-1.0)
+    upper = dict(a=np.array([0.9, 5.0]), E=np.array([5.0, 5.0]), c=1.0)          # a[0] = 1.0 is cut off at 0.9
+    fit = amd.nonlinear_fit(data=(x, y, sd), fcn=fcn, p0=p0, fitter='mi355x_trf', bounds=(lower, upper), tol=1e-10)
+    lo = np.array([0.0, 0.0, 0.0, 0.0, -1.0])
+    hi = np.array([0.9, 5.0, 5.0, 5.0, 1.0])
+    ref = ofit.nonlinear_fit(x, y, sd, flat, p0=np.array([0.8, 0.3, 0.4, 1.2, 0.0]), tol=1e-10, fitter='scipy_least_squares',
+                             bounds=(lo, hi))
+    assert [n for n, _ in fit.model.programs] == [39, 21]                         # the step at x > 2: two formulas
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and fit.chi2 == pytest.approx(ref.chi2, rel=1e-6)
+    assert abs(fit.p['a'][0] - 0.9) < 1e-6 and fit.p['c'].shape == ()

@@ -166,6 +166,26 @@ def test_matmul_stack_concatenate():
     np.testing.assert_allclose(run_tape(tr.model, tr.x, p), fcn(p), rtol=1e-13)
 
 
+def test_selection_on_the_data_is_a_piecewise_model():
+    """numpy.where / boolean masks on x (not on parameters): rows split into one formula per range"""
+    x = np.linspace(0.0, 2.0, 10)
+
+    def fcn(x, p):
+        return np.where(x < 1.0, p[0] * x, p[1] + p[2] * np.exp(-x))
+
+    tr = amd.trace(fcn, x, np.zeros(3))
+    assert [n for n, _ in tr.model.programs] == [5, 5]
+    p = np.array([0.7, 1.1, 2.0])
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), fcn(x, p), rtol=1e-15)
+
+    def fcn2(x, p):
+        out = p[0] * x
+        return np.concatenate([out[x < 0.5], (p[1] * x ** 2)[x >= 0.5]])
+
+    tr2 = amd.trace(fcn2, x, np.zeros(2))
+    np.testing.assert_allclose(run_tape(tr2.model, tr2.x, p[:2]), fcn2(x, p[:2]), rtol=1e-15)
+
+
 @pytest.mark.parametrize('bad', [
     lambda x, p: p[0] * x if p[0] > 0 else p[1] * x,
     lambda x, p: np.where(p[0] * x > 1, p[0], p[1]),
