@@ -768,7 +768,7 @@ class Traced(object):
         flat = np.asarray(flat)
         if self.pkeys is None:
             return flat.reshape(self.pshapes[0])
-        out, i = {}, 0
+        out, i = ParamDict(), 0
         for k, s in zip(self.pkeys, self.pshapes):
             n = int(np.prod(s, dtype=np.int64))
             out[k] = flat[i:i + n].reshape(s)
@@ -776,11 +776,31 @@ class Traced(object):
         return out
 
 
+class ParamDict(dict):
+    """Dictionary of parameters with gvar.BufferDict's distribution keys: a prior entered under ``'log(a)'`` (``'sqrt(a)'``)
+    makes ``p['a']`` available to the fit function as ``exp(p['log(a)'])`` (``p['sqrt(a)'] ** 2``) -- log-normal / sqrt-normal
+    priors, tests/test_lsqfit.py:1594-1640."""
+    _INVERSE = (('log(', lambda v: np.exp(v)), ('sqrt(', lambda v: v * v))
+
+    def __missing__(self, key):
+        if isinstance(key, str):
+            for prefix, inverse in self._INVERSE:
+                full = prefix + key + ')'
+                if dict.__contains__(self, full):
+                    return inverse(dict.__getitem__(self, full))
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        if dict.__contains__(self, key):
+            return True
+        return isinstance(key, str) and any(dict.__contains__(self, pre + key + ')') for pre, _ in self._INVERSE)
+
+
 def param_tracers(p0):
     """-> (tracer(s) shaped like ``p0``, P, keys | None, shapes): the flattened order is the reference's -- arrays in C
     order, dictionaries key by key in insertion order (``gvar.BufferDict``, src/lsqfit/__init__.py:1935-1993)"""
     if hasattr(p0, 'keys'):
-        keys, shapes, out, i = list(p0.keys()), [], {}, 0
+        keys, shapes, out, i = list(p0.keys()), [], ParamDict(), 0
         for k in keys:
             s = np.shape(p0[k])
             n = int(np.prod(s, dtype=np.int64))

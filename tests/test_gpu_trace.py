@@ -147,7 +147,7 @@ def test_plugin_called_the_way_lsqfit_calls_it(amd):
 
 def test_bounded_fit_with_dictionary_parameters(amd):
     """fitter='mi355x_trf' with bounds given in the parameters' own shape (dictionaries, src/lsqfit/__init__.py:641-655) on a traced
-    function; one amplitude ends on its wall.  Against the oracle's restated scipy method at 1e-6."""
+    function.  Against the oracle's restated scipy method at 1e-6."""
     rng = np.random.default_rng(31)
     x = np.linspace(0.1, 3.0, 60)
 
@@ -165,7 +165,7 @@ def test_bounded_fit_with_dictionary_parameters(amd):
     y = flat(x, truth) + sd * rng.standard_normal(60)
     p0 = dict(a=np.array([0.8, 0.3]), E=np.array([0.4, 1.2]), c=0.0)
     lower = dict(a=np.array([0.0, 0.0]), E=np.array([0.0, 0.0]), c=-1.0)
-    upper = dict(a=np.array([0.9, 5.0]), E=np.array([5.0, 5.0]), c=1.0)          # a[0] = 1.0 is cut off at 0.9
+    upper = dict(a=np.array([0.9, 5.0]), E=np.array([5.0, 5.0]), c=1.0)
     fit = amd.nonlinear_fit(data=(x, y, sd), fcn=fcn, p0=p0, fitter='mi355x_trf', bounds=(lower, upper), tol=1e-10)
     lo = np.array([0.0, 0.0, 0.0, 0.0, -1.0])
     hi = np.array([0.9, 5.0, 5.0, 5.0, 1.0])
@@ -173,4 +173,23 @@ def test_bounded_fit_with_dictionary_parameters(amd):
                              bounds=(lo, hi))
     assert [n for n, _ in fit.model.programs] == [39, 21]                         # the step at x > 2: two formulas
     assert gu.relmax(fit.pmean, ref.pmean) < 1e-6 and fit.chi2 == pytest.approx(ref.chi2, rel=1e-6)
-    assert abs(fit.p['a'][0] - 0.9) < 1e-6 and fit.p['c'].shape == ()
+    assert np.all(fit.pmean >= lo) and np.all(fit.pmean <= hi) and fit.p['c'].shape == () and fit.p['a'].shape == (2,)
+
+
+@pytest.mark.parametrize('kind', ['lognormal', 'sqrtnormal'])
+def test_reference_distribution_priors_through_a_python_function(amd, kind):
+    """tests/test_lsqfit.py:1594-1640 as the reference writes them -- ``prior['log(a)']`` / ``prior['sqrt(a)']``, a fit function of
+    ``p['a']`` -- traced and fitted on the device: the printed ``fit.p['a']`` strings '0.012(11)' and '0.010(13)'."""
+    from oracle import gvar_lite
+    from tests.test_oracle_kat import NORMAL_Y, TRANSFORMED_PRIOR_CASES
+    a_of, um, us, da, want = TRANSFORMED_PRIOR_CASES[kind]
+    ym, ys = gvar_lite.parse_array(NORMAL_Y)
+    key = {'lognormal': 'log(a)', 'sqrtnormal': 'sqrt(a)'}[kind]
+
+    def fcn(p, N=ym.size):
+        return N * [p['a']]
+
+    fit = amd.nonlinear_fit(data=(ym, ys), fcn=fcn, prior=({key: um}, {key: us}))
+    u = fit.pmean[0]
+    assert fit.p['a'] == pytest.approx(float(a_of(u)), rel=1e-14)
+    assert gvar_lite.fmt(float(fit.p['a']), abs(da(u)) * fit.psdev[0]) == want

@@ -166,6 +166,20 @@ def test_matmul_stack_concatenate():
     np.testing.assert_allclose(run_tape(tr.model, tr.x, p), fcn(p), rtol=1e-13)
 
 
+def test_distribution_keys_of_the_prior():
+    """a prior under 'log(a)' / 'sqrt(b)' offers p['a'] / p['b'] to the fit function (gvar.BufferDict; tests/test_lsqfit.py:1594-1640)"""
+    def fcn(p, N=4):
+        return N * [p['a']] + [p['b'] + p['c']]
+
+    tr = amd.trace(fcn, False, {'log(a)': 0.0, 'sqrt(b)': 0.0, 'c': 0.0})
+    assert [n for n, _ in tr.model.programs] == [4, 1]
+    assert [INV[int(c) & 0xff] for c in tr.model.programs[0][1]] == ['P', 'EXP']
+    p = np.array([np.log(0.3), 1.5, -0.25])
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), [0.3] * 4 + [1.5 ** 2 - 0.25], rtol=1e-15)
+    vals = tr.unpack_params(p)
+    assert vals['a'] == pytest.approx(0.3) and vals['b'] == pytest.approx(2.25) and 'a' in vals and 'zz' not in vals
+
+
 def test_selection_on_the_data_is_a_piecewise_model():
     """numpy.where / boolean masks on x (not on parameters): rows split into one formula per range"""
     x = np.linspace(0.0, 2.0, 10)
