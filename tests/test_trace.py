@@ -245,3 +245,37 @@ def test_residual_function_as_lsqfit_hands_it_over():
     assert tr.n_rows == 10
     for p in (np.array([1.7, 0.6]), np.array([0.9, 1.4])):
         np.testing.assert_allclose(run_tape(tr.model, tr.x, p), chiv(p), rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_formulas_trace_to_the_string_compilers_tape(seed):
+    """the formula fuzzer of tests/test_gpu_jit_fuzz.py (wide sums with contiguous / scattered / interleaved parameter indices,
+    shared parameters, sums inside products and functions, unread parameters) written as a Python function of numpy calls:
+    recorded operation by operation (fold=False) it is the string compiler's tape, instruction for instruction -- and with
+    parameter-free arithmetic folded (the default) still the same function"""
+    from tests.test_gpu_jit_fuzz import random_formula
+    rng = np.random.default_rng(1000 + seed)
+    text, names = random_formula(rng)
+    code = compile(text, '<fuzz>', 'eval')
+    funcs = dict(exp=np.exp, cos=np.cos, sin=np.sin, sqrt=np.sqrt, log=np.log, arctan=np.arctan)
+
+    def fcn(x, p):
+        ns = dict(funcs)
+        ns['x'] = x
+        for i, n in enumerate(names):
+            ns[n] = p[i]
+        return eval(code, {'__builtins__': {}}, ns)
+
+    x = np.sort(rng.uniform(0.05, 2.0, 40))
+    P = len(names)
+    tr = amd.trace(fcn, x, np.zeros(P), fold=False)
+    ref = amd.expr(text, names)
+
+    def resolve(model):
+        return [(INV[int(c) & 0xff], float(model.consts[int(c) >> 8])) if INV[int(c) & 0xff] == 'CONST' else (INV[int(c) & 0xff], int(c) >> 8)
+                for c in model.tape]
+    assert tr.model.programs is None and resolve(tr.model) == resolve(ref)
+    p = rng.uniform(0.3, 1.2, P)
+    tf = amd.trace(fcn, x, np.zeros(P))
+    assert tf.model.tape.size <= tr.model.tape.size
+    np.testing.assert_allclose(run_tape(tf.model, tf.x, p), fcn(x, p), rtol=1e-12)
