@@ -23,6 +23,11 @@ __device__ __attribute__((noinline)) inline double cos_far(double t) { return co
 // is pi/2 to 2e-32): 1.1e-16 absolute up to |t| = 1e13 (checked against libm), where a double's own spacing is
 // already 2e-3.
 constexpr double TRIG_FAST_LIMIT = 1.0e13;
+constexpr double ROUND_MAGIC = 6755399441055744.0;      // 1.5 * 2^52
+// v with its sign flipped where bit 1 of q is set: the bit moved onto the sign bit, one shift + and + xor
+__device__ __forceinline__ double flip_sign(double v, int q) {
+  return __hiloint2double(__double2hiint(v) ^ ((q << 30) & (int)0x80000000), __double2loint(v));
+}
 // FAR = false: the caller guarantees |t| < TRIG_FAST_LIMIT (a device flag computed from the parameters, see
 // trig_range_kernel) -- no far-range code in the kernel at all
 template <bool FAR = true>
@@ -33,7 +38,11 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
     *cs = f.c;
     return;
   }
-  const double n = rint(t * 6.36619772367581382433e-01);      // 2/pi
+  // n = t * 2/pi rounded to an integer by adding 1.5 * 2^52 (|n| < 2^51: the sum's last place is 1, the rounding
+  // mode does the rest); its two low bits -- the quadrant -- are the two low bits of the sum's mantissa.  No
+  // double -> integer conversion (four instructions, none of them full rate).
+  const double m = __builtin_fma(t, 6.36619772367581382433e-01, ROUND_MAGIC);      // 2/pi
+  const double n = m - ROUND_MAGIC;
   double r = __builtin_fma(-n, 1.57079632679489655800e+00, t);   // pi/2 = HI + MID + ...
   r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
   const double z = r * r;
@@ -49,10 +58,10 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
                                    z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
   const double s = __builtin_fma(r * z, ps, r);
   const double c = __builtin_fma(z * z, pc, __builtin_fma(-0.5, z, 1.0));
-  const int q = (int)((long long)n & 3);
+  const int q = __double2loint(m);
   const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
-  *sn = (q & 2) ? -s1 : s1;
-  *cs = ((q + 1) & 2) ? -c1 : c1;
+  *sn = flip_sign(s1, q);              // quadrants 2, 3
+  *cs = flip_sign(c1, q + 1);          // quadrants 1, 2
 }
 
 // cos alone (the residual kernels): ONE polynomial with its coefficients chosen per lane by the quadrant
@@ -60,11 +69,12 @@ __device__ __forceinline__ void sincos_moderate(double t, double *sn, double *cs
 template <bool FAR = true>
 __device__ __forceinline__ double cos_moderate(double t) {
   if (FAR && !(fabs(t) < TRIG_FAST_LIMIT)) return cos_far(t);
-  const double n = rint(t * 6.36619772367581382433e-01);
+  const double m = __builtin_fma(t, 6.36619772367581382433e-01, ROUND_MAGIC);
+  const double n = m - ROUND_MAGIC;
   double r = __builtin_fma(-n, 1.57079632679489655800e+00, t);
   r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
   const double z = r * r;
-  const int q = (int)((long long)n & 3);
+  const int q = __double2loint(m);
   const bool odd = q & 1;             // cos(t) = -+ sin(r) in the odd quadrants, +- cos(r) in the even ones
   const double c5 = odd ? 1.58969099521155010221e-10 : -1.13596475577881948265e-11;
   const double c4 = odd ? -2.50507602534068634195e-08 : 2.08757232129817482790e-09;
@@ -76,7 +86,7 @@ __device__ __forceinline__ double cos_moderate(double t) {
   const double a = odd ? r * z : z * z;
   const double b = odd ? r : __builtin_fma(-0.5, z, 1.0);
   const double v = __builtin_fma(a, p, b);
-  return ((q + 1) & 2) ? -v : v;
+  return flip_sign(v, q + 1);
 }
 
 }  // namespace lsqamd

@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void whiten_synth_kernel(WhitenSynth a, int
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (a.trig_far && (a.trig_far[0] != 0) != FAR) return;    // (FAR = false: no far-range trig code, see model.hip)
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the triangular skips become scalar branches)
   const int wm = wave >> 1, wn = wave & 1;
   const int tm_first = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
   // pair_rows (blocks of many tile rows: the k-range of a tile row grows with it): this workgroup does tile

@@ -228,10 +228,11 @@ def test_cosine_model_range_flag_at_size(amd, scale):
     pr.close()
 
 
-@pytest.mark.parametrize('scale', [1.0, 1e4, 1e9, 1e14, 1e17])
+@pytest.mark.parametrize('scale', [1.0, 1e4, 1e9, 1e14, 1e17, -1.0, -3e12])
 def test_cosine_model_at_large_arguments(amd, scale):
     """cos / sin of w x in the model kernels: a two-term Cody-Waite reduction carried by FMAs up to |w x| = 1e13
-    (1.1e-16 absolute), the library routine beyond -- model values and Jacobian (analytic kernel, the kernel fused
+    (1.1e-16 absolute; the quadrant read off the mantissa of w x 2/pi + 1.5 2^52, negative arguments included), the
+    library routine beyond -- model values and Jacobian (analytic kernel, the kernel fused
     into the whitening product, and the residual kernel's cosine-only path) against numpy at every magnitude."""
     from lsqfit_amd import synth
     for block in (0, 128):
