@@ -177,3 +177,14 @@ if 'time' in what:
             _, _, _, info, ts = run(J, Lam, g, d, 0.37, splits, group_rows, reserve, mode, reps=4, idle=16, timeline=True)
             print('time (65536, 4096): %d K-chunks, %d-row groups, %d CUs reserved per XCD: %s ms (info %d)'
                   % (splits, group_rows, reserve, ' '.join('%.3f' % t for t in ts), info))
+if 'potrf' in what:
+    # the same machinery with (almost) no J^T J in front of it: the pace of the persistent factorisation alone, next to
+    # potrf_upper's 1.48 ms at P = 4096 (tools/time_potrf.py)
+    import os
+    for Pq in (4096, 1024):
+        J, Lam, g, d = make(128, Pq, seed=3)
+        for splits, group_rows, reserve, ct in ((1, 1, 1, 1), (1, 2, 1, 1), (1, 1, 2, 1), (1, 1, 1, 2)):
+            os.environ['LSQAMD_SF_CHAIN_TILES'] = str(ct)
+            _, _, _, info, ts = run(J, Lam, g, d, 0.37, splits, group_rows, reserve, mode, reps=5, idle=16, timeline=True)
+            print('time (128, %d): %d K-chunks, %d-row groups, %d CUs reserved per XCD, chain makes %d tiles: %s ms (info %d)'
+                  % (Pq, splits, group_rows, reserve, ct, ' '.join('%.3f' % t for t in ts), info))
