@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--ndata', type=int, default=0, help='override N_data (debug)')
     ap.add_argument('--nparam', type=int, default=0, help='override N_param (debug)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--two-pass', action='store_true', help='time the steps without phase timers, the phases in a second pass (always so for P <= 1024 on one rank)')
     ap.add_argument('--cpu-seconds', type=float, default=40.0)
     ap.add_argument('--whole-fit-maxit', type=int, default=200, help='iteration cap of the one whole fit reported in config.whole_fit (0: skip it)')
     return ap.parse_args()
@@ -309,7 +310,7 @@ def main():
     # timers would force back to eager launches with ~18 event records per step -- 0.30 instead of 0.19 ms at
     # (4096, 256): there the timed region runs uninstrumented and the phases are timed in a second pass of the same
     # number of steps right after it (said so in roofline.timing_pass).
-    two_pass = P <= 1024 and world == 1
+    two_pass = (P <= 1024 and world == 1) or args.two_pass
     if not two_pass:
         pr.timing(True)
         pr.timing_reset()

@@ -252,7 +252,16 @@ hipEvent_t take_event(lsqamd_fit *f) {  // events are recycled: creating one cos
 }
 
 
-void resolve_timers(lsqamd_fit *f) {
+// Between the steps of a fit the pairs just pile up: reading them back costs ~100 us of host time per step (18 event
+// queries), all of it between the arrival of a step's record and the first launch of the next -- measured as GPU idle
+// time with rocprofv3 at the 8-GPU shard shape.  They are read when somebody asks (lsqamd_get_timers / _reset /
+// _finish) or when a few hundred have piled up.
+void resolve_timers(lsqamd_fit *f, bool only_if_many = false) {
+  if (only_if_many) {
+    size_t n = 0;
+    for (auto &t : f->timers) n += t.pending.size();
+    if (n < 512) return;
+  }
   for (auto &t : f->timers) {
     for (auto &pr : t.pending) {
       (void)hipEventSynchronize(pr.second);
@@ -2320,7 +2329,7 @@ int lsqamd_step(lsqamd_fit *f, int32_t *info) {
   const int rc = iterate(f);
   if (rc < 0) return rc;
   f->nit++;
-  if (f->timing) resolve_timers(f);
+  if (f->timing) resolve_timers(f, true);
   if (rc == LSQAMD_ENOPROG) {
     if (info) *info = LSQAMD_ENOPROG;
     return LSQAMD_ENOPROG;
