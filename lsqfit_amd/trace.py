@@ -236,6 +236,52 @@ class TArr(object):
     def cumsum(self, axis=None):
         return _cumsum(self, axis)
 
+    def prod(self, axis=None, dtype=None, out=None, keepdims=False, **kw):
+        return _prod(self, axis, keepdims)
+
+    def cumprod(self, axis=None):
+        return _cumprod(self, axis)
+
+    def var(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **kw):
+        return _var(self, axis, ddof, keepdims)
+
+    def std(self, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **kw):
+        return _unary('SQRT', _var(self, axis, ddof, keepdims))
+
+    def trace(self, offset=0, axis1=0, axis2=1, **kw):
+        return _sum(self.diagonal(offset, axis1, axis2), -1)
+
+    def diagonal(self, offset=0, axis1=0, axis2=1):
+        return _gather(self, self._index_map().diagonal(offset, axis1, axis2))
+
+    def swapaxes(self, a, b):
+        return _gather(self, self._index_map().swapaxes(a, b))
+
+    def repeat(self, repeats, axis=None):
+        return _gather(self, self._index_map().repeat(repeats, axis))
+
+    def take(self, indices, axis=None, **kw):
+        return _gather(self, self._index_map().take(indices, axis))
+
+    def copy(self, *a, **kw):
+        return self
+
+    def astype(self, dtype, *a, **kw):
+        if np.dtype(dtype).kind not in 'fO':
+            raise _control_flow('a conversion to %s' % np.dtype(dtype))
+        return self
+
+    def conj(self):
+        return self
+
+    conjugate = conj
+    real = property(lambda self: self)
+
+    def _selection(self, *a, **kw):
+        raise _control_flow('max / min / sort / round / clip')
+
+    max = min = argmax = argmin = sort = argsort = round = clip = ptp = any = all = nonzero = item = tolist = _selection
+
     # -- numpy protocols ----------------------------------------------------------------------
     def __array_ufunc__(self, ufunc, method, *inputs, **kw):
         if kw.get('out') is not None:
@@ -264,10 +310,25 @@ class TArr(object):
                 return _binary('DIV', _unary('LOG', inputs[0]), float(np.log(2.0)))
             if name == 'matmul':
                 return _matmul(inputs[0], inputs[1])
+            if name == 'hypot':
+                return _unary('SQRT', _binary('ADD', _binary('POW', inputs[0], 2.0), _binary('POW', inputs[1], 2.0)))
+            if name == 'arctan2':       # 2 atan(y / (r + x)): every point but the negative real axis
+                y, x = inputs
+                r = _unary('SQRT', _binary('ADD', _binary('POW', x, 2.0), _binary('POW', y, 2.0)))
+                return _binary('MUL', 2.0, _unary('ATAN', _binary('DIV', y, _binary('ADD', r, x))))
+            if name == 'cbrt':
+                raise TraceError('numpy.cbrt has no counterpart on the device tape (x ** (1 / 3) for positive x)')
+            if name in ('conjugate', 'real'):
+                return _lift(inputs[0])
             if name in _COMPARE:
                 raise _control_flow('numpy.' + name)
         elif method == 'reduce' and name == 'add':
             return _sum(inputs[0], kw.get('axis', 0), kw.get('keepdims', False))
+        elif method == 'reduce' and name == 'multiply':
+            return _prod(inputs[0], kw.get('axis', 0), kw.get('keepdims', False))
+        elif method == 'outer' and name in _BINARY:
+            a, b = _lift(inputs[0]), _lift(inputs[1])
+            return _binary(_BINARY[name], a.reshape(a.shape + (1,) * b.ndim), b)
         raise TraceError('numpy.%s%s has no counterpart on the device tape' % (name, '' if method == '__call__' else '.' + method))
 
     def __array_function__(self, func, types, args, kwargs):
@@ -399,6 +460,139 @@ def _cumsum(a, axis=None):
     return _concatenate(parts, axis)
 
 
+def _prod(a, axis=None, keepdims=False):
+    """product along an axis: a chain of multiplications (the tape has sums of terms, not products of factors)"""
+    a = _lift(a)
+    if isinstance(axis, tuple):
+        for ax in sorted((x % a.ndim for x in axis), reverse=True):
+            a = _prod(a, ax, keepdims)
+        return a
+    if a.op == 'data':
+        return _data(a.aux.prod(axis=axis, keepdims=keepdims))
+    if axis is None:
+        shape = (1,) * a.ndim if keepdims else ()
+        a, axis = a.ravel(), 0
+        parts = [a[k] for k in range(a.shape[0])]
+    else:
+        axis = axis % a.ndim
+        sl = (slice(None),) * axis
+        parts = [a[sl + ((slice(k, k + 1) if keepdims else k),)] for k in range(a.shape[axis])]
+        shape = parts[0].shape if parts else tuple(1 if i == axis else n for i, n in enumerate(a.shape) if keepdims or i != axis)
+    if not parts:
+        return _data(np.ones(shape))
+    out = parts[0]
+    for q in parts[1:]:
+        out = _binary('MUL', out, q)
+    return out.reshape(shape)
+
+
+def _cumprod(a, axis=None):
+    a = _lift(a)
+    if axis is None:
+        a, axis = a.ravel(), 0
+    axis = axis % a.ndim
+    sl = (slice(None),) * axis
+    parts = [a[sl + (slice(0, 1),)]] if a.shape[axis] else []
+    for k in range(1, a.shape[axis]):
+        parts.append(_binary('MUL', parts[-1], a[sl + (slice(k, k + 1),)]))
+    return _concatenate(parts, axis) if parts else a
+
+
+def _var(a, axis=None, ddof=0, keepdims=False):
+    a = _lift(a)
+    n = a.size if axis is None else (int(np.prod([a.shape[x] for x in axis])) if isinstance(axis, tuple) else a.shape[axis])
+    d = _binary('SUB', a, _binary('DIV', _sum(a, axis, True), float(n)))
+    return _binary('DIV', _sum(_binary('MUL', d, d), axis, keepdims), float(n - ddof))
+
+
+def _norm(a, ord=None, axis=None, keepdims=False):
+    if ord not in (None, 2, 'fro') or (ord == 2 and axis is None and _lift(a).ndim > 1):
+        raise TraceError('numpy.linalg.norm: only the 2-norm of vectors and the Frobenius norm are traced')
+    a = _lift(a)
+    return _unary('SQRT', _sum(_binary('MUL', a, a), axis, keepdims))
+
+
+def _tensordot(a, b, axes=2):
+    a, b = _lift(a), _lift(b)
+    if isinstance(axes, (int, np.integer)):
+        axa, axb = list(range(a.ndim - axes, a.ndim)), list(range(axes))
+    else:
+        axa, axb = axes
+        axa = [axa] if isinstance(axa, (int, np.integer)) else list(axa)
+        axb = [axb] if isinstance(axb, (int, np.integer)) else list(axb)
+    axa, axb = [x % a.ndim for x in axa], [x % b.ndim for x in axb]
+    keep_a, keep_b = [i for i in range(a.ndim) if i not in axa], [i for i in range(b.ndim) if i not in axb]
+    k = int(np.prod([a.shape[i] for i in axa], dtype=np.int64))
+    if k != int(np.prod([b.shape[i] for i in axb], dtype=np.int64)):
+        raise ValueError('shape-mismatch for sum')
+    oa, ob = tuple(a.shape[i] for i in keep_a), tuple(b.shape[i] for i in keep_b)
+    a2 = a.transpose(keep_a + axa).reshape((int(np.prod(oa, dtype=np.int64)), k))
+    b2 = b.transpose(axb + keep_b).reshape((k, int(np.prod(ob, dtype=np.int64))))
+    return _matmul(a2, b2).reshape(oa + ob)
+
+
+def _einsum(subscripts, *ops, **kw):
+    """explicit or implicit subscripts without ellipses or repeated labels inside one operand: every operand is laid out over
+    the union of the labels, multiplied, and the labels that do not appear in the output are summed"""
+    if not isinstance(subscripts, str) or '.' in subscripts:
+        raise TraceError('numpy.einsum: only subscript strings without ellipses are traced')
+    sub = subscripts.replace(' ', '')
+    ins, out = sub.split('->') if '->' in sub else (sub, None)
+    ins = ins.split(',')
+    if len(ins) != len(ops):
+        raise ValueError('einsum: %d operands for %d subscript groups' % (len(ops), len(ins)))
+    labels = sorted(set(''.join(ins)))
+    if out is None:
+        out = ''.join(c for c in labels if ''.join(ins).count(c) == 1)
+    prod = None
+    for lab, o in zip(ins, ops):
+        o = _lift(o)
+        if len(set(lab)) != len(lab) or len(lab) != o.ndim:
+            raise TraceError('numpy.einsum: repeated labels inside one operand are not traced')
+        order = [lab.index(c) for c in labels if c in lab]
+        o = o.transpose(order) if o.ndim > 1 else o
+        o = o.reshape(tuple(o.shape[[c for c in labels if c in lab].index(c)] if c in lab else 1 for c in labels))
+        prod = o if prod is None else _binary('MUL', prod, o)
+    gone = tuple(i for i, c in enumerate(labels) if c not in out)
+    if gone:
+        prod = _sum(prod, gone)
+    left = [c for c in labels if c in out]
+    return prod.transpose([left.index(c) for c in out]) if len(out) > 1 else prod
+
+
+def _via_index(func):
+    """a numpy function that only rearranges / repeats elements: applied to the index map"""
+    def h(a, *args, **kw):
+        a = _lift(a)
+        r = func(a._index_map(), *args, **kw)
+        return [_gather(a, q) for q in r] if isinstance(r, (list, tuple)) else _gather(a, r)
+    return h
+
+
+def _like(value):
+    def h(a, *args, **kw):
+        shape = kw.get('shape') or _lift(a).shape
+        return _data(np.full(shape, value if value is not None else (args[0] if args else kw.get('fill_value'))))
+    return h
+
+
+def _select_triangle(func):
+    def h(a, k=0):
+        a = _lift(a)
+        keep = func(np.ones(a.shape, bool), k)
+        return _where(keep, a, 0.0)
+    return h
+
+
+def _diag(a, k=0):
+    a = _lift(a)
+    if a.ndim == 2:
+        return a.diagonal(k)
+    n = a.size + abs(k)
+    idx = np.diag(np.arange(1, a.size + 1), k)       # 0 = no element
+    return _where(idx > 0, _gather(a, np.maximum(idx - 1, 0)), 0.0)
+
+
 def _concatenate(arrays, axis=0, **kw):
     kids = [_lift(a) for a in arrays]
     if axis is None:
@@ -499,7 +693,48 @@ _FUNCTIONS = {
     np.moveaxis: lambda a, s, d: _gather(_lift(a), np.moveaxis(_lift(a)._index_map(), s, d)),
     np.swapaxes: lambda a, s, d: _gather(_lift(a), np.swapaxes(_lift(a)._index_map(), s, d)),
     np.diff: lambda a, n=1, axis=-1, **kw: _diff(a, axis),
+    np.prod: lambda a, axis=None, dtype=None, out=None, keepdims=False, **kw: _prod(a, axis, keepdims),
+    np.cumprod: lambda a, axis=None, **kw: _cumprod(a, axis),
+    np.var: lambda a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **kw: _var(a, axis, ddof, keepdims),
+    np.std: lambda a, axis=None, dtype=None, out=None, ddof=0, keepdims=False, **kw: _unary('SQRT', _var(a, axis, ddof, keepdims)),
+    np.linalg.norm: _norm,
+    np.tensordot: _tensordot,
+    np.einsum: _einsum,
+    np.inner: lambda a, b: _tensordot(a, b, ((-1,), (-1,))) if _lift(a).ndim and _lift(b).ndim else _binary('MUL', a, b),
+    np.vdot: lambda a, b: _sum(_binary('MUL', _lift(a).ravel(), _lift(b).ravel())),
+    np.trace: lambda a, offset=0, axis1=0, axis2=1, **kw: _lift(a).trace(offset, axis1, axis2),
+    np.diagonal: lambda a, offset=0, axis1=0, axis2=1: _lift(a).diagonal(offset, axis1, axis2),
+    np.diag: _diag,
+    np.triu: _select_triangle(np.triu),
+    np.tril: _select_triangle(np.tril),
+    np.tile: _via_index(np.tile),
+    np.repeat: _via_index(np.repeat),
+    np.roll: _via_index(np.roll),
+    np.rot90: _via_index(np.rot90),
+    np.fliplr: _via_index(np.fliplr),
+    np.flipud: _via_index(np.flipud),
+    np.atleast_2d: _via_index(np.atleast_2d),
+    np.split: _via_index(np.split),
+    np.array_split: _via_index(np.array_split),
+    np.delete: _via_index(np.delete),
+    np.column_stack: lambda t, **kw: _concatenate([(lambda k: k.reshape((k.size, 1)) if k.ndim < 2 else k)(_lift(x)) for x in t], 1),
+    np.append: lambda a, v, axis=None: _concatenate([a, v], axis),
+    np.zeros_like: _like(0.0),
+    np.ones_like: _like(1.0),
+    np.empty_like: _like(0.0),
+    np.full_like: _like(None),
+    np.copy: lambda a, **kw: _lift(a),
+    np.real: lambda a: _lift(a),
+    np.conj: lambda a: _lift(a),
+    np.square: lambda a: _binary('POW', a, 2.0),
+    np.average: lambda a, axis=None, weights=None, **kw: (_lift(a).mean(axis) if weights is None else
+                                                         _sum(_binary('MUL', a, np.asarray(weights, float)), axis) / float(np.sum(weights))),
 }
+for _name in ('amax', 'amin', 'max', 'min', 'argmax', 'argmin', 'sort', 'argsort', 'clip', 'round', 'around', 'median', 'percentile',
+              'quantile', 'nanmax', 'nanmin', 'maximum', 'minimum', 'sign', 'floor', 'ceil', 'trunc', 'isclose', 'allclose', 'array_equal',
+              'searchsorted', 'digitize', 'unique', 'nonzero', 'argwhere', 'any', 'all', 'interp', 'select', 'piecewise', 'heaviside'):
+    if hasattr(np, _name):
+        _FUNCTIONS[getattr(np, _name)] = (lambda n: lambda *a, **kw: (_ for _ in ()).throw(_control_flow('numpy.' + n)))(_name)
 
 
 def _diff(a, axis=-1):

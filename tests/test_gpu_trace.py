@@ -193,3 +193,42 @@ def test_reference_distribution_priors_through_a_python_function(amd, kind):
     u = fit.pmean[0]
     assert fit.p['a'] == pytest.approx(float(a_of(u)), rel=1e-14)
     assert gvar_lite.fmt(float(fit.p['a']), abs(da(u)) * fit.psdev[0]) == want
+
+
+def test_fit_function_written_with_products_norms_and_einsum(amd):
+    """the wider numpy vocabulary of the tracer (prod, linalg.norm, einsum, arctan2, hypot, subtract.outer) in ONE fit, against the
+    oracle differentiating an independently written version of the same function with its dual numbers"""
+    rng = np.random.default_rng(20266)
+    N = 60
+    x = np.linspace(0.1, 3.0, N)
+    A = rng.uniform(0.2, 1.0, (N, 2))
+    ptrue = np.array([0.8, 1.4, 0.7, 0.5, 0.3, 0.9])
+
+    def fcn(x, p):
+        amp = np.prod(p[2:4])
+        rate = np.linalg.norm(p[2:4])
+        bumps = np.exp(-np.subtract.outer(x, p[:2]) ** 2).sum(axis=1)
+        return np.arctan2(p[0] * x, p[1]) + amp * np.exp(-rate * x) + np.einsum('ij,j->i', A, p[4:6]) + 0.1 * np.hypot(p[5], x) + 0.05 * bumps
+
+    def flat_fcn(x, p):
+        if isinstance(p, Dual):
+            amp, rate = p[2] * p[3], dual.sqrt(p[2] * p[2] + p[3] * p[3])
+            t = p[0] * x
+            r = dual.sqrt(t * t + p[1] * p[1])
+            at2 = 2.0 * dual.arctan(t / (r + p[1]))
+            lin = p[4] * A[:, 0] + p[5] * A[:, 1]
+            bumps = dual.exp(-((x - p[0]) * (x - p[0]))) + dual.exp(-((x - p[1]) * (x - p[1])))
+            return at2 + amp * dual.exp(-(rate * x)) + lin + 0.1 * dual.sqrt(p[5] * p[5] + x * x) + 0.05 * bumps
+        return fcn(x, p)
+
+    f0 = fcn(x, ptrue)
+    sd = 0.02 * (0.2 + np.abs(f0))
+    y = f0 + sd * rng.standard_normal(N)
+    prior = (np.array([1.0, 1.0, 0.5, 0.5, 0.5, 0.5]), np.full(6, 0.6))
+    fit = amd.nonlinear_fit(data=(x, y, sd), fcn=fcn, prior=prior, tol=1e-10)
+    ref = ofit.nonlinear_fit(x, y, sd, flat_fcn, prior_mean=prior[0], prior_err=prior[1], tol=1e-10, solver='cholesky')
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert fit.chi2 / fit.dof == pytest.approx(ref.chi2 / ref.dof, rel=1e-6)
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    assert fit.chi2 / fit.dof < 2.0

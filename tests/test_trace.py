@@ -213,8 +213,63 @@ def test_data_dependent_control_flow_is_refused(bad):
 
 
 def test_unsupported_numpy_function_is_refused_by_name():
-    with pytest.raises(amd.TraceError, match='arctan2'):
-        amd.trace(lambda x, p: np.arctan2(p[0] * x, p[1]), np.linspace(0, 1, 5), np.ones(2))
+    with pytest.raises(amd.TraceError, match='cbrt'):
+        amd.trace(lambda x, p: np.cbrt(p[0] * x), np.linspace(0, 1, 5), np.ones(2))
+    with pytest.raises(amd.TraceError, match='linalg.inv|numpy.inv'):
+        amd.trace(lambda x, p: np.linalg.inv(np.outer(p, p))[0, 0] * x, np.linspace(0, 1, 5), np.ones(2))
+
+
+_XV = np.linspace(0.2, 1.7, 6)
+_AV = np.random.default_rng(11).uniform(0.5, 1.5, (6, 4))
+VOCABULARY = {
+    'prod': lambda x, p: np.prod(p[:3]) * x + p.prod(),
+    'prod axis': lambda x, p: np.prod(np.outer(x, p[:2]) + 1.0, axis=1),
+    'multiply.reduce': lambda x, p: np.multiply.reduce(p[1:3]) * x,
+    'cumprod': lambda x, p: np.cumprod(p)[-1] * x + np.cumprod(p)[1],
+    'norm': lambda x, p: np.linalg.norm(p) * x + np.linalg.norm(np.outer(x, p), axis=1),
+    'var std': lambda x, p: np.var(p) * x + np.std(p * 2.0, ddof=1) + (p * x[0]).var(),
+    'tensordot': lambda x, p: np.tensordot(_AV, p, 1) + np.tensordot(p[:2], np.vstack([x, x ** 2]), axes=([0], [0])),
+    'einsum': lambda x, p: np.einsum('ij,j->i', _AV, p) + np.einsum('i,j->j', p[:2], x) + np.einsum('i,i', p, p),
+    'einsum matrix': lambda x, p: np.einsum('ik,kj->ji', np.outer(x, p[:2]), np.outer(p[2:], x[:3])).ravel(),
+    'inner vdot': lambda x, p: np.inner(_AV, p) + np.vdot(p, p[::-1]),
+    'trace diagonal diag': lambda x, p: np.trace(np.outer(p, p)) * x + np.diagonal(np.outer(p, x[:4]))[1] + np.diag(p * 2.0)[2, 2],
+    'triu tril': lambda x, p: (np.triu(np.outer(p, p)) - np.tril(np.outer(p, p), -1)).sum(axis=0)[[0, 1, 2, 3, 0, 1]] * x,
+    'tile repeat roll': lambda x, p: np.tile(p[:2], 3) * x + np.repeat(p[:3], 2) + np.roll(np.append(p, p[:2] * x[:2]), 2),
+    'split delete': lambda x, p: np.split(p * 1.0, 2)[1][0] * x + np.delete(p, 1)[2],
+    'column_stack': lambda x, p: np.column_stack([p[0] * x, p[1] * x ** 2, np.ones_like(x) * p[2]]).ravel(),
+    'like': lambda x, p: np.zeros_like(p)[0] + np.ones_like(p * x[:4]).sum() * p[0] * x + np.full_like(p, 2.5)[1] * p[3],
+    'arctan2 hypot': lambda x, p: np.arctan2(p[0] * x, p[1]) + np.hypot(p[2], x) + np.arctan2(x, -p[3]),
+    'subtract.outer': lambda x, p: np.exp(-np.subtract.outer(x, p[:2]) ** 2).sum(axis=1),
+    'average': lambda x, p: np.average(np.outer(x, p), axis=1, weights=[1.0, 2.0, 3.0, 4.0]) + np.average(p),
+    'methods': lambda x, p: (p * 1.0).copy().astype(float).swapaxes(0, 0).take([1, 2]).repeat(3) * x + np.outer(p, p).trace(),
+}
+
+
+@pytest.mark.parametrize('name', sorted(VOCABULARY))
+def test_numpy_vocabulary_of_the_tracer(name):
+    """the rest of the numpy functions a fit function is likely to be written with: recorded, then the tape against numpy itself"""
+    fcn = VOCABULARY[name]
+    tr = amd.trace(fcn, _XV, np.zeros(4))
+    p = np.array([0.8, 1.3, 0.6, 1.1])
+    ref = np.asarray(fcn(_XV, p), float).ravel()
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, p), ref, rtol=2e-13, atol=1e-14)
+    q = np.array([1.4, 0.7, 0.9, 0.55])          # (a second point: nothing parameter-dependent was folded into a constant)
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, q), np.asarray(fcn(_XV, q), float).ravel(), rtol=2e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize('bad', [
+    lambda x, p: p.max() * x,
+    lambda x, p: np.sort(p)[0] * x,
+    lambda x, p: np.clip(p[0] * x, 0, 1),
+    lambda x, p: np.round(p[0]) * x,
+    lambda x, p: np.sign(p[0]) * x,
+    lambda x, p: np.interp(p[0], x, x) * x,
+    lambda x, p: np.median(p) * x,
+    lambda x, p: p.astype(int)[0] * x,
+])
+def test_selections_and_rounding_of_parameters_are_refused(bad):
+    with pytest.raises(amd.TraceError, match='parameter-dependent'):
+        amd.trace(bad, np.linspace(0, 1, 5), np.ones(2))
 
 
 def test_residual_function_as_lsqfit_hands_it_over():
