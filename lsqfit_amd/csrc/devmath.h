@@ -26,7 +26,7 @@ constexpr double TRIG_FAST_LIMIT = 1.0e13;
 constexpr double ROUND_MAGIC = 6755399441055744.0;      // 1.5 * 2^52
 // v with its sign flipped where bit 1 of q is set: the bit moved onto the sign bit, one shift + and + xor
 __device__ __forceinline__ double flip_sign(double v, int q) {
-  return __hiloint2double(__double2hiint(v) ^ ((q << 30) & (int)0x80000000), __double2loint(v));
+  return __hiloint2double(__double2hiint(v) ^ (int)(((unsigned)q << 30) & 0x80000000u), __double2loint(v));
 }
 // FAR = false: the caller guarantees |t| < TRIG_FAST_LIMIT (a device flag computed from the parameters, see
 // trig_range_kernel) -- no far-range code in the kernel at all
