@@ -119,6 +119,30 @@ def cpu_baseline(d, wh_blocks_from, budget_s):
                 faithful_qr_1thread=faithful_qr_estimate(ymean.size + P, P)), res
 
 
+def scipy_lm_sanity(d, budget_s):
+    """scipy.optimize.least_squares(method='lm') (MINPACK, analytic Jacobian) on the uncorrelated problem, as an
+    independent sanity number next to the port's: Jacobian evaluations per second and the chi2 it ends on."""
+    import scipy.optimize
+    x, ymean = d['x'], d['ymean']
+    pm, perr = d['prior']
+    sd = np.asarray(d['yerr'], float)
+    K = pm.size // 2
+    t0 = time.perf_counter()
+
+    def f(p):
+        return np.concatenate([(np.cos(np.outer(x, p[K:])) @ p[:K] - ymean) / sd, (p - pm) / perr])
+
+    def jac(p):
+        wx = np.outer(x, p[K:])
+        J = np.hstack([np.cos(wx), -p[:K] * x[:, None] * np.sin(wx)]) / sd[:, None]
+        return np.vstack([J, np.diag(1.0 / np.asarray(perr, float))])
+
+    r = scipy.optimize.least_squares(f, d['p0'], jac=jac, method='lm', xtol=1e-8, ftol=1e-10, gtol=1e-10, max_nfev=200)
+    dt = time.perf_counter() - t0
+    return dict(value=r.njev / dt, unit='Jacobian evaluations/s', njev=int(r.njev), nfev=int(r.nfev), chi2=float(2.0 * r.cost),
+                status=int(r.status), seconds=dt)
+
+
 def faithful_qr_estimate(n, P):
     """SURVEY.md 8d "faithful" mode: what the reference's default solver costs per LM step -- one thread, an
     UNBLOCKED column-pivoted Householder QR of the n x P Jacobian (lm/more/qr, src/lsqfit/__init__.py:1336;
@@ -510,6 +534,11 @@ def main():
                 out['config']['chi2_match'] = {'after_lm_steps': int(res.nit), 'device_chi2': s2.chi2,
                                                'cpu_port_chi2': float(res.fnorm2), 'rel_diff': rel,
                                                'ok': bool(rc == 0 and rel < 1e-6)}
+                if not B and np.ndim(d['prior'][1]) == 1 and N * P <= 4096 * 256:     # (the uncorrelated workload, c2)
+                    try:
+                        out['cpu_baseline']['scipy_least_squares_lm'] = scipy_lm_sanity(d, args.cpu_seconds)
+                    except Exception as e:
+                        out['cpu_baseline']['scipy_least_squares_lm'] = {'value': None, 'sample': 'failed: %r' % (e,)}
             except Exception as e:   # the baseline must never take the measurement down
                 out['cpu_baseline'] = {'value': None, 'unit': 'LM steps/s', 'cores': 0, 'kind': 'port',
                                        'sample': 'failed: %r' % (e,)}
