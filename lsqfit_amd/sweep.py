@@ -31,6 +31,16 @@ SweepFit = namedtuple('SweepFit', 'width pmean psdev chi2 dof Q logGBF nit stopp
 _BATCHABLE = {'data', 'model', 'prior', 'p0', 'tol', 'maxit', 'svdcut'}
 
 
+def _same_x(a, b):
+    if a is b:
+        return True
+    if hasattr(a, 'keys') or hasattr(b, 'keys'):
+        return hasattr(a, 'keys') and hasattr(b, 'keys') and list(a) == list(b) and all(_same_x(a[k], b[k]) for k in a)
+    if a is False or b is False or a is None or b is None:
+        return False
+    return _same(a, b)
+
+
 def _same(a, b):
     if a is b:
         return True
@@ -55,10 +65,44 @@ class EvidenceSurface:
         self.zbest, self.fbest = None, np.inf
         self.nfits = self.nbatches = 0
         self._engine = self._engine_key = None
+        self._traced = None
 
-    def unpack(self, zrow):
+    def unpack(self, zrow, canonical=True):
         out = self.fitargs(float(zrow[0]) if self.scalar else zrow)
-        return (dict(out), 0.0) if hasattr(out, 'keys') else (dict(out[0]), float(out[1]))
+        a, pl = (dict(out), 0.0) if hasattr(out, 'keys') else (dict(out[0]), float(out[1]))
+        return (self._canonical(a) if canonical and self.fitter is nonlinear_fit else a), pl
+
+    def _canonical(self, a):
+        """The reference's own form of the arguments -- ``fcn=`` a Python function, array or dictionary parameters
+        (examples/empbayes.py:31-34) -- as the batch engine wants them: the function is recorded ONCE
+        (lsqfit_amd.trace) and every z reuses that model object; data and prior flattened in the traced order."""
+        if a.get('model') is not None or a.get('fcn') is None or 'data' not in a or a.get('prior') is None:
+            return a
+        from .trace import flatten_mean_err, trace
+        dd = a['data'] if len(a['data']) == 3 else (False,) + tuple(a['data'])
+        xx, ym, ye = dd
+        prior = a['prior']
+        if not isinstance(prior, tuple) or len(prior) != 2:
+            return a
+        c = self._traced
+        if c is None or c[0] is not a['fcn'] or not _same_x(c[1], xx):
+            tr = trace(a['fcn'], xx, prior[0], y=ym)
+            ymf, yef = flatten_mean_err(ym, ye)
+            c = self._traced = (a['fcn'], xx, tr, ym, ye, ymf, yef)
+        tr = c[2]
+        if c[3] is ym and c[4] is ye:
+            ymf, yef = c[5], c[6]
+        else:
+            ymf, yef = flatten_mean_err(ym, ye)
+            if _same(ymf, c[5]) and _same(yef, c[6]):
+                ymf, yef = c[5], c[6]
+        b = {k: v for k, v in a.items() if k != 'fcn'}
+        b['model'] = tr.model
+        b['data'] = (tr.x, ymf, yef)
+        b['prior'] = flatten_mean_err(prior[0], prior[1])
+        if b.get('p0') is not None:
+            b['p0'] = tr.pack_params(b['p0'])
+        return b
 
     # -- one lockstep batch --------------------------------------------------------------------
     def _engine_for(self, args, n):
@@ -89,6 +133,8 @@ class EvidenceSurface:
             if any(a.get(k) != a0.get(k) for k in ('tol', 'maxit', 'svdcut')):
                 return None
             pm, pe = a['prior']
+            if hasattr(pe, 'keys'):
+                return None
             pe = np.asarray(pe, float)
             if pe.ndim > 1:
                 return None
@@ -181,7 +227,7 @@ def empbayes_fit(z0, fitargs, p0=None, tol=1e-4, maxit=1000, fitter=nonlinear_fi
             raise ValueError('empbayes_fit: logGBF is undefined at every z that was tried')
         if surface.nfits and not np.isfinite(surface.fbest):
             warnings.warn('empbayes_fit: null logGBF')
-        args, _ = surface.unpack(surface.zbest)
+        args, _ = surface.unpack(surface.zbest, canonical=False)    # (the caller's own form: fit.p comes back in its layout)
         args.setdefault('p0', surface.warm)
         z = float(surface.zbest[0]) if surface.scalar else surface.zbest
         return fitter(**args), z

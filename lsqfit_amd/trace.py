@@ -995,8 +995,11 @@ class Traced(object):
 
     def pack_params(self, p):
         """array / dict of parameters -> flat vector in the traced order"""
-        if self.pkeys is None:
-            return np.asarray(p, float).reshape(-1)
+        if self.pkeys is None or not hasattr(p, 'keys'):      # (a flat vector in the traced order passes through: warm starts)
+            flat = np.asarray(p, float).reshape(-1)
+            if flat.size != self.n_param:
+                raise ValueError('%d parameter values for a fit function of %d' % (flat.size, self.n_param))
+            return flat
         return np.concatenate([np.asarray(p[k], float).reshape(-1) for k in self.pkeys])
 
     def unpack_params(self, flat):

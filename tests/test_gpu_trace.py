@@ -232,3 +232,79 @@ def test_fit_function_written_with_products_norms_and_einsum(amd):
     assert gu.relmax(fit.cov, ref.cov) < 1e-6
     assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
     assert fit.chi2 / fit.dof < 2.0
+
+
+def test_empbayes_example_written_the_reference_way(amd):
+    """examples/empbayes.py:22-36 as it stands there -- ``fitargs(z)`` returns ``dict(data=(x, y), fcn=fcn, prior=prior)`` with a
+    Python fit function -- through lsqfit_amd.empbayes_fit: the function is recorded once, the candidate fits of the z search
+    run as lockstep batches, the answer is examples/empbayes.out's (logGBF 21.274 at prior width 5.3).  Then the same with
+    dictionary parameters."""
+    from tests.helpers import load
+    from oracle import gvar_lite
+    k = load('kat.json')['empbayes']
+    x = np.array(k['src_inputs']['x'])
+    ym, ys = gvar_lite.parse_array(k['src_inputs']['y'])
+
+    def fcn(x, p):
+        return np.exp(-p[0] - p[1] * x - p[2] * x ** 2 - p[3] * x ** 3)
+
+    def fitargs(z):
+        return dict(data=(x, ym, ys), fcn=fcn, prior=(np.zeros(4), np.full(4, abs(z))))
+
+    from lsqfit_amd import sweep
+    calls = []
+    orig = sweep.EvidenceSurface._batch
+
+    def spy(self, items):
+        r = orig(self, items)
+        calls.append(r is not None)
+        return r
+    sweep.EvidenceSurface._batch = spy
+    try:
+        fit, z = amd.empbayes_fit(1.0, fitargs)
+    finally:
+        sweep.EvidenceSurface._batch = orig
+    assert calls and all(calls)                      # every simplex move was one lockstep batch
+    assert '%.1f' % abs(z) == '5.3'
+    assert '%.5g' % fit.logGBF == '21.274'
+    assert gvar_lite.fmt_array(fit.pmean, fit.psdev) == '[2.5904(22) -6.530(22) 7.832(65) -1.688(55)]'
+    assert fit.traced is not None and fit.p.shape == (4,)
+
+    def fcn_d(x, p):
+        c = p['c']
+        return np.exp(-p['c0'] - c[0] * x - c[1] * x ** 2 - c[2] * x ** 3)
+
+    def fitargs_d(z):
+        return dict(data=(x, ym, ys), fcn=fcn_d, prior=(dict(c0=0.0, c=np.zeros(3)), dict(c0=abs(z), c=np.full(3, abs(z)))))
+    fit_d, z_d = amd.empbayes_fit(1.0, fitargs_d)
+    assert '%.1f' % abs(z_d) == '5.3' and '%.5g' % fit_d.logGBF == '21.274'
+    assert set(fit_d.p) == {'c0', 'c'} and np.allclose(np.concatenate([[fit_d.p['c0']], fit_d.p['c']]), fit.pmean, rtol=1e-7)
+
+
+def test_resampled_copies_of_a_traced_fit(amd):
+    """simulated / bootstrapped copies (src/lsqfit/__init__.py:1391-1642) of a fit whose function was a Python callable: the
+    same copies, bit for bit, as those of the fit given the formula string (the recording made with fold=False IS the string's
+    tape), and a dictionary-parameter fit resamples in the batch engine too"""
+    rng = np.random.default_rng(5)
+    x = np.linspace(0.1, 3.0, 48)
+    y = 1.7 * np.exp(-0.8 * x) + 0.3 + 0.02 * rng.standard_normal(x.size)
+    sd = np.full(x.size, 0.02)
+    prior = (np.array([1.0, 1.0, 0.0]), np.array([2.0, 2.0, 1.0]))
+    m = amd.expr('a*exp(-b*x)+c', ['a', 'b', 'c'])
+    f_str = amd.nonlinear_fit(data=(x, y, sd), model=m, prior=prior)
+    tr = amd.trace(lambda x, p: p[0] * np.exp(-p[1] * x) + p[2], x, prior[0], fold=False)
+    f_tr = amd.nonlinear_fit(data=(tr.x, y, sd), model=tr.model, prior=prior)
+    assert np.array_equal(f_str.pmean, f_tr.pmean)
+    a, b = f_str.simulated_fits(5, seed=11), f_tr.simulated_fits(5, seed=11)
+    assert a.engine == b.engine == 'batched' and np.array_equal(a.pmean, b.pmean) and np.array_equal(a.chi2, b.chi2)
+    a, b = f_str.bootstrapped_fits(5, seed=12), f_tr.bootstrapped_fits(5, seed=12)
+    assert np.array_equal(a.pmean, b.pmean)
+
+    def fcn(x, p):
+        return p['amp'] * np.exp(-p['rate'] * x) + p['off']
+    pd = (dict(amp=1.0, rate=1.0, off=0.0), dict(amp=2.0, rate=2.0, off=1.0))
+    f_d = amd.nonlinear_fit(data=(x, y, sd), fcn=fcn, prior=pd)
+    assert np.allclose(f_d.pmean, f_str.pmean, rtol=1e-9, atol=1e-12)
+    r = f_d.simulated_fits(8, seed=13)
+    assert r.engine == 'batched' and r.pmean.shape == (8, 3)
+    assert np.all(np.abs(r.pmean.mean(axis=0) - f_d.pmean) < 4 * f_d.psdev / np.sqrt(8) + 1e-12)
