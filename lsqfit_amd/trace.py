@@ -32,6 +32,8 @@ _NP_BIN = dict(ADD=np.add, SUB=np.subtract, MUL=np.multiply, DIV=np.true_divide,
 _COMPARE = {'greater', 'greater_equal', 'less', 'less_equal', 'equal', 'not_equal', 'logical_and', 'logical_or', 'logical_not',
             'maximum', 'minimum', 'fmax', 'fmin', 'sign', 'heaviside', 'isnan', 'isfinite', 'isinf', 'floor', 'ceil', 'rint'}
 MAX_PROGRAMS = 512
+TAPE_MAX_CODE = 16384     # LSQAMD_TAPE_MAX_CODE (include/lsqfit_amd.h)
+MANY_PROGRAMS = 48       # beyond this many row ranges a parameter selected row by row is written with indicator columns
 _FOLD = [True]          # arithmetic between ARRAYS of constants is done by numpy during the recording (see trace(fold=))
 
 
@@ -1074,9 +1076,56 @@ def flatten_output(out, y=None):
     return v.ravel(), None, [v.shape]
 
 
+def _select_by_indicator(t):
+    """a parameter leaf whose index changes from row to row, written as sum_j [row reads p_j] * p_j over the indices it takes:
+    the rows share ONE formula again, the selection travels in 0 / 1 predictor columns"""
+    k = t[0]
+    if k == 'P':
+        a = t[1]
+        if a.size == 0 or not np.any(a != a[0]):
+            return t
+        return ('S', [('B', 'MUL', ('D', (a == j).astype(np.float64)), ('P', np.full(a.size, j, a.dtype))) for j in np.unique(a)])
+    if k == 'D':
+        return t
+    if k == 'U':
+        return ('U', t[1], _select_by_indicator(t[2]))
+    if k == 'B':
+        return ('B', t[1], _select_by_indicator(t[2]), _select_by_indicator(t[3]))
+    return ('S', [_select_by_indicator(x) for x in t[1]])
+
+
+def _count_nodes(t):
+    k = t[0]
+    if k == 'P' or k == 'D':
+        return 1
+    if k == 'U':
+        return 1 + _count_nodes(t[2])
+    if k == 'B':
+        return 1 + _count_nodes(t[2]) + _count_nodes(t[3])
+    return len(t[1]) + sum(_count_nodes(x) for x in t[1])
+
+
 def programs_of(flat):
     """one 1-d traced array -> ([(row0, row1, tree)], N): the resolved expression of every contiguous range of rows that
-    shares one formula (same operations, same parameters; constants may differ row by row)"""
+    shares one formula (same operations, same parameters; constants may differ row by row).  Rows that read DIFFERENT
+    parameters through one expression (``p['x'][i]`` in row i -- errors in variables, examples/x-err.py; ``p['norm'][group]``)
+    are different formulas, one program per contiguous run -- unless that makes more than MANY_PROGRAMS of them: then the
+    selection is written with indicator columns (_select_by_indicator) and the rows are one formula."""
+    try:
+        out, N = _programs_of(flat, False)
+    except TraceError:
+        return _programs_of(flat, True)
+    if len(out) > MANY_PROGRAMS:
+        try:
+            alt, _ = _programs_of(flat, True)
+        except TraceError:
+            return out, N
+        if len(alt) < len(out) and sum(_count_nodes(t) for _, _, t in alt) <= TAPE_MAX_CODE:
+            return alt, N
+    return out, N
+
+
+def _programs_of(flat, by_indicator):
     N = flat.size
     tree = _resolve(flat, np.arange(N, dtype=np.int64), {})
     pieces = []
@@ -1084,7 +1133,9 @@ def programs_of(flat):
         rows = np.arange(N) if rows is None else rows
         # rows that read different parameters through the same expression (p[index_array]) are different formulas
         pl = [l[1] for l in _leaves(t, []) if l[0] == 'P']
-        if pl and any(a.size and np.any(a != a[0]) for a in pl):
+        if by_indicator and pl and any(a.size and np.any(a != a[0]) for a in pl):
+            pieces.append((rows, _select_by_indicator(t)))
+        elif pl and any(a.size and np.any(a != a[0]) for a in pl):
             mat = np.stack(pl, 1)
             uniq, inv = np.unique(mat, axis=0, return_inverse=True)
             inv = inv.reshape(-1)

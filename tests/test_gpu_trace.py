@@ -308,3 +308,61 @@ def test_resampled_copies_of_a_traced_fit(amd):
     r = f_d.simulated_fits(8, seed=13)
     assert r.engine == 'batched' and r.pmean.shape == (8, 3)
     assert np.all(np.abs(r.pmean.mean(axis=0) - f_d.pmean) < 4 * f_d.psdev / np.sqrt(8) + 1e-12)
+
+
+def test_errors_in_variables_with_hundreds_of_points(amd):
+    """examples/x-err.py's construction at 300 points: every abscissa is a fit parameter with its own prior (the measured
+    x +- its error), row i of the function reads p['x'][i] -- 304 parameters, one formula with indicator columns -- against the
+    oracle differentiating the same function with dual numbers"""
+    rng = np.random.default_rng(20267)
+    n = 300
+    xt = np.linspace(2.0, 12.0, n)
+    bt = np.array([10.0, 6.0, 1.2, 0.9])
+
+    def curve(b, x, exp=np.exp):
+        return b[0] / ((1. + exp(b[1] - b[2] * x)) ** (1. / b[3]))
+
+    xs, ys = 0.05 + 0.01 * xt, 0.02 * curve(bt, xt) + 0.01
+    xm = xt + xs * rng.standard_normal(n)
+    ym = curve(bt, xt) + ys * rng.standard_normal(n)
+
+    def fcn(p):
+        return curve(p['b'], p['x'])
+
+    prior = (dict(b=np.array([9.0, 5.0, 1.0, 1.0]), x=xm), dict(b=np.array([5.0, 5.0, 1.0, 0.5]), x=xs))
+    fit = amd.nonlinear_fit(data=(ym, ys), fcn=fcn, prior=prior, tol=1e-10)
+    assert fit.traced.model.programs is None and fit.traced.x.shape == (n, n)
+
+    def flat(x, p):
+        if isinstance(p, Dual):
+            return curve([p[0], p[1], p[2], p[3]], p[4:], exp=dual.exp)
+        return curve(p[:4], p[4:])
+    pm = np.concatenate([prior[0]['b'], xm])
+    pe = np.concatenate([prior[1]['b'], xs])
+    ref = ofit.nonlinear_fit(None, ym, ys, flat, prior_mean=pm, prior_err=pe, tol=1e-10, solver='cholesky')
+    assert gu.relmax(fit.pmean, ref.pmean) < 1e-6
+    assert fit.chi2 / fit.dof == pytest.approx(ref.chi2 / ref.dof, rel=1e-6)
+    assert gu.relmax(fit.cov, ref.cov) < 1e-6
+    assert fit.logGBF == pytest.approx(ref.logGBF, rel=1e-8, abs=1e-6)
+    assert fit.p['x'].shape == (n,) and np.all(np.abs(fit.p['b'] - bt) < 5 * fit.psdev[:4])
+
+
+def test_interleaved_groups_share_one_formula(amd):
+    """p['norm'][group] with the groups interleaved row by row: one formula, two indicator columns; equals the fit of the
+    same data sorted by group (two programs)"""
+    rng = np.random.default_rng(20268)
+    n = 1200
+    x = np.linspace(0.0, 2.0, n)
+    group = np.arange(n) % 2
+    truth = dict(norm=np.array([2.0, 3.0]), E=0.7)
+    sd = np.full(n, 0.02)
+    y = truth['norm'][group] * np.exp(-truth['E'] * x) + sd * rng.standard_normal(n)
+    prior = (dict(norm=np.array([1.0, 1.0]), E=1.0), dict(norm=np.array([5.0, 5.0]), E=2.0))
+    fit = amd.nonlinear_fit(data=(x, y, sd), fcn=lambda x, p: p['norm'][group] * np.exp(-p['E'] * x), prior=prior, tol=1e-10)
+    assert fit.traced.model.programs is None
+    o = np.argsort(group, kind='stable')
+    gs = group[o]
+    srt = amd.nonlinear_fit(data=(x[o], y[o], sd[o]), fcn=lambda x, p: p['norm'][gs] * np.exp(-p['E'] * x), prior=prior, tol=1e-10)
+    assert len(srt.traced.model.programs) == 2
+    assert gu.relmax(fit.pmean, srt.pmean) < 1e-9 and gu.relmax(fit.cov, srt.cov) < 1e-8
+    assert fit.chi2 == pytest.approx(srt.chi2, rel=1e-10)

@@ -334,3 +334,29 @@ def test_random_formulas_trace_to_the_string_compilers_tape(seed):
     tf = amd.trace(fcn, x, np.zeros(P))
     assert tf.model.tape.size <= tr.model.tape.size
     np.testing.assert_allclose(run_tape(tf.model, tf.x, p), fcn(x, p), rtol=1e-12)
+
+
+def test_parameter_selected_row_by_row_becomes_indicator_columns():
+    """errors in variables (examples/x-err.py:40-43: ``x = p['x']``, row i reads its own x_i) and interleaved groups
+    (``p['norm'][group]``): one program per contiguous run of rows while there are few of them, ONE formula with 0 / 1 predictor
+    columns doing the selection when there would be dozens"""
+    def fcn(p):
+        b0, b1, b2, b3 = p['b']
+        return b0 / ((1. + np.exp(b1 - b2 * p['x'])) ** (1. / b3))
+
+    for n, nprog in ((15, 15), (600, None)):
+        pp = dict(b=np.array([1.0, 0.5, 2.0, 1.5]), x=np.linspace(1, 2, n))
+        tr = amd.trace(fcn, False, pp)
+        assert (tr.model.programs is None) == (nprog is None) and (nprog is None or len(tr.model.programs) == nprog)
+        np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), fcn(pp), rtol=1e-15)
+        if nprog is None:
+            assert tr.x.shape == (n, n) and set(np.unique(tr.x)) == {0.0, 1.0} and len(tr.model.tape) < 4 * n + 40
+    x = np.linspace(0, 1, 1000)
+    group = np.arange(1000) % 2
+
+    def f2(x, p):
+        return p['norm'][group] * np.exp(-p['E'] * x)
+    pp = dict(norm=np.array([2.0, 3.0]), E=0.25)
+    tr = amd.trace(f2, x, pp)
+    assert tr.model.programs is None and tr.x.shape == (1000, 3)
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), f2(x, pp), rtol=1e-15)
