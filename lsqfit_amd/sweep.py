@@ -85,10 +85,11 @@ class EvidenceSurface:
         if not isinstance(prior, tuple) or len(prior) != 2:
             return a
         c = self._traced
-        if c is None or c[0] is not a['fcn'] or not _same_x(c[1], xx):
+        layout = (tuple((k, np.shape(v)) for k, v in prior[0].items()) if hasattr(prior[0], 'keys') else np.shape(prior[0]))
+        if c is None or c[0] is not a['fcn'] or not _same_x(c[1], xx) or c[7] != layout:
             tr = trace(a['fcn'], xx, prior[0], y=ym)
             ymf, yef = flatten_mean_err(ym, ye)
-            c = self._traced = (a['fcn'], xx, tr, ym, ye, ymf, yef)
+            c = self._traced = (a['fcn'], xx, tr, ym, ye, ymf, yef, layout)
         tr = c[2]
         if c[3] is ym and c[4] is ye:
             ymf, yef = c[5], c[6]

@@ -130,3 +130,31 @@ def test_scipy_plugin_option_validation_needs_no_device():
                     (dict(method='newton'), ValueError)]:
         with pytest.raises(exc):
             mi355x_trf([1.0, 2.0], 5, problem=object(), **kw)
+
+
+def test_reference_style_fitargs_are_recorded_once_and_flattened():
+    """``fitargs(z) -> dict(data=(x, y), fcn=fcn, prior=...)`` (examples/empbayes.py:31-34) inside the evidence surface: the
+    Python function is recorded ONCE, every z gets the SAME model object (the batch engine is keyed on it) and data / prior
+    in the traced layout; another fitter callable receives the caller's own arguments untouched."""
+    from lsqfit_amd.sweep import EvidenceSurface
+    x = np.linspace(0.1, 1.0, 6)
+    y, ys = np.exp(-x), np.full(6, 0.01)
+    ncalls = []
+
+    def fcn(x, p):
+        ncalls.append(1)
+        return p['a'] * np.exp(-p['E'][0] * x) + p['E'][1]
+
+    def fitargs(z):
+        return dict(data=(x, y, ys), fcn=fcn, prior=(dict(a=1.0, E=np.array([1.0, 0.0])), dict(a=abs(z), E=np.full(2, abs(z)))), p0=dict(a=0.9, E=[1.1, 0.1]))
+    s = EvidenceSurface(fitargs)
+    a1, _ = s.unpack(np.array([0.5]))
+    a2, _ = s.unpack(np.array([2.0]))
+    assert len(ncalls) == 1 and a1['model'] is a2['model'] and 'fcn' not in a1
+    assert a1['data'][0] is a2['data'][0] and a1['data'][1] is a2['data'][1] and a1['data'][0].shape[0] == 6
+    assert np.array_equal(a1['prior'][0], [1.0, 1.0, 0.0]) and np.array_equal(a1['prior'][1], [0.5, 0.5, 0.5])
+    assert np.array_equal(a2['prior'][1], [2.0, 2.0, 2.0]) and np.array_equal(a1['p0'], [0.9, 1.1, 0.1])
+    raw, _ = s.unpack(np.array([0.5]), canonical=False)
+    assert raw['fcn'] is fcn and 'model' not in raw
+    other = EvidenceSurface(fitargs, fitter=lambda **kw: None)
+    assert other.unpack(np.array([0.5]))[0]['fcn'] is fcn
