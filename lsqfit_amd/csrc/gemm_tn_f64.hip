@@ -35,6 +35,12 @@
 
 namespace lsqamd {
 
+#ifdef LSQAMD_SYRK_STAMPS
+// developer build (tools/build_variant.sh syrkstamps gemm_tn_f64.hip -DLSQAMD_SYRK_STAMPS; tools/syrk_schedule.py): every
+// workgroup of the work-list launch leaves (start, end) in 100 MHz ticks, XCC_ID, HW_ID and its list index
+__device__ unsigned long long *g_syrk_stamps = nullptr;
+#endif
+
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -261,11 +267,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn, split;
+#ifdef LSQAMD_SYRK_STAMPS
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
+  int stamp_w = -1;
+#endif
   if (WORKMAP) {
     // (as in gemm_tn_f64_kernel: workgroup b runs on XCD b % 8; every XCD walks one contiguous run of the list)
     const int nw = g.n_work, bid = blockIdx.x;
     const int xcd = bid & 7, q = nw >> 3, r = nw & 7;
     const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+#ifdef LSQAMD_SYRK_STAMPS
+    stamp_w = w;
+#endif
     const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
     tm = e.x; tn = e.y; split = e.z;
   } else {
@@ -485,6 +498,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
     }
   }
   }  // pass
+#ifdef LSQAMD_SYRK_STAMPS
+  if (WORKMAP && g_syrk_stamps && tid == 0) {
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned long long *o = g_syrk_stamps + 5 * (size_t)blockIdx.x;
+    o[0] = stamp0;
+    o[1] = __builtin_amdgcn_s_memrealtime();
+    o[2] = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+    o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    o[4] = (unsigned long long)stamp_w;
+  }
+#endif
 }
 
 // 64 x 64-tile variant for the latency-bound contractions of the Cholesky family (K = 128,
@@ -1278,3 +1302,9 @@ hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a0) {
 }
 
 }  // namespace lsqamd
+
+#ifdef LSQAMD_SYRK_STAMPS
+extern "C" int lsqamd_debug_set_syrk_stamps(void *dev_ptr) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(lsqamd::g_syrk_stamps), &dev_ptr, sizeof(void *));
+}
+#endif
