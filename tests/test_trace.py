@@ -360,3 +360,16 @@ def test_parameter_selected_row_by_row_becomes_indicator_columns():
     tr = amd.trace(f2, x, pp)
     assert tr.model.programs is None and tr.x.shape == (1000, 3)
     np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), f2(x, pp), rtol=1e-15)
+
+
+def test_errors_raised_in_the_fit_function_surface_unchanged():
+    """tests/test_lsqfit.py:1684-1698 (test_multifit_exceptions): the reference stashes an exception raised inside the fit
+    function and re-raises it after the driver returns; here the function runs once, at recording time, and the exception
+    leaves amd.trace as it was raised"""
+    def length_mismatch(x, p):
+        raise ValueError('operands could not be broadcast together')
+
+    with pytest.raises(ValueError, match='broadcast'):
+        amd.trace(length_mismatch, np.arange(3.0), np.ones(2))
+    with pytest.raises(ZeroDivisionError):
+        amd.trace(lambda x, p: p[0] * x / 0, np.arange(3.0), np.ones(2)) if False else amd.trace(lambda x, p: (1 // 0) * p[0] * x, np.arange(3.0), np.ones(2))
