@@ -17,11 +17,14 @@ run() { # program-tag, pass-name, counters -- program args...
   local tag=$1 pass=$2 ctr=$3; shift 3
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/$tag/$pass -- "$@" > $OUT/${tag}_$pass.log 2>&1 || echo "pass $tag/$pass failed" >&2
 }
-for tag in potrf whiten c5; do
+TAGS=${LSQAMD_PMC_TAGS:-"potrf whiten c5"}      # (+ c3: the triangular whitening product of one dense 8192-row block; shard: the 8-GPU shard shape)
+for tag in $TAGS; do
   case $tag in
     potrf)  prog=(python3 $ROOT/tools/time_potrf.py) ;;
     whiten) prog=(python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline) ;;
     c5)     prog=(python3 $ROOT/tools/run_c5.py nograph) ;;
+    c3)     prog=(python3 $ROOT/bench.py --workload c3 --steps 10 --warmup 2 --no-cpu-baseline --two-pass) ;;
+    shard)  prog=(python3 $ROOT/bench.py --ndata 8192 --steps 6 --warmup 2 --no-cpu-baseline --whole-fit-maxit 0) ;;
   esac
   run $tag sq "$SQ" "${prog[@]}"
   run $tag sq2 "$SQ2" "${prog[@]}"
@@ -30,4 +33,4 @@ for tag in potrf whiten c5; do
 done
 cd $ROOT
 python3 tools/summarize_kernel_pmc.py $OUT
-for tag in potrf whiten c5; do rm -rf $OUT/$tag; done      # raw per-dispatch CSVs: tens of MB
+for tag in $TAGS; do rm -rf $OUT/$tag; done      # raw per-dispatch CSVs: tens of MB
