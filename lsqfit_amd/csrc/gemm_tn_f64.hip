@@ -58,6 +58,7 @@ struct GemmDev {
   int32_t tiles_n, upper_only, x_upper_tri, xy_lower_tri, splits;
   int32_t tiles_m, pair_rows;
   int32_t tri_halves;    // XTRI interior launch with two K-halves per tile row (grid.y = 2), see GemmTN::tri_halves
+  int32_t xcd_groups;    // XTRI interior launch as a 1-D grid: the tile columns of one (tile row [pair], K-half) on ONE XCD; = number of tile rows [pairs]
   int32_t syrk_diag;     // WORKMAP launch with X == Y: diagonal tiles take the triangular schedule (see kernel)
   int32_t vec_x, vec_y;  // operand rows are 16-byte aligned -> dwordx4 loads
   int64_t kchunk, split_stride;
@@ -281,6 +282,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
 #endif
     const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
     tm = e.x; tn = e.y; split = e.z;
+  } else if (XTRI && g.xcd_groups) {
+    // Workgroup b runs on XCD b % 8.  With the tile column as the fastest index (and 8 of them) every XCD would own ONE
+    // tile column and read ALL of X for it -- config 3's triangular whitening matrix went past the L2 eight times (L2 hit
+    // 12 %, 3.9 GB per launch, r05_c3_pmc.json).  Here the tile columns of one (tile row [pair], K-half) are neighbours on
+    // ONE XCD: they walk the same rows of X at the same pace and share them in its L2.
+    const int L = blockIdx.x, xcd = L & 7, sl = L >> 3;
+    const int gidx = xcd + 8 * (sl / g.tiles_n);
+    tn = sl % g.tiles_n;
+    tm = gidx % g.xcd_groups;
+    split = gidx / g.xcd_groups;
   } else {
     tm = blockIdx.x / g.tiles_n;
     tn = blockIdx.x % g.tiles_n;
@@ -932,6 +943,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.tiles_m = (int32_t)tiles_m;
   g.pair_rows = 0;
   g.tri_halves = 0;
+  g.xcd_groups = 0;
   g.upper_only = a.upper_only;
   g.x_upper_tri = a.x_upper_tri;
   g.xy_lower_tri = a.xy_lower_tri;
@@ -1015,6 +1027,15 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
         g.splits = 2;                       // (epilogue: beta ignored, split s -> C + s * split_stride)
         g.split_stride = a.split_stride;
         grid.y = 2;
+      }
+    }
+    {
+      static const bool xg_off = [] { const char *e = getenv("LSQAMD_XTRI_XCD_GROUPS"); return e && e[0] == '0'; }();   // developer knob
+      const unsigned rows = grid.x / (unsigned)tiles_n, groups = rows * grid.y;
+      if (!xg_off && !a.work_map && tiles_n >= 2 && groups % 8 == 0 && grid.x == rows * (unsigned)tiles_n) {
+        g.xcd_groups = (int32_t)rows;
+        grid.x = groups * (unsigned)tiles_n;
+        grid.y = 1;
       }
     }
     hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<true, false>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
