@@ -10,6 +10,10 @@
 
 #include "common.h"
 
+#ifndef LSQAMD_LEAF_FMA_LAYOUT
+#define LSQAMD_LEAF_FMA_LAYOUT 1
+#endif
+
 namespace lsqamd {
 
 constexpr int NB = CHOL_NB;
@@ -358,11 +362,28 @@ __device__ __forceinline__ double pivot4_reg(double reg, int &bad, int lane) {
   const double v13 = -y1 * __builtin_fma(u12, v23, u13 * y3);
   const double v03 = -y0 * __builtin_fma(u01, v13, __builtin_fma(u02, v23, u03 * y3));
   const int col = lane & 15, q = lane >> 4;
+#if LSQAMD_LEAF_FMA_LAYOUT
+  // The operand's ten entries laid out with ten FMAs against 0 / 1 lane masks (loop invariants: the compiler keeps them in
+  // registers) instead of two levels of selects -- 10 instructions for 28 (each select is two v_cndmask_b32 + a compare),
+  // and the last value off the chain, v03, is one FMA from the MFMA instead of three selects.
+  auto at = [&](int qq, int cc) { return (q == qq && col == cc) ? 1.0 : 0.0; };
+  double m = y0 * at(0, 0);
+  m = __builtin_fma(y1, at(1, 1), m);
+  m = __builtin_fma(v01, at(0, 1), m);
+  m = __builtin_fma(y2, at(2, 2), m);
+  m = __builtin_fma(v12, at(1, 2), m);
+  m = __builtin_fma(v02, at(0, 2), m);
+  m = __builtin_fma(y3, at(3, 3), m);
+  m = __builtin_fma(v23, at(2, 3), m);
+  m = __builtin_fma(v13, at(1, 3), m);
+  return __builtin_fma(v03, at(0, 3), m);
+#else
   const double r0 = col == 0 ? y0 : (col == 1 ? v01 : (col == 2 ? v02 : v03));
   const double r1 = col == 1 ? y1 : (col == 2 ? v12 : v13);
   const double r2 = col == 2 ? y2 : v23;
   const double m = q == 0 ? r0 : (q == 1 ? r1 : (q == 2 ? r2 : y3));
   return (col < 4 && q <= col) ? m : 0.0;
+#endif
 }
 
 template <int R>
