@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define LSQAMD_ABI_VERSION 7
+#define LSQAMD_ABI_VERSION 8
 
 /* error codes (negative = backend, positive = GSL numbering) */
 #define LSQAMD_SUCCESS 0
@@ -50,12 +50,14 @@ extern "C" {
 #define LSQAMD_ETOLG 31
 #define LSQAMD_EINVAL (-1)    /* bad argument / call order               */
 #define LSQAMD_EHIP (-2)      /* HIP runtime error                       */
-#define LSQAMD_ENOMEM (-3)    /* workspace too small                     */
+#define LSQAMD_ENOMEM (-3)    /* workspace too small, or a host allocation failed (std::bad_alloc) */
 #define LSQAMD_ENOTPD (-4)    /* J^T J + mu D^2 not positive definite    */
 #define LSQAMD_ENONFINITE (-5)/* residual or Jacobian not finite         */
 #define LSQAMD_EUNSUPPORTED (-6)
 #define LSQAMD_EREDUCE (-7)   /* the all-reduce hook reported failure    */
 #define LSQAMD_ECAPACITY (-8) /* caller's output buffer too small        */
+#define LSQAMD_EINTERNAL (-10) /* a C++ exception other than bad_alloc was caught at the ABI (never propagated:
+                                 * every export is a function-try-block, csrc/common.h LSQAMD_ABI_CATCH) */
 #define LSQAMD_EINACCURATE (-9) /* summary.cov_status only: the covariance was delivered, but the factorisation
                                  * behind it missed its own accuracy test (solver = qr: Q not orthogonal to 1e-6
                                  * after six passes) */
@@ -451,7 +453,11 @@ int32_t lsqamdb_rounds(const lsqamdb_fits *fits);
 enum {
   LSQAMD_T_RESIDUAL = 0, LSQAMD_T_JACOBIAN = 1, LSQAMD_T_WHITEN = 2, LSQAMD_T_SYRK = 3,
   LSQAMD_T_GRAD = 4, LSQAMD_T_REDUCE = 5, LSQAMD_T_CHOLESKY = 6, LSQAMD_T_SOLVE = 7,
-  LSQAMD_T_COVAR = 8, LSQAMD_T_COUNT = 9
+  LSQAMD_T_COVAR = 8,
+  /* sharded fits: the collective itself (HIP events around it on the stream it runs on: the step's stream, or the handle's
+   * exchange stream when LSQAMD_EXCHANGE_GROUPS > 1) and the time the STEP's stream spent waiting for it -- their ratio is the
+   * exposed share of the exchange (1 when nothing overlaps it) */
+  LSQAMD_T_EXCH_COLL = 9, LSQAMD_T_EXCH_WAIT = 10, LSQAMD_T_COUNT = 11
 };
 /* HIP-event timing of each phase on the handle's stream; off by default */
 int lsqamd_timing_enable(lsqamd_fit *fit, int32_t on);
@@ -475,6 +481,14 @@ int64_t lsqamd_debug_flags(const lsqamd_fit *fit);
  * device memory after a stream synchronisation instead, out3[2] = words the test knob LSQAMD_VERIFY_HANDOFF=1 found
  * different from the device's own copy after the host had acted on them (must stay 0).  Process-wide counters. */
 int lsqamd_handoff_stats(int64_t *out3);
+/* self-tests of the boundary (no GPU needed; tests/test_abi.py).  lsqamd_debug_throw raises a C++ exception INSIDE the
+ * library (kind 1 std::bad_alloc, 2 std::runtime_error, 3 a non-std object, 4 a real over-sized allocation) and must come
+ * back as LSQAMD_ENOMEM / LSQAMD_EINTERNAL with the text in lsqamd_last_error(fit) -- the reference's callbacks are
+ * `noexcept` and stash Python errors (src/lsqfit/_gsl.pyx:726-760,:680-685); nothing may unwind into the host language.
+ * lsqamd_debug_per_device_once(dev, 0) returns how many times the per-device "set kernel attributes" action has run for
+ * device `dev` after this call (1 however often it is called, separately per device; reset != 0 clears the counters). */
+int lsqamd_debug_throw(lsqamd_fit *fit, int32_t kind);
+int lsqamd_debug_per_device_once(int32_t dev, int32_t reset);
 /* The process-wide cache of compiled formulas (lsqamd_set_tape compiles with hiprtc and keeps the loaded code object):
  * out3[0] = kernels loaded now, out3[1] = of those, held by a live handle, out3[2] = kernels unloaded so far.  At most
  * LSQAMD_JIT_CACHE_CAP (default 1024) stay loaded; beyond that the ones no handle holds go, least recently used first. */
@@ -492,21 +506,6 @@ int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const double *const
 /* developer builds (-DLSQAMD_POTF2_TIMING): device buffer of 32 int64 cycle stamps written by the
  * diagonal-block Cholesky kernel; NULL (default) disables */
 void lsqamd_debug_set_potf2_stamps(void *dev_ptr);
-/* developer probe: where do the workgroups of a launch on `stream` run?  dev_out[2 b] = XCC_ID, dev_out[2 b + 1] = HW_ID of
- * workgroup b (n_wg workgroups of one wave that ask for lds_bytes of LDS each; tools/exp_cumask.py) */
-int lsqamd_debug_where(void *stream, int32_t n_wg, uint32_t *dev_out, int32_t lds_bytes);
-/* developer / test entry points of the factorisation streamed behind the J^T J product (csrc/sf_chol.hip; the first trial solve
- * after an accepted LM step: replaces gsl's solver init + solve behind src/lsqfit/_gsl.pyx:646-653,:677).  Device pointers.
- *   J [n_rows][ldj] (P columns used), prior (nullable: dense P x P or diagonal), g [P], mu, d [P] (updated like the LM scaling)
- *   -> apk (packed upper 128 x 128 tiles of A = J^T J + prior), M [P][P + 128] (U with A + mu D^2 = U^T U; column P = U^-T g).
- * reserve_per_xcd CUs of every XCD run the latency chain (hipExtStreamCreateWithCUMask; mask_mode 'c' / 'i': bit layout);
- * 0 = no masks (plain streams: results only). */
-size_t lsqamd_op_sf_work_bytes(int64_t n_rows, int64_t P, int32_t splits);
-int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_rows, int64_t P, int32_t splits, int32_t group_rows,
-                        int32_t reserve_per_xcd, int32_t mask_mode, const double *prior, int32_t prior_dense, const double *g,
-                        double mu, int32_t scaler, double *d, double *apk, double *M, void *work, size_t work_bytes,
-                        int32_t *info_host, long long *dev_stamps /* nullable: [24 + 4 P / 128] wall-clock stamps and per-item-type time sums */, int32_t idle_max);
-
 #ifdef __cplusplus
 }
 #endif

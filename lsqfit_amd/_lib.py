@@ -8,14 +8,14 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.environ.get('LSQAMD_LIBPATH') or os.path.join(HERE, 'liblsqfit_amd.so')   # (the variable: developer builds, tools/build_variant.sh)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 COMM_ID_BYTES = 128
 
-T_NAMES = ['residual', 'jacobian', 'whiten', 'syrk', 'grad', 'reduce', 'cholesky', 'solve', 'covar']
+T_NAMES = ['residual', 'jacobian', 'whiten', 'syrk', 'grad', 'reduce', 'cholesky', 'solve', 'covar', 'exch_coll', 'exch_wait']
 
 ERRORS = {-1: 'EINVAL', -2: 'EHIP', -3: 'ENOMEM', -4: 'ENOTPD', -5: 'ENONFINITE',
-          -6: 'EUNSUPPORTED', -7: 'EREDUCE', -8: 'ECAPACITY'}
+          -6: 'EUNSUPPORTED', -7: 'EREDUCE', -8: 'ECAPACITY', -9: 'EINACCURATE', -10: 'EINTERNAL'}
 
 
 class Config(C.Structure):
@@ -131,12 +131,10 @@ PROTOTYPES = {
     'lsqamd_timing_reset': (C.c_int, [_vp]),
     'lsqamd_debug_flags': (C.c_int64, [_vp]),
     'lsqamd_handoff_stats': (C.c_int, [C.POINTER(C.c_int64)]),
+    'lsqamd_debug_throw': (C.c_int, [_vp, C.c_int32]),
+    'lsqamd_debug_per_device_once': (C.c_int, [C.c_int32, C.c_int32]),
     'lsqamd_jit_cache_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_debug_set_potf2_stamps': (None, [_vp]),
-    'lsqamd_debug_where': (C.c_int, [_vp, C.c_int32, _vp, C.c_int32]),
-    'lsqamd_op_sf_work_bytes': (C.c_size_t, [C.c_int64, C.c_int64, C.c_int32]),
-    'lsqamd_op_sf_factor': (C.c_int, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp,
-                                      C.c_int32, _vp, C.c_double, C.c_int32, _vp, _vp, _vp, _vp, C.c_size_t, _vp, _vp, C.c_int32]),
 }
 
 _lib = None

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'liblsqfit_amd.so')
 SOURCES = ['gemm_tn_f64.hip', 'chol.hip', 'potf2_mfma.hip', 'model.hip', 'vecops.hip', 'api.hip', 'scipy_methods.hip',
-           'batch.hip', 'comm.hip', 'whiten.hip', 'qr.hip', 'jit.hip', 'rankdef.hip', 'robust.hip', 'sf_chol.hip']
+           'batch.hip', 'comm.hip', 'whiten.hip', 'qr.hip', 'jit.hip', 'rankdef.hip', 'robust.hip']
 # per-file code-generation switches (reasons in the files' headers)
 EXTRA = {'potf2_mfma.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = os.environ.get('HIPCC', 'hipcc')
     headers = [os.path.join(CSRC, 'common.h'), os.path.join(CSRC, 'fit_state.h'), os.path.join(CSRC, 'devmath.h'),
-               os.path.join(CSRC, 'jit.h'), os.path.join(CSRC, 'sf_chol.h'), os.path.join(HERE, '..', 'include', 'lsqfit_amd.h')]
+               os.path.join(CSRC, 'jit.h'), os.path.join(HERE, '..', 'include', 'lsqfit_amd.h')]
     # devmath.h as a string literal for the run-time compiled tapes (jit.hip embeds it in the code it generates, so
     # that compiled formulas and the hand-written kernels share one sincos); generated, git-ignored
     text = open(os.path.join(CSRC, 'devmath.h')).read()

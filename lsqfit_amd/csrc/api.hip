@@ -388,6 +388,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   }
   f->syrk_nwork = (int32_t)syrk_work_count(P, f->splits);
   f->syrk_map = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);
+  f->syrk_map_g = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);   // the same entries grouped by tile rows (grouped exchange)
   return cv.off;
 }
 
@@ -450,6 +451,7 @@ int ready(lsqamd_fit *f) {
 int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
   if (f->comm) {   // RCCL on the handle's stream: nothing to wait for on the host
     Scope sc(f, LSQAMD_T_REDUCE);
+    Scope sc2(f, LSQAMD_T_EXCH_COLL), sc3(f, LSQAMD_T_EXCH_WAIT);   // on the step's own stream: all of it is waited for
     return comm_all_reduce(f, buf, count);
   }
   if (!f->reduce) return 0;
@@ -739,40 +741,30 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     }
   }
   bool syrk_colsum = false;
-  {
-    Scope sc(f, LSQAMD_T_SYRK);
-    GemmTN g;
-    g.X = f->J; g.Y = f->J; g.ldx = g.ldy = f->ld;
-    g.C = f->slabs; g.ldc = f->ldm;
-    g.M = P; g.N = P; g.K = f->N;
-    g.upper_only = 1;
-    g.splits = f->splits;
-    g.split_stride = P * f->ldm;
-    if (P > 64) {   // (one tile: nothing to order, and the 64 x 64 kernel takes no work list)
-      g.work_map = f->syrk_map;
-      g.n_work = f->syrk_nwork;
-    }
-    if (fused_chunks == 0 && f->N > 0) {   // J^T f and chi2 out of the diagonal tiles of this launch, when it is that kernel
-      g.colsum_out = f->partial;            // [splits][P + 1] (splits <= 256 <= npartial)
-      g.colsum_ld = P + 1;
-      g.colsum_rcol = P;
-      if (gemm_tn_fuses_colsum(g)) syrk_colsum = true;
-      else g.colsum_out = nullptr;
-    }
-    if (f->N > 0) {
-      HIPCHK(f, launch_gemm_tn(f->st, g));
-    } else {
-      HIPCHK(f, hipMemsetAsync(f->slabs, 0, sizeof(double) * f->splits * P * f->ldm, f->st));
-    }
+  // the exchange in groups (sharded fits with the library's communicator): launch g forms the tile rows of
+  // group g, its slab sum packs them, and their sum over the ranks runs on the exchange stream while launch g + 1 computes
+  const bool grouped = f->comm && f->xg > 1 && P > 64 && f->N > 0;
+  GemmTN g;
+  g.X = f->J; g.Y = f->J; g.ldx = g.ldy = f->ld;
+  g.C = f->slabs; g.ldc = f->ldm;
+  g.M = P; g.N = P; g.K = f->N;
+  g.upper_only = 1;
+  g.splits = f->splits;
+  g.split_stride = P * f->ldm;
+  if (P > 64) {   // (one tile: nothing to order, and the 64 x 64 kernel takes no work list)
+    g.work_map = f->syrk_map;
+    g.n_work = f->syrk_nwork;
+  }
+  if (fused_chunks == 0 && f->N > 0) {   // J^T f and chi2 out of the diagonal tiles of this launch, when it is that kernel
+    g.colsum_out = f->partial;            // [splits][P + 1] (splits <= 256 <= npartial)
+    g.colsum_ld = P + 1;
+    g.colsum_rcol = P;
+    if (gemm_tn_fuses_colsum(g)) syrk_colsum = true;
+    else g.colsum_out = nullptr;
   }
   double *gvec = f->redbuf + f->npk;
-  {
-    Scope sc(f, LSQAMD_T_GRAD);
-    // when splits == 1 the kernel ignored split_stride and wrote slab 0 directly
-    const bool with_prior = f->cfg.has_prior && f->adds_prior;
-    // the slab sum and the prior precision in ONE pass over the packed tiles
-    HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
-                                   with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
+  const bool with_prior = f->cfg.has_prior && f->adds_prior;
+  auto finish_gvec = [&]() -> int {       // J^T f, chi2 (+ the prior's share) into gvec: after the LAST product launch
     if (syrk_colsum)
       HIPCHK(f, launch_colsum_reduce(f->st, f->partial, f->splits, P + 1, gvec));
     else if (fused_chunks == 0)
@@ -782,9 +774,71 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
     if (with_prior && !f->prior_deferred)   // (r_here: the trial evaluation at this point left Lambda (p - pbar) in tvec)
       HIPCHK(f, launch_add_prior(f->st, f->redbuf, P, f->prior_prec, f->cfg.prior_dense,
                                  f->prior_mean, p, f->tvec, gvec, 0, r_here ? 1 : 0));
+    return 0;
+  };
+  if (grouped) {
+    if (!f->xst) f->xst = stream_take();
+    for (int q = 0; q < f->xg; ++q) {
+      if (!f->xg_ready[q]) f->xg_ready[q] = event_take();
+      if (!f->xg_done[q]) f->xg_done[q] = event_take();
+    }
+    if (!f->xst) FAIL(f, LSQAMD_EHIP, "no stream for the grouped exchange");
+    for (int q = 0; q < f->xg; ++q) {
+      const bool last = q == f->xg - 1;
+      {
+        Scope sc(f, LSQAMD_T_SYRK);
+        GemmTN gq = g;
+        gq.work_map = f->syrk_map_g + 4 * (int64_t)f->xg_work[q];
+        gq.n_work = f->xg_work[q + 1] - f->xg_work[q];
+        HIPCHK(f, launch_gemm_tn(f->st, gq));
+      }
+      {
+        Scope sc(f, LSQAMD_T_GRAD);
+        HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
+                                       with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense, f->xg_tile[q],
+                                       f->xg_tile[q + 1] - f->xg_tile[q]));
+        if (last) {
+          rc = finish_gvec();
+          if (rc) return rc;
+        }
+      }
+      HIPCHK(f, hipEventRecord(f->xg_ready[q], f->st));
+      HIPCHK(f, hipStreamWaitEvent(f->xst, f->xg_ready[q], 0));
+      {
+        Scope sc(f, LSQAMD_T_EXCH_COLL, f->xst);
+        const int64_t off = f->xg_tile[q] * 128 * 128;
+        const int64_t cnt = (last ? f->npk + P + 1 : f->xg_tile[q + 1] * 128 * 128) - off;   // the last group carries [J^T f | chi2]
+        rc = comm_all_reduce_on(f, f->xst, f->redbuf + off, cnt);
+        if (rc) return rc;
+      }
+      HIPCHK(f, hipEventRecord(f->xg_done[q], f->xst));
+    }
+    {
+      Scope sc(f, LSQAMD_T_REDUCE);
+      Scope sc2(f, LSQAMD_T_EXCH_WAIT);
+      for (int q = 0; q < f->xg; ++q) HIPCHK(f, hipStreamWaitEvent(f->st, f->xg_done[q], 0));
+    }
+  } else {
+    {
+      Scope sc(f, LSQAMD_T_SYRK);
+      if (f->N > 0) {
+        HIPCHK(f, launch_gemm_tn(f->st, g));
+      } else {
+        HIPCHK(f, hipMemsetAsync(f->slabs, 0, sizeof(double) * f->splits * P * f->ldm, f->st));
+      }
+    }
+    {
+      Scope sc(f, LSQAMD_T_GRAD);
+      // when splits == 1 the kernel ignored split_stride and wrote slab 0 directly
+      // the slab sum and the prior precision in ONE pass over the packed tiles
+      HIPCHK(f, launch_finalize_pack(f->st, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
+                                     with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense));
+      rc = finish_gvec();
+      if (rc) return rc;
+    }
+    rc = do_reduce(f, f->redbuf, f->npk + P + 1);
+    if (rc) return rc;
   }
-  rc = do_reduce(f, f->redbuf, f->npk + P + 1);
-  if (rc) return rc;
   if (mirror) HIPCHK(f, launch_packed_diag(f->st, f->redbuf, P, f->diag_dev));   // (else: lm_accept_tail_kernel, the caller's next launch)
   f->have_cov = false;
   f->have_dense_A = false;
@@ -1830,7 +1884,7 @@ extern "C" {
 
 int lsqamd_abi_version(void) { return LSQAMD_ABI_VERSION; }
 
-int lsqamd_query_devices(int32_t *count, int32_t index, char *arch, size_t cap, int64_t *hbm_bytes) {
+int lsqamd_query_devices(int32_t *count, int32_t index, char *arch, size_t cap, int64_t *hbm_bytes) try {
   if (!count) return LSQAMD_EINVAL;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) n = 0;   // no driver / no GPU: zero devices
@@ -1843,17 +1897,17 @@ int lsqamd_query_devices(int32_t *count, int32_t index, char *arch, size_t cap, 
   if (arch && cap) snprintf(arch, cap, "%s", pr.gcnArchName);
   if (hbm_bytes) *hbm_bytes = (int64_t)pr.totalGlobalMem;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-size_t lsqamd_workspace_bytes(const lsqamd_config *cfg) {
+size_t lsqamd_workspace_bytes(const lsqamd_config *cfg) try {
   if (check_cfg(cfg) != 0) return 0;
   lsqamd_fit tmp;
   tmp.cfg = *cfg;
   return carve(&tmp, nullptr, 0, true);
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
 int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspace_bytes, void *stream,
-                  lsqamd_fit **out) {
+                  lsqamd_fit **out) try {
   if (!out) return LSQAMD_EINVAL;
   *out = nullptr;
   const int rc = check_cfg(cfg);
@@ -1910,22 +1964,62 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
       delete f;
       return LSQAMD_EHIP;
     }
+    // LSQAMD_EXCHANGE_GROUPS = G (default 1): groups of tile rows with (about) equal tile counts -- the last one holds
+    // LSQAMD_EXCHANGE_TAIL_PCT per cent of the tiles when given (its exchange is the one nothing can hide)
+    const int T = (int)((f->P + 127) / 128);
+    int G = 1;
+    if (const char *e = getenv("LSQAMD_EXCHANGE_GROUPS")) G = atoi(e);
+    if (G > 8) G = 8;
+    if (G > T) G = T;
+    if (G < 1 || f->P <= 64) G = 1;
+    f->xg = G;
+    if (G > 1) {
+      const int64_t total = (int64_t)T * (T + 1) / 2;
+      double tail = 1.0 / G;
+      if (const char *e = getenv("LSQAMD_EXCHANGE_TAIL_PCT")) {
+        const double v = atof(e) / 100.0;
+        if (v > 0.0 && v < 1.0) tail = v;
+      }
+      int row = 0;
+      int64_t tiles = 0;
+      f->xg_row[0] = 0;
+      for (int g = 1; g < G; ++g) {
+        const double want = (1.0 - tail) * g / (G - 1) * (double)total;
+        while (row < T - (G - g) && (double)(tiles + (T - row) / 2) < want) { tiles += T - row; ++row; }
+        if (row <= f->xg_row[g - 1]) { tiles += T - row; ++row; }      // every group holds at least one tile row
+        f->xg_row[g] = row;
+      }
+      f->xg_row[G] = T;
+      int64_t o = 0;
+      for (int g = 0; g < G; ++g) {
+        f->xg_work[g] = (int32_t)o;
+        const int r0 = f->xg_row[g];
+        f->xg_tile[g] = (int64_t)r0 * T - (int64_t)r0 * (r0 - 1) / 2;
+        o += syrk_work_fill_rows(f->P, f->splits, r0, f->xg_row[g + 1], wm.data() + 4 * o);
+      }
+      f->xg_work[G] = (int32_t)o;
+      f->xg_tile[G] = total;
+      if (o != f->syrk_nwork || up(f->syrk_map_g, wm.data(), wm.size() * sizeof(int32_t)) != hipSuccess || up.finish() != hipSuccess) {
+        delete f;
+        return LSQAMD_EHIP;
+      }
+    }
   }
   *out = f;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int lsqamd_destroy(lsqamd_fit *fit) {
+int lsqamd_destroy(lsqamd_fit *fit) try {
   if (!fit) return 0;
   (void)hipStreamSynchronize(fit->st);
   resolve_timers(fit);
   delete fit;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 const char *lsqamd_last_error(const lsqamd_fit *fit) { return fit ? fit->err.c_str() : "null handle"; }
 
-int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
+int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) try {
   if (!f) return LSQAMD_EINVAL;
   if (!x || n_rows != f->N || n_x != (f->cfg.n_x > 0 ? f->cfg.n_x : 1))
     FAIL(f, LSQAMD_EINVAL, "set_x: expected %lld x %d", (long long)f->N, f->cfg.n_x);
@@ -1942,7 +2036,7 @@ int lsqamd_set_x(lsqamd_fit *f, const double *x, int64_t n_rows, int32_t n_x) {
   }
   f->have_x = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 // stack discipline and operand ranges of one RPN program (host side)
 static int validate_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, int32_t n_consts) {
@@ -1962,7 +2056,7 @@ static int validate_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, int
 }
 
 int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const double *consts,
-                    int32_t n_consts) {
+                    int32_t n_consts) try {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
   if (f->st_used) (void)hipStreamSynchronize(f->st);      // (work queued on this handle may still run the kernel about to be released)
@@ -2064,10 +2158,10 @@ int lsqamd_set_tape(lsqamd_fit *f, const int32_t *code, int32_t n_code, const do
   f->jit_why.clear();
   f->jit = lsqamd_jit::compile_tape(code, n_code, consts, n_consts, (int)f->P, f->cfg.n_x > 0 ? f->cfg.n_x : 1, f->jit_why);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 int lsqamd_set_tape_programs(lsqamd_fit *f, int32_t n_prog, const int64_t *row0, const int32_t *code,
-                             const int32_t *code_off, const double *consts, int32_t n_consts) {
+                             const int32_t *code_off, const double *consts, int32_t n_consts) try {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
   f->used_nrm = false;
@@ -2112,11 +2206,11 @@ int lsqamd_set_tape_programs(lsqamd_fit *f, int32_t n_prog, const int64_t *row0,
   f->tape_n_seg = 0;
   f->have_tape = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int32_t n_blocks,
                     const int64_t *block_row0, const int64_t *block_size, const int64_t *block_modes,
-                    const int32_t *block_tri, const double *wt) {
+                    const int32_t *block_tri, const double *wt) try {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
   if (n_blocks != f->cfg.n_blocks) FAIL(f, LSQAMD_EINVAL, "set_data: n_blocks differs from the config");
@@ -2165,9 +2259,9 @@ int lsqamd_set_data(lsqamd_fit *f, const double *ymean, const double *wdiag, int
   HIPCHK(f, up.finish());
   f->have_data = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_ymean(lsqamd_fit *f, const double *ymean) {
+int lsqamd_set_ymean(lsqamd_fit *f, const double *ymean) try {
   if (!f || !ymean) return LSQAMD_EINVAL;
   if (!f->have_data) FAIL(f, LSQAMD_EINVAL, "set_ymean: call lsqamd_set_data first");
   {
@@ -2177,9 +2271,9 @@ int lsqamd_set_ymean(lsqamd_fit *f, const double *ymean) {
   }
   f->have_cov = false;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) {
+int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) try {
   if (!f) return LSQAMD_EINVAL;
   if (!f->cfg.has_prior) FAIL(f, LSQAMD_EINVAL, "set_prior: the config says has_prior = 0");
   if (!mean || !prec) FAIL(f, LSQAMD_EINVAL, "set_prior: null argument");
@@ -2192,9 +2286,9 @@ int lsqamd_set_prior(lsqamd_fit *f, const double *mean, const double *prec) {
   }
   f->have_prior = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
+int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) try {
   if (!f || !opt) return LSQAMD_EINVAL;
   if (opt->xtol < 0 || opt->gtol < 0 || opt->maxit < 0) FAIL(f, LSQAMD_EINVAL, "set_options: negative tolerance/maxit");
   if (opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT) FAIL(f, LSQAMD_EINVAL, "set_options: unknown scaler");
@@ -2204,26 +2298,26 @@ int lsqamd_set_options(lsqamd_fit *f, const lsqamd_options *opt) {
   f->opt = *opt;
   f->drop_step_graphs();   // tolerances, factors and the scaler are baked into the captured nodes
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 size_t lsqamd_qr_work_bytes(const lsqamd_fit *f) { return f ? qr_work_bytes(f) : 0; }
 
-int lsqamd_set_qr_work(lsqamd_fit *f, void *dev_work, size_t work_bytes) {
+int lsqamd_set_qr_work(lsqamd_fit *f, void *dev_work, size_t work_bytes) try {
   if (!f) return LSQAMD_EINVAL;
   if (dev_work && work_bytes < qr_work_bytes(f)) FAIL(f, LSQAMD_ENOMEM, "set_qr_work: need %zu bytes", qr_work_bytes(f));
   f->qr_work = dev_work;
   f->qr_work_bytes = dev_work ? work_bytes : 0;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_qr_info(const lsqamd_fit *f, int32_t *passes, double *delta) {
+int lsqamd_qr_info(const lsqamd_fit *f, int32_t *passes, double *delta) try {
   if (!f) return LSQAMD_EINVAL;
   if (passes) *passes = f->qr_passes;
   if (delta) *delta = f->qr_delta;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
+int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) try {
   if (!f) return LSQAMD_EINVAL;
   if (!lower && !upper) {
     f->lb.clear();
@@ -2242,9 +2336,9 @@ int lsqamd_set_bounds(lsqamd_fit *f, const double *lower, const double *upper) {
   f->lb.swap(lb);
   f->ub.swap(ub);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_loss(lsqamd_fit *f, int32_t loss, double f_scale) {
+int lsqamd_set_loss(lsqamd_fit *f, int32_t loss, double f_scale) try {
   if (!f) return LSQAMD_EINVAL;
   if (loss < LSQAMD_LOSS_LINEAR || loss > LSQAMD_LOSS_ARCTAN) FAIL(f, LSQAMD_EINVAL, "set_loss: `loss` must be linear, soft_l1, huber, cauchy or arctan");
   if (!(f_scale > 0.0) || !std::isfinite(f_scale)) FAIL(f, LSQAMD_EINVAL, "set_loss: f_scale must be positive");
@@ -2252,9 +2346,9 @@ int lsqamd_set_loss(lsqamd_fit *f, int32_t loss, double f_scale) {
   f->f_scale = f_scale;
   f->drop_step_graphs();
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_x_scale(lsqamd_fit *f, const double *x_scale) {
+int lsqamd_set_x_scale(lsqamd_fit *f, const double *x_scale) try {
   if (!f) return LSQAMD_EINVAL;
   std::vector<double> v;
   if (x_scale) {
@@ -2264,9 +2358,9 @@ int lsqamd_set_x_scale(lsqamd_fit *f, const double *x_scale) {
   }
   f->x_scale.swap(v);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) {
+int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) try {
   if (!f) return LSQAMD_EINVAL;
   f->drop_step_graphs();
   if (!row_param) {
@@ -2286,9 +2380,9 @@ int lsqamd_set_param_rows(lsqamd_fit *f, const int32_t *row_param) {
   f->have_param_rows = any;
   f->initialised = false;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_linear(lsqamd_fit *f, const int32_t *index, int32_t n) {
+int lsqamd_set_linear(lsqamd_fit *f, const int32_t *index, int32_t n) try {
   if (!f || n < 0 || (n > 0 && !index)) return LSQAMD_EINVAL;
   std::vector<char> mask;
   if (n > 0) {
@@ -2300,29 +2394,29 @@ int lsqamd_set_linear(lsqamd_fit *f, const int32_t *index, int32_t n) {
   }
   f->linear.swap(mask);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_set_reduce(lsqamd_fit *f, lsqamd_reduce_fn fn, void *user) {
+int lsqamd_set_reduce(lsqamd_fit *f, lsqamd_reduce_fn fn, void *user) try {
   if (!f) return LSQAMD_EINVAL;
   f->reduce = fn;
   f->reduce_user = user;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 // rank that contributes the (replicated) prior terms before the all-reduce; default: this one
-int lsqamd_set_adds_prior(lsqamd_fit *f, int32_t on) {
+int lsqamd_set_adds_prior(lsqamd_fit *f, int32_t on) try {
   if (!f) return LSQAMD_EINVAL;
   f->adds_prior = on != 0;
   f->drop_step_graphs();
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_init(lsqamd_fit *f, const double *p0) {
+int lsqamd_init(lsqamd_fit *f, const double *p0) try {
   if (!f || !p0) return LSQAMD_EINVAL;
   return do_init(f, p0);
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_step(lsqamd_fit *f, int32_t *info) {
+int lsqamd_step(lsqamd_fit *f, int32_t *info) try {
   if (!f) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_step before lsqamd_init");
   if (f->opt.trs >= LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the scipy-plugin methods (trf, dogbox, minpack lm) run through lsqamd_run only");
@@ -2336,9 +2430,9 @@ int lsqamd_step(lsqamd_fit *f, int32_t *info) {
   }
   if (info) *info = convergence_test(f);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
+int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) try {
   if (!f) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_finish before lsqamd_init");
   const int rc = do_covariance(f);
@@ -2346,7 +2440,7 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) {
   fill_summary(f, out, 0, 0);
   if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : (rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : (rc == 0 ? f->cov_dropped : 0));
   return rc == LSQAMD_ENOTPD ? 0 : rc;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 // A whole small fit in ONE launch (jit.hip lsqamd_jit_lm): a compiled formula with at most a dozen parameters, uncorrelated rows,
 // a few thousand of them at most, plain lm on one rank -- the fits of examples/nist.py and tests/test_lsqfit.py, where the
@@ -2515,7 +2609,7 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   return 1;
 }
 
-int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
+int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) try {
   if (!f || !p0) return LSQAMD_EINVAL;
   struct Pair {   // recycled events: every return path hands them back
     lsqamd_fit *f;
@@ -2605,9 +2699,9 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) {
     out->cov_status = rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : (rc == 0 ? f->cov_dropped : rc);
   }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) {
+int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) try {
   if (!f || !p || !chi2) return LSQAMD_EINVAL;
   int rc = ready(f);
   if (rc) return rc;
@@ -2615,9 +2709,9 @@ int lsqamd_eval_residual(lsqamd_fit *f, const double *p, double *chi2) {
   rc = eval_residual_dev(f, f->p_trial, chi2);
   if (f->timing) resolve_timers(f);
   return rc;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) {
+int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) try {
   if (!f || !p || !out) return LSQAMD_EINVAL;
   int rc = ready(f);
   if (rc) return rc;
@@ -2644,9 +2738,9 @@ int lsqamd_eval_fcn(lsqamd_fit *f, const double *p, double *out, size_t cap) {
   for (int64_t i = 0; i < N; ++i)
     out[i] = y[(size_t)i] + (inb[(size_t)i] ? rr[(size_t)i] : r[(size_t)i] / w[(size_t)i]);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_eval_normal(lsqamd_fit *f, const double *p, double *chi2) {
+int lsqamd_eval_normal(lsqamd_fit *f, const double *p, double *chi2) try {
   if (!f || !p) return LSQAMD_EINVAL;
   int rc = ready(f);
   if (rc) return rc;
@@ -2668,9 +2762,9 @@ int lsqamd_eval_normal(lsqamd_fit *f, const double *p, double *chi2) {
   f->initialised = true;
   if (chi2) *chi2 = f->chi2;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_solve_damped(lsqamd_fit *f, double mu, const double *diag, double *v) {
+int lsqamd_solve_damped(lsqamd_fit *f, double mu, const double *diag, double *v) try {
   if (!f || !diag || !v) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "solve_damped needs lsqamd_eval_normal / lsqamd_init first");
   const int rc = solve_damped_dev(f, mu, diag);
@@ -2681,11 +2775,11 @@ int lsqamd_solve_damped(lsqamd_fit *f, double mu, const double *diag, double *v)
   }
   std::memcpy(v, f->hv.data(), sizeof(double) * f->P);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 int lsqamd_op_gemm_tn(void *stream, int64_t M, int64_t N, int64_t K, double alpha, const double *X,
                       int64_t ldx, const double *Y, int64_t ldy, double beta, double *C, int64_t ldc,
-                      int32_t upper_only, int32_t x_upper_tri) {
+                      int32_t upper_only, int32_t x_upper_tri) try {
   GemmTN g;
   g.X = X; g.Y = Y; g.C = C;
   g.M = M; g.N = N; g.K = K;
@@ -2694,47 +2788,47 @@ int lsqamd_op_gemm_tn(void *stream, int64_t M, int64_t N, int64_t K, double alph
   g.upper_only = upper_only;
   g.x_upper_tri = x_upper_tri;
   return launch_gemm_tn(reinterpret_cast<hipStream_t>(stream), g) == hipSuccess ? 0 : LSQAMD_EHIP;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 size_t lsqamd_op_potrf_work_bytes(int64_t n) { return potrf_work_bytes(n); }
 
 int lsqamd_op_potrf_upper(void *stream, double *A, int64_t n, int64_t lda, int64_t n_cols, double *work,
-                          size_t work_bytes, int32_t *dev_info) {
+                          size_t work_bytes, int32_t *dev_info) try {
   if (work_bytes < potrf_work_bytes(n)) return LSQAMD_ENOMEM;
   return potrf_upper(reinterpret_cast<hipStream_t>(stream), A, n, lda, n_cols, work, dev_info) == hipSuccess
              ? 0 : LSQAMD_EHIP;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int64_t lsqamd_nf(const lsqamd_fit *f) {
+int64_t lsqamd_nf(const lsqamd_fit *f) try {
   if (!f) return 0;
   int64_t nf = f->N;
   for (size_t b = 0; b < f->h_size.size(); ++b) nf -= f->h_size[b] - f->h_modes[b];
   if (f->cfg.has_prior) nf += f->P;
   return nf;
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
-int lsqamd_get_x(lsqamd_fit *f, double *out, size_t cap) {
+int lsqamd_get_x(lsqamd_fit *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (cap < (size_t)f->P) FAIL(f, LSQAMD_ECAPACITY, "get_x: need %lld", (long long)f->P);
   if ((int64_t)f->hx.size() != f->P) FAIL(f, LSQAMD_EINVAL, "get_x: no fit has run");
   if (const int rcm = refresh_mirrors(f)) return rcm;
   std::memcpy(out, f->hx.data(), sizeof(double) * f->P);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_get_grad(lsqamd_fit *f, double *out, size_t cap) {
+int lsqamd_get_grad(lsqamd_fit *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (cap < (size_t)f->P) FAIL(f, LSQAMD_ECAPACITY, "get_grad: need %lld", (long long)f->P);
   if ((int64_t)f->hg.size() != f->P) FAIL(f, LSQAMD_EINVAL, "get_grad: no fit has run");
   if (const int rcm = refresh_mirrors(f)) return rcm;
   std::memcpy(out, f->hg.data(), sizeof(double) * f->P);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 // Data part of f / J in the reference's order (_utilities.pyx:85-93): all 1x1 rows first,
 // then each block's kept modes.  Prior rows are appended by the host layer, which owns the
 // prior's whitening (any W with W^T W = precision is equivalent: SURVEY.md App. B).
-int lsqamd_get_f(lsqamd_fit *f, double *out, size_t cap) {
+int lsqamd_get_f(lsqamd_fit *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_f: no fit has run");
   int64_t nfd = f->N;
@@ -2755,9 +2849,9 @@ int lsqamd_get_f(lsqamd_fit *f, double *out, size_t cap) {
   for (size_t b = 0; b < f->h_size.size(); ++b)
     for (int64_t m = 0; m < f->h_modes[b]; ++m) out[o++] = r[(size_t)(f->h_row0[b] + m)];
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_get_J(lsqamd_fit *f, double *out, size_t cap) {
+int lsqamd_get_J(lsqamd_fit *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_J: no fit has run");
   const int64_t P = f->P;
@@ -2790,9 +2884,9 @@ int lsqamd_get_J(lsqamd_fit *f, double *out, size_t cap) {
   }
   HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_get_jtj(lsqamd_fit *f, double *out, size_t cap) {
+int lsqamd_get_jtj(lsqamd_fit *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_jtj: no fit has run");
   const int64_t P = f->P;
@@ -2802,9 +2896,9 @@ int lsqamd_get_jtj(lsqamd_fit *f, double *out, size_t cap) {
                              (size_t)P, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
+int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "get_cov: no fit has run");
   const int64_t P = f->P;
@@ -2822,7 +2916,7 @@ int lsqamd_get_cov(lsqamd_fit *f, double *out, size_t cap) {
                              (size_t)P, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 namespace {
 struct DpdyPlan {
@@ -2846,13 +2940,13 @@ DpdyPlan dpdy_plan(const lsqamd_fit *f, int64_t m, void *base) {
 }
 }  // namespace
 
-size_t lsqamd_dpdy_work_bytes(const lsqamd_fit *f, int64_t m) {
+size_t lsqamd_dpdy_work_bytes(const lsqamd_fit *f, int64_t m) try {
   if (!f || m < 1) return 0;
   return dpdy_plan(f, m, nullptr).bytes + 256;
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
 int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, size_t scratch_bytes,
-                double *out_t, size_t cap) {
+                double *out_t, size_t cap) try {
   if (!f || !out_t || !dev_scratch) return LSQAMD_EINVAL;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "dpdy: no fit has run");
   const int64_t P = f->P, N = f->N;
@@ -2927,7 +3021,7 @@ int lsqamd_dpdy(lsqamd_fit *f, const double *gt, int64_t m, void *dev_scratch, s
                              (size_t)nrows, hipMemcpyDeviceToHost, f->st));
   HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 namespace {
 struct Chi2Plan {
@@ -2951,13 +3045,13 @@ Chi2Plan chi2_plan(const lsqamd_fit *f, int64_t mc, void *base) {
 }
 }  // namespace
 
-size_t lsqamd_chi2_points_work_bytes(const lsqamd_fit *f, int64_t m) {
+size_t lsqamd_chi2_points_work_bytes(const lsqamd_fit *f, int64_t m) try {
   if (!f || m < 1) return 0;
   return chi2_plan(f, m, nullptr).bytes + 256;
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
 int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scratch, size_t scratch_bytes,
-                       double *chi2_out) {
+                       double *chi2_out) try {
   if (!f || !p || !chi2_out || !dev_scratch || m < 0) return LSQAMD_EINVAL;
   int rc = ready(f);
   if (rc) return rc;
@@ -3002,45 +3096,70 @@ int lsqamd_chi2_points(lsqamd_fit *f, const double *p, int64_t m, void *dev_scra
     f->nfev += (int32_t)mm;
   }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_handoff_stats(int64_t *out3) {
+int lsqamd_handoff_stats(int64_t *out3) try {
   if (!out3) return LSQAMD_EINVAL;
   for (int i = 0; i < 3; ++i) out3[i] = g_handoff[i].load();
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 void lsqamd_debug_set_potf2_stamps(void *dev_ptr) { lsqamd::g_potf2_dbg = (long long *)dev_ptr; }
 
+// self-tests of the boundary's own machinery, runnable without a GPU (tests/test_abi.py)
+int lsqamd_debug_throw(lsqamd_fit *f, int32_t kind) try {
+  if (kind == 1) throw std::bad_alloc();
+  if (kind == 2) throw std::runtime_error("lsqamd_debug_throw");
+  if (kind == 3) throw 42;
+  if (kind == 4) { std::vector<double> v; v.reserve(v.max_size()); }   // a real allocation failure (std::length_error / bad_alloc)
+  return 0;
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
+
+int lsqamd_debug_per_device_once(int32_t dev, int32_t reset) try {
+  // how often has the "set the kernel attributes" action of a PerDeviceOnce run for device `dev`?  (the bookkeeping that
+  // guards every kernel-attribute call of the library, on an instance of its own: no HIP call)
+  static lsqamd::PerDeviceOnce once;
+  static std::atomic<int> runs[lsqamd::PerDeviceOnce::kMaxDev + 1];
+  if (reset) {
+    once.done.store(0);
+    for (auto &r : runs) r.store(0);
+    return 0;
+  }
+  const int slot = (dev >= 0 && dev < lsqamd::PerDeviceOnce::kMaxDev) ? dev : lsqamd::PerDeviceOnce::kMaxDev;
+  const hipError_t e = once.run_for(dev, [slot] { runs[slot].fetch_add(1); return hipSuccess; });
+  if (e != hipSuccess) return LSQAMD_EHIP;
+  return runs[slot].load();
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
+
 // introspection for tests: bit0 uniform-block batched whitening, bits 8.. split-K factor
-int64_t lsqamd_debug_flags(const lsqamd_fit *f) {
+int64_t lsqamd_debug_flags(const lsqamd_fit *f) try {
   if (!f) return -1;
   return (int64_t)(f->uniform_blocks ? 1 : 0) | (int64_t)(f->used_synth ? 2 : 0) | (int64_t)(f->graph_launches > 0 ? 4 : 0) |
          (int64_t)(f->used_nrm ? 16 : 0) | (int64_t)(f->used_one_launch ? 32 : 0) |
          (int64_t)(f->jit || (!f->progs.empty() && f->progs_compiled == (int)f->progs.size()) ? 8 : 0) |
          ((int64_t)f->splits << 8) |
          ((int64_t)f->h_size.size() << 32);
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
-int lsqamd_timing_enable(lsqamd_fit *f, int32_t on) {
+int lsqamd_timing_enable(lsqamd_fit *f, int32_t on) try {
   if (!f) return LSQAMD_EINVAL;
   f->timing = on != 0;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_timing_get(lsqamd_fit *f, int32_t which, double *total_ms, int64_t *count) {
+int lsqamd_timing_get(lsqamd_fit *f, int32_t which, double *total_ms, int64_t *count) try {
   if (!f || which < 0 || which >= LSQAMD_T_COUNT) return LSQAMD_EINVAL;
   resolve_timers(f);
   if (total_ms) *total_ms = f->timers[which].total_ms;
   if (count) *count = f->timers[which].count;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_timing_reset(lsqamd_fit *f) {
+int lsqamd_timing_reset(lsqamd_fit *f) try {
   if (!f) return LSQAMD_EINVAL;
   resolve_timers(f);
   for (auto &t : f->timers) { t.total_ms = 0.0; t.count = 0; }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 }  // extern "C"

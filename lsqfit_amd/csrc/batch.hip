@@ -760,16 +760,16 @@ int round_all(lsqamdb_fits *f) {
 
 extern "C" {
 
-size_t lsqamdb_workspace_bytes(const lsqamd_config *cfg, int32_t n_fits) {
+size_t lsqamdb_workspace_bytes(const lsqamd_config *cfg, int32_t n_fits) try {
   if (check_cfg_b(cfg, n_fits) != 0) return 0;
   lsqamdb_fits tmp;
   tmp.cfg = *cfg;
   tmp.B = n_fits;
   return carve_b(&tmp, nullptr, true);
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
 int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace, size_t workspace_bytes,
-                   void *stream, lsqamdb_fits **out) {
+                   void *stream, lsqamdb_fits **out) try {
   if (!out) return LSQAMD_EINVAL;
   *out = nullptr;
   const int rc = check_cfg_b(cfg, n_fits);
@@ -800,9 +800,9 @@ int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace
   }
   *out = f;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int lsqamdb_destroy(lsqamdb_fits *f) {
+int lsqamdb_destroy(lsqamdb_fits *f) try {
   if (!f) return 0;
   (void)hipStreamSynchronize(f->st);
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
@@ -811,19 +811,19 @@ int lsqamdb_destroy(lsqamdb_fits *f) {
   if (f->jit) lsqamd_jit::release(static_cast<const lsqamd_jit::Kernel *>(f->jit));
   delete f;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 const char *lsqamdb_last_error(const lsqamdb_fits *f) { return f ? f->err.c_str() : "null handle"; }
 
-int lsqamdb_set_x(lsqamdb_fits *f, const double *x, int64_t n_rows, int32_t n_x) {
+int lsqamdb_set_x(lsqamdb_fits *f, const double *x, int64_t n_rows, int32_t n_x) try {
   if (!f) return LSQAMD_EINVAL;
   if (!x || n_rows != f->N || n_x != (f->cfg.n_x > 0 ? f->cfg.n_x : 1)) BFAIL(f, LSQAMD_EINVAL, "set_x: shape");
   BHIP(f, hipMemcpy(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice));
   f->have_x = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts) {
+int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts) try {
   if (!f) return LSQAMD_EINVAL;
   if (!code || n_code < 1 || n_code > LSQAMD_TAPE_MAX_CODE || n_consts < 0 || n_consts > 1024 || (n_consts > 0 && !consts))
     BFAIL(f, LSQAMD_EINVAL, "set_tape: sizes");
@@ -857,31 +857,31 @@ int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const
   f->n_tape = n_code;
   f->have_tape = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 /* shared data: ymean[N], wdiag[N] = 1/sdev of the 1x1 rows */
-int lsqamdb_set_data(lsqamdb_fits *f, const double *ymean, const double *wdiag) {
+int lsqamdb_set_data(lsqamdb_fits *f, const double *ymean, const double *wdiag) try {
   if (!f || !ymean || !wdiag) return LSQAMD_EINVAL;
   BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice));
   BHIP(f, hipMemcpy(f->wdiag, wdiag, sizeof(double) * f->N, hipMemcpyHostToDevice));
   f->ymean_stride = 0;
   f->have_data = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 /* per-fit data means ymean[B*N] (simulated / bootstrap copies of one data set: same
  * covariance, new means); the whitening set by lsqamdb_set_data / _set_blocks is kept */
-int lsqamdb_set_data_means(lsqamdb_fits *f, const double *ymean) {
+int lsqamdb_set_data_means(lsqamdb_fits *f, const double *ymean) try {
   if (!f || !ymean) return LSQAMD_EINVAL;
   if (!f->have_data) BFAIL(f, LSQAMD_EINVAL, "set_data_means: call lsqamdb_set_data first");
   BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->B * f->N, hipMemcpyHostToDevice));
   f->ymean_stride = f->N;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 /* correlated data blocks shared by all fits; same layout as lsqamd_set_data */
 int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, const int64_t *size,
-                       const int64_t *modes, const int32_t *tri, const double *wt) {
+                       const int64_t *modes, const int32_t *tri, const double *wt) try {
   if (!f) return LSQAMD_EINVAL;
   if (n_blocks != f->cfg.n_blocks) BFAIL(f, LSQAMD_EINVAL, "set_blocks: n_blocks differs from the config");
   if (n_blocks == 0) { f->have_blocks = true; return 0; }
@@ -913,11 +913,11 @@ int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, c
   BHIP(f, hipMemcpy(f->wt, wt, sizeof(double) * off, hipMemcpyDefault));   // host or device source
   f->have_blocks = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 /* per-fit priors: mean[B*P]; prec[B*P] = 1/sdev^2 per fit (diagonal), or -- cfg.prior_dense -- ONE dense
  * P x P precision shared by all fits (copies of a fit differ in their prior means, not its covariance) */
-int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) {
+int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) try {
   if (!f || !mean || !prec) return LSQAMD_EINVAL;
   if (!f->cfg.has_prior) BFAIL(f, LSQAMD_EINVAL, "set_priors: config has no prior");
   BHIP(f, hipMemcpy(f->pmean, mean, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
@@ -925,20 +925,20 @@ int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) 
                     hipMemcpyDefault));   // host or device source
   f->have_prior = true;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamdb_set_options(lsqamdb_fits *f, const lsqamd_options *opt) {
+int lsqamdb_set_options(lsqamdb_fits *f, const lsqamd_options *opt) try {
   if (!f || !opt) return LSQAMD_EINVAL;
   if (opt->xtol < 0 || opt->gtol < 0 || opt->maxit < 0 || opt->scaler < 0 || opt->scaler > LSQAMD_SCALE_MARQUARDT)
     BFAIL(f, LSQAMD_EINVAL, "set_options: bad value");
   if (opt->trs != LSQAMD_TRS_LM) BFAIL(f, LSQAMD_EUNSUPPORTED, "set_options: the batched engine runs alg='lm' only");
   f->opt = *opt;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 /* run all fits from p0[B*P]; summaries[B] (may be NULL).  use_graph != 0: capture one round in a
  * hipGraph after the first eager round and replay it. */
-int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, int32_t use_graph) {
+int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, int32_t use_graph) try {
   if (!f || !p0) return LSQAMD_EINVAL;
   if (!f->have_data || (f->cfg.has_prior && !f->have_prior) || (f->cfg.n_blocks > 0 && !f->have_blocks) ||
       (f->cfg.model != LSQAMD_MODEL_IDENTITY && !f->have_x) || (f->cfg.model == LSQAMD_MODEL_TAPE && !f->have_tape))
@@ -1089,17 +1089,17 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     }
   }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamdb_get_x(lsqamdb_fits *f, double *out, size_t cap) {
+int lsqamdb_get_x(lsqamdb_fits *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (cap < (size_t)(f->B * f->P)) BFAIL(f, LSQAMD_ECAPACITY, "get_x: need %lld", (long long)(f->B * f->P));
   BHIP(f, hipMemcpy(out, f->px, sizeof(double) * f->B * f->P, hipMemcpyDeviceToHost));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 /* (J^T J)^-1 of every fit at its final point + log det(J^T J); results stay on the device */
-int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) {
+int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) try {
   if (!f) return LSQAMD_EINVAL;
   if (!f->ran) BFAIL(f, LSQAMD_EINVAL, "covariance: run first");
   if (f->have_cov && f->one_launch) {     // formed by the fit kernel itself
@@ -1137,9 +1137,9 @@ int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) {
     BHIP(f, hipMemcpy(logdet_out, f->logdet, sizeof(double) * B, hipMemcpyDeviceToHost));
   }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamdb_get_cov(lsqamdb_fits *f, int32_t fit, double *out, size_t cap) {
+int lsqamdb_get_cov(lsqamdb_fits *f, int32_t fit, double *out, size_t cap) try {
   if (!f || !out || fit < 0 || fit >= f->B) return LSQAMD_EINVAL;
   const int64_t P = f->P;
   if (cap < (size_t)(P * P)) BFAIL(f, LSQAMD_ECAPACITY, "get_cov: need %lld", (long long)(P * P));
@@ -1150,9 +1150,9 @@ int lsqamdb_get_cov(lsqamdb_fits *f, int32_t fit, double *out, size_t cap) {
   BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov + (int64_t)fit * P * f->ldm, sizeof(double) * f->ldm,
                       sizeof(double) * P, (size_t)P, hipMemcpyDeviceToHost));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamdb_get_cov_all(lsqamdb_fits *f, double *out, size_t cap) {
+int lsqamdb_get_cov_all(lsqamdb_fits *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   const int64_t P = f->P, B = f->B;
   if (cap < (size_t)(B * P * P)) BFAIL(f, LSQAMD_ECAPACITY, "get_cov_all: need %lld", (long long)(B * P * P));
@@ -1164,7 +1164,7 @@ int lsqamdb_get_cov_all(lsqamdb_fits *f, double *out, size_t cap) {
   BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P, (size_t)(B * P),
                       hipMemcpyDeviceToHost));
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 int32_t lsqamdb_rounds(const lsqamdb_fits *f) { return f ? f->rounds : -1; }
 

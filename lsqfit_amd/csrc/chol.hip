@@ -353,21 +353,22 @@ __global__ __launch_bounds__(256) void potf2_inv_kernel(double *A, int64_t lda, 
   STAMP(18);
 }
 
-static bool g_potf2_attr = false;
+static PerDeviceOnce g_potf2_attr;   // per device, thread-safe (common.h)
 long long *g_potf2_dbg = nullptr;  // device buffer of 32 cycle stamps (LSQAMD_POTF2_TIMING builds)
 static constexpr size_t POTF2_LDS = (size_t)(NB * PLD + NB + SB * WLD) * sizeof(double);  // 140 KiB
 
 static hipError_t launch_potf2(hipStream_t st, double *A, int64_t lda, int nb, double *uinv,
                                int32_t *info, int32_t k0, int32_t batch = 1, int64_t strideA = 0,
                                int64_t strideW = 0, const int32_t *active = nullptr) {
-  if (!g_potf2_attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
-    if (e != hipSuccess) return e;
-    g_potf2_attr = true;
+  {
+    const hipError_t ea = g_potf2_attr.run([] {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
+      if (e != hipSuccess) return e;
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(potf2_inv_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTF2_LDS);
+    });
+    if (ea != hipSuccess) return ea;
   }
   static const bool use_mfma = [] {
     const char *e = getenv("LSQAMD_POTF2");

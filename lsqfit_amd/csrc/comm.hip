@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -112,8 +113,10 @@ struct Shared {
   Comm comm = nullptr;
   int refs = 0, rank = 0, nranks = 1;
   double init_ms = 0.0;
+  bool initialising = false;   // a thread is inside ncclCommInitRank for this key (g_reg_mu NOT held meanwhile)
 };
 std::mutex g_reg_mu;
+std::condition_variable g_reg_cv;   // signalled when an entry leaves the `initialising` state
 std::map<std::string, Shared> &registry() {
   static std::map<std::string, Shared> r;
   return r;
@@ -135,26 +138,39 @@ bool use_rsag() {   // read per call (a getenv next to a 69 MB collective is fre
 
 namespace lsqamd_host {
 
-int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count) {
+// sums enqueued on `st` (the handle's stream, or its exchange stream for the grouped exchange of api.hip eval_normal_dev)
+int comm_all_reduce_on(lsqamd_fit *f, hipStream_t st, double *buf, int64_t count) {
   Api &a = api();
   Comm c = (Comm)f->comm;
   const int64_t n = f->comm_nranks;
   // slices of whole 256-byte lines; below 64 KiB per rank the latency-optimised all-reduce wins
   const int64_t slice = (count / n) / 32 * 32;
   if (!use_rsag() || slice < 8192) {
-    NCCLCHK(f, a.AllReduce(buf, buf, (size_t)count, DT_FLOAT64, OP_SUM, c, f->st));
+    NCCLCHK(f, a.AllReduce(buf, buf, (size_t)count, DT_FLOAT64, OP_SUM, c, st));
     return 0;
   }
   double *mine = buf + (int64_t)f->comm_rank * slice;
   const int64_t done = slice * n;
   const bool group = a.GroupStart && done < count;
   if (group) NCCLCHK(f, a.GroupStart());
-  NCCLCHK(f, a.ReduceScatter(buf, mine, (size_t)slice, DT_FLOAT64, OP_SUM, c, f->st));
-  if (done < count) NCCLCHK(f, a.AllReduce(buf + done, buf + done, (size_t)(count - done), DT_FLOAT64, OP_SUM, c, f->st));
-  if (group) NCCLCHK(f, a.GroupEnd());
-  NCCLCHK(f, a.AllGather(mine, buf, (size_t)slice, DT_FLOAT64, c, f->st));
+  // an error between GroupStart and GroupEnd must still close the group (an open group swallows every later call of the
+  // thread): remember the first failure, end the group, then report
+  int r1 = a.ReduceScatter(buf, mine, (size_t)slice, DT_FLOAT64, OP_SUM, c, st);
+  const char *what = "ncclReduceScatter";
+  if (r1 == RESULT_SUCCESS && done < count) {
+    r1 = a.AllReduce(buf + done, buf + done, (size_t)(count - done), DT_FLOAT64, OP_SUM, c, st);
+    what = "ncclAllReduce (tail)";
+  }
+  if (group) {
+    const int r2 = a.GroupEnd();
+    if (r1 == RESULT_SUCCESS && r2 != RESULT_SUCCESS) { r1 = r2; what = "ncclGroupEnd"; }
+  }
+  if (r1 != RESULT_SUCCESS) FAIL(f, LSQAMD_EREDUCE, "%s: %s", what, a.GetErrorString(r1));
+  NCCLCHK(f, a.AllGather(mine, buf, (size_t)slice, DT_FLOAT64, c, st));
   return 0;
 }
+
+int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count) { return comm_all_reduce_on(f, f->st, buf, count); }
 
 void comm_release(lsqamd_fit *f) {
   if (f->comm) {     // the communicator itself stays with the process (lsqamd_comm_shutdown ends it): the next handle reuses it
@@ -172,7 +188,7 @@ void comm_release(lsqamd_fit *f) {
 
 extern "C" {
 
-int lsqamd_comm_unique_id(void *id_out, size_t cap) {
+int lsqamd_comm_unique_id(void *id_out, size_t cap) try {
   if (!id_out || cap < LSQAMD_COMM_ID_BYTES) return LSQAMD_EINVAL;
   Api &a = api();
   if (!a.ok) return LSQAMD_EUNSUPPORTED;
@@ -180,9 +196,9 @@ int lsqamd_comm_unique_id(void *id_out, size_t cap) {
   if (a.GetUniqueId(&id) != RESULT_SUCCESS) return LSQAMD_EREDUCE;
   std::memcpy(id_out, id.internal, LSQAMD_COMM_ID_BYTES);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int lsqamd_comm_init(lsqamd_fit *f, const void *id, size_t id_bytes, int32_t rank, int32_t nranks) {
+int lsqamd_comm_init(lsqamd_fit *f, const void *id, size_t id_bytes, int32_t rank, int32_t nranks) try {
   if (!f) return LSQAMD_EINVAL;
   if (!id || id_bytes != LSQAMD_COMM_ID_BYTES || nranks < 1 || rank < 0 || rank >= nranks)
     FAIL(f, LSQAMD_EINVAL, "comm_init: need the %d-byte id of lsqamd_comm_unique_id and 0 <= rank < nranks", LSQAMD_COMM_ID_BYTES);
@@ -193,46 +209,73 @@ int lsqamd_comm_init(lsqamd_fit *f, const void *id, size_t id_bytes, int32_t ran
   (void)hipGetDevice(&dev);
   std::string key = std::to_string(dev) + ":";
   key.append(static_cast<const char *>(id), LSQAMD_COMM_ID_BYTES);
-  std::lock_guard<std::mutex> lk(g_reg_mu);
-  auto it = registry().find(key);
-  if (it != registry().end()) {
+  // ncclCommInitRank is a COLLECTIVE (it returns when every rank has joined): it must not run under the registry's lock.
+  // One process may drive several GPUs with a thread per rank (the key holds the device): thread 0 inside CommInitRank
+  // waiting for rank 1 while thread 1 waits for the lock would never finish.  So: claim the key under the lock
+  // (`initialising`), release the lock around the call, publish or withdraw the entry afterwards; a second handle naming
+  // a key that is being initialised waits on the condition variable for the outcome.
+  std::unique_lock<std::mutex> lk(g_reg_mu);
+  for (;;) {
+    auto it = registry().find(key);
+    if (it == registry().end()) break;
+    if (it->second.initialising) {
+      g_reg_cv.wait(lk);
+      continue;                      // (the entry may be gone: the initialisation failed)
+    }
     if (it->second.rank != rank || it->second.nranks != nranks)
       FAIL(f, LSQAMD_EINVAL, "comm_init: this id already names a communicator with rank %d of %d", it->second.rank, it->second.nranks);
     it->second.refs++;
     f->comm = it->second.comm;
-  } else {
-    UniqueId u;
-    std::memcpy(u.internal, id, LSQAMD_COMM_ID_BYTES);
-    Comm c = nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    NCCLCHK(f, a.CommInitRank(&c, nranks, u, rank));
-    Shared sh;
-    sh.comm = c; sh.refs = 1; sh.rank = rank; sh.nranks = nranks;
-    sh.init_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    registry()[key] = sh;
-    f->comm = c;
+    f->comm_key = key;
+    f->comm_rank = rank;
+    f->comm_nranks = nranks;
+    return 0;
   }
+  {
+    Shared claim;
+    claim.initialising = true; claim.rank = rank; claim.nranks = nranks;
+    registry()[key] = claim;
+  }
+  lk.unlock();
+  UniqueId u;
+  std::memcpy(u.internal, id, LSQAMD_COMM_ID_BYTES);
+  Comm c = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  const int ir = a.CommInitRank(&c, nranks, u, rank);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  lk.lock();
+  if (ir != RESULT_SUCCESS) {
+    registry().erase(key);
+    g_reg_cv.notify_all();
+    FAIL(f, LSQAMD_EREDUCE, "ncclCommInitRank: %s", a.GetErrorString(ir));
+  }
+  {
+    Shared &sh = registry()[key];
+    sh.comm = c; sh.refs = 1; sh.rank = rank; sh.nranks = nranks; sh.init_ms = ms; sh.initialising = false;
+  }
+  g_reg_cv.notify_all();
+  f->comm = c;
   f->comm_key = key;
   f->comm_rank = rank;
   f->comm_nranks = nranks;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_comm_stats(const lsqamd_fit *f, double *init_ms, int32_t *handles) {
+int lsqamd_comm_stats(const lsqamd_fit *f, double *init_ms, int32_t *handles) try {
   if (!f) return LSQAMD_EINVAL;
   std::lock_guard<std::mutex> lk(g_reg_mu);
   auto it = registry().find(f->comm_key);
-  const bool have = f->comm && it != registry().end();
+  const bool have = f->comm && it != registry().end() && !it->second.initialising;
   if (init_ms) *init_ms = have ? it->second.init_ms : 0.0;
   if (handles) *handles = have ? it->second.refs : 0;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int lsqamd_comm_shutdown(void) {
+int lsqamd_comm_shutdown(void) try {
   std::lock_guard<std::mutex> lk(g_reg_mu);
   int busy = 0;
   for (auto it = registry().begin(); it != registry().end();) {
-    if (it->second.refs > 0) {
+    if (it->second.refs > 0 || it->second.initialising) {
       ++busy;
       ++it;
       continue;
@@ -241,20 +284,20 @@ int lsqamd_comm_shutdown(void) {
     it = registry().erase(it);
   }
   return busy;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
-int lsqamd_comm_destroy(lsqamd_fit *f) {
+int lsqamd_comm_destroy(lsqamd_fit *f) try {
   if (!f) return LSQAMD_EINVAL;
   (void)hipStreamSynchronize(f->st);
   lsqamd_host::comm_release(f);
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
-int lsqamd_comm_info(const lsqamd_fit *f, int32_t *rank, int32_t *nranks) {
+int lsqamd_comm_info(const lsqamd_fit *f, int32_t *rank, int32_t *nranks) try {
   if (!f) return LSQAMD_EINVAL;
   if (rank) *rank = f->comm ? f->comm_rank : -1;
   if (nranks) *nranks = f->comm ? f->comm_nranks : 0;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 }  // extern "C"

@@ -4,9 +4,92 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <cstdio>
+#include <exception>
+#include <mutex>
+#include <new>
+
 #include "../../include/lsqfit_amd.h"
 
 namespace lsqamd {
+
+struct lsqamd_abi_no_handle { const char *err; };   // (abi_exception(nullptr): nothing to record the text in)
+
+// ---- exception barrier of the C ABI ------------------------------------------------
+// "never throw across the ABI" (the reference's callbacks are `noexcept`, src/lsqfit/_gsl.pyx:726-760, and a
+// C++ exception unwinding into ctypes / cgo / JNI frames aborts the host process).  Every `extern "C"` export with a body of
+// more than one statement is a function-try-block closed by LSQAMD_ABI_CATCH: std::bad_alloc -> LSQAMD_ENOMEM, anything
+// else -> LSQAMD_EINTERNAL, the text in the handle's last_error where there is a (non-const) handle.
+// (tests/test_abi.py checks the source for the guard on every export and drives it through lsqamd_debug_throw.)
+template <class H> int abi_exception(H *h) noexcept {
+  int code = LSQAMD_EINTERNAL;
+  char buf[320];
+  std::snprintf(buf, sizeof buf, "internal error: unknown C++ exception caught at the C ABI");
+  try {
+    throw;   // the exception in flight (only ever called from a catch handler)
+  } catch (const std::bad_alloc &) {
+    code = LSQAMD_ENOMEM;
+    std::snprintf(buf, sizeof buf, "out of host memory (std::bad_alloc caught at the C ABI)");
+  } catch (const std::exception &e) {
+    std::snprintf(buf, sizeof buf, "internal error: %s (C++ exception caught at the C ABI)", e.what());
+  } catch (...) {
+  }
+  if (h) {
+    try { h->err = buf; } catch (...) {}
+  }
+  return code;
+}
+inline int abi_exception(std::nullptr_t) noexcept { return abi_exception(static_cast<lsqamd_abi_no_handle *>(nullptr)); }
+#define LSQAMD_ABI_CATCH(...) catch (...) { __VA_ARGS__ }
+
+// ---- once per DEVICE, from any thread ---------------------------------------------
+// hipFuncSetAttribute(..., MaxDynamicSharedMemorySize, ...) applies to the CURRENT device only, and the ABI lets one
+// process hold handles on several GPUs from several host threads (lsqamd_create records the device, lsqamd_query_devices
+// enumerates them): every "set the attribute the first time this launcher runs" is therefore bookkeeping per device id,
+// read lock-free on the launch path and written under a mutex.  Devices beyond the table run the setter every time.
+struct PerDeviceOnce {
+  static constexpr int kMaxDev = 64;
+  std::atomic<uint64_t> done{0};   // bit d: device d holds the attributes
+  std::mutex mu;
+  template <class F> hipError_t run_for(int dev, F &&setter) {
+    if (dev < 0 || dev >= kMaxDev) return setter();
+    const uint64_t bit = 1ull << dev;
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.load(std::memory_order_relaxed) & bit) return hipSuccess;
+    const hipError_t e = setter();
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+  }
+  template <class F> hipError_t run(F &&setter) {
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    return run_for(dev, static_cast<F &&>(setter));
+  }
+};
+// the same for an attribute that grows with the problem (a kernel whose dynamic LDS depends on the tape): the largest value
+// set so far, per device; the setter runs under the mutex only when a launch needs more
+struct PerDeviceMax {
+  std::atomic<size_t> have[PerDeviceOnce::kMaxDev] = {};
+  std::mutex mu;
+  template <class F> hipError_t ensure_for(int dev, size_t want, F &&setter) {
+    if (dev < 0 || dev >= PerDeviceOnce::kMaxDev) return setter(want);
+    if (have[dev].load(std::memory_order_acquire) >= want) return hipSuccess;
+    std::lock_guard<std::mutex> lk(mu);
+    if (have[dev].load(std::memory_order_relaxed) >= want) return hipSuccess;
+    const hipError_t e = setter(want);
+    if (e == hipSuccess) have[dev].store(want, std::memory_order_release);
+    return e;
+  }
+  template <class F> hipError_t ensure(size_t want, F &&setter) {
+    int dev = 0;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    return ensure_for(dev, want, static_cast<F &&>(setter));
+  }
+};
 
 // ---- fp64 MFMA GEMM, "TN" form (gemm_tn_f64.hip) ---------------------------------
 // C[M x N] = alpha * sum_k X[k][m] * Y[k][n] + beta * C      (all row-major)
@@ -64,6 +147,7 @@ bool whiten_synth_eligible(int32_t model, int64_t B, int64_t P);
 hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a);
 int64_t syrk_work_count(int64_t P, int32_t splits);
 void syrk_work_fill(int64_t P, int32_t splits, int32_t *out);
+int64_t syrk_work_fill_rows(int64_t P, int32_t splits, int row0, int row1, int32_t *out);   // tile rows [row0, row1) only
 
 // ---- Cholesky family (chol.hip) ---------------------------------------------------
 constexpr int CHOL_NB = 128;
@@ -191,7 +275,8 @@ hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64
 // packed upper tiles <- sum over split-K slabs (matrix layout, P x ld each)
 hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
                                 int64_t split_stride, int64_t P, int64_t ld, double *apk,
-                                const double *prior = nullptr, int32_t prior_dense = 0);
+                                const double *prior = nullptr, int32_t prior_dense = 0,
+                                int64_t tile0 = 0, int64_t n_tiles = -1);   // packed tiles [tile0, tile0 + n_tiles) only (-1: all)
 // prior precision into the packed tiles (with_matrix) and into gvec = [J^T f ; chi2]
 hipError_t launch_add_prior(hipStream_t st, double *apk, int64_t P, const double *prec, int32_t dense,
                             const double *pmean, const double *p, double *tvec, double *gvec,

@@ -24,6 +24,7 @@ void event_give(hipEvent_t e, int dev = -1);
 hipStream_t stream_take();          // a non-blocking stream (recycled ones are idle: their last owner synchronised them)
 void stream_give(hipStream_t s);
 int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count);   // sums enqueued on f->st
+int comm_all_reduce_on(lsqamd_fit *f, hipStream_t st, double *buf, int64_t count);   // ... on another stream of the handle
 
 struct TimerSlot {
   double total_ms = 0.0;
@@ -100,6 +101,15 @@ struct lsqamd_fit {
   void *comm = nullptr;
   int32_t comm_rank = 0, comm_nranks = 1;
   std::string comm_key;            // its entry in the process-wide registry of communicators (comm.hip)
+  // grouped exchange (api.hip eval_normal_dev; LSQAMD_EXCHANGE_GROUPS = G > 1, read at lsqamd_create): the J^T J work list cut
+  // into G groups of tile rows, group g's packed tiles summed over the ranks on `xst` while group g + 1 is computed on `st`
+  int32_t xg = 1;                  // groups (1: one launch, one exchange on the step's stream)
+  int32_t xg_row[9] = {0};         // tile rows [xg_row[g], xg_row[g + 1]) of group g
+  int32_t xg_work[9] = {0};        // its entries in syrk_map_g: [xg_work[g], xg_work[g + 1])
+  int64_t xg_tile[9] = {0};        // its packed tiles: [xg_tile[g], xg_tile[g + 1])
+  int32_t *syrk_map_g = nullptr;   // the groups' work lists, one after the other (device)
+  hipStream_t xst = nullptr;       // exchange stream (taken at the first grouped exchange, given back with the handle)
+  hipEvent_t xg_ready[8] = {nullptr}, xg_done[8] = {nullptr};
 
   // solver = qr: caller-provided device scratch (lsqamd_set_qr_work) and what the last run did
   void *qr_work = nullptr;
@@ -203,6 +213,14 @@ struct lsqamd_fit {
     if (pin) lsqamd_host::pinned_give(pin, pin_bytes, dev);
     if (stage) lsqamd_host::pinned_give(stage, stage_bytes, dev);
     lsqamd_host::comm_release(this);
+    if (xst) {
+      (void)hipStreamSynchronize(xst);
+      lsqamd_host::stream_give(xst);
+    }
+    for (int g = 0; g < 8; ++g) {
+      if (xg_ready[g]) lsqamd_host::event_give(xg_ready[g], dev);
+      if (xg_done[g]) lsqamd_host::event_give(xg_done[g], dev);
+    }
   }
 };
 
@@ -228,16 +246,17 @@ struct Scope {  // HIP-event bracket for one phase
   lsqamd_fit *f;
   int which;
   hipEvent_t a = nullptr, b = nullptr;
-  Scope(lsqamd_fit *fit, int w) : f(fit), which(w) {
+  hipStream_t on;
+  Scope(lsqamd_fit *fit, int w, hipStream_t stream = nullptr) : f(fit), which(w), on(stream ? stream : fit->st) {
     if (f->timing) {
       a = take_event(f);
       b = take_event(f);
-      (void)hipEventRecord(a, f->st);
+      (void)hipEventRecord(a, on);
     }
   }
   ~Scope() {
     if (f->timing) {
-      (void)hipEventRecord(b, f->st);
+      (void)hipEventRecord(b, on);
       f->timers[which].pending.emplace_back(a, b);
     }
   }

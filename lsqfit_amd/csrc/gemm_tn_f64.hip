@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_panel_kernel(GemmDev g) {
     }
 }
 
-static bool g_attr_set = false;
+static PerDeviceOnce g_attr_once;   // dynamic-LDS attributes of the product kernels, per device
 
 static int64_t small_gemm_max() {
   static const int64_t v = [] {
@@ -907,27 +907,21 @@ bool gemm_tn_fuses_colsum(const GemmTN &a) {
 
 hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (!g_attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_kernel<false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    g_attr_set = true;
+  {
+    const hipError_t ea = g_attr_once.run([] {
+      const void *fns[] = {reinterpret_cast<const void *>(gemm_tn_f64_kernel<true>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_kernel<false>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, false>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true, false>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, true>)};
+      for (const void *fn : fns) {
+        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
+        if (e != hipSuccess) return e;
+      }
+      return hipSuccess;
+    });
+    if (ea != hipSuccess) return ea;
   }
   GemmDev g;
   g.X = a.X; g.Y = a.Y; g.C = a.C;
@@ -982,13 +976,12 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
     const int64_t nb_ = a.batch < 1 ? 1 : a.batch;
     if (force_pn == 0 && a.M == BM && a.K == BM && a.N % OS_PN == 0 && a.x_upper_tri && g.vec_x && g.vec_y &&
         a.alpha == 1.0 && a.beta == 0.0 && a.ldx >= BM) {
-      static bool attr = false;
-      if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_panel_oneshot_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES_OS);
-        if (e != hipSuccess) return e;
-        attr = true;
-      }
+      static PerDeviceOnce attr_os;
+      const hipError_t eo = attr_os.run([] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(gemm_tn_f64_panel_oneshot_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES_OS);
+      });
+      if (eo != hipSuccess) return eo;
       dim3 grido((unsigned)(a.N / OS_PN), 1, (unsigned)nb_);
       hipLaunchKernelGGL(gemm_tn_f64_panel_oneshot_kernel, grido, dim3(256), GEMM_LDS_BYTES_OS, st, g);
       return hipGetLastError();
@@ -1066,18 +1059,28 @@ int64_t syrk_work_count(int64_t P, int32_t splits) {
   return T * (T + 1) / 2 * (splits < 1 ? 1 : splits);
 }
 
-void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
+void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) { (void)syrk_work_fill_rows(P, splits, 0, (int)((P + BM - 1) / BM), out); }
+
+// the same list for the tile rows [row0, row1) only (the exchange groups of a sharded fit, api.hip eval_normal_dev: one launch
+// per group of tile rows, so that a group's packed tiles can be on their way to the other ranks while the next group is being
+// computed); returns the number of entries.  Same ordering rules as the full list: 8 x 8 patches of tiles for the L2, one
+// eighth of the list per XCD, a chunk's diagonal tiles last.
+int64_t syrk_work_fill_rows(int64_t P, int32_t splits, int row0, int row1, int32_t *out) {
   const int T = (int)((P + BM - 1) / BM), PS = 8;
   const int NP = (T + PS - 1) / PS;
+  if (row0 < 0) row0 = 0;
+  if (row1 > T) row1 = T;
   int64_t o = 0;
   for (int s = 0; s < (splits < 1 ? 1 : splits); ++s)
     for (int pi = 0; pi < NP; ++pi)
       for (int pj = pi; pj < NP; ++pj)
-        for (int tm = pi * PS; tm < (pi + 1) * PS && tm < T; ++tm)
+        for (int tm = pi * PS; tm < (pi + 1) * PS && tm < T; ++tm) {
+          if (tm < row0 || tm >= row1) continue;
           for (int tn = pj * PS; tn < (pj + 1) * PS && tn < T; ++tn) {
             if (tn < tm) continue;
             out[o++] = tm; out[o++] = tn; out[o++] = s; out[o++] = 0;
           }
+        }
   const int64_t nw = o / 4, q = nw / 8, r = nw % 8;
   std::vector<int32_t> tmp;
   for (int xcd = 0; xcd < 8; ++xcd) {
@@ -1091,6 +1094,7 @@ void syrk_work_fill(int64_t P, int32_t splits, int32_t *out) {
           ++w;
         }
   }
+  return nw;
 }
 
 // ---- whitening product with the raw Jacobian rows synthesised in LDS ---------------------------------
@@ -1281,13 +1285,12 @@ constexpr size_t SYNTH_LDS_BYTES = GEMM_LDS_BYTES + 3 * 32 * sizeof(double);
 
 template <int MODEL, int NT, bool FAR>
 static hipError_t launch_whiten_synth_one(hipStream_t st, const WhitenSynth &a, dim3 grid, int tiles_m, int tiles_n, int pair) {
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<MODEL, NT, FAR>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
+  static PerDeviceOnce attr;   // one per instantiation
+  const hipError_t ea = attr.run([] {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(whiten_synth_kernel<MODEL, NT, FAR>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)SYNTH_LDS_BYTES);
+  });
+  if (ea != hipSuccess) return ea;
   hipLaunchKernelGGL((whiten_synth_kernel<MODEL, NT, FAR>), grid, dim3(256), SYNTH_LDS_BYTES, st, a, tiles_m, tiles_n, pair);
   return hipGetLastError();
 }
@@ -1325,7 +1328,7 @@ hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a0) {
 }  // namespace lsqamd
 
 #ifdef LSQAMD_SYRK_STAMPS
-extern "C" int lsqamd_debug_set_syrk_stamps(void *dev_ptr) {
+extern "C" int lsqamd_debug_set_syrk_stamps(void *dev_ptr) try {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(lsqamd::g_syrk_stamps), &dev_ptr, sizeof(void *));
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 #endif

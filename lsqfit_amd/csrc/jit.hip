@@ -1815,16 +1815,16 @@ bool available(std::string *why) {
 
 }  // namespace lsqamd_jit
 
-extern "C" int lsqamd_jit_cache_stats(int64_t *out3) {
+extern "C" int lsqamd_jit_cache_stats(int64_t *out3) try {
   if (!out3) return LSQAMD_EINVAL;
   long long v[3];
   lsqamd_jit::cache_stats(v);
   for (int i = 0; i < 3; ++i) out3[i] = v[i];
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 extern "C" int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const double *consts, int32_t n_consts, int32_t n_param,
-                                   int32_t n_x, char *src_out, size_t cap, int32_t *variant, int32_t compile) {
+                                   int32_t n_x, char *src_out, size_t cap, int32_t *variant, int32_t compile) try {
   if (!code || n_code < 1 || n_param < 0) return LSQAMD_EINVAL;
   for (int t = 0; t < n_code; ++t) {
     const int op = code[t] & 0xff, arg = code[t] >> 8;
@@ -1849,4 +1849,4 @@ extern "C" int lsqamd_tape_codegen(const int32_t *code, int32_t n_code, const do
     }
   }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)

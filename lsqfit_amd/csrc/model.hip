@@ -766,13 +766,14 @@ static hipError_t launch_model(hipStream_t st, const ModelArgs &a, double *out_w
           sg.seg_per_chunk = (int32_t)((sg.n_seg + chunks - 1) / chunks);
           sg.ftot = a.tape_part;
           const size_t lds = sizeof(double) * (size_t)(((a.n_param + 1) & ~(int64_t)1) + 4 * (sg.depth + sg.slots) * 64 * R);
-          static size_t lds_set[3] = {0, 0, 0};
+          static PerDeviceMax lds_set[3];   // per device, thread-safe (common.h)
           const void *kfn = R == 2 ? reinterpret_cast<const void *>(tape_segment_kernel<JAC, 2>)
                                    : reinterpret_cast<const void *>(tape_segment_kernel<JAC, 1>);
-          if (lds > lds_set[R]) {
-            hipError_t e2 = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          {
+            const hipError_t e2 = lds_set[R].ensure(lds, [kfn](size_t want) {
+              return hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+            });
             if (e2 != hipSuccess) return e2;
-            lds_set[R] = lds;
           }
           const int64_t units = groups * chunks;
           if (R == 2) hipLaunchKernelGGL((tape_segment_kernel<JAC, 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds, st, sg);

@@ -1185,7 +1185,7 @@ __global__ __launch_bounds__(256) void trail_potf2_kernel(TrailArgs t, double *A
 
 static_assert(sizeof(Leaf4Shared) <= (size_t)128 * DLD4 * sizeof(double), "the sweep's scratch lives in the dead panel tile");
 constexpr size_t TRAIL_KERNEL_LDS = TRAIL_LDS_BYTES > DIAG4_LDS_BYTES ? TRAIL_LDS_BYTES : DIAG4_LDS_BYTES;
-static bool g_trail_attr = false;
+static PerDeviceOnce g_trail_attr;   // per device, thread-safe (common.h)
 
 // trailing update of the step whose panel is P (128 x rest), fused with the diagonal block of the
 // next step.  Requires mrest and rest multiples of 128 and 16-byte aligned rows.
@@ -1197,11 +1197,12 @@ bool trail_potf2_available() {
 
 hipError_t launch_trail_potf2(hipStream_t st, const double *P, double *C, int64_t lda, int64_t mrest,
                               int64_t rest, int nb_next, double *uinv_next, int32_t *info, int32_t k0_next) {
-  if (!g_trail_attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(trail_potf2_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRAIL_KERNEL_LDS);
-    if (e != hipSuccess) return e;
-    g_trail_attr = true;
+  {
+    const hipError_t ea = g_trail_attr.run([] {
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(trail_potf2_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRAIL_KERNEL_LDS);
+    });
+    if (ea != hipSuccess) return ea;
   }
   TrailArgs t;
   t.P = P; t.C = C; t.lda = lda;

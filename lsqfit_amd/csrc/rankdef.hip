@@ -173,11 +173,11 @@ int covariance_rank_deficient(lsqamd_fit *f) {
 
 // host-only entry point for the parity tests of the two recipes (no GPU needed)
 extern "C" int lsqamd_op_truncated_inverse(const double *G, int64_t n, int64_t n_rows, int32_t scipy_form, double *cov_out,
-                                           int32_t *dropped) {
+                                           int32_t *dropped) try {
   if (!G || !cov_out || n < 1) return LSQAMD_EINVAL;
   std::vector<double> g(G, G + n * n), cov;
   const int k = scipy_form ? eigen_pseudo_inverse(g, n, n_rows, cov) : pivoted_inverse(g, n, cov);
   std::copy(cov.begin(), cov.end(), cov_out);
   if (dropped) *dropped = k;
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)

@@ -244,12 +244,13 @@ hipError_t launch_block_whiten_vec(hipStream_t st, const double *wt, const int64
 __global__ __launch_bounds__(256) void finalize_pack_kernel(const double *slabs, int32_t splits,
                                                             int64_t split_stride, int64_t P,
                                                             int64_t ld, int64_t T, double *apk,
-                                                            const double *prior, int prior_dense) {
-  // blockIdx.x = packed tile index, blockIdx.y = 8-row strip inside the tile; thread -> two columns, two rows
-  int64_t t = blockIdx.x, tm = 0;
+                                                            const double *prior, int prior_dense, int64_t tile0) {
+  // tile0 + blockIdx.x = packed tile index, blockIdx.y = 8-row strip inside the tile; thread -> two columns, two rows
+  const int64_t tile = tile0 + blockIdx.x;
+  int64_t t = tile, tm = 0;
   while (t >= T - tm) { t -= T - tm; ++tm; }
   const int64_t tn = tm + t;
-  double *dst = apk + (int64_t)blockIdx.x * TB * TB;
+  double *dst = apk + tile * TB * TB;
   const int c = 2 * (threadIdx.x & 63);
   const int64_t j = tn * TB + c;
   const bool vec = !(ld & 1) && !(split_stride & 1) && !(reinterpret_cast<uintptr_t>(slabs) & 15) && j + 1 < P;
@@ -288,11 +289,13 @@ __global__ __launch_bounds__(256) void finalize_pack_kernel(const double *slabs,
 
 hipError_t launch_finalize_pack(hipStream_t st, const double *slabs, int32_t splits,
                                 int64_t split_stride, int64_t P, int64_t ld, double *apk,
-                                const double *prior, int32_t prior_dense) {
+                                const double *prior, int32_t prior_dense, int64_t tile0, int64_t n_tiles) {
   const int64_t T = (P + TB - 1) / TB;
-  dim3 grid((unsigned)(T * (T + 1) / 2), 16);
+  if (n_tiles < 0) { tile0 = 0; n_tiles = T * (T + 1) / 2; }
+  if (n_tiles == 0) return hipSuccess;
+  dim3 grid((unsigned)n_tiles, 16);
   hipLaunchKernelGGL(finalize_pack_kernel, grid, dim3(256), 0, st, slabs, splits, split_stride, P, ld,
-                     T, apk, prior, (int)prior_dense);
+                     T, apk, prior, (int)prior_dense, tile0);
   return hipGetLastError();
 }
 

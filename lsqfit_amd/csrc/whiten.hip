@@ -166,14 +166,14 @@ using namespace lsqamd;
 
 extern "C" {
 
-size_t lsqamd_whiten_work_bytes(int64_t block_size, int32_t n_blocks) {
+size_t lsqamd_whiten_work_bytes(int64_t block_size, int32_t n_blocks) try {
   if (block_size < 1 || n_blocks < 1) return 0;
   return make_plan(block_size, n_blocks, nullptr).bytes + 256;
-}
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
 int lsqamd_whiten_blocks(void *stream, int64_t B, int32_t nb, const double *cov, double svdcut,
                          double *wt_out, double *prec_out, void *dev_work, size_t work_bytes,
-                         double *logdet_out, double *lam_min_out, double *lam_max_out, int32_t *status_out) {
+                         double *logdet_out, double *lam_min_out, double *lam_max_out, int32_t *status_out) try {
   if (B < 1 || nb < 1 || !cov || !wt_out || !dev_work || !logdet_out || !status_out) return LSQAMD_EINVAL;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   char *base = (char *)dev_work;
@@ -263,6 +263,6 @@ int lsqamd_whiten_blocks(void *stream, int64_t B, int32_t nb, const double *cov,
     if (lam_max_out) lam_max_out[b] = hi;
   }
   return 0;
-}
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 }  // extern "C"

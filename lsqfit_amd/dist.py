@@ -78,18 +78,56 @@ def cuda_sync():
     torch.cuda.current_stream().synchronize()
 
 
-_COMM_IDS = {}      # (group, world) -> the id of the communicator this process already joined
+_COMM_IDS = {}      # (ranks of the group) -> (communicator id this process joined, the ProcessGroup object it was agreed over)
+
+
+def _group_key(group):
+    """(key, ProcessGroup object) of `group` (None: the default group).  The key is the tuple of the group's global ranks; the
+    OBJECT is kept with the cache entry -- a strong reference, so its id() cannot be recycled for another group while the entry
+    lives, and an entry whose object is no longer the group it is asked for (destroy_process_group + a new init_process_group
+    gives a new default group) is a miss."""
+    import torch.distributed as dist
+    pg = group if group is not None else dist.group.WORLD
+    try:
+        ranks = tuple(dist.get_process_group_ranks(pg))
+    except Exception:
+        ranks = ('world', dist.get_world_size(group))
+    return ranks, pg
+
+
+def forget_communicators():
+    """Drop the remembered ids (after lsqamd_comm_shutdown / destroy_process_group: the communicators they name are gone)."""
+    _COMM_IDS.clear()
+
+
+def comm_shutdown():
+    """End the library's unheld communicators (lsqamd_comm_shutdown) and forget their ids; -> number still held by live handles."""
+    from . import _lib
+    busy = int(_lib.load().lsqamd_comm_shutdown())
+    forget_communicators()
+    return busy
 
 
 def attach_rccl(problem, rank, world, group=None):
     """Library-side communicator for this handle: rank 0 makes the id, torch.distributed
     carries it (setup only), every rank joins.  The communicator belongs to the process: the second problem of a
-    job names the same id and shares it (no second ncclCommInitRank, no second broadcast)."""
+    job names the same id and shares it (no second ncclCommInitRank).  Whether the remembered id is reused is agreed
+    COLLECTIVELY (one small all_gather_object per attach): a rank that held a cache entry the others lack used to skip the
+    broadcast they were waiting in (round-5 advisor finding)."""
+    import hashlib
     import torch.distributed as dist
-    key = (id(group) if group is not None else None, world)
-    if key in _COMM_IDS:
-        problem.comm_init(_COMM_IDS[key], rank, world)
+    key, pg = _group_key(group)
+    have = _COMM_IDS.get(key)
+    if have is not None and have[1] is not pg:          # remembered over a group that no longer exists
+        del _COMM_IDS[key]
+        have = None
+    mine = hashlib.sha1(have[0]).hexdigest() if have is not None else None
+    every = [None] * world
+    dist.all_gather_object(every, mine, group=group)
+    if mine is not None and all(e == mine for e in every):
+        problem.comm_init(have[0], rank, world)
         return
+    _COMM_IDS.pop(key, None)
     box = [None]
     if rank == 0:
         try:
@@ -101,7 +139,7 @@ def attach_rccl(problem, rank, world, group=None):
     if isinstance(box[0], Exception):
         raise RuntimeError(str(box[0]))
     problem.comm_init(box[0], rank, world)
-    _COMM_IDS[key] = box[0]
+    _COMM_IDS[key] = (bytes(box[0]), pg)
 
 
 def sharded_problem(model, x, whitening, rank, world, group=None, collective=None):

@@ -71,7 +71,10 @@ def _batchable(fit):
     """the lockstep engine runs plain LM: a fit made with another fitter, another algorithm, a robust loss, bounds or
     ``x_scale`` is refitted copy by copy with ITS fitter and arguments (src/lsqfit/__init__.py:1457-1459,:1603-1604)"""
     args = getattr(fit, 'fitterargs', {})
-    return fit.fitter == 'mi355x_lm' and args.get('alg', 'lm') == 'lm' and set(args) <= _BATCHED_ARGS and not getattr(fit, 'linear', None)
+    # the batch engine factors the normal equations (solver = cholesky) with the default avmax: a fit made with solver='qr' or
+    # another avmax keeps ITS arguments, i.e. goes copy by copy; scaler / factor_up / factor_down are forwarded (refit)
+    return (fit.fitter == 'mi355x_lm' and args.get('alg', 'lm') == 'lm' and set(args) <= _BATCHED_ARGS and not getattr(fit, 'linear', None)
+            and args.get('solver', 'cholesky') == 'cholesky' and float(args.get('avmax', 0.75)) == 0.75)
 
 
 def _sequential_copies(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
@@ -145,10 +148,7 @@ def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
                      None if (dense or not wh.has_prior) else wh.prior_sdev, whitening=wh, n_fits=n,
                      prior_prec=wh.prior_prec if dense else None,
                      prior_logdet=(wh.logdet - wh.logdet_data) if dense else None, rows_permuted=perm is not None)
-    out = bf.run(p0=p0, tol=tol, maxit=maxit, covariance=covariance)
-    bf.close()
-    res = ResampledFits(out)
-    res['engine'] = 'batched'
+XX
     res['ymeans'] = ymeans
     res['prior_means'] = prior_means
     return res

@@ -302,9 +302,12 @@ class TArr(object):
                 return _binary('DIV', 1.0, inputs[0])
             if name == 'exp2':
                 return _unary('EXP', _binary('MUL', inputs[0], float(np.log(2.0))))
-            if name == 'expm1':
-                return _binary('SUB', _unary('EXP', inputs[0]), 1.0)
+            if name == 'expm1':       # e^x - 1 = 2 e^(x/2) sinh(x/2): no cancellation for small x (exp(x) - 1 loses the digits numpy's keeps)
+                h = _binary('MUL', 0.5, inputs[0])
+                return _binary('MUL', 2.0, _binary('MUL', _unary('EXP', h), _unary('SINH', h)))
             if name == 'log1p':
+                # the tape has no log1p: log(1 + x) -- for |x| << 1 the sum 1 + x keeps only ~16 + log10|x| digits of x, numpy's
+                # log1p keeps them all (documented in INTEGRATION.md; a fit that depends on it should fit log(1 + x)'s argument)
                 return _unary('LOG', _binary('ADD', 1.0, inputs[0]))
             if name == 'log10':
                 return _binary('DIV', _unary('LOG', inputs[0]), float(np.log(10.0)))
@@ -314,10 +317,25 @@ class TArr(object):
                 return _matmul(inputs[0], inputs[1])
             if name == 'hypot':
                 return _unary('SQRT', _binary('ADD', _binary('POW', inputs[0], 2.0), _binary('POW', inputs[1], 2.0)))
-            if name == 'arctan2':       # 2 atan(y / (r + x)): every point but the negative real axis
+            if name == 'arctan2':
+                # half-angle forms: 2 atan(y / (r + x)) is exact in the right half plane and NaN / inaccurate on and near the
+                # negative real axis; 2 atan((r - x) / y) is the form for x < 0.  Which one a row needs depends on the SIGN OF
+                # x: known when x is data (a selection by row, like numpy.where on the data), control flow when x depends on the
+                # parameters -- refused rather than silently wrong on the left half plane
                 y, x = inputs
-                r = _unary('SQRT', _binary('ADD', _binary('POW', x, 2.0), _binary('POW', y, 2.0)))
-                return _binary('MUL', 2.0, _unary('ATAN', _binary('DIV', y, _binary('ADD', r, x))))
+                if isinstance(x, TArr) and x.op != 'data':
+                    raise TraceError('numpy.arctan2(y, x) with x depending on the parameters: the branch is chosen by the sign of x, which '
+                                     'one recording cannot capture (write 2*arctan(y/(sqrt(x*x + y*y) + x)) if x > 0 is guaranteed)')
+                xd = np.asarray(x.aux if isinstance(x, TArr) else x, float)
+                r = _unary('SQRT', _binary('ADD', _binary('POW', xd, 2.0), _binary('POW', y, 2.0)))
+                right = _binary('MUL', 2.0, _unary('ATAN', _binary('DIV', y, _binary('ADD', r, xd))))
+                if np.all(xd >= 0.0):
+                    return right
+                left = _binary('MUL', 2.0, _unary('ATAN', _binary('DIV', _binary('SUB', r, xd), y)))
+                if np.all(xd < 0.0):
+                    return left
+                shape = np.broadcast_shapes(xd.shape, _lift(y).shape)
+                return _where(np.broadcast_to(xd >= 0.0, shape), right, left)
             if name == 'cbrt':
                 raise TraceError('numpy.cbrt has no counterpart on the device tape (x ** (1 / 3) for positive x)')
             if name in ('conjugate', 'real'):
@@ -729,14 +747,39 @@ _FUNCTIONS = {
     np.real: lambda a: _lift(a),
     np.conj: lambda a: _lift(a),
     np.square: lambda a: _binary('POW', a, 2.0),
-    np.average: lambda a, axis=None, weights=None, **kw: (_lift(a).mean(axis) if weights is None else
-                                                         _sum(_binary('MUL', a, np.asarray(weights, float)), axis) / float(np.sum(weights))),
+    np.average: lambda a, axis=None, weights=None, **kw: _average(a, axis, weights, **kw),
 }
 for _name in ('amax', 'amin', 'max', 'min', 'argmax', 'argmin', 'sort', 'argsort', 'clip', 'round', 'around', 'median', 'percentile',
               'quantile', 'nanmax', 'nanmin', 'maximum', 'minimum', 'sign', 'floor', 'ceil', 'trunc', 'isclose', 'allclose', 'array_equal',
               'searchsorted', 'digitize', 'unique', 'nonzero', 'argwhere', 'any', 'all', 'interp', 'select', 'piecewise', 'heaviside'):
     if hasattr(np, _name):
         _FUNCTIONS[getattr(np, _name)] = (lambda n: lambda *a, **kw: (_ for _ in ()).throw(_control_flow('numpy.' + n)))(_name)
+
+
+def _average(a, axis=None, weights=None, returned=False, keepdims=False, **kw):
+    """numpy.average: 1-D weights lie along `axis` (numpy's rule), the normalisation is the sum of the weights along that axis"""
+    a = _lift(a)
+    if returned:
+        raise TraceError('numpy.average(..., returned=True) is not recorded')
+    if weights is None:
+        return a.mean(axis, keepdims=keepdims)
+    if isinstance(weights, TArr) or _has_tracer(weights):
+        raise TraceError('numpy.average with weights that depend on the parameters is not recorded (write sum(w * a) / sum(w))')
+    w = np.asarray(weights, float)
+    if w.shape != a.shape:
+        if axis is None:
+            raise TypeError('Axis must be specified when shapes of a and weights differ.')
+        if w.ndim != 1:
+            raise TypeError('1D weights expected when shapes of a and weights differ.')
+        if w.shape[0] != a.shape[axis]:
+            raise ValueError('Length of weights not compatible with specified axis.')
+        shp = [1] * a.ndim
+        shp[axis % a.ndim] = w.size
+        w = np.broadcast_to(w.reshape(shp), a.shape)
+    den = w.sum(axis=axis, keepdims=keepdims)
+    if np.any(den == 0.0):
+        raise ZeroDivisionError("Weights sum to zero, can't be normalized")
+    return _binary('DIV', _sum(_binary('MUL', a, w), axis, keepdims), den)
 
 
 def _diff(a, axis=-1):
@@ -828,8 +871,7 @@ def _combine(parts, n, build):
     """parts: per operand a list of (rows | None, tree); -> list of (rows | None, build(trees))"""
     if all(len(p) == 1 and p[0][0] is None for p in parts):
         return [(None, build([p[0][1] for p in parts]))]
-    label = np.zeros(n, np.int64)
-    full = []
+    labs, full = [], []
     for p in parts:
         lab = np.zeros(n, np.int64)
         norm = []
@@ -838,18 +880,18 @@ def _combine(parts, n, build):
             lab[rows] = i
             norm.append((rows, tree))
         full.append(norm)
-        label = label * len(p) + lab
+        labs.append(lab)
+    # rows with the same combination of pieces share a formula.  The combinations are found on the STACKED labels (a mixed-radix
+    # number  label * len(p) + lab  in int64 overflows silently from 64 two-piece operands on -- a sum over 64 columns of a
+    # numpy.where on the data -- and merged rows of different formulas)
+    combos, inverse = np.unique(np.stack(labs, axis=1), axis=0, return_inverse=True)
+    inverse = np.asarray(inverse).reshape(-1)
     out = []
-    for v in np.unique(label):
-        rows = np.nonzero(label == v)[0]
+    for v, picks in enumerate(combos):
+        rows = np.nonzero(inverse == v)[0]
         trees = []
-        digits = int(v)
-        picks = []
-        for p in reversed(full):
-            picks.append(digits % len(p))
-            digits //= len(p)
-        for p, i in zip(full, reversed(picks)):
-            prow, tree = p[i]
+        for p, i in zip(full, picks):
+            prow, tree = p[int(i)]
             trees.append(_restrict(tree, np.searchsorted(prow, rows)))
         out.append((rows, build(trees)))
     return out

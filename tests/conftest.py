@@ -22,7 +22,7 @@ _GPU_ORDER = [
     'test_gpu_tape', 'test_gpu_edge', 'test_gpu_interleaved', 'test_gpu_programs', 'test_gpu_robust', 'test_gpu_cosh', 'test_gpu_one_launch', 'test_gpu_fused_normal',
     'test_gpu_comm', 'test_gpu_comm_multi', 'test_gpu_dist2', 'test_gpu_bench_smoke',
     'test_gpu_ops', 'test_gpu_syrk_colsum', 'test_gpu_tri_halves', 'test_gpu_uninit',
-    'test_gpu_fused_jacobian', 'test_gpu_stepgraph', 'test_gpu_sf',
+    'test_gpu_fused_jacobian', 'test_gpu_stepgraph',
 ]
 
 

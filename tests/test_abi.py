@@ -84,6 +84,86 @@ def test_query_devices_without_compute(libpath):
     assert lib.lsqamd_query_devices(None, 0, None, 0, None) == -1
 
 
+def test_exceptions_never_cross_the_abi(libpath):
+    """SURVEY.md 8(b) "never throw across the ABI" (the reference's callbacks are noexcept and stash errors,
+    src/lsqfit/_gsl.pyx:726-760,:680-685).  (1) a C++ exception raised INSIDE the library comes back as a code -- a
+    std::bad_alloc unwinding into ctypes would abort this interpreter; (2) every export the header declares whose body is
+    more than one statement is a function-try-block closed by LSQAMD_ABI_CATCH (source check: a new export cannot forget)."""
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    assert lib.lsqamd_debug_throw(None, 0) == 0
+    assert lib.lsqamd_debug_throw(None, 1) == -3      # LSQAMD_ENOMEM
+    assert lib.lsqamd_debug_throw(None, 2) == -10     # LSQAMD_EINTERNAL
+    assert lib.lsqamd_debug_throw(None, 3) == -10
+    assert lib.lsqamd_debug_throw(None, 4) in (-3, -10)   # a real over-sized allocation (length_error or bad_alloc)
+    import glob
+    names = set(header_symbols())
+    seen, unguarded = set(), []
+    for path in glob.glob(os.path.join(ROOT, 'lsqfit_amd', 'csrc', '*.hip')):
+        lines = open(path).read().split('\n')
+        for i, ln in enumerate(lines):
+            m = re.match(r'^(?:extern "C" )?[A-Za-z_0-9 \*]+?\b(lsqamdb?_[A-Za-z_0-9]+)\s*\(', ln)
+            if not m or m.group(1) not in names:
+                continue
+            j = i
+            while not lines[j].rstrip().endswith(('{', ';', '}')):
+                j += 1
+            end = lines[j].rstrip()
+            if end.endswith(';') and not end.endswith('}'):
+                continue                         # a declaration
+            seen.add(m.group(1))
+            if end.endswith('}'):
+                assert end.count(';') == 1, (path, ln)        # a one-statement body: nothing in it can throw ...
+                assert 'std::' not in end and 'new ' not in end, (path, ln)
+                continue
+            if not end.endswith('try {'):
+                unguarded.append((os.path.basename(path), m.group(1)))
+                continue
+            k = j + 1
+            while not lines[k].startswith('}'):
+                k += 1
+            assert lines[k].startswith('} LSQAMD_ABI_CATCH('), (path, m.group(1), lines[k])
+    assert not unguarded, unguarded
+    assert seen == names, sorted(names - seen)
+
+
+def test_kernel_attribute_bookkeeping_is_per_device(libpath):
+    """hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only; the ABI lets one process hold
+    handles on several GPUs from several threads.  The bookkeeping in front of every such call (csrc/common.h PerDeviceOnce)
+    must run the setter once per DEVICE -- not once per process -- and exactly once under concurrent first launches."""
+    import threading
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    lib.lsqamd_debug_per_device_once(0, 1)
+    assert lib.lsqamd_debug_per_device_once(0, 0) == 1
+    assert lib.lsqamd_debug_per_device_once(0, 0) == 1      # second launch on device 0: not again
+    assert lib.lsqamd_debug_per_device_once(1, 0) == 1      # first launch on device 1: its own
+    assert lib.lsqamd_debug_per_device_once(7, 0) == 1
+    assert lib.lsqamd_debug_per_device_once(1, 0) == 1
+    assert lib.lsqamd_debug_per_device_once(64, 0) == 1     # beyond the table: the setter runs every time (correct, slower)
+    assert lib.lsqamd_debug_per_device_once(64, 0) == 2
+    lib.lsqamd_debug_per_device_once(0, 1)
+    out = []
+    go = threading.Barrier(8)
+
+    def first_launch(dev):
+        go.wait()
+        for _ in range(200):
+            out.append(lib.lsqamd_debug_per_device_once(dev, 0))
+    ts = [threading.Thread(target=first_launch, args=(i % 2,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert set(out) == {1}, sorted(set(out))
+    # and no process-global "attribute set" flag is left in the sources
+    import glob
+    for path in glob.glob(os.path.join(ROOT, 'lsqfit_amd', 'csrc', '*.hip')):
+        src = open(path).read()
+        for m in re.finditer(r"hipFuncSetAttribute\(", src):
+            before = src[max(0, m.start() - 900):m.start()]
+            assert re.search(r'\.run\(\[|\.ensure\(', before), (path, src.count('\n', 0, m.start()) + 1)
+        assert not re.search(r'static bool [a-z_]*attr', src), path
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product refuses to fit (it must never route through the oracle)."""
     import torch

@@ -131,3 +131,55 @@ def test_headline_blocks_over_eight_ranks():
     for a, b in ranges:
         assert a >= 250 * 256 or a % 256 == 0
         assert abs((b - a) - n / 8) <= 256
+
+
+class _FakeHandle:
+    """stands in for DeviceProblem's two communicator calls (the real ones need a GPU): ids are counted, joins recorded"""
+    made = 0
+
+    def __init__(self, log):
+        self.log = log
+
+    def comm_unique_id(self):
+        _FakeHandle.made += 1
+        return bytes([_FakeHandle.made]) * 128
+
+    def comm_init(self, uid, rank, world):
+        self.log.append(bytes(uid))
+
+
+def _id_worker(rank, world, outdir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lsqfit_amd import dist as ldist
+    log = []
+    dist.init_process_group('gloo', init_method='file://' + os.path.join(outdir, 'rdv1'), rank=rank, world_size=world)
+    ldist.attach_rccl(_FakeHandle(log), rank, world)            # first problem: a new id
+    ldist.attach_rccl(_FakeHandle(log), rank, world)            # second problem of the job: the same id, no new one made
+    if rank == 1:
+        ldist.forget_communicators()                            # ONE rank loses its memory (the advisor's deadlock: the others
+    ldist.attach_rccl(_FakeHandle(log), rank, world)            #   skipped the broadcast this rank waited in): all agree on a new id
+    sub = dist.new_group([0, 1])                                # a subgroup has its own entry
+    ldist.attach_rccl(_FakeHandle(log), rank, world, group=sub)
+    ldist.attach_rccl(_FakeHandle(log), rank, world, group=sub)
+    dist.barrier()
+    dist.destroy_process_group()
+    dist.init_process_group('gloo', init_method='file://' + os.path.join(outdir, 'rdv2'), rank=rank, world_size=world)
+    ldist.attach_rccl(_FakeHandle(log), rank, world)            # a NEW default group: the remembered id belongs to a dead one
+    dist.barrier()
+    dist.destroy_process_group()
+    np.save(os.path.join(outdir, 'ids%d.npy' % rank), np.array([l[0] for l in log]))
+
+
+def test_communicator_id_cache_is_agreed_collectively(tmp_path):
+    """lsqfit_amd.dist.attach_rccl: reuse of a remembered communicator id is decided by ALL ranks together, entries are keyed by
+    the group's ranks and die with the ProcessGroup object (round-5 advisor: id(group) reuse, stale entries after
+    destroy_process_group, a rank with a cache hit skipping the broadcast the others wait in)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_id_worker, args=(2, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / 'ids0.npy'), np.load(tmp_path / 'ids1.npy')
+    assert np.array_equal(a, b)                 # both ranks joined the same communicator every time (ids are made by rank 0)
+    assert a[0] == a[1]                         # second problem: shared
+    assert a[2] != a[1]                         # one rank forgot: a fresh id for everybody, no deadlock
+    assert a[3] == a[4] and a[3] not in (a[0], a[2])   # the subgroup's own
+    assert a[5] not in a[:5]                    # after re-initialising torch.distributed: never the dead group's id

@@ -45,7 +45,10 @@ def _problem(case):
 def _one(rank, world, outdir, case, fake, algo, missing):
     import lsqfit_amd as amd
     from lsqfit_amd.dist import shard_rows
-    os.environ['LSQAMD_COMM_ALGO'] = algo
+    # algo = 'rsag' | 'allreduce' | 'rsag.gG': the last form asks for the exchange in G groups of tile rows on the handle's
+    # exchange stream (LSQAMD_EXCHANGE_GROUPS, read at lsqamd_create)
+    os.environ['LSQAMD_COMM_ALGO'] = algo.split('.')[0]
+    os.environ['LSQAMD_EXCHANGE_GROUPS'] = algo.split('.g')[1] if '.g' in algo else '1'
     tag = '%s_%s' % (case, algo)
     d = _problem(case)
     wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
@@ -103,8 +106,9 @@ def _worker(rank, world, outdir, jobs, fake, missing):
         _one(rank, world, outdir, case, fake, algo, missing)
 
 
-JOBS = {2: [('blocks', 'rsag'), ('blocks', 'allreduce')], 3: [('blocks', 'rsag'), ('small', 'rsag')],
-        8: [('eight', 'rsag'), ('small8', 'rsag'), ('c4_packed', 'rsag')]}
+JOBS = {2: [('blocks', 'rsag'), ('blocks', 'allreduce'), ('blocks', 'rsag.g2')],
+        3: [('blocks', 'rsag'), ('small', 'rsag'), ('blocks', 'rsag.g3'), ('small', 'rsag.g2')],
+        8: [('eight', 'rsag'), ('small8', 'rsag'), ('c4_packed', 'rsag'), ('eight', 'rsag.g2'), ('c4_packed', 'rsag.g4')]}
 
 
 def _spawn(world, outdir, jobs, fake, missing=False, nstart=None):
@@ -169,6 +173,21 @@ def test_rsag_and_allreduce_forms_agree_bit_for_bit(runs):
     b = _results(runs, 2, 'blocks', 'allreduce')
     for k in ('pmean', 'cov', 'chi2', 'nit'):
         assert np.array_equal(a[0][k], b[0][k]), k
+
+
+@pytest.mark.parametrize('case,world,groups', [('blocks', 2, 2), ('blocks', 3, 3), ('small', 3, 2), ('eight', 8, 2), ('c4_packed', 8, 4)])
+def test_grouped_exchange_is_bit_identical(case, world, groups, runs):
+    """LSQAMD_EXCHANGE_GROUPS = G: the J^T J launch cut into G groups of tile rows, group g's packed tiles summed over the ranks
+    on the handle's exchange stream (event-ordered) while group g + 1 is computed, the step's stream waiting for the last
+    event before the damped matrix is built (api.hip eval_normal_dev).  Every element is still the same sum of the same split-K
+    slabs and the stand-in sums ranks in rank order whatever the slice: fits must be the same BITS as with one exchange, on
+    every rank; one exposed wait per Jacobian in the `reduce` timer.  ('small': P = 30 is one tile -- the request is ignored.)"""
+    a = _results(runs, world, case, 'rsag')
+    b = _results(runs, world, case, 'rsag.g%d' % groups)
+    for r in b:
+        assert int(r['reduces']) == int(r['expect'])
+        for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
+            assert np.array_equal(a[0][k], r[k]), k
 
 
 def test_missing_rank_is_an_error_not_a_hang(tmp_path, fake_rccl):

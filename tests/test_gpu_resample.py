@@ -272,3 +272,31 @@ def test_noise_with_data_correlated_with_the_prior(amd):
     cutn = amd.nonlinear_fit(data=(x, y, Cyy), model=model, prior=(pm, Cpp), cross=Cyp, tol=1e-10, svdcut=0.3, noise=(True, False), rng=7)
     assert cut.svdn > 0 and cutn.svdn == cut.svdn and not np.array_equal(cutn.pmean, cut.pmean)
     assert np.all(np.abs(cutn.pmean - cut.pmean) < 8 * cut.psdev)
+
+
+def test_batched_copies_keep_the_fits_scaler_and_factors(amd):
+    """The reference refits every copy with the ORIGINAL fit's fitter arguments (src/lsqfit/__init__.py:1457-1459,:1603-1604).
+    scaler / factor_up / factor_down travel into the lockstep engine (same trajectories as single fits with those arguments:
+    same nit, same bits to 1e-10); solver='qr' or another avmax is not what the engine does -> copy by copy with the fit's own
+    arguments.  (Round-5 advisor finding: the batch ran such copies with the defaults.)"""
+    from lsqfit_amd import synth
+    d = synth.make_cosmix(N=300, P=8, seed=77, block=0, prior_corr=False)
+    data = (d['x'], d['ymean'], d['yerr'])
+    kw = dict(scaler='levenberg', factor_up=7.0, factor_down=1.5)
+    fit = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], **kw)
+    res = fit.bootstrapped_fits(4, seed=3)
+    assert res.engine == 'batched'
+    dflt = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior']).bootstrapped_fits(4, seed=3)
+    assert np.array_equal(res.ymeans, dflt.ymeans)
+    differs = False
+    for k in range(4):
+        single = amd.nonlinear_fit(data=(d['x'], res.ymeans[k], d['yerr']), model=d['model'], prior=(res.prior_means[k], d['prior'][1]),
+                                   p0=fit.pmean, **kw)
+        assert int(res.nit[k]) == single.nit
+        assert gu.relmax(res.pmean[k], single.pmean) < 1e-10 and res.chi2[k] == pytest.approx(single.chi2, rel=1e-10)
+        differs = differs or int(res.nit[k]) != int(dflt.nit[k]) or not np.array_equal(res.pmean[k], dflt.pmean[k])
+    assert differs                      # (the arguments do change the trajectories: the check above is not vacuous)
+    fq = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], solver='qr')
+    assert fq.bootstrapped_fits(2, seed=3).engine.startswith('sequential')
+    fa = amd.nonlinear_fit(data=data, model=d['model'], prior=d['prior'], avmax=0.5)
+    assert fa.bootstrapped_fits(2, seed=3).engine.startswith('sequential')

@@ -200,6 +200,15 @@ def test_selection_on_the_data_is_a_piecewise_model():
     np.testing.assert_allclose(run_tape(tr2.model, tr2.x, p[:2]), fcn2(x, p[:2]), rtol=1e-15)
 
 
+def test_arctan2_with_a_parameter_dependent_abscissa_is_refused():
+    """the half-angle form for x > 0 is NaN on / inaccurate near the negative real axis: which form a row needs is the sign of x,
+    control flow when x depends on the parameters (round-5 advisor finding: it was recorded as 2 atan(y / (r + x)) silently)"""
+    with pytest.raises(amd.TraceError, match='arctan2'):
+        amd.trace(lambda x, p: np.arctan2(x, p[0]), np.linspace(0, 1, 5), np.ones(2))
+    with pytest.raises(amd.TraceError):
+        amd.trace(lambda x, p: np.average(x * p[0], weights=p[1] * x), np.linspace(0, 1, 5), np.ones(2))
+
+
 @pytest.mark.parametrize('bad', [
     lambda x, p: p[0] * x if p[0] > 0 else p[1] * x,
     lambda x, p: np.where(p[0] * x > 1, p[0], p[1]),
@@ -238,7 +247,13 @@ VOCABULARY = {
     'split delete': lambda x, p: np.split(p * 1.0, 2)[1][0] * x + np.delete(p, 1)[2],
     'column_stack': lambda x, p: np.column_stack([p[0] * x, p[1] * x ** 2, np.ones_like(x) * p[2]]).ravel(),
     'like': lambda x, p: np.zeros_like(p)[0] + np.ones_like(p * x[:4]).sum() * p[0] * x + np.full_like(p, 2.5)[1] * p[3],
-    'arctan2 hypot': lambda x, p: np.arctan2(p[0] * x, p[1]) + np.hypot(p[2], x) + np.arctan2(x, -p[3]),
+    # arctan2(y, x): the branch follows the sign of x -- data here: all positive, all negative, mixed (a selection by row), incl.
+    # points ON the negative real axis (y = 0 at x < 0 is the one place no half-angle form reaches: pi there needs y != 0)
+    'arctan2 hypot': lambda x, p: np.arctan2(p[0] * x, x + 0.5) + np.hypot(p[2], x) + np.arctan2(p[3] * x, -x) + np.arctan2(p[1] * x, x - 0.9)
+                                  + np.arctan2(p[1] + x, np.array(-3.0)),
+    'expm1 log1p': lambda x, p: np.expm1(1e-9 * p[0] * x) * 1e9 + np.log1p(p[1] * x) + np.expm1(p[2] * x),
+    'average axis 0': lambda x, p: np.average(np.outer(p, x), axis=0, weights=[1.0, 2.0, 3.0, 4.0]) + np.average(np.outer(p, p), weights=np.outer(np.ones(4), [1., 2., 3., 4.])),
+    'sum of many selections': lambda x, p: np.sum(np.where(x[:, None] < np.linspace(0.1, 1.8, 70)[None, :], p[0] * x[:, None], p[1] + 0 * x[:, None]), axis=1),
     'subtract.outer': lambda x, p: np.exp(-np.subtract.outer(x, p[:2]) ** 2).sum(axis=1),
     'average': lambda x, p: np.average(np.outer(x, p), axis=1, weights=[1.0, 2.0, 3.0, 4.0]) + np.average(p),
     'methods': lambda x, p: (p * 1.0).copy().astype(float).swapaxes(0, 0).take([1, 2]).repeat(3) * x + np.outer(p, p).trace(),

@@ -4,7 +4,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/lsqfit_amd/build/dbg
 mkdir -p $OUT
-for f in gemm_tn_f64 chol potf2_mfma model vecops api batch scipy_methods comm whiten qr jit rankdef robust sf_chol; do
+for f in gemm_tn_f64 chol potf2_mfma model vecops api batch scipy_methods comm whiten qr jit rankdef robust; do
   EXTRA=""; [ $f = potf2_mfma ] && EXTRA="-mllvm -amdgpu-mfma-vgpr-form"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $EXTRA -DLSQAMD_POTF2_TIMING -c $ROOT/lsqfit_amd/csrc/$f.hip -o $OUT/$f.o &
 done

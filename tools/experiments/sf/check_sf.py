@@ -1,4 +1,5 @@
-"""-m gpu: the factorisation streamed behind the J^T J product (csrc/sf_chol.hip; developer entry point lsqamd_op_sf_factor) --
+"""NOT part of the default suite (round 6): run as `tools/experiments/sf/build.sh && python -m pytest tools/experiments/sf/check_sf.py -m gpu`.
+The factorisation streamed behind the J^T J product (csrc/sf_chol.hip; developer entry point lsqamd_op_sf_factor) --
 a persistent worker launch on all CUs but a few, the latency chain on CU-masked reserved CUs, hand-offs through device flags --
 against numpy: packed tiles of A = J^T J + prior, the updated scaling D, U with A + mu D^2 = U^T U, and U^-T g.  Two runs
 must agree bit for bit whatever order the workgroups ran in.  Spec: what gsl's solver init + solve compute behind
@@ -14,8 +15,11 @@ vp = C.c_void_p
 
 @pytest.fixture(scope='module')
 def lib():
-    from lsqfit_amd import _lib
-    return _lib.load()
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import sf_lib
+    return sf_lib.load()
 
 
 def run(lib, J, Lam, g, d, mu, splits, group_rows, reserve, scaler, _retry=True):

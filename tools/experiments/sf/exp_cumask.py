@@ -10,10 +10,11 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
-from lsqfit_amd import _lib
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sf_lib
 
-lib = _lib.load()
+lib = sf_lib.load()
 torch.zeros(1, device='cuda')
 hip_path = [ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64' in ln][0]
 hip = C.CDLL(hip_path)

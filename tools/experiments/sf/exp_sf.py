@@ -2,7 +2,7 @@
 (1) where do the workgroups of CU-masked streams run (mask bit layout 'c' vs 'i'); (2) the streamed factorisation against numpy;
 (3) its time at the 8-GPU shard shape (8192 rows, 4096 parameters, 4 K-chunks) for a few reservations, next to the serial
 sequence it replaces (J^T J launch + slab sum + damped matrix + potrf_upper; bench.py --ndata 8192 phases).
-usage: exp_sf.py [probe] [check] [time]"""
+usage (after tools/experiments/sf/build.sh): python tools/experiments/sf/exp_sf.py [probe] [check] [time]"""
 import ctypes as C
 import sys
 import time
@@ -10,10 +10,11 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
-from lsqfit_amd import _lib
+import os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import sf_lib
 
-lib = _lib.load()
+lib = sf_lib.load()
 torch.zeros(1, device='cuda')
 hip = C.CDLL([ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64' in ln][0])
 what = sys.argv[1:] or ['probe', 'check', 'time']

@@ -51,3 +51,22 @@ hipError_t sf_launch(const SfLaunch &a);
 int sf_streams_create(int reserve_per_xcd, int mode, hipStream_t *work, hipStream_t *chain, int *n_work_cus);
 
 }  // namespace lsqamd
+
+// ---- the experiment's own C entry points (were in include/lsqfit_amd.h until round 6: a lost experiment has no place in the
+// product ABI; tools/experiments/sf/build.sh links them into a VARIANT library, lsqfit_amd/build/libsf.so) ----
+extern "C" {
+/* developer probe: where do the workgroups of a launch on `stream` run?  dev_out[2 b] = XCC_ID, dev_out[2 b + 1] = HW_ID of
+ * workgroup b (n_wg workgroups of one wave that ask for lds_bytes of LDS each; tools/exp_cumask.py) */
+int lsqamd_debug_where(void *stream, int32_t n_wg, uint32_t *dev_out, int32_t lds_bytes);
+/* developer / test entry points of the factorisation streamed behind the J^T J product (csrc/sf_chol.hip; the first trial solve
+ * after an accepted LM step: replaces gsl's solver init + solve behind src/lsqfit/_gsl.pyx:646-653,:677).  Device pointers.
+ *   J [n_rows][ldj] (P columns used), prior (nullable: dense P x P or diagonal), g [P], mu, d [P] (updated like the LM scaling)
+ *   -> apk (packed upper 128 x 128 tiles of A = J^T J + prior), M [P][P + 128] (U with A + mu D^2 = U^T U; column P = U^-T g).
+ * reserve_per_xcd CUs of every XCD run the latency chain (hipExtStreamCreateWithCUMask; mask_mode 'c' / 'i': bit layout);
+ * 0 = no masks (plain streams: results only). */
+size_t lsqamd_op_sf_work_bytes(int64_t n_rows, int64_t P, int32_t splits);
+int lsqamd_op_sf_factor(void *stream, const double *J, int64_t ldj, int64_t n_rows, int64_t P, int32_t splits, int32_t group_rows,
+                        int32_t reserve_per_xcd, int32_t mask_mode, const double *prior, int32_t prior_dense, const double *g,
+                        double mu, int32_t scaler, double *d, double *apk, double *M, void *work, size_t work_bytes,
+                        int32_t *info_host, long long *dev_stamps /* nullable: [24 + 4 P / 128] wall-clock stamps and per-item-type time sums */, int32_t idle_max);
+}

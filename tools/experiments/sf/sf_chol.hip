@@ -25,7 +25,7 @@
 #include <cstdlib>
 #include <vector>
 
-#include "common.h"
+#include "../../../lsqfit_amd/csrc/common.h"
 #include "sf_chol.h"
 
 namespace lsqamd {
