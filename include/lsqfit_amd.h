@@ -448,6 +448,11 @@ int lsqamdb_covariance(lsqamdb_fits *fits, double *logdet_jtj_out, size_t cap); 
 int lsqamdb_get_cov(lsqamdb_fits *fits, int32_t fit, double *out, size_t cap);          /* P*P */
 int lsqamdb_get_cov_all(lsqamdb_fits *fits, double *out, size_t cap);                    /* n_fits*P*P, one copy */
 int32_t lsqamdb_rounds(const lsqamdb_fits *fits);
+/* phase timers of the batched engine (the measurement side of SURVEY.md 8d for BASELINE config 5): with timing on, every
+ * round runs eagerly with HIP events around the batched J^T J launch (which = LSQAMD_T_SYRK) and the batched
+ * factorisation (LSQAMD_T_CHOLESKY) on the engine's stream; _get waits for the stream and returns the totals since _enable. */
+int lsqamdb_timing_enable(lsqamdb_fits *fits, int32_t on);
+int lsqamdb_timing_get(lsqamdb_fits *fits, int32_t which, double *total_ms, int64_t *count);
 
 /* ---- measurement ------------------------------------------------------------ */
 enum {

@@ -126,6 +126,8 @@ PROTOTYPES = {
     'lsqamdb_get_cov': (C.c_int, [_vp, C.c_int32, _dp, C.c_size_t]),
     'lsqamdb_get_cov_all': (C.c_int, [_vp, _dp, C.c_size_t]),
     'lsqamdb_rounds': (C.c_int32, [_vp]),
+    'lsqamdb_timing_enable': (C.c_int, [_vp, C.c_int32]),
+    'lsqamdb_timing_get': (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(C.c_int64)]),
     'lsqamd_timing_enable': (C.c_int, [_vp, C.c_int32]),
     'lsqamd_timing_get': (C.c_int, [_vp, C.c_int32, _dp, C.POINTER(C.c_int64)]),
     'lsqamd_timing_reset': (C.c_int, [_vp]),

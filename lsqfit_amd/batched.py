@@ -124,6 +124,19 @@ class BatchedFits:
             raise RuntimeError('lsqfit_amd: batched %s failed (%s): %s' % (
                 what, _lib.ERRORS.get(rc, rc), msg.decode() if msg else ''))
 
+    def timing(self, on=True):
+        """HIP-event timers around the batched J^T J launch and the batched factorisation (rounds then run eagerly)."""
+        self._check(self.lib.lsqamdb_timing_enable(self.h, int(bool(on))), 'timing_enable')
+
+    def timings(self):
+        """-> {'syrk': (total ms, launches), 'cholesky': (...)} since ``timing(True)``"""
+        out = {}
+        for name, which in (('syrk', 3), ('cholesky', 6)):
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            self._check(self.lib.lsqamdb_timing_get(self.h, which, C.byref(ms), C.byref(n)), 'timing_get')
+            out[name] = (ms.value, n.value)
+        return out
+
     def set_data_means(self, ymeans):
         """New data means, one row per fit (same covariance): shape (n_fits, N)."""
         ymeans = np.ascontiguousarray(ymeans, np.float64)
@@ -172,7 +185,7 @@ class BatchedFits:
         self._check(self.lib.lsqamdb_get_x(self.h, _lib.dptr(x), x.size), 'get_x')
         out = dict(pmean=x.reshape(B, P),
                    chi2=np.array([s.chi2 for s in summ]), nit=np.array([s.nit for s in summ]),
-                   nfev=np.array([s.nfev for s in summ]), status=np.array([s.status for s in summ]),
+                   nfev=np.array([s.nfev for s in summ]), njev=np.array([s.njev for s in summ]), status=np.array([s.status for s in summ]),
                    stopping_criterion=np.array([s.stopping_criterion for s in summ]),
                    rounds=int(self.lib.lsqamdb_rounds(self.h)), graph_rounds=int(summ[0].t_setup_ms),
                    time=t_run, device_ms=float(summ[0].t_run_ms))

@@ -531,6 +531,17 @@ struct lsqamdb_fits {
   hipGraphExec_t gexec = nullptr;
   int32_t graph_used = 0, rounds = 0;
   bool one_launch = false, have_cov_from_run = false;   // the last run was one launch (lsqamd_jit_lmb) / it formed the covariances too
+  // phase timers (lsqamdb_timing_enable): HIP events around the J^T J launch and the batched factorisation of every round;
+  // rounds then run eagerly (events are not recorded into a captured graph)
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> tm_syrk, tm_chol;
+  ~lsqamdb_fits() {
+    for (auto *v : {&tm_syrk, &tm_chol})
+      for (auto &pr : *v) {
+        lsqamd_host::event_give(pr.first);
+        lsqamd_host::event_give(pr.second);
+      }
+  }
 };
 
 namespace {
@@ -678,7 +689,15 @@ int normal_all(lsqamdb_fits *f, const int32_t *mask) {
   g.colsum_out = f->partial; g.colsum_ld = P + 1; g.colsum_rcol = P;
   const bool syrk_colsum = gemm_tn_fuses_colsum(g);
   if (!syrk_colsum) g.colsum_out = nullptr;
-  BHIP(f, launch_gemm_tn(f->st, g));
+  if (f->timing) {
+    hipEvent_t a = lsqamd_host::event_take(), b = lsqamd_host::event_take();
+    (void)hipEventRecord(a, f->st);
+    BHIP(f, launch_gemm_tn(f->st, g));
+    (void)hipEventRecord(b, f->st);
+    f->tm_syrk.emplace_back(a, b);
+  } else {
+    BHIP(f, launch_gemm_tn(f->st, g));
+  }
   const int64_t red_stride = f->npk + P + 1;
   hipLaunchKernelGGL(b_finalize_pack_kernel, dim3((unsigned)(f->T * (f->T + 1) / 2), 16, (unsigned)B),
                      dim3(256), 0, f->st, f->slabs, f->splits, P * f->ldm, (int64_t)f->splits * P * f->ldm, P,
@@ -720,8 +739,17 @@ int round_all(lsqamdb_fits *f) {
   hipLaunchKernelGGL(b_build_damped_kernel, dim3(ntile, 16, (unsigned)B), dim3(256), 0, f->st, f->red,
                      red_stride, P, f->T, f->ldm, f->s.mu, f->diag, f->red + f->npk, red_stride, f->M, m_stride,
                      f->s.active, 1);
-  BHIP(f, potrf_upper_batched(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->s.cholinfo, (int32_t)B,
-                              m_stride, w_stride, f->s.active));
+  if (f->timing) {
+    hipEvent_t a = lsqamd_host::event_take(), b = lsqamd_host::event_take();
+    (void)hipEventRecord(a, f->st);
+    BHIP(f, potrf_upper_batched(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->s.cholinfo, (int32_t)B,
+                                m_stride, w_stride, f->s.active));
+    (void)hipEventRecord(b, f->st);
+    f->tm_chol.emplace_back(a, b);
+  } else {
+    BHIP(f, potrf_upper_batched(f->st, f->M, P, f->ldm, f->ncols_aug, f->chol_work, f->s.cholinfo, (int32_t)B,
+                                m_stride, w_stride, f->s.active));
+  }
   hipLaunchKernelGGL(b_extract_y_kernel, dim3((unsigned)((P + 255) / 256), (unsigned)B), dim3(256), 0, f->st,
                      f->M, m_stride, f->ldm, P, f->yv, 2 * P, f->s.active);
   BHIP(f, backsolve_upper_batched(f->st, f->M, P, f->ldm, f->chol_work, f->yv, (int32_t)B, m_stride, w_stride,
@@ -944,6 +972,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
       (f->cfg.model != LSQAMD_MODEL_IDENTITY && !f->have_x) || (f->cfg.model == LSQAMD_MODEL_TAPE && !f->have_tape))
     BFAIL(f, LSQAMD_EINVAL, "run: inputs missing");
   const int64_t P = f->P, B = f->B;
+  if (f->timing) use_graph = 0;      // (events around single launches: eager rounds)
   (void)hipStreamSynchronize(f->user_st);
   hipEvent_t e0 = lsqamd_host::event_take(), e1 = lsqamd_host::event_take();
   (void)hipEventRecord(e0, f->st);
@@ -1167,5 +1196,33 @@ int lsqamdb_get_cov_all(lsqamdb_fits *f, double *out, size_t cap) try {
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 int32_t lsqamdb_rounds(const lsqamdb_fits *f) { return f ? f->rounds : -1; }
+
+int lsqamdb_timing_enable(lsqamdb_fits *f, int32_t on) try {
+  if (!f) return LSQAMD_EINVAL;
+  (void)hipStreamSynchronize(f->st);
+  f->timing = on != 0;
+  for (auto *v : {&f->tm_syrk, &f->tm_chol}) {
+    for (auto &pr : *v) {
+      lsqamd_host::event_give(pr.first);
+      lsqamd_host::event_give(pr.second);
+    }
+    v->clear();
+  }
+  return 0;
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
+
+int lsqamdb_timing_get(lsqamdb_fits *f, int32_t which, double *total_ms, int64_t *count) try {
+  if (!f || (which != LSQAMD_T_SYRK && which != LSQAMD_T_CHOLESKY)) return LSQAMD_EINVAL;
+  (void)hipStreamSynchronize(f->st);
+  double tot = 0.0;
+  int64_t n = 0;
+  for (auto &pr : which == LSQAMD_T_SYRK ? f->tm_syrk : f->tm_chol) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) { tot += ms; ++n; }
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = n;
+  return 0;
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
 }  // extern "C"

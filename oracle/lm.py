@@ -538,10 +538,11 @@ def gsl_multifit(x0, n, f, df, tol=(1e-5, 0.0, 0.0), maxit=1000, alg='lm',
 
 
 def lm_normal(x0, normal_eq, chi2_fn, tol=(1e-5, 0.0, 0.0), maxit=1000,
-              scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', stop=None):
-    """Same driver fed by ``normal_eq(x) -> (A, g, chi2)`` and ``chi2_fn(x)``."""
+              scaler='more', factor_up=3.0, factor_down=2.0, alg='lm', stop=None, lin=None):
+    """Same driver fed by ``normal_eq(x) -> (A, g, chi2)`` and ``chi2_fn(x)``.  ``lin``: a ``_NormalLin`` (or a subclass: the
+    bench's CPU baseline times its factorisations) -- same algebra."""
     tol = normalize_tol(tol)
-    lin = _NormalLin()
+    lin = _NormalLin() if lin is None else lin
 
     def evaluate(x):
         A, g, c2 = normal_eq(x)

@@ -208,14 +208,14 @@ def test_fit_function_written_with_products_norms_and_einsum(amd):
         amp = np.prod(p[2:4])
         rate = np.linalg.norm(p[2:4])
         bumps = np.exp(-np.subtract.outer(x, p[:2]) ** 2).sum(axis=1)
-        return np.arctan2(p[0] * x, p[1]) + amp * np.exp(-rate * x) + np.einsum('ij,j->i', A, p[4:6]) + 0.1 * np.hypot(p[5], x) + 0.05 * bumps
+        return np.arctan2(p[0] * x, 1.0 + x) + amp * np.exp(-rate * x) + np.einsum('ij,j->i', A, p[4:6]) + 0.1 * np.hypot(p[5], x) + 0.05 * bumps
 
     def flat_fcn(x, p):
         if isinstance(p, Dual):
             amp, rate = p[2] * p[3], dual.sqrt(p[2] * p[2] + p[3] * p[3])
             t = p[0] * x
-            r = dual.sqrt(t * t + p[1] * p[1])
-            at2 = 2.0 * dual.arctan(t / (r + p[1]))
+            r = dual.sqrt(t * t + (1.0 + x) * (1.0 + x))
+            at2 = 2.0 * dual.arctan(t / (r + (1.0 + x)))        # (the abscissa is data: arctan2's branch is known row by row)
             lin = p[4] * A[:, 0] + p[5] * A[:, 1]
             bumps = dual.exp(-((x - p[0]) * (x - p[0]))) + dual.exp(-((x - p[1]) * (x - p[1])))
             return at2 + amp * dual.exp(-(rate * x)) + lin + 0.1 * dual.sqrt(p[5] * p[5] + x * x) + 0.05 * bumps

@@ -25,7 +25,8 @@ struct Out {
 
 __device__ __forceinline__ unsigned long long now() { return __builtin_readcyclecounter(); }   // s_memtime: shader clock
 
-// role of each of the 8 waves: 0 idle, 1 MFMA, 2 FMA, 3 = MFMA and FMA interleaved in ONE wave (what whiten_synth does)
+// role of each of the 8 waves: 0 idle, 1 MFMA, 2 FMA, 3 = MFMA and FMA interleaved in ONE wave (what whiten_synth does),
+// 4 = fp32 FMAs only (v_fma_f32: does NON-fp64 VALU work hide behind fp64 MFMAs?), 5 = 32-bit integer multiply-adds only
 __global__ __launch_bounds__(512, 1) void probe(const int *roles, unsigned long long budget, Out *out, double seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int role = roles[wave];
@@ -66,6 +67,30 @@ __global__ __launch_bounds__(512, 1) void probe(const int *roles, unsigned long 
     double s = 0.0;
     for (int i = 0; i < 16; ++i) s += x[i];
     if (s == 12345.678) out[8].count = 1;
+  } else if (role == 4 || role == 5) {
+    float xf[16];
+    int xi[16];
+    for (int i = 0; i < 16; ++i) { xf[i] = (float)seed + i + lane * 1e-3f; xi[i] = i + lane; }
+    const float a = 1.0f - 1e-6f * (float)seed, b = 1e-7f;
+    const int ia = 3 + (int)seed, ib = 7;
+    do {
+      if (role == 4) {
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) xf[i] = __builtin_fmaf(xf[i], a, b);
+      } else {
+#pragma unroll
+        for (int rep = 0; rep < 16; ++rep)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) xi[i] = xi[i] * ia + ib;
+      }
+      n += 256;
+      t1 = now();
+    } while (t1 - t0 < budget);
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) s += xf[i] + (float)xi[i];
+    if (s == 12345.678f) out[8].count = 1;
   } else {
     // one wave, both kinds interleaved: 4 FMAs after every MFMA (an MFMA occupies the pipe for 16 passes x 4 clocks; four
     // wave64 FMAs are 4 x 4 = 16 issue clocks: would fit in its shadow if the pipes were separate)
@@ -118,6 +143,11 @@ int main() {
       {"(8) MFMA on all 4 SIMDs + FMA on all 4 SIMDs", {1, 1, 1, 1, 2, 2, 2, 2}},
       {"(9) MFMA on all 4 SIMDs", {1, 1, 1, 1, 0, 0, 0, 0}},
       {"(10) FMA on all 4 SIMDs", {2, 2, 2, 2, 0, 0, 0, 0}},
+      {"(11) fp32 FMA wave alone", {4, 0, 0, 0, 0, 0, 0, 0}},
+      {"(12) MFMA + fp32 FMA, same SIMD", {1, 0, 0, 0, 4, 0, 0, 0}},
+      {"(13) int32 mad wave alone", {5, 0, 0, 0, 0, 0, 0, 0}},
+      {"(14) MFMA + int32 mad, same SIMD", {1, 0, 0, 0, 5, 0, 0, 0}},
+      {"(15) fp64 FMA + fp32 FMA, same SIMD", {2, 0, 0, 0, 4, 0, 0, 0}},
   };
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
@@ -141,8 +171,8 @@ int main() {
       if (!h[w].role) continue;
       const double us = 1e3 * ms * (double)h[w].cycles / (double)(h[w].cycles ? h[w].cycles : 1);   // every wave runs (almost) the whole launch
       const double ticks = (double)h[w].cycles;
-      const char *kind = h[w].role == 1 ? "MFMA" : h[w].role == 2 ? "FMA " : "MFMA(+4 FMA each)";
-      const double flop = h[w].role == 1 ? 2048.0 : h[w].role == 2 ? 128.0 : 2048.0 + 4 * 128.0;
+      const char *kind = h[w].role == 1 ? "MFMA" : h[w].role == 2 ? "FMA " : h[w].role == 4 ? "FMA32" : h[w].role == 5 ? "IMAD32" : "MFMA(+4 FMA each)";
+      const double flop = h[w].role == 1 ? 2048.0 : (h[w].role == 2 || h[w].role == 4 || h[w].role == 5) ? 128.0 : 2048.0 + 4 * 128.0;
       printf("    wave %d  SIMD %u  CU %u  %-18s %12llu instr in %10.0f ticks  = %9.2f instr/us = %7.2f GFLOP/s  (ticks/us %.1f)\n", w,
              (h[w].hw_id >> 4) & 3, (h[w].hw_id >> 8) & 15, kind, h[w].count, ticks, (double)h[w].count / us,
              (double)h[w].count * flop / us * 1e-3, ticks / us);
