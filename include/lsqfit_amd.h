@@ -21,7 +21,18 @@
  *     (LSQAMD_E*); lsqamd_last_error() gives the text;
  *   - all state is handle-scoped (the reference keeps module globals
  *     _valder/_p_f/_pyerr, _gsl.pyx:397-399): handles are re-entrant and may be
- *     used from different host threads, one handle = one HIP stream;
+ *     used from different host threads, one handle = one HIP stream.  Give every
+ *     handle a NON-BLOCKING stream of its own (hipStreamNonBlocking): handles
+ *     replay their LM step from captured graphs, and a capture cannot coexist
+ *     with work on the legacy default stream -- on ROCm 7 a legacy-stream call
+ *     (hipMemcpy, a NULL-stream launch) from ANY thread fails with
+ *     hipErrorStreamCaptureImplicit while a capture is open and invalidates it
+ *     (the library then falls back to eager launches for that handle).  The
+ *     library itself never uses the legacy stream; a NULL stream argument is
+ *     accepted but then nothing is ordered against the caller's legacy-stream work;
+ *   - no C++ exception crosses the boundary: std::bad_alloc comes back as
+ *     LSQAMD_ENOMEM, anything else as LSQAMD_EINTERNAL (csrc/common.h
+ *     LSQAMD_ABI_CATCH on every export);
  *   - host buffers passed to lsqamd_set_* are copied before the call returns
  *     and never retained; output buffers are caller-allocated with an element
  *     capacity; device memory is ONE caller-provided workspace

@@ -163,6 +163,30 @@ def load():
     return lib
 
 
+_side = None
+
+
+def side_stream(device=None):
+    """A non-blocking torch stream per host thread for the package's OWN device work outside a handle (block factorisations
+    of the whitening set-up, concatenating device-made weights, fetching them to the host).  Never the legacy default
+    stream: a legacy-stream operation synchronises with every blocking stream of the process and, on this runtime, fails
+    with hipErrorStreamCaptureImplicit -- and invalidates the capture -- while ANY other thread is capturing a graph
+    (handles capture their LM step; tests/test_gpu_threads.py).  Work queued on it is waited for (``.synchronize()``) before
+    its results are handed to another stream."""
+    global _side
+    import threading
+    import torch
+    if _side is None:
+        _side = threading.local()
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    key = 's%d' % dev
+    s = getattr(_side, key, None)
+    if s is None:
+        s = torch.cuda.Stream(device=dev)
+        setattr(_side, key, s)
+    return s
+
+
 def dptr(a):
     return a.ctypes.data_as(_dp)
 

@@ -1258,7 +1258,10 @@ int iterate_varpro(lsqamd_fit *f) {
     }
     if (stashed) {                                   // back to the current point's A, g
       if (dev_stash) HIPCHK(f, hipMemcpyAsync(f->redbuf, f->cov, sizeof(double) * nstash, hipMemcpyDeviceToDevice, f->st));
-      else HIPCHK(f, hipMemcpy(f->redbuf, host_stash.data(), sizeof(double) * nstash, hipMemcpyHostToDevice));
+      else {   // (on the handle's stream: the library never touches the legacy default stream -- see copy_sync in batch.hip)
+        HIPCHK(f, hipMemcpyAsync(f->redbuf, host_stash.data(), sizeof(double) * nstash, hipMemcpyHostToDevice, f->st));
+        HIPCHK(f, hipStreamSynchronize(f->st));
+      }
       f->hg = keep_g; f->hcoln = keep_c;
       f->chi2 = chi2_cur;
       f->have_dense_A = false;
@@ -1407,7 +1410,10 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
       (void)hipGetLastError();
       exec = nullptr;
       f->step_graph_off = true;
-      if (rc) return rc;
+      // enqueue failed AND the capture ended in error: the capture was invalidated (another thread's legacy-stream call, for
+      // one) and took the captured launches down with it -- nothing ran; the half step is queued again, eagerly.  A failure
+      // with a healthy capture is the enqueue's own
+      if (rc && e == hipSuccess) return rc;
       return enqueue(f);
     }
     (void)hipGraphDestroy(gr);
@@ -1459,7 +1465,8 @@ static int wait_record(lsqamd_fit *f) {
     if (!getenv("LSQAMD_VERIFY_HANDOFF")) return 0;
     unsigned long long dev[LMS_COUNT];
     HIPCHK(f, hipStreamSynchronize(f->st));
-    HIPCHK(f, hipMemcpy(dev, f->lmd, sizeof(dev), hipMemcpyDeviceToHost));
+    HIPCHK(f, hipMemcpyAsync(dev, f->lmd, sizeof(dev), hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
     for (int i = 0; i < LMS_COUNT; ++i)
       if (dev[i] != w[i]) {
         fprintf(stderr, "lsqamd HANDOFF MISMATCH record word %d: host %016llx device %016llx\n", i, w[i], dev[i]);
@@ -1483,7 +1490,8 @@ static int wait_record(lsqamd_fit *f) {
   if (arrived()) return audited();
   // the stream has drained and the mirror still does not verify: take the record from the device
   g_handoff[1]++;
-  HIPCHK(f, hipMemcpy(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost));
+  HIPCHK(f, hipMemcpyAsync(f->pin_lm, f->lmd, sizeof(double) * LMS_COUNT, hipMemcpyDeviceToHost, f->st));
+  HIPCHK(f, hipStreamSynchronize(f->st));
   return 0;
 }
 
@@ -2542,12 +2550,14 @@ static int run_one_launch(lsqamd_fit *f, const double *p0, int *iter, int *info)
   }
   if (!have) {
     HIPCHK(f, hipStreamSynchronize(f->st));
-    HIPCHK(f, hipMemcpy(f->fit_rec.data(), f->fit_block, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost));
+    HIPCHK(f, hipMemcpyAsync(f->fit_rec.data(), f->fit_block, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
   }
   if (getenv("LSQAMD_VERIFY_HANDOFF")) {   // test knob: the block the host acted on vs the device's own copy once the stream has drained
     std::vector<double> dev((size_t)nw);
     HIPCHK(f, hipStreamSynchronize(f->st));
-    HIPCHK(f, hipMemcpy(dev.data(), f->fit_block, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost));
+    HIPCHK(f, hipMemcpyAsync(dev.data(), f->fit_block, sizeof(double) * (size_t)nw, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
     int bad = 0;
     for (int i = 0; i < nw; ++i)
       if (i != 23 && std::memcmp(&dev[(size_t)i], &f->fit_rec[(size_t)i], sizeof(double)) != 0) {

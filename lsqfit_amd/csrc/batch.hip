@@ -559,6 +559,17 @@ namespace {
     if (_e != hipSuccess) BFAIL(f, LSQAMD_EHIP, "%s: %s", #expr, hipGetErrorString(_e));  \
   } while (0)
 
+// Synchronous copies go through the engine's OWN (non-blocking) stream, never the legacy default stream: a legacy-stream
+// operation synchronises with every blocking stream of the process and -- on this runtime -- fails with
+// hipErrorStreamCaptureImplicit while ANY thread of the process is capturing a graph, invalidating that thread's capture
+// too (found by tests/test_gpu_threads.py: a batch's setters against another handle's step-graph capture).
+hipError_t copy_sync(lsqamdb_fits *f, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+  if (bytes == 0) return hipSuccess;
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, f->st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(f->st);
+}
+
 size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
   const lsqamd_config &c = f->cfg;
   const int64_t N = c.n_data, P = c.n_param, B = f->B;
@@ -846,7 +857,7 @@ const char *lsqamdb_last_error(const lsqamdb_fits *f) { return f ? f->err.c_str(
 int lsqamdb_set_x(lsqamdb_fits *f, const double *x, int64_t n_rows, int32_t n_x) try {
   if (!f) return LSQAMD_EINVAL;
   if (!x || n_rows != f->N || n_x != (f->cfg.n_x > 0 ? f->cfg.n_x : 1)) BFAIL(f, LSQAMD_EINVAL, "set_x: shape");
-  BHIP(f, hipMemcpy(f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->x, x, sizeof(double) * n_rows * n_x, hipMemcpyHostToDevice));
   f->have_x = true;
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
@@ -879,8 +890,8 @@ int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const
   if (!f->jit && (n_code > 1024 || n_consts > 256))
     BFAIL(f, LSQAMD_EUNSUPPORTED, "set_tape: %d instructions need the compiled route, which is unavailable (%s)", n_code, why.c_str());
   if (n_code <= 1024 && n_consts <= 256) {
-    BHIP(f, hipMemcpy(f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice));
-    if (n_consts > 0) BHIP(f, hipMemcpy(f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice));
+    BHIP(f, copy_sync(f, f->tape, code, sizeof(int32_t) * n_code, hipMemcpyHostToDevice));
+    if (n_consts > 0) BHIP(f, copy_sync(f, f->consts, consts, sizeof(double) * n_consts, hipMemcpyHostToDevice));
   }
   f->n_tape = n_code;
   f->have_tape = true;
@@ -890,8 +901,8 @@ int lsqamdb_set_tape(lsqamdb_fits *f, const int32_t *code, int32_t n_code, const
 /* shared data: ymean[N], wdiag[N] = 1/sdev of the 1x1 rows */
 int lsqamdb_set_data(lsqamdb_fits *f, const double *ymean, const double *wdiag) try {
   if (!f || !ymean || !wdiag) return LSQAMD_EINVAL;
-  BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->wdiag, wdiag, sizeof(double) * f->N, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->ymean, ymean, sizeof(double) * f->N, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->wdiag, wdiag, sizeof(double) * f->N, hipMemcpyHostToDevice));
   f->ymean_stride = 0;
   f->have_data = true;
   return 0;
@@ -902,7 +913,7 @@ int lsqamdb_set_data(lsqamdb_fits *f, const double *ymean, const double *wdiag) 
 int lsqamdb_set_data_means(lsqamdb_fits *f, const double *ymean) try {
   if (!f || !ymean) return LSQAMD_EINVAL;
   if (!f->have_data) BFAIL(f, LSQAMD_EINVAL, "set_data_means: call lsqamdb_set_data first");
-  BHIP(f, hipMemcpy(f->ymean, ymean, sizeof(double) * f->B * f->N, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->ymean, ymean, sizeof(double) * f->B * f->N, hipMemcpyHostToDevice));
   f->ymean_stride = f->N;
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
@@ -934,11 +945,11 @@ int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, c
   }
   if (off != f->cfg.sum_block_sq) BFAIL(f, LSQAMD_EINVAL, "set_blocks: sum of squares differs from the config");
   f->h_woff = woff;
-  BHIP(f, hipMemcpy(f->in_block, inb.data(), inb.size(), hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->blk_row0, row0, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->blk_size, size, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->blk_woff, woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->wt, wt, sizeof(double) * off, hipMemcpyDefault));   // host or device source
+  BHIP(f, copy_sync(f, f->in_block, inb.data(), inb.size(), hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->blk_row0, row0, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->blk_size, size, sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->blk_woff, woff.data(), sizeof(int64_t) * n_blocks, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->wt, wt, sizeof(double) * off, hipMemcpyDefault));   // host or device source
   f->have_blocks = true;
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
@@ -948,8 +959,8 @@ int lsqamdb_set_blocks(lsqamdb_fits *f, int32_t n_blocks, const int64_t *row0, c
 int lsqamdb_set_priors(lsqamdb_fits *f, const double *mean, const double *prec) try {
   if (!f || !mean || !prec) return LSQAMD_EINVAL;
   if (!f->cfg.has_prior) BFAIL(f, LSQAMD_EINVAL, "set_priors: config has no prior");
-  BHIP(f, hipMemcpy(f->pmean, mean, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
-  BHIP(f, hipMemcpy(f->pprec, prec, sizeof(double) * (f->cfg.prior_dense ? f->P * f->P : f->B * f->P),
+  BHIP(f, copy_sync(f, f->pmean, mean, sizeof(double) * f->B * f->P, hipMemcpyHostToDevice));
+  BHIP(f, copy_sync(f, f->pprec, prec, sizeof(double) * (f->cfg.prior_dense ? f->P * f->P : f->B * f->P),
                     hipMemcpyDefault));   // host or device source
   f->have_prior = true;
   return 0;
@@ -973,7 +984,10 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     BFAIL(f, LSQAMD_EINVAL, "run: inputs missing");
   const int64_t P = f->P, B = f->B;
   if (f->timing) use_graph = 0;      // (events around single launches: eager rounds)
-  (void)hipStreamSynchronize(f->user_st);
+  // inputs the caller made on ITS stream (device-resident weights) are complete before the engine's stream reads them.  A null
+  // stream is not waited for: synchronising the legacy stream from here would collide with any graph capture another
+  // thread has open (see copy_sync); a caller working on the legacy stream orders its own work (include/lsqfit_amd.h)
+  if (f->user_st) (void)hipStreamSynchronize(f->user_st);
   hipEvent_t e0 = lsqamd_host::event_take(), e1 = lsqamd_host::event_take();
   (void)hipEventRecord(e0, f->st);
   BHIP(f, hipMemcpyAsync(f->px, p0, sizeof(double) * B * P, hipMemcpyHostToDevice, f->st));
@@ -1058,10 +1072,14 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
           rc = round_all(f);
           hipGraph_t gr = nullptr;
           e = hipStreamEndCapture(f->st, &gr);
-          if (rc) return rc;
+          // a capture another thread's activity invalidated makes the captured launches fail too: that is a failed CAPTURE
+          // (nothing ran, nothing changed on the device), not a failed round -- the round below runs eagerly
+          if (rc && e == hipSuccess) return rc;
+          rc = 0;
           if (e == hipSuccess && gr && hipGraphInstantiate(&f->gexec, gr, nullptr, nullptr, 0) == hipSuccess) {
             f->graph = gr;
           } else {
+            if (gr) (void)hipGraphDestroy(gr);
             f->gexec = nullptr;
             use_graph = 0;
           }
@@ -1098,7 +1116,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
     // the per-fit scalars lie one after the other in the workspace (carve_b: s.mu .. s.njev): ONE copy instead of seven
     const char *lo = reinterpret_cast<const char *>(f->s.mu), *hi = reinterpret_cast<const char *>(f->s.njev + B);
     std::vector<char> span((size_t)(hi - lo));
-    BHIP(f, hipMemcpy(span.data(), lo, span.size(), hipMemcpyDeviceToHost));
+    BHIP(f, copy_sync(f, span.data(), lo, span.size(), hipMemcpyDeviceToHost));
     auto at = [&](const void *dev) { return span.data() + (reinterpret_cast<const char *>(dev) - lo); };
     const double *mu = reinterpret_cast<const double *>(at(f->s.mu)), *chi2 = reinterpret_cast<const double *>(at(f->s.chi2));
     const int32_t *nit = reinterpret_cast<const int32_t *>(at(f->s.nit)), *info = reinterpret_cast<const int32_t *>(at(f->s.info));
@@ -1123,7 +1141,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
 int lsqamdb_get_x(lsqamdb_fits *f, double *out, size_t cap) try {
   if (!f || !out) return LSQAMD_EINVAL;
   if (cap < (size_t)(f->B * f->P)) BFAIL(f, LSQAMD_ECAPACITY, "get_x: need %lld", (long long)(f->B * f->P));
-  BHIP(f, hipMemcpy(out, f->px, sizeof(double) * f->B * f->P, hipMemcpyDeviceToHost));
+  BHIP(f, copy_sync(f, out, f->px, sizeof(double) * f->B * f->P, hipMemcpyDeviceToHost));
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
 
@@ -1134,7 +1152,7 @@ int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) try {
   if (f->have_cov && f->one_launch) {     // formed by the fit kernel itself
     if (logdet_out) {
       if (cap < (size_t)f->B) BFAIL(f, LSQAMD_ECAPACITY, "covariance: need %lld", (long long)f->B);
-      BHIP(f, hipMemcpy(logdet_out, f->logdet, sizeof(double) * f->B, hipMemcpyDeviceToHost));
+      BHIP(f, copy_sync(f, logdet_out, f->logdet, sizeof(double) * f->B, hipMemcpyDeviceToHost));
     }
     return 0;
   }
@@ -1163,7 +1181,7 @@ int lsqamdb_covariance(lsqamdb_fits *f, double *logdet_out, size_t cap) try {
   f->have_cov = true;
   if (logdet_out) {
     if (cap < (size_t)B) BFAIL(f, LSQAMD_ECAPACITY, "covariance: need %lld", (long long)B);
-    BHIP(f, hipMemcpy(logdet_out, f->logdet, sizeof(double) * B, hipMemcpyDeviceToHost));
+    BHIP(f, copy_sync(f, logdet_out, f->logdet, sizeof(double) * B, hipMemcpyDeviceToHost));
   }
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)

@@ -148,7 +148,12 @@ def refit(fit, ymeans, prior_means, p0, tol=None, maxit=None, covariance=True):
                      None if (dense or not wh.has_prior) else wh.prior_sdev, whitening=wh, n_fits=n,
                      prior_prec=wh.prior_prec if dense else None,
                      prior_logdet=(wh.logdet - wh.logdet_data) if dense else None, rows_permuted=perm is not None)
-XX
+    args = getattr(fit, 'fitterargs', {})      # the copies are fitted with the original fit's arguments (src/lsqfit/__init__.py:1457-1459)
+    out = bf.run(p0=p0, tol=tol, maxit=maxit, covariance=covariance, scaler=args.get('scaler', 'more'),
+                 factor_up=float(args.get('factor_up', 3.0)), factor_down=float(args.get('factor_down', 2.0)))
+    bf.close()
+    res = ResampledFits(out)
+    res['engine'] = 'batched'
     res['ymeans'] = ymeans
     res['prior_means'] = prior_means
     return res

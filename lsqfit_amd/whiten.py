@@ -102,15 +102,26 @@ class _Block(dict):
     """One covariance block.  ``Wt`` (host copy of the transposed weights) and ``S`` (sampling
     factor, S S^T = regulated covariance) are made on first use: the device path needs neither."""
 
+    @staticmethod
+    def _to_host(t):
+        """device tensor -> numpy, copied on the package's side stream (not the legacy default stream: _lib.side_stream)"""
+        import torch
+        from . import _lib
+        side = _lib.side_stream(t.device)
+        with torch.cuda.stream(side):
+            h = t.cpu()
+        side.synchronize()
+        return h.numpy()
+
     def __missing__(self, key):
         if key == 'Wt':
-            v = self['Wt_dev'].cpu().numpy()
+            v = self._to_host(self['Wt_dev'])
         elif key == 'S':
             cov = np.asarray(self['cov'], float)
             sd = np.sqrt(np.diag(cov))
             v = sd[:, None] * sla.cholesky(cov / np.outer(sd, sd), lower=True)
         elif key == 'prec':
-            v = self['prec_dev'].cpu().numpy()
+            v = self._to_host(self['prec_dev'])
         else:
             raise KeyError(key)
         self[key] = v
@@ -135,17 +146,20 @@ def _device_regulate(covs, svdcut, want_prec):
     nb, B = len(covs), covs[0].shape[0]
     stack = np.ascontiguousarray(covs[0] if nb == 1 else np.stack(covs), np.float64)
     dev = torch.device('cuda', torch.cuda.current_device())
-    wt = torch.empty((nb, B, B), dtype=torch.float64, device=dev)
-    prec = torch.empty((nb, B, B), dtype=torch.float64, device=dev) if want_prec else None
-    nbytes = lib.lsqamd_whiten_work_bytes(B, nb)
-    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    logdet, lmin, lmax = np.empty(nb), np.empty(nb), np.empty(nb)
-    status = np.empty(nb, np.int32)
-    rc = lib.lsqamd_whiten_blocks(
-        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), B, nb, C.c_void_p(stack.ctypes.data),
-        0.0 if svdcut is None else float(svdcut), C.c_void_p(wt.data_ptr()),
-        C.c_void_p(prec.data_ptr()) if want_prec else None, C.c_void_p(work.data_ptr()), nbytes,
-        _lib.dptr(logdet), _lib.dptr(lmin), _lib.dptr(lmax), status.ctypes.data_as(C.POINTER(C.c_int32)))
+    side = _lib.side_stream(dev)          # the package's own non-blocking stream (never the legacy default stream)
+    with torch.cuda.stream(side):
+        wt = torch.empty((nb, B, B), dtype=torch.float64, device=dev)
+        prec = torch.empty((nb, B, B), dtype=torch.float64, device=dev) if want_prec else None
+        nbytes = lib.lsqamd_whiten_work_bytes(B, nb)
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        logdet, lmin, lmax = np.empty(nb), np.empty(nb), np.empty(nb)
+        status = np.empty(nb, np.int32)
+        rc = lib.lsqamd_whiten_blocks(
+            C.c_void_p(side.cuda_stream), B, nb, C.c_void_p(stack.ctypes.data),
+            0.0 if svdcut is None else float(svdcut), C.c_void_p(wt.data_ptr()),
+            C.c_void_p(prec.data_ptr()) if want_prec else None, C.c_void_p(work.data_ptr()), nbytes,
+            _lib.dptr(logdet), _lib.dptr(lmin), _lib.dptr(lmax), status.ctypes.data_as(C.POINTER(C.c_int32)))
+        side.synchronize()                # (the call hands host results back, so it has waited already: this is for the record)
     if rc != 0:
         raise RuntimeError('lsqfit_amd: lsqamd_whiten_blocks failed (%s)' % _lib.ERRORS.get(rc, rc))
     del work
@@ -478,8 +492,14 @@ class Whitening:
         tri = np.array([k['tri'] for k in sel], np.int32)
         if sel and all('Wt_dev' in k for k in sel):
             import torch                                  # weights made on the device stay there
-            wt = sel[0]['Wt_dev'].reshape(-1) if len(sel) == 1 else torch.cat([k['Wt_dev'].reshape(-1) for k in sel])
-            return row0, size, modes, tri, wt.contiguous()
+            from . import _lib
+            if len(sel) == 1:
+                return row0, size, modes, tri, sel[0]['Wt_dev'].reshape(-1).contiguous()
+            side = _lib.side_stream(sel[0]['Wt_dev'].device)
+            with torch.cuda.stream(side):                 # (not the legacy default stream: _lib.side_stream)
+                wt = torch.cat([k['Wt_dev'].reshape(-1) for k in sel]).contiguous()
+            side.synchronize()
+            return row0, size, modes, tri, wt
         wt = (np.concatenate([k['Wt'].reshape(-1) for k in sel]) if sel else np.zeros(0))
         return row0, size, modes, tri, np.ascontiguousarray(wt, np.float64)
 

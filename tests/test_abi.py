@@ -202,3 +202,14 @@ def test_unloadable_rccl_is_reported_not_crashed(libpath, tmp_path):
                            timeout=300)
         assert r.returncode == 0, r.stdout
         assert 'rc -6' in r.stdout, r.stdout
+
+
+def test_every_module_of_the_package_compiles():
+    """A syntax error in a module only the GPU tests import must not wait for the GPU box to be found."""
+    import glob
+    import py_compile
+    files = glob.glob(os.path.join(ROOT, 'lsqfit_amd', '*.py')) + glob.glob(os.path.join(ROOT, 'tests', '*.py')) + \
+        glob.glob(os.path.join(ROOT, 'oracle', '*.py')) + [os.path.join(ROOT, 'bench.py'), os.path.join(ROOT, '__graft_entry__.py')]
+    assert len(files) > 40
+    for f in files:
+        compile(open(f).read(), f, "exec")
