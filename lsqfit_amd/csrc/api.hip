@@ -1414,6 +1414,7 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
       // one) and took the captured launches down with it -- nothing ran; the half step is queued again, eagerly.  A failure
       // with a healthy capture is the enqueue's own
       if (rc && e == hipSuccess) return rc;
+      capture_reset(f->st);      // (an invalidated capture leaves the stream unusable until it is reset: common.h)
       return enqueue(f);
     }
     (void)hipGraphDestroy(gr);

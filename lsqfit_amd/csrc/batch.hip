@@ -570,6 +570,13 @@ hipError_t copy_sync(lsqamdb_fits *f, void *dst, const void *src, size_t bytes, 
   return hipStreamSynchronize(f->st);
 }
 
+hipError_t copy2d_sync(lsqamdb_fits *f, void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height,
+                       hipMemcpyKind kind) {
+  hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, kind, f->st);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(f->st);
+}
+
 size_t carve_b(lsqamdb_fits *f, void *ws, bool dry) {
   const lsqamd_config &c = f->cfg;
   const int64_t N = c.n_data, P = c.n_param, B = f->B;
@@ -1082,6 +1089,7 @@ int lsqamdb_run(lsqamdb_fits *f, const double *p0, lsqamd_summary *summaries, in
             if (gr) (void)hipGraphDestroy(gr);
             f->gexec = nullptr;
             use_graph = 0;
+            capture_reset(f->st);      // (an invalidated capture leaves the stream unusable until it is reset: common.h)
           }
         } else {
           use_graph = 0;
@@ -1194,7 +1202,7 @@ int lsqamdb_get_cov(lsqamdb_fits *f, int32_t fit, double *out, size_t cap) try {
     const int rc = lsqamdb_covariance(f, nullptr, 0);
     if (rc) return rc;
   }
-  BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov + (int64_t)fit * P * f->ldm, sizeof(double) * f->ldm,
+  BHIP(f, copy2d_sync(f, out, sizeof(double) * P, f->cov + (int64_t)fit * P * f->ldm, sizeof(double) * f->ldm,
                       sizeof(double) * P, (size_t)P, hipMemcpyDeviceToHost));
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
@@ -1208,7 +1216,7 @@ int lsqamdb_get_cov_all(lsqamdb_fits *f, double *out, size_t cap) try {
     if (rc) return rc;
   }
   // fit b's rows follow fit b - 1's in f->cov (P rows of ldm doubles each): one strided copy of B * P rows
-  BHIP(f, hipMemcpy2D(out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P, (size_t)(B * P),
+  BHIP(f, copy2d_sync(f, out, sizeof(double) * P, f->cov, sizeof(double) * f->ldm, sizeof(double) * P, (size_t)(B * P),
                       hipMemcpyDeviceToHost));
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)

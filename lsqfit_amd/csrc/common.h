@@ -43,6 +43,30 @@ template <class H> int abi_exception(H *h) noexcept {
 inline int abi_exception(std::nullptr_t) noexcept { return abi_exception(static_cast<lsqamd_abi_no_handle *>(nullptr)); }
 #define LSQAMD_ABI_CATCH(...) catch (...) { __VA_ARGS__ }
 
+// ---- a stream whose graph capture was invalidated ---------------------------------
+// On ROCm 7 a legacy-stream call from ANY thread (hipMemcpy, a NULL-stream launch: the library makes none, other code in the
+// process may) fails with hipErrorStreamCaptureImplicit while a capture is open and invalidates that capture; and
+// hipStreamEndCapture then returns hipErrorStreamCaptureInvalidated but LEAVES the stream in the invalidated state: every
+// later launch and synchronisation on it fails (measured: tools/dbg_capture_reset.hip).  What brings the stream back is a
+// fresh (empty) begin / end capture pair.  Called on every failed capture before the work is queued again eagerly.
+inline void capture_reset(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  hipGraph_t g = nullptr;
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) {
+    (void)hipStreamEndCapture(st, &g);
+    if (g) (void)hipGraphDestroy(g);
+    g = nullptr;
+  }
+  (void)hipGetLastError();
+  if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      (void)hipStreamEndCapture(st, &g);
+      if (g) (void)hipGraphDestroy(g);
+    }
+  }
+  (void)hipGetLastError();
+}
+
 // ---- once per DEVICE, from any thread ---------------------------------------------
 // hipFuncSetAttribute(..., MaxDynamicSharedMemorySize, ...) applies to the CURRENT device only, and the ABI lets one
 // process hold handles on several GPUs from several host threads (lsqamd_create records the device, lsqamd_query_devices

@@ -153,9 +153,11 @@ class DeviceProblem:
         # library synchronises its stream before handing results back, so callers see no difference
         idle = _STREAMS.get(self.device.index)
         self.stream = idle.pop() if idle else torch.cuda.Stream(device=self.device)
-        # device-made whitening weights (block_arrays above: torch.cat on the caller's current stream)
-        # are read by lsqamd_set_data on OUR stream: order the two
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        # device-made whitening weights are complete when the whitening hands them over (made on the package's side stream
+        # and waited for: _lib.side_stream); work the CALLER queued on a stream of its own is ordered before ours.  The legacy
+        # default stream is never touched -- recording an event on it collides with any graph capture another thread has
+        # open (include/lsqfit_amd.h, "threads")
+        self._after_callers_stream()
         h = C.c_void_p()
         rc = self.lib.lsqamd_create(C.byref(cfg), C.c_void_p(base + self._ws_off), nbytes,
                                     C.c_void_p(self.stream.cuda_stream), C.byref(h))
@@ -221,6 +223,12 @@ class DeviceProblem:
         self.t_setup = time.perf_counter() - t0
 
     # -- knobs ------------------------------------------------------------------------
+    def _after_callers_stream(self):
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != 0:
+            self.stream.wait_stream(cur)
+
     def set_prior(self, mean, prec):
         """Prior mean (P) and precision: P entries (diagonal) or P x P (dense).  A diagonal given
         to a handle created with a dense prior is expanded; the reverse is refused (the library
@@ -235,8 +243,7 @@ class DeviceProblem:
         if mean.size != P:
             raise ValueError('prior mean has %d entries, the model has %d parameters' % (mean.size, P))
         if hasattr(prec, 'data_ptr'):
-            import torch                             # produced on the caller's stream, copied on ours
-            self.stream.wait_stream(torch.cuda.current_stream(self.device))
+            self._after_callers_stream()             # produced on the caller's stream (if it has one), copied on ours
         elif self.cfg.prior_dense:
             if prec.size == P:
                 prec = np.ascontiguousarray(np.diag(prec.reshape(-1)))

@@ -230,3 +230,46 @@ def test_exception_inside_the_library_stays_in_its_handle(amd):
     _same(ref, got['fit'])
     assert pr.chi2(d['p0']) > 0           # the handle that caught the exceptions still works
     pr.close()
+
+
+def test_a_legacy_stream_user_in_another_thread_does_not_break_fits(amd):
+    """Other code in the process may use the legacy default stream (a plain hipMemcpy; torch's default stream).  On ROCm 7 such
+    a call fails with hipErrorStreamCaptureImplicit while ANY thread has a graph capture open, invalidates that capture, and
+    hipStreamEndCapture then leaves the stream in the invalidated state (tools/dbg_capture_reset.hip).  The library's answer:
+    it never uses the legacy stream itself, and a handle whose capture was invalidated resets its stream and queues the step
+    eagerly (csrc/common.h capture_reset).  Here: one thread hammers hipMemcpy on the legacy stream while another runs
+    general-path fits (captured LM steps) and lockstep batches (a capture per run): every fit succeeds with the serial bits."""
+    import ctypes as C
+    import torch
+    torch.zeros(1, device='cuda')
+    hip = C.CDLL([ln.split()[-1] for ln in open('/proc/self/maps') if 'libamdhip64' in ln][0])
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    dbuf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dbuf), 4096) == 0
+    host = (C.c_double * 512)()
+    gen = [_general_job(amd, 940 + i) for i in range(2)]
+    bat = [_batched_job(amd, 950 + i) for i in range(2)]
+    gref, bref = [j() for j in gen], [j() for j in bat]
+    stop = threading.Event()
+    counts = {'calls': 0, 'refused': 0}
+
+    def hammer():
+        while not stop.is_set():
+            rc = hip.hipMemcpy(host, dbuf, 4096, 2)       # hipMemcpyDeviceToHost on the legacy stream
+            counts['calls'] += 1
+            counts['refused'] += rc != 0
+            hip.hipGetLastError()
+    t = threading.Thread(target=hammer)
+    t.start()
+    try:
+        for rep in range(6):
+            for j, r in zip(gen, gref):
+                _same(r, j())
+            for j, r in zip(bat, bref):
+                _same(r, j())
+    finally:
+        stop.set()
+        t.join(timeout=60)
+    assert counts['calls'] > 100
+    print('legacy-stream copies issued: %d, refused by the runtime during captures: %d' % (counts['calls'], counts['refused']))

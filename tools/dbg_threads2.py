@@ -46,10 +46,18 @@ for gen_graph in ('1', '0'):
             out = {}
 
             def wg():
-                out['g'] = [j() for j in gen]
+                try:
+                    out['g'] = [j() for j in gen]
+                except Exception as e:
+                    print('GENERAL thread failed:', e, flush=True)
+                    out['g'] = []
 
             def wb():
-                out['b'] = [j() for j in bat]
+                try:
+                    out['b'] = [j() for j in bat]
+                except Exception as e:
+                    print('BATCHED thread failed:', e, flush=True)
+                    out['b'] = []
             ts = [threading.Thread(target=wg), threading.Thread(target=wb)]
             [t.start() for t in ts]
             [t.join() for t in ts]
