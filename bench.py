@@ -72,7 +72,7 @@ def parse():
 
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the oracle's LM driver (oracle/lm.py, the GSL restatement) on a host-core port of the cosmix workload's
-# normal equations.  "strong" mode of SURVEY.md 8d: every host core, blocked kernels --
+# normal equations (oracle/port.py CosmixPort).  "strong" mode of SURVEY.md 8d: every host core, blocked kernels --
 #   trig       cos / sin of the N x K phase matrix in row chunks on a thread pool (numpy releases the GIL inside its loops),
 #              written straight into the preallocated Jacobian (no hstack, no 2 GB temporaries);
 #   whiten     J_b = W_b J_b per covariance block (blocks up to 1024 rows inside the same pool task, one BLAS thread each;
@@ -80,129 +80,11 @@ def parse():
 #   syrk       J^T J with BLAS dsyrk (the triangle only: half the flops of J.T @ J), mirrored once;
 #   cholesky   the damped factorisations + solves of the trial steps (LAPACK potrf / potrs, all cores).
 # A baseline, not the target (the GPU / CPU ratio says nothing about kernel quality; roofline.frac does).
-class CosmixPort:
-    def __init__(self, d):
-        import scipy.linalg as sla
-        self.x, self.ymean = np.asarray(d['x'], float), np.asarray(d['ymean'], float)
-        self.pm, perr = d['prior']
-        self.P = self.pm.size
-        self.K = self.P // 2
-        self.N = self.ymean.size
-        yerr = d['yerr']
-        sd = np.asarray(yerr['sdev'] if isinstance(yerr, dict) else yerr, float)
-        blocks = yerr['blocks'] if isinstance(yerr, dict) else []
-        # whitening set-up (untimed, as on the GPU side): W_b = inv(chol(C_b))
-        self.Ws = []
-        for r0, cov in blocks:
-            L = sla.cholesky(cov, lower=True)
-            self.Ws.append((int(r0), sla.solve_triangular(L, np.eye(cov.shape[0]), lower=True)))
-        inblk = np.zeros(self.N, bool)
-        for r0, W in self.Ws:
-            inblk[r0:r0 + W.shape[0]] = True
-        self.wdiag = np.where(inblk, 1.0, 1.0 / sd)
-        self.prec = np.linalg.inv(perr) if np.ndim(perr) == 2 else np.diag(1.0 / np.asarray(perr, float) ** 2)
-        self.cores = os.cpu_count() or 1
-        self.workers = max(1, min(self.cores, 64))
-        # row chunks: whole small blocks, else 512 rows; big blocks are whitened afterwards
-        edges, small, r = [], {}, 0
-        big = []
-        for r0, W in sorted(self.Ws, key=lambda t: t[0]):
-            B = W.shape[0]
-            while r < r0:
-                edges.append((r, min(r + 512, r0), None)); r = edges[-1][1]
-            if B <= 1024:
-                edges.append((r0, r0 + B, W))
-            else:
-                big.append((r0, W))
-                a = r0
-                while a < r0 + B:
-                    edges.append((a, min(a + 512, r0 + B), None)); a = edges[-1][1]
-            r = r0 + B
-        while r < self.N:
-            edges.append((r, min(r + 512, self.N), None)); r = edges[-1][1]
-        self.chunks, self.big = edges, big
-        self.J = np.empty((self.N, self.P))
-        self.rw = np.empty(self.N)
-        self.phases = dict(trig=0.0, whiten=0.0, syrk=0.0, cholesky=0.0)
-        from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(self.workers)
-
-    def _limits(self, n):
-        try:
-            import threadpoolctl
-            return threadpoolctl.threadpool_limits(limits=n)
-        except Exception:
-            import contextlib
-            return contextlib.nullcontext()
-
-    def _rows(self, a, b, W, p, jac, acc):
-        K, x = self.K, self.x[a:b]
-        t0 = time.perf_counter()
-        wx = np.multiply.outer(x, p[K:])
-        c = np.cos(wx)
-        raw = c @ p[:K] - self.ymean[a:b]
-        if jac:
-            np.sin(wx, out=wx)
-            wx *= -p[:K]
-            wx *= x[:, None]
-        t1 = time.perf_counter()
-        if W is not None:
-            self.rw[a:b] = W @ raw
-            if jac:
-                self.J[a:b, :K] = W @ c
-                self.J[a:b, K:] = W @ wx
-        else:
-            wd = self.wdiag[a:b]
-            self.rw[a:b] = wd * raw
-            if jac:
-                np.multiply(c, wd[:, None], out=self.J[a:b, :K])
-                np.multiply(wx, wd[:, None], out=self.J[a:b, K:])
-        t2 = time.perf_counter()
-        acc.append((t1 - t0, t2 - t1))
-
-    def _assemble(self, p, jac):
-        """whitened residual (and Jacobian) at p -> self.rw (self.J); thread-time of the two sub-phases apportions the wall"""
-        acc = []
-        t0 = time.perf_counter()
-        with self._limits(1):
-            list(self.pool.map(lambda ch: self._rows(ch[0], ch[1], ch[2], p, jac, acc), self.chunks))
-        wall = time.perf_counter() - t0
-        tt, tw = sum(a for a, _ in acc), sum(b for _, b in acc)
-        self.phases['trig'] += wall * tt / max(tt + tw, 1e-30)
-        self.phases['whiten'] += wall * tw / max(tt + tw, 1e-30)
-        t0 = time.perf_counter()
-        for r0, W in self.big:                    # one large dense block (c3): a multi-threaded GEMM
-            B = W.shape[0]
-            self.rw[r0:r0 + B] = W @ self.rw[r0:r0 + B]
-            if jac:
-                self.J[r0:r0 + B] = W @ self.J[r0:r0 + B]
-        self.phases['whiten'] += time.perf_counter() - t0
-
-    def chi2_fn(self, p):
-        self._assemble(p, False)
-        dp = p - self.pm
-        return float(self.rw @ self.rw + dp @ self.prec @ dp)
-
-    def normal_eq(self, p):
-        import scipy.linalg.blas as blas
-        self._assemble(p, True)
-        t0 = time.perf_counter()
-        U = blas.dsyrk(1.0, self.J.T, trans=0, lower=0)      # J.T is Fortran-contiguous: no copy; upper triangle of J^T J
-        A = np.ascontiguousarray(U)
-        A += np.triu(U, 1).T
-        g = self.J.T @ self.rw
-        self.phases['syrk'] += time.perf_counter() - t0
-        dp = p - self.pm
-        return A + self.prec, g + self.prec @ dp, float(self.rw @ self.rw + dp @ self.prec @ dp)
-
-    def close(self):
-        self.pool.shutdown()
-
-
 def cpu_baseline(d, budget_s, maxit=8, faithful=True):
     """Oracle (numpy / BLAS 'port') LM steps/s on the same inputs.  Bounded: the driver stops after the first LM iteration
     that ends beyond the time budget (at least one iteration)."""
     from oracle import lm as olm
+    from oracle.port import CosmixPort
     port = CosmixPort(d)
 
     class TimedLin(olm._NormalLin):       # the oracle's normal-equation algebra, its factorisations timed
@@ -778,6 +660,7 @@ def c5_chi2(line):
     B = pm.shape[0]
     try:
         from oracle import lm as olm
+        from oracle.port import CosmixPort
         cm = []
         for b in (0, B - 1):
             db = dict(d, prior=(pm[b], ps[b]), p0=np.where(pm[b] != 0.0, pm[b], pm[b] + 0.1 * ps[b]))

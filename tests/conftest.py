@@ -17,10 +17,10 @@ def pytest_configure(config):
 # path; (3) unit checks of single kernels against numpy; (4) route-vs-route equivalence files (one implementation against
 # another of this library: a failure there says two routes differ, not that a result is wrong) -- last.
 _GPU_ORDER = [
-    'test_gpu_parity', 'test_gpu_trace', 'test_gpu_scale', 'test_gpu_whiten', 'test_gpu_trf', 'test_gpu_trs', 'test_gpu_qr', 'test_gpu_points',
+    'test_gpu_parity', 'test_gpu_trace', 'test_gpu_protocol', 'test_gpu_scale', 'test_gpu_whiten', 'test_gpu_trf', 'test_gpu_trs', 'test_gpu_qr', 'test_gpu_points',
     'test_gpu_resample', 'test_gpu_fitp', 'test_gpu_fuzz', 'test_gpu_jit_fuzz', 'test_gpu_midsize', 'test_gpu_batched',
     'test_gpu_tape', 'test_gpu_edge', 'test_gpu_interleaved', 'test_gpu_programs', 'test_gpu_robust', 'test_gpu_cosh', 'test_gpu_one_launch', 'test_gpu_fused_normal',
-    'test_gpu_comm', 'test_gpu_comm_multi', 'test_gpu_dist2', 'test_gpu_bench_smoke',
+    'test_gpu_comm', 'test_gpu_comm_multi', 'test_gpu_dist2', 'test_gpu_threads', 'test_gpu_bench_smoke',
     'test_gpu_ops', 'test_gpu_syrk_colsum', 'test_gpu_tri_halves', 'test_gpu_uninit',
     'test_gpu_fused_jacobian', 'test_gpu_stepgraph',
 ]

@@ -130,7 +130,16 @@ def numpy_normal_equations(d):
     return normal_eq, chi2_fn, float(logdet)
 
 
-def check_fit_vs_normal_oracle(fit, d, p0, tol=1e-6, lm_tol=(1e-8, 1e-10, 1e-10), seed=17, restart=False):
+def threaded_normal_equations(d):
+    """the same sums from oracle/port.py (threaded trig, per-block whitening with inv(chol(C_b)), BLAS dsyrk): the full-size
+    checks use it (an oracle iteration at (65536, 4096) takes ~6 s with it, ~15 s with the plain restatement above -- which
+    the two agree with to 1e-15, tests/test_oracle_port.py)"""
+    from oracle.port import CosmixPort
+    port = CosmixPort(d)
+    return port.normal_eq, port.chi2_fn, port.logdet
+
+
+def check_fit_vs_normal_oracle(fit, d, p0, tol=1e-6, lm_tol=(1e-8, 1e-10, 1e-10), seed=17, restart=False, fast=False, first=None):
     """a converged device fit against the oracle's LM driver (oracle.lm.lm_normal: the restated gsl_multifit_nlinear trust
     / lm / nielsen / more / convergence, src/lsqfit/_gsl.pyx:563-706) run on numpy_normal_equations: p, chi2/dof, the diagonal
     and 64 random columns of cov, logGBF at ``tol``; -> the oracle's result.
@@ -140,7 +149,15 @@ def check_fit_vs_normal_oracle(fit, d, p0, tol=1e-6, lm_tol=(1e-8, 1e-10, 1e-10)
     device's to ``tol`` -- which is what 'the same converged fit' means; the trajectory itself is compared iteration for
     iteration at (4096, 512) (test_iteration_count_from_the_prior_mean_matches_oracle)."""
     from oracle import lm as olm
-    normal_eq, chi2_fn, logdet_c = numpy_normal_equations(d)
+    normal_eq, chi2_fn, logdet_c = (threaded_normal_equations if fast else numpy_normal_equations)(d)
+    if first is not None:           # the caller wants the oracle's first evaluation (point, A, g, chi2, log det C) as well
+        inner = normal_eq
+
+        def normal_eq(p):
+            out = inner(p)
+            if not first:
+                first.extend([np.array(p, float), np.array(out[0]), np.array(out[1]), float(out[2]), logdet_c])
+            return out
     ref = olm.lm_normal(fit.pmean if restart else p0, normal_eq, chi2_fn, tol=lm_tol, maxit=1000 if not restart else 3)
     if restart:
         assert ref.nit <= 2 and ref.stopping_criterion in (1, 2), (ref.nit, ref.stopping_criterion)

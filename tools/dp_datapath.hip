@@ -26,7 +26,8 @@ struct Out {
 __device__ __forceinline__ unsigned long long now() { return __builtin_readcyclecounter(); }   // s_memtime: shader clock
 
 // role of each of the 8 waves: 0 idle, 1 MFMA, 2 FMA, 3 = MFMA and FMA interleaved in ONE wave (what whiten_synth does),
-// 4 = fp32 FMAs only (v_fma_f32: does NON-fp64 VALU work hide behind fp64 MFMAs?), 5 = 32-bit integer multiply-adds only
+// 4 = fp32 FMAs only (v_pk_fma_f32: does NON-fp64 VALU work hide behind fp64 MFMAs?), 5 = 32-bit integer multiply-adds only
+// (v_mad_u64_u32), 6 = ONE wave with 8 fp32 FMAs (4 v_pk_fma_f32) after every MFMA, 7 = ONE wave with 4 v_mad_u64_u32 after every MFMA
 __global__ __launch_bounds__(512, 1) void probe(const int *roles, unsigned long long budget, Out *out, double seed) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int role = roles[wave];
@@ -91,6 +92,37 @@ __global__ __launch_bounds__(512, 1) void probe(const int *roles, unsigned long 
     float s = 0.f;
     for (int i = 0; i < 16; ++i) s += xf[i] + (float)xi[i];
     if (s == 12345.678f) out[8].count = 1;
+  } else if (role == 6 || role == 7) {
+    v4d acc[8];
+    for (int i = 0; i < 8; ++i) acc[i] = (v4d){seed, 0.0, 0.0, 0.0};
+    float xf[16];
+    int xi[16];
+    for (int i = 0; i < 16; ++i) { xf[i] = (float)seed + i + lane * 1e-3f; xi[i] = i + lane; }
+    const double a = seed + lane * 1e-9, b = 1.0 - seed;
+    const float fa = 1.0f - 1e-6f * (float)seed, fb = 1e-7f;
+    const int ia = 3 + (int)seed, ib = 7;
+    do {
+#pragma unroll
+      for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+          if (role == 6) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) xf[(2 * i + q) & 15] = __builtin_fmaf(xf[(2 * i + q) & 15], fa, fb);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xi[(2 * i + q) & 15] = xi[(2 * i + q) & 15] * ia + ib;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      n += 64;
+      t1 = now();
+    } while (t1 - t0 < budget);
+    double s = 0.0;
+    for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y + acc[i].z + acc[i].w;
+    for (int i = 0; i < 16; ++i) s += xf[i] + xi[i];
+    if (s == 12345.678) out[8].count = 1;
   } else {
     // one wave, both kinds interleaved: 4 FMAs after every MFMA (an MFMA occupies the pipe for 16 passes x 4 clocks; four
     // wave64 FMAs are 4 x 4 = 16 issue clocks: would fit in its shadow if the pipes were separate)
@@ -148,6 +180,8 @@ int main() {
       {"(13) int32 mad wave alone", {5, 0, 0, 0, 0, 0, 0, 0}},
       {"(14) MFMA + int32 mad, same SIMD", {1, 0, 0, 0, 5, 0, 0, 0}},
       {"(15) fp64 FMA + fp32 FMA, same SIMD", {2, 0, 0, 0, 4, 0, 0, 0}},
+      {"(16) one wave, 1 MFMA : 8 fp32 FMA (4 v_pk_fma_f32) interleaved", {6, 0, 0, 0, 0, 0, 0, 0}},
+      {"(17) one wave, 1 MFMA : 4 v_mad_u64_u32 interleaved", {7, 0, 0, 0, 0, 0, 0, 0}},
   };
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
@@ -171,8 +205,10 @@ int main() {
       if (!h[w].role) continue;
       const double us = 1e3 * ms * (double)h[w].cycles / (double)(h[w].cycles ? h[w].cycles : 1);   // every wave runs (almost) the whole launch
       const double ticks = (double)h[w].cycles;
-      const char *kind = h[w].role == 1 ? "MFMA" : h[w].role == 2 ? "FMA " : h[w].role == 4 ? "FMA32" : h[w].role == 5 ? "IMAD32" : "MFMA(+4 FMA each)";
-      const double flop = h[w].role == 1 ? 2048.0 : (h[w].role == 2 || h[w].role == 4 || h[w].role == 5) ? 128.0 : 2048.0 + 4 * 128.0;
+      const char *kind = h[w].role == 1 ? "MFMA" : h[w].role == 2 ? "FMA " : h[w].role == 4 ? "FMA32" : h[w].role == 5 ? "IMAD32" :
+                         h[w].role == 6 ? "MFMA(+8 FMA32 each)" : h[w].role == 7 ? "MFMA(+4 IMAD each)" : "MFMA(+4 FMA each)";
+      const double flop = h[w].role == 1 ? 2048.0 : (h[w].role == 2 || h[w].role == 4 || h[w].role == 5) ? 128.0 :
+                          h[w].role == 6 ? 2048.0 + 8 * 128.0 : h[w].role == 7 ? 2048.0 + 4 * 128.0 : 2048.0 + 4 * 128.0;
       printf("    wave %d  SIMD %u  CU %u  %-18s %12llu instr in %10.0f ticks  = %9.2f instr/us = %7.2f GFLOP/s  (ticks/us %.1f)\n", w,
              (h[w].hw_id >> 4) & 3, (h[w].hw_id >> 8) & 15, kind, h[w].count, ticks, (double)h[w].count / us,
              (double)h[w].count * flop / us * 1e-3, ticks / us);
