@@ -504,6 +504,11 @@ int lsqamd_handoff_stats(int64_t *out3);
  * lsqamd_debug_per_device_once(dev, 0) returns how many times the per-device "set kernel attributes" action has run for
  * device `dev` after this call (1 however often it is called, separately per device; reset != 0 clears the counters). */
 int lsqamd_debug_throw(lsqamd_fit *fit, int32_t kind);
+/* GPU self-test of the recovery from an invalidated graph capture (csrc/common.h capture_reset): a capture on
+ * `stream` (non-blocking, idle), ONE legacy-stream hipMemcpy from another thread while it is open, the reset, an eager copy.
+ * report[6]: intruder's hipMemcpy result, hipStreamEndCapture's result, capture status after it, status after the reset,
+ * result of the eager copy + synchronise, the value it delivered (42). */
+int lsqamd_debug_capture_selftest(void *stream, int32_t *report);
 int lsqamd_debug_per_device_once(int32_t dev, int32_t reset);
 /* The process-wide cache of compiled formulas (lsqamd_set_tape compiles with hiprtc and keeps the loaded code object):
  * out3[0] = kernels loaded now, out3[1] = of those, held by a live handle, out3[2] = kernels unloaded so far.  At most

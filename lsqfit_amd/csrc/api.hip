@@ -21,6 +21,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <sched.h>
 
@@ -262,6 +263,17 @@ void resolve_timers(lsqamd_fit *f, bool only_if_many = false) {
     for (auto &t : f->timers) n += t.pending.size();
     if (n < 512) return;
   }
+  for (auto &t : f->timers) {      // intervals another timer owns the events of: before those events are recycled below
+    for (auto &pr : t.pending_shared) {
+      (void)hipEventSynchronize(pr.second);
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        t.total_ms += ms;
+        t.count += 1;
+      }
+    }
+    t.pending_shared.clear();
+  }
   for (auto &t : f->timers) {
     for (auto &pr : t.pending) {
       (void)hipEventSynchronize(pr.second);
@@ -451,7 +463,7 @@ int ready(lsqamd_fit *f) {
 int do_reduce(lsqamd_fit *f, double *buf, int64_t count) {
   if (f->comm) {   // RCCL on the handle's stream: nothing to wait for on the host
     Scope sc(f, LSQAMD_T_REDUCE);
-    Scope sc2(f, LSQAMD_T_EXCH_COLL), sc3(f, LSQAMD_T_EXCH_WAIT);   // on the step's own stream: all of it is waited for
+    Scope sc2(f, LSQAMD_T_EXCH_COLL, nullptr, LSQAMD_T_EXCH_WAIT);   // on the step's own stream: ONE interval, all of it waited for
     return comm_all_reduce(f, buf, count);
   }
   if (!f->reduce) return 0;
@@ -3125,6 +3137,56 @@ int lsqamd_debug_throw(lsqamd_fit *f, int32_t kind) try {
   if (kind == 4) { std::vector<double> v; v.reserve(v.max_size()); }   // a real allocation failure (std::length_error / bad_alloc)
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(f);)
+
+// The runtime behaviour capture_reset (common.h) exists for, reproduced deterministically: a ThreadLocal capture on `stream`,
+// ONE legacy-stream hipMemcpy from another thread while it is open, then the recovery.  report[0] = what the intruder's
+// hipMemcpy returned, [1] = what hipStreamEndCapture returned, [2] = the stream's capture status after EndCapture
+// (2 = still "invalidated": the runtime defect), [3] = the status after capture_reset (0 = usable), [4] = result of an
+// eager copy + synchronise on the stream afterwards (0 = success), [5] = the value that copy delivered (42).
+int lsqamd_debug_capture_selftest(void *stream, int32_t *report) try {
+  if (!report) return LSQAMD_EINVAL;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!st) return LSQAMD_EINVAL;
+  for (int i = 0; i < 6; ++i) report[i] = -1;
+  int32_t *dev = nullptr, *dev2 = nullptr;
+  if (hipMalloc(&dev, 64) != hipSuccess || hipMalloc(&dev2, 64) != hipSuccess) return LSQAMD_EHIP;
+  const int32_t v42 = 42;
+  (void)hipMemcpyAsync(dev, &v42, sizeof v42, hipMemcpyHostToDevice, st);
+  (void)hipStreamSynchronize(st);
+  if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return LSQAMD_EHIP; }
+  (void)hipMemcpyAsync(dev2, dev, 4, hipMemcpyDeviceToDevice, st);
+  {
+    std::atomic<int> rc{-1};
+    std::thread other([&] {
+      int32_t h = 0;
+      rc.store((int)hipMemcpy(&h, dev, 4, hipMemcpyDeviceToHost));   // legacy default stream, from ANOTHER thread
+      (void)hipGetLastError();
+    });
+    other.join();
+    report[0] = rc.load();
+  }
+  (void)hipMemcpyAsync(dev2, dev, 4, hipMemcpyDeviceToDevice, st);
+  (void)hipGetLastError();
+  hipGraph_t g = nullptr;
+  report[1] = (int32_t)hipStreamEndCapture(st, &g);
+  (void)hipGetLastError();
+  if (g) (void)hipGraphDestroy(g);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cs);
+  report[2] = (int32_t)cs;
+  lsqamd::capture_reset(st);
+  (void)hipStreamIsCapturing(st, &cs);
+  report[3] = (int32_t)cs;
+  int32_t back = 0;
+  hipError_t e = hipMemcpyAsync(&back, dev, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  report[4] = (int32_t)e;
+  report[5] = back;
+  (void)hipGetLastError();
+  (void)hipFree(dev);
+  (void)hipFree(dev2);
+  return 0;
+} LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
 
 int lsqamd_debug_per_device_once(int32_t dev, int32_t reset) try {
   // how often has the "set the kernel attributes" action of a PerDeviceOnce run for device `dev`?  (the bookkeeping that

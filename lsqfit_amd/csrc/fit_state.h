@@ -30,6 +30,8 @@ struct TimerSlot {
   double total_ms = 0.0;
   int64_t count = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+  // event pairs OWNED by another timer's `pending` list that count for this timer too (resolved first, never recycled here)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_shared;
 };
 
 }  // namespace lsqamd_host
@@ -247,7 +249,8 @@ struct Scope {  // HIP-event bracket for one phase
   int which;
   hipEvent_t a = nullptr, b = nullptr;
   hipStream_t on;
-  Scope(lsqamd_fit *fit, int w, hipStream_t stream = nullptr) : f(fit), which(w), on(stream ? stream : fit->st) {
+  int also;     // a second timer the same interval counts for (-1: none)
+  Scope(lsqamd_fit *fit, int w, hipStream_t stream = nullptr, int also_ = -1) : f(fit), which(w), on(stream ? stream : fit->st), also(also_) {
     if (f->timing) {
       a = take_event(f);
       b = take_event(f);
@@ -258,6 +261,7 @@ struct Scope {  // HIP-event bracket for one phase
     if (f->timing) {
       (void)hipEventRecord(b, on);
       f->timers[which].pending.emplace_back(a, b);
+      if (also >= 0) f->timers[also].pending_shared.emplace_back(a, b);
     }
   }
 };

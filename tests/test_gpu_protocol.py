@@ -46,7 +46,8 @@ def test_simple_example_through_the_protocol(fitters):
     r, chiv, fit = _fit(fitters, lp.simple_example())
     out = KAT['simple']['out']
     check_header(r, out)                                            # chi2/dof 0.17 [5], Q 0.97, logGBF 0.65538
-    assert [gvar_lite.fmt(m, s) for m, s in zip(r.pmean, r.psdev)] == parse_parameter_table(out)[:2] == ['0.253(32)', '0.449(65)']
+    assert [gvar_lite.fmt(m, s) for m, s in zip(r.pmean, r.psdev)] == ['0.253(32)', '0.449(65)']      # simple.out's parameter table
+    assert 'a   0.253 (32)' in out and 'b   0.449 (65)' in out
     assert (np.dtype(object), True) in chiv.calls                   # the plugin differentiated chiv by recording it
     assert r.description.startswith('methods = lm/more/') and r.stopping_criterion in (1, 2, 3)
     assert fit.f.shape == (7,) and fit.J.shape == (7, 2) and fit.cov.shape == (2, 2)

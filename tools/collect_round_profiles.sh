@@ -3,12 +3,13 @@
 # the rocprofv3 kernel trace of the c4 bench, the three PMC passes of the J^T J launch, and the
 # tape-model Jacobian timings.  gpurun -- 'bash tools/collect_round_profiles.sh'
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-R=${LSQAMD_ROUND:-r04}
+R=${LSQAMD_ROUND:-r06}
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT
 cd $ROOT
-python3 bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_c4_1gpu.json 2> $OUT/bench_c4.err
-python3 bench.py --ndata 8192 --steps 40 --warmup 5 --no-cpu-baseline > $OUT/${R}_bench_shard8192_1gpu.json 2>/dev/null
+python3 bench.py --steps 20 --warmup 5 > $OUT/${R}_bench_default.json 2> $OUT/bench_c4.err      # the driver's command: c4 headline + config.other_workloads
+python3 bench.py --workload shard8192 --steps 40 --warmup 5 --no-cpu-baseline | grep '^{' > $OUT/${R}_bench_shard8192_1gpu.json 2>/dev/null
+python3 bench.py --workload c5 | grep '^{' > $OUT/${R}_bench_c5_1gpu.json 2>/dev/null
 python3 bench.py --workload c2 --steps 200 --warmup 20 --cpu-seconds 5 > $OUT/${R}_bench_c2_1gpu.json 2>/dev/null
 python3 bench.py --workload c3 --steps 40 --warmup 5 --cpu-seconds 10 > $OUT/${R}_bench_c3_1gpu.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
