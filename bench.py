@@ -334,14 +334,20 @@ def lm_workload(name, args, env, steps, warmup, headline):
     if not two_pass:
         pr.timing(True)
         pr.timing_reset()
-    state['reinits'] = 0
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    reinits_timed = state['reinits']
+    # the headline: exactly K steps, once (the contract).  A companion with a sub-millisecond step is timed three times over
+    # K steps and the MEDIAN region counts (all three are in the entry): on the pool's shared hosts a 40 ms region catches a
+    # one-off stall of 10-70 ms (another tenant's CPU burst preempting the polling thread, a deferred free in the runtime)
+    # every few runs -- tools/dbg_c2_after_c4.py shows single lsqamd_step calls of 14 ms among 0.16 ms ones
+    regions = []
+    for _ in range(1 if (headline or not two_pass) else 3):
+        state['reinits'] = 0
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        barrier()
+        regions.append((time.perf_counter() - t0, state['reinits']))
+    elapsed, reinits_timed = sorted(regions)[len(regions) // 2]
     if two_pass:
         pr.timing(True)
         pr.timing_reset()
@@ -447,6 +453,7 @@ def lm_workload(name, args, env, steps, warmup, headline):
         peak = PEAK_FP64_MFMA_TFLOPS if v['bound'] == 'mfma' else HBM_PEAK / 1e9
         ach = work / (v['ms'] * 1e-3) / (1e12 if v['bound'] == 'mfma' else 1e9)
         line = {'workload': workload_label(name, N, P, block, dense_prior, world), 'ms_per_step': 1e3 * elapsed / steps,
+                'ms_per_step_of_every_timed_region': [1e3 * e / steps for e, _ in regions],
                 'value': steps / elapsed, 'unit': 'LM steps/s', 'steps': steps, 'warmup': warmup,
                 'restarts_in_timed_region': state['reinits'], 'setup_s': round(t_setup, 3), 'generate_s': round(t_generate, 3),
                 'phases_ms_per_call': phases, 'phases_calls': calls,
