@@ -17,6 +17,18 @@ import time
 import numpy as np
 
 
+class _Factor:
+    """a large block's Cholesky factor standing in for W = inv(L): ``W @ v`` is a triangular solve"""
+
+    def __init__(self, L):
+        self.L = L
+        self.shape = L.shape
+
+    def __matmul__(self, v):
+        import scipy.linalg as sla
+        return sla.solve_triangular(self.L, v, lower=True)
+
+
 class CosmixPort:
     def __init__(self, d):
         import scipy.linalg as sla
@@ -33,7 +45,9 @@ class CosmixPort:
         for r0, cov in blocks:
             L = sla.cholesky(cov, lower=True)
             self._ld.append(2.0 * float(np.sum(np.log(np.diag(L)))))
-            self.Ws.append((int(r0), sla.solve_triangular(L, np.eye(cov.shape[0]), lower=True)))
+            # W_b = inv(L) explicitly for the blocks whitened inside a pool task (small GEMMs); a LARGE block keeps its factor
+            # and is whitened by a triangular solve (an 8192^3 explicit inverse would cost more than the fit's iterations)
+            self.Ws.append((int(r0), sla.solve_triangular(L, np.eye(cov.shape[0]), lower=True) if cov.shape[0] <= 1024 else _Factor(L)))
         inblk = np.zeros(self.N, bool)
         for r0, W in self.Ws:
             inblk[r0:r0 + W.shape[0]] = True
