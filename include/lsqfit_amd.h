@@ -510,6 +510,10 @@ int lsqamd_debug_throw(lsqamd_fit *fit, int32_t kind);
  * result of the eager copy + synchronise, the value it delivered (42). */
 int lsqamd_debug_capture_selftest(void *stream, int32_t *report);
 int lsqamd_debug_per_device_once(int32_t dev, int32_t reset);
+/* the work list of the J^T J launch as the library builds it (host arithmetic; tests/test_abi.py): entries (tile row, tile
+ * column, K-split, exchange group or 0) in launch order -- workgroup b takes entry  run_start(b % 8) + b / 8  of eight
+ * contiguous runs.  G = 0: the plain list; G >= 1: rows[G + 1] tile-row bounds of the exchange groups, count[G] filled. */
+int64_t lsqamd_debug_syrk_work(int64_t n_param, int32_t splits, int32_t n_groups, const int32_t *rows, int32_t *out4, int32_t *count);
 /* The process-wide cache of compiled formulas (lsqamd_set_tape compiles with hiprtc and keeps the loaded code object):
  * out3[0] = kernels loaded now, out3[1] = of those, held by a live handle, out3[2] = kernels unloaded so far.  At most
  * LSQAMD_JIT_CACHE_CAP (default 1024) stay loaded; beyond that the ones no handle holds go, least recently used first. */

@@ -135,6 +135,7 @@ PROTOTYPES = {
     'lsqamd_handoff_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_debug_throw': (C.c_int, [_vp, C.c_int32]),
     'lsqamd_debug_capture_selftest': (C.c_int, [_vp, C.POINTER(C.c_int32)]),
+    'lsqamd_debug_syrk_work': (C.c_int64, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     'lsqamd_debug_per_device_once': (C.c_int, [C.c_int32, C.c_int32]),
     'lsqamd_jit_cache_stats': (C.c_int, [C.POINTER(C.c_int64)]),
     'lsqamd_debug_set_potf2_stamps': (None, [_vp]),

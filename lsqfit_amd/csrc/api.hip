@@ -401,6 +401,7 @@ size_t carve(lsqamd_fit *f, void *ws, size_t cap, bool dry) {
   f->syrk_nwork = (int32_t)syrk_work_count(P, f->splits);
   f->syrk_map = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);
   f->syrk_map_g = cv.take<int32_t>(4 * (int64_t)f->syrk_nwork);   // the same entries grouped by tile rows (grouped exchange)
+  f->xg_ctr = cv.take<int32_t>(16);
   return cv.off;
 }
 
@@ -795,6 +796,53 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
       if (!f->xg_done[q]) f->xg_done[q] = event_take();
     }
     if (!f->xst) FAIL(f, LSQAMD_EHIP, "no stream for the grouped exchange");
+    if (f->xg_signal) {
+      // ONE product launch; the exchange stream follows it group by group through the counters
+      HIPCHK(f, hipMemsetAsync(f->xg_ctr, 0, 8 * sizeof(int32_t), f->st));
+      HIPCHK(f, hipEventRecord(f->xg_ready[0], f->st));          // "the counters are zero": nothing on xst reads them earlier
+      HIPCHK(f, hipStreamWaitEvent(f->xst, f->xg_ready[0], 0));
+      {
+        Scope sc(f, LSQAMD_T_SYRK);
+        GemmTN gq = g;
+        gq.work_map = f->syrk_map_g;
+        gq.n_work = f->syrk_nwork;
+        static const bool dbg_nosig = [] { const char *e = getenv("LSQAMD_EXCHANGE_DEBUG"); return e && e[0] == 'n'; }();   // developer knob: the grouped ORDER with the plain kernel
+        gq.done_ctr = dbg_nosig ? nullptr : f->xg_ctr;
+        HIPCHK(f, launch_gemm_tn(f->st, gq));
+      }
+      {
+        Scope sc(f, LSQAMD_T_GRAD);
+        rc = finish_gvec();
+        if (rc) return rc;
+      }
+      HIPCHK(f, hipEventRecord(f->xg_ready[1], f->st));          // "[J^T f | chi2] is final" (goes out with the last group)
+      static const int dbg_seq = [] { const char *e = getenv("LSQAMD_EXCHANGE_DEBUG"); return e ? (e[0] == 's' ? 1 : (e[0] == 'n' ? 2 : 0)) : 0; }();   // developer knob: nothing on the exchange stream before the product is done
+      if (dbg_seq) HIPCHK(f, hipStreamWaitEvent(f->xst, f->xg_ready[1], 0));
+      for (int q = 0; q < f->xg; ++q) {
+        const bool last = q == f->xg - 1;
+        if (dbg_seq != 2) HIPCHK(f, launch_wait_counter(f->xst, f->xg_ctr + q, f->xg_count[q], f->xg_ctr + 8));
+        {
+          Scope sc(f, LSQAMD_T_GRAD, f->xst);
+          HIPCHK(f, launch_finalize_pack(f->xst, f->slabs, f->splits, P * f->ldm, P, f->ldm, f->redbuf,
+                                         with_prior ? f->prior_prec : nullptr, f->cfg.prior_dense, f->xg_tile[q],
+                                         f->xg_tile[q + 1] - f->xg_tile[q]));
+        }
+        if (last) HIPCHK(f, hipStreamWaitEvent(f->xst, f->xg_ready[1], 0));
+        {
+          Scope sc(f, LSQAMD_T_EXCH_COLL, f->xst);
+          const int64_t off = f->xg_tile[q] * 128 * 128;
+          const int64_t cnt = (last ? f->npk + P + 1 : f->xg_tile[q + 1] * 128 * 128) - off;
+          rc = comm_all_reduce_on(f, f->xst, f->redbuf + off, cnt);
+          if (rc) return rc;
+        }
+        HIPCHK(f, hipEventRecord(f->xg_done[q], f->xst));
+      }
+      {
+        Scope sc(f, LSQAMD_T_REDUCE);
+        Scope sc2(f, LSQAMD_T_EXCH_WAIT);
+        for (int q = 0; q < f->xg; ++q) HIPCHK(f, hipStreamWaitEvent(f->st, f->xg_done[q], 0));
+      }
+    } else {
     for (int q = 0; q < f->xg; ++q) {
       const bool last = q == f->xg - 1;
       {
@@ -829,6 +877,7 @@ int eval_normal_dev(lsqamd_fit *f, const double *p, bool mirror) {
       Scope sc(f, LSQAMD_T_REDUCE);
       Scope sc2(f, LSQAMD_T_EXCH_WAIT);
       for (int q = 0; q < f->xg; ++q) HIPCHK(f, hipStreamWaitEvent(f->st, f->xg_done[q], 0));
+    }
     }
   } else {
     {
@@ -2008,18 +2057,39 @@ int lsqamd_create(const lsqamd_config *cfg, void *dev_workspace, size_t workspac
         const double want = (1.0 - tail) * g / (G - 1) * (double)total;
         while (row < T - (G - g) && (double)(tiles + (T - row) / 2) < want) { tiles += T - row; ++row; }
         if (row <= f->xg_row[g - 1]) { tiles += T - row; ++row; }      // every group holds at least one tile row
+        // the work list walks 8 x 8 PATCHES of tiles (two row panels serve eight tiles each way in the L2): a group
+        // boundary inside a patch row leaves 1 x 8 slivers on both sides -- measured + 5 % on the product at the shard
+        // shape.  Snap to the nearest multiple of 8 tile rows where that keeps the groups distinct
+        if (T >= 16) {
+          int snapped = (row + 4) / 8 * 8;
+          if (snapped <= f->xg_row[g - 1]) snapped = f->xg_row[g - 1] + 8;
+          if (snapped > f->xg_row[g - 1] && snapped <= T - (G - g)) {
+            while (row < snapped) { tiles += T - row; ++row; }
+            while (row > snapped) { --row; tiles -= T - row; }
+          }
+        }
         f->xg_row[g] = row;
       }
       f->xg_row[G] = T;
+      const char *mode = getenv("LSQAMD_EXCHANGE_MODE");
+      f->xg_signal = !(mode && mode[0] == 's' && mode[1] == 'p');          // "split": one product launch per group
       int64_t o = 0;
       for (int g = 0; g < G; ++g) {
-        f->xg_work[g] = (int32_t)o;
         const int r0 = f->xg_row[g];
         f->xg_tile[g] = (int64_t)r0 * T - (int64_t)r0 * (r0 - 1) / 2;
-        o += syrk_work_fill_rows(f->P, f->splits, r0, f->xg_row[g + 1], wm.data() + 4 * o);
       }
-      f->xg_work[G] = (int32_t)o;
       f->xg_tile[G] = total;
+      if (f->xg_signal) {
+        syrk_work_fill_grouped(f->P, f->splits, G, f->xg_row, wm.data(), f->xg_count);
+        for (int g = 0; g < G; ++g) o += f->xg_count[g];
+        if (hipMemsetAsync(f->xg_ctr, 0, 16 * sizeof(int32_t), f->st) != hipSuccess) { delete f; return LSQAMD_EHIP; }
+      } else {
+        for (int g = 0; g < G; ++g) {
+          f->xg_work[g] = (int32_t)o;
+          o += syrk_work_fill_rows(f->P, f->splits, f->xg_row[g], f->xg_row[g + 1], wm.data() + 4 * o);
+        }
+        f->xg_work[G] = (int32_t)o;
+      }
       if (o != f->syrk_nwork || up(f->syrk_map_g, wm.data(), wm.size() * sizeof(int32_t)) != hipSuccess || up.finish() != hipSuccess) {
         delete f;
         return LSQAMD_EHIP;
@@ -2458,6 +2528,12 @@ int lsqamd_finish(lsqamd_fit *f, lsqamd_summary *out) try {
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_finish before lsqamd_init");
   const int rc = do_covariance(f);
   if (f->timing) resolve_timers(f);
+  if (f->comm && f->xg > 1 && f->xg_signal) {     // did a wait of the grouped exchange give up? (bounded spin: never a hang)
+    int32_t to = 0;
+    HIPCHK(f, hipMemcpyAsync(&to, f->xg_ctr + 8, sizeof to, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    if (to) FAIL(f, LSQAMD_EREDUCE, "grouped exchange: the wait for a group of J^T J tiles timed out (the sums of this fit are not to be trusted)");
+  }
   fill_summary(f, out, 0, 0);
   if (out) out->cov_status = rc == LSQAMD_ENOTPD ? rc : (rc == 0 && f->cov_inaccurate ? LSQAMD_EINACCURATE : (rc == 0 ? f->cov_dropped : 0));
   return rc == LSQAMD_ENOTPD ? 0 : rc;
@@ -2715,6 +2791,12 @@ int lsqamd_run(lsqamd_fit *f, const double *p0, lsqamd_summary *out) try {
     (void)hipEventElapsedTime(&ms, ev.a, ev.b);
   }
   if (f->timing) resolve_timers(f);
+  if (f->comm && f->xg > 1 && f->xg_signal) {     // did a wait of the grouped exchange give up? (bounded spin: never a hang)
+    int32_t to = 0;
+    HIPCHK(f, hipMemcpyAsync(&to, f->xg_ctr + 8, sizeof to, hipMemcpyDeviceToHost, f->st));
+    HIPCHK(f, hipStreamSynchronize(f->st));
+    if (to) FAIL(f, LSQAMD_EREDUCE, "grouped exchange: the wait for a group of J^T J tiles timed out (the sums of this fit are not to be trusted)");
+  }
   fill_summary(f, out, status, info);
   if (out) {
     out->t_run_ms = ms;
@@ -3187,6 +3269,19 @@ int lsqamd_debug_capture_selftest(void *stream, int32_t *report) try {
   (void)hipFree(dev2);
   return 0;
 } LSQAMD_ABI_CATCH(return lsqamd::abi_exception(nullptr);)
+
+// the work lists of the J^T J launch (host arithmetic only): G == 0: the plain list; G >= 1: the list of the grouped exchange
+// in group-major order inside every XCD run (rows[G + 1] = tile-row bounds, count[G] = entries per group).  -> entries
+int64_t lsqamd_debug_syrk_work(int64_t P, int32_t splits, int32_t G, const int32_t *rows, int32_t *out4, int32_t *count) try {
+  if (P < 1 || splits < 1 || !out4) return -1;
+  if (G <= 0) {
+    syrk_work_fill(P, splits, out4);
+    return syrk_work_count(P, splits);
+  }
+  if (!rows || !count || G > 8) return -1;
+  syrk_work_fill_grouped(P, splits, G, rows, out4, count);
+  return syrk_work_count(P, splits);
+} LSQAMD_ABI_CATCH((void)lsqamd::abi_exception(nullptr); return 0;)
 
 int lsqamd_debug_per_device_once(int32_t dev, int32_t reset) try {
   // how often has the "set the kernel attributes" action of a PerDeviceOnce run for device `dev`?  (the bookkeeping that

@@ -149,6 +149,9 @@ struct GemmTN {
   // X[k][colsum_rcol]^2 -- formed by the diagonal tiles' workgroups from the rows they stage anyway.
   double *colsum_out = nullptr;
   int64_t colsum_ld = 0, colsum_rcol = 0;
+  // work-list launches: the list's 4th word is the entry's exchange group (1-based, syrk_work_fill_grouped); the workgroup
+  // that completes an entry adds one to done_ctr[group - 1] (release) -- see launch_wait_counter
+  int32_t *done_ctr = nullptr;
 };
 // true when launch_gemm_tn would take the kernel that honours colsum_out for this call
 bool gemm_tn_fuses_colsum(const GemmTN &g);
@@ -172,6 +175,10 @@ hipError_t launch_whiten_synth(hipStream_t st, const WhitenSynth &a);
 int64_t syrk_work_count(int64_t P, int32_t splits);
 void syrk_work_fill(int64_t P, int32_t splits, int32_t *out);
 int64_t syrk_work_fill_rows(int64_t P, int32_t splits, int row0, int row1, int32_t *out);   // tile rows [row0, row1) only
+// one list whose entries complete group by group (rows[g] .. rows[g + 1] = tile rows of group g; 4th word = group + 1)
+void syrk_work_fill_grouped(int64_t P, int32_t splits, int G, const int32_t *rows, int32_t *out, int32_t *count);
+// a one-wave kernel on `st` that returns when *ctr >= expect (acquire; bounded: *timed_out = 1 after ~4 s)
+hipError_t launch_wait_counter(hipStream_t st, const int32_t *ctr, int32_t expect, int32_t *timed_out);
 
 // ---- Cholesky family (chol.hip) ---------------------------------------------------
 constexpr int CHOL_NB = 128;

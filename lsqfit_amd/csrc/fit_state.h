@@ -109,7 +109,13 @@ struct lsqamd_fit {
   int32_t xg_row[9] = {0};         // tile rows [xg_row[g], xg_row[g + 1]) of group g
   int32_t xg_work[9] = {0};        // its entries in syrk_map_g: [xg_work[g], xg_work[g + 1])
   int64_t xg_tile[9] = {0};        // its packed tiles: [xg_tile[g], xg_tile[g + 1])
-  int32_t *syrk_map_g = nullptr;   // the groups' work lists, one after the other (device)
+  int32_t *syrk_map_g = nullptr;   // the groups' work lists, one after the other (device); xg_signal: ONE list in group-major order
+  // xg_signal (LSQAMD_EXCHANGE_MODE=signal, the default for G > 1): ONE product launch whose workgroups count a group's
+  // finished entries in xg_ctr[g] (release); the exchange stream waits for the count with a one-wave kernel, then packs and
+  // exchanges the group -- no split launches.  LSQAMD_EXCHANGE_MODE=split: one product launch per group (round 6's first form)
+  bool xg_signal = false;
+  int32_t *xg_ctr = nullptr;       // device: [0..8) the counters, [8] "a wait timed out" (sticky)
+  int32_t xg_count[8] = {0};       // entries per group
   hipStream_t xst = nullptr;       // exchange stream (taken at the first grouped exchange, given back with the handle)
   hipEvent_t xg_ready[8] = {nullptr}, xg_done[8] = {nullptr};
 

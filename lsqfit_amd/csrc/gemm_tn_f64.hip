@@ -67,6 +67,7 @@ struct GemmDev {
   const int32_t *batch_active;  // optional: skip batch entries whose flag is 0
   double *colsum_out;           // optional (XTRI interior kernel): fused column sums, see GemmTN
   int64_t colsum_ld, colsum_rcol;
+  int32_t *done_ctr;            // optional (WORKMAP + SIGNAL): done_ctr[group - 1] += 1 when an entry whose 4th word is `group` is complete
 };
 
 // Branch-free staging loads.  Out-of-range rows/columns are CLAMPED to a valid
@@ -261,13 +262,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_kernel(GemmDev g) {
 // that are in LDS anyway, so the gradient costs no second pass over J.  The residual column's 16 values of a
 // stage land in the (unused) Y half of the stage buffer; column rcol itself gets sum_k X[k][rcol]^2 from tile 0.
 // colsum_out[(b * splits + split) * colsum_ld + m]: per-split partials, summed in split order by the caller.
-template <bool XTRI, bool WORKMAP, bool CS = false>
+// SIGNAL (with WORKMAP): the work list's 4th word names the entry's exchange group (1-based); when the entry's tile is in its
+// slab the workgroup adds one to done_ctr[group - 1] with release semantics -- a one-wave kernel on another stream of the
+// handle waits for the count of a group's entries (api.hip: the grouped exchange without splitting this launch).
+template <bool XTRI, bool WORKMAP, bool CS = false, bool SIGNAL = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   int tm, tn, split;
+  int sig_group = 0;
 #ifdef LSQAMD_SYRK_STAMPS
   const unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime();
   int stamp_w = -1;
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
 #endif
     const int4 e = reinterpret_cast<const int4 *>(g.work_map)[w];
     tm = e.x; tn = e.y; split = e.z;
+    if (SIGNAL) sig_group = e.w;
   } else if (XTRI && g.xcd_groups) {
     // Workgroup b runs on XCD b % 8.  With the tile column as the fastest index (and 8 of them) every XCD would own ONE
     // tile column and read ALL of X for it -- config 3's triangular whitening matrix went past the L2 eight times (L2 hit
@@ -509,6 +515,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_f64_interior_kernel(GemmDev g)
     }
   }
   }  // pass
+  if (SIGNAL && WORKMAP && sig_group > 0 && g.done_ctr) {
+    // the guide's counter hand-off (cdna_hip_programming.md 6 G16 / 5.x "in-launch split-K reduction"): every wave drains its
+    // own stores, barrier, ONE lane issues the agent-scope release (buffer_wbl2: this XCD's L2 is not coherent with the one
+    // the consumer kernel will read through), waits for it, then counts with a RELAXED add.  NOT __threadfence() in every
+    // thread: that is a write-back AND an invalidate per thread -- it cost the product 6 % (the panels' L2 lines went with it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_fetch_add(g.done_ctr + (sig_group - 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 #ifdef LSQAMD_SYRK_STAMPS
   if (WORKMAP && g_syrk_stamps && tid == 0) {
     __builtin_amdgcn_s_waitcnt(0);
@@ -914,7 +933,9 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
                            reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, false>),
                            reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true>),
                            reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<true, false>),
-                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, true>)};
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, true>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, false, true>),
+                           reinterpret_cast<const void *>(gemm_tn_f64_interior_kernel<false, true, true, true>)};
       for (const void *fn : fns) {
         const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_BYTES);
         if (e != hipSuccess) return e;
@@ -956,6 +977,7 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   g.colsum_out = a.colsum_out;
   g.colsum_ld = a.colsum_ld;
   g.colsum_rcol = a.colsum_rcol;
+  g.done_ctr = a.work_map ? a.done_ctr : nullptr;
   dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)g.splits, (unsigned)(a.batch < 1 ? 1 : a.batch));
   if (a.work_map) grid = dim3((unsigned)a.n_work, 1, (unsigned)(a.batch < 1 ? 1 : a.batch));
   const bool interior = g.vec_x && g.vec_y && (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) &&
@@ -1035,8 +1057,11 @@ hipError_t launch_gemm_tn(hipStream_t st, const GemmTN &a) {
   }
   else if (interior && a.work_map && a.colsum_out) {
     if (!g.syrk_diag || !a.upper_only) return hipErrorInvalidValue;   // (callers ask gemm_tn_fuses_colsum first)
-    hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
+    if (g.done_ctr) hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true, true, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
+    else hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   }
+  else if (interior && a.work_map && g.done_ctr)
+    hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true, false, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (interior && a.work_map)
     hipLaunchKernelGGL((gemm_tn_f64_interior_kernel<false, true>), grid, dim3(256), GEMM_LDS_BYTES, st, g);
   else if (interior)
@@ -1095,6 +1120,93 @@ int64_t syrk_work_fill_rows(int64_t P, int32_t splits, int row0, int row1, int32
         }
   }
   return nw;
+}
+
+// ONE list for ONE launch whose entries finish group by group: every XCD's run of the list (the kernel's blockIdx -> entry
+// map: eight contiguous runs) holds its share of group 0 first, then of group 1, ... -- so all of group 0's tiles are in their
+// slabs when about count[0] / total of the launch has run, and their exchange can start while the rest is computed.
+// rows[g] .. rows[g + 1]: the tile rows of group g.  The 4th word of an entry is its group + 1; count[g] = entries of group g.
+void syrk_work_fill_grouped(int64_t P, int32_t splits, int G, const int32_t *rows, int32_t *out, int32_t *count) {
+  const int64_t nw = syrk_work_count(P, splits), q = nw / 8, r = nw % 8;
+  std::vector<std::vector<int32_t>> lists((size_t)G);
+  for (int g = 0; g < G; ++g) {
+    lists[(size_t)g].resize(4 * (size_t)nw);
+    // (rows-only fill WITHOUT its per-XCD diagonal-last pass: that pass is applied per (XCD run, group) segment below)
+    const int T = (int)((P + BM - 1) / BM), PS = 8, NP = (T + PS - 1) / PS;
+    int64_t o = 0;
+    int32_t *L = lists[(size_t)g].data();
+    for (int s = 0; s < (splits < 1 ? 1 : splits); ++s)
+      for (int pi = 0; pi < NP; ++pi)
+        for (int pj = pi; pj < NP; ++pj)
+          for (int tm = pi * PS; tm < (pi + 1) * PS && tm < T; ++tm) {
+            if (tm < rows[g] || tm >= rows[g + 1]) continue;
+            for (int tn = pj * PS; tn < (pj + 1) * PS && tn < T; ++tn) {
+              if (tn < tm) continue;
+              L[o++] = tm; L[o++] = tn; L[o++] = s; L[o++] = g + 1;
+            }
+          }
+    lists[(size_t)g].resize((size_t)o);
+    count[g] = (int32_t)(o / 4);
+  }
+  // shares: group g gives XCD x  c[g][x] entries, sum_x = count[g], sum_g = the run length the kernel computes for x
+  std::vector<int64_t> cap(8), pos((size_t)G, 0);
+  for (int x = 0; x < 8; ++x) cap[(size_t)x] = q + (x < r ? 1 : 0);
+  std::vector<std::vector<int64_t>> c((size_t)G, std::vector<int64_t>(8, 0));
+  for (int g = 0; g < G; ++g) {
+    if (g == G - 1) {
+      for (int x = 0; x < 8; ++x) c[(size_t)g][(size_t)x] = cap[(size_t)x];
+      break;
+    }
+    int64_t left = count[g];
+    for (int x = 0; x < 8; ++x) {
+      int64_t v = count[g] / 8;
+      if (v > cap[(size_t)x]) v = cap[(size_t)x];
+      c[(size_t)g][(size_t)x] = v;
+      cap[(size_t)x] -= v;
+      left -= v;
+    }
+    while (left > 0) {            // the remainder to the runs with the most room
+      int best = 0;
+      for (int x = 1; x < 8; ++x)
+        if (cap[(size_t)x] > cap[(size_t)best]) best = x;
+      c[(size_t)g][(size_t)best]++;
+      cap[(size_t)best]--;
+      --left;
+    }
+  }
+  int64_t w = 0;
+  for (int x = 0; x < 8; ++x)
+    for (int g = 0; g < G; ++g) {
+      const int32_t *L = lists[(size_t)g].data() + 4 * pos[(size_t)g];
+      const int64_t n = c[(size_t)g][(size_t)x];
+      for (int keep = 0; keep < 2; ++keep)          // stable: off-diagonal entries, then diagonal ones
+        for (int64_t e = 0; e < n; ++e)
+          if ((L[4 * e] == L[4 * e + 1]) == (keep == 1)) {
+            for (int k = 0; k < 4; ++k) out[4 * w + k] = L[4 * e + k];
+            ++w;
+          }
+      pos[(size_t)g] += n;
+    }
+}
+
+// one wave waits until *ctr >= expect (acquire); gives up after ~4 s of wall clock and says so in *timed_out
+__global__ __launch_bounds__(64) void wait_counter_kernel(const int32_t *ctr, int32_t expect, int32_t *timed_out) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();     // 100 MHz
+  // poll RELAXED (an acquire per poll would invalidate this CU's L1 -- and cost the product beside it -- every time); the
+  // kernels queued behind this one on the stream start with clean caches: the kernel boundary is their acquire
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
+    __builtin_amdgcn_s_sleep(64);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+      __hip_atomic_store(timed_out, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+
+hipError_t launch_wait_counter(hipStream_t st, const int32_t *ctr, int32_t expect, int32_t *timed_out) {
+  hipLaunchKernelGGL(wait_counter_kernel, dim3(1), dim3(64), 0, st, ctr, expect, timed_out);
+  return hipGetLastError();
 }
 
 // ---- whitening product with the raw Jacobian rows synthesised in LDS ---------------------------------

@@ -164,6 +164,43 @@ def test_kernel_attribute_bookkeeping_is_per_device(libpath):
         assert not re.search(r'static bool [a-z_]*attr', src), path
 
 
+def test_grouped_work_list_of_the_exchange(libpath):
+    """The J^T J launch of the grouped exchange: ONE list, every (tile, K-split) of the upper triangle exactly
+    once, each XCD's run of the list in group-major order (so that a group's tiles are complete when that share of the launch
+    has run), the runs as long as the kernel's blockIdx -> entry map assumes, diagonal tiles last inside a (run, group)."""
+    import numpy as np
+    from lsqfit_amd import _lib
+    lib = _lib.load()
+    ip = ctypes.POINTER(ctypes.c_int32)
+    for P, splits, rows in ((4096, 4, [0, 5, 12, 32]), (4096, 16, [0, 9, 32]), (1024, 3, [0, 1, 2, 4, 8]), (384, 2, [0, 1, 3])):
+        T = (P + 127) // 128
+        G = len(rows) - 1
+        nw = T * (T + 1) // 2 * splits
+        plain = np.zeros((nw, 4), np.int32)
+        assert lib.lsqamd_debug_syrk_work(P, splits, 0, None, plain.ctypes.data_as(ip), None) == nw
+        out = np.full((nw, 4), -1, np.int32)
+        count = np.zeros(G, np.int32)
+        r = np.array(rows, np.int32)
+        assert lib.lsqamd_debug_syrk_work(P, splits, G, r.ctypes.data_as(ip), out.ctypes.data_as(ip), count.ctypes.data_as(ip)) == nw
+        key = lambda a: sorted(map(tuple, a[:, :3].tolist()))
+        assert key(out) == key(plain) and len(set(map(tuple, out[:, :3].tolist()))) == nw          # a permutation of the plain list
+        grp = out[:, 3] - 1
+        assert np.all((out[:, 0] >= r[grp]) & (out[:, 0] < r[grp + 1]))                             # the group IS the tile row's group
+        assert list(count) == [int(np.sum(grp == g)) for g in range(G)] and count.sum() == nw
+        q, rem = divmod(nw, 8)
+        start = 0
+        for x in range(8):
+            n = q + (1 if x < rem else 0)
+            run = out[start:start + n]
+            assert np.all(np.diff(run[:, 3]) >= 0)                                                  # group-major inside the run
+            for g in range(G):
+                seg = run[run[:, 3] == g + 1]
+                diag = (seg[:, 0] == seg[:, 1]).astype(int)
+                assert np.all(np.diff(diag) >= 0)                                                   # diagonal tiles last
+                assert abs(len(seg) - count[g] / 8) <= G + 1                                        # an even share of every group
+            start += n
+
+
 def test_no_cpu_fallback():
     """Without a GPU the product refuses to fit (it must never route through the oracle)."""
     import torch

@@ -48,7 +48,8 @@ def _one(rank, world, outdir, case, fake, algo, missing):
     # algo = 'rsag' | 'allreduce' | 'rsag.gG': the last form asks for the exchange in G groups of tile rows on the handle's
     # exchange stream (LSQAMD_EXCHANGE_GROUPS, read at lsqamd_create)
     os.environ['LSQAMD_COMM_ALGO'] = algo.split('.')[0]
-    os.environ['LSQAMD_EXCHANGE_GROUPS'] = algo.split('.g')[1] if '.g' in algo else '1'
+    os.environ['LSQAMD_EXCHANGE_GROUPS'] = algo.split('.g')[1].rstrip('s') if '.g' in algo else '1'
+    os.environ['LSQAMD_EXCHANGE_MODE'] = 'split' if algo.endswith('s') and '.g' in algo else 'signal'
     tag = '%s_%s' % (case, algo)
     d = _problem(case)
     wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
@@ -106,9 +107,10 @@ def _worker(rank, world, outdir, jobs, fake, missing):
         _one(rank, world, outdir, case, fake, algo, missing)
 
 
-JOBS = {2: [('blocks', 'rsag'), ('blocks', 'allreduce'), ('blocks', 'rsag.g2')],
-        3: [('blocks', 'rsag'), ('small', 'rsag'), ('blocks', 'rsag.g3'), ('small', 'rsag.g2')],
-        8: [('eight', 'rsag'), ('small8', 'rsag'), ('c4_packed', 'rsag'), ('eight', 'rsag.g2'), ('c4_packed', 'rsag.g4')]}
+# 'rsag.gG': G groups signalled out of ONE product launch (the default form); 'rsag.gGs': one product launch per group
+JOBS = {2: [('blocks', 'rsag'), ('blocks', 'allreduce'), ('blocks', 'rsag.g2'), ('blocks', 'rsag.g2s')],
+        3: [('blocks', 'rsag'), ('small', 'rsag'), ('blocks', 'rsag.g3'), ('small', 'rsag.g2'), ('blocks', 'rsag.g3s')],
+        8: [('eight', 'rsag'), ('small8', 'rsag'), ('c4_packed', 'rsag'), ('eight', 'rsag.g2'), ('c4_packed', 'rsag.g4'), ('c4_packed', 'rsag.g4s')]}
 
 
 def _spawn(world, outdir, jobs, fake, missing=False, nstart=None):
@@ -175,15 +177,18 @@ def test_rsag_and_allreduce_forms_agree_bit_for_bit(runs):
         assert np.array_equal(a[0][k], b[0][k]), k
 
 
-@pytest.mark.parametrize('case,world,groups', [('blocks', 2, 2), ('blocks', 3, 3), ('small', 3, 2), ('eight', 8, 2), ('c4_packed', 8, 4)])
+@pytest.mark.parametrize('case,world,groups', [('blocks', 2, '2'), ('blocks', 2, '2s'), ('blocks', 3, '3'), ('blocks', 3, '3s'), ('small', 3, '2'),
+                                               ('eight', 8, '2'), ('c4_packed', 8, '4'), ('c4_packed', 8, '4s')])
 def test_grouped_exchange_is_bit_identical(case, world, groups, runs):
-    """LSQAMD_EXCHANGE_GROUPS = G: the J^T J launch cut into G groups of tile rows, group g's packed tiles summed over the ranks
-    on the handle's exchange stream (event-ordered) while group g + 1 is computed, the step's stream waiting for the last
-    event before the damped matrix is built (api.hip eval_normal_dev).  Every element is still the same sum of the same split-K
+    """LSQAMD_EXCHANGE_GROUPS = G: the J^T J tiles in G groups of tile rows, group g's packed tiles summed over the ranks
+    on the handle's exchange stream while the rest of the product is computed, the step's stream waiting for the last
+    event before the damped matrix is built (api.hip eval_normal_dev).  Two forms: ONE product launch whose workgroups count
+    a group's finished entries, a one-wave kernel on the exchange stream waiting for the count ('G', the default); one
+    product launch per group ('Gs', LSQAMD_EXCHANGE_MODE=split).  Every element is still the same sum of the same split-K
     slabs and the stand-in sums ranks in rank order whatever the slice: fits must be the same BITS as with one exchange, on
     every rank; one exposed wait per Jacobian in the `reduce` timer.  ('small': P = 30 is one tile -- the request is ignored.)"""
     a = _results(runs, world, case, 'rsag')
-    b = _results(runs, world, case, 'rsag.g%d' % groups)
+    b = _results(runs, world, case, 'rsag.g%s' % groups)
     for r in b:
         assert int(r['reduces']) == int(r['expect'])
         for k in ('pmean', 'cov', 'chi2', 'nit', 'logGBF', 'c2'):
