@@ -1456,6 +1456,8 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
   if (!exec) {
     if (f->step_seen[par][which]++ == 0) return enqueue(f);      // warm-up: one-time attribute calls happen here
     const int64_t njev0 = f->njev;
+    static const bool diag_capture = getenv("LSQAMD_FIT_DIAG") != nullptr;       // developer knob: how long do captures take?
+    const auto tc0 = std::chrono::steady_clock::now();
     hipError_t e = hipStreamBeginCapture(f->st, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) {
       (void)hipGetLastError();
@@ -1479,6 +1481,9 @@ static int run_half(lsqamd_fit *f, int which, int (*enqueue)(lsqamd_fit *)) {
       return enqueue(f);
     }
     (void)hipGraphDestroy(gr);
+    if (diag_capture)
+      fprintf(stderr, "lsqamd: captured + instantiated half-step graph [parity %d][%s] of handle %p in %.2f ms\n", par, which ? "accept" : "trial",
+              (void *)f, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
   }
   HIPCHK(f, hipGraphLaunch(exec, f->st));
   f->graph_launches++;
