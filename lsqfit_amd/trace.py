@@ -943,6 +943,20 @@ def _signature(t):
     return ('S',) + tuple(_signature(x) for x in t[1])
 
 
+def _signature_any_parameter(t):
+    """the formula's shape with the parameter INDICES left out: rows that differ only in which parameter they read"""
+    k = t[0]
+    if k == 'P':
+        return 'P'
+    if k == 'D':
+        return 'D'
+    if k == 'U':
+        return ('U', t[1], _signature_any_parameter(t[2]))
+    if k == 'B':
+        return ('B', t[1], _signature_any_parameter(t[2]), _signature_any_parameter(t[3]))
+    return ('S',) + tuple(_signature_any_parameter(x) for x in t[1])
+
+
 def _rebuild(t, it):
     k = t[0]
     if k == 'P' or k == 'D':
@@ -1147,17 +1161,21 @@ def _count_nodes(t):
     return len(t[1]) + sum(_count_nodes(x) for x in t[1])
 
 
-def programs_of(flat):
+def programs_of(flat, many=None):
     """one 1-d traced array -> ([(row0, row1, tree)], N): the resolved expression of every contiguous range of rows that
     shares one formula (same operations, same parameters; constants may differ row by row).  Rows that read DIFFERENT
     parameters through one expression (``p['x'][i]`` in row i -- errors in variables, examples/x-err.py; ``p['norm'][group]``)
     are different formulas, one program per contiguous run -- unless that makes more than MANY_PROGRAMS of them: then the
-    selection is written with indicator columns (_select_by_indicator) and the rows are one formula."""
+    selection is written with indicator columns (_select_by_indicator) and the rows are one formula.  ``many``: that threshold
+    (default MANY_PROGRAMS; the recorded residual of the plugin path passes 3: its P prior rows ``w_j (p_j - mean_j)`` each read
+    another parameter, and P + 1 formulas cost P + 1 run-time compilations -- 8 s for a 9-parameter fit, 27 s for
+    examples/x-err.py -- where two do)."""
+    many = MANY_PROGRAMS if many is None else many
     try:
         out, N = _programs_of(flat, False)
     except TraceError:
         return _programs_of(flat, True)
-    if len(out) > MANY_PROGRAMS:
+    if len(out) > many:
         try:
             alt, _ = _programs_of(flat, True)
         except TraceError:
@@ -1191,7 +1209,10 @@ def _programs_of(flat, by_indicator):
     for rows, t in pieces:
         if rows.size == 0:
             continue
-        sig = _signature(t)
+        # by_indicator: pieces that differ only in WHICH parameter a leaf reads (the P prior rows of a recorded residual, the
+        # rows of an errors-in-variables model assembled element by element) are one formula too -- the selection becomes
+        # 0 / 1 predictor columns below
+        sig = _signature_any_parameter(t) if by_indicator else _signature(t)
         if sig not in merged:
             merged[sig] = []
             order.append(sig)
@@ -1206,6 +1227,10 @@ def _programs_of(flat, by_indicator):
             leaf_lists = [_leaves(t, []) for _, t in lst]
             arrays = [np.concatenate([ll[i][1] for ll in leaf_lists]) for i in range(len(leaf_lists[0]))]
             t = _rebuild(lst[0][1], iter(arrays))
+            if by_indicator and any(l[0] == 'P' and l[1].size and np.any(l[1] != l[1][0]) for l in _leaves(t, [])):
+                o = np.argsort(rows, kind='stable')          # (the indicator columns are built per row: sort first)
+                rows, t = rows[o], _restrict(t, o)
+                t = _select_by_indicator(t)
         o = np.argsort(rows, kind='stable')
         if np.any(o != np.arange(o.size)):
             rows, t = rows[o], _restrict(t, o)
@@ -1303,7 +1328,7 @@ def trace_residual(f, P):
             raise
         out = f(p)
     flat, _, _ = flatten_output(out, None)
-    progs, N = programs_of(flat)
+    progs, N = programs_of(flat, many=3)
     model, X = emit_programs(progs, N, P, text='traced:residual')
     return Traced(model, X, None, [(P,)], None, [(N,)])
 

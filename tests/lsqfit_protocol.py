@@ -293,3 +293,38 @@ def x_err_example(k):
         x = p['x']
         return b0 / ((1. + gv.exp(b1 - b2 * x)) ** (1. / b3))
     return dict(fcn=fcn, x=False, ymean=ym, yerr=ys, prior_mean=prior, prior_err=np.concatenate([bs, xs]))
+
+
+def y_vs_x_example(k, nexp):
+    """examples/y-vs-x.py:20-67: array data with a dense 8 x 8 covariance whose smallest correlation eigenvalue the svdcut
+    raises (``svdcut/n = 1e-12/1``: gvar whitens that block in its eigen basis), dictionary parameters ``p['a']``, ``p['E']``,
+    the fit function a Python ``sum`` over ``zip(a, E)`` of ``ai * np.exp(-Ei * x)``."""
+    prior = BufferDict()
+    prior['a'] = np.full(nexp, 0.5)
+    prior['E'] = np.arange(1, nexp + 1.0)
+
+    def fcn(x, p):
+        a = p['a']
+        E = p['E']
+        return sum(ai * np.exp(-Ei * x) for ai, Ei in zip(a, E))
+    return dict(fcn=fcn, x=np.array(k['x']), ymean=np.array(k['ymean']), yerr=np.array(k['ycov']), prior_mean=prior,
+                prior_err=np.full(2 * nexp, 0.4))
+
+
+def nist_example(name, nist):
+    """examples/nist.py (one function per StRD problem, e.g. misra1a :102-120): ``fcn(x, b)`` unpacks ``b1, b2, ... = b`` and
+    evaluates the certified formula with gvar's functions; priors ``0 +- 200 |b|``, start 2, ``tol = 1e-10``."""
+    from tests.helpers import nist_problem
+    pr = nist_problem(name, nist)
+    cols = pr['columns'][1:]
+    code = compile(pr['expr'], '<nist:%s>' % name, 'eval')
+    ns = {'exp': gv.exp, 'log': gv.log, 'sqrt': gv.sqrt, 'sin': gv.sin, 'cos': gv.cos, 'arctan': gv.arctan, 'pi': np.pi}
+
+    def fcn(x, b):
+        env = dict(ns)
+        env.update(x if isinstance(x, dict) else {cols[0]: x})
+        for i in range(pr['P']):
+            env['b%d' % (i + 1)] = b[i]
+        return eval(code, {'__builtins__': {}}, env)
+    x = {c: pr['x'][c] for c in cols} if len(cols) > 1 else pr['x'][cols[0]]
+    return dict(fcn=fcn, x=x, ymean=pr['y'], yerr=pr['ysd'], prior_mean=pr['prior_mean'], prior_err=pr['prior_sd'], p0=pr['p0']), pr

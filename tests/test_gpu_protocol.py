@@ -72,3 +72,39 @@ def test_x_err_example_through_the_protocol(fitters):
     check_header(r, out)                                            # chi2/dof 0.35 [15], Q 0.99, logGBF -40.156
     assert [gvar_lite.fmt(m, s) for m, s in zip(r.pmean, r.psdev)] == parse_parameter_table(out)
     assert r.nit in (12, 13)                                        # x-err.out prints 13 (no reference test asserts it)
+
+
+@pytest.mark.parametrize('nexp', [2, 3])
+def test_y_vs_x_example_through_the_protocol(fitters, nexp):
+    """examples/y-vs-x.py / .out: the one reference fixture with a MODIFIED svd mode (svdcut/n = 1e-12/1: the 8 x 8 block is
+    whitened in its eigen basis, a non-triangular weight matrix inside chiv), dictionary parameters, a Python sum over
+    zip(a, E) of ai * np.exp(-Ei * x)."""
+    r, chiv, fit = _fit(fitters, lp.y_vs_x_example(KAT['y_vs_x'], nexp))
+    want_p = {2: '[0.4024(40) 0.4471(46) 0.90104(51) 1.8282(14)]',
+              3: '[0.4019(40) 0.406(14) 0.61(36) 0.90039(54) 1.8026(82) 2.83(19)]'}[nexp]
+    assert gvar_lite.fmt_array(r.pmean, r.psdev) == want_p
+    assert '%.5g' % r.logGBF == {2: '111.69', 3: '116.29'}[nexp] and r.dof == 8
+    assert '%.2g' % (r.chi2 / r.dof) == {2: '2.2', 3: '0.63'}[nexp]
+
+
+NIST = load('nist.json')
+
+
+@pytest.mark.parametrize('name', sorted(NIST))
+def test_nist_problems_through_the_protocol(fitters, name):
+    """examples/nist.py: the 27 StRD problems with their functions written as the reference writes them (b1, b2, ... = b; gvar's
+    exp / cos / arctan), handed to the plugin as lsqfit hands them over: nist.out's parameter strings (or agreement to sigma / 10,
+    the reference's own criterion, examples/nist.py:85-99), the certified values, dof, logGBF."""
+    ex, pr = lp.nist_example(name, NIST)
+    p0, nf, chiv, pdf = lp.fitter_call(**ex)
+    fit = fitters['mi355x_lm'](p0, nf, chiv, tol=pr['tol'], maxit=1000, solver='qr')      # the reference's default solver
+    r = types.SimpleNamespace(**lp.reduce(fit, pdf, p0.size))
+    got = gvar_lite.fmt_array(r.pmean, r.psdev)
+    em, es = gvar_lite.parse_array(pr['expected_p'][1:-1].split())
+    if got != pr['expected_p']:
+        assert np.all(np.abs(r.pmean - em) <= np.maximum(es, r.psdev) / 10.), (got, pr['expected_p'])
+    assert np.all(np.abs(r.pmean - pr['certified']) <= 1e-2 * pr['certified_sd'] + 1e-9 * np.abs(pr['certified']))
+    np.testing.assert_allclose(r.psdev, pr['certified_sd'], rtol=2e-3)
+    assert r.dof == pr['out']['dof'] and r.description == 'methods = lm/more/qr'
+    if name != 'lanczos1':          # (sigma_y = 8.9e-14: chi2 is roundoff, examples/nist.py:16-19)
+        assert '%.5g' % r.logGBF == pr['out']['logGBF'], (r.logGBF, pr['out']['logGBF'])

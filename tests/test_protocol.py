@@ -14,8 +14,11 @@ from tests.helpers import load
 from tests.test_trace import run_tape
 
 KAT = load('kat.json')
+NIST = load('nist.json')
 EXAMPLES = {'simple': lambda: lp.simple_example(), 'p_corr': lambda: lp.p_corr_example(KAT['p_corr']),
-            'x_err': lambda: lp.x_err_example(KAT['x_err'])}
+            'x_err': lambda: lp.x_err_example(KAT['x_err']), 'y_vs_x_3': lambda: lp.y_vs_x_example(KAT['y_vs_x'], 3),
+            'nist_misra1a': lambda: lp.nist_example('misra1a', NIST)[0], 'nist_nelson': lambda: lp.nist_example('nelson', NIST)[0],
+            'nist_roszman1': lambda: lp.nist_example('roszman1', NIST)[0], 'nist_enso': lambda: lp.nist_example('enso', NIST)[0]}
 
 
 @pytest.mark.parametrize('name', sorted(EXAMPLES))
@@ -32,7 +35,8 @@ def test_chiv_as_lsqfit_builds_it_is_recorded_faithfully(name):
         p = p0 * (1 + 0.05 * rng.standard_normal(p0.size)) + 0.01 * rng.standard_normal(p0.size)
         want = np.asarray(chiv(p), float)                 # lsqfit's float branch (src/lsqfit/_utilities.pyx:81-83)
         got = run_tape(rec.model, rec.x, p)
-        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.max(np.abs(want)))
+        # (1e-10: the eigen-whitened rows of y-vs-x's 8 x 8 block are sums of terms 1e6 times their result, in another order)
+        np.testing.assert_allclose(got, want, rtol=1e-10, atol=1e-10 * np.max(np.abs(want)))
 
 
 def test_protocol_pieces_behave_like_their_originals():
