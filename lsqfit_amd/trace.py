@@ -1167,7 +1167,7 @@ def programs_of(flat, many=None):
     parameters through one expression (``p['x'][i]`` in row i -- errors in variables, examples/x-err.py; ``p['norm'][group]``)
     are different formulas, one program per contiguous run -- unless that makes more than MANY_PROGRAMS of them: then the
     selection is written with indicator columns (_select_by_indicator) and the rows are one formula.  ``many``: that threshold
-    (default MANY_PROGRAMS; the recorded residual of the plugin path passes 3: its P prior rows ``w_j (p_j - mean_j)`` each read
+    (default MANY_PROGRAMS; the recorded residual of the plugin path passes 2: its P prior rows ``w_j (p_j - mean_j)`` each read
     another parameter, and P + 1 formulas cost P + 1 run-time compilations -- 8 s for a 9-parameter fit, 27 s for
     examples/x-err.py -- where two do)."""
     many = MANY_PROGRAMS if many is None else many
@@ -1328,7 +1328,7 @@ def trace_residual(f, P):
             raise
         out = f(p)
     flat, _, _ = flatten_output(out, None)
-    progs, N = programs_of(flat, many=3)
+    progs, N = programs_of(flat, many=2)
     model, X = emit_programs(progs, N, P, text='traced:residual')
     return Traced(model, X, None, [(P,)], None, [(N,)])
 
