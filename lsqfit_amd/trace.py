@@ -1175,7 +1175,9 @@ def programs_of(flat, many=None):
         out, N = _programs_of(flat, False)
     except TraceError:
         return _programs_of(flat, True)
-    if len(out) > many:
+    # ... or when the runs are SHORT (a parameter per row, examples/x-err.py: 15 rows, 15 formulas, 15 run-time compilations of
+    # ~0.7 s each on a cold cache against one): few rows per formula make the indicator columns cheap and the formulas dear
+    if len(out) > many or (len(out) > 2 and N < 16 * len(out)):
         try:
             alt, _ = _programs_of(flat, True)
         except TraceError:

@@ -359,13 +359,19 @@ def test_parameter_selected_row_by_row_becomes_indicator_columns():
         b0, b1, b2, b3 = p['b']
         return b0 / ((1. + np.exp(b1 - b2 * p['x'])) ** (1. / b3))
 
-    for n, nprog in ((15, 15), (600, None)):
+    for n in (15, 600):      # short runs (one row each): ONE formula whatever their number (a formula is a run-time compilation)
         pp = dict(b=np.array([1.0, 0.5, 2.0, 1.5]), x=np.linspace(1, 2, n))
         tr = amd.trace(fcn, False, pp)
-        assert (tr.model.programs is None) == (nprog is None) and (nprog is None or len(tr.model.programs) == nprog)
+        assert tr.model.programs is None
         np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), fcn(pp), rtol=1e-15)
-        if nprog is None:
-            assert tr.x.shape == (n, n) and set(np.unique(tr.x)) == {0.0, 1.0} and len(tr.model.tape) < 4 * n + 40
+        assert tr.x.shape == (n, n) and set(np.unique(tr.x)) == {0.0, 1.0} and len(tr.model.tape) < 4 * n + 40
+    # few LONG runs (three groups of 100 contiguous rows): one program per run, no indicator columns
+    xs = np.linspace(0, 1, 300)
+    g3 = np.repeat(np.arange(3), 100)
+    pp = dict(norm=np.array([2.0, 3.0, 4.0]), E=0.25)
+    tr = amd.trace(lambda x, p: p['norm'][g3] * np.exp(-p['E'] * x), xs, pp)
+    assert len(tr.model.programs) == 3 and tr.x.shape == (300, 1)
+    np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), pp['norm'][g3] * np.exp(-0.25 * xs), rtol=1e-15)
     x = np.linspace(0, 1, 1000)
     group = np.arange(1000) % 2
 
