@@ -73,6 +73,18 @@ def oracle_fit(d, solver='cholesky', tol=1e-8, svdcut=1e-12, p0=None, fcn=cosmix
                               svdcut=svdcut, jac=jac, solver=solver, maxit=maxit)
 
 
+_C3 = []
+
+
+def config3_problem():
+    """BASELINE config 3 at full size (one dense 8192 x 8192 data block, dense 1024 x 1024 prior): its generator alone takes 11 s
+    (two 8192 x 16384 x 8192 products); three tests of the default suite use it -- made once per session.  Treat as read-only."""
+    if not _C3:
+        from lsqfit_amd import synth
+        _C3.append(synth.make_cosmix(N=8192, P=1024, seed=20262, block=8192, prior_corr=True))
+    return _C3[0]
+
+
 def relmax(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))

@@ -62,7 +62,7 @@ def test_config3_full_size_dense_block_8192x1024(amd):
     import scipy.linalg as sla
     from lsqfit_amd import synth
     N, P = 8192, 1024
-    d = synth.make_cosmix(N=N, P=P, seed=20262, block=N, prior_corr=True)
+    d = gu.config3_problem()
     wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
     assert wh.nblocks == {N: 1, P: 1} and wh.nmod == 0
     pr = amd.DeviceProblem(d['model'], d['x'], wh)
@@ -102,7 +102,7 @@ def test_config3_full_size_fit_vs_oracle(amd):
     src/lsqfit/__init__.py:665-725."""
     from lsqfit_amd import synth
     N, P = 8192, 1024
-    d = synth.make_cosmix(N=N, P=P, seed=20262, block=N, prior_corr=True)
+    d = gu.config3_problem()
     p0 = d['p_true'] * (1 + 1e-6 * np.random.default_rng(3).standard_normal(P))
     fit = amd.nonlinear_fit(data=(d['x'], d['ymean'], d['yerr']), model=d['model'], prior=d['prior'], p0=p0)
     assert fit.error is None and fit.dof == N

@@ -109,7 +109,7 @@ def test_config3_setup_time(amd):
     """BASELINE.json configs[2] shape: ONE dense 8192 x 8192 data block + a dense 1024 x 1024 prior.
     The factorisations that took 24 s in LAPACK on the host run on the device."""
     from lsqfit_amd import synth
-    d = synth.make_cosmix(N=8192, P=1024, seed=20262, block=8192, prior_corr=True)
+    d = gu.config3_problem()
     amd.Whitening(d['ymean'][:256], dict(sdev=d['yerr']['sdev'][:256], blocks=[(0, d['yerr']['blocks'][0][1][:256, :256])]))  # warm-up
     t0 = time.perf_counter()
     wh = amd.Whitening(d['ymean'], d['yerr'], *d['prior'])
