@@ -29,7 +29,11 @@
  *     hipErrorStreamCaptureImplicit while a capture is open and invalidates it
  *     (the library then falls back to eager launches for that handle).  The
  *     library itself never uses the legacy stream; a NULL stream argument is
- *     accepted but then nothing is ordered against the caller's legacy-stream work;
+ *     accepted but then nothing is ordered against the caller's legacy-stream work.
+ *     A handle belongs to the device that was current at lsqamd_create: that
+ *     device must be current in the calling thread for every later call on it
+ *     (the library does not switch devices; lsqamd_init / _run / _step refuse
+ *     with LSQAMD_EINVAL otherwise); kernel attributes are kept per device;
  *   - no C++ exception crosses the boundary: std::bad_alloc comes back as
  *     LSQAMD_ENOMEM, anything else as LSQAMD_EINTERNAL (csrc/common.h
  *     LSQAMD_ABI_CATCH on every export);

@@ -187,9 +187,9 @@ hipStream_t stream_take() {
   return s;
 }
 
-void stream_give(hipStream_t s) {
+void stream_give(hipStream_t s, int dev_taken) {
   if (!s) return;
-  const int dev = current_device();
+  const int dev = dev_taken >= 0 ? dev_taken : current_device();      // (filed under the device it was created on, whichever device the calling thread has current)
   if (dev >= 0) {
     Recycler &r = recycler();
     std::lock_guard<std::mutex> lk(r.mu);
@@ -453,7 +453,17 @@ ModelArgs model_args(const lsqamd_fit *f, const double *p) {
   return m;
 }
 
+// the library does not switch devices: the device that was current at lsqamd_create must be current in the calling thread
+// (a launch on a stream of another device fails -- or, worse, a recycled block of another device is touched)
+int device_ok(lsqamd_fit *f) {
+  const int dev = current_device();
+  if (f->dev >= 0 && dev != f->dev)
+    FAIL(f, LSQAMD_EINVAL, "this handle was created on device %d, the calling thread's current device is %d (hipSetDevice first)", f->dev, dev);
+  return 0;
+}
+
 int ready(lsqamd_fit *f) {
+  if (const int rc = device_ok(f)) return rc;
   if (!f->have_data) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_data has not been called");
   if (f->cfg.has_prior && !f->have_prior) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_prior has not been called");
   if (f->cfg.model != LSQAMD_MODEL_IDENTITY && !f->have_x) FAIL(f, LSQAMD_EINVAL, "lsqamd_set_x has not been called");
@@ -2514,6 +2524,7 @@ int lsqamd_init(lsqamd_fit *f, const double *p0) try {
 
 int lsqamd_step(lsqamd_fit *f, int32_t *info) try {
   if (!f) return LSQAMD_EINVAL;
+  if (const int rcd = device_ok(f)) return rcd;
   if (!f->initialised) FAIL(f, LSQAMD_EINVAL, "lsqamd_step before lsqamd_init");
   if (f->opt.trs >= LSQAMD_TRS_TRF) FAIL(f, LSQAMD_EUNSUPPORTED, "lsqamd_step: the scipy-plugin methods (trf, dogbox, minpack lm) run through lsqamd_run only");
   const int rc = iterate(f);

@@ -32,7 +32,7 @@ namespace lsqamd_host {   // process-wide recycling of streams and events (api.h
 hipEvent_t event_take();
 void event_give(hipEvent_t e, int dev = -1);
 hipStream_t stream_take();
-void stream_give(hipStream_t s);
+void stream_give(hipStream_t s, int dev = -1);
 }  // namespace lsqamd_host
 
 namespace lsqamd {
@@ -501,6 +501,7 @@ struct lsqamdb_fits {
   lsqamd_options opt;
   int32_t B = 0;
   hipStream_t user_st = nullptr, st = nullptr;
+  int dev = -1;                 // the device that was current at lsqamdb_create (recycled streams / events are filed under it)
   std::string err;
   int64_t N = 0, P = 0, ld = 0, ldm = 0, ncols_aug = 0, npk = 0, T = 0, nblk = 0;
   int32_t splits = 1, nparts = 256, nrparts = 64;
@@ -538,8 +539,8 @@ struct lsqamdb_fits {
   ~lsqamdb_fits() {
     for (auto *v : {&tm_syrk, &tm_chol})
       for (auto &pr : *v) {
-        lsqamd_host::event_give(pr.first);
-        lsqamd_host::event_give(pr.second);
+        lsqamd_host::event_give(pr.first, dev);
+        lsqamd_host::event_give(pr.second, dev);
       }
   }
 };
@@ -829,6 +830,7 @@ int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace
   if (carve_b(f, dev_workspace, true) > workspace_bytes) { delete f; return LSQAMD_ENOMEM; }
   carve_b(f, dev_workspace, false);
   // own (capturable) stream: the caller's may be the legacy default stream
+  (void)hipGetDevice(&f->dev);
   f->st = lsqamd_host::stream_take();
   if (!f->st) { delete f; return LSQAMD_EHIP; }
   f->opt.xtol = 1e-8; f->opt.gtol = 1e-10; f->opt.ftol = 1e-10;
@@ -840,7 +842,7 @@ int lsqamdb_create(const lsqamd_config *cfg, int32_t n_fits, void *dev_workspace
       hipMemsetAsync(f->M, 0, sizeof(double) * (size_t)(f->B * f->P * f->ldm), f->st) != hipSuccess ||
       hipStreamSynchronize(f->st) != hipSuccess) {
     (void)hipStreamSynchronize(f->st);
-    lsqamd_host::stream_give(f->st);
+    lsqamd_host::stream_give(f->st, f->dev);
     delete f;
     return LSQAMD_EHIP;
   }
@@ -853,7 +855,7 @@ int lsqamdb_destroy(lsqamdb_fits *f) try {
   (void)hipStreamSynchronize(f->st);
   if (f->gexec) (void)hipGraphExecDestroy(f->gexec);
   if (f->graph) (void)hipGraphDestroy(f->graph);
-  lsqamd_host::stream_give(f->st);       // (synchronised above)
+  lsqamd_host::stream_give(f->st, f->dev);       // (synchronised above)
   if (f->jit) lsqamd_jit::release(static_cast<const lsqamd_jit::Kernel *>(f->jit));
   delete f;
   return 0;

@@ -22,7 +22,7 @@ void pinned_give(void *p, size_t granted, int dev = -1);   // dev: the device it
 hipEvent_t event_take();
 void event_give(hipEvent_t e, int dev = -1);
 hipStream_t stream_take();          // a non-blocking stream (recycled ones are idle: their last owner synchronised them)
-void stream_give(hipStream_t s);
+void stream_give(hipStream_t s, int dev = -1);   // dev: the device it was taken on (-1: the current one)
 int comm_all_reduce(lsqamd_fit *f, double *buf, int64_t count);   // sums enqueued on f->st
 int comm_all_reduce_on(lsqamd_fit *f, hipStream_t st, double *buf, int64_t count);   // ... on another stream of the handle
 
@@ -223,7 +223,7 @@ struct lsqamd_fit {
     lsqamd_host::comm_release(this);
     if (xst) {
       (void)hipStreamSynchronize(xst);
-      lsqamd_host::stream_give(xst);
+      lsqamd_host::stream_give(xst, dev);
     }
     for (int g = 0; g < 8; ++g) {
       if (xg_ready[g]) lsqamd_host::event_give(xg_ready[g], dev);
