@@ -1259,6 +1259,48 @@ def _programs_of(flat, by_indicator):
     return out, N
 
 
+MERGE_MAX_ROWS = 1024      # small fits: several formulas are written as ONE (merge_small_programs)
+MERGE_MAX_FORMULAS = 8
+
+
+def _extend_rows(t, r0, r1, N):
+    """a program's tree over rows [r0, r1) -> the same tree over all N rows: outside its own rows every leaf repeats the value
+    (parameter index) of the program's FIRST row, so the formula evaluates there exactly as it does in a row of its own"""
+    k = t[0]
+    if k == 'P' or k == 'D':
+        a = np.asarray(t[1])
+        full = np.empty(N, a.dtype)
+        full[:] = a[0]
+        full[r0:r1] = a
+        return (k, full)
+    if k == 'U':
+        return ('U', t[1], _extend_rows(t[2], r0, r1, N))
+    if k == 'B':
+        return ('B', t[1], _extend_rows(t[2], r0, r1, N), _extend_rows(t[3], r0, r1, N))
+    return ('S', [_extend_rows(x, r0, r1, N) for x in t[1]])
+
+
+def merge_small_programs(progs, N, P):
+    """A SMALL fit whose rows follow several formulas (dictionary-valued fit functions -- one formula per key, examples/simple.py;
+    the data rows and the prior rows of a recorded residual) as ONE formula  sum_k [row belongs to k] * f_k : every row evaluates
+    every formula (on a copy of the first row of that formula's own rows where it does not belong: a value the fit meets anyway,
+    never an overflow of its own making) and keeps one.  0 * finite is an exact zero, so values and derivatives are those of
+    the separate formulas bit for bit.  What it buys: one run-time compilation instead of k, and the whole fit in ONE launch
+    (the one-launch kernel runs one compiled tape: 3-10x on fits of this size, profiles/r06_small_fits.txt).  Not applied to
+    larger fits, where the k-fold arithmetic and the extra predictor columns would cost more than they save."""
+    k = len(progs)
+    if k < 2 or k > MERGE_MAX_FORMULAS or N > MERGE_MAX_ROWS or P > 32:
+        return progs
+    if sum(_count_nodes(t) for _, _, t in progs) + 3 * k > TAPE_MAX_CODE:
+        return progs
+    terms = []
+    for r0, r1, t in progs:
+        ind = np.zeros(N)
+        ind[r0:r1] = 1.0
+        terms.append(('B', 'MUL', ('D', ind), _extend_rows(t, r0, r1, N)))
+    return [(0, N, ('S', terms))]
+
+
 def emit_programs(progs, N, P, text='traced'):
     """[(row0, row1, tree)] -> (Model, X[N, n_x])"""
     if P > TAPE_MAX_PARAM:
@@ -1289,13 +1331,14 @@ def emit_programs(progs, N, P, text='traced'):
                  text='%s{%d formulas}' % (text, len(programs)), programs=programs), X
 
 
-def trace(fcn, x=False, p0=None, y=None, fold=True):
+def trace(fcn, x=False, p0=None, y=None, fold=True, merge_small=True):
     """Record ``fcn(x, p)`` (``fcn(p)`` when ``x is False``, the reference's convention, src/lsqfit/__init__.py:2013-2016)
     for parameters shaped like ``p0`` (an array or a dictionary of arrays) -> :class:`Traced`.  ``y`` (optional: the data's
     mean, array or dictionary) fixes the key order of a dictionary-valued function and is checked for shape.
     ``fold``: arithmetic that involves no parameter (``x**2``, ``cos(2 * pi * x / 12)``) is done by numpy while the function is
     recorded and reaches the device as one more predictor column; ``fold=False`` keeps it on the tape, operation by
-    operation, exactly as the formula string front end (:func:`lsqfit_amd.expr`) would write it."""
+    operation, exactly as the formula string front end (:func:`lsqfit_amd.expr`) would write it.
+    ``merge_small``: a small fit with several formulas is recorded as one (:func:`merge_small_programs`)."""
     if p0 is None:
         raise ValueError('trace needs p0 (or the prior mean): the shape of the parameters')
     p, P, pkeys, pshapes = param_tracers(p0)
@@ -1310,6 +1353,8 @@ def trace(fcn, x=False, p0=None, y=None, fold=True):
     finally:
         _FOLD[0] = saved
     name = getattr(fcn, '__name__', 'fcn')
+    if merge_small:
+        progs = merge_small_programs(progs, N, P)
     model, X = emit_programs(progs, N, P, text='traced:' + name)
     return Traced(model, X, pkeys, pshapes, ykeys, yshapes)
 
@@ -1331,6 +1376,7 @@ def trace_residual(f, P):
         out = f(p)
     flat, _, _ = flatten_output(out, None)
     progs, N = programs_of(flat, many=2)
+    progs = merge_small_programs(progs, N, P)
     model, X = emit_programs(progs, N, P, text='traced:residual')
     return Traced(model, X, None, [(P,)], None, [(N,)])
 

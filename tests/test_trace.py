@@ -103,7 +103,7 @@ def test_dictionary_output_gives_one_program_per_formula():
         return dict(b=p[1] / p[0], a=np.exp(p[0] + x['a'] * p[1]))
 
     y = dict(a=np.zeros(4), b=0.0)
-    tr = amd.trace(fcn, dict(a=xa), np.zeros(2), y=y)
+    tr = amd.trace(fcn, dict(a=xa), np.zeros(2), y=y, merge_small=False)
     assert tr.ykeys == ['a', 'b'] and [n for n, _ in tr.model.programs] == [4, 1]
     ref = amd.piecewise([(4, 'exp(a + x*b)'), (1, 'b/a')], ['a', 'b'])
     for (n1, c1), (n2, c2) in zip(tr.model.programs, ref.programs):
@@ -136,7 +136,7 @@ def test_rows_that_read_different_parameters_are_different_formulas():
     def fcn(x, p):
         return p['norm'][group] * np.exp(-p['E'] * x)
 
-    tr = amd.trace(fcn, x, dict(norm=np.zeros(2), E=0.0))
+    tr = amd.trace(fcn, x, dict(norm=np.zeros(2), E=0.0), merge_small=False)
     assert [n for n, _ in tr.model.programs] == [3, 3]
     p = dict(norm=np.array([2.0, 3.0]), E=0.25)
     np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(p)), fcn(x, p), rtol=1e-15)
@@ -148,7 +148,7 @@ def test_output_built_element_by_element_is_merged_again():
     def fcn(x, p):
         return [p[0] * np.exp(-p[1] * xi) for xi in x] + [p[0] + p[1]]
 
-    tr = amd.trace(fcn, x, np.zeros(2))
+    tr = amd.trace(fcn, x, np.zeros(2), merge_small=False)
     assert [n for n, _ in tr.model.programs] == [9, 1]
     p = np.array([1.5, 0.5])
     np.testing.assert_allclose(run_tape(tr.model, tr.x, p), np.array(fcn(x, p), float), rtol=1e-15)
@@ -171,7 +171,7 @@ def test_distribution_keys_of_the_prior():
     def fcn(p, N=4):
         return N * [p['a']] + [p['b'] + p['c']]
 
-    tr = amd.trace(fcn, False, {'log(a)': 0.0, 'sqrt(b)': 0.0, 'c': 0.0})
+    tr = amd.trace(fcn, False, {'log(a)': 0.0, 'sqrt(b)': 0.0, 'c': 0.0}, merge_small=False)
     assert [n for n, _ in tr.model.programs] == [4, 1]
     assert [INV[int(c) & 0xff] for c in tr.model.programs[0][1]] == ['P', 'EXP']
     p = np.array([np.log(0.3), 1.5, -0.25])
@@ -187,7 +187,7 @@ def test_selection_on_the_data_is_a_piecewise_model():
     def fcn(x, p):
         return np.where(x < 1.0, p[0] * x, p[1] + p[2] * np.exp(-x))
 
-    tr = amd.trace(fcn, x, np.zeros(3))
+    tr = amd.trace(fcn, x, np.zeros(3), merge_small=False)
     assert [n for n, _ in tr.model.programs] == [5, 5]
     p = np.array([0.7, 1.1, 2.0])
     np.testing.assert_allclose(run_tape(tr.model, tr.x, p), fcn(x, p), rtol=1e-15)
@@ -196,7 +196,7 @@ def test_selection_on_the_data_is_a_piecewise_model():
         out = p[0] * x
         return np.concatenate([out[x < 0.5], (p[1] * x ** 2)[x >= 0.5]])
 
-    tr2 = amd.trace(fcn2, x, np.zeros(2))
+    tr2 = amd.trace(fcn2, x, np.zeros(2), merge_small=False)
     np.testing.assert_allclose(run_tape(tr2.model, tr2.x, p[:2]), fcn2(x, p[:2]), rtol=1e-15)
 
 
@@ -361,7 +361,7 @@ def test_parameter_selected_row_by_row_becomes_indicator_columns():
 
     for n in (15, 600):      # short runs (one row each): ONE formula whatever their number (a formula is a run-time compilation)
         pp = dict(b=np.array([1.0, 0.5, 2.0, 1.5]), x=np.linspace(1, 2, n))
-        tr = amd.trace(fcn, False, pp)
+        tr = amd.trace(fcn, False, pp, merge_small=False)
         assert tr.model.programs is None
         np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), fcn(pp), rtol=1e-15)
         assert tr.x.shape == (n, n) and set(np.unique(tr.x)) == {0.0, 1.0} and len(tr.model.tape) < 4 * n + 40
@@ -369,7 +369,7 @@ def test_parameter_selected_row_by_row_becomes_indicator_columns():
     xs = np.linspace(0, 1, 300)
     g3 = np.repeat(np.arange(3), 100)
     pp = dict(norm=np.array([2.0, 3.0, 4.0]), E=0.25)
-    tr = amd.trace(lambda x, p: p['norm'][g3] * np.exp(-p['E'] * x), xs, pp)
+    tr = amd.trace(lambda x, p: p['norm'][g3] * np.exp(-p['E'] * x), xs, pp, merge_small=False)
     assert len(tr.model.programs) == 3 and tr.x.shape == (300, 1)
     np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), pp['norm'][g3] * np.exp(-0.25 * xs), rtol=1e-15)
     x = np.linspace(0, 1, 1000)
@@ -378,7 +378,7 @@ def test_parameter_selected_row_by_row_becomes_indicator_columns():
     def f2(x, p):
         return p['norm'][group] * np.exp(-p['E'] * x)
     pp = dict(norm=np.array([2.0, 3.0]), E=0.25)
-    tr = amd.trace(f2, x, pp)
+    tr = amd.trace(f2, x, pp, merge_small=False)
     assert tr.model.programs is None and tr.x.shape == (1000, 3)
     np.testing.assert_allclose(run_tape(tr.model, tr.x, tr.pack_params(pp)), f2(x, pp), rtol=1e-15)
 
@@ -394,3 +394,41 @@ def test_errors_raised_in_the_fit_function_surface_unchanged():
         amd.trace(length_mismatch, np.arange(3.0), np.ones(2))
     with pytest.raises(ZeroDivisionError):
         amd.trace(lambda x, p: (1 // 0) * p[0] * x, np.arange(3.0), np.ones(2))
+
+
+
+def test_small_fits_with_several_formulas_are_recorded_as_one():
+    """A small fit whose rows follow several formulas (a dictionary-valued fit function, examples/simple.py: one formula per key)
+    is recorded as ONE formula  sum_k [row in k] * f_k  (trace.merge_small_programs): every row evaluates every formula -- on a
+    copy of the first row of the formula's own rows where it does not belong -- and keeps one.  Same values BIT FOR BIT as the
+    separate formulas (0 * finite is an exact zero); one tape = one run-time compilation and the one-launch fit route.  Larger
+    fits keep their formulas apart."""
+    xa = np.array([0.1, 1.0, 0.1, 0.5])
+
+    def fcn(x, p):
+        return dict(data1=np.exp(p['a'] + x['data1'] * p['b']), data2=np.exp(p['a'] + x['data2'] * p['b']) / (1 + x['data2']),
+                    ratio=p['b'] / p['a'], logs=np.log(p['a'] * x['data1'][:1]))
+    x = dict(data1=xa[:2], data2=xa[2:])
+    p0 = dict(a=0.5, b=0.5)
+    sep = amd.trace(fcn, x, p0, merge_small=False)
+    one = amd.trace(fcn, x, p0)
+    assert len(sep.model.programs) >= 3 and one.model.programs is None
+    for p in (np.array([0.5, 0.5]), np.array([0.25, 1.7]), np.array([3.0, -0.4])):
+        a, b = run_tape(sep.model, sep.x, p), run_tape(one.model, one.x, p)
+        assert np.array_equal(a, b), (a, b)
+    # a formula that is singular for the predictor values of ANOTHER formula's rows never sees them: 1 / (x - 1) on rows with
+    # x = 2, 3 beside rows whose x is exactly 1 under a different formula
+    xs = np.array([2.0, 3.0, 1.0, 1.0])
+
+    def piece(x, p):
+        return np.where(np.arange(4) < 2, p[0] / (x - 1.0), p[1] * x)
+    sep = amd.trace(piece, xs, np.zeros(2), merge_small=False)
+    one = amd.trace(piece, xs, np.zeros(2))
+    assert len(sep.model.programs) == 2 and one.model.programs is None
+    q = np.array([0.7, 1.3])
+    assert np.array_equal(run_tape(one.model, one.x, q), run_tape(sep.model, sep.x, q)) and np.all(np.isfinite(run_tape(one.model, one.x, q)))
+    # not for larger fits
+    big = np.linspace(0, 1, 3000)
+    g = (big > 0.5).astype(int)
+    tr = amd.trace(lambda x, p: np.where(x > 0.5, p[0] * x, np.exp(p[1] * x)), big, np.zeros(2))
+    assert len(tr.model.programs) == 2
